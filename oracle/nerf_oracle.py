@@ -1,0 +1,430 @@
+"""CPU restatement (torch, fp32) of the reference ray-march hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is the *checker* for the HIP path in ``nerf_amd``: it is imported by ``tests/``, by
+``__graft_entry__.smoke()`` and by ``bench.py``'s ``cpu_baseline`` leg, never by the product.
+
+Why torch and not numpy/C: the reference (Enigmatisms/NeRF) is itself pure torch, so restating it
+on the same aten CPU kernels (``cumsum``/``cumprod`` accumulate in fp64 and round per element,
+``searchsorted(right=True)``, ``sort``) is the closest thing to the reference that can travel to the
+GPU box.  Every function below is pinned against the real reference, imported in the build
+container, by the golden vectors in ``tests/golden/`` (generator: ``tests/golden/make_golden.py``).
+
+Differences from the reference are deliberate and limited to the call convention:
+  * every random draw is an explicit ``u`` argument (the reference draws from the CPU default
+    generator inside the function: ``utils.py:89,115``, ``procedures.py:65``);
+  * nothing calls ``.cuda()``; tensors stay on the device of their inputs;
+  * networks are plain dicts of tensors keyed exactly like the reference ``state_dict``s.
+
+All citations are ``file:line`` under ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+RENDER_COARSE_PNUM = 64                     # procedures.py:22
+POSSIBLE_PATCH_SIZE = (50, 40, 60, 30)      # procedures.py:21
+
+
+# --------------------------------------------------------------------------------------------
+# row 1: ray generation
+# --------------------------------------------------------------------------------------------
+def _focal_pair(focal) -> Tuple[float, float]:
+    """(f_for_x, f_for_y).  Tuple focal: x is divided by focal[1], y by focal[0]
+    (procedures.py:45-47, utils.py:79-81); scalar focal divides both (procedures.py:49)."""
+    if isinstance(focal, (tuple, list)) or (hasattr(focal, "__len__") and len(focal) == 2):
+        return float(focal[1]), float(focal[0])
+    return float(focal), float(focal)
+
+
+def pixel_camera_coords(H: int, W: int, focal, device=None) -> Tensor:
+    """(H, W, 3) camera-space ray of every pixel: ((col - W/2 + .5)/fx, (H/2 - row + .5)/fy, -1).
+    procedures.py:43-50."""
+    fx, fy = _focal_pair(focal)
+    col = torch.arange(W, dtype=torch.int64, device=device).view(1, W).expand(H, W)
+    row = torch.arange(H, dtype=torch.int64, device=device).view(H, 1).expand(H, W)
+    # the reference forms (col - W/2) in float (python float W/2) and then adds 0.5
+    cx = (col - W / 2) + 0.5
+    cy = (H / 2 - row) + 0.5
+    cx = (cx / fx).to(torch.float32)
+    cy = (cy / fy).to(torch.float32)
+    return torch.stack((cx, cy, -torch.ones_like(cx)), dim=-1)
+
+
+def ray_dirs_image(pose: Tensor, H: int, W: int, focal) -> Tensor:
+    """Unnormalised world ray directions (H, W, 3) = R . c.  procedures.py:51."""
+    cam = pixel_camera_coords(H, W, focal, pose.device)
+    return torch.sum(cam.unsqueeze(-2) * pose[..., :-1], dim=-1)
+
+
+def ray_dirs_pixels(coords: Tensor, pose: Tensor, focal) -> Tensor:
+    """Training twin: integer (col - W//2, H//2 - row) coordinates from ``randomFromOneImage``
+    -> world directions.  utils.py:78-85."""
+    fx, fy = _focal_pair(focal)
+    c = coords.to(torch.float32) + 0.5
+    c = torch.stack((c[..., 0] / fx, c[..., 1] / fy), dim=-1)
+    cam = torch.cat((c, -torch.ones_like(c[..., :1])), dim=-1)
+    return torch.sum(cam.unsqueeze(-2) * pose[:, :-1], dim=-1)
+
+
+def pixel_table(img: Tensor, crop_xy=(1.0, 1.0)) -> Tuple[Tensor, Tensor]:
+    """``randomFromOneImage`` (utils.py:47-69): (H*W,3) pixels and (H*W,2) integer coords
+    (col - W//2, H//2 - row), optionally centre-cropped."""
+    if img.dim() > 3:
+        img = img.squeeze(0)
+    Himg, Wimg = img.shape[1], img.shape[2]
+    hw, hh = Wimg // 2, Himg // 2
+    x_lb, x_ub = (int(hw * (1.0 - crop_xy[0])), int(hw + hw * crop_xy[0])) if crop_xy[0] < 0.99 else (0, Wimg)
+    y_lb, y_ub = (int(hh * (1.0 - crop_xy[1])), int(hh + hh * crop_xy[1])) if crop_xy[1] < 0.99 else (0, Himg)
+    rows = torch.arange(y_lb, y_ub).view(-1, 1).expand(y_ub - y_lb, x_ub - x_lb)
+    cols = torch.arange(x_lb, x_ub).view(1, -1).expand(y_ub - y_lb, x_ub - x_lb)
+    coords = torch.stack((cols - hw, hh - rows), dim=-1).to(img.device).reshape(-1, 2)
+    pix = img[:, rows, cols].reshape(3, -1).transpose(0, 1).contiguous()
+    return pix, coords
+
+
+def fov2focal(fov, img_size):
+    """utils.py:96-105 -- note the square-image branch has no 1/2 (a caller-side quirk)."""
+    if isinstance(fov, (tuple, list)):
+        return (0.5 * img_size[0] / math.tan(0.5 * fov[1]), 0.5 * img_size[1] / math.tan(0.5 * fov[0]))
+    if img_size[0] == img_size[1]:
+        img_size = img_size[0]
+    f = img_size / math.tan(0.5 * fov)
+    return (f, f)
+
+
+def pose_spherical(theta: float, phi: float, radius: float) -> Tensor:
+    """utils.py:136-159: orbit camera-to-world (4,4)."""
+    ph, th = phi / 180.0 * math.pi, theta / 180.0 * math.pi
+    t = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], dtype=torch.float32)
+    rp = torch.tensor([[1, 0, 0, 0], [0, math.cos(ph), -math.sin(ph), 0],
+                       [0, math.sin(ph), math.cos(ph), 0], [0, 0, 0, 1]], dtype=torch.float32)
+    rt = torch.tensor([[math.cos(th), 0, -math.sin(th), 0], [0, 1, 0, 0],
+                       [math.sin(th), 0, math.cos(th), 0], [0, 0, 0, 1]], dtype=torch.float32)
+    flip = torch.tensor([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    return flip @ (rt @ (rp @ t))
+
+
+# --------------------------------------------------------------------------------------------
+# row 2: stratified sampling
+# --------------------------------------------------------------------------------------------
+def stratified_train(near: float, far: float, C: int, u: Tensor) -> Tensor:
+    """z = linspace(near, far - d, C) + u*d, d = (far-near)/C.  utils.py:87-89."""
+    res = (far - near) / C
+    base = torch.linspace(near, far - res, C, device=u.device)
+    return base + u * res
+
+
+def stratified_render(near: float, far: float, sample_num: int, u: Tensor) -> Tensor:
+    """render_image: 64 coarse planes over [near, far] *inclusive*, jitter scaled by the FINE
+    count.  procedures.py:52,59,65.  u: (N, 64)."""
+    res = (far - near) / sample_num
+    base = torch.linspace(near, far, RENDER_COARSE_PNUM, device=u.device)
+    return base + u * res
+
+
+# --------------------------------------------------------------------------------------------
+# row 3: positional encoding
+# --------------------------------------------------------------------------------------------
+def positional_encoding(x: Tensor, L: int) -> Tensor:
+    """[sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] on the last dim (each block keeps the xyz order).
+    nerf_helper.py:38-48."""
+    parts = []
+    for f in range(L):
+        a = (2.0 ** f) * x
+        parts.append(torch.sin(a))
+        parts.append(torch.cos(a))
+    return torch.cat(parts, dim=-1)
+
+
+# --------------------------------------------------------------------------------------------
+# rows 4 / 9: the two MLPs, functional, on state_dict-shaped dicts
+# --------------------------------------------------------------------------------------------
+def _bf16(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _linear(x: Tensor, w: Tensor, b: Tensor, emulate_bf16: bool) -> Tensor:
+    """nn.Linear.  ``emulate_bf16`` models the MFMA bf16 path of the HIP kernels: operands rounded
+    to bf16 (RNE), products and sums in fp32, bias added in fp32."""
+    if emulate_bf16:
+        return F.linear(_bf16(x), _bf16(w)) + b
+    return F.linear(x, w, b)
+
+
+def proposal_forward(sd: Dict[str, Tensor], pts: Tensor, L: int = 10, emulate_bf16: bool = False) -> Tensor:
+    """ProposalNetwork.forward: [x, PE_L(x)] -> 4x(Linear+ReLU) -> Linear(.,1).  addtional.py:67-71,88-96.
+    pts (N, C, 3) -> density (N, C) (no activation)."""
+    h = torch.cat((pts, positional_encoding(pts, L)), dim=-1)
+    for i in (0, 2, 4, 6):
+        h = F.relu(_linear(h, sd[f"layers.{i}.weight"], sd[f"layers.{i}.bias"], emulate_bf16))
+    return _linear(h, sd["layers.8.weight"], sd["layers.8.bias"], emulate_bf16).squeeze(-1)
+
+
+def mip_forward(sd: Dict[str, Tensor], pts: Tensor, Lp: int = 10, Ld: int = 4, emulate_bf16: bool = False) -> Tensor:
+    """MipNeRF.forward (mip_model.py:41-60).  pts (N, S, 6) = [position | raw direction] -> (N, S, 4)
+    = [sigmoid rgb | raw sigma].  Skip-cat order (enc, h) (:55); head-cat order (bottleneck, dir) (:59)."""
+    x = pts[..., :3]
+    d = pts[..., 3:6]
+    d = d / d.norm(dim=-1, keepdim=True)
+    ex = torch.cat((x, positional_encoding(x, Lp)), dim=-1)
+    ed = torch.cat((d, positional_encoding(d, Ld)), dim=-1)
+    h = ex
+    for i in (0, 2, 4, 6):
+        h = F.relu(_linear(h, sd[f"lin_block1.{i}.weight"], sd[f"lin_block1.{i}.bias"], emulate_bf16))
+    g = torch.cat((ex, h), dim=-1)
+    for i in (0, 2, 4):
+        g = F.relu(_linear(g, sd[f"lin_block2.{i}.weight"], sd[f"lin_block2.{i}.bias"], emulate_bf16))
+    sigma = _linear(g, sd["opacity_head.0.weight"], sd["opacity_head.0.bias"], emulate_bf16)
+    b = _linear(g, sd["bottle_neck.0.weight"], sd["bottle_neck.0.bias"], emulate_bf16)
+    c = F.relu(_linear(torch.cat((b, ed), dim=-1), sd["rgb_layer.0.weight"], sd["rgb_layer.0.bias"], emulate_bf16))
+    rgb = torch.sigmoid(_linear(c, sd["rgb_layer.2.weight"], sd["rgb_layer.2.bias"], emulate_bf16))
+    return torch.cat((rgb, sigma), dim=-1)
+
+
+def init_linear_params(shapes: Sequence[Tuple[str, int, int]], seed: int, std: float = 0.02,
+                       bias_std: float = 0.0) -> Dict[str, Tensor]:
+    """Deterministic test weights: trunc-normal(std) like nerf_base.py:15-19 (bias_std>0 gives
+    non-zero biases so tests exercise the bias path)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, out_f, in_f in shapes:
+        w = torch.empty(out_f, in_f)
+        torch.nn.init.trunc_normal_(w, std=std, a=-2 * std, b=2 * std, generator=g)
+        sd[name + ".weight"] = w
+        sd[name + ".bias"] = torch.randn(out_f, generator=g) * bias_std
+    return sd
+
+
+def proposal_shapes(L: int = 10, hidden: int = 256):
+    i = 6 * L + 3
+    return [("layers.0", hidden, i), ("layers.2", hidden, hidden), ("layers.4", hidden, hidden),
+            ("layers.6", hidden, hidden), ("layers.8", 1, hidden)]
+
+
+def mip_shapes(Lp: int = 10, Ld: int = 4, hidden: int = 256):
+    i = 6 * Lp + 3
+    return [("lin_block1.0", hidden, i), ("lin_block1.2", hidden, hidden), ("lin_block1.4", hidden, hidden),
+            ("lin_block1.6", hidden, hidden), ("lin_block2.0", hidden, hidden + i), ("lin_block2.2", hidden, hidden),
+            ("lin_block2.4", 256, hidden), ("bottle_neck.0", 256, 256), ("opacity_head.0", 1, 256),
+            ("rgb_layer.0", 128, 256 + 6 * Ld + 3), ("rgb_layer.2", 3, 128)]
+
+
+# --------------------------------------------------------------------------------------------
+# row 5: sigma -> weights
+# --------------------------------------------------------------------------------------------
+def sigma_to_weights(sigma: Tensor, z: Tensor, ray_dirs: Optional[Tensor] = None, density_act=F.relu) -> Tensor:
+    """addtional.py:100-107 (ray_dirs given -> z scaled by |d|, act = relu) and nerf_base.py:80-86
+    (caller pre-scales z).  delta_last = 1e10; alpha = 1 - exp(-act(sigma) delta);
+    T = exclusive cumprod of (exp(..) + 1e-10)."""
+    if ray_dirs is not None:
+        z = z * ray_dirs.norm(dim=-1, keepdim=True)
+    big = torch.full((z.shape[0], 1), 1e10, dtype=z.dtype, device=z.device)
+    delta = torch.cat((z[:, 1:] - z[:, :-1], big), dim=-1)
+    m = torch.exp(-density_act(sigma) * delta)
+    alpha = 1.0 - m
+    ones = torch.ones((z.shape[0], 1), dtype=z.dtype, device=z.device)
+    T = torch.cumprod(torch.cat((ones, m + 1e-10), dim=-1), dim=-1)[:, :-1]
+    return alpha * T
+
+
+# --------------------------------------------------------------------------------------------
+# row 6: max-blur filter
+# --------------------------------------------------------------------------------------------
+def max_blur(w: Tensor, alpha: float) -> Tensor:
+    """mip_methods.py:61-66: mx_i = max(w_i, w_{i+1}); out = .5*([w_0, mx] + [mx, w_last]) + alpha."""
+    mx = torch.maximum(w[..., :-1], w[..., 1:])
+    front = torch.cat((w[..., :1], mx), dim=-1)
+    rear = torch.cat((mx, w[..., -1:]), dim=-1)
+    return 0.5 * (front + rear) + alpha
+
+
+# --------------------------------------------------------------------------------------------
+# row 7: inverse-transform sampling
+# --------------------------------------------------------------------------------------------
+def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """utils.py:108-133 with u explicit.  bins (N, B), weights (N, B-1), u (N, K) -> samples,
+    below, above."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat((torch.zeros_like(cdf[..., :1]), cdf), -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    bin_lo, bin_hi = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    denom = cdf_hi - cdf_lo
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_lo) / denom
+    return bin_lo + t * (bin_hi - bin_lo), below, above
+
+
+def inverse_sample(weights: Tensor, coarse_z: Tensor, u: Tensor, sort: bool = True):
+    """utils.py:34-44: bins = mid-points of z; pdf over weights[1:-1]; optional sort (+ gather of
+    ``below`` by the sort permutation).  u: (N, sample_pnum)."""
+    weights = weights.detach()
+    mids = 0.5 * (coarse_z[..., 1:] + coarse_z[..., :-1])
+    z, below, _ = sample_pdf(mids, weights[..., 1:-1], u)
+    if sort:
+        z, order = torch.sort(z, dim=-1)
+        return z, torch.gather(below, -1, order)
+    return z
+
+
+# --------------------------------------------------------------------------------------------
+# row 8: sample assembly
+# --------------------------------------------------------------------------------------------
+def length2pts(rays: Tensor, z: Tensor) -> Tensor:
+    """nerf_base.py:53-56: (N, S, 6) = [o + z d | d]."""
+    pts = rays[:, None, :3] + rays[:, None, 3:] * z[:, :, None]
+    return torch.cat((pts, rays[:, None, 3:].expand(-1, z.shape[1], -1)), dim=-1)
+
+
+def coarse_fine_merge(rays: Tensor, c_z: Tensor, f_z: Tensor, f_inds: Optional[Tensor] = None):
+    """nerf_base.py:59-73: cat(fine, coarse) -> sort -> drop last -> points (2- or 4-tuple)."""
+    z, order = torch.sort(torch.cat((f_z, c_z), dim=-1), dim=-1)
+    if f_inds is not None:
+        c_inds = torch.arange(c_z.shape[-1], device=z.device).unsqueeze(0).expand(c_z.shape[0], -1)
+        inds = torch.gather(torch.cat((f_inds, c_inds), dim=-1), -1, order)
+    z = z[..., :-1]
+    samples = length2pts(rays, z)
+    if f_inds is not None:
+        return samples, z, inds, order[..., :-1]
+    return samples, z
+
+
+# --------------------------------------------------------------------------------------------
+# row 10: alpha compositing
+# --------------------------------------------------------------------------------------------
+def composite(rgbo: Tensor, z: Tensor, ray_dirs: Tensor, mul_norm: bool = True, white_bkg: bool = False,
+              density_act=F.relu, render_depth: Optional[Tuple[float, float]] = None, normal_info=None):
+    """NeRF.render (nerf_base.py:91-113) -> (rgb (N,3), weights (N,S), extras)."""
+    if mul_norm:
+        z = z * ray_dirs.norm(dim=-1, keepdim=True)
+    w = sigma_to_weights(rgbo[..., -1], z, None, density_act)
+    rgb = torch.sum(w[:, :, None] * rgbo[..., :3], dim=-2)
+    if white_bkg:
+        rgb = rgb + (1.0 - torch.sum(w, -1)[..., None])
+    extras = {}
+    if render_depth is not None:
+        near, far = render_depth
+        extras["depth_img"] = (torch.sum(w * z, dim=-1) - near) / (far - near)
+    if normal_info is not None:
+        normal, cam_dir = normal_info
+        extras["normal_img"] = (torch.sum(w * (normal @ cam_dir), dim=-1) + 1.0) * 0.5
+    return rgb, w, extras
+
+
+# --------------------------------------------------------------------------------------------
+# row 11: distillation bound + losses
+# --------------------------------------------------------------------------------------------
+def get_bounds(prop_w: Tensor, below: Tensor) -> Tensor:
+    """addtional.py:14-18 (index-offset quirk reproduced: ``below`` indexes the C-long prefix sum)."""
+    starts, ends = below[:, :-1], below[:, 1:] + 1
+    sat = torch.cat((torch.zeros(prop_w.shape[0], 1, device=prop_w.device), torch.cumsum(prop_w, dim=-1)), dim=-1)
+    return torch.gather(sat, -1, ends) - torch.gather(sat, -1, starts)
+
+
+def proposal_loss(bounds: Tensor, fine_w: Tensor) -> Tensor:
+    """addtional.py:20-24."""
+    return torch.sum(F.relu(fine_w - bounds) ** 2 / (fine_w + 1e-8))
+
+
+def loss_psnr(mse: Tensor) -> Tensor:
+    """addtional.py:45-51."""
+    return -10.0 * torch.log(mse) / 2.3025851249694824
+
+
+# --------------------------------------------------------------------------------------------
+# row 12: integrated PE (dead code in the reference; pinned by golden only)
+# --------------------------------------------------------------------------------------------
+def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float):
+    """mip_methods.py:15-58.  z (N, S+1) -> (N, S, 6L) feature, mu (N,S,3), mu_t (N,S).
+    Quirk kept: ``.norm()`` at :31 is over the whole (N,3) direction tensor."""
+    mid = (z[:, 1:] + z[:, :-1]) / 2
+    hw2 = ((z[:, 1:] - z[:, :-1]) / 2) ** 2
+    t1 = 3 * mid ** 2 + hw2
+    mu_t = mid + 2 * mid * hw2 / t1
+    var_t = hw2 / 3 - 4 * (hw2 ** 2) * (12 * mid ** 2 - hw2) / 15 / (t1 ** 2)
+    var_r = (r ** 2) * (0.25 * mid ** 2 + 5 / 12 * hw2 - 4 * hw2 ** 2 / (15 * t1))
+    o, d = rays[:, :3], rays[:, 3:]
+    mu = o[:, None, :] + mu_t[:, :, None] * d[:, None, :]
+    dd = d * d
+    perp = torch.ones(3, device=z.device)[None, :] - dd / d.norm()
+    diag = var_t[:, :, None] * dd[:, None, :] + var_r[:, :, None] * perp[:, None, :]
+    N, S, _ = mu.shape
+    f2 = torch.tensor([2.0 ** i for i in range(L)], device=z.device)
+    f4 = torch.tensor([4.0 ** i for i in range(L)], device=z.device)
+    mu_r = (f2[None, None, :, None] * mu[:, :, None, :])                 # (N,S,L,3)
+    var = (f4[None, None, :, None] * diag[:, :, None, :])
+    att = torch.exp(-0.5 * var)
+    feat = torch.cat((torch.sin(mu_r) * att, torch.cos(mu_r) * att), dim=-1).reshape(N, S, -1)
+    return feat, mu, mu_t
+
+
+# --------------------------------------------------------------------------------------------
+# the per-batch pipeline = body of the render_image tile loop (procedures.py:64-85), non-ref
+# --------------------------------------------------------------------------------------------
+def render_rays(prop_sd, mip_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float,
+                sample_num: int = 128, white_bkg: bool = False, emulate_bf16: bool = False,
+                stages: Optional[dict] = None):
+    """rays (N,6), u_strat (N,64), u_inv (N,sample_num+1) -> rgb (N,3), weights (N,S), depth (N,).
+    ``stages`` (optional dict) receives every intermediate for stage-by-stage parity tests."""
+    z_c = stratified_render(near, far, sample_num, u_strat)
+    pts_c = rays[:, None, :3] + z_c[..., None] * rays[:, None, 3:]
+    density = proposal_forward(prop_sd, pts_c, emulate_bf16=emulate_bf16)       # no softplus here (:67-68)
+    w_raw = sigma_to_weights(density, z_c, rays[:, 3:])
+    w_prop = max_blur(w_raw, 0.01)
+    z_f, below = inverse_sample(w_prop, z_c, u_inv, sort=True)
+    z_f = z_f[..., :-1]
+    rgbo = mip_forward(mip_sd, length2pts(rays, z_f), emulate_bf16=emulate_bf16)
+    rgb, w, extras = composite(rgbo, z_f, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far))
+    if stages is not None:
+        stages.update(z_coarse=z_c, density=density, w_raw=w_raw, w_prop=w_prop, z_fine=z_f, below=below,
+                      rgbo=rgbo)
+    return rgb, w, extras["depth_img"]
+
+
+def patch_size(image_size):
+    """procedures.py:24-31 (raises like the reference when no patch size divides W)."""
+    for p in POSSIBLE_PATCH_SIZE:
+        if image_size[1] % p == 0:
+            return p, (image_size[0] // p, image_size[1] // p)
+    raise UnboundLocalError("no patch size in (50,40,60,30) divides the image width")
+
+
+def render_image(prop_sd, mip_sd, pose: Tensor, image_size, focal, near: float, far: float, sample_num: int = 128,
+                 white_bkg: bool = False, render_depth: bool = False, generator: Optional[torch.Generator] = None,
+                 max_tiles: Optional[int] = None):
+    """Whole-image render with the reference's tile order AND RNG draw order (per tile: one
+    (sz,sz,64) draw, then one (sz*sz, sample_num+1) draw; procedures.py:62-70, utils.py:115).
+    With ``generator=None`` the CPU default generator is used, like the reference."""
+    if not isinstance(image_size, (tuple, list)):
+        image_size = (image_size, image_size)
+    H, W = image_size
+    dirs = ray_dirs_image(pose, H, W, focal)
+    out = {"rgb": torch.zeros(3, H, W)}
+    if render_depth:
+        out["depth_img"] = torch.zeros(3, H, W)
+    sz, (pr, pc) = patch_size(image_size)
+    done = 0
+    for k in range(pr):
+        for j in range(pc):
+            d = dirs[sz * k: sz * (k + 1), sz * j: sz * (j + 1)].reshape(-1, 3)
+            rays = torch.cat((pose[:, -1].expand(sz * sz, -1), d), dim=-1)
+            u1 = torch.rand((sz, sz, RENDER_COARSE_PNUM), generator=generator).view(-1, RENDER_COARSE_PNUM)
+            u2 = torch.rand((sz * sz, sample_num + 1), generator=generator)
+            rgb, _, depth = render_rays(prop_sd, mip_sd, rays, u1, u2, near, far, sample_num, white_bkg)
+            out["rgb"][:, sz * k: sz * (k + 1), sz * j: sz * (j + 1)] = rgb.view(sz, sz, 3).permute(2, 0, 1)
+            if render_depth:
+                out["depth_img"][:, sz * k: sz * (k + 1), sz * j: sz * (j + 1)] = depth.view(sz, sz)
+            done += 1
+            if max_tiles is not None and done >= max_tiles:
+                return out
+    return out

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden(dict):
+    """npz fixture -> dict of torch tensors (0-d arrays become python scalars)."""
+
+    def __init__(self, name):
+        super().__init__()
+        with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+            for k in f.files:
+                a = f[k]
+                self[k] = torch.from_numpy(a.copy()) if a.ndim else a.item()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+
+    return load
+
+
+def max_abs(a, b):
+    return (a.double() - b.double()).abs().max().item()

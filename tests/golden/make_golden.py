@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REAL reference (Enigmatisms/NeRF,
+mounted read-only at /root/reference) on CPU.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The reference never travels to the GPU box; only the .npz files written here do.  They hold
+inputs + the reference's outputs (data, not source).  Network weights are produced by the
+closed-form generator ``tests/weights.py`` (integer hash, libm-free) and loaded into the reference
+modules with ``load_state_dict``, so they are not stored.
+
+Import shims (in-process, no reference file is edited):
+  1. ``torch.Tensor.cuda`` / ``nn.Module.cuda`` -> identity (the reference hard-codes ``.cuda()``);
+  2. ``numpy.math = math`` (ref_func.py uses ``np.math.factorial``);
+  3. stub modules for torchvision / natsort / tensorboard (imported at module top, never run).
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+
+
+def install_shims():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    np.math = math
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional",
+                 "torchvision.utils", "natsort", "tensorboard", "torch.utils.tensorboard"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    sys.modules["torchvision.transforms.functional"].resize = None
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision.utils"].save_image = None
+    sys.modules["natsort"].natsorted = sorted
+    sys.modules["torch.utils.tensorboard"].SummaryWriter = object
+    sys.path.insert(0, REF)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def main():
+    install_shims()
+    from nerf import nerf_helper, nerf_base, mip_methods, mip_model, addtional, utils, procedures
+    import weights as W
+
+    torch.set_num_threads(8)
+    T = torch.tensor
+    near, far = 2.0, 6.0
+
+    # ---------------- G1 ray generation (+ fov2Focal, pose_spherical) ----------------
+    pose = utils.pose_spherical(37.0, -30.0, 4.0)[:3]
+    fs = utils.fov2Focal(0.6911112070083618, (100, 100))
+    ft = utils.fov2Focal((0.6911112070083618, 0.5), (60, 100))
+    ft_img = utils.fov2Focal((0.6911112070083618, 0.5), (100, 150))
+    # render_image's prologue (procedures.py:43-51) is not a separate function, so the image-path ray table is
+    # captured from the REAL render_image as a black box: NeRF.length2pts receives ``camera_rays`` of every tile.
+    def ref_ray_raw(pose, image_size, focal):
+        rec = []
+        orig = nerf_base.NeRF.length2pts
+        def spy(rays, z):
+            rec.append(rays.clone())
+            return orig(rays, z)
+        nerf_base.NeRF.length2pts = staticmethod(spy)
+        try:
+            prop = addtional.ProposalNetwork(10, 256); mip = mip_model.MipNeRF(10, 4, 256)
+            with torch.no_grad():
+                procedures.render_image(mip, prop, pose, image_size, focal, near, far, 2)
+        finally:
+            nerf_base.NeRF.length2pts = staticmethod(orig)
+        H, Wd = image_size
+        sz, (pr, pc) = procedures.get_patch_size(image_size)
+        out = torch.zeros(H, Wd, 3)
+        for t, rays in enumerate(rec):
+            k, j = divmod(t, pc)
+            assert torch.equal(rays[:, :3], pose[:, -1].expand(sz * sz, -1))
+            out[sz * k: sz * (k + 1), sz * j: sz * (j + 1)] = rays[:, 3:].view(sz, sz, 3)
+        return out
+    img = torch.rand(3, 60, 100, generator=torch.Generator().manual_seed(3))
+    pix, coords = utils.randomFromOneImage(img, (1.0, 1.0))
+    pixc, coordsc = utils.randomFromOneImage(img, (0.5, 0.5))
+    torch.manual_seed(11)
+    rgb_s, rays_s = utils.validSampler(pix, coords, pose, 16, 32, ft, near, far, False)
+    torch.manual_seed(11)
+    idx_s = torch.randint(0, coords.shape[0], (16,))
+    npz("g01_raygen", pose=pose, focal_sq=np.array(fs), focal_tuple=np.array(ft),
+        pose_full=utils.pose_spherical(37.0, -30.0, 4.0),
+        ray_raw_sq=ref_ray_raw(pose, (100, 100), fs), ray_raw_scalar=ref_ray_raw(pose, (100, 100), 138.5),
+        focal_tuple_img=np.array(ft_img), ray_raw_tuple=ref_ray_raw(pose, (100, 150), ft_img),
+        img=img, pix=pix, coords=coords, pix_crop=pixc, coords_crop=coordsc,
+        sampler_idx=idx_s, sampler_rgb=rgb_s, sampler_rays=rays_s)
+
+    # ---------------- G2 stratified z / pts (train + render flavours) ----------------
+    torch.manual_seed(5)
+    pts_t, len_t, rgb_t, rays_t = utils.validSampler(pix, coords, pose, 8, 32, ft, near, far, True)
+    torch.manual_seed(5)
+    idx_t = torch.randint(0, coords.shape[0], (8,))
+    u_t = torch.rand((8, 32))
+    # render flavour (procedures.py:52,59,65-66): captured from the REAL render_image (one 50x50 tile) by spying
+    # on ProposalNetwork.forward (receives pts) and ProposalNetwork.get_weights (receives sampled_lengths).
+    cap = {}
+    prop = addtional.ProposalNetwork(10, 256); mip = mip_model.MipNeRF(10, 4, 256)
+    orig_fwd, orig_gw = addtional.ProposalNetwork.forward, addtional.ProposalNetwork.get_weights
+    def spy_fwd(self, pts, encoded_pt=None):
+        cap["pts"] = pts.clone(); return orig_fwd(self, pts, encoded_pt)
+    def spy_gw(density, zvals, ray_dirs=None):
+        cap["z"] = zvals.clone(); cap["dirs"] = ray_dirs.clone(); return orig_gw(density, zvals, ray_dirs)
+    addtional.ProposalNetwork.forward = spy_fwd
+    addtional.ProposalNetwork.get_weights = staticmethod(spy_gw)
+    try:
+        f50 = utils.fov2Focal(0.6911112070083618, (50, 50))
+        torch.manual_seed(6)
+        with torch.no_grad():
+            procedures.render_image(mip, prop, pose, 50, f50, near, far, 96)
+    finally:
+        addtional.ProposalNetwork.forward = orig_fwd
+        addtional.ProposalNetwork.get_weights = staticmethod(orig_gw)
+    torch.manual_seed(6)
+    u_r = torch.rand((50, 50, 64)).view(-1, 64)                      # the tile's first draw (procedures.py:65)
+    sel = torch.arange(0, 2500, 97)
+    npz("g02_stratified", idx=idx_t, u_train=u_t, z_train=len_t, pts_train=pts_t, rays_train=rays_t, rgb_train=rgb_t,
+        render_sample_num=np.array(96), render_focal=np.array(f50), u_render=u_r[sel], z_render=cap["z"][sel],
+        pts_render=cap["pts"][sel], dirs_render=cap["dirs"][sel], origin=pose[:, -1])
+
+    # ---------------- G3 positional encoding ----------------
+    x = (torch.rand(6, 5, 3, generator=torch.Generator().manual_seed(7)) - 0.5) * 14.0
+    x[0, 0] = T([6.9, -6.9, 0.0]); x[0, 1] = T([1e-3, -1e-3, 3.14159265])
+    npz("g03_pe", x=x, pe10=nerf_helper.positional_encoding(x, 10), pe4=nerf_helper.positional_encoding(x, 4),
+        x2d=x.reshape(-1, 3), pe4_2d=nerf_helper.positional_encoding(x.reshape(-1, 3), 4))
+
+    # ---------------- G4 / G9 the two MLPs ----------------
+    g = torch.Generator().manual_seed(9)
+    rays = torch.cat((pose[:, -1].expand(12, -1), ref_ray_raw(pose, (100, 100), fs)[::9, ::8].reshape(-1, 3)[:12]), -1)
+    out = {}
+    for tag in ("small", "he"):
+        prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state(tag)); prop.eval()
+        mip = mip_model.MipNeRF(10, 4, 256); mip.load_state_dict(W.mip_state(tag)); mip.eval()
+        zc = torch.linspace(near, far, 64) + torch.rand(12, 64, generator=g) * ((far - near) / 128)
+        pts_c = rays[:, None, :3] + zc[..., None] * rays[:, None, 3:]
+        zf, _ = torch.sort(near + (far - near) * torch.rand(12, 40, generator=g), dim=-1)
+        pts_f = nerf_base.NeRF.length2pts(rays, zf)
+        with torch.no_grad():
+            out[tag + "_density"] = prop.forward(pts_c)
+            out[tag + "_rgbo"] = mip.forward(pts_f)
+        out[tag + "_pts_c"] = pts_c; out[tag + "_pts_f"] = pts_f
+    npz("g04_g09_mlp", rays=rays, **out)
+
+    # ---------------- G5 sigma -> weights ----------------
+    sig = torch.randn(10, 64, generator=g) * 3.0
+    zz, _ = torch.sort(near + (far - near) * torch.rand(10, 64, generator=g), dim=-1)
+    dd = torch.randn(10, 3, generator=g) * 0.7
+    npz("g05_weights", sigma=sig, z=zz, dirs=dd,
+        w_prop=addtional.ProposalNetwork.get_weights(sig, zz, dd),
+        w_prop_nodir=addtional.ProposalNetwork.get_weights(sig, zz, None),
+        w_nerf=nerf_base.NeRF.getNormedWeight(sig, zz),
+        w_nerf_id=nerf_base.NeRF.getNormedWeight(sig, zz, lambda t: t.abs()))
+
+    # ---------------- G6 max-blur ----------------
+    wr = torch.rand(10, 64, generator=g) ** 4
+    npz("g06_maxblur", w=wr, out=mip_methods.maxBlurFilter(wr, 0.01), out_a=mip_methods.maxBlurFilter(wr, 0.25))
+
+    # ---------------- G7 inverse sampling (given u) ----------------
+    wp = mip_methods.maxBlurFilter(addtional.ProposalNetwork.get_weights(sig, zz, dd), 0.01)
+    wp[3] = 0.0; wp[3, 20] = 1.0                                   # a delta: exercises denom < 1e-5 and edge bins
+    wp[4] = 0.01                                                    # flat pdf
+    torch.manual_seed(21)
+    zs_sorted, below_sorted = utils.inverseSample(wp, zz, 129, sort=True)
+    torch.manual_seed(21)
+    zs_raw = utils.inverseSample(wp, zz, 129, sort=False)
+    torch.manual_seed(21)
+    u_inv = torch.rand(10, 129)
+    torch.manual_seed(22)
+    mids = 0.5 * (zz[..., 1:] + zz[..., :-1])
+    s_pdf, b_pdf, a_pdf = utils.sample_pdf(mids, wp[..., 1:-1], 33)
+    torch.manual_seed(22)
+    u_pdf = torch.rand(10, 33)
+    npz("g07_inverse", w=wp, z=zz, u=u_inv, z_sorted=zs_sorted, below_sorted=below_sorted, z_raw=zs_raw,
+        u_pdf=u_pdf, s_pdf=s_pdf, below_pdf=b_pdf, above_pdf=a_pdf)
+
+    # ---------------- G8 sample assembly ----------------
+    zc8 = zz[:, :16].contiguous()
+    zf8 = zs_sorted[:, :33].contiguous()
+    fi8 = below_sorted[:, :33].contiguous()
+    r8 = torch.cat((torch.randn(10, 3, generator=g), dd), -1)
+    m2 = nerf_base.NeRF.coarseFineMerge(r8, zc8, zf8)
+    m4 = nerf_base.NeRF.coarseFineMerge(r8, zc8, zf8, fi8)
+    npz("g08_assembly", rays=r8, zc=zc8, zf=zf8, finds=fi8, l2p=nerf_base.NeRF.length2pts(r8, zf8),
+        m2_samples=m2[0], m2_z=m2[1], m4_samples=m4[0], m4_z=m4[1], m4_inds=m4[2], m4_sort=m4[3])
+
+    # ---------------- G10 compositing ----------------
+    rgbo = torch.cat((torch.rand(10, 48, 3, generator=g), torch.randn(10, 48, 1, generator=g) * 4), -1)
+    z10, _ = torch.sort(near + (far - near) * torch.rand(10, 48, generator=g), dim=-1)
+    nrm = torch.randn(10, 48, 3, generator=g)
+    camz = pose[:, -2]
+    o = {}
+    for wb in (False, True):
+        for mn in (False, True):
+            rgb, w, ex = nerf_base.NeRF.render(rgbo, z10, dd, mul_norm=mn, white_bkg=wb, render_depth=(near, far),
+                                               normal_info=(nrm, camz))
+            k = "wb%d_mn%d_" % (wb, mn)
+            o[k + "rgb"], o[k + "w"], o[k + "depth"], o[k + "normal"] = rgb, w, ex["depth_img"], ex["normal_img"]
+    rgb, w, ex = nerf_base.NeRF.render(rgbo, z10, dd, density_act=torch.nn.functional.softplus)
+    o["softplus_rgb"], o["softplus_w"] = rgb, w
+    npz("g10_composite", rgbo=rgbo, z=z10, dirs=dd, normal=nrm, cam_z=camz, **o)
+
+    # ---------------- G11 render_image end-to-end (reference RNG order) ----------------
+    o = {}
+    for tag, size, sn in (("small_50", 50, 128), ("he_50", 50, 128), ("small_100", 100, 64), ("small_200", 200, 64)):
+        wt = tag.split("_")[0]
+        prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state(wt)); prop.eval()
+        mip = mip_model.MipNeRF(10, 4, 256); mip.load_state_dict(W.mip_state(wt)); mip.eval()
+        f = utils.fov2Focal(0.6911112070083618, (size, size))
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            res = procedures.render_image(mip, prop, pose, size, f, near, far, sn, white_bkg=True, render_depth=True)
+        o[tag + "_rgb"] = res["rgb"]; o[tag + "_depth"] = res["depth_img"][0]
+        o[tag + "_focal"] = np.array(f)
+    npz("g11_render_image", pose=pose, **o)
+
+    # ---------------- G12 integrated PE (dead code) ----------------
+    z12, _ = torch.sort(near + (far - near) * torch.rand(6, 9, generator=g), dim=-1)
+    r12 = torch.cat((torch.randn(6, 3, generator=g), torch.randn(6, 3, generator=g)), -1)
+    feat, mu, mu_t = mip_methods.ipe_feature(z12, r12, 6, 0.0015)
+    npz("g12_ipe", z=z12, rays=r12, feat=feat, mu=mu, mu_t=mu_t)
+
+    # ---------------- G14 train-step losses + parameter grads (non-ref) ----------------
+    prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state("small"))
+    mip = mip_model.MipNeRF(10, 4, 256); mip.load_state_dict(W.mip_state("small"))
+    torch.manual_seed(77)
+    pts_c, len_c, rgb_tgt, rays_c = utils.validSampler(pix, coords, pose, 32, 32, ft, near, far, True)
+    torch.manual_seed(77)
+    idx14 = torch.randint(0, coords.shape[0], (32,)); u14 = torch.rand(32, 32)
+    import torch.nn.functional as F
+    density = F.softplus(prop.forward(pts_c))                                         # train.py:166-169
+    pw_raw = addtional.ProposalNetwork.get_weights(density, len_c, rays_c[:, 3:])
+    pw = mip_methods.maxBlurFilter(pw_raw, 0.01)
+    torch.manual_seed(78)
+    fl, below = utils.inverseSample(pw, len_c, 65, sort=True)
+    torch.manual_seed(78)
+    u14b = torch.rand(32, 65)
+    fl = fl[..., :-1]
+    rgbo14 = mip.forward(nerf_base.NeRF.length2pts(rays_c, fl))
+    rend, wts, _ = nerf_base.NeRF.render(rgbo14, fl, rays_c[:, 3:])
+    bounds = addtional.getBounds(pw, below)
+    img_loss = torch.nn.MSELoss()(rend, rgb_tgt)
+    p_loss = addtional.ProposalLoss()(bounds, wts.detach())
+    (p_loss + img_loss).backward()
+    npz("g14_train_step", idx=idx14, u_strat=u14, u_inv=u14b, rays=rays_c, rgb_tgt=rgb_tgt, z_coarse=len_c,
+        z_fine=fl, below=below, bounds=bounds, rendered=rend, weights=wts, img_loss=img_loss, prop_loss=p_loss,
+        psnr=addtional.LossPSNR()(img_loss),
+        g_mip_l1=mip.lin_block1[0].weight.grad[:8, :], g_mip_rgb=mip.rgb_layer[2].weight.grad,
+        g_mip_sigma=mip.opacity_head[0].weight.grad, g_prop_l0=prop.layers[0].weight.grad[:8, :],
+        g_prop_head=prop.layers[8].weight.grad)
+
+    # ---------------- G15 LR schedule ----------------
+    sch = nerf_base.DecayLrScheduler(0.01, 0.1, 100000, 3e-4, 500)
+    steps = np.array([0, 1, 250, 499, 500, 501, 10000, 100500, 500000, 2000000])
+    npz("g15_lr", steps=steps, lr=np.array([sch.update_opt_lr(int(s))[1] for s in steps]))
+
+
+if __name__ == "__main__":
+    main()

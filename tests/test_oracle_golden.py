@@ -1,0 +1,173 @@
+"""Pin the CPU oracle (oracle/nerf_oracle.py) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py, run in the build container).  CPU-only; runs in seconds.
+
+Both sides run the same aten CPU kernels, so most checks are bit-exact (tol 0); the few that are not
+(different-but-equivalent op order) use 1e-6, the bar SURVEY.md section 7 step 2 sets.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import weights as W
+from conftest import max_abs
+from oracle import nerf_oracle as O
+
+NEAR, FAR = 2.0, 6.0
+
+
+def test_g01_raygen(golden):
+    g = golden("g01_raygen")
+    pose = g["pose"]
+    assert torch.equal(O.pose_spherical(37.0, -30.0, 4.0), g["pose_full"])
+    assert np.allclose(O.fov2focal(0.6911112070083618, (100, 100)), g["focal_sq"].numpy(), rtol=0, atol=0)
+    assert np.allclose(O.fov2focal((0.6911112070083618, 0.5), (60, 100)), g["focal_tuple"].numpy(), rtol=0, atol=0)
+    assert torch.equal(O.ray_dirs_image(pose, 100, 100, tuple(g["focal_sq"].tolist())), g["ray_raw_sq"])
+    assert torch.equal(O.ray_dirs_image(pose, 100, 100, 138.5), g["ray_raw_scalar"])
+    assert torch.equal(O.ray_dirs_image(pose, 100, 150, tuple(g["focal_tuple_img"].tolist())), g["ray_raw_tuple"])
+    pix, coords = O.pixel_table(g["img"], (1.0, 1.0))
+    assert torch.equal(pix, g["pix"]) and torch.equal(coords, g["coords"])
+    pix, coords = O.pixel_table(g["img"], (0.5, 0.5))
+    assert torch.equal(pix, g["pix_crop"]) and torch.equal(coords, g["coords_crop"])
+    idx = g["sampler_idx"]
+    d = O.ray_dirs_pixels(g["coords"][idx], pose, tuple(g["focal_tuple"].tolist()))
+    assert torch.equal(d, g["sampler_rays"][:, 3:])
+    assert torch.equal(g["pix"][idx], g["sampler_rgb"])
+    assert torch.equal(pose[:, -1].expand(16, -1), g["sampler_rays"][:, :3])
+
+
+def test_g02_stratified(golden):
+    g1, g = golden("g01_raygen"), golden("g02_stratified")
+    z = O.stratified_train(NEAR, FAR, 32, g["u_train"])
+    assert torch.equal(z, g["z_train"])
+    d = O.ray_dirs_pixels(g1["coords"][g["idx"]], g1["pose"], tuple(g1["focal_tuple"].tolist()))
+    assert torch.equal(d, g["rays_train"][:, 3:])
+    pts = g1["pose"][:, -1] + d[:, None, :] * z[:, :, None]                   # utils.py:90
+    assert torch.equal(pts, g["pts_train"])
+    zr = O.stratified_render(NEAR, FAR, g["render_sample_num"], g["u_render"])
+    assert torch.equal(zr, g["z_render"])
+    pr = g["origin"][None, None, :] + zr[..., None] * g["dirs_render"][:, None, :]   # procedures.py:66
+    assert torch.equal(pr, g["pts_render"])
+
+
+def test_g03_positional_encoding(golden):
+    g = golden("g03_pe")
+    assert torch.equal(O.positional_encoding(g["x"], 10), g["pe10"])
+    assert torch.equal(O.positional_encoding(g["x"], 4), g["pe4"])
+    assert torch.equal(O.positional_encoding(g["x2d"], 4), g["pe4_2d"])
+
+
+@pytest.mark.parametrize("tag", ["small", "he"])
+def test_g04_g09_mlps(golden, tag):
+    g = golden("g04_g09_mlp")
+    with torch.no_grad():
+        dens = O.proposal_forward(W.proposal_state(tag), g[tag + "_pts_c"])
+        rgbo = O.mip_forward(W.mip_state(tag), g[tag + "_pts_f"])
+    assert max_abs(dens, g[tag + "_density"]) <= 1e-6 * max(1.0, g[tag + "_density"].abs().max().item())
+    assert max_abs(rgbo, g[tag + "_rgbo"]) <= 1e-6 * max(1.0, g[tag + "_rgbo"].abs().max().item())
+
+
+def test_g05_sigma_to_weights(golden):
+    g = golden("g05_weights")
+    assert torch.equal(O.sigma_to_weights(g["sigma"], g["z"], g["dirs"]), g["w_prop"])
+    assert torch.equal(O.sigma_to_weights(g["sigma"], g["z"], None), g["w_prop_nodir"])
+    assert torch.equal(O.sigma_to_weights(g["sigma"], g["z"], None, F.relu), g["w_nerf"])
+    assert torch.equal(O.sigma_to_weights(g["sigma"], g["z"], None, lambda t: t.abs()), g["w_nerf_id"])
+
+
+def test_g06_max_blur(golden):
+    g = golden("g06_maxblur")
+    assert torch.equal(O.max_blur(g["w"], 0.01), g["out"])
+    assert torch.equal(O.max_blur(g["w"], 0.25), g["out_a"])
+
+
+def test_g07_inverse_sampling(golden):
+    g = golden("g07_inverse")
+    z, below = O.inverse_sample(g["w"], g["z"], g["u"], sort=True)
+    assert torch.equal(z, g["z_sorted"]) and torch.equal(below, g["below_sorted"])
+    assert torch.equal(O.inverse_sample(g["w"], g["z"], g["u"], sort=False), g["z_raw"])
+    mids = 0.5 * (g["z"][..., 1:] + g["z"][..., :-1])
+    s, b, a = O.sample_pdf(mids, g["w"][..., 1:-1], g["u_pdf"])
+    assert torch.equal(s, g["s_pdf"]) and torch.equal(b, g["below_pdf"]) and torch.equal(a, g["above_pdf"])
+
+
+def test_g08_assembly(golden):
+    g = golden("g08_assembly")
+    assert torch.equal(O.length2pts(g["rays"], g["zf"]), g["l2p"])
+    s, z = O.coarse_fine_merge(g["rays"], g["zc"], g["zf"])
+    assert torch.equal(s, g["m2_samples"]) and torch.equal(z, g["m2_z"])
+    s, z, inds, order = O.coarse_fine_merge(g["rays"], g["zc"], g["zf"], g["finds"])
+    assert torch.equal(s, g["m4_samples"]) and torch.equal(z, g["m4_z"])
+    assert torch.equal(inds, g["m4_inds"]) and torch.equal(order, g["m4_sort"])
+
+
+def test_g10_composite(golden):
+    g = golden("g10_composite")
+    for wb in (False, True):
+        for mn in (False, True):
+            rgb, w, ex = O.composite(g["rgbo"], g["z"], g["dirs"], mul_norm=mn, white_bkg=wb,
+                                     render_depth=(NEAR, FAR), normal_info=(g["normal"], g["cam_z"]))
+            k = "wb%d_mn%d_" % (wb, mn)
+            assert torch.equal(rgb, g[k + "rgb"]) and torch.equal(w, g[k + "w"])
+            assert torch.equal(ex["depth_img"], g[k + "depth"]) and torch.equal(ex["normal_img"], g[k + "normal"])
+    rgb, w, _ = O.composite(g["rgbo"], g["z"], g["dirs"], density_act=F.softplus)
+    assert torch.equal(rgb, g["softplus_rgb"]) and torch.equal(w, g["softplus_w"])
+
+
+@pytest.mark.parametrize("tag,size,sn", [("small_50", 50, 128), ("he_50", 50, 128), ("small_100", 100, 64)])
+def test_g11_render_image(golden, tag, size, sn):
+    """End-to-end incl. the reference's per-tile RNG draw order (CPU default generator)."""
+    g = golden("g11_render_image")
+    wt = tag.split("_")[0]
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        res = O.render_image(W.proposal_state(wt), W.mip_state(wt), g["pose"], size, tuple(g[tag + "_focal"].tolist()),
+                             NEAR, FAR, sn, white_bkg=True, render_depth=True)
+    assert max_abs(res["rgb"], g[tag + "_rgb"]) <= 2e-6
+    assert max_abs(res["depth_img"][0], g[tag + "_depth"]) <= 2e-6
+
+
+def test_g12_ipe(golden):
+    g = golden("g12_ipe")
+    feat, mu, mu_t = O.ipe_feature(g["z"], g["rays"], 6, 0.0015)
+    assert max_abs(feat, g["feat"]) <= 1e-6 and max_abs(mu, g["mu"]) <= 1e-6 and max_abs(mu_t, g["mu_t"]) <= 1e-6
+
+
+def test_g14_train_step_forward_and_losses(golden):
+    """Forward half of train.py:164-199 (non-ref): softplus'd proposal density, bounds, losses."""
+    g1, g = golden("g01_raygen"), golden("g14_train_step")
+    prop_sd, mip_sd = W.proposal_state("small"), W.mip_state("small")
+    pose = g1["pose"]
+    d = O.ray_dirs_pixels(g1["coords"][g["idx"]], pose, tuple(g1["focal_tuple"].tolist()))
+    rays = torch.cat((pose[:, -1].expand(32, -1), d), -1)
+    assert torch.equal(rays, g["rays"])
+    z_c = O.stratified_train(NEAR, FAR, 32, g["u_strat"])
+    assert torch.equal(z_c, g["z_coarse"])
+    with torch.no_grad():
+        dens = F.softplus(O.proposal_forward(prop_sd, pose[:, -1] + d[:, None, :] * z_c[:, :, None]))
+        pw = O.max_blur(O.sigma_to_weights(dens, z_c, d), 0.01)
+        z_f, below = O.inverse_sample(pw, z_c, g["u_inv"], sort=True)
+        z_f = z_f[..., :-1]
+        rgbo = O.mip_forward(mip_sd, O.length2pts(rays, z_f))
+        rend, wts, _ = O.composite(rgbo, z_f, d)
+        bounds = O.get_bounds(pw, below)
+        img_loss = torch.mean((rend - g["rgb_tgt"]) ** 2)
+        p_loss = O.proposal_loss(bounds, wts)
+    assert max_abs(z_f, g["z_fine"]) <= 2e-6
+    assert (below != g["below"]).float().mean().item() <= 0.01
+    assert max_abs(rend, g["rendered"]) <= 2e-6 and max_abs(wts, g["weights"]) <= 2e-6
+    assert max_abs(bounds, g["bounds"]) <= 1e-5
+    assert abs(img_loss.item() - g["img_loss"]) <= 1e-6 and abs(p_loss.item() - g["prop_loss"]) <= 1e-5 * max(1, g["prop_loss"])
+    assert abs(O.loss_psnr(img_loss).item() - g["psnr"]) <= 1e-4
+
+
+def test_g15_lr_schedule(golden):
+    g = golden("g15_lr")
+    min_r, decay_r, step, lr, warm = 0.01, 0.1, 100000, 3e-4, 500             # nerf_base.py:115-134
+    for s, want in zip(g["steps"].tolist(), g["lr"].tolist()):
+        if s < warm:
+            r = s / warm
+            got = lr * (min_r * (1.0 - r) + r)
+        else:
+            got = lr * max(decay_r ** ((s - warm) / step), min_r)
+        assert abs(got - want) <= 1e-12
