@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the NeRF ray-march hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full 800x800 image (640 000 rays, 64 proposal + 128 fine samples per ray) through
+ray generation -> stratified sampling -> proposal MLP -> sigma->weights -> max-blur -> inverse-transform
+sampling (sorted) -> fine MLP -> alpha compositing (rgb, depth, weights written), i.e. SURVEY.md section 8a
+rows 1-10 -- BASELINE configs[1] ("Original NeRF, Lego 800x800, 64+128 samples, bf16, 1xMI355X").
+Synthetic inputs (no dataset on the box): orbit pose pose_spherical(theta,-30,4), Lego's camera_angle_x,
+near/far 2/6, white background, closed-form deterministic network weights, uniforms pre-generated and
+RESIDENT IN HBM before the timed region.
+
+N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL); every rank renders its own image
+per step (weak scaling, rays are independent: no data-path collective); value = total rays / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+H = W = 800
+C_COARSE, N_FINE = 64, 128
+NEAR, FAR = 2.0, 6.0
+MAC_PROP, MAC_FINE = 212_992, 527_872                      # per sample
+FLOP_PER_RAY = 2 * (C_COARSE * MAC_PROP + N_FINE * MAC_FINE)   # 162.4e6
+PEAK_BF16_DENSE = 2.5e15                                   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_F32_MFMA = 157.3e12
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rays", type=int, default=5000, help="rays of the same workload timed on the host cores")
+    return p.parse_args()
+
+
+def cpu_baseline(n_rays: int):
+    """The reference CPU path (= the oracle, proven equal to the reference by tests/test_oracle_golden.py),
+    fp32, all host cores, on the first `n_rays` rays of the same image; one 2500-ray tile at a time like
+    render_image does."""
+    import weights as Wt
+    from oracle import nerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prop_sd, mip_sd = Wt.proposal_state("small"), Wt.mip_state("small")
+    pose = O.pose_spherical(30.0, -30.0, 4.0)[:3]
+    dirs = O.ray_dirs_image(pose, H, W, O.fov2focal(0.6911112070083618, (H, W))).reshape(-1, 3)
+    g = torch.Generator().manual_seed(0)
+    tile = 2500
+    n_tiles = max(1, n_rays // tile)
+
+    def one(t):
+        rays = torch.cat((pose[:, -1].expand(tile, -1), dirs[t * tile:(t + 1) * tile]), -1)
+        u1, u2 = torch.rand(tile, 64, generator=g), torch.rand(tile, N_FINE + 1, generator=g)
+        with torch.no_grad():
+            O.render_rays(prop_sd, mip_sd, rays, u1, u2, NEAR, FAR, N_FINE, white_bkg=True)
+    one(0)                                                  # warm-up tile
+    t0 = time.perf_counter()
+    for t in range(n_tiles):
+        one(t)
+    dt = time.perf_counter() - t0
+    return {"value": n_tiles * tile / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "%d rays (%d tiles of 2500) of the same 800x800, 64+128 workload, torch CPU fp32, %d threads, %.1f s"
+                      % (n_tiles * tile, n_tiles, cores, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import weights as Wt
+    from nerf_amd import ops
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.utils import fov2Focal, pose_spherical
+
+    prec = ops.BF16 if a.precision == "bf16" else ops.F32
+    prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
+    prop.load_state_dict(Wt.proposal_state("small"))
+    mip.load_state_dict(Wt.mip_state("small"))
+    prop, mip = prop.to(dev).eval(), mip.to(dev).eval()
+    pk_prop, pk_mip = prop.packed(prec), mip.packed(prec)               # weight upload + pack: outside the timed region
+
+    n_rays = H * W
+    focal = fov2Focal(0.6911112070083618, (H, W))
+    fx, fy = float(focal[1]), float(focal[0])
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    u_strat = torch.rand((n_rays, C_COARSE), device=dev, generator=g)    # resident in HBM before timing
+    u_inv = torch.rand((n_rays, N_FINE + 1), device=dev, generator=g)
+    z_base = torch.linspace(NEAR, FAR, C_COARSE).to(dev)
+    jitter = (FAR - NEAR) / N_FINE
+    density = torch.empty((n_rays, C_COARSE), device=dev)
+    poses = [pose_spherical(float(th), -30.0, 4.0)[:3] for th in torch.linspace(-180, 180, 41)[:-1]]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i, timed_idx=None):
+        pose = poses[(i + 7 * rank) % len(poses)]
+        rays = ops.generate_rays(pose, H, W, fx, fy, dev)                                            # row 1
+        sc = ops.samples_rays(rays, C_COARSE, z_base=z_base, u=u_strat, z_jitter=jitter)            # rows 2-4
+        dens = ops.proposal_forward_samples(pk_prop, prec, sc, (n_rays, C_COARSE), dev)
+        z_fine, _, _, _ = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1)   # rows 5-7
+        sf = ops.samples_rays(rays, N_FINE, z=z_fine)                                                 # rows 8-9
+        if timed_idx is not None:
+            ev[timed_idx][0].record()
+        rgbo = ops.mip_forward_samples(pk_mip, prec, sf, (n_rays, N_FINE), dev)
+        if timed_idx is not None:
+            ev[timed_idx][1].record()
+        rgb, w, depth, _ = ops.composite(rgbo, z_fine, rays[:, 3:], True, True, ops.ACT_RELU, (NEAR, FAR))   # row 10
+        return rgb, depth, w
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(a.warmup + i, i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out[0]).all())
+
+    if rank == 0:
+        fine_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+        fine_flops = n_rays * N_FINE * 2 * MAC_FINE
+        peak = PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA
+        achieved = fine_flops / (fine_ms * 1e-3)
+        rec = {
+            "metric": "rays/s (64+128 samples), 800x800", "value": world * a.steps * n_rays / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: NeRF render 800x800 (640000 rays/step/GPU), 64 proposal + 128 fine samples, "
+                                   "proposal MLP 63->256x4->1 + MipNeRF 8x256 MLP, rows 1-10 of SURVEY 8a, uniforms resident in HBM",
+                       "rays_per_step_per_gpu": n_rays, "samples": [C_COARSE, N_FINE], "mlp_arith": "bf16 MFMA, fp32 accumulate"
+                       if prec == ops.BF16 else "fp32 MFMA", "parallelism": "ray-sharded replicas (dp%d)" % world},
+            "roofline": {"bound": "mfma", "kernel": "mip_kernel (fine MLP, 527872 MAC/sample)",
+                         "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": None},
+            "whole_path_tflops": world * a.steps * n_rays * FLOP_PER_RAY / dt / 1e12,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

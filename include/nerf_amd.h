@@ -1,0 +1,185 @@
+/*
+ * nerf_amd.h -- C-ABI of libnerf_amd.so: the MI355X (gfx950) native NeRF ray-march hot path.
+ *
+ * The reference (Enigmatisms/NeRF) has no FFI layer: its hot path is plain Python/torch functions
+ * (SURVEY.md section 8b).  This header declares, one entry point per reference callee, what a
+ * maintainer of the reference would bind from Python (ctypes stub: INTEGRATION.md) to replace the
+ * torch expressions with the hand-written HIP kernels.  Citations are file:line under the
+ * reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 (or int64 where stated) unless
+ *     marked "host"; no torch types cross this boundary;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     asynchronous on that stream, nothing synchronises the device;
+ *   - every function returns 0 on success, a negative NERF_AMD_E* code otherwise;
+ *     nerf_amd_last_error() returns a host string describing the last failure of the calling thread;
+ *   - inputs are never written; outputs never alias inputs.
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_AMD_OK            0
+#define NERF_AMD_EINVAL       -1   /* bad argument (NULL pointer, unsupported size)            */
+#define NERF_AMD_EUNSUPPORTED -2   /* a configuration the HIP kernels are not instantiated for */
+#define NERF_AMD_EHIP         -3   /* a HIP runtime call failed (see nerf_amd_last_error)      */
+
+/* arithmetic of the MLP matrix products */
+#define NERF_AMD_F32   0   /* v_mfma_f32_32x32x2_f32: exact fp32 products + fp32 accumulate (parity mode, <=1e-4) */
+#define NERF_AMD_BF16  1   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (throughput mode)          */
+
+/* which network a packed weight blob belongs to */
+#define NERF_AMD_NET_PROPOSAL 0    /* ProposalNetwork(10, 256)        addtional.py:53-96  */
+#define NERF_AMD_NET_MIP      1    /* MipNeRF(10, 4, 256)             mip_model.py:14-60  */
+
+/* density activation applied inside sigma->alpha (nerf_base.py:82 `density_act`) */
+#define NERF_AMD_ACT_RELU     0
+#define NERF_AMD_ACT_IDENTITY 1    /* RefNeRF passes `lambda x: x` (ref_model.py:26)          */
+#define NERF_AMD_ACT_SOFTPLUS 2
+
+const char* nerf_amd_last_error(void);
+int         nerf_amd_version(void);                       /* 100*major + minor */
+int         nerf_amd_device_info(int* n_cu, int* arch_is_gfx950);
+
+/* ------------------------------------------------------------------------------------------------
+ * Where the samples of an MLP launch come from.  Three sources, so that positions never have to be
+ * materialised in HBM on the render path:
+ *   mode 0  points in memory        pts (M, pts_stride): xyz at [0:3], raw direction at [3:6]
+ *                                   (MipNeRF.forward input, mip_model.py:41; ProposalNetwork.forward
+ *                                   input, addtional.py:88)
+ *   mode 1  rays + depths           x = o + z*d  (NeRF.length2pts nerf_base.py:53-56;
+ *                                   procedures.py:66).  rays (N,6) = [o|d]; depth of sample s on ray n:
+ *                                   z[n*z_stride + s]                         if z  != NULL
+ *                                   z_base[s] + u[n*S + s] * z_jitter          otherwise (stratified
+ *                                   draw of procedures.py:65 / utils.py:89 fused in)
+ *   mode 2  camera + depths         like mode 1 with o = pose[:,3] and d = R.((col-W/2+.5)/fx,
+ *                                   (H/2-row+.5)/fy, -1) generated in-kernel for ray n = row*W + col
+ *                                   (procedures.py:43-51)
+ * M = total samples = N*S in modes 1/2.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct nerf_amd_samples {
+    int32_t      mode;
+    int32_t      S;            /* samples per ray (modes 1, 2)                 */
+    int64_t      M;            /* total number of samples                      */
+    const float* pts;          /* mode 0                                       */
+    int32_t      pts_stride;   /* mode 0: floats per sample (3 or 6)           */
+    int32_t      z_stride;     /* modes 1/2: floats between rays in z          */
+    const float* rays;         /* mode 1: (N, 6)                               */
+    const float* z;            /* modes 1/2 or NULL                            */
+    const float* z_base;       /* (S) when z == NULL                           */
+    const float* u;            /* (N, S) uniforms when z == NULL               */
+    float        z_jitter;     /* scale of u when z == NULL                    */
+    int32_t      H, W;         /* mode 2                                       */
+    float        fx, fy;       /* mode 2: x is divided by fx, y by fy          */
+    float        pose[12];     /* mode 2: row-major 3x4 camera-to-world (host) */
+} nerf_amd_samples;
+
+/* ------------------------------------------------------------------------------------------------
+ * Weights.  The kernels stream MFMA-fragment-ordered weights through LDS; packing turns the
+ * reference's nn.Linear tensors ((out,in) row-major fp32, state_dict order below) into that stream.
+ * Re-pack after every optimiser step (a few microseconds).
+ *   proposal: layers.{0,2,4,6,8}                                   (addtional.py:67-71)
+ *   mip     : lin_block1.{0,2,4,6}, lin_block2.{0,2,4}, bottle_neck.0, opacity_head.0,
+ *             rgb_layer.{0,2}                                        (mip_model.py:19-37)
+ * `weights` / `biases` are HOST arrays of DEVICE pointers in that order.
+ * ------------------------------------------------------------------------------------------------ */
+size_t nerf_amd_packed_bytes(int net, int precision);
+int    nerf_amd_pack_weights(int net, int precision, const float* const* weights, const float* const* biases,
+                             int n_tensors, void* packed, void* stream);
+
+/* ProposalNetwork.forward (addtional.py:88-96): density (M) fp32, no activation. */
+int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_samples* src,
+                              float* density, void* stream);
+/* MipNeRF.forward (mip_model.py:41-60): rgbo (M, 4) = [sigmoid rgb | raw sigma]. */
+int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src,
+                         float* rgbo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampling / compositing kernels (one 64-lane wavefront per ray; HBM-bound).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* positional_encoding (nerf_helper.py:38-48): x (M,3) -> out (M, 6L) = [sin 2^0 x, cos 2^0 x, sin 2^1 x, ...] */
+int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, void* stream);
+
+/* Ray table of render_image (procedures.py:43-51,64): rays (N, 6) = [pose[:,3] | R.c] for pixels
+ * n = row*W + col in [ray_offset, ray_offset+N); `pose_host` is a HOST row-major 3x4. */
+int nerf_amd_generate_rays(const float* pose_host, int H, int W, float fx, float fy, int64_t ray_offset, int64_t N,
+                           float* rays, void* stream);
+
+/* NeRF.length2pts (nerf_base.py:53-56): out (N, S, 6) = [o + z d | d]. */
+int nerf_amd_length2pts(const float* rays, const float* z, int64_t N, int S, float* out, void* stream);
+
+/* ProposalNetwork.get_weights (addtional.py:100-107) / NeRF.getNormedWeight (nerf_base.py:80-86):
+ * sigma (N,S), z (N,S), dirs (N,3) or NULL (NULL = z already scaled) -> w (N,S). */
+int nerf_amd_sigma_to_weights(const float* sigma, const float* z, const float* dirs, int64_t N, int S, int act,
+                              float* w, void* stream);
+
+/* maxBlurFilter (mip_methods.py:61-66): w (N,S) -> out (N,S). */
+int nerf_amd_max_blur(const float* w, int64_t N, int S, float alpha, float* out, void* stream);
+
+/* inverseSample (utils.py:34-44) + sample_pdf (utils.py:108-133) with the uniforms explicit:
+ * w (N,C), z (N,C), u (N,K) -> z_out (N,K) [sorted when sort!=0], below (N,K) int64 (NULL to skip). C <= 256. */
+int nerf_amd_inverse_sample(const float* w, const float* z, const float* u, int64_t N, int C, int K, int sort,
+                            float* z_out, int64_t* below, void* stream);
+
+/* sample_pdf (utils.py:108-133): bins (N,B), weights (N,B-1), u (N,K) -> samples (N,K), below/above (N,K) int64 or NULL. */
+int nerf_amd_sample_pdf(const float* bins, const float* weights, const float* u, int64_t N, int B, int K, float* samples,
+                        int64_t* below, int64_t* above, void* stream);
+
+/* Training twin of the ray table (validSampler, utils.py:78-85): integer pixel coords (N,2) int64 =
+ * (col - W//2, H//2 - row) from randomFromOneImage -> rays (N,6). */
+int nerf_amd_pixel_rays(const float* pose_host, float fx, float fy, const int64_t* coords, int64_t N, float* rays, void* stream);
+
+/* Stratified depths and points (utils.py:87-90, procedures.py:65-66): z = z_base[s] + u*z_jitter (N,S);
+ * pts (N,S,3) = o + d*z, or NULL to skip. */
+int nerf_amd_stratified_points(const float* rays, const float* z_base, const float* u, float z_jitter, int64_t N, int S,
+                               float* z_out, float* pts, void* stream);
+
+/* Fused proposal resampling of the render/train loop (procedures.py:68-70, train.py:169-172):
+ * density -> [softplus] -> get_weights(|d| scaling, relu) -> maxBlur(alpha) -> inverse sample (sorted).
+ * Depths as in nerf_amd_samples (z, or z_base + u_strat*z_jitter).  dirs row n at dirs[n*dirs_stride .. +3]
+ * (pass rays+3 with stride 6).  Optional outputs (NULL to skip): w_prop (N,C), below (N,K) int64, z_coarse (N,C). */
+int nerf_amd_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
+                      const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K,
+                      int softplus_density, float blur_alpha,
+                      float* z_fine, int64_t* below, float* w_prop, float* z_coarse, void* stream);
+
+/* NeRF.render (nerf_base.py:91-113).  rgbo (N,S,4), z (N,z_stride) [first S used], dirs as above.
+ * flags: bit0 mul_norm, bit1 white_bkg.  Outputs: rgb (N,3), weights (N,S) or NULL, depth (N) or NULL
+ * ((sum w z - near)/(far-near)), normal_img (N) or NULL when normal (N,S,3) and cam_dir (3, device) given. */
+int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride,
+                       int64_t N, int S, int flags, int act, float near, float far,
+                       const float* normal, const float* cam_dir,
+                       float* rgb, float* weights, float* depth, float* normal_img, void* stream);
+
+/* getBounds (addtional.py:14-18): w_prop (N,C), below (N,K) int64 -> bounds (N,K-1). */
+int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The whole tile body of render_image (procedures.py:64-85, non-Ref) for N rays in four launches:
+ *   proposal MLP (stratified z fused) -> resample -> fine MLP (length2pts fused) -> composite.
+ * rays: (N,6) device, or NULL to generate them in-kernel from `camera` (mode 2 of nerf_amd_samples;
+ * only H, W, fx, fy, pose are read; ray n = row*W + col, n in [ray_offset, ray_offset+N)).
+ * z_base (64) = linspace(near, far, 64) (procedures.py:52; an input so that it is bit-identical to the
+ * caller's torch.linspace), u_strat (N,64), u_inv (N, n_fine+1).
+ * Outputs rgb (N,3), depth (N) or NULL, weights (N,n_fine) or NULL.
+ * workspace: nerf_amd_render_workspace_bytes(N, n_fine) bytes of device scratch.
+ * ------------------------------------------------------------------------------------------------ */
+size_t nerf_amd_render_workspace_bytes(int64_t N, int n_fine);
+int    nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int precision,
+                            const float* rays, const nerf_amd_samples* camera, int64_t ray_offset,
+                            const float* z_base, const float* u_strat, const float* u_inv, int64_t N, int n_fine,
+                            float near, float far, int white_bkg,
+                            float* rgb, float* depth, float* weights, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libnerf_amd.so (include/nerf_amd.h).  There is NO fallback: if the HIP library
+is missing or fails to load, importing this module raises -- the product never silently runs a
+torch/CPU substitute."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
+
+F32, BF16 = 0, 1
+NET_PROPOSAL, NET_MIP = 0, 1
+ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS = 0, 1, 2
+
+c_float_p = C.POINTER(C.c_float)
+c_void = C.c_void_p
+i64 = C.c_int64
+
+
+class Samples(C.Structure):
+    """struct nerf_amd_samples"""
+    _fields_ = [("mode", C.c_int32), ("S", C.c_int32), ("M", C.c_int64), ("pts", c_void), ("pts_stride", C.c_int32),
+                ("z_stride", C.c_int32), ("rays", c_void), ("z", c_void), ("z_base", c_void), ("u", c_void),
+                ("z_jitter", C.c_float), ("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("pose", C.c_float * 12)]
+
+
+# name -> (restype, argtypes); mirrors include/nerf_amd.h one to one (tests check the two agree)
+SIGNATURES = {
+    "nerf_amd_last_error": (C.c_char_p, []),
+    "nerf_amd_version": (C.c_int, []),
+    "nerf_amd_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nerf_amd_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "nerf_amd_pack_weights": (C.c_int, [C.c_int, C.c_int, C.POINTER(c_void), C.POINTER(c_void), C.c_int, c_void, c_void]),
+    "nerf_amd_proposal_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void]),
+    "nerf_amd_mip_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void]),
+    "nerf_amd_positional_encoding": (C.c_int, [c_void, i64, C.c_int, c_void, c_void]),
+    "nerf_amd_generate_rays": (C.c_int, [c_float_p, C.c_int, C.c_int, C.c_float, C.c_float, i64, i64, c_void, c_void]),
+    "nerf_amd_length2pts": (C.c_int, [c_void, c_void, i64, C.c_int, c_void, c_void]),
+    "nerf_amd_sigma_to_weights": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
+    "nerf_amd_max_blur": (C.c_int, [c_void, i64, C.c_int, C.c_float, c_void, c_void]),
+    "nerf_amd_inverse_sample": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
+    "nerf_amd_sample_pdf": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
+    "nerf_amd_pixel_rays": (C.c_int, [c_float_p, C.c_float, C.c_float, c_void, i64, c_void, c_void]),
+    "nerf_amd_stratified_points": (C.c_int, [c_void, c_void, c_void, C.c_float, i64, C.c_int, c_void, c_void, c_void]),
+    "nerf_amd_resample": (C.c_int, [c_void, c_void, c_void, c_void, C.c_float, c_void, C.c_int, c_void, i64, C.c_int,
+                                    C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_composite": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_get_bounds": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
+    "nerf_amd_render_workspace_bytes": (C.c_size_t, [i64, C.c_int]),
+    "nerf_amd_render_rays": (C.c_int, [c_void, c_void, C.c_int, c_void, C.POINTER(Samples), i64, c_void, c_void, c_void, i64,
+                                       C.c_int, C.c_float, C.c_float, C.c_int, c_void, c_void, c_void, c_void, c_void]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "nerf_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C nerf_amd/csrc`). There is no CPU/torch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)                 # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class NerfAmdError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib.nerf_amd_last_error()
+        raise NerfAmdError("%s failed (%d): %s" % (what or "nerf_amd call", rc, msg.decode() if msg else "?"))

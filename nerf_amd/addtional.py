@@ -1,0 +1,97 @@
+"""Host-side mirror of the reference's ``nerf/addtional.py`` (sic): ProposalNetwork, getBounds and the
+scalar losses.  Same names, signatures and ``state_dict`` keys."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from ._packed import PackedWeightsMixin, require_no_grad
+from .nerf_helper import makeMLP
+
+
+def getBounds(weights: torch.Tensor, inds: torch.Tensor):
+    """Proposal weight mass covering each fine interval (addtional.py:14-18, index quirk included)."""
+    require_no_grad(weights)
+    return ops.get_bounds(weights, inds)
+
+
+class ProposalLoss(nn.Module):
+    def forward(self, prop_bounds: torch.Tensor, nerf_weights: torch.Tensor) -> torch.Tensor:
+        """sum relu(w - bound)^2 / (w + 1e-8)  (addtional.py:20-24)."""
+        return torch.sum(F.relu(nerf_weights - prop_bounds) ** 2 / (nerf_weights + 1e-8))
+
+
+class SoftL1Loss(nn.Module):
+    def __init__(self, epsilon=0.001) -> None:
+        super().__init__()
+        self.eps = epsilon
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor):
+        """Despite the name: plain MSE (addtional.py:37-42)."""
+        return torch.mean((pred - target) ** 2)
+
+
+class LossPSNR(nn.Module):
+    __LOG_10__ = 2.3025851249694824
+
+    def forward(self, x):
+        """-10 log10(mse)  (addtional.py:45-51)."""
+        return -10. * torch.log(x) / LossPSNR.__LOG_10__
+
+
+class ProposalNetwork(nn.Module, PackedWeightsMixin):
+    _net_id = ops.NET_PROPOSAL
+
+    @staticmethod
+    def init_weight(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def __init__(self, position_flevel, hidden_unit=128, cat_origin=True) -> None:
+        super().__init__()
+        self.position_dims = position_flevel * 6
+        self.position_flevel = position_flevel
+        self.cat_origin = cat_origin
+        self.hidden_unit = hidden_unit
+        in_dim = self.position_dims + (3 if cat_origin else 0)
+        self.layers = nn.Sequential(*makeMLP(in_dim, hidden_unit), *makeMLP(hidden_unit, hidden_unit),
+                                    *makeMLP(hidden_unit, hidden_unit), *makeMLP(hidden_unit, hidden_unit),
+                                    *makeMLP(hidden_unit, 1, None))
+        self.apply(self.init_weight)
+
+    def _linear_layers(self):
+        return [self.layers[0], self.layers[2], self.layers[4], self.layers[6], self.layers[8]]
+
+    def _check_config(self):
+        if not (self.position_flevel == 10 and self.hidden_unit == 256 and self.cat_origin):
+            raise NotImplementedError("nerf_amd: the HIP proposal kernel is instantiated for ProposalNetwork(10, 256, cat_origin=True)")
+
+    def loadFromFile(self, load_path: str, use_amp=False, other_stuff=None):
+        """addtional.py:73-86."""
+        save = torch.load(load_path, map_location="cpu")
+        own = self.state_dict()
+        own.update({k: save["model"][k] for k in own.keys()})
+        self.load_state_dict(own)
+        if use_amp:
+            from apex import amp
+            amp.load_state_dict(save["amp"])
+        print("NeRF Model loaded from '%s'" % (load_path))
+        if other_stuff is not None:
+            return [save[k] for k in other_stuff]
+
+    def forward(self, pts: torch.Tensor, encoded_pt: torch.Tensor = None) -> torch.Tensor:
+        """pts (N,C,3) -> density (N,C), no activation (addtional.py:88-96).  ``encoded_pt`` (a pre-computed
+        encoding) is accepted for signature parity and ignored: the kernel encodes in-register."""
+        self._check_config()
+        require_no_grad(pts, *self.parameters())
+        prec = ops.current_precision()
+        return ops.proposal_forward(self.packed(prec), prec, pts)
+
+    @staticmethod
+    def get_weights(density: torch.Tensor, zvals: torch.Tensor, ray_dirs: torch.Tensor = None) -> torch.Tensor:
+        """relu(sigma) -> alpha -> exclusive transmittance product; z scaled by |d| when ray_dirs is
+        given (addtional.py:100-107)."""
+        require_no_grad(density, zvals)
+        return ops.sigma_to_weights(density, zvals, ray_dirs, ops.ACT_RELU)

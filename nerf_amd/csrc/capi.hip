@@ -1,0 +1,251 @@
+// extern "C" boundary of libnerf_amd.so (declared in include/nerf_amd.h).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nerf_amd.h"
+#include "mlp_layout.h"
+
+// launchers defined in the kernel translation units
+int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
+int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
+int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
+int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
+int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
+int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
+int sk_length2pts(const float*, const float*, int64_t, int, float*, hipStream_t);
+int sk_sigma_to_weights(const float*, const float*, const float*, int64_t, int, int, float*, hipStream_t);
+int sk_max_blur(const float*, int64_t, int, float, float*, hipStream_t);
+int sk_inverse_sample(const float*, const float*, const float*, int64_t, int, int, int, int, float*, int64_t*, int64_t*, hipStream_t);
+int sk_pixel_rays(const float*, float, float, const int64_t*, int64_t, float*, hipStream_t);
+int sk_stratified_points(const float*, const float*, const float*, float, int64_t, int, float*, float*, hipStream_t);
+int sk_resample(const float*, const float*, const float*, const float*, float, const float*, int, const float*, int64_t, int,
+                int, int, float, float*, int64_t*, float*, float*, hipStream_t);
+int sk_composite(const float*, const float*, int, const float*, int, int64_t, int, int, int, float, float, const float*,
+                 const float*, float*, float*, float*, float*, hipStream_t);
+int sk_get_bounds(const float*, const int64_t*, int64_t, int, int, float*, hipStream_t);
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a);
+    return code;
+}
+int hip_status(int e, const char* where) {
+    if (e == 0) return NERF_AMD_OK;
+    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, e, hipGetErrorString((hipError_t)e));
+    return NERF_AMD_EHIP;
+}
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+int check_samples(const nerf_amd_samples* s, bool need_dir) {
+    if (!s) return fail(NERF_AMD_EINVAL, "samples descriptor is NULL");
+    if (s->M < 0) return fail(NERF_AMD_EINVAL, "negative sample count");
+    if (s->mode == 0) {
+        if (!s->pts && s->M) return fail(NERF_AMD_EINVAL, "mode 0 needs pts");
+        if (s->pts_stride < (need_dir ? 6 : 3)) return fail(NERF_AMD_EINVAL, "pts_stride too small for this network");
+    } else if (s->mode == 1 || s->mode == 2) {
+        if (s->S <= 0) return fail(NERF_AMD_EINVAL, "S must be positive");
+        if (s->mode == 1 && !s->rays && s->M) return fail(NERF_AMD_EINVAL, "mode 1 needs rays");
+        if (s->mode == 2 && (s->H <= 0 || s->W <= 0)) return fail(NERF_AMD_EINVAL, "mode 2 needs H, W");
+        if (!s->z && !(s->z_base && s->u) && s->M) return fail(NERF_AMD_EINVAL, "need z, or z_base and u");
+    } else {
+        return fail(NERF_AMD_EINVAL, "unknown sample mode");
+    }
+    return NERF_AMD_OK;
+}
+bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
+}  // namespace
+
+extern "C" {
+
+const char* nerf_amd_last_error(void) { return g_err; }
+int nerf_amd_version(void) { return 100; }
+
+int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    int e = (int)hipGetDevice(&dev);
+    if (!e) e = (int)hipGetDeviceProperties(&p, dev);
+    if (e) return hip_status(e, "nerf_amd_device_info");
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (arch_is_gfx950) *arch_is_gfx950 = strncmp(p.gcnArchName, "gfx950", 6) == 0;
+    return NERF_AMD_OK;
+}
+
+size_t nerf_amd_packed_bytes(int net, int precision) {
+    if (bad_prec(precision)) return 0;
+    if (net == NERF_AMD_NET_PROPOSAL) return PropLayout::packed_bytes(precision);
+    if (net == NERF_AMD_NET_MIP) return MipLayout::packed_bytes(precision);
+    return 0;
+}
+
+int nerf_amd_pack_weights(int net, int precision, const float* const* weights, const float* const* biases, int n_tensors,
+                          void* packed, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (!weights || !biases || !packed) return fail(NERF_AMD_EINVAL, "NULL argument");
+    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : -1);
+    if (want < 0) return fail(NERF_AMD_EINVAL, "unknown network");
+    if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
+    for (int i = 0; i < want; ++i)
+        if (!weights[i] || !biases[i]) return fail(NERF_AMD_EINVAL, "NULL weight or bias tensor");
+    const int e = net == NERF_AMD_NET_PROPOSAL ? pack_proposal(precision, weights, biases, packed, S(stream))
+                                               : pack_mip(precision, weights, biases, packed, S(stream));
+    return hip_status(e, "nerf_amd_pack_weights");
+}
+
+int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (!packed || !density) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (int c = check_samples(src, false)) return c;
+    return hip_status(mlp_launch_proposal(packed, precision, *src, density, S(stream)), "nerf_amd_proposal_forward");
+}
+
+int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (int c = check_samples(src, true)) return c;
+    return hip_status(mlp_launch_mip(packed, precision, *src, rgbo, S(stream)), "nerf_amd_mip_forward");
+}
+
+int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, void* stream) {
+    if (M < 0 || L < 1 || L > 24) return fail(NERF_AMD_EINVAL, "bad M or L");
+    if (M && (!x || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_positional_encoding(x, M, L, out, S(stream)), "nerf_amd_positional_encoding");
+}
+
+int nerf_amd_generate_rays(const float* pose_host, int H, int W, float fx, float fy, int64_t ray_offset, int64_t N, float* rays,
+                           void* stream) {
+    if (!pose_host || !rays || H <= 0 || W <= 0) return fail(NERF_AMD_EINVAL, "bad argument");
+    if (ray_offset < 0 || N < 0 || ray_offset + N > (int64_t)H * W) return fail(NERF_AMD_EINVAL, "ray range outside the image");
+    return hip_status(sk_generate_rays(pose_host, H, W, fx, fy, ray_offset, N, rays, S(stream)), "nerf_amd_generate_rays");
+}
+
+int nerf_amd_length2pts(const float* rays, const float* z, int64_t N, int Sn, float* out, void* stream) {
+    if (N < 0 || Sn < 0) return fail(NERF_AMD_EINVAL, "negative size");
+    if (N * Sn && (!rays || !z || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_length2pts(rays, z, N, Sn, out, S(stream)), "nerf_amd_length2pts");
+}
+
+int nerf_amd_sigma_to_weights(const float* sigma, const float* z, const float* dirs, int64_t N, int Sn, int act, float* w,
+                              void* stream) {
+    if (N < 0 || Sn < 0 || act < 0 || act > 2) return fail(NERF_AMD_EINVAL, "bad size or activation");
+    if (N * Sn && (!sigma || !z || !w)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_sigma_to_weights(sigma, z, dirs, N, Sn, act, w, S(stream)), "nerf_amd_sigma_to_weights");
+}
+
+int nerf_amd_max_blur(const float* w, int64_t N, int Sn, float alpha, float* out, void* stream) {
+    if (N < 0 || Sn < 0) return fail(NERF_AMD_EINVAL, "negative size");
+    if (N * Sn && (!w || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_max_blur(w, N, Sn, alpha, out, S(stream)), "nerf_amd_max_blur");
+}
+
+int nerf_amd_inverse_sample(const float* w, const float* z, const float* u, int64_t N, int C, int K, int sort, float* z_out,
+                            int64_t* below, void* stream) {
+    if (N < 0 || C < 3 || C > 256 || K < 1 || K > 1024) return fail(NERF_AMD_EINVAL, "need 3 <= C <= 256 and 1 <= K <= 1024");
+    if (N && (!w || !z || !u || !z_out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_inverse_sample(w, z, u, N, C, K, sort, 0, z_out, below, nullptr, S(stream)), "nerf_amd_inverse_sample");
+}
+
+int nerf_amd_sample_pdf(const float* bins, const float* weights, const float* u, int64_t N, int B, int K, float* samples,
+                        int64_t* below, int64_t* above, void* stream) {
+    if (N < 0 || B < 2 || B > 256 || K < 1 || K > 1024) return fail(NERF_AMD_EINVAL, "need 2 <= B <= 256 and 1 <= K <= 1024");
+    if (N && (!bins || !weights || !u || !samples)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_inverse_sample(weights, bins, u, N, B, K, 0, 1, samples, below, above, S(stream)), "nerf_amd_sample_pdf");
+}
+
+int nerf_amd_pixel_rays(const float* pose_host, float fx, float fy, const int64_t* coords, int64_t N, float* rays, void* stream) {
+    if (!pose_host || N < 0 || (N && (!coords || !rays))) return fail(NERF_AMD_EINVAL, "bad argument");
+    return hip_status(sk_pixel_rays(pose_host, fx, fy, coords, N, rays, S(stream)), "nerf_amd_pixel_rays");
+}
+
+int nerf_amd_stratified_points(const float* rays, const float* z_base, const float* u, float z_jitter, int64_t N, int Sn,
+                               float* z_out, float* pts, void* stream) {
+    if (N < 0 || Sn < 0) return fail(NERF_AMD_EINVAL, "negative size");
+    if (N * Sn && (!z_base || !u || !z_out || (pts && !rays))) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_stratified_points(rays, z_base, u, z_jitter, N, Sn, z_out, pts, S(stream)), "nerf_amd_stratified_points");
+}
+
+int nerf_amd_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
+                      const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K, int softplus_density,
+                      float blur_alpha, float* z_fine, int64_t* below, float* w_prop, float* z_coarse, void* stream) {
+    if (N < 0 || C < 3 || C > 256 || K < 1 || K > 1024) return fail(NERF_AMD_EINVAL, "need 3 <= C <= 256 and 1 <= K <= 1024");
+    if (N && (!density || !dirs || !u_inv || !z_fine)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (N && !z && !(z_base && u_strat)) return fail(NERF_AMD_EINVAL, "need z, or z_base and u_strat");
+    return hip_status(sk_resample(density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus_density,
+                                  blur_alpha, z_fine, below, w_prop, z_coarse, S(stream)), "nerf_amd_resample");
+}
+
+int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int Sn,
+                       int flags, int act, float near, float far, const float* normal, const float* cam_dir, float* rgb,
+                       float* weights, float* depth, float* normal_img, void* stream) {
+    if (N < 0 || Sn < 1 || act < 0 || act > 2 || z_stride < Sn) return fail(NERF_AMD_EINVAL, "bad size, stride or activation");
+    if (N && (!rgbo || !z || !dirs || !rgb)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (normal_img && !(normal && cam_dir)) return fail(NERF_AMD_EINVAL, "normal_img needs normal and cam_dir");
+    return hip_status(sk_composite(rgbo, z, z_stride, dirs, dirs_stride, N, Sn, flags, act, near, far, normal, cam_dir, rgb,
+                                   weights, depth, normal_img, S(stream)), "nerf_amd_composite");
+}
+
+int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream) {
+    if (N < 0 || C < 1 || C > 4096 || K < 2) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N && (!w_prop || !below || !bounds)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_get_bounds(w_prop, below, N, C, K, bounds, S(stream)), "nerf_amd_get_bounds");
+}
+
+// workspace: density (N,64) | z_fine (N, n_fine+1) | rgbo (N, n_fine, 4) | rays (N, 6)
+size_t nerf_amd_render_workspace_bytes(int64_t N, int n_fine) {
+    if (N < 0 || n_fine < 1) return 0;
+    const size_t a = ((size_t)N * 64 * 4 + 255) & ~(size_t)255;
+    const size_t b = ((size_t)N * (n_fine + 1) * 4 + 255) & ~(size_t)255;
+    const size_t c = ((size_t)N * n_fine * 16 + 255) & ~(size_t)255;
+    const size_t d = (size_t)N * 24;
+    return a + b + c + d + 256;
+}
+
+int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int precision, const float* rays,
+                         const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
+                         const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, float* rgb,
+                         float* depth, float* weights, void* workspace, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
+    if (N == 0) return NERF_AMD_OK;
+    if (!packed_prop || !packed_mip || !z_base || !u_strat || !u_inv || !rgb || !workspace)
+        return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (!rays && !camera) return fail(NERF_AMD_EINVAL, "need rays or camera");
+    constexpr int C = 64;                                   // procedures.py:22 RENDER_COARSE_PNUM
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float* density = reinterpret_cast<float*>(ws);
+    ws += ((size_t)N * C * 4 + 255) & ~(size_t)255;
+    float* z_fine = reinterpret_cast<float*>(ws);
+    ws += ((size_t)N * (n_fine + 1) * 4 + 255) & ~(size_t)255;
+    float* rgbo = reinterpret_cast<float*>(ws);
+    ws += ((size_t)N * n_fine * 16 + 255) & ~(size_t)255;
+    hipStream_t st = S(stream);
+    if (!rays) {                                            // row 1: procedures.py:43-51,64
+        if (camera->H <= 0 || camera->W <= 0 || ray_offset < 0 || ray_offset + N > (int64_t)camera->H * camera->W)
+            return fail(NERF_AMD_EINVAL, "ray range outside the camera image");
+        float* gen = reinterpret_cast<float*>(ws);
+        if (int e = sk_generate_rays(camera->pose, camera->H, camera->W, camera->fx, camera->fy, ray_offset, N, gen, st))
+            return hip_status(e, "ray generation");
+        rays = gen;
+    }
+    const float jitter = (far - near) / (float)n_fine;      // procedures.py:59
+
+    nerf_amd_samples sc{};                                  // rows 2-4: stratified z fused into the proposal MLP
+    sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
+    sc.z_jitter = jitter; sc.z_stride = C;
+    if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
+    // rows 5-7: weights -> max-blur(0.01) -> inverse sampling of n_fine+1 sorted depths (procedures.py:68-70)
+    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, z_fine,
+                            nullptr, nullptr, nullptr, st)) return hip_status(e, "resample");
+    nerf_amd_samples sf{};                                  // rows 8-9: drop the last depth, length2pts fused into the MLP
+    sf.mode = 1; sf.rays = rays; sf.S = n_fine; sf.M = N * n_fine; sf.z = z_fine; sf.z_stride = n_fine + 1;
+    if (int e = mlp_launch_mip(packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");
+    const int flags = 1 | (white_bkg ? 2 : 0);              // row 10
+    if (int e = sk_composite(rgbo, z_fine, n_fine + 1, rays + 3, 6, N, n_fine, flags, NERF_AMD_ACT_RELU, near, far, nullptr,
+                             nullptr, rgb, weights, depth, nullptr, st)) return hip_status(e, "composite");
+    return NERF_AMD_OK;
+}
+
+}  // extern "C"

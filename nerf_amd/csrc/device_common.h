@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 NeRF kernels.  Compiled with -ffp-contract=off: every FMA in
+// this code base is an explicit __builtin_fmaf, so position arithmetic (o + z*d, z_base + u*res)
+// rounds exactly like the reference's separate torch mul/add (SURVEY.md section 7 "hard parts").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// ------------------------------------------------------------------------------------------------
+// sin / cos with exact-to-~1ulp range reduction for |a| <~ 2^15 (PE arguments are 2^f * x <= ~8e3).
+// k = rint(a*2/pi); r = a - k*pi/2 by a 3-term Cody-Waite split evaluated with FMAs: the first FMA
+// is exact (a - k*c1 is a multiple of 2^-23 below 1), the second rounds once (<= 2^-25).
+// `quad` = 0 -> sin(a), 1 -> cos(a) = sin(a + pi/2): both lane halves run the same instruction stream.
+// ------------------------------------------------------------------------------------------------
+DEVINL float sin_quadrant(float a, int quad) {
+    const float k = __builtin_rintf(a * 0.6366197466850281f);
+    float r = __builtin_fmaf(-k, 1.57079637050628662109375f, a);       // fl(pi/2)
+    r = __builtin_fmaf(-k, -4.371138828673793e-08f, r);                    // fl(pi/2 - c1)
+    r = __builtin_fmaf(-k, -1.7151245100058819e-15f, r);                  // fl(pi/2 - c1 - c2)
+    const int n = (int)k + quad;
+    const float z = r * r;
+    // sin(r) on [-pi/4, pi/4]  (fdlibm k_sinf coefficients)
+    float ps = __builtin_fmaf(z, 1.5896910177e-10f, -2.5050759689e-08f);
+    ps = __builtin_fmaf(z, ps, 2.7557314297e-06f);
+    ps = __builtin_fmaf(z, ps, -1.9841270114e-04f);
+    ps = __builtin_fmaf(z, ps, 8.3333337680e-03f);
+    ps = __builtin_fmaf(z, ps, -1.6666667163e-01f);
+    const float s = __builtin_fmaf(r * z, ps, r);
+    // cos(r) on [-pi/4, pi/4]  (fdlibm k_cosf coefficients)
+    float pc = __builtin_fmaf(z, -1.1359647598e-11f, 2.0875723372e-09f);
+    pc = __builtin_fmaf(z, pc, -2.7557314297e-07f);
+    pc = __builtin_fmaf(z, pc, 2.4801587642e-05f);
+    pc = __builtin_fmaf(z, pc, -1.3888889225e-03f);
+    pc = __builtin_fmaf(z, pc, 4.1666667908e-02f);
+    const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    float v = (n & 1) ? c : s;
+    return (n & 2) ? -v : v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64-lane inclusive scans (log-step shuffles).  fp64 versions mirror torch's CPU cumsum/cumprod,
+// which accumulate float inputs in double and round each prefix to float.
+// ------------------------------------------------------------------------------------------------
+DEVINL double wave_incl_scan_mul(double v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d, 64);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+DEVINL double wave_incl_scan_add(double v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+DEVINL double wave_sum_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+DEVINL float softplus_f(float x) {            // torch softplus: beta=1, threshold=20
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+DEVINL float density_act(float x, int act) {
+    if (act == 0) return fmaxf(x, 0.0f);
+    if (act == 2) return softplus_f(x);
+    return x;
+}
+DEVINL float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }

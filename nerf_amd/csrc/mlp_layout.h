@@ -1,0 +1,66 @@
+// Packed-weight stream layout shared by the MLP kernels and the pack kernels.
+//
+// A packed blob = [fragment stream][bias table].
+//   fragment (layer, fb, kg) holds A-operand registers of one 32x32 MFMA tile: rows = output features
+//   32*fb .. 32*fb+31, K = the 16 input "slots" of K group kg.  Element (lane, e) with i = lane&31,
+//   h = lane>>5, e in 0..7 is W[32*fb + i][ column(kg, h, e) ]:
+//       bf16: [lane][e]             1 KiB per fragment  (one ds_read_b128 per lane)
+//       fp32: [e>>2][lane][e&3]     2 KiB per fragment  (two conflict-free ds_read_b128 per lane)
+//   Fragments are stored in exactly the order the kernels consume them: layer, fb, kg.
+//
+// Slot -> feature maps (why the activations never leave registers):
+//   D map   a layer's MFMA output registers (lane half h, reg r) hold feature (r&3) + 8*(r>>2) + 4*h of
+//           each 32-row block; read back as B operand of the next layer they are K slot
+//           (kg, h, e) = feature 16*kg + 8*(e>>2) + 4*h + (e&3).
+//   PE map  encoded inputs are generated in-register; slot q = 8*kg + e:
+//           q < 3L      -> frequency q/3, component q%3; half 0 holds sin, half 1 holds cos
+//           q == 3L     -> half 0: x, half 1: z      q == 3L+1 -> half 0: y, half 1: (zero pad)
+//           reference column order (nerf_helper.py:38-48 + cat_origin): [x y z | sin f0 xyz | cos f0 xyz | ...]
+#pragma once
+#include "../../include/nerf_amd.h"
+
+#define MLP_CHUNK_BYTES 16384
+#define MLP_NSLOT 4
+#define MLP_RING_BYTES (MLP_CHUNK_BYTES * MLP_NSLOT)
+#define MLP_NW_BF16 8
+#define MLP_NW_F32 4
+
+#if defined(__HIPCC__)
+#define LAYOUT_HD __host__ __device__
+#else
+#define LAYOUT_HD
+#endif
+
+// column of the reference weight matrix that PE slot (q, h) multiplies, or -1 for zero padding
+LAYOUT_HD inline int pe_slot_column(int q, int h, int L) {
+    if (q < 3 * L) return 3 + 6 * (q / 3) + 3 * h + (q % 3);
+    if (q == 3 * L) return h ? 2 : 0;
+    if (q == 3 * L + 1) return h ? -1 : 1;
+    return -1;
+}
+LAYOUT_HD inline int dmap_feature(int kg, int h, int e) { return 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3); }
+
+struct PropLayout {
+    static constexpr int N_LAYERS = 5;
+    static constexpr int NKG[5] = {4, 16, 16, 16, 16};
+    static constexpr int NFB[5] = {8, 8, 8, 8, 1};
+    static constexpr int START[5] = {0, 32, 160, 288, 416};
+    static constexpr int BIAS_OFF[5] = {0, 256, 512, 768, 1024};
+    static constexpr int N_FRAGS = 432;
+    static constexpr int N_BIAS = 1056;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4; }
+};
+
+struct MipLayout {
+    static constexpr int N_LAYERS = 10;
+    //                             l1.0 l1.2 l1.4 l1.6 l2.0 l2.2 l2.4 bn+op rgb0 rgb2
+    static constexpr int NKG[10] = {4, 16, 16, 16, 20, 16, 16, 16, 18, 8};
+    static constexpr int NFB[10] = {8, 8, 8, 8, 8, 8, 8, 9, 4, 1};
+    static constexpr int START[10] = {0, 32, 160, 288, 416, 576, 704, 832, 976, 1048};
+    static constexpr int BIAS_OFF[10] = {0, 256, 512, 768, 1024, 1280, 1536, 1792, 2080, 2208};
+    static constexpr int N_FRAGS = 1056;
+    static constexpr int N_BIAS = 2240;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4; }
+};

@@ -1,0 +1,107 @@
+// Weight packing: nn.Linear tensors ((out,in) row-major fp32, reference state_dict order) -> the
+// MFMA-fragment-ordered stream + bias table consumed by mlp_kernels.hip (layout: mlp_layout.h).
+// Runs on the GPU (a few microseconds) so it can be repeated after every optimiser step.
+#include "device_common.h"
+#include "mlp_layout.h"
+
+namespace {
+
+enum { SEG_DMAP = 0, SEG_PE = 1 };
+
+struct PackLayer {
+    const float* w[2];      // up to two row segments (e.g. bottle_neck rows 0..255, opacity_head row 256)
+    const float* b[2];
+    int rows[2];
+    int in_features;        // row stride of both matrices
+    int nkg, nfb;
+    int frag_start, bias_off;
+    int seg_kind[2], seg_nkg[2], seg_col[2], seg_L[2], seg_width[2];
+};
+
+template <bool BF16>
+__global__ void pack_layer_kernel(PackLayer L, char* __restrict__ stream, float* __restrict__ bias) {
+    const int n_elem = L.nfb * L.nkg * 512;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_elem; i += gridDim.x * blockDim.x) {
+        const int e = i & 7, lane = (i >> 3) & 63, frag = i >> 9;
+        const int fb = frag / L.nkg, kg = frag - fb * L.nkg;
+        const int row = 32 * fb + (lane & 31), h = lane >> 5;
+        int seg = 0, lkg = kg;
+        if (kg >= L.seg_nkg[0]) { seg = 1; lkg = kg - L.seg_nkg[0]; }
+        int col = (L.seg_kind[seg] == SEG_PE) ? pe_slot_column(8 * lkg + e, h, L.seg_L[seg]) : dmap_feature(lkg, h, e);
+        if (col >= L.seg_width[seg]) col = -1;
+        float v = 0.0f;
+        if (col >= 0) {
+            col += L.seg_col[seg];
+            if (row < L.rows[0]) v = L.w[0][(size_t)row * L.in_features + col];
+            else if (row < L.rows[0] + L.rows[1]) v = L.w[1][(size_t)(row - L.rows[0]) * L.in_features + col];
+        }
+        const size_t f = (size_t)(L.frag_start + frag);
+        if (BF16) reinterpret_cast<__bf16*>(stream + f * 1024)[lane * 8 + e] = (__bf16)v;
+        else reinterpret_cast<float*>(stream + f * 2048)[(e >> 2) * 256 + lane * 4 + (e & 3)] = v;
+    }
+    const int n_b = 32 * L.nfb;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (i < L.rows[0]) v = L.b[0][i];
+        else if (i < L.rows[0] + L.rows[1]) v = L.b[1][i - L.rows[0]];
+        bias[L.bias_off + i] = v;
+    }
+}
+
+PackLayer make_layer(const float* w, const float* b, int rows, int in_f, int nkg, int nfb, int start, int bias_off) {
+    PackLayer L{};
+    L.w[0] = w; L.b[0] = b; L.rows[0] = rows; L.w[1] = nullptr; L.b[1] = nullptr; L.rows[1] = 0;
+    L.in_features = in_f; L.nkg = nkg; L.nfb = nfb; L.frag_start = start; L.bias_off = bias_off;
+    L.seg_kind[0] = SEG_DMAP; L.seg_nkg[0] = nkg; L.seg_col[0] = 0; L.seg_L[0] = 0; L.seg_width[0] = 16 * nkg;
+    L.seg_kind[1] = SEG_DMAP; L.seg_nkg[1] = 0; L.seg_col[1] = 0; L.seg_L[1] = 0; L.seg_width[1] = 0;
+    return L;
+}
+void set_seg(PackLayer& L, int s, int kind, int nkg, int col, int pe_L, int width) {
+    L.seg_kind[s] = kind; L.seg_nkg[s] = nkg; L.seg_col[s] = col; L.seg_L[s] = pe_L; L.seg_width[s] = width;
+}
+
+int launch_pack(const PackLayer& L, int precision, char* stream, float* bias, hipStream_t st) {
+    const int n = L.nfb * L.nkg * 512;
+    const int blocks = (n + 255) / 256;
+    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL(pack_layer_kernel<true>, dim3(blocks), dim3(256), 0, st, L, stream, bias);
+    else hipLaunchKernelGGL(pack_layer_kernel<false>, dim3(blocks), dim3(256), 0, st, L, stream, bias);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int pack_proposal(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
+    using Lay = PropLayout;
+    char* stream = reinterpret_cast<char*>(packed);
+    float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    const int rows[5] = {256, 256, 256, 256, 1};
+    const int inf[5] = {63, 256, 256, 256, 256};
+    for (int l = 0; l < 5; ++l) {
+        PackLayer L = make_layer(w[l], b[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
+        int e = launch_pack(L, precision, stream, bias, st);
+        if (e) return e;
+    }
+    return 0;
+}
+
+int pack_mip(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
+    using Lay = MipLayout;
+    char* stream = reinterpret_cast<char*>(packed);
+    float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    // tensors: 0..3 lin_block1.{0,2,4,6}; 4..6 lin_block2.{0,2,4}; 7 bottle_neck.0; 8 opacity_head.0; 9,10 rgb_layer.{0,2}
+    const int tensor_of[10] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 10};
+    const int rows[10] = {256, 256, 256, 256, 256, 256, 256, 256, 128, 3};
+    const int inf[10] = {63, 256, 256, 256, 319, 256, 256, 256, 283, 128};
+    for (int l = 0; l < 10; ++l) {
+        const int t = tensor_of[l];
+        PackLayer L = make_layer(w[t], b[t], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
+        if (l == 4) { set_seg(L, 0, SEG_PE, 4, 0, 10, 63); set_seg(L, 1, SEG_DMAP, 16, 63, 0, 256); }
+        if (l == 7) { L.w[1] = w[8]; L.b[1] = b[8]; L.rows[1] = 1; }
+        if (l == 8) { set_seg(L, 0, SEG_DMAP, 16, 0, 0, 256); set_seg(L, 1, SEG_PE, 2, 256, 4, 27); }
+        int e = launch_pack(L, precision, stream, bias, st);
+        if (e) return e;
+    }
+    return 0;
+}

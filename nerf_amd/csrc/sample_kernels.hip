@@ -1,0 +1,447 @@
+// Sampling / compositing kernels: one 64-lane wavefront per
+// ray, samples across lanes, wave-level prefix scans for transmittance and CDF.  All HBM-bound.
+//
+// Numerics follow the reference's CPU torch kernels so that results agree to ~1 ulp:
+//   * cumprod / cumsum accumulate float inputs in fp64 and round every prefix to fp32;
+//   * position and depth arithmetic is separate mul + add (the file is built with -ffp-contract=off);
+//   * searchsorted(right=True) = number of CDF entries <= u.
+#include "device_common.h"
+#include "../../include/nerf_amd.h"
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+DEVINL int wave_in_block() { return (int)(threadIdx.x >> 6); }
+
+// ---------------------------------------------------------------------------------------- row 3
+__global__ void pe_kernel(const float* __restrict__ x, int64_t total, int L, float* __restrict__ out) {
+    const int width = 6 * L;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / width;
+        const int k = (int)(i - m * width);
+        const int f = k / 6, t = (k % 6) / 3, c = k % 3;
+        out[i] = sin_quadrant(x[m * 3 + c] * (float)(1 << f), t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- row 1
+struct Cam { int H, W; float fx, fy; float pose[12]; };
+
+__global__ void raygen_kernel(Cam cam, int64_t first, int64_t count, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = first + i;
+        float* rays = out - first * 6;
+        const int row = (int)(n / cam.W), col = (int)(n - (int64_t)row * cam.W);
+        const float cx = (((float)col - (float)cam.W * 0.5f) + 0.5f) / cam.fx;
+        const float cy = (((float)cam.H * 0.5f - (float)row) + 0.5f) / cam.fy;
+        float* r = rays + n * 6;
+        r[0] = cam.pose[3]; r[1] = cam.pose[7]; r[2] = cam.pose[11];
+        r[3] = (cx * cam.pose[0] + cy * cam.pose[1]) + (-1.0f) * cam.pose[2];
+        r[4] = (cx * cam.pose[4] + cy * cam.pose[5]) + (-1.0f) * cam.pose[6];
+        r[5] = (cx * cam.pose[8] + cy * cam.pose[9]) + (-1.0f) * cam.pose[10];
+    }
+}
+
+// training twin of row 1 (utils.py:78-85): integer (col - W//2, H//2 - row) coords -> rays
+__global__ void pixel_rays_kernel(Cam cam, const int64_t* __restrict__ coords, int64_t N, float* __restrict__ rays) {
+    for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const float cx = ((float)coords[n * 2] + 0.5f) / cam.fx;
+        const float cy = ((float)coords[n * 2 + 1] + 0.5f) / cam.fy;
+        float* r = rays + n * 6;
+        r[0] = cam.pose[3]; r[1] = cam.pose[7]; r[2] = cam.pose[11];
+        r[3] = (cx * cam.pose[0] + cy * cam.pose[1]) + (-1.0f) * cam.pose[2];
+        r[4] = (cx * cam.pose[4] + cy * cam.pose[5]) + (-1.0f) * cam.pose[6];
+        r[5] = (cx * cam.pose[8] + cy * cam.pose[9]) + (-1.0f) * cam.pose[10];
+    }
+}
+
+// row 2 (utils.py:87-90 / procedures.py:65-66): z = z_base + u*jitter ; pts = o + d*z
+__global__ void stratified_points_kernel(const float* __restrict__ rays, const float* __restrict__ z_base,
+                                         const float* __restrict__ u, float jitter, int64_t N, int S,
+                                         float* __restrict__ z_out, float* __restrict__ pts) {
+    const int64_t total = N * S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / S;
+        const int s = (int)(i - n * S);
+        const float zv = z_base[s] + u[i] * jitter;
+        z_out[i] = zv;
+        if (pts) {
+            const float* r = rays + n * 6;
+            pts[i * 3] = r[0] + r[3] * zv; pts[i * 3 + 1] = r[1] + r[4] * zv; pts[i * 3 + 2] = r[2] + r[5] * zv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- row 8
+__global__ void length2pts_kernel(const float* __restrict__ rays, const float* __restrict__ z, int64_t N, int S,
+                                  float* __restrict__ out) {
+    const int64_t total = N * S * 6;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ns = i / 6;
+        const int k = (int)(i - ns * 6);
+        const int64_t n = ns / S;
+        const float* r = rays + n * 6;
+        out[i] = (k < 3) ? (r[k] + r[3 + k] * z[ns]) : r[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sigma -> weights for one ray handled by one wavefront (rows 5 / 10).
+//   sig(s), zn(s): loaders for sample s (zn already scaled by |d| when required)
+//   emit(s, w, zn_s): called by the lane that owns sample s
+// ------------------------------------------------------------------------------------------------
+template <class SigF, class ZF, class EmitF>
+DEVINL void wave_sigma_to_weights(int S, int act, SigF&& sig, ZF&& zn, EmitF&& emit) {
+    const int lane = lane_id();
+    double carry = 1.0;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool ok = s < S;
+        float w = 0.0f, z0 = 0.0f;
+        double p = 1.0;
+        if (ok) {
+            z0 = zn(s);
+            const float delta = (s + 1 < S) ? (zn(s + 1) - z0) : 1e10f;
+            const float m = expf(-density_act(sig(s), act) * delta);
+            w = 1.0f - m;                                    // alpha
+            p = (double)(m + 1e-10f);
+        }
+        const double incl = wave_incl_scan_mul(p);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        const float T = (float)(carry * excl);
+        carry *= __shfl(incl, 63, 64);
+        if (ok) emit(s, w * T, z0);
+    }
+}
+
+__global__ __launch_bounds__(256) void sigma_to_weights_kernel(const float* __restrict__ sigma, const float* __restrict__ z,
+                                                              const float* __restrict__ dirs, int64_t N, int S, int act,
+                                                              float* __restrict__ w) {
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        float nrm = 1.0f;
+        const bool scale = dirs != nullptr;
+        if (scale) nrm = norm3(dirs[n * 3], dirs[n * 3 + 1], dirs[n * 3 + 2]);
+        const float* sg = sigma + n * S;
+        const float* zz = z + n * S;
+        float* wo = w + n * S;
+        wave_sigma_to_weights(S, act, [&](int s) { return sg[s]; },
+                              [&](int s) { return scale ? zz[s] * nrm : zz[s]; },
+                              [&](int s, float wv, float) { wo[s] = wv; });
+    }
+}
+
+// ---------------------------------------------------------------------------------------- row 6
+__global__ void max_blur_kernel(const float* __restrict__ w, int64_t N, int S, float alpha, float* __restrict__ out) {
+    const int64_t total = N * S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % S);
+        const float c = w[i];
+        const float front = (s == 0) ? c : fmaxf(w[i - 1], c);
+        const float rear = (s == S - 1) ? c : fmaxf(c, w[i + 1]);
+        out[i] = 0.5f * (front + rear) + alpha;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse-transform sampling for one ray by one wavefront (row 7, utils.py:108-133).
+//   pw[nw]   raw pdf weights (1e-5 is added here), bins[nw+1] bin edges -- both in LDS, visible to the wave
+//   cdf[nw+1], samp[K], bel[K]: LDS scratch
+// ------------------------------------------------------------------------------------------------
+DEVINL void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, float* cdf, float* samp, int* bel,
+                                const float* __restrict__ u, int K, int sort, float* __restrict__ z_out,
+                                int64_t* __restrict__ below_out, int64_t* __restrict__ above_out) {
+    const int lane = lane_id();
+    const int nb = nw + 1;           // bins == cdf entries incl. the leading 0
+    float part = 0.0f;               // pdf normaliser
+    for (int j = lane; j < nw; j += 64) part += pw[j] + 1e-5f;
+    const float total = wave_sum(part);
+    // cdf: fp64 running sum of fp32 pdf values, rounded per element (torch CPU cumsum)
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.0f;
+    for (int base = 0; base < nw; base += 64) {
+        const int j = base + lane;
+        double p = 0.0;
+        if (j < nw) p = (double)((pw[j] + 1e-5f) / total);
+        const double incl = wave_incl_scan_add(p);
+        if (j < nw) cdf[1 + j] = (float)(carry + incl);
+        carry += __shfl(incl, 63, 64);
+    }
+    lds_wave_sync();
+    for (int k = lane; k < K; k += 64) {
+        const float uu = u[k];
+        int lo = 0, hi = nb;                         // searchsorted(right=True): count of entries <= uu
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < nb - 1 ? lo : nb - 1;
+        const float c0 = cdf[below], c1 = cdf[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (uu - c0) / denom;
+        const float b0 = bins[below], b1 = bins[above];
+        const float v = b0 + t * (b1 - b0);
+        if (sort) { samp[k] = v; bel[k] = below; }
+        else {
+            z_out[k] = v;
+            if (below_out) below_out[k] = below;
+            if (above_out) above_out[k] = above;
+        }
+    }
+    if (!sort) return;
+    lds_wave_sync();
+    // stable rank sort: K is small (<= ~1e3); every lane ranks its own elements against all (LDS broadcast reads)
+    for (int k = lane; k < K; k += 64) {
+        const float v = samp[k];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) {
+            const float o = samp[j];
+            rank += (o < v || (o == v && j < k)) ? 1 : 0;
+        }
+        z_out[rank] = v;
+        if (below_out) below_out[rank] = bel[k];
+    }
+}
+
+// LDS floats per wave: pw[C] bins[C] cdf[C] samp[K] bel[K]
+DEVINL size_t inv_lds_floats(int C, int K) { return (size_t)3 * C + 2 * K; }
+
+// mode 0: inverseSample(weights (N,C), depths (N,C)) -> bins = mid-points, pdf = weights[1:-1]   (utils.py:34-44)
+// mode 1: sample_pdf(bins (N,C), weights (N,C-1))                                               (utils.py:108-133)
+__global__ __launch_bounds__(256) void inverse_sample_kernel(const float* __restrict__ w, const float* __restrict__ z,
+                                                            const float* __restrict__ u, int64_t N, int C, int K, int sort,
+                                                            int mode, float* __restrict__ z_out, int64_t* __restrict__ below,
+                                                            int64_t* __restrict__ above) {
+    float* base = reinterpret_cast<float*>(smem) + wave_in_block() * inv_lds_floats(C, K);
+    float* pw = base; float* bins = pw + C; float* cdf = bins + C; float* samp = cdf + C;
+    int* bel = reinterpret_cast<int*>(samp + K);
+    const int lane = lane_id();
+    const int nw = mode == 0 ? C - 2 : C - 1;
+    const int wstride = mode == 0 ? C : C - 1;
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        if (mode == 0) {
+            for (int j = lane; j < nw; j += 64) pw[j] = w[n * wstride + 1 + j];
+            for (int j = lane; j < nw + 1; j += 64) bins[j] = 0.5f * (z[n * C + j + 1] + z[n * C + j]);
+        } else {
+            for (int j = lane; j < nw; j += 64) pw[j] = w[n * wstride + j];
+            for (int j = lane; j < nw + 1; j += 64) bins[j] = z[n * C + j];
+        }
+        lds_wave_sync();
+        wave_inverse_sample(pw, bins, nw, cdf, samp, bel, u + n * K, K, sort, z_out + n * K, below ? below + n * K : nullptr,
+                            above ? above + n * K : nullptr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused proposal resampling: density -> weights -> max-blur -> inverse sampling (procedures.py:68-70).
+// ------------------------------------------------------------------------------------------------
+struct ResampleArgs {
+    const float* density; const float* z; const float* z_base; const float* u_strat; float z_jitter;
+    const float* dirs; int dirs_stride; const float* u_inv; int64_t N; int C; int K; int softplus; float alpha;
+    float* z_fine; int64_t* below; float* w_prop; float* z_coarse;
+};
+
+__global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
+    const int C = a.C, K = a.K;
+    // per wave: pw[C] bins[C] cdf[C] samp[K] bel[K] | zl[C] wraw[C]
+    float* base = reinterpret_cast<float*>(smem) + wave_in_block() * (inv_lds_floats(C, K) + 2 * C);
+    float* pw = base; float* bins = pw + C; float* cdf = bins + C; float* samp = cdf + C;
+    int* bel = reinterpret_cast<int*>(samp + K);
+    float* zl = reinterpret_cast<float*>(bel + K);
+    float* wraw = zl + C;
+    const int lane = lane_id();
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        const float* dd = a.dirs + n * a.dirs_stride;
+        const float nrm = norm3(dd[0], dd[1], dd[2]);
+        for (int j = lane; j < C; j += 64) {
+            const float zv = a.z ? a.z[n * C + j] : (a.z_base[j] + a.u_strat[n * C + j] * a.z_jitter);
+            zl[j] = zv;
+            if (a.z_coarse) a.z_coarse[n * C + j] = zv;
+        }
+        lds_wave_sync();
+        const float* sg = a.density + n * C;
+        const int soft = a.softplus;
+        wave_sigma_to_weights(C, NERF_AMD_ACT_RELU,
+                              [&](int s) { const float d = sg[s]; return soft ? softplus_f(d) : d; },
+                              [&](int s) { return zl[s] * nrm; },
+                              [&](int s, float wv, float) { wraw[s] = wv; });
+        lds_wave_sync();
+        for (int j = lane; j < C; j += 64) {                                   // max-blur (mip_methods.py:61-66)
+            const float c = wraw[j];
+            const float front = (j == 0) ? c : fmaxf(wraw[j - 1], c);
+            const float rear = (j == C - 1) ? c : fmaxf(c, wraw[j + 1]);
+            const float wb = 0.5f * (front + rear) + a.alpha;
+            if (j >= 1 && j <= C - 2) pw[j - 1] = wb;                          // pdf over weights[1:-1]
+            if (a.w_prop) a.w_prop[n * C + j] = wb;
+        }
+        for (int j = lane; j < C - 1; j += 64) bins[j] = 0.5f * (zl[j + 1] + zl[j]);   // mid-points of the RAW depths
+        lds_wave_sync();
+        wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, a.u_inv + n * K, K, 1, a.z_fine + n * K,
+                            a.below ? a.below + n * K : nullptr, nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- row 10
+struct CompositeArgs {
+    const float* rgbo; const float* z; int z_stride; const float* dirs; int dirs_stride; int64_t N; int S;
+    int flags; int act; float near, far; const float* normal; const float* cam_dir;
+    float* rgb; float* weights; float* depth; float* normal_img;
+};
+
+__global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
+    const int S = a.S;
+    const int lane = lane_id();
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const float* dd = a.dirs + n * a.dirs_stride;
+        const bool mul = (a.flags & 1) != 0;
+        const float nrm = mul ? norm3(dd[0], dd[1], dd[2]) : 1.0f;
+        const float* zz = a.z + n * a.z_stride;
+        const f32x4* px = reinterpret_cast<const f32x4*>(a.rgbo) + n * S;
+        float accr = 0.0f, accg = 0.0f, accb = 0.0f, accw = 0.0f, accd = 0.0f, accn = 0.0f;
+        float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+        if (a.normal_img) { cx = a.cam_dir[0]; cy = a.cam_dir[1]; cz = a.cam_dir[2]; }
+        float* wout = a.weights ? a.weights + n * S : nullptr;
+        const float* nm = a.normal ? a.normal + n * S * 3 : nullptr;
+        wave_sigma_to_weights(S, a.act, [&](int s) { return px[s][3]; },
+                              [&](int s) { return mul ? zz[s] * nrm : zz[s]; },
+                              [&](int s, float w, float zn) {
+                                  const f32x4 c = px[s];
+                                  accr += w * c[0]; accg += w * c[1]; accb += w * c[2];
+                                  accw += w; accd += w * zn;
+                                  if (nm) accn += w * ((nm[s * 3] * cx + nm[s * 3 + 1] * cy) + nm[s * 3 + 2] * cz);
+                                  if (wout) wout[s] = w;
+                              });
+        accr = wave_sum(accr); accg = wave_sum(accg); accb = wave_sum(accb); accw = wave_sum(accw);
+        accd = wave_sum(accd);
+        if (a.normal_img) accn = wave_sum(accn);
+        if (lane == 0) {
+            if (a.flags & 2) { const float bg = 1.0f - accw; accr += bg; accg += bg; accb += bg; }
+            a.rgb[n * 3] = accr; a.rgb[n * 3 + 1] = accg; a.rgb[n * 3 + 2] = accb;
+            if (a.depth) a.depth[n] = (accd - a.near) / (a.far - a.near);
+            if (a.normal_img) a.normal_img[n] = (accn + 1.0f) * 0.5f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- row 11
+__global__ __launch_bounds__(256) void get_bounds_kernel(const float* __restrict__ w, const int64_t* __restrict__ below,
+                                                        int64_t N, int C, int K, float* __restrict__ bounds) {
+    float* sat = reinterpret_cast<float*>(smem) + wave_in_block() * (C + 1);
+    const int lane = lane_id();
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        double carry = 0.0;
+        if (lane == 0) sat[0] = 0.0f;
+        for (int base = 0; base < C; base += 64) {
+            const int j = base + lane;
+            const double p = (j < C) ? (double)w[n * C + j] : 0.0;
+            const double incl = wave_incl_scan_add(p);
+            if (j < C) sat[1 + j] = (float)(carry + incl);
+            carry += __shfl(incl, 63, 64);
+        }
+        lds_wave_sync();
+        const int64_t* bl = below + n * K;
+        for (int k = lane; k < K - 1; k += 64) {
+            const int st = (int)bl[k], en = (int)bl[k + 1] + 1;
+            bounds[n * (K - 1) + k] = sat[en] - sat[st];
+        }
+    }
+}
+
+int blocks_for(int64_t work, int per_block) {
+    int64_t b = (work + per_block - 1) / per_block;
+    const int64_t cap = 256 * 8;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host launchers
+int sk_positional_encoding(const float* x, int64_t M, int L, float* out, hipStream_t st) {
+    const int64_t total = M * 6 * L;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(pe_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, x, total, L, out);
+    return (int)hipGetLastError();
+}
+int sk_generate_rays(const float* pose, int H, int W, float fx, float fy, int64_t first, int64_t count, float* rays,
+                     hipStream_t st) {
+    Cam c; c.H = H; c.W = W; c.fx = fx; c.fy = fy;
+    for (int i = 0; i < 12; ++i) c.pose[i] = pose[i];
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(raygen_kernel, dim3(blocks_for(count, 256)), dim3(256), 0, st, c, first, count, rays);
+    return (int)hipGetLastError();
+}
+int sk_pixel_rays(const float* pose, float fx, float fy, const int64_t* coords, int64_t N, float* rays, hipStream_t st) {
+    Cam c; c.H = 0; c.W = 0; c.fx = fx; c.fy = fy;
+    for (int i = 0; i < 12; ++i) c.pose[i] = pose[i];
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(pixel_rays_kernel, dim3(blocks_for(N, 256)), dim3(256), 0, st, c, coords, N, rays);
+    return (int)hipGetLastError();
+}
+int sk_stratified_points(const float* rays, const float* z_base, const float* u, float jitter, int64_t N, int S, float* z_out,
+                         float* pts, hipStream_t st) {
+    if (N * S == 0) return 0;
+    hipLaunchKernelGGL(stratified_points_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, st, rays, z_base, u, jitter, N, S, z_out, pts);
+    return (int)hipGetLastError();
+}
+int sk_length2pts(const float* rays, const float* z, int64_t N, int S, float* out, hipStream_t st) {
+    if (N * S == 0) return 0;
+    hipLaunchKernelGGL(length2pts_kernel, dim3(blocks_for(N * S * 6, 256)), dim3(256), 0, st, rays, z, N, S, out);
+    return (int)hipGetLastError();
+}
+int sk_sigma_to_weights(const float* sigma, const float* z, const float* dirs, int64_t N, int S, int act, float* w, hipStream_t st) {
+    if (N * S == 0) return 0;
+    hipLaunchKernelGGL(sigma_to_weights_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, sigma, z, dirs, N, S, act, w);
+    return (int)hipGetLastError();
+}
+int sk_max_blur(const float* w, int64_t N, int S, float alpha, float* out, hipStream_t st) {
+    if (N * S == 0) return 0;
+    hipLaunchKernelGGL(max_blur_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, st, w, N, S, alpha, out);
+    return (int)hipGetLastError();
+}
+int sk_inverse_sample(const float* w, const float* z, const float* u, int64_t N, int C, int K, int sort, int mode, float* z_out,
+                      int64_t* below, int64_t* above, hipStream_t st) {
+    if (N == 0) return 0;
+    const size_t lds = WAVES_PER_BLOCK * ((size_t)3 * C + 2 * K) * 4;
+    hipLaunchKernelGGL(inverse_sample_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, w, z, u, N, C, K, sort, mode,
+                       z_out, below, above);
+    return (int)hipGetLastError();
+}
+int sk_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
+                const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K, int softplus, float alpha,
+                float* z_fine, int64_t* below, float* w_prop, float* z_coarse, hipStream_t st) {
+    if (N == 0) return 0;
+    ResampleArgs a{density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus, alpha, z_fine, below, w_prop, z_coarse};
+    const size_t lds = WAVES_PER_BLOCK * ((size_t)5 * C + 2 * K) * 4;
+    hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+}
+int sk_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int S, int flags,
+                 int act, float near, float far, const float* normal, const float* cam_dir, float* rgb, float* weights,
+                 float* depth, float* normal_img, hipStream_t st) {
+    if (N == 0) return 0;
+    CompositeArgs a{rgbo, z, z_stride, dirs, dirs_stride, N, S, flags, act, near, far, normal, cam_dir, rgb, weights, depth, normal_img};
+    hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int sk_get_bounds(const float* w, const int64_t* below, int64_t N, int C, int K, float* bounds, hipStream_t st) {
+    if (N == 0 || K < 2) return 0;
+    const size_t lds = WAVES_PER_BLOCK * ((size_t)C + 1) * 4;
+    hipLaunchKernelGGL(get_bounds_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, w, below, N, C, K, bounds);
+    return (int)hipGetLastError();
+}

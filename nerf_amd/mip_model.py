@@ -1,0 +1,54 @@
+"""Host-side mirror of the reference's ``nerf/mip_model.py``.  The module tree (and therefore every
+``state_dict`` key and weight shape) is identical to the reference's, so checkpoints interchange;
+``forward`` runs the fused HIP MLP kernel instead of eleven aten GEMMs."""
+import torch
+from torch import nn
+
+from . import ops
+from ._packed import PackedWeightsMixin, require_no_grad
+from .nerf_base import NeRF
+from .nerf_helper import makeMLP
+
+
+class MipNeRF(NeRF, PackedWeightsMixin):
+    _net_id = ops.NET_MIP
+
+    def __init__(self, position_flevel, direction_flevel, hidden_unit=256, cat_origin=True) -> None:
+        super().__init__(position_flevel, cat_origin)
+        self.direction_flevel = direction_flevel
+        self.hidden_unit = hidden_unit
+        extra = 3 if cat_origin else 0
+        in_dim = 6 * position_flevel + extra
+        block1 = makeMLP(in_dim, hidden_unit)
+        for _ in range(3):
+            block1.extend(makeMLP(hidden_unit, hidden_unit))
+        self.lin_block1 = nn.Sequential(*block1)                                   # before the skip connection
+        self.lin_block2 = nn.Sequential(*makeMLP(hidden_unit + in_dim, hidden_unit), *makeMLP(hidden_unit, hidden_unit),
+                                        *makeMLP(hidden_unit, 256))
+        self.bottle_neck = nn.Sequential(*makeMLP(256, 256, None))
+        self.opacity_head = nn.Sequential(*makeMLP(256, 1, None))
+        self.rgb_layer = nn.Sequential(*makeMLP(280 + extra, 128), *makeMLP(128, 3, nn.Sigmoid()))
+        self.apply(self.init_weight)
+
+    def _linear_layers(self):
+        return [self.lin_block1[0], self.lin_block1[2], self.lin_block1[4], self.lin_block1[6],
+                self.lin_block2[0], self.lin_block2[2], self.lin_block2[4], self.bottle_neck[0], self.opacity_head[0],
+                self.rgb_layer[0], self.rgb_layer[2]]
+
+    def _check_config(self):
+        if not (self.position_flevel == 10 and self.direction_flevel == 4 and self.hidden_unit == 256 and self.cat_origin):
+            raise NotImplementedError("nerf_amd: the HIP fine-MLP kernel is instantiated for MipNeRF(10, 4, 256, cat_origin=True)")
+
+    def forward(self, pts: torch.Tensor) -> torch.Tensor:
+        """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60)."""
+        self._check_config()
+        require_no_grad(pts, *self.parameters())
+        prec = ops.current_precision()
+        return ops.mip_forward(self.packed(prec), prec, pts)
+
+    def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int) -> torch.Tensor:
+        """Same as ``forward(NeRF.length2pts(rays, z[:, :n_samples]))`` without materialising the points."""
+        self._check_config()
+        prec = ops.current_precision()
+        s = ops.samples_rays(rays, n_samples, z=z)
+        return ops.mip_forward_samples(self.packed(prec), prec, s, (rays.shape[0], n_samples), rays.device)

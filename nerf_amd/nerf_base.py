@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference's ``nerf/nerf_base.py``: same class, statics, defaults and return
+arity; the arithmetic runs in the HIP kernels of libnerf_amd.so."""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from ._packed import require_no_grad
+
+
+def _act_code(density_act):
+    """Map the reference's callable ``density_act`` onto a kernel activation code; unknown callables are
+    applied on the device with torch first and the kernel then uses identity."""
+    if density_act in (F.relu, torch.relu):
+        return ops.ACT_RELU, None
+    if density_act is F.softplus:
+        return ops.ACT_SOFTPLUS, None
+    return ops.ACT_IDENTITY, density_act
+
+
+class NeRF(nn.Module):
+    @staticmethod
+    def init_weight(m):
+        """trunc-normal(0.02) weights, zero biases (nerf_base.py:15-22)."""
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm1d):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def __init__(self, position_flevel, cat_origin=True, density_act=F.relu) -> None:
+        super().__init__()
+        self.position_flevel = position_flevel
+        self.cat_origin = cat_origin
+        self.density_act = density_act
+
+    def loadFromFile(self, load_path: str, use_amp=False, opt=None, other_stuff=None):
+        """Checkpoint loader: strips DDP's ``module.`` prefix, restores the optimizer (nerf_base.py:30-50)."""
+        save = torch.load(load_path, map_location="cpu")
+        stripped = {(k[7:] if k.startswith("module") else k): v for k, v in save["model"].items()}
+        own = self.state_dict()
+        own.update({k: stripped[k] for k in own.keys()})
+        self.load_state_dict(own)
+        if opt is not None:
+            opt.load_state_dict(save["optimizer"])
+        if use_amp:
+            from apex import amp
+            amp.load_state_dict(save["amp"])
+        print("NeRF Model loaded from '%s'" % (load_path))
+        if other_stuff is not None:
+            return [save[k] for k in other_stuff]
+
+    @staticmethod
+    def length2pts(rays: torch.Tensor, f_zvals: torch.Tensor) -> torch.Tensor:
+        """(N,S,6) = [o + z d | d]  (nerf_base.py:53-56)."""
+        require_no_grad(rays, f_zvals)
+        return ops.length2pts(rays, f_zvals)
+
+    @staticmethod
+    def coarseFineMerge(rays: torch.Tensor, c_zvals: torch.Tensor, f_zvals: torch.Tensor, f_inds: Optional[torch.Tensor] = None):
+        """cat(fine, coarse) -> sort -> drop last -> points (nerf_base.py:59-73).  The sort/gather are
+        device torch ops (Ref-NeRF path); the points come from the HIP kernel."""
+        z, order = torch.sort(torch.cat((f_zvals, c_zvals), dim=-1), dim=-1)
+        if f_inds is not None:
+            c_inds = torch.arange(c_zvals.shape[-1], device=z.device).unsqueeze(0).expand(c_zvals.shape[0], -1)
+            all_inds = torch.gather(torch.cat((f_inds, c_inds), dim=-1), -1, order)
+        z = z[..., :-1].contiguous()
+        samples = ops.length2pts(rays, z)
+        if f_inds is not None:
+            return samples, z, all_inds, order[..., :-1]
+        return samples, z,
+
+    @staticmethod
+    def getNormedWeight(opacity: torch.Tensor, depth: torch.Tensor, density_act=F.relu) -> torch.Tensor:
+        """alpha_i * prod_{j<i}(1 - alpha_j + 1e-10), delta_last = 1e10 (nerf_base.py:80-86)."""
+        require_no_grad(opacity, depth)
+        code, pre = _act_code(density_act)
+        if pre is not None:
+            opacity = pre(opacity)
+        return ops.sigma_to_weights(opacity, depth, None, code)
+
+    @staticmethod
+    def render(rgbo: torch.Tensor, depth: torch.Tensor, ray_dirs: torch.Tensor, mul_norm: bool = True,
+               white_bkg: bool = False, density_act=F.relu, render_depth: Optional[Tuple[float, float]] = None,
+               normal_info: Optional[Tuple] = None):
+        """Alpha compositing (nerf_base.py:91-113) -> (rgb (N,3), weights (N,S), extras)."""
+        require_no_grad(rgbo, depth, ray_dirs)
+        code, pre = _act_code(density_act)
+        if pre is not None:
+            rgbo = torch.cat((rgbo[..., :3], pre(rgbo[..., 3:])), dim=-1)
+        normal, cam_dir = (normal_info if normal_info is not None else (None, None))
+        rgb, w, d, nimg = ops.composite(rgbo, depth, ray_dirs, mul_norm == True, bool(white_bkg), code, render_depth, normal, cam_dir)
+        extras = dict()
+        if render_depth is not None:
+            extras["depth_img"] = d
+        if normal_info is not None:
+            extras["normal_img"] = nimg
+        return rgb, w, extras
+
+
+class DecayLrScheduler:
+    """Linear warm-up then exponential decay with a floor (nerf_base.py:115-134)."""
+
+    def __init__(self, min_r, decay_r, step, lr, warmup_step=0):
+        self.min_ratio, self.decay_rate, self.decay_step = min_r, decay_r, step
+        self.warmup_step, self.lr = warmup_step, lr
+        if warmup_step > 0:
+            print("Warming up step: %d" % (warmup_step))
+
+    def update_opt_lr(self, train_cnt, opt: torch.optim.Optimizer = None):
+        if train_cnt < self.warmup_step:
+            r = train_cnt / self.warmup_step
+            new_lr = self.lr * (self.min_ratio * (1. - r) + r)
+        else:
+            new_lr = self.lr * max(self.decay_rate ** ((train_cnt - self.warmup_step) / self.decay_step), self.min_ratio)
+        if opt is not None:
+            for group in opt.param_groups:
+                group['lr'] = new_lr
+        return opt, new_lr

@@ -1,0 +1,267 @@
+"""Functional torch-tensor front end of the C-ABI (include/nerf_amd.h).  PyTorch is plumbing here:
+it owns device memory and the HIP stream; every computation below is a hand-written HIP kernel in
+libnerf_amd.so.  CPU tensors are rejected -- there is no fallback path."""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, Samples, F32, BF16, NET_PROPOSAL, NET_MIP, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
+
+_PRECISION_OVERRIDE = None          # None -> follow torch autocast (on: bf16, off: fp32)
+
+
+def set_precision(p: Optional[str]):
+    """'fp32' (exact-fp32 MFMA, parity mode), 'bf16' (bf16 MFMA, fp32 accumulate) or None = follow
+    ``torch.autocast`` like the reference's Linear layers do (train.py:202, procedures.py:150)."""
+    global _PRECISION_OVERRIDE
+    if p not in (None, "fp32", "bf16"):
+        raise ValueError("precision must be None, 'fp32' or 'bf16'")
+    _PRECISION_OVERRIDE = p
+
+
+def current_precision() -> int:
+    if _PRECISION_OVERRIDE is not None:
+        return BF16 if _PRECISION_OVERRIDE == "bf16" else F32
+    return BF16 if torch.is_autocast_enabled() else F32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("nerf_amd: '%s' must live on the HIP device (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------ weights
+def pack_weights(net: int, precision: int, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
+    ws = [_dev(w.detach(), "weight") for w in weights]
+    bs = [_dev(b.detach(), "bias") for b in biases]
+    nbytes = lib.nerf_amd_packed_bytes(net, precision)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=ws[0].device)
+    n = len(ws)
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+    check(lib.nerf_amd_pack_weights(net, precision, wp, bp, n, _ptr(packed), _stream()), "nerf_amd_pack_weights")
+    return packed
+
+
+# ------------------------------------------------------------------------------------------------ MLPs
+def _samples_pts(pts: torch.Tensor, stride: int) -> Samples:
+    s = Samples()
+    s.mode = 0
+    s.M = pts.numel() // stride
+    s.pts = pts.data_ptr()
+    s.pts_stride = stride
+    return s
+
+
+def samples_rays(rays: torch.Tensor, S: int, z: Optional[torch.Tensor] = None, z_base: Optional[torch.Tensor] = None,
+                 u: Optional[torch.Tensor] = None, z_jitter: float = 0.0) -> Samples:
+    s = Samples()
+    s.mode = 1
+    s.S = S
+    s.M = rays.shape[0] * S
+    s.rays = rays.data_ptr()
+    if z is not None:
+        s.z = z.data_ptr()
+        s.z_stride = z.shape[-1]
+    else:
+        s.z_base = z_base.data_ptr()
+        s.u = u.data_ptr()
+        s.z_jitter = z_jitter
+        s.z_stride = S
+    return s
+
+
+def proposal_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor) -> torch.Tensor:
+    """pts (..., 3) -> density (...)   [addtional.py:88-96]"""
+    pts = _dev(pts, "pts")
+    out = torch.empty(pts.shape[:-1], dtype=torch.float32, device=pts.device)
+    s = _samples_pts(pts, 3)
+    check(lib.nerf_amd_proposal_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
+    return out
+
+
+def proposal_forward_samples(packed, precision, s: Samples, shape, device) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib.nerf_amd_proposal_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
+    return out
+
+
+def mip_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor) -> torch.Tensor:
+    """pts (..., 6) -> rgbo (..., 4)   [mip_model.py:41-60]"""
+    pts = _dev(pts, "pts")
+    out = torch.empty(pts.shape[:-1] + (4,), dtype=torch.float32, device=pts.device)
+    s = _samples_pts(pts, 6)
+    check(lib.nerf_amd_mip_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
+    return out
+
+
+def mip_forward_samples(packed, precision, s: Samples, shape, device) -> torch.Tensor:
+    out = torch.empty(tuple(shape) + (4,), dtype=torch.float32, device=device)
+    check(lib.nerf_amd_mip_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ sampling ops
+def positional_encoding(x: torch.Tensor, L: int) -> torch.Tensor:
+    x = _dev(x, "x")
+    out = torch.empty(x.shape[:-1] + (6 * L,), dtype=torch.float32, device=x.device)
+    check(lib.nerf_amd_positional_encoding(_ptr(x), x.numel() // 3, L, _ptr(out), _stream()), "nerf_amd_positional_encoding")
+    return out
+
+
+def generate_rays(pose: torch.Tensor, H: int, W: int, fx: float, fy: float, device, ray_offset: int = 0,
+                  n: Optional[int] = None) -> torch.Tensor:
+    n = H * W - ray_offset if n is None else n
+    host = (C.c_float * 12)(*pose.detach().float().cpu().reshape(-1).tolist()[:12])
+    rays = torch.empty((n, 6), dtype=torch.float32, device=device)
+    check(lib.nerf_amd_generate_rays(host, H, W, float(fx), float(fy), ray_offset, n, _ptr(rays), _stream()), "nerf_amd_generate_rays")
+    return rays
+
+
+def length2pts(rays: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    rays, z = _dev(rays, "rays"), _dev(z, "z")
+    N, S = z.shape
+    out = torch.empty((N, S, 6), dtype=torch.float32, device=z.device)
+    check(lib.nerf_amd_length2pts(_ptr(rays), _ptr(z), N, S, _ptr(out), _stream()), "nerf_amd_length2pts")
+    return out
+
+
+def sigma_to_weights(sigma: torch.Tensor, z: torch.Tensor, dirs: Optional[torch.Tensor], act: int = ACT_RELU) -> torch.Tensor:
+    sigma, z = _dev(sigma, "sigma"), _dev(z, "z")
+    dirs = None if dirs is None else _dev(dirs, "dirs")
+    N, S = z.shape
+    w = torch.empty((N, S), dtype=torch.float32, device=z.device)
+    check(lib.nerf_amd_sigma_to_weights(_ptr(sigma), _ptr(z), _ptr(dirs), N, S, act, _ptr(w), _stream()), "nerf_amd_sigma_to_weights")
+    return w
+
+
+def max_blur(w: torch.Tensor, alpha: float) -> torch.Tensor:
+    w = _dev(w, "weights")
+    S = w.shape[-1]
+    out = torch.empty_like(w)
+    check(lib.nerf_amd_max_blur(_ptr(w), w.numel() // S, S, float(alpha), _ptr(out), _stream()), "nerf_amd_max_blur")
+    return out
+
+
+def inverse_sample(w: torch.Tensor, z: torch.Tensor, u: torch.Tensor, sort: bool, want_below: bool = True):
+    w, z, u = _dev(w, "weights"), _dev(z, "z"), _dev(u, "u")
+    N, Cn = z.shape
+    K = u.shape[-1]
+    z_out = torch.empty((N, K), dtype=torch.float32, device=z.device)
+    below = torch.empty((N, K), dtype=torch.int64, device=z.device) if want_below else None
+    check(lib.nerf_amd_inverse_sample(_ptr(w), _ptr(z), _ptr(u), N, Cn, K, int(sort), _ptr(z_out), _ptr(below), _stream()),
+          "nerf_amd_inverse_sample")
+    return z_out, below
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, u: torch.Tensor):
+    bins, weights, u = _dev(bins, "bins"), _dev(weights, "weights"), _dev(u, "u")
+    N, B = bins.shape
+    K = u.shape[-1]
+    out = torch.empty((N, K), dtype=torch.float32, device=bins.device)
+    below = torch.empty((N, K), dtype=torch.int64, device=bins.device)
+    above = torch.empty((N, K), dtype=torch.int64, device=bins.device)
+    check(lib.nerf_amd_sample_pdf(_ptr(bins), _ptr(weights), _ptr(u), N, B, K, _ptr(out), _ptr(below), _ptr(above), _stream()),
+          "nerf_amd_sample_pdf")
+    return out, below, above
+
+
+def pixel_rays(coords: torch.Tensor, pose: torch.Tensor, fx: float, fy: float) -> torch.Tensor:
+    if not coords.is_cuda:
+        raise RuntimeError("nerf_amd: 'coords' must live on the HIP device")
+    coords = coords.to(torch.int64).contiguous()
+    host = (C.c_float * 12)(*pose.detach().float().cpu().reshape(-1).tolist()[:12])
+    rays = torch.empty((coords.shape[0], 6), dtype=torch.float32, device=coords.device)
+    check(lib.nerf_amd_pixel_rays(host, float(fx), float(fy), _ptr(coords), coords.shape[0], _ptr(rays), _stream()), "nerf_amd_pixel_rays")
+    return rays
+
+
+def stratified_points(rays: torch.Tensor, z_base: torch.Tensor, u: torch.Tensor, jitter: float, want_pts: bool = True):
+    rays, z_base, u = _dev(rays, "rays"), _dev(z_base, "z_base"), _dev(u, "u")
+    N, S = u.shape
+    z = torch.empty((N, S), dtype=torch.float32, device=u.device)
+    pts = torch.empty((N, S, 3), dtype=torch.float32, device=u.device) if want_pts else None
+    check(lib.nerf_amd_stratified_points(_ptr(rays), _ptr(z_base), _ptr(u), float(jitter), N, S, _ptr(z), _ptr(pts), _stream()),
+          "nerf_amd_stratified_points")
+    return z, pts
+
+
+def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm: bool, white_bkg: bool, act: int,
+              near_far=None, normal: Optional[torch.Tensor] = None, cam_dir: Optional[torch.Tensor] = None,
+              want_weights: bool = True):
+    rgbo, z, dirs = _dev(rgbo, "rgbo"), _dev(z, "depth"), _dev(dirs, "ray_dirs")
+    N, S = rgbo.shape[0], rgbo.shape[1]
+    dev = rgbo.device
+    rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    w = torch.empty((N, S), dtype=torch.float32, device=dev) if want_weights else None
+    depth = torch.empty((N,), dtype=torch.float32, device=dev) if near_far is not None else None
+    nimg = None
+    if normal is not None:
+        normal, cam_dir = _dev(normal, "normal"), _dev(cam_dir.reshape(-1), "cam_dir")
+        nimg = torch.empty((N,), dtype=torch.float32, device=dev)
+    near, far = (near_far if near_far is not None else (0.0, 1.0))
+    flags = (1 if mul_norm else 0) | (2 if white_bkg else 0)
+    check(lib.nerf_amd_composite(_ptr(rgbo), _ptr(z), z.shape[-1], _ptr(dirs), dirs.shape[-1], N, S, flags, act, float(near),
+                                 float(far), _ptr(normal), _ptr(cam_dir), _ptr(rgb), _ptr(w), _ptr(depth), _ptr(nimg),
+                                 _stream()), "nerf_amd_composite")
+    return rgb, w, depth, nimg
+
+
+def get_bounds(w_prop: torch.Tensor, below: torch.Tensor) -> torch.Tensor:
+    w_prop = _dev(w_prop, "weights")
+    if not below.is_cuda:
+        raise RuntimeError("nerf_amd: 'inds' must live on the HIP device")
+    below = below.to(torch.int64).contiguous()
+    N, Cn = w_prop.shape
+    K = below.shape[-1]
+    out = torch.empty((N, K - 1), dtype=torch.float32, device=w_prop.device)
+    check(lib.nerf_amd_get_bounds(_ptr(w_prop), _ptr(below), N, Cn, K, _ptr(out), _stream()), "nerf_amd_get_bounds")
+    return out
+
+
+def resample(density, z, z_base, u_strat, z_jitter, rays, u_inv, K, softplus=False, alpha=0.01, want_below=False,
+             want_w=False, want_zc=False):
+    """Fused rows 5-7 (procedures.py:68-70 / train.py:169-172).  rays (N,6)."""
+    N, Cn = density.shape
+    dev = density.device
+    z_fine = torch.empty((N, K), dtype=torch.float32, device=dev)
+    below = torch.empty((N, K), dtype=torch.int64, device=dev) if want_below else None
+    w = torch.empty((N, Cn), dtype=torch.float32, device=dev) if want_w else None
+    zc = torch.empty((N, Cn), dtype=torch.float32, device=dev) if want_zc else None
+    dirs_ptr = C.c_void_p(rays.data_ptr() + 12)
+    check(lib.nerf_amd_resample(_ptr(density), _ptr(z), _ptr(z_base), _ptr(u_strat), float(z_jitter), dirs_ptr, 6, _ptr(u_inv),
+                                N, Cn, K, int(softplus), float(alpha), _ptr(z_fine), _ptr(below), _ptr(w), _ptr(zc), _stream()),
+          "nerf_amd_resample")
+    return z_fine, below, w, zc
+
+
+def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
+                want_depth=True, want_weights=False, workspace: Optional[torch.Tensor] = None, camera: Optional[Samples] = None,
+                ray_offset: int = 0, n_rays: Optional[int] = None):
+    """The tile body of render_image (procedures.py:64-85) for all given rays in four launches."""
+    dev = u_strat.device
+    N = u_strat.shape[0] if n_rays is None else n_rays
+    need = lib.nerf_amd_render_workspace_bytes(N, n_fine)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
+    w = torch.empty((N, n_fine), dtype=torch.float32, device=dev) if want_weights else None
+    check(lib.nerf_amd_render_rays(_ptr(packed_prop), _ptr(packed_mip), precision, _ptr(rays),
+                                   C.byref(camera) if camera is not None else None, ray_offset, _ptr(z_base), _ptr(u_strat),
+                                   _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(rgb), _ptr(depth),
+                                   _ptr(w), _ptr(workspace), _stream()), "nerf_amd_render_rays")
+    return rgb, depth, w, workspace

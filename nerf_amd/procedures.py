@@ -1,0 +1,127 @@
+"""Host-side mirror of the reference's ``nerf/procedures.py``: ``render_image`` with the reference's
+signature, tile order, RNG protocol and return dict -- but the whole image goes through the HIP
+pipeline in four launches instead of a Python loop over 2500-ray tiles."""
+import argparse
+from collections.abc import Iterable
+
+import torch
+
+from . import ops
+from .addtional import ProposalNetwork
+from .nerf_base import NeRF
+
+POSSIBLE_PATCH_SIZE = [50, 40, 60, 30]
+RENDER_COARSE_PNUM = 64
+
+
+def get_patch_size(image_size):
+    """First patch size in (50,40,60,30) that divides the width (procedures.py:24-31); None when there is
+    none (the reference raises UnboundLocalError there; this build then renders the image un-tiled)."""
+    for p in POSSIBLE_PATCH_SIZE:
+        if image_size[1] % p == 0:
+            return p, (image_size[0] // p, image_size[1] // p)
+    return None, None
+
+
+def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
+    """Uniforms for every ray, in TILE order when tiling applies.
+    rng='reference': per tile one (sz,sz,64) draw then one (sz*sz, sample_num+1) draw from the CPU default
+    generator -- exactly the reference's order (procedures.py:65, utils.py:115), so a seeded run reproduces it;
+    rng='device': two draws on the device generator (fast path, used by bench.py)."""
+    if rng == "device":
+        n = (patch_num[0] * patch_num[1] * sz * sz) if sz else H * W
+        return (torch.rand((n, RENDER_COARSE_PNUM), device=device), torch.rand((n, sample_num + 1), device=device))
+    if sz is None:
+        return torch.rand((H * W, RENDER_COARSE_PNUM)).to(device), torch.rand((H * W, sample_num + 1)).to(device)
+    n_tiles = patch_num[0] * patch_num[1]
+    u1 = torch.empty((n_tiles, sz * sz, RENDER_COARSE_PNUM))
+    u2 = torch.empty((n_tiles, sz * sz, sample_num + 1))
+    for t in range(n_tiles):
+        u1[t] = torch.rand((sz, sz, RENDER_COARSE_PNUM)).view(-1, RENDER_COARSE_PNUM)
+        u2[t] = torch.rand((sz * sz, sample_num + 1))
+    return u1.view(-1, RENDER_COARSE_PNUM).to(device), u2.view(-1, sample_num + 1).to(device)
+
+
+def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
+                 near: float, far: float, sample_num: int = 128, white_bkg: bool = False, render_depth=False,
+                 render_normal=False, rng: str = "reference") -> dict:
+    """Whole-image inference (procedures.py:34-97) -> {"rgb" (3,H,W) [, "depth_img" (3,H,W)]} on
+    ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference."""
+    if not isinstance(image_size, Iterable):
+        image_size = (image_size, image_size)
+    if type(network).__name__ == "RefNeRF":
+        raise NotImplementedError("nerf_amd: the Ref-NeRF render path is not built yet (SURVEY.md section 8a row 13)")
+    H, W = int(image_size[0]), int(image_size[1])
+    dev = render_pose.device
+    if dev.type != "cuda":
+        raise RuntimeError("nerf_amd.render_image: render_pose must live on the HIP device; there is no CPU path")
+    if isinstance(focal, Iterable):
+        fx, fy = float(focal[1]), float(focal[0])                                  # procedures.py:45-47
+    else:
+        fx = fy = float(focal)
+    network._check_config()
+    prop_net._check_config()
+    prec = ops.current_precision()
+    rays = ops.generate_rays(render_pose[:3], H, W, fx, fy, dev)                   # (H*W, 6), raster order
+    sz, patch_num = get_patch_size((H, W))
+    if sz is not None:                                                             # reorder rays tile by tile
+        pr, pc = patch_num
+        rays = rays.view(H, W, 6)[: pr * sz].reshape(pr, sz, pc, sz, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
+    u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
+    z_base = torch.linspace(near, far, RENDER_COARSE_PNUM, device="cpu").to(dev)   # procedures.py:52 (CPU linspace bits)
+    rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
+                                       sample_num, near, far, white_bkg, want_depth=bool(render_depth))
+
+    def to_image(t, ch):
+        if sz is None:
+            return t.view(H, W, ch).permute(2, 0, 1).contiguous()
+        pr, pc = patch_num
+        img = torch.zeros((ch, H, W), dtype=torch.float32, device=dev)
+        img[:, : pr * sz] = t.view(pr, pc, sz, sz, ch).permute(4, 0, 2, 1, 3).reshape(ch, pr * sz, pc * sz)
+        return img
+
+    result = dict()
+    result["rgb"] = to_image(rgb, 3)
+    if render_depth:
+        result["depth_img"] = to_image(depth.unsqueeze(-1), 1).expand(3, -1, -1).contiguous()   # procedures.py:88
+    return result
+
+
+def get_parser():
+    """The reference's flag set (procedures.py:166-213) so that its entry scripts parse unchanged."""
+    p = argparse.ArgumentParser()
+    for name, typ, default, hlp in (
+        ("--epochs", int, 2400, "Training lasts for . epochs"), ("--max_save", int, 3, "Check point max save number"),
+        ("--sample_ray_num", int, 1024, "<x> rays to sample per training time"),
+        ("--coarse_sample_pnum", int, 64, "Points to sample in coarse net"),
+        ("--fine_sample_pnum", int, 128, "Points to sample in fine net"),
+        ("--eval_time", int, 5, "Tensorboard output interval (train time)"),
+        ("--output_time", int, 20, "Image output interval (train time)"),
+        ("--center_crop_iter", int, 0, "Produce center"), ("--prop_net_width", int, 256, "Width of proposal network"),
+        ("--nerf_net_width", int, 256, "Width of nerf network"), ("--near", float, 2., "Nearest sample depth"),
+        ("--far", float, 6., "Farthest sample depth"), ("--center_crop_x", float, 0.5, "Center crop x axis ratio"),
+        ("--center_crop_y", float, 0.5, "Center crop y axis ratio"), ("--name", str, "model_1", "Model name for loading"),
+        ("--dataset_name", str, "lego", "Input dataset name in nerf synthetic dataset"),
+        ("--img_scale", float, 0.5, "Scale of the image"), ("--scene_scale", float, 1.0, "Scale of the scene"),
+        ("--grad_clip", float, -0.01, "Gradient clipping parameter (Negative number means no clipping)"),
+        ("--pe_period_scale", float, 0.5, "Scale of positional encoding"),
+        ("--opt_mode", str, "O1", "Optimization mode: none, native (torch amp), O1, O2 (apex amp)"),
+        ("--min_ratio", float, 0.01, "Minimum for now_lr / lr"), ("--decay_rate", float, 0.1, "After <decay step>, lr = lr * <decay_rate>"),
+        ("--decay_step", int, 100000, "After <decay step>, lr = lr * <decay_rate>"),
+        ("--warmup_step", int, 500, "Warm up step (from lowest lr to starting lr)"), ("--lr", float, 1.5e-4, "Start lr"),
+        ("--ide_level", int, 4, "Max level of spherical harmonics to be used"),
+        ("--bottle_neck_noise", float, 0.02, "Noise std for perturbing bottle_neck vector"),
+    ):
+        p.add_argument(name, type=typ, default=default, help=hlp)
+    for short, long_, hlp in (
+        ("-d", "--del_dir", "Delete dir ./logs and start new tensorboard records"), ("-l", "--load", "Load checkpoint or trained model."),
+        ("-s", "--use_scaler", "Use AMP scaler to speed up"), ("-b", "--debug", "Code debugging (detect gradient anomaly and NaNs)"),
+        ("-v", "--visualize", "Visualize proposal network"), ("-r", "--do_render", "Only render the result"),
+        ("-w", "--white_bkg", "Output white background"), ("-t", "--ref_nerf", "Test Ref NeRF"),
+        ("-u", "--use_srgb", "Whether to use srgb in the output or not"), ("-e", "--eval_poses", "Whether to use test set poses to render image"),
+    ):
+        p.add_argument(short, long_, default=False, action="store_true", help=hlp)
+    for long_, hlp in (("--render_depth", "Render depth image"), ("--render_normal", "Render normal image"),
+                       ("--prop_normal", "(For proposal net) Whether to learn normals")):
+        p.add_argument(long_, default=False, action="store_true", help=hlp)
+    return p

@@ -22,6 +22,11 @@ class Golden(dict):
 
     def __init__(self, name):
         super().__init__()
+        js = os.path.join(GOLDEN, name + ".json")
+        if os.path.exists(js):
+            import json
+            self.update(json.load(open(js)))
+            return
         with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
             for k in f.files:
                 a = f[k]

@@ -272,6 +272,16 @@ def main():
         g_mip_sigma=mip.opacity_head[0].weight.grad, g_prop_l0=prop.layers[0].weight.grad[:8, :],
         g_prop_head=prop.layers[8].weight.grad)
 
+    # ---------------- G16 state_dict ABI (key names + shapes of the reference modules) ----------------
+    import json
+    abi = {}
+    for name, mod in (("mip", mip_model.MipNeRF(10, 4, 256)), ("prop", addtional.ProposalNetwork(10, 256)),
+                      ("prop128", addtional.ProposalNetwork(10))):
+        abi[name] = [[k, list(v.shape)] for k, v in mod.state_dict().items()]
+    with open(os.path.join(HERE, "g16_state_dict_abi.json"), "w") as f:
+        json.dump(abi, f, indent=0)
+    print("wrote g16_state_dict_abi.json")
+
     # ---------------- G15 LR schedule ----------------
     sch = nerf_base.DecayLrScheduler(0.01, 0.1, 100000, 3e-4, 500)
     steps = np.array([0, 1, 250, 499, 500, 501, 10000, 100500, 500000, 2000000])

@@ -1,0 +1,357 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libnerf_amd.so, via the host-side mirror of the
+reference interface) against the CPU oracle on identical inputs, and against the golden vectors produced by
+the real reference.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances (north_star: <= 1e-4 abs fp32 on RGB / depth / weights):
+  * sampling / compositing kernels: 1e-6 .. 1e-5 (same arithmetic, different summation order);
+  * fp32-MFMA MLPs: 1e-5 x output scale;   end-to-end fp32 render: 1e-4 abs;
+  * bf16-MFMA MLPs: compared with the oracle run in bf16-operand emulation (operands rounded to bf16, fp32
+    accumulate), 5e-3 x output scale; bf16 end-to-end is judged on image error / PSNR, not on 1e-4.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import weights as W
+from conftest import max_abs
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+NEAR, FAR = 2.0, 6.0
+
+
+@pytest.fixture(scope="module")
+def A():
+    """The product package, imported lazily so that collection works without a GPU."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import nerf_amd
+    from nerf_amd import ops, procedures, utils, nerf_base, mip_model, addtional, mip_methods, nerf_helper
+
+    class NS:
+        pass
+    ns = NS()
+    ns.pkg, ns.ops, ns.procedures, ns.utils, ns.nerf_base = nerf_amd, ops, procedures, utils, nerf_base
+    ns.mip_model, ns.addtional, ns.mip_methods, ns.nerf_helper = mip_model, addtional, mip_methods, nerf_helper
+    return ns
+
+
+def dev(t):
+    return t.cuda()
+
+
+def build_nets(A, tag):
+    prop = A.addtional.ProposalNetwork(10, 256)
+    mip = A.mip_model.MipNeRF(10, 4, 256)
+    prop.load_state_dict(W.proposal_state(tag))
+    mip.load_state_dict(W.mip_state(tag))
+    return prop.cuda().eval(), mip.cuda().eval()
+
+
+def test_loaded_library_is_native(A):
+    n_cu, is950 = A.ops.C.c_int(0), A.ops.C.c_int(0)
+    assert A.ops.lib.nerf_amd_device_info(A.ops.C.byref(n_cu), A.ops.C.byref(is950)) == 0
+    assert n_cu.value >= 64 and is950.value == 1
+
+
+# ------------------------------------------------------------------------------------------------ rows 1-3
+def test_raygen(A, golden):
+    g = golden("g01_raygen")
+    pose = g["pose"]
+    for size, focal, key in (((100, 100), tuple(g["focal_sq"].tolist()), "ray_raw_sq"), ((100, 100), 138.5, "ray_raw_scalar"),
+                             ((100, 150), tuple(g["focal_tuple_img"].tolist()), "ray_raw_tuple")):
+        fx, fy = (focal[1], focal[0]) if isinstance(focal, tuple) else (focal, focal)
+        rays = A.ops.generate_rays(pose, size[0], size[1], fx, fy, "cuda").cpu()
+        assert max_abs(rays[:, 3:].view(size[0], size[1], 3), g[key]) <= 1e-6
+        assert torch.equal(rays[:, :3], pose[:, -1].expand(size[0] * size[1], -1))
+    # sub-range == slice of the full table
+    full = A.ops.generate_rays(pose, 100, 100, 138.5, 138.5, "cuda")
+    part = A.ops.generate_rays(pose, 100, 100, 138.5, 138.5, "cuda", ray_offset=1234, n=777)
+    assert torch.equal(full[1234:1234 + 777], part)
+
+
+def test_valid_sampler_matches_reference_rng(A, golden):
+    g1, g = golden("g01_raygen"), golden("g02_stratified")
+    torch.manual_seed(5)
+    pts, z, rgb, rays = A.utils.validSampler(dev(g1["pix"]), dev(g1["coords"]), dev(g1["pose"]), 8, 32,
+                                             tuple(g1["focal_tuple"].tolist()), NEAR, FAR, True)
+    assert torch.equal(z.cpu(), g["z_train"]) and torch.equal(rgb.cpu(), g["rgb_train"])
+    assert max_abs(rays.cpu(), g["rays_train"]) <= 1e-6
+    assert max_abs(pts.cpu(), g["pts_train"]) <= 1e-5
+    torch.manual_seed(11)
+    rgb2, rays2 = A.utils.validSampler(dev(g1["pix"]), dev(g1["coords"]), dev(g1["pose"]), 16, 32,
+                                       tuple(g1["focal_tuple"].tolist()), NEAR, FAR, False)
+    assert torch.equal(rgb2.cpu(), g1["sampler_rgb"]) and max_abs(rays2.cpu(), g1["sampler_rays"]) <= 1e-6
+
+
+def test_positional_encoding(A, golden):
+    g = golden("g03_pe")
+    assert max_abs(A.nerf_helper.positional_encoding(dev(g["x"]), 10).cpu(), g["pe10"]) <= 3e-7
+    assert max_abs(A.nerf_helper.positional_encoding(dev(g["x"]), 4).cpu(), g["pe4"]) <= 3e-7
+    assert max_abs(A.nerf_helper.positional_encoding(dev(g["x2d"]), 4).cpu(), g["pe4_2d"]) <= 3e-7
+    x = (torch.rand(4096, 3, generator=torch.Generator().manual_seed(1)) - 0.5) * 20
+    assert max_abs(A.nerf_helper.positional_encoding(dev(x), 10).cpu(), O.positional_encoding(x, 10)) <= 3e-7
+    assert A.nerf_helper.positional_encoding(torch.empty(0, 3, device="cuda"), 10).shape == (0, 60)
+
+
+# ------------------------------------------------------------------------------------------------ rows 5-8, 10, 11
+def test_sigma_to_weights(A, golden):
+    g = golden("g05_weights")
+    s, z, d = dev(g["sigma"]), dev(g["z"]), dev(g["dirs"])
+    assert max_abs(A.addtional.ProposalNetwork.get_weights(s, z, d).cpu(), g["w_prop"]) <= 1e-6
+    assert max_abs(A.addtional.ProposalNetwork.get_weights(s, z, None).cpu(), g["w_prop_nodir"]) <= 1e-6
+    assert max_abs(A.nerf_base.NeRF.getNormedWeight(s, z).cpu(), g["w_nerf"]) <= 1e-6
+    assert max_abs(A.nerf_base.NeRF.getNormedWeight(s, z, lambda t: t.abs()).cpu(), g["w_nerf_id"]) <= 1e-6
+    # ragged sample counts, incl. > 64 (multi-chunk scan carry) and 1
+    gen = torch.Generator().manual_seed(3)
+    for S in (1, 2, 63, 64, 65, 128, 129, 192, 257):
+        sig = torch.randn(7, S, generator=gen) * 2
+        zz, _ = torch.sort(NEAR + (FAR - NEAR) * torch.rand(7, S, generator=gen), dim=-1)
+        assert max_abs(A.nerf_base.NeRF.getNormedWeight(dev(sig), dev(zz)).cpu(), O.sigma_to_weights(sig, zz)) <= 1e-6, S
+
+
+def test_max_blur(A, golden):
+    g = golden("g06_maxblur")
+    assert torch.equal(A.mip_methods.maxBlurFilter(dev(g["w"]), 0.01).cpu(), g["out"])
+    assert torch.equal(A.mip_methods.maxBlurFilter(dev(g["w"]), 0.25).cpu(), g["out_a"])
+
+
+def _below_mismatch(a, b):
+    return (a != b).float().mean().item()
+
+
+def test_inverse_sampling(A, golden):
+    g = golden("g07_inverse")
+    z, below = A.utils.inverseSample(dev(g["w"]), dev(g["z"]), 129, sort=True, u=g["u"])
+    assert max_abs(z.cpu(), g["z_sorted"]) <= 2e-6
+    assert _below_mismatch(below.cpu(), g["below_sorted"]) <= 0.005
+    assert bool((z[:, 1:] >= z[:, :-1]).all())
+    zr = A.utils.inverseSample(dev(g["w"]), dev(g["z"]), 129, sort=False, u=g["u"])
+    assert max_abs(zr.cpu(), g["z_raw"]) <= 2e-6
+    mids = 0.5 * (g["z"][..., 1:] + g["z"][..., :-1])
+    s, b, a = A.utils.sample_pdf(dev(mids), dev(g["w"][..., 1:-1].contiguous()), 33, u=g["u_pdf"])
+    assert max_abs(s.cpu(), g["s_pdf"]) <= 2e-6
+    assert _below_mismatch(b.cpu(), g["below_pdf"]) <= 0.005 and _below_mismatch(a.cpu(), g["above_pdf"]) <= 0.005
+    # the reference's own RNG protocol: a seeded CPU draw inside inverseSample
+    torch.manual_seed(21)
+    z2, _ = A.utils.inverseSample(dev(g["w"]), dev(g["z"]), 129, sort=True)
+    assert torch.equal(z2, z)
+
+
+def test_assembly(A, golden):
+    g = golden("g08_assembly")
+    assert max_abs(A.nerf_base.NeRF.length2pts(dev(g["rays"]), dev(g["zf"])).cpu(), g["l2p"]) == 0.0
+    s, z = A.nerf_base.NeRF.coarseFineMerge(dev(g["rays"]), dev(g["zc"]), dev(g["zf"]))
+    assert torch.equal(s.cpu(), g["m2_samples"]) and torch.equal(z.cpu(), g["m2_z"])
+    s, z, inds, order = A.nerf_base.NeRF.coarseFineMerge(dev(g["rays"]), dev(g["zc"]), dev(g["zf"]), dev(g["finds"]))
+    assert torch.equal(s.cpu(), g["m4_samples"]) and torch.equal(z.cpu(), g["m4_z"])
+    assert torch.equal(inds.cpu(), g["m4_inds"])
+
+
+def test_composite(A, golden):
+    g = golden("g10_composite")
+    rgbo, z, d, nrm, cz = dev(g["rgbo"]), dev(g["z"]), dev(g["dirs"]), dev(g["normal"]), dev(g["cam_z"])
+    for wb in (False, True):
+        for mn in (False, True):
+            rgb, w, ex = A.nerf_base.NeRF.render(rgbo, z, d, mul_norm=mn, white_bkg=wb, render_depth=(NEAR, FAR),
+                                                 normal_info=(nrm, cz))
+            k = "wb%d_mn%d_" % (wb, mn)
+            assert max_abs(rgb.cpu(), g[k + "rgb"]) <= 2e-6 and max_abs(w.cpu(), g[k + "w"]) <= 1e-6
+            assert max_abs(ex["depth_img"].cpu(), g[k + "depth"]) <= 2e-6
+            assert max_abs(ex["normal_img"].cpu(), g[k + "normal"]) <= 2e-6
+    rgb, w, _ = A.nerf_base.NeRF.render(rgbo, z, d, density_act=F.softplus)
+    assert max_abs(rgb.cpu(), g["softplus_rgb"]) <= 2e-6 and max_abs(w.cpu(), g["softplus_w"]) <= 1e-6
+
+
+def test_get_bounds(A, golden):
+    g = golden("g14_train_step")
+    gen = torch.Generator().manual_seed(4)
+    w = torch.rand(32, 32, generator=gen)
+    got = A.addtional.getBounds(dev(w), dev(g["below"])).cpu()
+    assert max_abs(got, O.get_bounds(w, g["below"])) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ rows 4 / 9: MLPs
+@pytest.mark.parametrize("tag", ["small", "he"])
+def test_mlps_fp32_vs_reference_golden(A, golden, tag):
+    g = golden("g04_g09_mlp")
+    prop, mip = build_nets(A, tag)
+    A.pkg.set_precision("fp32")
+    with torch.no_grad():
+        dens = prop.forward(dev(g[tag + "_pts_c"])).cpu()
+        rgbo = mip.forward(dev(g[tag + "_pts_f"])).cpu()
+    sd = max(1.0, g[tag + "_density"].abs().max().item())
+    so = max(1.0, g[tag + "_rgbo"].abs().max().item())
+    assert max_abs(dens, g[tag + "_density"]) <= 1e-5 * sd
+    assert max_abs(rgbo, g[tag + "_rgbo"]) <= 1e-5 * so
+
+
+@pytest.mark.parametrize("tag", ["small", "he"])
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 1000, 70001])
+def test_mlps_ragged_sizes(A, tag, M):
+    """Tail handling: sample counts around the 128 (fp32) / 256 (bf16) tile sizes, persistent multi-tile grids."""
+    if tag == "he" and M not in (33, 257, 70001):
+        pytest.skip("one weight flavour is enough for the small sizes")
+    prop, mip = build_nets(A, tag)
+    gen = torch.Generator().manual_seed(M)
+    pts = torch.cat(((torch.rand(M, 1, 3, generator=gen) - 0.5) * 8, torch.randn(M, 1, 3, generator=gen)), -1)
+    with torch.no_grad():
+        want_d = O.proposal_forward(W.proposal_state(tag), pts[..., :3])
+        want_o = O.mip_forward(W.mip_state(tag), pts)
+        want_d16 = O.proposal_forward(W.proposal_state(tag), pts[..., :3], emulate_bf16=True)
+        want_o16 = O.mip_forward(W.mip_state(tag), pts, emulate_bf16=True)
+        A.pkg.set_precision("fp32")
+        got_d, got_o = prop.forward(dev(pts[..., :3].contiguous())).cpu(), mip.forward(dev(pts)).cpu()
+        A.pkg.set_precision("bf16")
+        got_d16, got_o16 = prop.forward(dev(pts[..., :3].contiguous())).cpu(), mip.forward(dev(pts)).cpu()
+        A.pkg.set_precision("fp32")
+    sd, so = max(1.0, want_d.abs().max().item()), max(1.0, want_o.abs().max().item())
+    assert max_abs(got_d, want_d) <= 1e-5 * sd and max_abs(got_o, want_o) <= 1e-5 * so
+    assert max_abs(got_d16, want_d16) <= 5e-3 * sd and max_abs(got_o16, want_o16) <= 5e-3 * so
+
+
+def test_mlp_empty_and_autocast(A):
+    prop, mip = build_nets(A, "small")
+    A.pkg.set_precision(None)
+    with torch.no_grad():
+        assert prop.forward(torch.empty(0, 64, 3, device="cuda")).shape == (0, 64)
+        assert mip.forward(torch.empty(0, 128, 6, device="cuda")).shape == (0, 128, 4)
+        pts = torch.randn(5, 7, 6, device="cuda")
+        a = mip.forward(pts)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            b = mip.forward(pts)
+        A.pkg.set_precision("bf16")
+        c = mip.forward(pts)
+    A.pkg.set_precision("fp32")
+    assert torch.equal(b, c) and not torch.equal(a, b)
+
+
+def test_repack_after_inplace_update(A):
+    prop, _ = build_nets(A, "small")
+    pts = torch.randn(3, 64, 3, device="cuda")
+    with torch.no_grad():
+        a = prop.forward(pts)
+        prop.layers[8].bias.add_(1.0)
+        b = prop.forward(pts)
+    assert max_abs(b.cpu(), a.cpu() + 1.0) <= 1e-6
+
+
+def test_product_rejects_cpu_tensors(A):
+    prop, mip = build_nets(A, "small")
+    with pytest.raises(RuntimeError):
+        A.nerf_helper.positional_encoding(torch.zeros(4, 3), 10)
+    with pytest.raises(RuntimeError):
+        A.procedures.render_image(mip, prop, torch.eye(4)[:3], 50, 100.0, NEAR, FAR)
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+def _rays_and_u(n, n_fine, seed):
+    gen = torch.Generator().manual_seed(seed)
+    pose = O.pose_spherical(-63.0, -30.0, 4.0)[:3]
+    dirs = O.ray_dirs_image(pose, 80, 80, O.fov2focal(0.6911112070083618, (80, 80))).reshape(-1, 3)
+    pick = torch.randperm(dirs.shape[0], generator=gen)[:n]
+    rays = torch.cat((pose[:, -1].expand(n, -1), dirs[pick]), -1).contiguous()
+    return rays, torch.rand(n, 64, generator=gen), torch.rand(n, n_fine + 1, generator=gen)
+
+
+@pytest.mark.parametrize("tag,n,n_fine", [("small", 256, 64), ("small", 300, 128), ("he", 300, 128)])
+def test_render_rays_fp32_parity(A, tag, n, n_fine):
+    """The north-star gate: RGB / depth / weights vs the CPU path on identical rays and uniforms, <= 1e-4 abs."""
+    prop, mip = build_nets(A, tag)
+    rays, u1, u2 = _rays_and_u(n, n_fine, 17)
+    stages = {}
+    with torch.no_grad():
+        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state(tag), W.mip_state(tag), rays, u1, u2, NEAR, FAR, n_fine,
+                                                     white_bkg=True, stages=stages)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    rgb, depth, w, _ = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2),
+                                         n_fine, NEAR, FAR, True, want_depth=True, want_weights=True)
+    assert max_abs(rgb.cpu(), want_rgb) <= 1e-4
+    assert max_abs(depth.cpu(), want_depth) <= 1e-4
+    assert max_abs(w.cpu(), want_w) <= 1e-4
+    # stage by stage through the individual entry points
+    jit = (FAR - NEAR) / n_fine
+    dens = A.ops.proposal_forward_samples(prop.packed(A.ops.F32), A.ops.F32,
+                                          A.ops.samples_rays(dev(rays), 64, z_base=z_base, u=dev(u1), z_jitter=jit), (n, 64), "cuda")
+    assert max_abs(dens.cpu(), stages["density"]) <= 1e-5 * max(1.0, stages["density"].abs().max().item())
+    z_f, below, w_prop, z_c = A.ops.resample(dens, None, z_base, dev(u1), jit, dev(rays), dev(u2), n_fine + 1, want_below=True,
+                                             want_w=True, want_zc=True)
+    assert torch.equal(z_c.cpu(), stages["z_coarse"])
+    assert max_abs(w_prop.cpu(), stages["w_prop"]) <= 1e-5
+    assert max_abs(z_f[:, :-1].cpu(), stages["z_fine"]) <= 2e-5
+    assert _below_mismatch(below.cpu(), stages["below"]) <= 0.01
+
+
+def test_render_rays_bf16_close(A):
+    prop, mip = build_nets(A, "small")
+    rays, u1, u2 = _rays_and_u(512, 128, 5)
+    with torch.no_grad():
+        want_rgb, _, want_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), rays, u1, u2, NEAR, FAR, 128,
+                                                white_bkg=True)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    rgb, depth, _, _ = A.ops.render_rays(prop.packed(A.ops.BF16), mip.packed(A.ops.BF16), A.ops.BF16, dev(rays), z_base, dev(u1), dev(u2),
+                                         128, NEAR, FAR, True)
+    mse = torch.mean((rgb.cpu() - want_rgb) ** 2).item()
+    assert -10 * math.log10(max(mse, 1e-12)) >= 40.0                     # bf16 vs fp32 image: > 40 dB
+    assert max_abs(depth.cpu(), want_depth) <= 5e-2
+
+
+@pytest.mark.parametrize("tag,size,sn", [("small_50", 50, 128), ("he_50", 50, 128), ("small_100", 100, 64), ("small_200", 200, 64)])
+def test_render_image_vs_reference(A, golden, tag, size, sn):
+    """Drop-in surface: same seed -> same image as the REAL reference's render_image (its tile order and
+    CPU RNG draw order reproduced), 1e-4 abs.  small_200 is BASELINE config 1's image size."""
+    g = golden("g11_render_image")
+    prop, mip = build_nets(A, tag.split("_")[0])
+    A.pkg.set_precision("fp32")
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        res = A.procedures.render_image(mip, prop, dev(g["pose"]), size, tuple(g[tag + "_focal"].tolist()), NEAR, FAR, sn,
+                                        white_bkg=True, render_depth=True)
+    assert list(res.keys()) == ["rgb", "depth_img"]
+    assert res["rgb"].shape == (3, size, size) and res["depth_img"].shape == (3, size, size)
+    assert max_abs(res["rgb"].cpu(), g[tag + "_rgb"]) <= 1e-4
+    assert max_abs(res["depth_img"][0].cpu(), g[tag + "_depth"]) <= 1e-4
+    assert torch.equal(res["depth_img"][0], res["depth_img"][2])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_size_properties(A, prec):
+    """BASELINE config 2 size (800x800, 64+128; fp32 on a 200k-ray slab to bound run time): properties that
+    need no oracle at this scale + an oracle spot check on a random subset."""
+    prop, mip = build_nets(A, "he")
+    P = A.ops.F32 if prec == "fp32" else A.ops.BF16
+    H = Wd = 800
+    pose = O.pose_spherical(20.0, -30.0, 4.0)[:3]
+    f = O.fov2focal(0.6911112070083618, (H, Wd))
+    n = H * Wd if prec == "bf16" else 200_000
+    rays = A.ops.generate_rays(pose, H, Wd, f[1], f[0], "cuda", 0, n)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    u1 = torch.rand(n, 64, device="cuda", generator=gen)
+    u2 = torch.rand(n, 129, device="cuda", generator=gen)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    pk_p, pk_m = prop.packed(P), mip.packed(P)
+    rgb_w, depth, w, ws = A.ops.render_rays(pk_p, pk_m, P, rays, z_base, u1, u2, 128, NEAR, FAR, True, want_depth=True, want_weights=True)
+    rgb_b, _, _, ws = A.ops.render_rays(pk_p, pk_m, P, rays, z_base, u1, u2, 128, NEAR, FAR, False, workspace=ws)
+    acc = w.sum(-1)
+    assert bool(torch.isfinite(rgb_w).all()) and bool(torch.isfinite(depth).all())
+    assert float(acc.max()) <= 1.0 + 1e-4 and float(w.min()) >= 0.0
+    assert max_abs(rgb_w - rgb_b, (1.0 - acc)[:, None].expand(-1, 3)) <= 2e-6          # white background is affine in (1 - sum w)
+    assert float(rgb_b.min()) >= 0.0 and float(rgb_b.max()) <= 1.0 + 1e-5
+    # batch-composition independence: any sub-batch reproduces the same bits
+    lo, cnt = 123_457, 4_099
+    r2, d2, w2, _ = A.ops.render_rays(pk_p, pk_m, P, rays[lo:lo + cnt].contiguous(), z_base, u1[lo:lo + cnt].contiguous(),
+                                      u2[lo:lo + cnt].contiguous(), 128, NEAR, FAR, True, want_depth=True, want_weights=True)
+    assert torch.equal(r2, rgb_w[lo:lo + cnt]) and torch.equal(d2, depth[lo:lo + cnt]) and torch.equal(w2, w[lo:lo + cnt])
+    # oracle spot check on a random subset
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(2))[:192]
+    with torch.no_grad():
+        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("he"), W.mip_state("he"), rays[pick].cpu(), u1[pick].cpu(),
+                                                     u2[pick].cpu(), NEAR, FAR, 128, white_bkg=True, emulate_bf16=False)
+    if prec == "fp32":
+        assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4 and max_abs(depth[pick].cpu(), want_depth) <= 1e-4
+        assert max_abs(w[pick].cpu(), want_w) <= 1e-4
+    else:
+        assert torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item() <= 1e-3
