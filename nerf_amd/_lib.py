@@ -4,6 +4,9 @@ torch/CPU substitute."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: torch bundles its own libamdhip64; loading ours first
+#                             would bring up a second HIP runtime that cannot see torch's device allocations.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 

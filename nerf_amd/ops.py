@@ -202,9 +202,17 @@ def stratified_points(rays: torch.Tensor, z_base: torch.Tensor, u: torch.Tensor,
 def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm: bool, white_bkg: bool, act: int,
               near_far=None, normal: Optional[torch.Tensor] = None, cam_dir: Optional[torch.Tensor] = None,
               want_weights: bool = True):
-    rgbo, z, dirs = _dev(rgbo, "rgbo"), _dev(z, "depth"), _dev(dirs, "ray_dirs")
+    """NeRF.render (nerf_base.py:91-113).  ``dirs`` is (N,3) ray directions or the (N,6) ray table (then the
+    direction half is read in place with stride 6)."""
+    rgbo, z = _dev(rgbo, "rgbo"), _dev(z, "depth")
     N, S = rgbo.shape[0], rgbo.shape[1]
     dev = rgbo.device
+    if dirs.shape[-1] == 6:
+        dirs = _dev(dirs, "rays")
+        dirs_ptr, dirs_stride = C.c_void_p(dirs.data_ptr() + 12), 6
+    else:
+        dirs = _dev(dirs, "ray_dirs")
+        dirs_ptr, dirs_stride = _ptr(dirs), 3
     rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
     w = torch.empty((N, S), dtype=torch.float32, device=dev) if want_weights else None
     depth = torch.empty((N,), dtype=torch.float32, device=dev) if near_far is not None else None
@@ -214,7 +222,7 @@ def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm:
         nimg = torch.empty((N,), dtype=torch.float32, device=dev)
     near, far = (near_far if near_far is not None else (0.0, 1.0))
     flags = (1 if mul_norm else 0) | (2 if white_bkg else 0)
-    check(lib.nerf_amd_composite(_ptr(rgbo), _ptr(z), z.shape[-1], _ptr(dirs), dirs.shape[-1], N, S, flags, act, float(near),
+    check(lib.nerf_amd_composite(_ptr(rgbo), _ptr(z), z.shape[-1], dirs_ptr, dirs_stride, N, S, flags, act, float(near),
                                  float(far), _ptr(normal), _ptr(cam_dir), _ptr(rgb), _ptr(w), _ptr(depth), _ptr(nimg),
                                  _stream()), "nerf_amd_composite")
     return rgb, w, depth, nimg
