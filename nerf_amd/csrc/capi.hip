@@ -97,15 +97,17 @@ int nerf_amd_pack_weights(int net, int precision, const float* const* weights, c
 
 int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
-    if (!packed || !density) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (int c = check_samples(src, false)) return c;
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !density) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(mlp_launch_proposal(packed, precision, *src, density, S(stream)), "nerf_amd_proposal_forward");
 }
 
 int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
-    if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (int c = check_samples(src, true)) return c;
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(mlp_launch_mip(packed, precision, *src, rgbo, S(stream)), "nerf_amd_mip_forward");
 }
 

@@ -88,6 +88,8 @@ def proposal_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor) ->
     """pts (..., 3) -> density (...)   [addtional.py:88-96]"""
     pts = _dev(pts, "pts")
     out = torch.empty(pts.shape[:-1], dtype=torch.float32, device=pts.device)
+    if out.numel() == 0:
+        return out
     s = _samples_pts(pts, 3)
     check(lib.nerf_amd_proposal_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
     return out
@@ -103,6 +105,8 @@ def mip_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor) -> torc
     """pts (..., 6) -> rgbo (..., 4)   [mip_model.py:41-60]"""
     pts = _dev(pts, "pts")
     out = torch.empty(pts.shape[:-1] + (4,), dtype=torch.float32, device=pts.device)
+    if out.numel() == 0:
+        return out
     s = _samples_pts(pts, 6)
     check(lib.nerf_amd_mip_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
     return out
