@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch bundles its 
 #                             would bring up a second HIP runtime that cannot see torch's device allocations.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
+LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")   # env override: diagnostic builds only
 
 F32, BF16 = 0, 1
 NET_PROPOSAL, NET_MIP = 0, 1

@@ -24,6 +24,10 @@
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
+// Ablation switches (diagnostic builds only: `make ablate`; results are wrong by construction, only timing matters)
+//   ABL_NOEPI  skip bias/ReLU/convert epilogues     ABL_NOPE    skip the sin/cos encodings
+//   ABL_NOBAR  no s_barrier in the chunk protocol    ABL_NOLDSA  A fragments not re-read from LDS
+//   ABL_NOGLDS no global_load_lds refills
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -35,11 +39,20 @@ struct PBF16 {
     static constexpr int NW = MLP_NW_BF16;     // wavefronts per workgroup
     static constexpr int FRAG_BYTES = 1024;    // one A fragment: 32 rows x 16 k, bf16
     static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
-    static DEVINL f32x16 mma(uint32_t frag_addr, const BReg& b, f32x16 acc) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + frag_addr);
+    using AReg = bf16x8;                       // one A fragment per lane (4 VGPRs)
+#ifndef MLP_DEPTH_BF16
+#define MLP_DEPTH_BF16 4
+#endif
+    static constexpr int DEPTH = MLP_DEPTH_BF16;   // A fragments prefetched LDS -> VGPR ahead of their MFMA
+    static DEVINL AReg load_a(uint32_t frag_addr) { return *reinterpret_cast<const bf16x8*>(smem + frag_addr); }
+    static DEVINL f32x16 mma(const AReg& a, const BReg& b, f32x16 acc) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
     static DEVINL void set(BReg& r, int e, float v) { r[e] = (__bf16)v; }
+    // per-lane LDS stash of one B register group (lane-linear 16-byte slots: conflict-free)
+    static constexpr int BREG_LDS = 1024;
+    static DEVINL void stash(uint32_t addr, const BReg& r) { *reinterpret_cast<bf16x8*>(smem + addr) = r; }
+    static DEVINL BReg unstash(uint32_t addr) { return *reinterpret_cast<const bf16x8*>(smem + addr); }
 };
 
 struct PF32 {
@@ -48,16 +61,33 @@ struct PF32 {
     static constexpr int NW = MLP_NW_F32;
     static constexpr int FRAG_BYTES = 2048;    // [2 halves][64 lanes][4 floats]
     static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
-    static DEVINL f32x16 mma(uint32_t frag_addr, const BReg& b, f32x16 acc) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + frag_addr);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + frag_addr + 1024);
+    struct AReg { f32x4 lo, hi; };
+    static constexpr int DEPTH = 2;
+    static DEVINL AReg load_a(uint32_t frag_addr) {
+        AReg a;
+        a.lo = *reinterpret_cast<const f32x4*>(smem + frag_addr);
+        a.hi = *reinterpret_cast<const f32x4*>(smem + frag_addr + 1024);
+        return a;
+    }
+    static DEVINL f32x16 mma(const AReg& a, const BReg& b, f32x16 acc) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b[e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[e], b[e], acc, 0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b[4 + e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[e], b[4 + e], acc, 0, 0, 0);
         return acc;
     }
     static DEVINL void set(BReg& r, int e, float v) { r[e] = v; }
+    static constexpr int BREG_LDS = 2048;
+    static DEVINL void stash(uint32_t addr, const BReg& r) {
+        f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
+        *reinterpret_cast<f32x4*>(smem + addr) = lo;
+        *reinterpret_cast<f32x4*>(smem + addr + 1024) = hi;
+    }
+    static DEVINL BReg unstash(uint32_t addr) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + addr), hi = *reinterpret_cast<const f32x4*>(smem + addr + 1024);
+        BReg r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -70,45 +100,145 @@ struct WeightStream {
     uint32_t n_chunks;      // chunks in one pass over the network
     uint32_t load_idx;      // next chunk of the stream to fetch (wraps)
     uint32_t load_slot;     // ring slot it goes to
-    uint32_t cur;           // LDS byte offset of the chunk being consumed (+ lane*16)
+    uint32_t cur;           // LDS byte offset of the chunk the register prefetch reads from (+ lane*16)
     uint32_t cur_slot;
     uint32_t wave_lds;      // wave-uniform LDS offset of this wave's pieces inside a slot
+#ifdef MLP_BURST
+    typename P::AReg q[2][P::DEPTH];   // double-buffered groups of DEPTH A fragments: one being multiplied, one in flight from LDS
+#else
+    typename P::AReg q[P::DEPTH];   // A fragments f .. f+DEPTH-1 already in registers (f = next fragment to multiply)
+#endif
 
+    static DEVINL void dummy_sink(const bf16x8& d) { asm volatile("" ::"v"(d)); }
+    template <class T> static DEVINL void dummy_sink(const T& d) { asm volatile("" ::"v"(d.lo), "v"(d.hi)); }
     DEVINL void issue() {
         const char* g = src + (size_t)load_idx * MLP_CHUNK_BYTES;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(load_slot * MLP_CHUNK_BYTES + wave_lds);
+        // global -> LDS DMA (16 B/lane, lane-linear).  Issued through inline asm on purpose: hipcc's waitcnt pass treats
+        // the builtin form as a "flat" access that may touch LDS and from then on turns EVERY s_waitcnt lgkmcnt(N) of
+        // the A-fragment prefetch into lgkmcnt(0) -- which serialises the LDS pipeline (measured: 59% -> MFMA-bound).
+        // The asm is invisible to that pass; completion is tracked by our own counted vmcnt in boundary().
 #pragma unroll
-        for (int i = 0; i < LPW; ++i)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g + i * 1024),
-                (__attribute__((address_space(3))) void*)(smem + dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < LPW; ++i) {
+#ifndef ABL_NOGLDS
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(g + i * 1024), "s"(dst + i * 1024)
+                         : "memory");
+#else
+            asm volatile("" ::"v"(g), "s"(dst));
+#endif
+        }
         load_idx = (load_idx + 1 == n_chunks) ? 0u : load_idx + 1;
         load_slot = (load_slot + 1) & (MLP_NSLOT - 1);
     }
+    // Synchronisation protocol (all code is branch-free; the only conditional instruction is the s_barrier itself):
+    //   * chunk boundary i = the moment a wave's register prefetch enters chunk i.  At EVERY boundary a wave waits
+    //     until at most 3 of its own chunk pieces are in flight and then issues its piece of one more chunk.
+    //   * "early" waves (first half of the workgroup) execute s_barrier at even boundaries, "late" waves (second
+    //     half = the other wavefront of each SIMD) at odd ones, so barrier b pairs early@2b with late@2b+1: the two
+    //     wavefronts of a SIMD run one chunk (FPC MFMAs = half a 256-wide feature block) apart, and between two
+    //     barriers (2 chunks) each has slack to overlap its VALU epilogue with the partner's MFMA run.
+    //   * invariants after barrier b: chunks <= 2b+2 are completely in LDS (every wave waited for its pieces);
+    //     every wave holds chunks <= 2b-1 in registers, so those ring slots may be refilled.  Early waves issue chunk
+    //     i+6 at boundary i, late waves chunk i+5: both groups issue the same chunk within the same barrier interval.
+    static constexpr int INFLIGHT = 3 * LPW;
+    uint32_t late;
+
     DEVINL void init(const void* packed, uint32_t nchunks) {
+        static_assert(MLP_NSLOT == 8, "protocol below is written for an 8-slot ring");
         const int lane = lane_id();
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         src = reinterpret_cast<const char*>(packed) + (size_t)wave * LPW * 1024 + lane * 16;
         wave_lds = wave * LPW * 1024;
         n_chunks = nchunks;
         load_idx = 0; load_slot = 0;
-        cur_slot = MLP_NSLOT - 1;                  // first boundary() advances to slot 0
-        cur = 0;
+        cur_slot = 0;
+        cur = lane * 16;
+        late = __builtin_amdgcn_readfirstlane((P::NW > 4 && wave >= P::NW / 2) ? 1 : 0);
 #pragma unroll
-        for (int i = 0; i < MLP_NSLOT - 1; ++i) issue();
-    }
-    // Called by every wavefront right before it reads the first fragment of the next chunk.
-    DEVINL void boundary() {
-        // my pieces of the next chunk have landed (two younger chunks may stay in flight) ...
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
-        // ... and so have everybody else's; also: everybody is done reading the previous chunk
-        __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < 6; ++i) issue();                                 // chunks 0..5
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my pieces of chunks 0..2 have landed ...
+        __builtin_amdgcn_s_barrier();                                        // ... and everybody else's
         asm volatile("" ::: "memory");
-        issue();                                   // refill the slot that was just retired
-        cur_slot = (cur_slot + 1) & (MLP_NSLOT - 1);
-        cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
+#pragma unroll
+#ifdef MLP_BURST
+        for (int i = 0; i < P::DEPTH; ++i) q[0][i] = P::load_a(cur + i * P::FRAG_BYTES);
+#else
+        for (int i = 0; i < P::DEPTH; ++i) q[i] = P::load_a(cur + i * P::FRAG_BYTES);
+#endif
+        if (!late) {                                                         // boundary 0 of the early waves
+            __builtin_amdgcn_s_barrier();                                    // barrier 0 (late waves: at their boundary 1)
+            asm volatile("" ::: "memory");
+            issue();                                                         // chunk 6
+        }
     }
-    DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // Fragment F of the stream (compile-time index, F mod DEPTH == queue slot): hand out its registers and
+    // start the LDS read of fragment F+DEPTH into the same slot.  The boundary work therefore runs DEPTH
+    // fragments BEFORE the first MFMA that needs the new chunk: the MFMA pipe keeps draining the register queue.
+#ifdef MLP_BURST
+    // Burst form: the LDS reads of a whole group of DEPTH fragments are issued together, then the DEPTH MFMAs of the
+    // previous group run back to back with nothing issued between them.
+    template <int F>
+    DEVINL typename P::AReg next() {
+        constexpr int R = F / P::DEPTH, S = F % P::DEPTH;
+        if constexpr (S == 0) {
+            constexpr int G = F + P::DEPTH;
+            static_assert(P::FPC % P::DEPTH == 0, "a group may not straddle chunks");
+            if (G % P::FPC == 0) {
+                cur_slot = (cur_slot + 1) & (MLP_NSLOT - 1);
+                cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
+                boundary<(G / P::FPC) & 1>();
+            }
+#pragma unroll
+            for (int i = 0; i < P::DEPTH; ++i) q[(R + 1) & 1][i] = P::load_a(cur + ((G + i) % P::FPC) * P::FRAG_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MLP_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+        }
+#ifdef MLP_SETPRIO
+        if constexpr (S == P::DEPTH - 1) __builtin_amdgcn_s_setprio(0);
+#endif
+        return q[R & 1][S];
+    }
+#else
+    template <int F>
+    DEVINL typename P::AReg next() {
+        const typename P::AReg a = q[F % P::DEPTH];
+        constexpr int G = F + P::DEPTH;
+        if (G % P::FPC == 0) {
+            cur_slot = (cur_slot + 1) & (MLP_NSLOT - 1);
+            cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
+            boundary<(G / P::FPC) & 1>();
+        }
+#if defined(ABL_NOLDSA)
+#elif defined(ABL_HALFLDS)
+        if (F % 2 == 0) q[F % P::DEPTH] = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES);
+#elif defined(ABL_DUMMYLDS)
+        { const typename P::AReg d = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES); dummy_sink(d); }
+#else
+        q[F % P::DEPTH] = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES);
+#endif
+        return a;
+    }
+#endif
+    template <int PARITY>
+    DEVINL void boundary() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        // s_barrier only when this boundary's parity is mine; the branch lives inside the asm so that the compiler
+        // sees straight-line code (a C++ `if` here splits every feature block into many basic blocks and spills)
+#ifndef ABL_NOBAR
+        asm volatile("s_cmp_lg_u32 %0, %1\n\ts_cbranch_scc1 .Lnobar%=\n\ts_barrier\n.Lnobar%=:" ::"s"(__builtin_amdgcn_readfirstlane(late)), "n"(PARITY) : "memory", "scc");
+#endif
+        issue();
+    }
+    // End of kernel: the early waves ran one barrier more (barrier 0 at init); the late waves supply its partner here.
+    DEVINL void drain() {
+        if (late) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -117,31 +247,86 @@ struct WeightStream {
 //   NFB    32-row output feature blocks;  out(fb, acc) receives the 16 accumulators of block fb
 //   START  fragment index of the layer inside the stream modulo FPC (chunk phase)
 // ------------------------------------------------------------------------------------------------
+// Feature blocks are processed two at a time with their MFMAs alternating between two independent accumulators.
+// Why: on gfx950 any instruction issued between two MFMAs that chain through the SAME accumulator (here: the
+// ds_read of the next A fragment) costs ~+43 cycles on the dependent MFMA (MI355X_MICROARCH.md, per-instruction
+// constants) -- measured here as 59% -> ~95% MFMA-pipe occupancy between "with" and "without" the A reads.
+// Alternating accumulators puts a full MFMA between dependent ones.  The stream stores a pair's fragments
+// interleaved (kg-major), so the B registers of K group kg are fetched once and feed both blocks.
+// A single trailing block (odd NFB) splits K over the two accumulators instead and adds them at the end.
+template <class P>
+DEVINL void load_bias(f32x4 (&bias)[4], uint32_t addr) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias[q] = *reinterpret_cast<const f32x4*>(smem + addr + 32 * q);
+}
+template <class P, int NKG, int FRAG0, int KG, class InF>
+DEVINL void pair_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x4 (&bias0)[4], f32x4 (&bias1)[4],
+                   uint32_t bias_addr, InF& in) {
+    if constexpr (KG < NKG) {
+        const typename P::BReg b = in(KG);
+        const typename P::AReg a0 = ws.template next<FRAG0 + 2 * KG>();
+        acc0 = P::mma(a0, b, acc0);
+        const typename P::AReg a1 = ws.template next<FRAG0 + 2 * KG + 1>();
+        acc1 = P::mma(a1, b, acc1);
+        if constexpr (KG == (NKG > 3 ? NKG - 3 : 0)) {          // bias reads issued late: short live range, latency
+            load_bias<P>(bias0, bias_addr);                       // still covered by the last MFMAs of the pair
+            load_bias<P>(bias1, bias_addr + 128);
+        }
+        pair_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, bias0, bias1, bias_addr, in);
+    }
+}
+template <class P, int NKG, int FRAG0, int KG, class InF>
+DEVINL void single_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x4 (&bias0)[4], uint32_t bias_addr, InF& in) {
+    if constexpr (KG < NKG) {
+        const typename P::AReg a = ws.template next<FRAG0 + KG>();
+        if constexpr (KG % 2 == 0) acc0 = P::mma(a, in(KG), acc0);
+        else acc1 = P::mma(a, in(KG), acc1);
+        if constexpr (KG == (NKG > 3 ? NKG - 3 : 0)) load_bias<P>(bias0, bias_addr);
+        single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, bias0, bias_addr, in);
+    }
+}
+template <class P, int NKG, int NFB, int START, int G, class InF, class OutF>
+DEVINL void dense_group(WeightStream<P>& ws, uint32_t bias_lds, InF& in, OutF& out) {
+    if constexpr (2 * G < NFB) {
+        constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x16 acc0 = zero, acc1 = zero;
+        f32x4 bias0[4];
+        const uint32_t bias_addr = bias_lds + (64 * G + 4 * (lane_id() >> 5)) * 4;
+        constexpr int FRAG0 = START + 2 * G * NKG;
+        if constexpr (2 * G + 1 < NFB) {
+            f32x4 bias1[4];
+            pair_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, bias0, bias1, bias_addr, in);
+#ifndef ABL_NOEPI
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] += bias0[r >> 2][r & 3]; acc1[r] += bias1[r >> 2][r & 3]; }
+#endif
+            out(2 * G, acc0);
+            out(2 * G + 1, acc1);
+        } else {
+            single_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, bias0, bias_addr, in);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = (acc0[r] + acc1[r]) + bias0[r >> 2][r & 3];
+            out(2 * G, acc0);
+        }
+        dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lds, in, out);
+    }
+}
 template <class P, int NKG, int NFB, int START, class InF, class OutF>
 DEVINL void dense(WeightStream<P>& ws, uint32_t bias_lds, InF&& in, OutF&& out) {
-    const int h = lane_id() >> 5;
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + bias_lds + (32 * fb + 8 * q + 4 * h) * 4);
-            acc[4 * q + 0] = b4[0]; acc[4 * q + 1] = b4[1]; acc[4 * q + 2] = b4[2]; acc[4 * q + 3] = b4[3];
-        }
-#pragma unroll
-        for (int kg = 0; kg < NKG; ++kg) {
-            constexpr int dummy = 0; (void)dummy;
-            const int f = START + fb * NKG + kg;                   // compile-time after unrolling
-            if (f % P::FPC == 0) ws.boundary();
-            acc = P::mma(ws.cur + (f % P::FPC) * P::FRAG_BYTES, in(kg), acc);
-        }
-        out(fb, acc);
-    }
+    static_assert(START % P::DEPTH == 0 && (NKG * NFB) % P::DEPTH == 0, "layers must start on a prefetch-queue boundary");
+    dense_group<P, NKG, NFB, START, 0>(ws, bias_lds, in, out);
 }
 
 // accumulators of feature block fb -> B registers of K groups 2fb, 2fb+1 of the next layer
 template <class P, bool RELU>
 DEVINL void to_breg(const f32x16& acc, typename P::BReg& lo, typename P::BReg& hi) {
+#ifdef ABL_NOEPI
+    if constexpr (sizeof(typename P::BReg) == 16) {
+        f32x4 l = {acc[0], acc[1], acc[2], acc[3]}, h2 = {acc[8], acc[9], acc[10], acc[11]};
+        lo = __builtin_bit_cast(typename P::BReg, l); hi = __builtin_bit_cast(typename P::BReg, h2);
+        return;
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float a = acc[e], b = acc[8 + e];
@@ -159,6 +344,9 @@ DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG])
 #pragma unroll
     for (int q = 0; q < 8 * NKG; ++q) {
         float v;
+#ifdef ABL_NOPE
+        if (q < 3 * L) { v = (q % 3 == 0) ? x : ((q % 3 == 1) ? y : z); } else
+#endif
         if (q < 3 * L) {
             const int c = q % 3;
             const float comp = (c == 0) ? x : ((c == 1) ? y : z);
@@ -209,6 +397,11 @@ DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) 
     return r;
 }
 
+constexpr uint32_t LDS_BIAS = MLP_RING_BYTES;
+constexpr uint32_t LDS_STASH = MLP_RING_BYTES + 9216;                 // bias table: <= 2240 floats
+template <class P> constexpr uint32_t lds_dir() { return LDS_STASH + P::NW * 4 * P::BREG_LDS; }
+template <class P> constexpr uint32_t lds_total() { return lds_dir<P>() + P::NW * 1024; }
+
 DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias) {
     const float* b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + stream_bytes);
     float* dst = reinterpret_cast<float*>(smem + MLP_RING_BYTES);
@@ -240,20 +433,20 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         BReg enc[4];
         encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
         BReg a[16], b[16];
-        dense<P, 4, 8, L::START[0] % FPC>(ws, bias0 + L::BIAS_OFF[0] * 4,
-            [&](int kg) -> const BReg& { return enc[kg]; },
+        dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
+            [&](int kg) -> BReg { return enc[kg]; },
             [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
-            dense<P, 16, 8, L::START[1] % FPC>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg) -> const BReg& { return a[kg]; },
+            dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
                 [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = b[k];
         }
         float dens = 0.0f;
-        dense<P, 16, 1, L::START[4] % FPC>(ws, bias0 + L::BIAS_OFF[4] * 4,
-            [&](int kg) -> const BReg& { return a[kg]; },
+        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
+            [&](int kg) -> BReg { return a[kg]; },
             [&](int, const f32x16& acc) { dens = acc[0]; });
         if (h == 0 && m < s.M) density[m] = dens;
     }
@@ -276,46 +469,56 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     const int wave = threadIdx.x >> 6;
     constexpr int TS = P::NW * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
-    const uint32_t bias0 = MLP_RING_BYTES;
+    const uint32_t bias0 = LDS_BIAS;
+    const uint32_t enc_lds = LDS_STASH + wave * 4 * P::BREG_LDS + lane * 16;
+    const uint32_t dir_lds = lds_dir<P>() + wave * 1024 + lane * 16;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t m = tile * TS + wave * 32 + j;
-        const Sample sm = fetch_sample(s, m < s.M ? m : s.M - 1, true);
-        BReg enc[4];
-        encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
         BReg a[16], b[16];
-        // lin_block1.0 : 63 -> 256
-        dense<P, 4, 8, L::START[0] % FPC>(ws, bias0 + L::BIAS_OFF[0] * 4,
-            [&](int kg) -> const BReg& { return enc[kg]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+        {
+            const Sample sm = fetch_sample(s, m < s.M ? m : s.M - 1, true);
+            BReg enc[4];
+            encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
+            // the encoding is needed again by the skip layer and the direction by the colour head: park them in
+            // this wavefront's private LDS stash instead of holding 20+ VGPRs through six layers
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P::stash(enc_lds + k * P::BREG_LDS, enc[k]);
+            f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
+            *reinterpret_cast<f32x4*>(smem + dir_lds) = dv;
+            // lin_block1.0 : 63 -> 256
+            dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
+                [&](int kg) -> BReg { return enc[kg]; },
+                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+        }
         // lin_block1.{2,4,6} : 256 -> 256
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
-            dense<P, 16, 8, L::START[1] % FPC>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg) -> const BReg& { return a[kg]; },
+            dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
                 [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = b[k];
         }
         // lin_block2.0 : cat(enc 63, h 256) -> 256
-        dense<P, 20, 8, L::START[4] % FPC>(ws, bias0 + L::BIAS_OFF[4] * 4,
-            [&](int kg) -> const BReg& { if (kg < 4) return enc[kg < 4 ? kg : 0]; return a[kg >= 4 ? kg - 4 : 0]; },
+        dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
+            [&](int kg) -> BReg { if (kg < 4) return P::unstash(enc_lds + kg * P::BREG_LDS); return a[kg >= 4 ? kg - 4 : 0]; },
             [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = b[k];
         // lin_block2.{2,4}
 #pragma unroll 1
         for (int l = 5; l <= 6; ++l) {
-            dense<P, 16, 8, L::START[5] % FPC>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
-                [&](int kg) -> const BReg& { return a[kg]; },
+            dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
                 [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = b[k];
         }
         // bottle_neck.0 (rows 0..255, no activation) + opacity_head.0 (row 256)
         float sigma = 0.0f;
-        dense<P, 16, 9, L::START[7] % FPC>(ws, bias0 + L::BIAS_OFF[7] * 4,
-            [&](int kg) -> const BReg& { return a[kg]; },
+        dense<P, 16, 9, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4,
+            [&](int kg) -> BReg { return a[kg]; },
             [&](int fb, const f32x16& acc) {
                 if (fb < 8) to_breg<P, false>(acc, b[2 * (fb < 8 ? fb : 0)], b[2 * (fb < 8 ? fb : 0) + 1]);
                 else sigma = acc[0];
@@ -323,18 +526,19 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
         BReg denc[2];
         {
-            const float nrm = norm3(sm.dx, sm.dy, sm.dz);
-            encode<P, 4, 2>(sm.dx / nrm, sm.dy / nrm, sm.dz / nrm, h, denc);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds);
+            const float nrm = norm3(dv[0], dv[1], dv[2]);
+            encode<P, 4, 2>(dv[0] / nrm, dv[1] / nrm, dv[2] / nrm, h, denc);
         }
         // rgb_layer.0 : cat(bottleneck 256, dir 27) -> 128, ReLU
         BReg c[8];
-        dense<P, 18, 4, L::START[8] % FPC>(ws, bias0 + L::BIAS_OFF[8] * 4,
-            [&](int kg) -> const BReg& { if (kg < 16) return b[kg < 16 ? kg : 0]; return denc[kg >= 16 ? kg - 16 : 0]; },
+        dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
+            [&](int kg) -> BReg { if (kg < 16) return b[kg < 16 ? kg : 0]; return denc[kg >= 16 ? kg - 16 : 0]; },
             [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, c[2 * fb], c[2 * fb + 1]); });
         // rgb_layer.2 : 128 -> 3, sigmoid
         float r = 0.0f, g = 0.0f, bl = 0.0f;
-        dense<P, 8, 1, L::START[9] % FPC>(ws, bias0 + L::BIAS_OFF[9] * 4,
-            [&](int kg) -> const BReg& { return c[kg]; },
+        dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
+            [&](int kg) -> BReg { return c[kg]; },
             [&](int, const f32x16& acc) { r = acc[0]; g = acc[1]; bl = acc[2]; });
         if (h == 0 && m < s.M) {
             f32x4 o;
@@ -364,7 +568,7 @@ int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, 
     constexpr int TS = P::NW * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
-    const size_t lds = MLP_RING_BYTES + Lay::N_BIAS * 4;
+    const size_t lds = lds_total<P>();
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -6,7 +6,9 @@
 //   h = lane>>5, e in 0..7 is W[32*fb + i][ column(kg, h, e) ]:
 //       bf16: [lane][e]             1 KiB per fragment  (one ds_read_b128 per lane)
 //       fp32: [e>>2][lane][e&3]     2 KiB per fragment  (two conflict-free ds_read_b128 per lane)
-//   Fragments are stored in exactly the order the kernels consume them: layer, fb, kg.
+//   Fragments are stored in exactly the order the kernels consume them: layer by layer; inside a layer the
+//   feature blocks go in pairs (2g, 2g+1) with the pair's fragments interleaved kg-major:
+//   (2g,kg0) (2g+1,kg0) (2g,kg1) (2g+1,kg1) ...; an odd trailing block follows in plain kg order.
 //
 // Slot -> feature maps (why the activations never leave registers):
 //   D map   a layer's MFMA output registers (lane half h, reg r) hold feature (r&3) + 8*(r>>2) + 4*h of
@@ -19,8 +21,8 @@
 #pragma once
 #include "../../include/nerf_amd.h"
 
-#define MLP_CHUNK_BYTES 16384
-#define MLP_NSLOT 4
+#define MLP_CHUNK_BYTES 8192
+#define MLP_NSLOT 8
 #define MLP_RING_BYTES (MLP_CHUNK_BYTES * MLP_NSLOT)
 #define MLP_NW_BF16 8
 #define MLP_NW_F32 4

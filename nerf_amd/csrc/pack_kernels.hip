@@ -23,7 +23,12 @@ __global__ void pack_layer_kernel(PackLayer L, char* __restrict__ stream, float*
     const int n_elem = L.nfb * L.nkg * 512;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_elem; i += gridDim.x * blockDim.x) {
         const int e = i & 7, lane = (i >> 3) & 63, frag = i >> 9;
-        const int fb = frag / L.nkg, kg = frag - fb * L.nkg;
+        // consumption order of mlp_kernels.hip: feature blocks in pairs, a pair's fragments interleaved kg-major;
+        // a trailing single block (odd nfb) in plain kg order
+        const int grp = frag / (2 * L.nkg);
+        int fb, kg;
+        if (2 * grp + 1 < L.nfb) { const int r = frag - grp * 2 * L.nkg; kg = r >> 1; fb = 2 * grp + (r & 1); }
+        else { fb = 2 * grp; kg = frag - 2 * grp * L.nkg; }
         const int row = 32 * fb + (lane & 31), h = lane >> 5;
         int seg = 0, lkg = kg;
         if (kg >= L.seg_nkg[0]) { seg = 1; lkg = kg - L.seg_nkg[0]; }
