@@ -1,0 +1,103 @@
+"""Multi-GPU glue: one process per GPU over torch.distributed (backend "nccl" = RCCL on
+ROCm; "gloo" in the CPU tests).
+
+* Rendering shards rays: every rank renders a contiguous, tile-aligned slice of the image's ray list with its own
+  replica of both networks (3 MB).  There is NO collective on the data path; one all_gather of the 16 B/ray result at
+  the end (or none, for throughput runs).
+* Training (what the reference's ddp_train.py does with DistributedDataParallel, ddp_train.py:98): all gradients --
+  fine AND proposal network; the reference leaves the proposal net un-reduced (ddp_train.py:97-99), a deviation noted
+  in DESIGN.md -- are flattened into ONE buffer and reduced with ONE all_reduce per step: 2.98 MB is latency-bound on
+  xGMI, so a single collective beats per-bucket machinery.
+"""
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous [start, end) slice of `n_items` for `rank`; boundaries are multiples of `align` (e.g. the 2500-ray
+    render tile) except the last one.  Slices differ by at most one `align` unit."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    units = (n_items + align - 1) // align
+    base, rem = divmod(units, world)
+    start_u = rank * base + min(rank, rem)
+    end_u = start_u + base + (1 if rank < rem else 0)
+    return min(start_u * align, n_items), min(end_u * align, n_items)
+
+
+def gather_shards(local: torch.Tensor, n_items: int, align: int = 1, group=None) -> torch.Tensor:
+    """all_gather of ragged per-rank slices (dim 0) back into the full (n_items, ...) tensor on every rank."""
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_items, r, world, align) for r in range(world)]
+    longest = max(e - s for s, e in sizes)
+    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[: e - s] for o, (s, e) in zip(out, sizes)], dim=0)
+
+
+def allreduce_gradients(modules: Sequence[torch.nn.Module], group=None, average: bool = True) -> int:
+    """One flat-buffer all_reduce over the gradients of every parameter of `modules` (missing grads count as zero).
+    Returns the number of elements reduced."""
+    params: List[torch.nn.Parameter] = [p for m in modules for p in m.parameters() if p.requires_grad]
+    if not params:
+        return 0
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off: off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return off
+
+
+def broadcast_parameters(modules: Sequence[torch.nn.Module], src: int = 0, group=None) -> None:
+    """Make every rank start from rank `src`'s weights (one flat broadcast)."""
+    params = [p for m in modules for p in m.parameters()]
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off: off + n].view_as(p))
+            off += n
+
+
+def render_image_sharded(network, prop_net, render_pose, image_size, focal, near, far, sample_num=128, white_bkg=False,
+                         render_depth=False, gather: bool = True, seed: int = 0, group=None) -> dict:
+    """Ray-sharded whole-image render: rank r renders rays [start_r, end_r) of the raster-order ray list.  Uniforms
+    are drawn on the device from a per-rank seeded generator (the reference's CPU RNG stream is inherently serial)."""
+    from . import ops
+    from .procedures import RENDER_COARSE_PNUM
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    H, W = (image_size, image_size) if not isinstance(image_size, (tuple, list)) else image_size
+    fx, fy = (float(focal[1]), float(focal[0])) if isinstance(focal, (tuple, list)) else (float(focal), float(focal))
+    dev = render_pose.device
+    n = H * W
+    start, end = shard_range(n, rank, world, align=256)
+    cnt = end - start
+    prec = ops.current_precision()
+    rays = ops.generate_rays(render_pose[:3], H, W, fx, fy, dev, start, cnt)
+    g = torch.Generator(device=dev).manual_seed(seed * 1000003 + rank)
+    u1 = torch.rand((cnt, RENDER_COARSE_PNUM), device=dev, generator=g)
+    u2 = torch.rand((cnt, sample_num + 1), device=dev, generator=g)
+    z_base = torch.linspace(near, far, RENDER_COARSE_PNUM).to(dev)
+    rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u1, u2, sample_num, near, far,
+                                       white_bkg, want_depth=bool(render_depth))
+    if not gather:
+        return {"rgb_rays": rgb, "depth_rays": depth, "range": (start, end)}
+    out = {"rgb": gather_shards(rgb, n, 256, group).view(H, W, 3).permute(2, 0, 1).contiguous()}
+    if render_depth:
+        out["depth_img"] = gather_shards(depth.unsqueeze(-1), n, 256, group).view(1, H, W).expand(3, -1, -1).contiguous()
+    return out

@@ -1,0 +1,85 @@
+"""World-size-2 `gloo` tests (CPU) of the N>1 glue: ray sharding, ragged gather, the single flat-buffer gradient
+all_reduce, parameter broadcast.  No GPU compute is involved."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_amd import parallel
+        from nerf_amd.addtional import ProposalNetwork
+        from nerf_amd.mip_model import MipNeRF
+        torch.manual_seed(100 + rank)                      # different initial weights per rank on purpose
+        mip, prop = MipNeRF(10, 4, 256), ProposalNetwork(10, 256)
+        parallel.broadcast_parameters([mip, prop], src=0)
+        w0 = torch.cat([p.detach().reshape(-1) for p in list(mip.parameters()) + list(prop.parameters())])
+        ws = [torch.empty_like(w0) for _ in range(world)]
+        dist.all_gather(ws, w0)
+        same_weights = all(torch.equal(ws[0], w) for w in ws)
+        # per-rank gradients = rank+1 everywhere; proposal net has one parameter without grad
+        for i, p in enumerate(list(mip.parameters()) + list(prop.parameters())):
+            p.grad = torch.full_like(p, float(rank + 1))
+        prop.layers[8].bias.grad = None
+        n = parallel.allreduce_gradients([mip, prop], average=True)
+        want = sum(range(1, world + 1)) / world
+        ok_grad = all(torch.allclose(p.grad, torch.full_like(p, want)) for p in mip.parameters())
+        # the missing grad counted as zero on every rank -> averaged value 0
+        ok_none = torch.allclose(prop.layers[8].bias.grad, torch.zeros(1))
+        # ragged gather
+        n_items = 1001
+        s, e = parallel.shard_range(n_items, rank, world, align=256)
+        local = torch.arange(s, e, dtype=torch.float32).unsqueeze(-1).repeat(1, 3)
+        full = parallel.gather_shards(local, n_items, 256)
+        ok_gather = torch.equal(full[:, 0], torch.arange(n_items, dtype=torch.float32)) and full.shape == (n_items, 3)
+        q.put((rank, same_weights, n, ok_grad, ok_none, ok_gather))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    from nerf_amd.parallel import shard_range
+    for n in (0, 1, 255, 256, 640000, 640001, 1017):
+        for world in (1, 2, 3, 8):
+            for align in (1, 256, 2500):
+                spans = [shard_range(n, r, world, align) for r in range(world)]
+                assert spans[0][0] == 0 and spans[-1][1] == n
+                assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+                assert all(s % align == 0 for s, _ in spans if s < n)
+                sizes = [e - s for s, e in spans]
+                assert max(sizes) - min(sizes) < 2 * align          # one unit of imbalance + the clipped tail
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+@pytest.mark.timeout(180)
+def test_world_size_2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, same_weights, n, ok_grad, ok_none, ok_gather in res:
+        assert same_weights and ok_grad and ok_none and ok_gather
+        assert n == 530052 + 214017
