@@ -49,6 +49,23 @@ struct PBF16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
     static DEVINL void set(BReg& r, int e, float v) { r[e] = (__bf16)v; }
+    // 8 accumulators -> one B register group.  ReLU is applied AFTER the bf16 conversion as a packed signed-int16
+    // max with 0 (negative floats have the sign bit set): 8 v_cvt_pk + 4 v_pk_max_i16 instead of 8 v_max + ... per group
+    template <bool RELU>
+    static DEVINL BReg from_acc(const f32x16& acc, int off) {
+        BReg r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (__bf16)acc[off + e];
+        if (RELU) {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 v = __builtin_bit_cast(s16x8, r);
+            const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            v = __builtin_elementwise_max(v, zero);
+            r = __builtin_bit_cast(BReg, v);
+        }
+        return r;
+    }
+    static constexpr bool FAST_PE = true;      // octaves by angle doubling (error << bf16 ulp)
     // per-lane LDS stash of one B register group (lane-linear 16-byte slots: conflict-free)
     static constexpr int BREG_LDS = 1024;
     static DEVINL void stash(uint32_t addr, const BReg& r) { *reinterpret_cast<bf16x8*>(smem + addr) = r; }
@@ -77,6 +94,14 @@ struct PF32 {
         return acc;
     }
     static DEVINL void set(BReg& r, int e, float v) { r[e] = v; }
+    template <bool RELU>
+    static DEVINL BReg from_acc(const f32x16& acc, int off) {
+        BReg r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = RELU ? fmaxf(acc[off + e], 0.0f) : acc[off + e];
+        return r;
+    }
+    static constexpr bool FAST_PE = false;     // parity mode: every octave through the exact range reduction
     static constexpr int BREG_LDS = 2048;
     static DEVINL void stash(uint32_t addr, const BReg& r) {
         f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
@@ -254,67 +279,71 @@ struct WeightStream {
 // Alternating accumulators puts a full MFMA between dependent ones.  The stream stores a pair's fragments
 // interleaved (kg-major), so the B registers of K group kg are fetched once and feed both blocks.
 // A single trailing block (odd NFB) splits K over the two accumulators instead and adds them at the end.
-template <class P>
-DEVINL void load_bias(f32x4 (&bias)[4], uint32_t addr) {
+// bias of one 32-row feature block in accumulator layout (acc[r] <- bias[(r&3) + 8(r>>2) + 4h]); it enters the chain
+// as the C operand of the block's first MFMA, so the epilogue needs no adds
+DEVINL f32x16 load_bias(uint32_t addr) {
+    f32x16 v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bias[q] = *reinterpret_cast<const f32x4*>(smem + addr + 32 * q);
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + addr + 32 * q);
+        v[4 * q] = b4[0]; v[4 * q + 1] = b4[1]; v[4 * q + 2] = b4[2]; v[4 * q + 3] = b4[3];
+    }
+    return v;
 }
-template <class P, int NKG, int FRAG0, int KG, class InF>
-DEVINL void pair_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x4 (&bias0)[4], f32x4 (&bias1)[4],
-                   uint32_t bias_addr, InF& in) {
+template <class P, int NKG, int FRAG0, int KG, bool MORE, class InF>
+DEVINL void pair_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)[2], uint32_t next_bias, InF& in) {
     if constexpr (KG < NKG) {
         const typename P::BReg b = in(KG);
         const typename P::AReg a0 = ws.template next<FRAG0 + 2 * KG>();
         acc0 = P::mma(a0, b, acc0);
         const typename P::AReg a1 = ws.template next<FRAG0 + 2 * KG + 1>();
         acc1 = P::mma(a1, b, acc1);
-        if constexpr (KG == (NKG > 3 ? NKG - 3 : 0)) {          // bias reads issued late: short live range, latency
-            load_bias<P>(bias0, bias_addr);                       // still covered by the last MFMAs of the pair
-            load_bias<P>(bias1, bias_addr + 128);
+        if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
+            nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
+            nb[1] = load_bias(next_bias + 128);
         }
-        pair_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, bias0, bias1, bias_addr, in);
+        pair_k<P, NKG, FRAG0, KG + 1, MORE>(ws, acc0, acc1, nb, next_bias, in);
     }
 }
 template <class P, int NKG, int FRAG0, int KG, class InF>
-DEVINL void single_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x4 (&bias0)[4], uint32_t bias_addr, InF& in) {
+DEVINL void single_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, InF& in) {
     if constexpr (KG < NKG) {
         const typename P::AReg a = ws.template next<FRAG0 + KG>();
         if constexpr (KG % 2 == 0) acc0 = P::mma(a, in(KG), acc0);
         else acc1 = P::mma(a, in(KG), acc1);
-        if constexpr (KG == (NKG > 3 ? NKG - 3 : 0)) load_bias<P>(bias0, bias_addr);
-        single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, bias0, bias_addr, in);
+        single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in);
     }
 }
 template <class P, int NKG, int NFB, int START, int G, class InF, class OutF>
-DEVINL void dense_group(WeightStream<P>& ws, uint32_t bias_lds, InF& in, OutF& out) {
+DEVINL void dense_group(WeightStream<P>& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out) {
     if constexpr (2 * G < NFB) {
-        constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        f32x16 acc0 = zero, acc1 = zero;
-        f32x4 bias0[4];
-        const uint32_t bias_addr = bias_lds + (64 * G + 4 * (lane_id() >> 5)) * 4;
         constexpr int FRAG0 = START + 2 * G * NKG;
         if constexpr (2 * G + 1 < NFB) {
-            f32x4 bias1[4];
-            pair_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, bias0, bias1, bias_addr, in);
-#ifndef ABL_NOEPI
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] += bias0[r >> 2][r & 3]; acc1[r] += bias1[r >> 2][r & 3]; }
-#endif
+            f32x16 acc0 = cb[0], acc1 = cb[1];
+            f32x16 nb[2];
+            constexpr bool MORE = 2 * (G + 1) < NFB;
+            pair_k<P, NKG, FRAG0, 0, MORE>(ws, acc0, acc1, nb, bias_lane + 256 * (G + 1), in);
             out(2 * G, acc0);
             out(2 * G + 1, acc1);
+            if constexpr (MORE) dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lane, nb, in, out);
         } else {
-            single_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, bias0, bias_addr, in);
+            constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            f32x16 acc0 = cb[0], acc1 = zero;
+            single_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, in);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = (acc0[r] + acc1[r]) + bias0[r >> 2][r & 3];
+            for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
             out(2 * G, acc0);
         }
-        dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lds, in, out);
     }
 }
 template <class P, int NKG, int NFB, int START, class InF, class OutF>
 DEVINL void dense(WeightStream<P>& ws, uint32_t bias_lds, InF&& in, OutF&& out) {
     static_assert(START % P::DEPTH == 0 && (NKG * NFB) % P::DEPTH == 0, "layers must start on a prefetch-queue boundary");
-    dense_group<P, NKG, NFB, START, 0>(ws, bias_lds, in, out);
+    const uint32_t bias_lane = bias_lds + 16 * (lane_id() >> 5);
+    f32x16 cb[2];
+    cb[0] = load_bias(bias_lane);
+    if constexpr (NFB > 1) cb[1] = load_bias(bias_lane + 128);
+    dense_group<P, NKG, NFB, START, 0>(ws, bias_lane, cb, in, out);
 }
 
 // accumulators of feature block fb -> B registers of K groups 2fb, 2fb+1 of the next layer
@@ -327,13 +356,8 @@ DEVINL void to_breg(const f32x16& acc, typename P::BReg& lo, typename P::BReg& h
         return;
     }
 #endif
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float a = acc[e], b = acc[8 + e];
-        if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
-        P::set(lo, e, a);
-        P::set(hi, e, b);
-    }
+    lo = P::template from_acc<RELU>(acc, 0);
+    hi = P::template from_acc<RELU>(acc, 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,6 +365,32 @@ DEVINL void to_breg(const f32x16& acc, typename P::BReg& lo, typename P::BReg& h
 // ------------------------------------------------------------------------------------------------
 template <class P, int L, int NKG>
 DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG]) {
+    if constexpr (P::FAST_PE) {
+        // bf16 mode: octave 0 through the exact reduction, octaves 1..L-1 by angle doubling
+        // (sin 2a = 2 s c, cos 2a = 1 - 2 s^2).  The error doubles per octave: <= 2^9 * 1e-7 = 5e-5 << bf16 ulp (4e-3).
+        float sv[3] = {sin_quadrant(x, 0), sin_quadrant(y, 0), sin_quadrant(z, 0)};
+        float cv[3] = {sin_quadrant(x, 1), sin_quadrant(y, 1), sin_quadrant(z, 1)};
+#pragma unroll
+        for (int f = 0; f < L; ++f) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int q = 3 * f + c;
+                P::set(B[q >> 3], q & 7, h ? cv[c] : sv[c]);
+                if (f + 1 < L) {
+                    const float s2 = 2.0f * sv[c];
+                    const float ns = s2 * cv[c];
+                    const float nc = __builtin_fmaf(-s2, sv[c], 1.0f);
+                    sv[c] = ns; cv[c] = nc;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 3 * L; q < 8 * NKG; ++q) {
+            const float v = (q == 3 * L) ? (h ? z : x) : ((q == 3 * L + 1) ? (h ? 0.0f : y) : 0.0f);
+            P::set(B[q >> 3], q & 7, v);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8 * NKG; ++q) {
         float v;
