@@ -565,14 +565,11 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = b[k];
         }
-        // bottle_neck.0 (rows 0..255, no activation) + opacity_head.0 (row 256)
+        // opacity_head.0 : 256 -> 1 (raw sigma)
         float sigma = 0.0f;
-        dense<P, 16, 9, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4,
+        dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4,
             [&](int kg) -> BReg { return a[kg]; },
-            [&](int fb, const f32x16& acc) {
-                if (fb < 8) to_breg<P, false>(acc, b[2 * (fb < 8 ? fb : 0)], b[2 * (fb < 8 ? fb : 0) + 1]);
-                else sigma = acc[0];
-            });
+            [&](int, const f32x16& acc) { sigma = acc[0]; });
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
         BReg denc[2];
         {
@@ -580,10 +577,10 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             const float nrm = norm3(dv[0], dv[1], dv[2]);
             encode<P, 4, 2>(dv[0] / nrm, dv[1] / nrm, dv[2] / nrm, h, denc);
         }
-        // rgb_layer.0 : cat(bottleneck 256, dir 27) -> 128, ReLU
+        // rgb_layer.0 with bottle_neck.0 folded in (mlp_layout.h): cat(g 256, dir 27) -> 128, ReLU
         BReg c[8];
         dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
-            [&](int kg) -> BReg { if (kg < 16) return b[kg < 16 ? kg : 0]; return denc[kg >= 16 ? kg - 16 : 0]; },
+            [&](int kg) -> BReg { if (kg < 16) return a[kg < 16 ? kg : 0]; return denc[kg >= 16 ? kg - 16 : 0]; },
             [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, c[2 * fb], c[2 * fb + 1]); });
         // rgb_layer.2 : 128 -> 3, sigmoid
         float r = 0.0f, g = 0.0f, bl = 0.0f;

@@ -9,12 +9,13 @@ namespace {
 enum { SEG_DMAP = 0, SEG_PE = 1 };
 
 struct PackLayer {
-    const float* w[2];      // up to two row segments (e.g. bottle_neck rows 0..255, opacity_head row 256)
-    const float* b[2];
-    int rows[2];
-    int in_features;        // row stride of both matrices
+    const float* b;         // bias (rows)
+    int rows;               // real output rows (the rest of the 32*nfb rows are zero)
     int nkg, nfb;
     int frag_start, bias_off;
+    // up to two K segments, each reading its own matrix: kind, #K groups, first column, PE levels, valid width
+    const float* seg_w[2];
+    int seg_stride[2];
     int seg_kind[2], seg_nkg[2], seg_col[2], seg_L[2], seg_width[2];
 };
 
@@ -35,34 +36,43 @@ __global__ void pack_layer_kernel(PackLayer L, char* __restrict__ stream, float*
         int col = (L.seg_kind[seg] == SEG_PE) ? pe_slot_column(8 * lkg + e, h, L.seg_L[seg]) : dmap_feature(lkg, h, e);
         if (col >= L.seg_width[seg]) col = -1;
         float v = 0.0f;
-        if (col >= 0) {
-            col += L.seg_col[seg];
-            if (row < L.rows[0]) v = L.w[0][(size_t)row * L.in_features + col];
-            else if (row < L.rows[0] + L.rows[1]) v = L.w[1][(size_t)(row - L.rows[0]) * L.in_features + col];
-        }
+        if (col >= 0 && row < L.rows) v = L.seg_w[seg][(size_t)row * L.seg_stride[seg] + L.seg_col[seg] + col];
         const size_t f = (size_t)(L.frag_start + frag);
         if (BF16) reinterpret_cast<__bf16*>(stream + f * 1024)[lane * 8 + e] = (__bf16)v;
         else reinterpret_cast<float*>(stream + f * 2048)[(e >> 2) * 256 + lane * 4 + (e & 3)] = v;
     }
     const int n_b = 32 * L.nfb;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += gridDim.x * blockDim.x) {
-        float v = 0.0f;
-        if (i < L.rows[0]) v = L.b[0][i];
-        else if (i < L.rows[0] + L.rows[1]) v = L.b[1][i - L.rows[0]];
-        bias[L.bias_off + i] = v;
+        bias[L.bias_off + i] = (i < L.rows) ? L.b[i] : 0.0f;
     }
 }
 
 PackLayer make_layer(const float* w, const float* b, int rows, int in_f, int nkg, int nfb, int start, int bias_off) {
     PackLayer L{};
-    L.w[0] = w; L.b[0] = b; L.rows[0] = rows; L.w[1] = nullptr; L.b[1] = nullptr; L.rows[1] = 0;
-    L.in_features = in_f; L.nkg = nkg; L.nfb = nfb; L.frag_start = start; L.bias_off = bias_off;
-    L.seg_kind[0] = SEG_DMAP; L.seg_nkg[0] = nkg; L.seg_col[0] = 0; L.seg_L[0] = 0; L.seg_width[0] = 16 * nkg;
-    L.seg_kind[1] = SEG_DMAP; L.seg_nkg[1] = 0; L.seg_col[1] = 0; L.seg_L[1] = 0; L.seg_width[1] = 0;
+    L.b = b; L.rows = rows; L.nkg = nkg; L.nfb = nfb; L.frag_start = start; L.bias_off = bias_off;
+    L.seg_w[0] = w; L.seg_stride[0] = in_f; L.seg_kind[0] = SEG_DMAP; L.seg_nkg[0] = nkg; L.seg_col[0] = 0; L.seg_L[0] = 0;
+    L.seg_width[0] = 16 * nkg;
+    L.seg_w[1] = w; L.seg_stride[1] = in_f; L.seg_kind[1] = SEG_DMAP; L.seg_nkg[1] = 0; L.seg_col[1] = 0; L.seg_L[1] = 0;
+    L.seg_width[1] = 0;
     return L;
 }
 void set_seg(PackLayer& L, int s, int kind, int nkg, int col, int pe_L, int width) {
     L.seg_kind[s] = kind; L.seg_nkg[s] = nkg; L.seg_col[s] = col; L.seg_L[s] = pe_L; L.seg_width[s] = width;
+}
+
+// fold bottle_neck into rgb_layer.0:  Wf (128,256) = W8[:, :256] @ Wb,  bf (128) = W8[:, :256] @ bb + b8   (fp32)
+__global__ void fold_bottleneck_kernel(const float* __restrict__ w8, const float* __restrict__ b8, const float* __restrict__ wb,
+                                       const float* __restrict__ bb, float* __restrict__ wf, float* __restrict__ bf) {
+    const int i = blockIdx.x;                        // output row 0..127
+    const int j = threadIdx.x;                       // output column 0..255
+    float acc = 0.0f;
+    for (int k = 0; k < 256; ++k) acc = __builtin_fmaf(w8[i * 283 + k], wb[k * 256 + j], acc);
+    wf[i * 256 + j] = acc;
+    if (j == 0) {
+        float s = 0.0f;
+        for (int k = 0; k < 256; ++k) s = __builtin_fmaf(w8[i * 283 + k], bb[k], s);
+        bf[i] = s + b8[i];
+    }
 }
 
 int launch_pack(const PackLayer& L, int precision, char* stream, float* bias, hipStream_t st) {
@@ -94,17 +104,24 @@ int pack_mip(int precision, const float* const* w, const float* const* b, void* 
     using Lay = MipLayout;
     char* stream = reinterpret_cast<char*>(packed);
     float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    float* wf = bias + Lay::N_BIAS;                  // (128,256) folded weight, then (128) folded bias
+    float* bf = wf + 128 * 256;
     // tensors: 0..3 lin_block1.{0,2,4,6}; 4..6 lin_block2.{0,2,4}; 7 bottle_neck.0; 8 opacity_head.0; 9,10 rgb_layer.{0,2}
-    const int tensor_of[10] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 10};
-    const int rows[10] = {256, 256, 256, 256, 256, 256, 256, 256, 128, 3};
-    const int inf[10] = {63, 256, 256, 256, 319, 256, 256, 256, 283, 128};
+    hipLaunchKernelGGL(fold_bottleneck_kernel, dim3(128), dim3(256), 0, st, w[9], b[9], w[7], b[7], wf, bf);
+    if (int e = (int)hipGetLastError()) return e;
+    const float* lw[10] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[8], wf, w[10]};
+    const float* lb[10] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[8], bf, b[10]};
+    const int rows[10] = {256, 256, 256, 256, 256, 256, 256, 1, 128, 3};
+    const int inf[10] = {63, 256, 256, 256, 319, 256, 256, 256, 256, 128};
     for (int l = 0; l < 10; ++l) {
-        const int t = tensor_of[l];
-        PackLayer L = make_layer(w[t], b[t], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        PackLayer L = make_layer(lw[l], lb[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
         if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
         if (l == 4) { set_seg(L, 0, SEG_PE, 4, 0, 10, 63); set_seg(L, 1, SEG_DMAP, 16, 63, 0, 256); }
-        if (l == 7) { L.w[1] = w[8]; L.b[1] = b[8]; L.rows[1] = 1; }
-        if (l == 8) { set_seg(L, 0, SEG_DMAP, 16, 0, 0, 256); set_seg(L, 1, SEG_PE, 2, 256, 4, 27); }
+        if (l == 8) {                                 // K = [folded 256 | direction encoding 27 from rgb_layer.0[:, 256:]]
+            set_seg(L, 0, SEG_DMAP, 16, 0, 0, 256);
+            set_seg(L, 1, SEG_PE, 2, 256, 4, 27);
+            L.seg_w[1] = w[9]; L.seg_stride[1] = 283;
+        }
         int e = launch_pack(L, precision, stream, bias, st);
         if (e) return e;
     }
