@@ -38,6 +38,7 @@ extern "C" {
 /* which network a packed weight blob belongs to */
 #define NERF_AMD_NET_PROPOSAL 0    /* ProposalNetwork(10, 256)        addtional.py:53-96  */
 #define NERF_AMD_NET_MIP      1    /* MipNeRF(10, 4, 256)             mip_model.py:14-60  */
+#define NERF_AMD_NET_REF      2    /* RefNeRF(10, 4, 128, 256, 256)   ref_model.py:16-66  */
 
 /* density activation applied inside sigma->alpha (nerf_base.py:82 `density_act`) */
 #define NERF_AMD_ACT_RELU     0
@@ -88,6 +89,12 @@ typedef struct nerf_amd_samples {
  *   proposal: layers.{0,2,4,6,8}                                   (addtional.py:67-71)
  *   mip     : lin_block1.{0,2,4,6}, lin_block2.{0,2,4}, bottle_neck.0, opacity_head.0,
  *             rgb_layer.{0,2}                                        (mip_model.py:19-37)
+ *   ref     : spa_block1.{0,2,4,6}, spa_block2.{0,2,4,6}, bottle_neck, heads, dir_block1.{0,2,4,6},
+ *             dir_block2.{0,2,4,6}, spec_rgb_head.0, ide_table                       (ref_model.py:31-62)
+ *             where `heads` is the (11,256) row-concatenation [norm_col_tint_head[0:3], rho_tau_head[0:1],
+ *             norm_col_tint_head[3:6], rho_tau_head[1:2], norm_col_tint_head[6:9]] (+ its (11) bias), and
+ *             `ide_table` is the (9,19) fp32 coefficient matrix of ref_func.py:60-74 passed in the `weights`
+ *             slot (its `biases` slot is ignored and may repeat any valid pointer).
  * `weights` / `biases` are HOST arrays of DEVICE pointers in that order.
  * ------------------------------------------------------------------------------------------------ */
 size_t nerf_amd_packed_bytes(int net, int precision);
@@ -100,6 +107,11 @@ int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_
 /* MipNeRF.forward (mip_model.py:41-60): rgbo (M, 4) = [sigmoid rgb | raw sigma]. */
 int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src,
                          float* rgbo, void* stream);
+
+/* RefNeRF.forward in eval mode, use_srgb=False (ref_model.py:68-106): rgbo (M,4) = [rgb | raw density],
+ * normal (M,3) (NULL to skip).  Samples need a direction (pts_stride >= 6 in mode 0). */
+int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src,
+                         float* rgbo, float* normal, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling / compositing kernels (one 64-lane wavefront per ray; HBM-bound).
@@ -152,10 +164,11 @@ int nerf_amd_resample(const float* density, const float* z, const float* z_base,
                       float* z_fine, int64_t* below, float* w_prop, float* z_coarse, void* stream);
 
 /* NeRF.render (nerf_base.py:91-113).  rgbo (N,S,4), z (N,z_stride) [first S used], dirs as above.
- * flags: bit0 mul_norm, bit1 white_bkg.  Outputs: rgb (N,3), weights (N,S) or NULL, depth (N) or NULL
+ * flags: bit0 mul_norm, bit1 white_bkg.  density = act(sigma + sigma_shift) (sigma_shift 0.5 + softplus is
+ * the Ref-NeRF render path, procedures.py:74).  Outputs: rgb (N,3), weights (N,S) or NULL, depth (N) or NULL
  * ((sum w z - near)/(far-near)), normal_img (N) or NULL when normal (N,S,3) and cam_dir (3, device) given. */
 int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride,
-                       int64_t N, int S, int flags, int act, float near, float far,
+                       int64_t N, int S, int flags, int act, float sigma_shift, float near, float far,
                        const float* normal, const float* cam_dir,
                        float* rgb, float* weights, float* depth, float* normal_img, void* stream);
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")   # env override: diagnostic builds only
 
 F32, BF16 = 0, 1
-NET_PROPOSAL, NET_MIP = 0, 1
+NET_PROPOSAL, NET_MIP, NET_REF = 0, 1, 2
 ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS = 0, 1, 2
 
 c_float_p = C.POINTER(C.c_float)
@@ -36,6 +36,7 @@ SIGNATURES = {
     "nerf_amd_pack_weights": (C.c_int, [C.c_int, C.c_int, C.POINTER(c_void), C.POINTER(c_void), C.c_int, c_void, c_void]),
     "nerf_amd_proposal_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void]),
     "nerf_amd_mip_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void]),
+    "nerf_amd_ref_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void]),
     "nerf_amd_positional_encoding": (C.c_int, [c_void, i64, C.c_int, c_void, c_void]),
     "nerf_amd_generate_rays": (C.c_int, [c_float_p, C.c_int, C.c_int, C.c_float, C.c_float, i64, i64, c_void, c_void]),
     "nerf_amd_length2pts": (C.c_int, [c_void, c_void, i64, C.c_int, c_void, c_void]),
@@ -47,7 +48,7 @@ SIGNATURES = {
     "nerf_amd_stratified_points": (C.c_int, [c_void, c_void, c_void, C.c_float, i64, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_resample": (C.c_int, [c_void, c_void, c_void, c_void, C.c_float, c_void, C.c_int, c_void, i64, C.c_int,
                                     C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
-    "nerf_amd_composite": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float,
+    "nerf_amd_composite": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_get_bounds": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_render_workspace_bytes": (C.c_size_t, [i64, C.c_int]),

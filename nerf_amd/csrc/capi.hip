@@ -9,6 +9,8 @@
 // launchers defined in the kernel translation units
 int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
+int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, hipStream_t);
+int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
@@ -21,7 +23,7 @@ int sk_pixel_rays(const float*, float, float, const int64_t*, int64_t, float*, h
 int sk_stratified_points(const float*, const float*, const float*, float, int64_t, int, float*, float*, hipStream_t);
 int sk_resample(const float*, const float*, const float*, const float*, float, const float*, int, const float*, int64_t, int,
                 int, int, float, float*, int64_t*, float*, float*, hipStream_t);
-int sk_composite(const float*, const float*, int, const float*, int, int64_t, int, int, int, float, float, const float*,
+int sk_composite(const float*, const float*, int, const float*, int, int64_t, int, int, int, float, float, float, const float*,
                  const float*, float*, float*, float*, float*, hipStream_t);
 int sk_get_bounds(const float*, const int64_t*, int64_t, int, int, float*, hipStream_t);
 
@@ -78,6 +80,7 @@ size_t nerf_amd_packed_bytes(int net, int precision) {
     if (bad_prec(precision)) return 0;
     if (net == NERF_AMD_NET_PROPOSAL) return PropLayout::packed_bytes(precision);
     if (net == NERF_AMD_NET_MIP) return MipLayout::packed_bytes(precision);
+    if (net == NERF_AMD_NET_REF) return RefLayout::packed_bytes(precision);
     return 0;
 }
 
@@ -85,13 +88,14 @@ int nerf_amd_pack_weights(int net, int precision, const float* const* weights, c
                           void* packed, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (!weights || !biases || !packed) return fail(NERF_AMD_EINVAL, "NULL argument");
-    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : -1);
+    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
     if (want < 0) return fail(NERF_AMD_EINVAL, "unknown network");
     if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
     for (int i = 0; i < want; ++i)
         if (!weights[i] || !biases[i]) return fail(NERF_AMD_EINVAL, "NULL weight or bias tensor");
     const int e = net == NERF_AMD_NET_PROPOSAL ? pack_proposal(precision, weights, biases, packed, S(stream))
-                                               : pack_mip(precision, weights, biases, packed, S(stream));
+                  : (net == NERF_AMD_NET_MIP ? pack_mip(precision, weights, biases, packed, S(stream))
+                                             : pack_ref(precision, weights, biases, packed, S(stream)));
     return hip_status(e, "nerf_amd_pack_weights");
 }
 
@@ -109,6 +113,14 @@ int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_sampl
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(mlp_launch_mip(packed, precision, *src, rgbo, S(stream)), "nerf_amd_mip_forward");
+}
+
+int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, float* normal, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (int c = check_samples(src, true)) return c;
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, S(stream)), "nerf_amd_ref_forward");
 }
 
 int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, void* stream) {
@@ -180,13 +192,13 @@ int nerf_amd_resample(const float* density, const float* z, const float* z_base,
 }
 
 int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int Sn,
-                       int flags, int act, float near, float far, const float* normal, const float* cam_dir, float* rgb,
+                       int flags, int act, float sigma_shift, float near, float far, const float* normal, const float* cam_dir, float* rgb,
                        float* weights, float* depth, float* normal_img, void* stream) {
     if (N < 0 || Sn < 1 || act < 0 || act > 2 || z_stride < Sn) return fail(NERF_AMD_EINVAL, "bad size, stride or activation");
     if (N && (!rgbo || !z || !dirs || !rgb)) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (normal_img && !(normal && cam_dir)) return fail(NERF_AMD_EINVAL, "normal_img needs normal and cam_dir");
-    return hip_status(sk_composite(rgbo, z, z_stride, dirs, dirs_stride, N, Sn, flags, act, near, far, normal, cam_dir, rgb,
-                                   weights, depth, normal_img, S(stream)), "nerf_amd_composite");
+    return hip_status(sk_composite(rgbo, z, z_stride, dirs, dirs_stride, N, Sn, flags, act, sigma_shift, near, far, normal, cam_dir,
+                                   rgb, weights, depth, normal_img, S(stream)), "nerf_amd_composite");
 }
 
 int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream) {
@@ -245,7 +257,7 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     sf.mode = 1; sf.rays = rays; sf.S = n_fine; sf.M = N * n_fine; sf.z = z_fine; sf.z_stride = n_fine + 1;
     if (int e = mlp_launch_mip(packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");
     const int flags = 1 | (white_bkg ? 2 : 0);              // row 10
-    if (int e = sk_composite(rgbo, z_fine, n_fine + 1, rays + 3, 6, N, n_fine, flags, NERF_AMD_ACT_RELU, near, far, nullptr,
+    if (int e = sk_composite(rgbo, z_fine, n_fine + 1, rays + 3, 6, N, n_fine, flags, NERF_AMD_ACT_RELU, 0.0f, near, far, nullptr,
                              nullptr, rgb, weights, depth, nullptr, st)) return hip_status(e, "composite");
     return NERF_AMD_OK;
 }

@@ -118,7 +118,7 @@ struct PF32 {
 // ------------------------------------------------------------------------------------------------
 // weight stream: L2 -> LDS ring, consumed in lock step by all wavefronts of the workgroup
 // ------------------------------------------------------------------------------------------------
-template <class P>
+template <class P, int NSLOT = MLP_NSLOT>
 struct WeightStream {
     static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk
     const char* src;        // packed stream + this lane's offset inside a chunk
@@ -156,7 +156,7 @@ struct WeightStream {
 #endif
         }
         load_idx = (load_idx + 1 == n_chunks) ? 0u : load_idx + 1;
-        load_slot = (load_slot + 1) & (MLP_NSLOT - 1);
+        load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
     }
     // Synchronisation protocol (all code is branch-free; the only conditional instruction is the s_barrier itself):
     //   * chunk boundary i = the moment a wave's register prefetch enters chunk i.  At EVERY boundary a wave waits
@@ -167,12 +167,13 @@ struct WeightStream {
     //     barriers (2 chunks) each has slack to overlap its VALU epilogue with the partner's MFMA run.
     //   * invariants after barrier b: chunks <= 2b+2 are completely in LDS (every wave waited for its pieces);
     //     every wave holds chunks <= 2b-1 in registers, so those ring slots may be refilled.  Early waves issue chunk
-    //     i+6 at boundary i, late waves chunk i+5: both groups issue the same chunk within the same barrier interval.
-    static constexpr int INFLIGHT = 3 * LPW;
+    //     i+NSLOT-2 at boundary i, late waves chunk i+NSLOT-3: both groups issue the same chunk within the same barrier
+    //     interval, and NSLOT-5 chunks per wave stay in flight across every wait.
+    static constexpr int INFLIGHT = (NSLOT - 5) * LPW;
     uint32_t late;
 
     DEVINL void init(const void* packed, uint32_t nchunks) {
-        static_assert(MLP_NSLOT == 8, "protocol below is written for an 8-slot ring");
+        static_assert(NSLOT >= 6, "the protocol needs at least 6 ring slots");
         const int lane = lane_id();
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         src = reinterpret_cast<const char*>(packed) + (size_t)wave * LPW * 1024 + lane * 16;
@@ -183,7 +184,7 @@ struct WeightStream {
         cur = lane * 16;
         late = __builtin_amdgcn_readfirstlane((P::NW > 4 && wave >= P::NW / 2) ? 1 : 0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) issue();                                 // chunks 0..5
+        for (int i = 0; i < NSLOT - 2; ++i) issue();                         // chunks 0 .. NSLOT-3
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my pieces of chunks 0..2 have landed ...
         __builtin_amdgcn_s_barrier();                                        // ... and everybody else's
         asm volatile("" ::: "memory");
@@ -196,7 +197,7 @@ struct WeightStream {
         if (!late) {                                                         // boundary 0 of the early waves
             __builtin_amdgcn_s_barrier();                                    // barrier 0 (late waves: at their boundary 1)
             asm volatile("" ::: "memory");
-            issue();                                                         // chunk 6
+            issue();                                                         // chunk NSLOT-2
         }
     }
     // Fragment F of the stream (compile-time index, F mod DEPTH == queue slot): hand out its registers and
@@ -212,7 +213,7 @@ struct WeightStream {
             constexpr int G = F + P::DEPTH;
             static_assert(P::FPC % P::DEPTH == 0, "a group may not straddle chunks");
             if (G % P::FPC == 0) {
-                cur_slot = (cur_slot + 1) & (MLP_NSLOT - 1);
+                cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
                 cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
                 boundary<(G / P::FPC) & 1>();
             }
@@ -234,7 +235,7 @@ struct WeightStream {
         const typename P::AReg a = q[F % P::DEPTH];
         constexpr int G = F + P::DEPTH;
         if (G % P::FPC == 0) {
-            cur_slot = (cur_slot + 1) & (MLP_NSLOT - 1);
+            cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
             cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
             boundary<(G / P::FPC) & 1>();
         }
@@ -290,8 +291,8 @@ DEVINL f32x16 load_bias(uint32_t addr) {
     }
     return v;
 }
-template <class P, int NKG, int FRAG0, int KG, bool MORE, class InF>
-DEVINL void pair_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)[2], uint32_t next_bias, InF& in) {
+template <class P, int NKG, int FRAG0, int KG, bool MORE, class WS, class InF>
+DEVINL void pair_k(WS& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)[2], uint32_t next_bias, InF& in) {
     if constexpr (KG < NKG) {
         const typename P::BReg b = in(KG);
         const typename P::AReg a0 = ws.template next<FRAG0 + 2 * KG>();
@@ -305,8 +306,8 @@ DEVINL void pair_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)
         pair_k<P, NKG, FRAG0, KG + 1, MORE>(ws, acc0, acc1, nb, next_bias, in);
     }
 }
-template <class P, int NKG, int FRAG0, int KG, class InF>
-DEVINL void single_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, InF& in) {
+template <class P, int NKG, int FRAG0, int KG, class WS, class InF>
+DEVINL void single_k(WS& ws, f32x16& acc0, f32x16& acc1, InF& in) {
     if constexpr (KG < NKG) {
         const typename P::AReg a = ws.template next<FRAG0 + KG>();
         if constexpr (KG % 2 == 0) acc0 = P::mma(a, in(KG), acc0);
@@ -314,8 +315,8 @@ DEVINL void single_k(WeightStream<P>& ws, f32x16& acc0, f32x16& acc1, InF& in) {
         single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in);
     }
 }
-template <class P, int NKG, int NFB, int START, int G, class InF, class OutF>
-DEVINL void dense_group(WeightStream<P>& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out) {
+template <class P, int NKG, int NFB, int START, int G, class WS, class InF, class OutF>
+DEVINL void dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out) {
     if constexpr (2 * G < NFB) {
         constexpr int FRAG0 = START + 2 * G * NKG;
         if constexpr (2 * G + 1 < NFB) {
@@ -336,8 +337,8 @@ DEVINL void dense_group(WeightStream<P>& ws, uint32_t bias_lane, f32x16 (&cb)[2]
         }
     }
 }
-template <class P, int NKG, int NFB, int START, class InF, class OutF>
-DEVINL void dense(WeightStream<P>& ws, uint32_t bias_lds, InF&& in, OutF&& out) {
+template <class P, int NKG, int NFB, int START, class WS, class InF, class OutF>
+DEVINL void dense(WS& ws, uint32_t bias_lds, InF&& in, OutF&& out) {
     static_assert(START % P::DEPTH == 0 && (NKG * NFB) % P::DEPTH == 0, "layers must start on a prefetch-queue boundary");
     const uint32_t bias_lane = bias_lds + 16 * (lane_id() >> 5);
     f32x16 cb[2];
@@ -452,9 +453,9 @@ constexpr uint32_t LDS_STASH = MLP_RING_BYTES + 9216;                 // bias ta
 template <class P> constexpr uint32_t lds_dir() { return LDS_STASH + P::NW * 4 * P::BREG_LDS; }
 template <class P> constexpr uint32_t lds_total() { return lds_dir<P>() + P::NW * 1024; }
 
-DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias) {
+DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias, uint32_t lds_off = MLP_RING_BYTES) {
     const float* b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + stream_bytes);
-    float* dst = reinterpret_cast<float*>(smem + MLP_RING_BYTES);
+    float* dst = reinterpret_cast<float*>(smem + lds_off);
     for (int i = threadIdx.x; i < n_bias; i += blockDim.x) dst[i] = b[i];
     __syncthreads();
 }
@@ -599,6 +600,174 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     ws.drain();
 }
 
+
+// ================================================================================================
+// RefNeRF (ref_model.py:68-106, eval mode, use_srgb = False)
+// ================================================================================================
+constexpr uint32_t REF_LDS_BIAS = MLP_CHUNK_BYTES * MLP_NSLOT_REF;
+constexpr uint32_t REF_LDS_STASH = REF_LDS_BIAS + RefLayout::N_BIAS * 4;          // 16-byte aligned (4288 floats)
+template <class P> constexpr uint32_t ref_lds_total() { return REF_LDS_STASH + P::NW * 11 * P::BREG_LDS; }
+
+// Integrated directional encoding (ref_func.py:76-108) of the reflected direction, straight into B-operand slots:
+// lane half 0 produces the real parts, half 1 the imaginary parts of the 19 (m,l) terms; slot 19 of half 0 = n.d
+template <class P>
+DEVINL void ide_encode(float x, float y, float z, float kappa_inv, float nv_dot, int h, const float* __restrict__ mat,
+                       typename P::BReg (&out)[3]) {
+    constexpr int TM[19] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 6, 7, 8};
+    constexpr int TL[19] = {1, 1, 2, 2, 2, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+    float zp[9], re[9], im[9];
+    zp[0] = 1.0f; re[0] = 1.0f; im[0] = 0.0f;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) {
+        zp[k] = zp[k - 1] * z;
+        re[k] = re[k - 1] * x - im[k - 1] * y;
+        im[k] = re[k - 1] * y + im[k - 1] * x;
+    }
+    const float att1 = expf(-1.0f * kappa_inv), att2 = expf(-3.0f * kappa_inv), att4 = expf(-10.0f * kappa_inv),
+                att8 = expf(-36.0f * kappa_inv);                                   // sigma_l = l(l+1)/2
+#pragma unroll
+    for (int t = 0; t < 19; ++t) {
+        const int m = TM[t], l = TL[t];
+        float poly = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= l - m; ++k) poly = __builtin_fmaf(mat[k * 19 + t], zp[k], poly);
+        const float att = (l == 1) ? att1 : ((l == 2) ? att2 : ((l == 4) ? att4 : att8));
+        const float v = ((h ? im[m] : re[m]) * poly) * att;
+        P::set(out[t >> 3], t & 7, v);
+    }
+    P::set(out[2], 3, h ? 0.0f : nv_dot);
+#pragma unroll
+    for (int e = 4; e < 8; ++e) P::set(out[2], e, 0.0f);
+}
+
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict__ packed, nerf_amd_samples s,
+                                                         float* __restrict__ rgbo, float* __restrict__ normal_out) {
+    using L = RefLayout;
+    using BReg = typename P::BReg;
+    constexpr int FPC = P::FPC;
+    load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS, REF_LDS_BIAS);
+    const float* ide_mat = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + L::stream_bytes(P::PREC)) + L::N_BIAS;
+    WeightStream<P, MLP_NSLOT_REF> ws;
+    ws.init(packed, L::N_FRAGS / FPC);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    constexpr int TS = P::NW * 32;
+    const int64_t n_tiles = (s.M + TS - 1) / TS;
+    const uint32_t bias0 = REF_LDS_BIAS;
+    const uint32_t stash = REF_LDS_STASH + wave * 11 * P::BREG_LDS + lane * 16;       // 11 per-wave blocks of one K group each
+    const uint32_t dir_lds = stash + 10 * P::BREG_LDS;                                 // block 10 doubles as the direction slot
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t m = tile * TS + wave * 32 + j;
+        BReg a[16], b[16];
+        {
+            const Sample sm = fetch_sample(s, m < s.M ? m : s.M - 1, true);
+            BReg enc[4];
+            encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P::stash(stash + k * P::BREG_LDS, enc[k]);
+            f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
+            *reinterpret_cast<f32x4*>(smem + dir_lds) = dv;
+            dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                      // spa_block1.0
+                [&](int kg) -> BReg { return enc[kg]; },
+                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+        }
+#pragma unroll 1
+        for (int l = 1; l <= 3; ++l) {                                                        // spa_block1.{2,4,6}
+            dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
+                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = b[k];
+        }
+        dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                          // spa_block2.0 (skip)
+            [&](int kg) -> BReg { if (kg < 4) return P::unstash(stash + kg * P::BREG_LDS); return a[kg >= 4 ? kg - 4 : 0]; },
+            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = b[k];
+#pragma unroll 1
+        for (int l = 5; l <= 7; ++l) {                                                        // spa_block2.{2,4,6}
+            dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
+                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = b[k];
+        }
+        // heads: bottle_neck (4 blocks, no activation) + [normal | roughness || diffuse | density || tint]
+        BReg bn[8];
+        f32x16 hd;
+        dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
+            [&](int kg) -> BReg { return a[kg]; },
+            [&](int fb, const f32x16& acc) {
+                if (fb < 4) to_breg<P, false>(acc, bn[2 * (fb < 4 ? fb : 0)], bn[2 * (fb < 4 ? fb : 0) + 1]);
+                else hd = acc;
+            });
+        // half 0 holds rows 0-3 (normal, roughness) in hd[0..3] and rows 8-10 (tint) in hd[4..6]; half 1 rows 4-7 (diffuse, density) in hd[0..3]
+        float keep[4];
+        BReg ide[3];
+        {
+            const float nx0 = __shfl(hd[0], j, 64), ny0 = __shfl(hd[1], j, 64), nz0 = __shfl(hd[2], j, 64);
+            const float rough = softplus_f(__shfl(hd[3], j, 64) - 1.0f);                      // ref_model.py:82
+            const float nn = norm3(nx0, ny0, nz0) + 1e-7f;                                    // ref_model.py:87
+            const float nx = -nx0 / nn, ny = -ny0 / nn, nz = -nz0 / nn;
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds);
+            const float dot = (dv[0] * nx + dv[1] * ny) + dv[2] * nz;
+            const float t2 = 2.0f * dot;
+            const float rx = dv[0] - t2 * nx, ry = dv[1] - t2 * ny, rz = dv[2] - t2 * nz;    // ref_model.py:90
+            ide_encode<P>(rx, ry, rz, rough, dot, h, ide_mat, ide);
+            if (normal_out && h == 0 && m < s.M) { normal_out[m * 3] = nx; normal_out[m * 3 + 1] = ny; normal_out[m * 3 + 2] = nz; }
+            keep[0] = h ? hd[0] : hd[4]; keep[1] = h ? hd[1] : hd[5]; keep[2] = h ? hd[2] : hd[6]; keep[3] = hd[3];
+        }
+        // all_inputs = [bottle_neck 128 | ide 38 | n.d]: needed again by dir_block2.0 -> park in the stash (blocks 0..10)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) P::stash(stash + k * P::BREG_LDS, bn[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P::stash(stash + (8 + k) * P::BREG_LDS, ide[k]);
+        dense<P, 11, 8, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,                          // dir_block1.0
+            [&](int kg) -> BReg { if (kg < 8) return bn[kg < 8 ? kg : 0]; return ide[kg >= 8 ? kg - 8 : 0]; },
+            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+#pragma unroll 1
+        for (int l = 10; l <= 12; ++l) {                                                      // dir_block1.{2,4,6}
+            dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + (l - 10) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
+                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = b[k];
+        }
+        dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                        // dir_block2.0 (skip)
+            [&](int kg) -> BReg { if (kg < 11) return P::unstash(stash + kg * P::BREG_LDS); return a[kg >= 11 ? kg - 11 : 0]; },
+            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = b[k];
+#pragma unroll 1
+        for (int l = 14; l <= 16; ++l) {                                                      // dir_block2.{2,4,6}
+            dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + (l - 14) * 256) * 4,
+                [&](int kg) -> BReg { return a[kg]; },
+                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = b[k];
+        }
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+        dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4,                        // spec_rgb_head.0
+            [&](int kg) -> BReg { return a[kg]; },
+            [&](int, const f32x16& acc) { sr = acc[0]; sg = acc[1]; sb = acc[2]; });
+        // half 1's keep[] = (diffuse, density); fetch it into half 0, which holds spec and tint (ref_model.py:98-105)
+        const float d0 = __shfl(keep[0], j + 32, 64), d1 = __shfl(keep[1], j + 32, 64), d2 = __shfl(keep[2], j + 32, 64),
+                    dens = __shfl(keep[3], j + 32, 64);
+        if (h == 0 && m < s.M) {
+            auto sig = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+            f32x4 o;
+            o[0] = sig(sr) * sig(keep[0]) + sig(d0);
+            o[1] = sig(sg) * sig(keep[1]) + sig(d1);
+            o[2] = sig(sb) * sig(keep[2]) + sig(d2);
+            o[3] = dens;
+            *reinterpret_cast<f32x4*>(rgbo + m * 4) = o;
+        }
+    }
+    ws.drain();
+}
+
 int grid_for(int64_t n_tiles) {
     static int n_cu = 0;
     if (!n_cu) {
@@ -636,4 +805,24 @@ int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_sample
 int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
     if (precision == NERF_AMD_BF16) return launch<PBF16, MipLayout>(mip_kernel<PBF16>, packed, s, rgbo, st);
     return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, rgbo, st);
+}
+
+template <class P>
+static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, hipStream_t st) {
+    constexpr int TS = P::NW * 32;
+    const int64_t n_tiles = (s.M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = ref_lds_total<P>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ref_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(ref_kernel<P>, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal);
+    return (int)hipGetLastError();
+}
+int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, hipStream_t st) {
+    if (precision == NERF_AMD_BF16) return launch_ref<PBF16>(packed, s, rgbo, normal, st);
+    return launch_ref<PF32>(packed, s, rgbo, normal, st);
 }

@@ -22,7 +22,8 @@
 #include "../../include/nerf_amd.h"
 
 #define MLP_CHUNK_BYTES 8192
-#define MLP_NSLOT 8
+#define MLP_NSLOT 8          /* ring slots of the proposal / MipNeRF kernels */
+#define MLP_NSLOT_REF 6      /* Ref-NeRF needs the LDS for its 11 KiB/wave activation stash */
 #define MLP_RING_BYTES (MLP_CHUNK_BYTES * MLP_NSLOT)
 #define MLP_NW_BF16 8
 #define MLP_NW_F32 4
@@ -69,3 +70,30 @@ struct MipLayout {
     LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4 + FOLD_SCRATCH; }
 };
+
+// RefNeRF(10, 4, bottle_neck 128, hidden 256, output 256)  (ref_model.py:16-66), eval mode, use_srgb = False.
+//   spatial: S0 63->256, S1-3, S4 319->256 (skip), S5-7;  H: [bottle_neck 128 rows | 11 head rows];
+//   directional: D0 167->256, D1-3, D4 423->256 (skip), D5-7;  R: spec_rgb_head 256->3.
+// Head rows of H's 5th feature block: 0-2 normal, 3 roughness, 4-6 diffuse, 7 density, 8-10 tint
+// (rows 0-3 / 8-10 land in lane half 0, rows 4-7 in lane half 1 of the accumulator).
+// The 167 directional inputs are [bottle_neck 128 | IDE real 19 | IDE imag 19 | n.d]; the 39 computed ones use
+// 3 K groups: slot q of lane half h is IDE term q (real part for h=0, imaginary for h=1), slot 19 of half 0 is n.d.
+struct RefLayout {
+    static constexpr int N_LAYERS = 18;
+    static constexpr int NKG[18] = {4, 16, 16, 16, 20, 16, 16, 16, 16, 11, 16, 16, 16, 27, 16, 16, 16, 16};
+    static constexpr int NFB[18] = {8, 8, 8, 8, 8, 8, 8, 8, 5, 8, 8, 8, 8, 8, 8, 8, 8, 1};
+    static constexpr int START[18] = {0, 32, 160, 288, 416, 576, 704, 832, 960, 1040, 1128, 1256, 1384, 1512, 1728, 1856, 1984, 2112};
+    static constexpr int BIAS_OFF[18] = {0, 256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2208, 2464, 2720, 2976, 3232, 3488, 3744, 4000, 4256};
+    static constexpr int N_FRAGS = 2128;
+    static constexpr int N_BIAS = 4288;
+    static constexpr int N_IDE = 176;                 // 9 x 19 spherical-harmonic coefficients (ref_func.py:60-74), padded
+    static constexpr int IDE_TERMS = 19;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + (N_BIAS + N_IDE) * 4; }
+};
+// column of dir_block{1,2}.0 that IDE slot (q, h) multiplies (relative to the start of the 39 computed inputs), or -1
+LAYOUT_HD inline int ide_slot_column(int q, int h) {
+    if (q < 19) return (h ? 19 : 0) + q;
+    if (q == 19) return h ? -1 : 38;
+    return -1;
+}

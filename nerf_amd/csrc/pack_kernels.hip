@@ -6,17 +6,19 @@
 
 namespace {
 
-enum { SEG_DMAP = 0, SEG_PE = 1 };
+enum { SEG_DMAP = 0, SEG_PE = 1, SEG_IDE = 2 };
 
 struct PackLayer {
-    const float* b;         // bias (rows)
+    const float* b;         // bias of rows [0, rows)
     int rows;               // real output rows (the rest of the 32*nfb rows are zero)
+    // optional second row segment [rows, rows + rows2) taken from its own matrix/bias with the same K map
+    const float* w2; const float* b2; int rows2; int stride2;
     int nkg, nfb;
     int frag_start, bias_off;
-    // up to two K segments, each reading its own matrix: kind, #K groups, first column, PE levels, valid width
-    const float* seg_w[2];
-    int seg_stride[2];
-    int seg_kind[2], seg_nkg[2], seg_col[2], seg_L[2], seg_width[2];
+    // up to three K segments, each reading its own matrix: kind, #K groups, first column, PE levels, valid width
+    const float* seg_w[3];
+    int seg_stride[3];
+    int seg_kind[3], seg_nkg[3], seg_col[3], seg_L[3], seg_width[3];
 };
 
 template <bool BF16>
@@ -32,24 +34,32 @@ __global__ void pack_layer_kernel(PackLayer L, char* __restrict__ stream, float*
         else { fb = 2 * grp; kg = frag - 2 * grp * L.nkg; }
         const int row = 32 * fb + (lane & 31), h = lane >> 5;
         int seg = 0, lkg = kg;
-        if (kg >= L.seg_nkg[0]) { seg = 1; lkg = kg - L.seg_nkg[0]; }
-        int col = (L.seg_kind[seg] == SEG_PE) ? pe_slot_column(8 * lkg + e, h, L.seg_L[seg]) : dmap_feature(lkg, h, e);
+        if (lkg >= L.seg_nkg[0]) { lkg -= L.seg_nkg[0]; seg = 1; if (lkg >= L.seg_nkg[1]) { lkg -= L.seg_nkg[1]; seg = 2; } }
+        int col;
+        if (L.seg_kind[seg] == SEG_PE) col = pe_slot_column(8 * lkg + e, h, L.seg_L[seg]);
+        else if (L.seg_kind[seg] == SEG_IDE) col = ide_slot_column(8 * lkg + e, h);
+        else col = dmap_feature(lkg, h, e);
         if (col >= L.seg_width[seg]) col = -1;
         float v = 0.0f;
-        if (col >= 0 && row < L.rows) v = L.seg_w[seg][(size_t)row * L.seg_stride[seg] + L.seg_col[seg] + col];
+        if (col >= 0) {
+            if (row < L.rows) v = L.seg_w[seg][(size_t)row * L.seg_stride[seg] + L.seg_col[seg] + col];
+            else if (row < L.rows + L.rows2) v = L.w2[(size_t)(row - L.rows) * L.stride2 + L.seg_col[seg] + col];
+        }
         const size_t f = (size_t)(L.frag_start + frag);
         if (BF16) reinterpret_cast<__bf16*>(stream + f * 1024)[lane * 8 + e] = (__bf16)v;
         else reinterpret_cast<float*>(stream + f * 2048)[(e >> 2) * 256 + lane * 4 + (e & 3)] = v;
     }
     const int n_b = 32 * L.nfb;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += gridDim.x * blockDim.x) {
-        bias[L.bias_off + i] = (i < L.rows) ? L.b[i] : 0.0f;
+        bias[L.bias_off + i] = (i < L.rows) ? L.b[i] : ((i < L.rows + L.rows2) ? L.b2[i - L.rows] : 0.0f);
     }
 }
 
 PackLayer make_layer(const float* w, const float* b, int rows, int in_f, int nkg, int nfb, int start, int bias_off) {
     PackLayer L{};
     L.b = b; L.rows = rows; L.nkg = nkg; L.nfb = nfb; L.frag_start = start; L.bias_off = bias_off;
+    L.w2 = nullptr; L.b2 = nullptr; L.rows2 = 0; L.stride2 = 0;
+    L.seg_w[2] = w; L.seg_stride[2] = in_f; L.seg_kind[2] = SEG_DMAP; L.seg_nkg[2] = 0; L.seg_col[2] = 0; L.seg_L[2] = 0; L.seg_width[2] = 0;
     L.seg_w[0] = w; L.seg_stride[0] = in_f; L.seg_kind[0] = SEG_DMAP; L.seg_nkg[0] = nkg; L.seg_col[0] = 0; L.seg_L[0] = 0;
     L.seg_width[0] = 16 * nkg;
     L.seg_w[1] = w; L.seg_stride[1] = in_f; L.seg_kind[1] = SEG_DMAP; L.seg_nkg[1] = 0; L.seg_col[1] = 0; L.seg_L[1] = 0;
@@ -125,5 +135,29 @@ int pack_mip(int precision, const float* const* w, const float* const* b, void* 
         int e = launch_pack(L, precision, stream, bias, st);
         if (e) return e;
     }
+    return 0;
+}
+
+// tensors: 0-3 spa_block1.{0,2,4,6}; 4-7 spa_block2.{0,2,4,6}; 8 bottle_neck; 9 heads (11,256); 10-13 dir_block1.{0,2,4,6};
+//          14-17 dir_block2.{0,2,4,6}; 18 spec_rgb_head.0; 19 ide_table (9,19) in the weights slot
+int pack_ref(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
+    using Lay = RefLayout;
+    char* stream = reinterpret_cast<char*>(packed);
+    float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    const int tensor_of[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18};
+    const int rows[18] = {256, 256, 256, 256, 256, 256, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 256, 3};
+    const int inf[18] = {63, 256, 256, 256, 319, 256, 256, 256, 256, 167, 256, 256, 256, 423, 256, 256, 256, 256};
+    for (int l = 0; l < 18; ++l) {
+        const int t = tensor_of[l];
+        PackLayer L = make_layer(w[t], b[t], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
+        if (l == 4) { set_seg(L, 0, SEG_PE, 4, 0, 10, 63); set_seg(L, 1, SEG_DMAP, 16, 63, 0, 256); }
+        if (l == 8) { L.w2 = w[9]; L.b2 = b[9]; L.rows2 = 11; L.stride2 = 256; }              // bottle_neck rows + the 11 head rows
+        if (l == 9) { set_seg(L, 0, SEG_DMAP, 8, 0, 0, 128); set_seg(L, 1, SEG_IDE, 3, 128, 0, 39); }
+        if (l == 13) { set_seg(L, 0, SEG_DMAP, 8, 0, 0, 128); set_seg(L, 1, SEG_IDE, 3, 128, 0, 39); set_seg(L, 2, SEG_DMAP, 16, 167, 0, 256); }
+        int e = launch_pack(L, precision, stream, bias, st);
+        if (e) return e;
+    }
+    if (int e = (int)hipMemcpyAsync(bias + Lay::N_BIAS, w[19], 9 * 19 * sizeof(float), hipMemcpyDeviceToDevice, st)) return e;
     return 0;
 }

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
 // ---------------------------------------------------------------------------------------- row 10
 struct CompositeArgs {
     const float* rgbo; const float* z; int z_stride; const float* dirs; int dirs_stride; int64_t N; int S;
-    int flags; int act; float near, far; const float* normal; const float* cam_dir;
+    int flags; int act; float sigma_shift; float near, far; const float* normal; const float* cam_dir;
     float* rgb; float* weights; float* depth; float* normal_img;
 };
 
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
         if (a.normal_img) { cx = a.cam_dir[0]; cy = a.cam_dir[1]; cz = a.cam_dir[2]; }
         float* wout = a.weights ? a.weights + n * S : nullptr;
         const float* nm = a.normal ? a.normal + n * S * 3 : nullptr;
-        wave_sigma_to_weights(S, a.act, [&](int s) { return px[s][3]; },
+        const float shift = a.sigma_shift;
+        wave_sigma_to_weights(S, a.act, [&](int s) { return px[s][3] + shift; },
                               [&](int s) { return mul ? zz[s] * nrm : zz[s]; },
                               [&](int s, float w, float zn) {
                                   const f32x4 c = px[s];
@@ -432,10 +433,10 @@ int sk_resample(const float* density, const float* z, const float* z_base, const
     return (int)hipGetLastError();
 }
 int sk_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int S, int flags,
-                 int act, float near, float far, const float* normal, const float* cam_dir, float* rgb, float* weights,
+                 int act, float sigma_shift, float near, float far, const float* normal, const float* cam_dir, float* rgb, float* weights,
                  float* depth, float* normal_img, hipStream_t st) {
     if (N == 0) return 0;
-    CompositeArgs a{rgbo, z, z_stride, dirs, dirs_stride, N, S, flags, act, near, far, normal, cam_dir, rgb, weights, depth, normal_img};
+    CompositeArgs a{rgbo, z, z_stride, dirs, dirs_stride, N, S, flags, act, sigma_shift, near, far, normal, cam_dir, rgb, weights, depth, normal_img};
     hipLaunchKernelGGL(composite_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }

@@ -7,7 +7,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import lib, check, Samples, F32, BF16, NET_PROPOSAL, NET_MIP, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
+from ._lib import lib, check, Samples, F32, BF16, NET_PROPOSAL, NET_MIP, NET_REF, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
 
 _PRECISION_OVERRIDE = None          # None -> follow torch autocast (on: bf16, off: fp32)
 
@@ -118,6 +118,29 @@ def mip_forward_samples(packed, precision, s: Samples, shape, device) -> torch.T
     return out
 
 
+def _ref_out(shape, device, want_normal):
+    rgbo = torch.empty(tuple(shape) + (4,), dtype=torch.float32, device=device)
+    normal = torch.empty(tuple(shape) + (3,), dtype=torch.float32, device=device) if want_normal else None
+    return rgbo, normal
+
+
+def ref_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, want_normal: bool = True):
+    """pts (..., 6) = [position | direction] -> (rgbo (..., 4), normal (..., 3))   [ref_model.py:68-106, eval mode]"""
+    pts = _dev(pts, "pts")
+    rgbo, normal = _ref_out(pts.shape[:-1], pts.device, want_normal)
+    if rgbo.numel() == 0:
+        return rgbo, normal
+    s = _samples_pts(pts, 6)
+    check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
+    return rgbo, normal
+
+
+def ref_forward_samples(packed, precision, s: Samples, shape, device, want_normal: bool = True):
+    rgbo, normal = _ref_out(shape, device, want_normal)
+    check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
+    return rgbo, normal
+
+
 # ------------------------------------------------------------------------------------------------ sampling ops
 def positional_encoding(x: torch.Tensor, L: int) -> torch.Tensor:
     x = _dev(x, "x")
@@ -205,7 +228,7 @@ def stratified_points(rays: torch.Tensor, z_base: torch.Tensor, u: torch.Tensor,
 
 def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm: bool, white_bkg: bool, act: int,
               near_far=None, normal: Optional[torch.Tensor] = None, cam_dir: Optional[torch.Tensor] = None,
-              want_weights: bool = True):
+              want_weights: bool = True, sigma_shift: float = 0.0):
     """NeRF.render (nerf_base.py:91-113).  ``dirs`` is (N,3) ray directions or the (N,6) ray table (then the
     direction half is read in place with stride 6)."""
     rgbo, z = _dev(rgbo, "rgbo"), _dev(z, "depth")
@@ -226,8 +249,8 @@ def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm:
         nimg = torch.empty((N,), dtype=torch.float32, device=dev)
     near, far = (near_far if near_far is not None else (0.0, 1.0))
     flags = (1 if mul_norm else 0) | (2 if white_bkg else 0)
-    check(lib.nerf_amd_composite(_ptr(rgbo), _ptr(z), z.shape[-1], dirs_ptr, dirs_stride, N, S, flags, act, float(near),
-                                 float(far), _ptr(normal), _ptr(cam_dir), _ptr(rgb), _ptr(w), _ptr(depth), _ptr(nimg),
+    check(lib.nerf_amd_composite(_ptr(rgbo), _ptr(z), z.shape[-1], dirs_ptr, dirs_stride, N, S, flags, act, float(sigma_shift),
+                                 float(near), float(far), _ptr(normal), _ptr(cam_dir), _ptr(rgb), _ptr(w), _ptr(depth), _ptr(nimg),
                                  _stream()), "nerf_amd_composite")
     return rgb, w, depth, nimg
 

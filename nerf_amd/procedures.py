@@ -49,8 +49,8 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference."""
     if not isinstance(image_size, Iterable):
         image_size = (image_size, image_size)
-    if type(network).__name__ == "RefNeRF":
-        raise NotImplementedError("nerf_amd: the Ref-NeRF render path is not built yet (SURVEY.md section 8a row 13)")
+    is_ref_model = type(network).__name__ == "RefNeRF"
+    render_normal = bool(render_normal) and is_ref_model
     H, W = int(image_size[0]), int(image_size[1])
     dev = render_pose.device
     if dev.type != "cuda":
@@ -69,8 +69,25 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         rays = rays.view(H, W, 6)[: pr * sz].reshape(pr, sz, pc, sz, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
     u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
     z_base = torch.linspace(near, far, RENDER_COARSE_PNUM, device="cpu").to(dev)   # procedures.py:52 (CPU linspace bits)
-    rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
-                                       sample_num, near, far, white_bkg, want_depth=bool(render_depth))
+    normal_px = None
+    if not is_ref_model:
+        rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
+                                           sample_num, near, far, white_bkg, want_depth=bool(render_depth))
+    else:
+        # Ref-NeRF branch (procedures.py:71-74): coarse and fine depths are merged and sorted, the last one dropped,
+        # sigma -> softplus(sigma + 0.5) before compositing.  The merge sort is a device torch.sort (index plumbing).
+        jitter = (far - near) / sample_num
+        sc = ops.samples_rays(rays, RENDER_COARSE_PNUM, z_base=z_base, u=u_strat, z_jitter=jitter)
+        dens = ops.proposal_forward_samples(prop_net.packed(prec), prec, sc, (rays.shape[0], RENDER_COARSE_PNUM), dev)
+        z_fine, _, _, z_coarse = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, sample_num + 1, want_zc=True)
+        z_all = torch.sort(torch.cat((z_fine, z_coarse), dim=-1), dim=-1)[0][:, :-1].contiguous()
+        n_all = z_all.shape[-1]
+        rgbo, normal = ops.ref_forward_samples(network.packed(prec), prec, ops.samples_rays(rays, n_all, z=z_all),
+                                               (rays.shape[0], n_all), dev, want_normal=render_normal)
+        rgb, _, depth, normal_px = ops.composite(rgbo, z_all, rays, True, white_bkg, ops.ACT_SOFTPLUS,
+                                                 (near, far) if render_depth else None,
+                                                 normal if render_normal else None, render_pose[:, -2] if render_normal else None,
+                                                 want_weights=False, sigma_shift=0.5)
 
     def to_image(t, ch):
         if sz is None:
@@ -84,6 +101,8 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     result["rgb"] = to_image(rgb, 3)
     if render_depth:
         result["depth_img"] = to_image(depth.unsqueeze(-1), 1).expand(3, -1, -1).contiguous()   # procedures.py:88
+    if render_normal:
+        result["normal_img"] = to_image(normal_px.unsqueeze(-1), 1).expand(3, -1, -1).contiguous()   # procedures.py:90
     return result
 
 

@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference's ``nerf/ref_model.py``: RefNeRF with the reference's module tree (identical
+``state_dict`` keys) whose ``forward`` runs the fused HIP kernel (spatial MLP -> heads -> normals / reflection / IDE in
+registers -> directional MLP), plus the two scalar losses."""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from ._packed import PackedWeightsMixin, require_no_grad
+from .nerf_base import NeRF
+from .nerf_helper import makeMLP
+from .ref_func import generate_ide_fn, ide_table
+
+
+class RefNeRF(NeRF, PackedWeightsMixin):
+    _net_id = ops.NET_REF
+
+    def __init__(self, position_flevel, sh_max_level, bottle_neck_dim=128, hidden_unit=256, output_dim=256, use_srgb=False,
+                 cat_origin=True, perturb_bottle_neck_w=0.1) -> None:
+        super().__init__(position_flevel, cat_origin, lambda x: x)            # density is not activated during render
+        self.sh_max_level = sh_max_level
+        self.bottle_neck_dim = bottle_neck_dim
+        self.hidden_unit, self.output_dim = hidden_unit, output_dim
+        self.dir_enc_dim = ((1 << sh_max_level) - 1 + sh_max_level) << 1
+        in_dim = 6 * position_flevel + (3 if cat_origin else 0)
+        spa1 = makeMLP(in_dim, hidden_unit)
+        for _ in range(3):
+            spa1.extend(makeMLP(hidden_unit, hidden_unit))
+        self.spa_block1 = nn.Sequential(*spa1)
+        self.spa_block2 = nn.Sequential(*makeMLP(hidden_unit + in_dim, hidden_unit), *makeMLP(hidden_unit, hidden_unit),
+                                        *makeMLP(hidden_unit, hidden_unit), *makeMLP(hidden_unit, output_dim))
+        self.rho_tau_head = nn.Linear(output_dim, 2)                           # roughness, density
+        self.norm_col_tint_head = nn.Linear(output_dim, 9)                     # normal, diffuse colour, tint
+        self.bottle_neck = nn.Linear(output_dim, bottle_neck_dim)
+        self.spec_rgb_head = nn.Sequential(*makeMLP(output_dim, 3, nn.Sigmoid()))
+        dir_in = 1 + bottle_neck_dim + self.dir_enc_dim
+        dir1 = makeMLP(dir_in, hidden_unit)
+        for _ in range(3):
+            dir1.extend(makeMLP(hidden_unit, hidden_unit))
+        self.dir_block1 = nn.Sequential(*dir1)
+        self.dir_block2 = nn.Sequential(*makeMLP(hidden_unit + dir_in, hidden_unit), *makeMLP(hidden_unit, hidden_unit),
+                                        *makeMLP(hidden_unit, output_dim), *makeMLP(hidden_unit, output_dim))
+        self.use_srgb = use_srgb
+        self.perturb_bottle_neck_w = perturb_bottle_neck_w
+        self.integrated_dir_enc = generate_ide_fn(sh_max_level)
+        self.apply(self.init_weight)
+
+    def _check_config(self):
+        ok = (self.position_flevel == 10 and self.sh_max_level == 4 and self.bottle_neck_dim == 128 and self.hidden_unit == 256
+              and self.output_dim == 256 and self.cat_origin and not self.use_srgb)
+        if not ok:
+            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, 4, 128, 256, 256, use_srgb=False)")
+        if self.training:
+            raise NotImplementedError("nerf_amd: Ref-NeRF train-mode forward (bottle-neck noise, density gradients) is not built; call .eval()")
+
+    def _pack_tensors(self):
+        nct, rt = self.norm_col_tint_head, self.rho_tau_head
+        # head rows in kernel order: normal(3) roughness(1) | diffuse(3) density(1) | tint(3)   (mlp_layout.h)
+        hw = torch.cat((nct.weight[0:3], rt.weight[0:1], nct.weight[3:6], rt.weight[1:2], nct.weight[6:9]), dim=0).detach().contiguous()
+        hb = torch.cat((nct.bias[0:3], rt.bias[0:1], nct.bias[3:6], rt.bias[1:2], nct.bias[6:9]), dim=0).detach().contiguous()
+        lin = [self.spa_block1[0], self.spa_block1[2], self.spa_block1[4], self.spa_block1[6],
+               self.spa_block2[0], self.spa_block2[2], self.spa_block2[4], self.spa_block2[6], self.bottle_neck]
+        tail = [self.dir_block1[0], self.dir_block1[2], self.dir_block1[4], self.dir_block1[6],
+                self.dir_block2[0], self.dir_block2[2], self.dir_block2[4], self.dir_block2[6], self.spec_rgb_head[0]]
+        table = ide_table(4).to(hw.device).contiguous()
+        ws = [l.weight for l in lin] + [hw] + [l.weight for l in tail] + [table]
+        bs = [l.bias for l in lin] + [hb] + [l.bias for l in tail] + [hb]
+        return ws, bs
+
+    def packed(self, precision: int) -> torch.Tensor:
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.setdefault("_packed_cache", {})
+        hit = cache.get(precision)
+        if hit is None or hit[0] != key:
+            ws, bs = self._pack_tensors()
+            blob = ops.pack_weights(self._net_id, precision, ws, bs)
+            cache[precision] = (key, blob)
+            return blob
+        return hit[1]
+
+    def forward(self, pts: torch.Tensor, ray_d: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """pts (N,S,6) [or (N,S,3) + ray_d (N,S,3)] -> ((N,S,4) = [rgb | raw density], normal (N,S,3))  (ref_model.py:68-106)."""
+        self._check_config()
+        require_no_grad(pts, ray_d, *self.parameters())
+        if ray_d is not None:
+            pts = torch.cat((pts[..., :3], ray_d), dim=-1)
+        prec = ops.current_precision()
+        return ops.ref_forward(self.packed(prec), prec, pts)
+
+    @staticmethod
+    def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum: int) -> torch.Tensor:
+        """Pick the gradients that belong to the coarse samples after the coarse/fine merge sort (ref_model.py:108-117)."""
+        n, total, _ = fine_grads.shape
+        sel = torch.cat((torch.zeros((n, total - c_pnum), dtype=torch.bool, device=fine_grads.device),
+                         torch.ones((n, c_pnum), dtype=torch.bool, device=fine_grads.device)), dim=-1)
+        sel = torch.gather(sel, -1, sort_inds)
+        return fine_grads[sel].reshape(n, c_pnum, -1)
+
+    @staticmethod
+    def get_grad(func_val: torch.Tensor, inputs: torch.Tensor) -> torch.Tensor:
+        """Normalised d(func)/d(inputs) (ref_model.py:119-125).  Needs autograd through the network: not available on
+        the forward-only HIP path."""
+        raise NotImplementedError("nerf_amd: RefNeRF.get_grad needs the HIP backward (SURVEY.md section 8f-1)")
+
+
+class WeightedNormalLoss(nn.Module):
+    def __init__(self, size_average=False):
+        super().__init__()
+        self.size_average = size_average
+
+    def forward(self, weight: torch.Tensor, d_norm: torch.Tensor, p_norm: torch.Tensor) -> torch.Tensor:
+        """sum / mean of w (1 - <n_density, n_pred>)  (ref_model.py:127-135)."""
+        diff = 1. - torch.sum(d_norm * p_norm, dim=-1)
+        return torch.mean(weight * diff) if self.size_average else torch.sum(weight * diff)
+
+
+class BackFaceLoss(nn.Module):
+    def forward(self, weight: torch.Tensor, normal: torch.Tensor, ray_d: torch.Tensor) -> torch.Tensor:
+        """mean of w relu(<n, d>)  (ref_model.py:137-143)."""
+        return torch.mean(weight * F.relu(torch.sum(normal * ray_d, dim=-1)))

@@ -428,3 +428,111 @@ def render_image(prop_sd, mip_sd, pose: Tensor, image_size, focal, near: float, 
             if max_tiles is not None and done >= max_tiles:
                 return out
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# row 13: Ref-NeRF (ref_model.py:16-106) and the integrated directional encoding (ref_func.py:10-110)
+# --------------------------------------------------------------------------------------------
+def ide_tables(deg_view: int):
+    """(ml_array (2,T) int64, mat (l_max+1, T) float32): spherical-harmonic coefficient table of ref_func.py:60-74,
+    computed in float64 like the reference (np.math.factorial / np.prod) and stored as float32."""
+    import numpy as np
+    if deg_view > 5:
+        raise ValueError("Only deg_view of at most 5 is numerically stable.")
+
+    def gen_binom(a, k):
+        return np.prod(a - np.arange(k)) / math.factorial(k)
+
+    def legendre(l, m, k):
+        return ((-1) ** m * 2 ** l * math.factorial(l) / math.factorial(k) / math.factorial(l - k - m) *
+                gen_binom(0.5 * (l + k + m - 1.0), l))
+
+    def sph(l, m, k):
+        return np.sqrt((2.0 * l + 1.0) * math.factorial(l - m) / (4.0 * np.pi * math.factorial(l + m))) * legendre(l, m, k)
+
+    ml = [(m, 2 ** i) for i in range(deg_view) for m in range(2 ** i + 1)]
+    ml_array = np.array(ml).T
+    l_max = 2 ** (deg_view - 1)
+    mat = torch.zeros(l_max + 1, ml_array.shape[1])
+    for i, (m, l) in enumerate(ml_array.T):
+        for k in range(l - m + 1):
+            mat[k, i] = sph(l, m, k)
+    return torch.from_numpy(ml_array), mat
+
+
+def ide_encode(xyz: Tensor, kappa_inv: Tensor, deg_view: int = 4) -> Tensor:
+    """integrated_dir_enc_fn (ref_func.py:76-108): (..., 3), (..., 1) -> (..., 2T) = [real | imag]."""
+    ml, mat = ide_tables(deg_view)
+    ml, mat = ml.to(xyz.device), mat.to(xyz.device)
+    x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
+    vmz = torch.cat([z ** i for i in range(mat.shape[0])], dim=-1)
+    vmxy = torch.cat([(x + 1j * y) ** m for m in ml[0, :]], dim=-1)
+    sph_harms = vmxy * (vmz @ mat)
+    sigma = 0.5 * ml[1, :] * (ml[1, :] + 1)
+    ide = sph_harms * torch.exp(-sigma * kappa_inv)
+    return torch.cat([torch.real(ide), torch.imag(ide)], dim=-1)
+
+
+def ref_shapes(Lp: int = 10, deg: int = 4, hidden: int = 256, bottle: int = 128, out_dim: int = 256):
+    i = 6 * Lp + 3
+    enc = ((1 << deg) - 1 + deg) << 1
+    din = 1 + bottle + enc
+    s = [("spa_block1.0", hidden, i), ("spa_block1.2", hidden, hidden), ("spa_block1.4", hidden, hidden), ("spa_block1.6", hidden, hidden),
+         ("spa_block2.0", hidden, hidden + i), ("spa_block2.2", hidden, hidden), ("spa_block2.4", hidden, hidden), ("spa_block2.6", out_dim, hidden),
+         ("rho_tau_head", 2, out_dim), ("norm_col_tint_head", 9, out_dim), ("bottle_neck", bottle, out_dim), ("spec_rgb_head.0", 3, out_dim),
+         ("dir_block1.0", hidden, din), ("dir_block1.2", hidden, hidden), ("dir_block1.4", hidden, hidden), ("dir_block1.6", hidden, hidden),
+         ("dir_block2.0", hidden, hidden + din), ("dir_block2.2", hidden, hidden), ("dir_block2.4", out_dim, hidden), ("dir_block2.6", out_dim, hidden)]
+    return s
+
+
+def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = None, Lp: int = 10, deg: int = 4,
+                emulate_bf16: bool = False):
+    """RefNeRF.forward in eval mode, use_srgb=False (ref_model.py:68-106).  pts (N,S,6) [or (N,S,3) + ray_d] ->
+    ((N,S,4) = [rgb | raw density], normal (N,S,3))."""
+    lin = lambda name, t: _linear(t, sd[name + ".weight"], sd[name + ".bias"], emulate_bf16)
+    x = pts[..., :3]
+    ex = torch.cat((x, positional_encoding(x, Lp)), dim=-1)
+    h = ex
+    for i in (0, 2, 4, 6):
+        h = F.relu(lin(f"spa_block1.{i}", h))
+    g = torch.cat((ex, h), dim=-1)
+    for i in (0, 2, 4, 6):
+        g = F.relu(lin(f"spa_block2.{i}", g))
+    nct = lin("norm_col_tint_head", g)
+    normal, diffuse, tint = nct[..., 0:3], nct[..., 3:6], nct[..., 6:9]
+    rt = lin("rho_tau_head", g)
+    rough, density = rt[..., 0:1], rt[..., 1:2]
+    rough = F.softplus(rough - 1.0)
+    b = lin("bottle_neck", g)
+    normal = -normal / (normal.norm(dim=-1, keepdim=True) + 1e-7)
+    d = pts[..., 3:] if ray_d is None else ray_d
+    refl = d - 2.0 * torch.sum(d * normal, dim=-1, keepdim=True) * normal
+    ide = ide_encode(refl, rough, deg)
+    nv = torch.sum(normal * d, dim=-1, keepdim=True)
+    allin = torch.cat((b, ide, nv), dim=-1)
+    r = allin
+    for i in (0, 2, 4, 6):
+        r = F.relu(lin(f"dir_block1.{i}", r))
+    r = torch.cat((allin, r), dim=-1)
+    for i in (0, 2, 4, 6):
+        r = F.relu(lin(f"dir_block2.{i}", r))
+    spec = torch.sigmoid(lin("spec_rgb_head.0", r)) * torch.sigmoid(tint)
+    rgb = spec + torch.sigmoid(diffuse)
+    return torch.cat((rgb, density), dim=-1), normal
+
+
+def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float, sample_num: int = 128,
+                    white_bkg: bool = False, cam_z: Optional[Tensor] = None):
+    """Tile body of render_image for a RefNeRF (procedures.py:64-85, is_ref_model branch): coarse+fine merge, sigma ->
+    softplus(sigma + 0.5), composite with relu (a no-op after softplus)."""
+    z_c = stratified_render(near, far, sample_num, u_strat)
+    pts_c = rays[:, None, :3] + z_c[..., None] * rays[:, None, 3:]
+    density = proposal_forward(prop_sd, pts_c)
+    w_prop = max_blur(sigma_to_weights(density, z_c, rays[:, 3:]), 0.01)
+    z_f, _ = inverse_sample(w_prop, z_c, u_inv, sort=True)
+    samples, z_all = coarse_fine_merge(rays, z_c, z_f)
+    rgbo, normal = ref_forward(ref_sd, samples)
+    rgbo = torch.cat((rgbo[..., :3], F.softplus(rgbo[..., 3:] + 0.5)), dim=-1)
+    rgb, w, extras = composite(rgbo, z_all, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far),
+                               normal_info=(normal, cam_z) if cam_z is not None else None)
+    return rgb, w, extras

@@ -243,6 +243,29 @@ def main():
     feat, mu, mu_t = mip_methods.ipe_feature(z12, r12, 6, 0.0015)
     npz("g12_ipe", z=z12, rays=r12, feat=feat, mu=mu, mu_t=mu_t)
 
+    # ---------------- G13 IDE + RefNeRF eval forward + render_image with a RefNeRF ----------------
+    from nerf import ref_model, ref_func
+    ide_fn = ref_func.generate_ide_fn(4)
+    dirs13 = torch.randn(9, 7, 3, generator=g); dirs13 = dirs13 / dirs13.norm(dim=-1, keepdim=True) * (0.5 + torch.rand(9, 7, 1, generator=g))
+    rho13 = torch.rand(9, 7, 1, generator=g) * 0.95 + 0.05
+    o13 = {"ide_dirs": dirs13, "ide_rho": rho13, "ide": ide_fn(dirs13, rho13)}
+    for tag in ("small", "he"):
+        net = ref_model.RefNeRF(10, 4); net.load_state_dict(W.ref_state(tag)); net.eval()
+        zf13, _ = torch.sort(near + (far - near) * torch.rand(12, 24, generator=g), dim=-1)
+        pts13 = nerf_base.NeRF.length2pts(rays, zf13)
+        with torch.no_grad():
+            rgbo13, nrm13 = net.forward(pts13)
+        o13[tag + "_pts"], o13[tag + "_rgbo"], o13[tag + "_normal"] = pts13, rgbo13, nrm13
+    prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state("small")); prop.eval()
+    net = ref_model.RefNeRF(10, 4); net.load_state_dict(W.ref_state("small")); net.eval()
+    f50 = utils.fov2Focal(0.6911112070083618, (50, 50))
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        res13 = procedures.render_image(net, prop, pose, 50, f50, near, far, 64, white_bkg=True, render_depth=True, render_normal=True)
+    o13["img_rgb"], o13["img_depth"], o13["img_normal"], o13["img_focal"] = res13["rgb"], res13["depth_img"][0], res13["normal_img"][0], np.array(f50)
+    npz("g13_refnerf", rays=rays, pose=pose, **o13)
+    abi_ref = [[k, list(v.shape)] for k, v in ref_model.RefNeRF(10, 4).state_dict().items()]
+
     # ---------------- G14 train-step losses + parameter grads (non-ref) ----------------
     prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state("small"))
     mip = mip_model.MipNeRF(10, 4, 256); mip.load_state_dict(W.mip_state("small"))
@@ -278,6 +301,7 @@ def main():
     for name, mod in (("mip", mip_model.MipNeRF(10, 4, 256)), ("prop", addtional.ProposalNetwork(10, 256)),
                       ("prop128", addtional.ProposalNetwork(10))):
         abi[name] = [[k, list(v.shape)] for k, v in mod.state_dict().items()]
+    abi["ref"] = abi_ref
     with open(os.path.join(HERE, "g16_state_dict_abi.json"), "w") as f:
         json.dump(abi, f, indent=0)
     print("wrote g16_state_dict_abi.json")

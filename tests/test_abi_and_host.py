@@ -60,7 +60,9 @@ def test_state_dict_keys_match_reference(golden):
     from nerf_amd.addtional import ProposalNetwork
     from nerf_amd.mip_model import MipNeRF
     g = golden("g16_state_dict_abi")
-    for name, mod in (("mip", MipNeRF(10, 4, 256)), ("prop", ProposalNetwork(10, 256)), ("prop128", ProposalNetwork(10))):
+    from nerf_amd.ref_model import RefNeRF
+    for name, mod in (("mip", MipNeRF(10, 4, 256)), ("prop", ProposalNetwork(10, 256)), ("prop128", ProposalNetwork(10)),
+                      ("ref", RefNeRF(10, 4))):
         sd = mod.state_dict()
         want = g[name]
         assert list(sd.keys()) == [k for k, _ in want]

@@ -364,3 +364,62 @@ def test_full_size_properties(A, prec):
         assert max_abs(w[pick].cpu(), want_w) <= 1e-4
     else:
         assert torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ row 13: Ref-NeRF
+def build_ref(A, tag):
+    from nerf_amd.ref_model import RefNeRF
+    net = RefNeRF(10, 4)
+    net.load_state_dict(W.ref_state(tag))
+    return net.cuda().eval()
+
+
+@pytest.mark.parametrize("tag", ["small", "he"])
+def test_refnerf_forward_vs_reference_golden(A, golden, tag):
+    g = golden("g13_refnerf")
+    net = build_ref(A, tag)
+    A.pkg.set_precision("fp32")
+    with torch.no_grad():
+        rgbo, normal = net.forward(dev(g[tag + "_pts"]))
+    scale = max(1.0, g[tag + "_rgbo"].abs().max().item())
+    assert max_abs(rgbo.cpu(), g[tag + "_rgbo"]) <= 2e-5 * scale
+    assert max_abs(normal.cpu(), g[tag + "_normal"]) <= 2e-5
+    # split position / direction call form (ref_model.py:68,89)
+    with torch.no_grad():
+        rgbo2, _ = net.forward(dev(g[tag + "_pts"][..., :3].contiguous()), dev(g[tag + "_pts"][..., 3:].contiguous()))
+    assert torch.equal(rgbo, rgbo2)
+    # bf16 mode against the bf16-operand emulation of the oracle
+    A.pkg.set_precision("bf16")
+    with torch.no_grad():
+        rgbo16, _ = net.forward(dev(g[tag + "_pts"]))
+        want16, _ = O.ref_forward(W.ref_state(tag), g[tag + "_pts"], emulate_bf16=True)
+    A.pkg.set_precision("fp32")
+    assert max_abs(rgbo16.cpu(), want16) <= 2e-2 * scale
+
+
+@pytest.mark.parametrize("M", [1, 33, 129, 1000, 40001])
+def test_refnerf_ragged_sizes(A, M):
+    net = build_ref(A, "small")
+    gen = torch.Generator().manual_seed(M)
+    pts = torch.cat(((torch.rand(M, 1, 3, generator=gen) - 0.5) * 8, torch.randn(M, 1, 3, generator=gen)), -1)
+    with torch.no_grad():
+        want, wn = O.ref_forward(W.ref_state("small"), pts)
+        A.pkg.set_precision("fp32")
+        got, gn = net.forward(dev(pts))
+    assert max_abs(got.cpu(), want) <= 2e-5 * max(1.0, want.abs().max().item()) and max_abs(gn.cpu(), wn) <= 2e-5
+
+
+def test_render_image_refnerf_vs_reference(A, golden):
+    """Drop-in surface with a RefNeRF: the reference's own image (coarse+fine merge, softplus(sigma+.5), normal map)."""
+    g = golden("g13_refnerf")
+    prop, _ = build_nets(A, "small")
+    net = build_ref(A, "small")
+    A.pkg.set_precision("fp32")
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        res = A.procedures.render_image(net, prop, dev(g["pose"]), 50, tuple(g["img_focal"].tolist()), NEAR, FAR, 64, white_bkg=True,
+                                        render_depth=True, render_normal=True)
+    assert list(res.keys()) == ["rgb", "depth_img", "normal_img"]
+    assert max_abs(res["rgb"].cpu(), g["img_rgb"]) <= 1e-4
+    assert max_abs(res["depth_img"][0].cpu(), g["img_depth"]) <= 1e-4
+    assert max_abs(res["normal_img"][0].cpu(), g["img_normal"]) <= 1e-4

@@ -171,3 +171,31 @@ def test_g15_lr_schedule(golden):
         else:
             got = lr * max(decay_r ** ((s - warm) / step), min_r)
         assert abs(got - want) <= 1e-12
+
+
+def test_g13_ide_and_refnerf(golden):
+    g = golden("g13_refnerf")
+    assert torch.equal(O.ide_encode(g["ide_dirs"], g["ide_rho"], 4), g["ide"])
+    for tag in ("small", "he"):
+        with torch.no_grad():
+            rgbo, normal = O.ref_forward(W.ref_state(tag), g[tag + "_pts"])
+        assert max_abs(rgbo, g[tag + "_rgbo"]) <= 2e-6 * max(1.0, g[tag + "_rgbo"].abs().max().item())
+        assert max_abs(normal, g[tag + "_normal"]) <= 2e-6
+
+
+def test_g13_render_image_refnerf(golden):
+    """Reference render_image with a RefNeRF (coarse+fine merge, softplus(sigma+.5), normals), one 50x50 tile."""
+    g = golden("g13_refnerf")
+    pose = g["pose"]
+    f = tuple(g["img_focal"].tolist())
+    dirs = O.ray_dirs_image(pose, 50, 50, f).reshape(-1, 3)
+    rays = torch.cat((pose[:, -1].expand(2500, -1), dirs), -1)
+    torch.manual_seed(4321)
+    u1 = torch.rand((50, 50, 64)).view(-1, 64)
+    u2 = torch.rand((2500, 65))
+    with torch.no_grad():
+        rgb, _, ex = O.render_rays_ref(W.proposal_state("small"), W.ref_state("small"), rays, u1, u2, NEAR, FAR, 64, white_bkg=True,
+                                       cam_z=pose[:, -2])
+    assert max_abs(rgb.view(50, 50, 3).permute(2, 0, 1), g["img_rgb"]) <= 2e-6
+    assert max_abs(ex["depth_img"].view(50, 50), g["img_depth"]) <= 2e-6
+    assert max_abs(ex["normal_img"].view(50, 50), g["img_normal"]) <= 2e-6

@@ -66,3 +66,15 @@ def mip_state(flavour: str = "small", hidden: int = 256, Lp: int = 10, Ld: int =
               ("lin_block2.4", 256, hidden), ("bottle_neck.0", 256, 256), ("opacity_head.0", 1, 256),
               ("rgb_layer.0", 128, 256 + 6 * Ld + 3), ("rgb_layer.2", 3, 128)]
     return _state(shapes, flavour, 5000)
+
+
+def ref_state(flavour: str = "small"):
+    """RefNeRF(10, 4) in the reference's state_dict order (ref_model.py:31-62)."""
+    i, hidden, out_dim, bottle = 63, 256, 256, 128
+    din = 1 + bottle + 38
+    shapes = [("spa_block1.0", hidden, i), ("spa_block1.2", hidden, hidden), ("spa_block1.4", hidden, hidden), ("spa_block1.6", hidden, hidden),
+              ("spa_block2.0", hidden, hidden + i), ("spa_block2.2", hidden, hidden), ("spa_block2.4", hidden, hidden), ("spa_block2.6", out_dim, hidden),
+              ("rho_tau_head", 2, out_dim), ("norm_col_tint_head", 9, out_dim), ("bottle_neck", bottle, out_dim), ("spec_rgb_head.0", 3, out_dim),
+              ("dir_block1.0", hidden, din), ("dir_block1.2", hidden, hidden), ("dir_block1.4", hidden, hidden), ("dir_block1.6", hidden, hidden),
+              ("dir_block2.0", hidden, hidden + din), ("dir_block2.2", hidden, hidden), ("dir_block2.4", out_dim, hidden), ("dir_block2.6", out_dim, hidden)]
+    return _state(shapes, flavour, 9000)
