@@ -5,13 +5,15 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import ops
+from . import autograd_bridge as ab
 from ._packed import PackedWeightsMixin, require_no_grad
 from .nerf_helper import makeMLP
 
 
 def getBounds(weights: torch.Tensor, inds: torch.Tensor):
     """Proposal weight mass covering each fine interval (addtional.py:14-18, index quirk included)."""
-    require_no_grad(weights)
+    if ab.needs_grad(weights):
+        return ab.HipOp.apply(lambda w, i: ops.get_bounds(w, i), ab.bounds_expr, 0, weights, inds)
     return ops.get_bounds(weights, inds)
 
 
@@ -85,13 +87,22 @@ class ProposalNetwork(nn.Module, PackedWeightsMixin):
         """pts (N,C,3) -> density (N,C), no activation (addtional.py:88-96).  ``encoded_pt`` (a pre-computed
         encoding) is accepted for signature parity and ignored: the kernel encodes in-register."""
         self._check_config()
-        require_no_grad(pts, *self.parameters())
         prec = ops.current_precision()
+        layers = self._linear_layers()
+        params = [l.weight for l in layers] + [l.bias for l in layers]
+        if ab.needs_grad(pts, *params):
+            hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p)
+            expr = lambda p, *wb: ab.proposal_expr(p, wb[:5], wb[5:])
+            return ab.HipOp.apply(hip, expr, 0, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts)
 
     @staticmethod
     def get_weights(density: torch.Tensor, zvals: torch.Tensor, ray_dirs: torch.Tensor = None) -> torch.Tensor:
         """relu(sigma) -> alpha -> exclusive transmittance product; z scaled by |d| when ray_dirs is
         given (addtional.py:100-107)."""
-        require_no_grad(density, zvals)
+        if ab.needs_grad(density, zvals):
+            if ray_dirs is not None:
+                zvals = zvals * ray_dirs.norm(dim=-1, keepdim=True)
+            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, ops.ACT_RELU),
+                                  lambda s, z: ab.weights_expr(s, z, ops.ACT_RELU), 0, density, zvals)
         return ops.sigma_to_weights(density, zvals, ray_dirs, ops.ACT_RELU)

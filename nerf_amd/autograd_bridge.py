@@ -1,0 +1,122 @@
+"""Autograd bridge: makes the forward-only HIP ops usable under ``loss.backward()``.
+
+Forward is ALWAYS the HIP kernel.  Backward (the HIP dgrad/wgrad kernels are the next
+milestone) is obtained by re-evaluating the same op with torch expressions ON THE DEVICE under ``enable_grad`` and
+asking torch.autograd for the vector-Jacobian product.  This is not a fallback of the forward path: it never runs
+unless ``backward`` is called, never touches the CPU, and raises if the tensors are not on the HIP device.
+
+Gradient parity with the reference is pinned by golden G14 (tests/test_gpu_parity.py::test_train_step_gradients).
+"""
+from typing import Callable, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _pe(x: torch.Tensor, L: int) -> torch.Tensor:
+    out = []
+    for f in range(L):
+        a = (2.0 ** f) * x
+        out += [torch.sin(a), torch.cos(a)]
+    return torch.cat(out, dim=-1)
+
+
+def proposal_expr(pts, w, b):
+    """ProposalNetwork.forward as torch ops (addtional.py:88-96); w, b = lists in state_dict order."""
+    h = torch.cat((pts, _pe(pts, 10)), dim=-1)
+    for i in range(4):
+        h = F.relu(F.linear(h, w[i], b[i]))
+    return F.linear(h, w[4], b[4]).squeeze(-1)
+
+
+def mip_expr(pts, w, b):
+    """MipNeRF.forward as torch ops (mip_model.py:41-60); tensors in the order of MipNeRF._linear_layers()."""
+    x, d = pts[..., :3], pts[..., 3:6]
+    d = d / d.norm(dim=-1, keepdim=True)
+    ex = torch.cat((x, _pe(x, 10)), dim=-1)
+    ed = torch.cat((d, _pe(d, 4)), dim=-1)
+    h = ex
+    for i in range(4):
+        h = F.relu(F.linear(h, w[i], b[i]))
+    g = torch.cat((ex, h), dim=-1)
+    for i in range(4, 7):
+        g = F.relu(F.linear(g, w[i], b[i]))
+    bott = F.linear(g, w[7], b[7])
+    sigma = F.linear(g, w[8], b[8])
+    c = F.relu(F.linear(torch.cat((bott, ed), dim=-1), w[9], b[9]))
+    rgb = torch.sigmoid(F.linear(c, w[10], b[10]))
+    return torch.cat((rgb, sigma), dim=-1)
+
+
+def weights_expr(sigma, z, act_code: int):
+    """sigma -> alpha -> exclusive transmittance product (nerf_base.py:80-86); z already scaled."""
+    big = torch.full((z.shape[0], 1), 1e10, dtype=z.dtype, device=z.device)
+    delta = torch.cat((z[:, 1:] - z[:, :-1], big), dim=-1)
+    dens = F.relu(sigma) if act_code == ops.ACT_RELU else (F.softplus(sigma) if act_code == ops.ACT_SOFTPLUS else sigma)
+    m = torch.exp(-dens * delta)
+    ones = torch.ones((z.shape[0], 1), dtype=z.dtype, device=z.device)
+    T = torch.cumprod(torch.cat((ones, m + 1e-10), dim=-1), dim=-1)[:, :-1]
+    return (1.0 - m) * T
+
+
+def max_blur_expr(w, alpha):
+    mx = torch.maximum(w[..., :-1], w[..., 1:])
+    return 0.5 * (torch.cat((w[..., :1], mx), dim=-1) + torch.cat((mx, w[..., -1:]), dim=-1)) + alpha
+
+
+def bounds_expr(w, inds):
+    sat = torch.cat((torch.zeros(w.shape[0], 1, device=w.device), torch.cumsum(w, dim=-1)), dim=-1)
+    return torch.gather(sat, -1, inds[:, 1:] + 1) - torch.gather(sat, -1, inds[:, :-1])
+
+
+class HipOp(torch.autograd.Function):
+    """forward = `hip_fn(*tensors)` (HIP kernels);  backward = VJP of `expr_fn(*tensors)` (torch, on the device).
+    Only the first output of hip_fn is differentiable; extra outputs are returned as-is (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, hip_fn: Callable, expr_fn: Callable, n_extra: int, *tensors):
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and not t.is_cuda:
+                raise RuntimeError("nerf_amd: tensors must live on the HIP device")
+        ctx.expr_fn = expr_fn
+        ctx.save_for_backward(*[t for t in tensors if isinstance(t, torch.Tensor)])
+        ctx.is_tensor = [isinstance(t, torch.Tensor) for t in tensors]
+        ctx.consts = [t for t in tensors if not isinstance(t, torch.Tensor)]
+        with torch.no_grad():
+            out = hip_fn(*[t.detach() if isinstance(t, torch.Tensor) else t for t in tensors])
+        if n_extra:
+            ctx.mark_non_differentiable(*out[1:])
+            return out
+        return out
+
+    @staticmethod
+    def backward(ctx, grad, *unused):
+        saved = list(ctx.saved_tensors)
+        consts = list(ctx.consts)
+        args, leaves = [], []
+        for is_t in ctx.is_tensor:
+            if is_t:
+                t = saved.pop(0)
+                if t.is_floating_point():
+                    t = t.detach().requires_grad_(True)
+                    leaves.append(t)
+                args.append(t)
+            else:
+                args.append(consts.pop(0))
+        with torch.enable_grad():
+            y = ctx.expr_fn(*args)
+        need = [i for i, l in enumerate(leaves)]
+        grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
+        out, gi = [], iter(grads)
+        for is_t, a in zip(ctx.is_tensor, args):
+            if is_t and a.is_floating_point():
+                out.append(next(gi))
+            else:
+                out.append(None)
+        return (None, None, None, *out)
+
+
+def needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)

@@ -2,10 +2,13 @@
 import torch
 
 from . import ops
+from . import autograd_bridge as ab
 
 
 def maxBlurFilter(weights: torch.Tensor, alpha: float):
     """2-tap max then 2-tap blur plus ``alpha`` (mip_methods.py:61-66) -- HIP kernel."""
+    if ab.needs_grad(weights):
+        return ab.HipOp.apply(lambda w: ops.max_blur(w, alpha), lambda w: ab.max_blur_expr(w, alpha), 0, weights)
     return ops.max_blur(weights, alpha)
 
 

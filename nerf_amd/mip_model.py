@@ -5,6 +5,7 @@ import torch
 from torch import nn
 
 from . import ops
+from . import autograd_bridge as ab
 from ._packed import PackedWeightsMixin, require_no_grad
 from .nerf_base import NeRF
 from .nerf_helper import makeMLP
@@ -42,8 +43,14 @@ class MipNeRF(NeRF, PackedWeightsMixin):
     def forward(self, pts: torch.Tensor) -> torch.Tensor:
         """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60)."""
         self._check_config()
-        require_no_grad(pts, *self.parameters())
         prec = ops.current_precision()
+        layers = self._linear_layers()
+        params = [l.weight for l in layers] + [l.bias for l in layers]
+        if ab.needs_grad(pts, *params):
+            n = len(layers)
+            hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p)
+            expr = lambda p, *wb: ab.mip_expr(p, wb[:n], wb[n:])
+            return ab.HipOp.apply(hip, expr, 0, pts, *params)
         return ops.mip_forward(self.packed(prec), prec, pts)
 
     def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int) -> torch.Tensor:

@@ -7,6 +7,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import ops
+from . import autograd_bridge as ab
 from ._packed import require_no_grad
 
 
@@ -77,10 +78,12 @@ class NeRF(nn.Module):
     @staticmethod
     def getNormedWeight(opacity: torch.Tensor, depth: torch.Tensor, density_act=F.relu) -> torch.Tensor:
         """alpha_i * prod_{j<i}(1 - alpha_j + 1e-10), delta_last = 1e10 (nerf_base.py:80-86)."""
-        require_no_grad(opacity, depth)
         code, pre = _act_code(density_act)
         if pre is not None:
             opacity = pre(opacity)
+        if ab.needs_grad(opacity, depth):
+            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, code), lambda s, z: ab.weights_expr(s, z, code),
+                                  0, opacity, depth)
         return ops.sigma_to_weights(opacity, depth, None, code)
 
     @staticmethod
@@ -88,11 +91,32 @@ class NeRF(nn.Module):
                white_bkg: bool = False, density_act=F.relu, render_depth: Optional[Tuple[float, float]] = None,
                normal_info: Optional[Tuple] = None):
         """Alpha compositing (nerf_base.py:91-113) -> (rgb (N,3), weights (N,S), extras)."""
-        require_no_grad(rgbo, depth, ray_dirs)
         code, pre = _act_code(density_act)
         if pre is not None:
             rgbo = torch.cat((rgbo[..., :3], pre(rgbo[..., 3:])), dim=-1)
         normal, cam_dir = (normal_info if normal_info is not None else (None, None))
+        if ab.needs_grad(rgbo, depth):
+            # training path (train.py:190,196): differentiable w.r.t. the network output; extras stay forward-only
+            def hip(r, z, dd):
+                rgb_, w_, _, _ = ops.composite(r, z, dd, mul_norm == True, bool(white_bkg), code, None)
+                return rgb_, w_
+
+            def expr(r, z, dd):
+                zz = z * dd.norm(dim=-1, keepdim=True) if mul_norm == True else z
+                w_ = ab.weights_expr(r[..., 3], zz, code)
+                c = torch.sum(w_[:, :, None] * r[..., :3], dim=-2)
+                return c + (1.0 - torch.sum(w_, -1)[..., None]) if white_bkg else c
+            rgb, w = ab.HipOp.apply(hip, expr, 1, rgbo, depth, ray_dirs)
+            extras = dict()
+            if render_depth is not None or normal_info is not None:
+                with torch.no_grad():
+                    _, _, d, nimg = ops.composite(rgbo.detach(), depth, ray_dirs, mul_norm == True, bool(white_bkg), code, render_depth,
+                                                  normal, cam_dir, want_weights=False)
+                if render_depth is not None:
+                    extras["depth_img"] = d
+                if normal_info is not None:
+                    extras["normal_img"] = nimg
+            return rgb, w, extras
         rgb, w, d, nimg = ops.composite(rgbo, depth, ray_dirs, mul_norm == True, bool(white_bkg), code, render_depth, normal, cam_dir)
         extras = dict()
         if render_depth is not None:
