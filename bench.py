@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--model", default="mip", choices=["mip", "ref"],
+                   help="mip = BASELINE configs[1] (the headline); ref = Ref-NeRF render path (configs[3] shape: 64 + 192 merged samples)")
     p.add_argument("--weights", default="small", choices=["small", "he", "zero"],
                    help="closed-form test weights; 'zero' is a power/DVFS diagnostic, never a reported number")
     p.add_argument("--cpu-rays", type=int, default=5000, help="rays of the same workload timed on the host cores")
@@ -113,10 +115,15 @@ def main():
     from nerf_amd.utils import fov2Focal, pose_spherical
 
     prec = ops.BF16 if a.precision == "bf16" else ops.F32
-    prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
+    is_ref = a.model == "ref"
+    if is_ref:
+        from nerf_amd.ref_model import RefNeRF
+        prop, mip = ProposalNetwork(10, 256), RefNeRF(10, 4)
+    else:
+        prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
     wtag = "small" if a.weights == "zero" else a.weights
     prop.load_state_dict(Wt.proposal_state(wtag))
-    mip.load_state_dict(Wt.mip_state(wtag))
+    mip.load_state_dict(Wt.ref_state(wtag) if is_ref else Wt.mip_state(wtag))
     if a.weights == "zero":
         for q in list(prop.parameters()) + list(mip.parameters()):
             q.data.zero_()
@@ -140,6 +147,17 @@ def main():
         sc = ops.samples_rays(rays, C_COARSE, z_base=z_base, u=u_strat, z_jitter=jitter)            # rows 2-4
         dens = ops.proposal_forward_samples(pk_prop, prec, sc, (n_rays, C_COARSE), dev)
         z_fine, _, _, _ = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1)   # rows 5-7
+        if is_ref:                                                                                    # procedures.py:71-74
+            z_fine, _, _, z_c = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1, want_zc=True)
+            z_all = torch.sort(torch.cat((z_fine, z_c), dim=-1), dim=-1)[0][:, :-1].contiguous()
+            if timed_idx is not None:
+                ev[timed_idx][0].record()
+            rgbo, _ = ops.ref_forward_samples(pk_mip, prec, ops.samples_rays(rays, z_all.shape[-1], z=z_all), (n_rays, z_all.shape[-1]), dev,
+                                              want_normal=False)
+            if timed_idx is not None:
+                ev[timed_idx][1].record()
+            rgb, w, depth, _ = ops.composite(rgbo, z_all, rays, True, True, ops.ACT_SOFTPLUS, (NEAR, FAR), sigma_shift=0.5)
+            return rgb, depth, w
         sf = ops.samples_rays(rays, N_FINE, z=z_fine)                                                 # rows 8-9
         if timed_idx is not None:
             ev[timed_idx][0].record()
@@ -171,21 +189,34 @@ def main():
     if rank == 0:
         fine_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
         fine_flops = n_rays * N_FINE * 2 * MAC_FINE
+        kernel_name = "mip_kernel (fine MLP, 527872 MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)"
+        flop_per_ray = FLOP_PER_RAY
+        if is_ref:
+            fine_flops = n_rays * (N_FINE + C_COARSE) * 2 * 1_071_616
+            kernel_name = "ref_kernel (Ref-NeRF spatial + directional MLP, 1071616 MAC/sample, 192 merged samples/ray)"
+            flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
+        # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command (profiles/*pmc*), FETCH_SIZE
+        # doubled per the gfx950 note of MI355X_MICROARCH.md; null when no profile for this configuration is committed
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("%s_%s" % (a.model, a.precision))
         peak = PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA
         achieved = fine_flops / (fine_ms * 1e-3)
         rec = {
-            "metric": "rays/s (64+128 samples), 800x800", "value": world * a.steps * n_rays / dt, "unit": "rays/s",
+            "metric": "rays/s (64+128 samples), 800x800" if not is_ref else "rays/s (64+192 samples, Ref-NeRF), 800x800", "value": world * a.steps * n_rays / dt, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic" if a.weights == "small" else "synthetic (DIAGNOSTIC weights=%s)" % a.weights,
-            "config": {"workload": "BASELINE configs[1]: NeRF render 800x800 (640000 rays/step/GPU), 64 proposal + 128 fine samples, "
-                                   "proposal MLP 63->256x4->1 + MipNeRF 8x256 MLP, rows 1-10 of SURVEY 8a, uniforms resident in HBM",
+            "config": {"workload": ("BASELINE configs[1]: NeRF render 800x800 (640000 rays/step/GPU), 64 proposal + 128 fine samples, "
+                                    "proposal MLP 63->256x4->1 + MipNeRF 8x256 MLP, rows 1-10 of SURVEY 8a, uniforms resident in HBM") if not is_ref else
+                                   ("Ref-NeRF render 800x800 (BASELINE configs[3] shape), 64 proposal + 192 merged samples, rows 1-8,10,13"),
                        "rays_per_step_per_gpu": n_rays, "samples": [C_COARSE, N_FINE], "mlp_arith": "bf16 MFMA, fp32 accumulate"
                        if prec == ops.BF16 else "fp32 MFMA", "parallelism": "ray-sharded replicas (dp%d)" % world},
-            "roofline": {"bound": "mfma", "kernel": "mip_kernel (fine MLP, 527872 MAC/sample)",
+            "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": None},
-            "whole_path_tflops": world * a.steps * n_rays * FLOP_PER_RAY / dt / 1e12,
+                         "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": traffic},
+            "whole_path_tflops": world * a.steps * n_rays * flop_per_ray / dt / 1e12,
         }
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
