@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--fused", action="store_true",
+                   help="fine MLP with the fused compositing epilogue (one launch for rows 8-10) instead of two launches; A/B switch")
     p.add_argument("--model", default="mip", choices=["mip", "ref"],
                    help="mip = BASELINE configs[1] (the headline); ref = Ref-NeRF render path (configs[3] shape: 64 + 192 merged samples)")
     p.add_argument("--weights", default="small", choices=["small", "he", "zero"],
@@ -158,13 +160,20 @@ def main():
                 ev[timed_idx][1].record()
             rgb, w, depth, _ = ops.composite(rgbo, z_all, rays, True, True, ops.ACT_SOFTPLUS, (NEAR, FAR), sigma_shift=0.5)
             return rgb, depth, w
-        sf = ops.samples_rays(rays, N_FINE, z=z_fine)                                                 # rows 8-9
-        if timed_idx is not None:
-            ev[timed_idx][0].record()
-        rgbo = ops.mip_forward_samples(pk_mip, prec, sf, (n_rays, N_FINE), dev)
+        if not a.fused:
+            if timed_idx is not None:
+                ev[timed_idx][0].record()
+            rgbo = ops.mip_forward_samples(pk_mip, prec, ops.samples_rays(rays, N_FINE, z=z_fine), (n_rays, N_FINE), dev)
+            if timed_idx is not None:
+                ev[timed_idx][1].record()
+            rgb, w, depth, _ = ops.composite(rgbo, z_fine, rays, True, True, ops.ACT_RELU, (NEAR, FAR))
+            return rgb, depth, w
+        if timed_idx is not None:                                                                     # rows 8-10, one launch:
+            ev[timed_idx][0].record()                                                                 # fine MLP + fused compositing
+        rgb, depth, w = ops.mip_forward_composite(pk_mip, prec, rays, z_fine, N_FINE, True, NEAR, FAR, want_depth=True,
+                                                  want_weights=not os.environ.get("BENCH_NO_WEIGHTS"))
         if timed_idx is not None:
             ev[timed_idx][1].record()
-        rgb, w, depth, _ = ops.composite(rgbo, z_fine, rays, True, True, ops.ACT_RELU, (NEAR, FAR))   # row 10
         return rgb, depth, w
 
     def sync():
@@ -189,7 +198,7 @@ def main():
     if rank == 0:
         fine_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
         fine_flops = n_rays * N_FINE * 2 * MAC_FINE
-        kernel_name = "mip_kernel (fine MLP, 527872 MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)"
+        kernel_name = "mip_kernel (fine MLP, 527872 MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)" + (" + fused compositing epilogue" if a.fused else "")
         flop_per_ray = FLOP_PER_RAY
         if is_ref:
             fine_flops = n_rays * (N_FINE + C_COARSE) * 2 * 1_071_616

@@ -108,6 +108,12 @@ int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_
 int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src,
                          float* rgbo, void* stream);
 
+/* MipNeRF.forward + NeRF.render fused (mip_model.py:41-60 + nerf_base.py:91-113, mul_norm = True, relu density): the
+ * (N,S,4) network output stays on chip; the last wavefront of each ray composites it.  `src` must be mode 1 (rays + z) with
+ * S in {32, 64, 128}.  Outputs rgb (N,3), depth (N) or NULL, weights (N,S) or NULL. */
+int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf_amd_samples* src, int white_bkg,
+                                   float near, float far, float* rgb, float* depth, float* weights, void* stream);
+
 /* RefNeRF.forward in eval mode, use_srgb=False (ref_model.py:68-106): rgbo (M,4) = [rgb | raw density],
  * normal (M,3) (NULL to skip).  Samples need a direction (pts_stride >= 6 in mode 0). */
 int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src,

@@ -9,6 +9,7 @@
 // launchers defined in the kernel translation units
 int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
+int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
 int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
@@ -113,6 +114,18 @@ int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_sampl
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(mlp_launch_mip(packed, precision, *src, rgbo, S(stream)), "nerf_amd_mip_forward");
+}
+
+int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf_amd_samples* src, int white_bkg, float near,
+                                   float far, float* rgb, float* depth, float* weights, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (int c = check_samples(src, true)) return c;
+    if (src->mode != 1 || !src->z) return fail(NERF_AMD_EUNSUPPORTED, "fused compositing needs mode 1 (rays + z)");
+    if (src->S != 32 && src->S != 64 && src->S != 128) return fail(NERF_AMD_EUNSUPPORTED, "fused compositing needs S in {32, 64, 128}");
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !rgb) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(mlp_launch_mip_composite(packed, precision, *src, rgb, depth, weights, white_bkg, near, far, S(stream)),
+                      "nerf_amd_mip_forward_composite");
 }
 
 int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, float* normal, void* stream) {
@@ -255,6 +268,8 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
                             nullptr, nullptr, nullptr, st)) return hip_status(e, "resample");
     nerf_amd_samples sf{};                                  // rows 8-9: drop the last depth, length2pts fused into the MLP
     sf.mode = 1; sf.rays = rays; sf.S = n_fine; sf.M = N * n_fine; sf.z = z_fine; sf.z_stride = n_fine + 1;
+    // rows 9 and 10 as two launches: measured 2-3 % faster than the fused epilogue of nerf_amd_mip_forward_composite on
+    // MI355X, and the composite kernel's HBM rate stays individually measurable
     if (int e = mlp_launch_mip(packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");
     const int flags = 1 | (white_bkg ? 2 : 0);              // row 10
     if (int e = sk_composite(rgbo, z_fine, n_fine + 1, rays + 3, 6, N, n_fine, flags, NERF_AMD_ACT_RELU, 0.0f, near, far, nullptr,

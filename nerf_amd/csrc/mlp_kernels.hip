@@ -48,6 +48,11 @@ struct PBF16 {
     static DEVINL f32x16 mma(const AReg& a, const BReg& b, f32x16 acc) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
+    // chain position: 0 first (C = bias in VGPRs), 1 middle, 2 last, 4 first with C = 0
+    template <int POS>
+    static DEVINL f32x16 mma_pos(const AReg& a, const BReg& b, f32x16 acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
     static DEVINL void set(BReg& r, int e, float v) { r[e] = (__bf16)v; }
     // 8 accumulators -> one B register group.  ReLU is applied AFTER the bf16 conversion as a packed signed-int16
     // max with 0 (negative floats have the sign bit set): 8 v_cvt_pk + 4 v_pk_max_i16 instead of 8 v_max + ... per group
@@ -93,6 +98,8 @@ struct PF32 {
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[e], b[4 + e], acc, 0, 0, 0);
         return acc;
     }
+    template <int POS>
+    static DEVINL f32x16 mma_pos(const AReg& a, const BReg& b, f32x16 acc) { return mma(a, b, acc); }
     static DEVINL void set(BReg& r, int e, float v) { r[e] = v; }
     template <bool RELU>
     static DEVINL BReg from_acc(const f32x16& acc, int off) {
@@ -296,9 +303,10 @@ DEVINL void pair_k(WS& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)[2], uint32_t
     if constexpr (KG < NKG) {
         const typename P::BReg b = in(KG);
         const typename P::AReg a0 = ws.template next<FRAG0 + 2 * KG>();
-        acc0 = P::mma(a0, b, acc0);
+        constexpr int POS = (KG == 0) ? 0 : ((KG == NKG - 1) ? 2 : 1);
+        acc0 = P::template mma_pos<POS>(a0, b, acc0);
         const typename P::AReg a1 = ws.template next<FRAG0 + 2 * KG + 1>();
-        acc1 = P::mma(a1, b, acc1);
+        acc1 = P::template mma_pos<POS>(a1, b, acc1);
         if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
             nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
             nb[1] = load_bias(next_bias + 128);
@@ -310,8 +318,9 @@ template <class P, int NKG, int FRAG0, int KG, class WS, class InF>
 DEVINL void single_k(WS& ws, f32x16& acc0, f32x16& acc1, InF& in) {
     if constexpr (KG < NKG) {
         const typename P::AReg a = ws.template next<FRAG0 + KG>();
-        if constexpr (KG % 2 == 0) acc0 = P::mma(a, in(KG), acc0);
-        else acc1 = P::mma(a, in(KG), acc1);
+        constexpr int LAST_EVEN = ((NKG - 1) / 2) * 2, LAST_ODD = (NKG % 2 == 0) ? NKG - 1 : NKG - 2;
+        if constexpr (KG % 2 == 0) acc0 = P::template mma_pos<(KG == 0) ? 0 : ((KG == LAST_EVEN) ? 2 : 1)>(a, in(KG), acc0);
+        else acc1 = P::template mma_pos<(KG == 1) ? 4 : ((KG == LAST_ODD) ? 2 : 1)>(a, in(KG), acc1);
         single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in);
     }
 }
@@ -451,7 +460,8 @@ DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) 
 constexpr uint32_t LDS_BIAS = MLP_RING_BYTES;
 constexpr uint32_t LDS_STASH = MLP_RING_BYTES + 9216;                 // bias table: <= 2240 floats
 template <class P> constexpr uint32_t lds_dir() { return LDS_STASH + P::NW * 4 * P::BREG_LDS; }
-template <class P> constexpr uint32_t lds_total() { return lds_dir<P>() + P::NW * 1024; }
+template <class P> constexpr uint32_t lds_tile() { return lds_dir<P>() + P::NW * 1024; }            // (tile samples) x float4 + 8 tickets
+template <class P> constexpr uint32_t lds_total() { return lds_tile<P>() + P::NW * 32 * 24 + 64; }
 
 DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias, uint32_t lds_off = MLP_RING_BYTES) {
     const float* b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + stream_bytes);
@@ -507,12 +517,24 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
 // ================================================================================================
 // MipNeRF
 // ================================================================================================
+// Optional fused compositing epilogue (nerf_base.py:91-113): when `rgb` is set, the (rgb, sigma) of a tile are parked in
+// LDS and the LAST wavefront of each ray to arrive (LDS atomic ticket) composites the ray: sigma -> alpha, wave
+// prefix-product transmittance, weighted sums -- the (N,S,4) network output never goes to HBM.
+struct FusedComposite {
+    float* rgb;        // (N,3) or nullptr = epilogue off
+    float* depth;      // (N) or nullptr
+    float* weights;    // (N,S) or nullptr
+    int white_bkg;
+    float near, far;
+};
+
 template <class P>
 __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict__ packed, nerf_amd_samples s,
-                                                         float* __restrict__ rgbo) {
+                                                         float* __restrict__ rgbo, FusedComposite fc) {
     using L = MipLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
+    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * 32 * 24)[threadIdx.x] = 0u;   // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
     WeightStream<P> ws;
     ws.init(packed, L::N_FRAGS / FPC);
@@ -536,6 +558,18 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) P::stash(enc_lds + k * P::BREG_LDS, enc[k]);
             f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
+            if (fc.rgb != nullptr) {
+                // fused compositing needs z|d| and the distance to the next sample at the END of the tile; fetch them now,
+                // while the tile's other global loads are in flight (a load at the tile end would drain the weight DMA queue)
+                const int64_t mm_ = m < s.M ? m : s.M - 1;
+                const int64_t n_ = mm_ / s.S;
+                const int si_ = (int)(mm_ - n_ * s.S);
+                const float nrm_ = norm3(sm.dx, sm.dy, sm.dz);
+                const float* zz_ = s.z + n_ * s.z_stride;
+                const float zn0 = zz_[si_] * nrm_;
+                const float dl = (si_ + 1 < s.S) ? (zz_[si_ + 1] * nrm_ - zn0) : 1e10f;
+                dv[3] = h ? dl : zn0;
+            }
             *reinterpret_cast<f32x4*>(smem + dir_lds) = dv;
             // lin_block1.0 : 63 -> 256
             dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
@@ -588,13 +622,78 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
             [&](int kg) -> BReg { return c[kg]; },
             [&](int, const f32x16& acc) { r = acc[0]; g = acc[1]; bl = acc[2]; });
-        if (h == 0 && m < s.M) {
-            f32x4 o;
-            o[0] = 1.0f / (1.0f + expf(-r));
-            o[1] = 1.0f / (1.0f + expf(-g));
-            o[2] = 1.0f / (1.0f + expf(-bl));
-            o[3] = sigma;
-            *reinterpret_cast<f32x4*>(rgbo + m * 4) = o;
+        f32x4 o;
+        o[0] = 1.0f / (1.0f + expf(-r));
+        o[1] = 1.0f / (1.0f + expf(-g));
+        o[2] = 1.0f / (1.0f + expf(-bl));
+        o[3] = sigma;
+        if (fc.rgb == nullptr) {
+            if (h == 0 && m < s.M) *reinterpret_cast<f32x4*>(rgbo + m * 4) = o;
+        } else {
+            // ---- fused compositing epilogue (S in {32, 64, 128} divides the tile: a ray = S/32 consecutive waves) ----
+            // Every wave parks (rgb, sigma, z|d|, delta) of its 32 samples in LDS and takes an LDS ticket; the LAST wave of
+            // the ray to arrive composites it: sigma -> alpha, wave prefix product of the transmittance (fp64, like torch's CPU
+            // cumprod), weighted sums.  Nobody waits for anybody, and nothing here touches global memory except the outputs.
+            const int S = s.S;
+            const int wpr = S >> 5;                                        // wavefronts per ray
+            const int ray_in_tile = wave / wpr;
+            const int64_t n = (tile * TS) / S + ray_in_tile;
+            char* tb = smem + lds_tile<P>();
+            f32x4* t_rgbo = reinterpret_cast<f32x4*>(tb);                               // [TS] rgb + sigma
+            f32x2* t_zd = reinterpret_cast<f32x2*>(tb + TS * 16);                       // [TS] z|d|, delta
+            unsigned* tickets = reinterpret_cast<unsigned*>(tb + TS * 24);
+            {
+                const float keep3 = (*reinterpret_cast<const f32x4*>(smem + dir_lds))[3];      // half 0: z|d|, half 1: delta (tile start)
+                const float dl = __shfl(keep3, j + 32, 64);
+                if (h == 0) {
+                    t_rgbo[wave * 32 + j] = o;
+                    f32x2 zd = {keep3, dl};
+                    t_zd[wave * 32 + j] = zd;
+                }
+            }
+            // LDS executes one wavefront's DS instructions in order, so the ticket is ordered behind the record writes without
+            // a fence (a workgroup-scope fence would also wait vmcnt(0) and drain the weight DMA queue); the asm statements only
+            // stop the compiler from moving LDS accesses across the ticket.
+            asm volatile("" ::: "memory");
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(&tickets[ray_in_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            asm volatile("" ::: "memory");
+            if (((old + 1) % (unsigned)wpr) == 0 && n * S < s.M) {         // last arriver of this ray (tickets only ever grow)
+                const f32x4* px = t_rgbo + ray_in_tile * S;
+                const f32x2* pz = t_zd + ray_in_tile * S;
+                float ar = 0.0f, ag = 0.0f, abl = 0.0f, aw = 0.0f, ad = 0.0f;
+                float* wout = fc.weights ? fc.weights + n * S : nullptr;
+                double carry = 1.0;
+                for (int base = 0; base < S; base += 64) {
+                    const int q = base + lane;
+                    float w = 0.0f;
+                    double p = 1.0;
+                    f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+                    f32x2 zd = {0.0f, 0.0f};
+                    if (q < S) {
+                        c = px[q]; zd = pz[q];
+                        const float mm = expf(-fmaxf(c[3], 0.0f) * zd[1]);
+                        w = 1.0f - mm;
+                        p = (double)(mm + 1e-10f);
+                    }
+                    const double incl = wave_incl_scan_mul(p);
+                    double excl = __shfl_up(incl, 1, 64);
+                    if (lane == 0) excl = 1.0;
+                    w *= (float)(carry * excl);
+                    carry *= __shfl(incl, 63, 64);
+                    if (q < S) {
+                        ar += w * c[0]; ag += w * c[1]; abl += w * c[2]; aw += w; ad += w * zd[0];
+                        if (wout) wout[q] = w;
+                    }
+                }
+                ar = wave_sum(ar); ag = wave_sum(ag); abl = wave_sum(abl); aw = wave_sum(aw); ad = wave_sum(ad);
+                if (lane == 0) {
+                    if (fc.white_bkg) { const float bg = 1.0f - aw; ar += bg; ag += bg; abl += bg; }
+                    fc.rgb[n * 3] = ar; fc.rgb[n * 3 + 1] = ag; fc.rgb[n * 3 + 2] = abl;
+                    if (fc.depth) fc.depth[n] = (ad - fc.near) / (fc.far - fc.near);
+                }
+            }
         }
     }
     ws.drain();
@@ -779,8 +878,8 @@ int grid_for(int64_t n_tiles) {
     return (int)(n_tiles < n_cu ? n_tiles : n_cu);
 }
 
-template <class P, class Lay, class K>
-int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st) {
+template <class P, class Lay, class K, class... Extra>
+int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st, Extra... extra) {
     constexpr int TS = P::NW * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
@@ -791,7 +890,7 @@ int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, 
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, out);
+    hipLaunchKernelGGL(kernel, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, out, extra...);
     return (int)hipGetLastError();
 }
 
@@ -803,8 +902,16 @@ int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_sample
     return launch<PF32, PropLayout>(proposal_kernel<PF32>, packed, s, density, st);
 }
 int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch<PBF16, MipLayout>(mip_kernel<PBF16>, packed, s, rgbo, st);
-    return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, rgbo, st);
+    const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
+    if (precision == NERF_AMD_BF16) return launch<PBF16, MipLayout>(mip_kernel<PBF16>, packed, s, rgbo, st, off);
+    return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, rgbo, st, off);
+}
+// fine MLP + compositing in one launch; requires mode 1 (rays + z) and S in {32, 64, 128}
+int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_samples& s, float* rgb, float* depth, float* weights,
+                             int white_bkg, float near, float far, hipStream_t st) {
+    const FusedComposite fc{rgb, depth, weights, white_bkg, near, far};
+    if (precision == NERF_AMD_BF16) return launch<PBF16, MipLayout>(mip_kernel<PBF16>, packed, s, (float*)nullptr, st, fc);
+    return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, (float*)nullptr, st, fc);
 }
 
 template <class P>

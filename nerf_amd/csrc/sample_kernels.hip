@@ -88,36 +88,6 @@ __global__ void length2pts_kernel(const float* __restrict__ rays, const float* _
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// sigma -> weights for one ray handled by one wavefront (rows 5 / 10).
-//   sig(s), zn(s): loaders for sample s (zn already scaled by |d| when required)
-//   emit(s, w, zn_s): called by the lane that owns sample s
-// ------------------------------------------------------------------------------------------------
-template <class SigF, class ZF, class EmitF>
-DEVINL void wave_sigma_to_weights(int S, int act, SigF&& sig, ZF&& zn, EmitF&& emit) {
-    const int lane = lane_id();
-    double carry = 1.0;
-    for (int base = 0; base < S; base += 64) {
-        const int s = base + lane;
-        const bool ok = s < S;
-        float w = 0.0f, z0 = 0.0f;
-        double p = 1.0;
-        if (ok) {
-            z0 = zn(s);
-            const float delta = (s + 1 < S) ? (zn(s + 1) - z0) : 1e10f;
-            const float m = expf(-density_act(sig(s), act) * delta);
-            w = 1.0f - m;                                    // alpha
-            p = (double)(m + 1e-10f);
-        }
-        const double incl = wave_incl_scan_mul(p);
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0;
-        const float T = (float)(carry * excl);
-        carry *= __shfl(incl, 63, 64);
-        if (ok) emit(s, w * T, z0);
-    }
-}
-
 __global__ __launch_bounds__(256) void sigma_to_weights_kernel(const float* __restrict__ sigma, const float* __restrict__ z,
                                                               const float* __restrict__ dirs, int64_t N, int S, int act,
                                                               float* __restrict__ w) {

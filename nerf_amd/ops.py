@@ -118,6 +118,20 @@ def mip_forward_samples(packed, precision, s: Samples, shape, device) -> torch.T
     return out
 
 
+def mip_forward_composite(packed, precision, rays: torch.Tensor, z: torch.Tensor, n_samples: int, white_bkg: bool, near: float,
+                          far: float, want_depth: bool = True, want_weights: bool = False):
+    """Fine MLP + alpha compositing in one launch (rows 8-10); z (N, >= n_samples) row stride = z.shape[-1]."""
+    N = rays.shape[0]
+    dev = rays.device
+    rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
+    w = torch.empty((N, n_samples), dtype=torch.float32, device=dev) if want_weights else None
+    s = samples_rays(rays, n_samples, z=z)
+    check(lib.nerf_amd_mip_forward_composite(_ptr(packed), precision, C.byref(s), int(white_bkg), float(near), float(far), _ptr(rgb),
+                                             _ptr(depth), _ptr(w), _stream()), "nerf_amd_mip_forward_composite")
+    return rgb, depth, w
+
+
 def _ref_out(shape, device, want_normal):
     rgbo = torch.empty(tuple(shape) + (4,), dtype=torch.float32, device=device)
     normal = torch.empty(tuple(shape) + (3,), dtype=torch.float32, device=device) if want_normal else None

@@ -463,3 +463,22 @@ def test_train_step_gradients(A, golden):
     opt.step()
     after = mip.forward(dev(g["rays"][:4, None, :].repeat(1, 3, 1))).detach()
     assert not torch.equal(before, after)
+
+
+@pytest.mark.parametrize("n_fine,n", [(128, 777), (64, 1000), (32, 513)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_compositing_epilogue_equals_two_launches(A, n_fine, n, prec):
+    """nerf_amd_mip_forward_composite (fine MLP + in-kernel wave-prefix-product compositing by the last wavefront of each
+    ray) against MipNeRF.forward followed by NeRF.render; ragged ray counts exercise the tile tail."""
+    _, mip = build_nets(A, "he")
+    P = A.ops.F32 if prec == "fp32" else A.ops.BF16
+    gen = torch.Generator().manual_seed(n)
+    pose = O.pose_spherical(10.0, -30.0, 4.0)[:3]
+    dirs = O.ray_dirs_image(pose, 40, 40, O.fov2focal(0.6911112070083618, (40, 40))).reshape(-1, 3)
+    rays = torch.cat((pose[:, -1].expand(n, -1), dirs[torch.randint(0, 1600, (n,), generator=gen)]), -1).contiguous().cuda()
+    z = torch.sort(NEAR + (FAR - NEAR) * torch.rand(n, n_fine + 1, generator=gen), dim=-1)[0].cuda()
+    for wb in (False, True):
+        rgb, depth, w = A.ops.mip_forward_composite(mip.packed(P), P, rays, z, n_fine, wb, NEAR, FAR, want_depth=True, want_weights=True)
+        rgbo = A.ops.mip_forward_samples(mip.packed(P), P, A.ops.samples_rays(rays, n_fine, z=z), (n, n_fine), "cuda")
+        rgb2, w2, depth2, _ = A.ops.composite(rgbo, z, rays, True, wb, A.ops.ACT_RELU, (NEAR, FAR))
+        assert max_abs(rgb, rgb2) <= 2e-6 and max_abs(depth, depth2) <= 2e-6 and max_abs(w, w2) <= 1e-6
