@@ -127,7 +127,10 @@ DEVINL void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, float* cdf, float* samp, int* bel,
+constexpr int SORT_NB = 256, SORT_CAP = 6;
+constexpr int SORT_LDS_FLOATS = 2 * SORT_NB + SORT_NB * SORT_CAP / 2;      // cnt, pre (int) + members (uint16)
+
+DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, float* cdf, float* samp, int* bel, int* sortbuf,
                                 const float* __restrict__ u, int K, int sort, float* __restrict__ z_out,
                                 int64_t* __restrict__ below_out, int64_t* __restrict__ above_out) {
     const int lane = lane_id();
@@ -171,21 +174,66 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
     }
     if (!sort) return;
     lds_wave_sync();
-    // stable rank sort: K is small (<= ~1e3); every lane ranks its own elements against all (LDS broadcast reads)
+    // Sort.  The inverse CDF is monotone, so the order of the samples is the order of their uniforms: bucket the
+    // elements by floor(u * 256) (LDS atomics hand out the slot inside a bucket), prefix-sum the bucket counts, and rank
+    // every element against the <= SORT_CAP members of its own bucket only.  Adversarial inputs (a bucket holding more
+    // than SORT_CAP elements) fall back to the O(K^2) stable rank sort; both give the same sorted values.
+    int* cnt = sortbuf;
+    int* pre = sortbuf + SORT_NB;
+    unsigned short* mem = reinterpret_cast<unsigned short*>(sortbuf + 2 * SORT_NB);
+    for (int b = lane; b < SORT_NB; b += 64) cnt[b] = 0;
+    lds_wave_sync();
+    int overflow = 0;
     for (int k = lane; k < K; k += 64) {
+        int b = (int)(u[k] * (float)SORT_NB);
+        b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
+        const int pos = atomicAdd(&cnt[b], 1);
+        if (pos < SORT_CAP) mem[b * SORT_CAP + pos] = (unsigned short)k; else overflow = 1;
+    }
+    lds_wave_sync();
+    if (__any(overflow)) {
+        for (int k = lane; k < K; k += 64) {          // stable rank sort (LDS broadcast reads)
+            const float v = samp[k];
+            int rank = 0;
+            for (int j = 0; j < K; ++j) {
+                const float o = samp[j];
+                rank += (o < v || (o == v && j < k)) ? 1 : 0;
+            }
+            z_out[rank] = v;
+            if (below_out) below_out[rank] = bel[k];
+        }
+        return;
+    }
+    {   // exclusive prefix sum of the 256 bucket counts: 4 per lane
+        int c[4], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[i] = cnt[lane * 4 + i]; tot += c[i]; }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        int run = incl - tot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pre[lane * 4 + i] = run; run += c[i]; }
+    }
+    lds_wave_sync();
+    for (int k = lane; k < K; k += 64) {
+        int b = (int)(u[k] * (float)SORT_NB);
+        b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
         const float v = samp[k];
-        int rank = 0;
-        for (int j = 0; j < K; ++j) {
-            const float o = samp[j];
-            rank += (o < v || (o == v && j < k)) ? 1 : 0;
+        int rank = pre[b];
+        const int nb_ = cnt[b];
+        for (int p = 0; p < nb_; ++p) {
+            const int jx = mem[b * SORT_CAP + p];
+            const float o = samp[jx];
+            rank += (o < v || (o == v && jx < k)) ? 1 : 0;
         }
         z_out[rank] = v;
         if (below_out) below_out[rank] = bel[k];
     }
 }
 
-// LDS floats per wave: pw[C] bins[C] cdf[C] samp[K] bel[K]
-DEVINL size_t inv_lds_floats(int C, int K) { return (size_t)3 * C + 2 * K; }
+// LDS floats per wave: pw[C] bins[C] cdf[C] samp[K] bel[K] sortbuf
+DEVINL size_t inv_lds_floats(int C, int K) { return (size_t)3 * C + 2 * K + SORT_LDS_FLOATS; }
 
 // mode 0: inverseSample(weights (N,C), depths (N,C)) -> bins = mid-points, pdf = weights[1:-1]   (utils.py:34-44)
 // mode 1: sample_pdf(bins (N,C), weights (N,C-1))                                               (utils.py:108-133)
@@ -196,6 +244,7 @@ __global__ __launch_bounds__(256) void inverse_sample_kernel(const float* __rest
     float* base = reinterpret_cast<float*>(smem) + wave_in_block() * inv_lds_floats(C, K);
     float* pw = base; float* bins = pw + C; float* cdf = bins + C; float* samp = cdf + C;
     int* bel = reinterpret_cast<int*>(samp + K);
+    int* sortbuf = bel + K;
     const int lane = lane_id();
     const int nw = mode == 0 ? C - 2 : C - 1;
     const int wstride = mode == 0 ? C : C - 1;
@@ -209,7 +258,7 @@ __global__ __launch_bounds__(256) void inverse_sample_kernel(const float* __rest
             for (int j = lane; j < nw + 1; j += 64) bins[j] = z[n * C + j];
         }
         lds_wave_sync();
-        wave_inverse_sample(pw, bins, nw, cdf, samp, bel, u + n * K, K, sort, z_out + n * K, below ? below + n * K : nullptr,
+        wave_inverse_sample(pw, bins, nw, cdf, samp, bel, sortbuf, u + n * K, K, sort, z_out + n * K, below ? below + n * K : nullptr,
                             above ? above + n * K : nullptr);
     }
 }
@@ -229,7 +278,8 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     float* base = reinterpret_cast<float*>(smem) + wave_in_block() * (inv_lds_floats(C, K) + 2 * C);
     float* pw = base; float* bins = pw + C; float* cdf = bins + C; float* samp = cdf + C;
     int* bel = reinterpret_cast<int*>(samp + K);
-    float* zl = reinterpret_cast<float*>(bel + K);
+    int* sortbuf = bel + K;
+    float* zl = reinterpret_cast<float*>(sortbuf + SORT_LDS_FLOATS);
     float* wraw = zl + C;
     const int lane = lane_id();
     for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
@@ -259,7 +309,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         }
         for (int j = lane; j < C - 1; j += 64) bins[j] = 0.5f * (zl[j + 1] + zl[j]);   // mid-points of the RAW depths
         lds_wave_sync();
-        wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, a.u_inv + n * K, K, 1, a.z_fine + n * K,
+        wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, sortbuf, a.u_inv + n * K, K, 1, a.z_fine + n * K,
                             a.below ? a.below + n * K : nullptr, nullptr);
     }
 }
@@ -388,7 +438,7 @@ int sk_max_blur(const float* w, int64_t N, int S, float alpha, float* out, hipSt
 int sk_inverse_sample(const float* w, const float* z, const float* u, int64_t N, int C, int K, int sort, int mode, float* z_out,
                       int64_t* below, int64_t* above, hipStream_t st) {
     if (N == 0) return 0;
-    const size_t lds = WAVES_PER_BLOCK * ((size_t)3 * C + 2 * K) * 4;
+    const size_t lds = WAVES_PER_BLOCK * ((size_t)3 * C + 2 * K + SORT_LDS_FLOATS) * 4;
     hipLaunchKernelGGL(inverse_sample_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, w, z, u, N, C, K, sort, mode,
                        z_out, below, above);
     return (int)hipGetLastError();
@@ -398,7 +448,7 @@ int sk_resample(const float* density, const float* z, const float* z_base, const
                 float* z_fine, int64_t* below, float* w_prop, float* z_coarse, hipStream_t st) {
     if (N == 0) return 0;
     ResampleArgs a{density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus, alpha, z_fine, below, w_prop, z_coarse};
-    const size_t lds = WAVES_PER_BLOCK * ((size_t)5 * C + 2 * K) * 4;
+    const size_t lds = WAVES_PER_BLOCK * ((size_t)5 * C + 2 * K + SORT_LDS_FLOATS) * 4;
     hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a);
     return (int)hipGetLastError();
 }

@@ -482,3 +482,23 @@ def test_fused_compositing_epilogue_equals_two_launches(A, n_fine, n, prec):
         rgbo = A.ops.mip_forward_samples(mip.packed(P), P, A.ops.samples_rays(rays, n_fine, z=z), (n, n_fine), "cuda")
         rgb2, w2, depth2, _ = A.ops.composite(rgbo, z, rays, True, wb, A.ops.ACT_RELU, (NEAR, FAR))
         assert max_abs(rgb, rgb2) <= 2e-6 and max_abs(depth, depth2) <= 2e-6 and max_abs(w, w2) <= 1e-6
+
+
+@pytest.mark.parametrize("K,kind", [(129, "uniform"), (193, "uniform"), (65, "uniform"), (129, "clustered"), (129, "constant"), (300, "uniform")])
+def test_inverse_sampling_sort_paths(A, K, kind):
+    """The bucket-rank sort (uniform u) and its O(K^2) fallback (clustered / constant u overflow a bucket) against torch.sort."""
+    gen = torch.Generator().manual_seed(K)
+    N, C = 37, 64
+    w = torch.rand(N, C, generator=gen) ** 3 + 0.01
+    z = torch.sort(NEAR + (FAR - NEAR) * torch.rand(N, C, generator=gen), dim=-1)[0]
+    if kind == "uniform":
+        u = torch.rand(N, K, generator=gen)
+    elif kind == "clustered":
+        u = 0.5 + 1e-4 * torch.rand(N, K, generator=gen)
+    else:
+        u = torch.full((N, K), 0.25)
+    want_z, want_b = O.inverse_sample(w, z, u, sort=True)
+    got_z, got_b = A.utils.inverseSample(dev(w), dev(z), K, sort=True, u=u)
+    assert bool((got_z[:, 1:] >= got_z[:, :-1]).all())
+    assert max_abs(got_z.cpu(), want_z) <= 1e-4          # irregular random bins up to 0.3 wide x eps(cdf)/pdf (see test_inverse_sampling)
+    assert _below_mismatch(got_b.cpu(), want_b) <= 0.01
