@@ -132,3 +132,52 @@ def test_ipe_restatement_matches_golden(golden):
     g = golden("g12_ipe")
     feat, mu, mu_t = ipe_feature(g["z"], g["rays"], 6, 0.0015)
     assert (feat - g["feat"]).abs().max() <= 1e-6 and (mu - g["mu"]).abs().max() <= 1e-6 and (mu_t - g["mu_t"]).abs().max() <= 1e-6
+
+
+def test_checkpoint_roundtrip_with_reference_modules(tmp_path):
+    """Checkpoint ABI: a file written by the reference's saveModel loads into the nerf_amd modules and
+    back.  Needs the reference checkout (build container only); skipped where /root/reference is absent (GPU box)."""
+    import importlib
+    import sys
+    if not os.path.isdir("/root/reference/nerf"):
+        pytest.skip("reference checkout not present")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    saved_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    make_golden.install_shims()
+    try:
+        ref_mip = importlib.import_module("nerf.mip_model")
+        ref_add = importlib.import_module("nerf.addtional")
+        ref_helper = importlib.import_module("nerf.nerf_helper")
+        from nerf_amd.addtional import ProposalNetwork
+        from nerf_amd.mip_model import MipNeRF
+        from nerf_amd.nerf_helper import saveModel
+        torch.manual_seed(0)
+        r_mip, r_prop = ref_mip.MipNeRF(10, 4, 256), ref_add.ProposalNetwork(10, 256)
+        opt = torch.optim.Adam(list(r_mip.parameters()), lr=1e-3)
+        ref_helper.saveModel(r_mip, str(tmp_path / "a_mip.pt"), {"train_cnt": 123, "epoch": 4}, opt=opt)
+        ref_helper.saveModel(r_prop, str(tmp_path / "a_prop.pt"))
+        mine_mip, mine_prop = MipNeRF(10, 4, 256), ProposalNetwork(10, 256)
+        opt2 = torch.optim.Adam(list(mine_mip.parameters()), lr=1e-3)
+        assert mine_mip.loadFromFile(str(tmp_path / "a_mip.pt"), False, opt2, ["train_cnt", "epoch"]) == [123, 4]
+        mine_prop.loadFromFile(str(tmp_path / "a_prop.pt"))
+        for k, v in r_mip.state_dict().items():
+            assert torch.equal(v, mine_mip.state_dict()[k])
+        for k, v in r_prop.state_dict().items():
+            assert torch.equal(v, mine_prop.state_dict()[k])
+        # and back: DDP-style "module." prefixes are stripped on load (nerf_base.py:34-38)
+        sd = {"module." + k: v for k, v in mine_mip.state_dict().items()}
+        torch.save({"model": sd}, str(tmp_path / "b_mip.pt"))
+        r2 = ref_mip.MipNeRF(10, 4, 256)
+        r2.loadFromFile(str(tmp_path / "b_mip.pt"))
+        assert all(torch.equal(v, r2.state_dict()[k]) for k, v in mine_mip.state_dict().items())
+        saveModel(mine_prop, str(tmp_path / "c_prop.pt"))
+        r3 = ref_add.ProposalNetwork(10, 256)
+        r3.loadFromFile(str(tmp_path / "c_prop.pt"))
+        assert all(torch.equal(v, r3.state_dict()[k]) for k, v in mine_prop.state_dict().items())
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = saved_cuda
+        for m in [k for k in sys.modules if k == "nerf" or k.startswith("nerf.")]:
+            del sys.modules[m]
+        if "/root/reference" in sys.path:
+            sys.path.remove("/root/reference")

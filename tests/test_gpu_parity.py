@@ -502,3 +502,42 @@ def test_inverse_sampling_sort_paths(A, K, kind):
     assert bool((got_z[:, 1:] >= got_z[:, :-1]).all())
     assert max_abs(got_z.cpu(), want_z) <= 1e-4          # irregular random bins up to 0.3 wide x eps(cdf)/pdf (see test_inverse_sampling)
     assert _below_mismatch(got_b.cpu(), want_b) <= 0.01
+
+
+# ------------------------------------------------------------------------------------------------ robustness
+def test_non_contiguous_inputs_and_side_stream(A):
+    """Views / strided tensors are accepted (made contiguous by the host layer) and the kernels run on the caller's
+    current HIP stream."""
+    prop, mip = build_nets(A, "small")
+    A.pkg.set_precision("fp32")
+    gen = torch.Generator().manual_seed(5)
+    big = torch.randn(64, 20, 12, generator=gen).cuda()
+    pts_view = big[::2, :, 3:9]                                      # non-contiguous (32, 20, 6)
+    with torch.no_grad():
+        a = mip.forward(pts_view)
+        b = mip.forward(pts_view.contiguous())
+        assert torch.equal(a, b)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            c = mip.forward(pts_view)
+            d = A.nerf_helper.positional_encoding(big[..., :3], 4)
+        st.synchronize()
+        assert torch.equal(a, c) and d.shape == (64, 20, 24)
+    z = torch.sort(torch.rand(9, 70, generator=gen) * 4 + 2, dim=-1)[0].cuda()
+    rgbo = torch.rand(9, 70, 4, generator=gen).cuda()
+    dirs6 = torch.randn(9, 6, generator=gen).cuda()
+    r1, w1, _ = A.nerf_base.NeRF.render(rgbo, z, dirs6[:, 3:])      # strided direction view
+    r2, w2, _ = A.nerf_base.NeRF.render(rgbo, z, dirs6[:, 3:].contiguous())
+    assert torch.equal(r1, r2) and torch.equal(w1, w2)
+
+
+def test_error_reporting(A):
+    from nerf_amd._lib import NerfAmdError
+    with pytest.raises(NerfAmdError):                                  # C < 3 is rejected by the C-ABI with a message
+        A.ops.inverse_sample(torch.rand(4, 2).cuda(), torch.rand(4, 2).cuda(), torch.rand(4, 8).cuda(), True)
+    with pytest.raises(NerfAmdError):
+        A.ops.mip_forward_composite(build_nets(A, "small")[1].packed(A.ops.F32), A.ops.F32, torch.rand(4, 6).cuda(),
+                                    torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
+    with pytest.raises(NotImplementedError):
+        A.addtional.ProposalNetwork(10).cuda().forward(torch.rand(2, 3, 3).cuda())          # width 128: no kernel instance
