@@ -171,6 +171,10 @@ def main():
             rgbo = ops.mip_forward_samples(pk_mip, prec, ops.samples_rays(rays, N_FINE, z=z_fine), (n_rays, N_FINE), dev)
             if timed_idx is not None:
                 ev[timed_idx][1].record()
+            if os.environ.get("NERF_AMD_CLOCKPROBE") and timed_idx is not None:       # diagnostic lib variants only (MLP_CLOCKPROBE)
+                torch.cuda.synchronize()
+                cyc, ticks = rgbo.view(-1)[:4].view(torch.int64).tolist()
+                sys.stderr.write("clockprobe: fine kernel %.2f ms at %.0f MHz\n" % (ticks / 1e5, cyc / max(ticks, 1) * 100.0))
             rgb, w, depth, _ = ops.composite(rgbo, z_fine, rays, True, True, ops.ACT_RELU, (NEAR, FAR))
             return rgb, depth, w
         if timed_idx is not None:                                                                     # rows 8-10, one launch:

@@ -37,6 +37,7 @@ struct PBF16 {
     using BReg = bf16x8;                       // one 16-feature K group of the B operand (4 VGPRs)
     static constexpr int PREC = NERF_AMD_BF16;
     static constexpr int NW = MLP_NW_BF16;     // wavefronts per workgroup
+    static constexpr int NT = 1;               // 32-sample MFMA column tiles per wavefront
     static constexpr int FRAG_BYTES = 1024;    // one A fragment: 32 rows x 16 k, bf16
     static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
     using AReg = bf16x8;                       // one A fragment per lane (4 VGPRs)
@@ -77,10 +78,19 @@ struct PBF16 {
     static DEVINL BReg unstash(uint32_t addr) { return *reinterpret_cast<const bf16x8*>(smem + addr); }
 };
 
+// bf16, wide tile: 4 wavefronts x 64 samples.  Every A fragment read from LDS feeds TWO MFMAs (one per 32-sample column
+// tile), which halves the LDS->VGPR traffic per flop -- the limiter of the 32-sample tile.
+// One wavefront per SIMD with the 512-register budget; the activations of both column tiles stay in registers.
+struct PBF16W : PBF16 {
+    static constexpr int NW = 4;
+    static constexpr int NT = 2;
+};
+
 struct PF32 {
     using BReg = f32x8;                        // 8 VGPRs per 16-feature K group
     static constexpr int PREC = NERF_AMD_F32;
     static constexpr int NW = MLP_NW_F32;
+    static constexpr int NT = 1;
     static constexpr int FRAG_BYTES = 2048;    // [2 halves][64 lanes][4 floats]
     static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
     struct AReg { f32x4 lo, hi; };
@@ -152,7 +162,7 @@ struct WeightStream {
         // The asm is invisible to that pass; completion is tracked by our own counted vmcnt in boundary().
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-#ifndef ABL_NOGLDS
+#if !defined(ABL_NOGLDS)
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
@@ -259,7 +269,9 @@ struct WeightStream {
 #endif
     template <int PARITY>
     DEVINL void boundary() {
+#ifndef ABL_NOVMWAIT
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+#endif
         // s_barrier only when this boundary's parity is mine; the branch lives inside the asm so that the compiler
         // sees straight-line code (a C++ `if` here splits every feature block into many basic blocks and spills)
 #ifndef ABL_NOBAR
@@ -299,14 +311,18 @@ DEVINL f32x16 load_bias(uint32_t addr) {
     return v;
 }
 template <class P, int NKG, int FRAG0, int KG, bool MORE, class WS, class InF>
-DEVINL void pair_k(WS& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)[2], uint32_t next_bias, InF& in) {
+DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 (&nb)[2], uint32_t next_bias, InF& in) {
     if constexpr (KG < NKG) {
-        const typename P::BReg b = in(KG);
+        typename P::BReg b[P::NT];
+#pragma unroll
+        for (int t = 0; t < P::NT; ++t) b[t] = in(KG, t);
         const typename P::AReg a0 = ws.template next<FRAG0 + 2 * KG>();
         constexpr int POS = (KG == 0) ? 0 : ((KG == NKG - 1) ? 2 : 1);
-        acc0 = P::template mma_pos<POS>(a0, b, acc0);
+#pragma unroll
+        for (int t = 0; t < P::NT; ++t) acc0[t] = P::template mma_pos<POS>(a0, b[t], acc0[t]);
         const typename P::AReg a1 = ws.template next<FRAG0 + 2 * KG + 1>();
-        acc1 = P::template mma_pos<POS>(a1, b, acc1);
+#pragma unroll
+        for (int t = 0; t < P::NT; ++t) acc1[t] = P::template mma_pos<POS>(a1, b[t], acc1[t]);
         if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
             nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
             nb[1] = load_bias(next_bias + 128);
@@ -315,12 +331,15 @@ DEVINL void pair_k(WS& ws, f32x16& acc0, f32x16& acc1, f32x16 (&nb)[2], uint32_t
     }
 }
 template <class P, int NKG, int FRAG0, int KG, class WS, class InF>
-DEVINL void single_k(WS& ws, f32x16& acc0, f32x16& acc1, InF& in) {
+DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& in) {
     if constexpr (KG < NKG) {
         const typename P::AReg a = ws.template next<FRAG0 + KG>();
         constexpr int LAST_EVEN = ((NKG - 1) / 2) * 2, LAST_ODD = (NKG % 2 == 0) ? NKG - 1 : NKG - 2;
-        if constexpr (KG % 2 == 0) acc0 = P::template mma_pos<(KG == 0) ? 0 : ((KG == LAST_EVEN) ? 2 : 1)>(a, in(KG), acc0);
-        else acc1 = P::template mma_pos<(KG == 1) ? 4 : ((KG == LAST_ODD) ? 2 : 1)>(a, in(KG), acc1);
+#pragma unroll
+        for (int t = 0; t < P::NT; ++t) {
+            if constexpr (KG % 2 == 0) acc0[t] = P::template mma_pos<(KG == 0) ? 0 : ((KG == LAST_EVEN) ? 2 : 1)>(a, in(KG, t), acc0[t]);
+            else acc1[t] = P::template mma_pos<(KG == 1) ? 4 : ((KG == LAST_ODD) ? 2 : 1)>(a, in(KG, t), acc1[t]);
+        }
         single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in);
     }
 }
@@ -329,20 +348,27 @@ DEVINL void dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, Ou
     if constexpr (2 * G < NFB) {
         constexpr int FRAG0 = START + 2 * G * NKG;
         if constexpr (2 * G + 1 < NFB) {
-            f32x16 acc0 = cb[0], acc1 = cb[1];
+            f32x16 acc0[P::NT], acc1[P::NT];
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t) { acc0[t] = cb[0]; acc1[t] = cb[1]; }
             f32x16 nb[2];
             constexpr bool MORE = 2 * (G + 1) < NFB;
             pair_k<P, NKG, FRAG0, 0, MORE>(ws, acc0, acc1, nb, bias_lane + 256 * (G + 1), in);
-            out(2 * G, acc0);
-            out(2 * G + 1, acc1);
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t) { out(2 * G, t, acc0[t]); out(2 * G + 1, t, acc1[t]); }
             if constexpr (MORE) dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lane, nb, in, out);
         } else {
             constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            f32x16 acc0 = cb[0], acc1 = zero;
+            f32x16 acc0[P::NT], acc1[P::NT];
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t) { acc0[t] = cb[0]; acc1[t] = zero; }
             single_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, in);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] += acc1[r];
-            out(2 * G, acc0);
+            for (int t = 0; t < P::NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[t][r] += acc1[t][r];
+                out(2 * G, t, acc0[t]);
+            }
         }
     }
 }
@@ -459,9 +485,9 @@ DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) 
 
 constexpr uint32_t LDS_BIAS = MLP_RING_BYTES;
 constexpr uint32_t LDS_STASH = MLP_RING_BYTES + 9216;                 // bias table: <= 2240 floats
-template <class P> constexpr uint32_t lds_dir() { return LDS_STASH + P::NW * 4 * P::BREG_LDS; }
-template <class P> constexpr uint32_t lds_tile() { return lds_dir<P>() + P::NW * 1024; }            // (tile samples) x float4 + 8 tickets
-template <class P> constexpr uint32_t lds_total() { return lds_tile<P>() + P::NW * 32 * 24 + 64; }
+template <class P> constexpr uint32_t lds_dir() { return LDS_STASH + P::NW * P::NT * 4 * P::BREG_LDS; }
+template <class P> constexpr uint32_t lds_tile() { return lds_dir<P>() + P::NW * P::NT * 1024; }            // (tile samples) x float4 + 8 tickets
+template <class P> constexpr uint32_t lds_total() { return lds_tile<P>() + P::NW * P::NT * 32 * 24 + 64; }
 
 DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias, uint32_t lds_off = MLP_RING_BYTES) {
     const float* b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + stream_bytes);
@@ -484,32 +510,41 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
-    constexpr int TS = P::NW * 32;
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = MLP_RING_BYTES;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t m = tile * TS + wave * 32 + j;
-        const Sample sm = fetch_sample(s, m < s.M ? m : s.M - 1, false);
-        BReg enc[4];
-        encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
-        BReg a[16], b[16];
+        int64_t m[NT];
+        BReg enc[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            m[t] = tile * TS + (wave * NT + t) * 32 + j;
+            const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, false);
+            encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+        }
+        BReg a[NT][16], b[NT][16];
         dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
-            [&](int kg) -> BReg { return enc[kg]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+            [&](int kg, int t) -> BReg { return enc[t][kg]; },
+            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
             dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
 #pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
         }
-        float dens = 0.0f;
+        float dens[NT];
         dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
-            [&](int kg) -> BReg { return a[kg]; },
-            [&](int, const f32x16& acc) { dens = acc[0]; });
-        if (h == 0 && m < s.M) density[m] = dens;
+            [&](int kg, int t) -> BReg { return a[t][kg]; },
+            [&](int, int t, const f32x16& acc) { dens[t] = acc[0]; });
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
     }
     ws.drain();
 }
@@ -534,121 +569,142 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     using L = MipLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
-    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * 32 * 24)[threadIdx.x] = 0u;   // ray tickets
+#ifdef MLP_CLOCKPROBE
+    const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 24)[threadIdx.x] = 0u;   // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
     WeightStream<P> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
-    constexpr int TS = P::NW * 32;
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = LDS_BIAS;
-    const uint32_t enc_lds = LDS_STASH + wave * 4 * P::BREG_LDS + lane * 16;
-    const uint32_t dir_lds = lds_dir<P>() + wave * 1024 + lane * 16;
+    // per 32-sample column tile ("subtile" sub = wave*NT + t) LDS slots
+    const uint32_t enc_lds0 = LDS_STASH + wave * NT * 4 * P::BREG_LDS + lane * 16;
+    const uint32_t dir_lds0 = lds_dir<P>() + wave * NT * 1024 + lane * 16;
+    auto enc_lds = [&](int t) -> uint32_t { return enc_lds0 + t * 4 * P::BREG_LDS; };
+    auto dir_lds = [&](int t) -> uint32_t { return dir_lds0 + t * 1024; };
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t m = tile * TS + wave * 32 + j;
-        BReg a[16], b[16];
+        int64_t m[NT];
+        BReg a[NT][16], b[NT][16];
         {
-            const Sample sm = fetch_sample(s, m < s.M ? m : s.M - 1, true);
-            BReg enc[4];
-            encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
-            // the encoding is needed again by the skip layer and the direction by the colour head: park them in
-            // this wavefront's private LDS stash instead of holding 20+ VGPRs through six layers
+            BReg enc[NT][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) P::stash(enc_lds + k * P::BREG_LDS, enc[k]);
-            f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
-            if (fc.rgb != nullptr) {
-                // fused compositing needs z|d| and the distance to the next sample at the END of the tile; fetch them now,
-                // while the tile's other global loads are in flight (a load at the tile end would drain the weight DMA queue)
-                const int64_t mm_ = m < s.M ? m : s.M - 1;
-                const int64_t n_ = mm_ / s.S;
-                const int si_ = (int)(mm_ - n_ * s.S);
-                const float nrm_ = norm3(sm.dx, sm.dy, sm.dz);
-                const float* zz_ = s.z + n_ * s.z_stride;
-                const float zn0 = zz_[si_] * nrm_;
-                const float dl = (si_ + 1 < s.S) ? (zz_[si_ + 1] * nrm_ - zn0) : 1e10f;
-                dv[3] = h ? dl : zn0;
+            for (int t = 0; t < NT; ++t) {
+                m[t] = tile * TS + (wave * NT + t) * 32 + j;
+                const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, true);
+                encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+                // the encoding is needed again by the skip layer and the direction by the colour head: park them in
+                // this wavefront's private LDS stash instead of holding 20+ VGPRs through six layers
+#pragma unroll
+                for (int k = 0; k < 4; ++k) P::stash(enc_lds(t) + k * P::BREG_LDS, enc[t][k]);
+                f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
+                if (fc.rgb != nullptr) {
+                    // fused compositing needs z|d| and the distance to the next sample at the END of the tile; fetch them now,
+                    // while the tile's other global loads are in flight (a load at the tile end would drain the weight DMA queue)
+                    const int64_t mm_ = m[t] < s.M ? m[t] : s.M - 1;
+                    const int64_t n_ = mm_ / s.S;
+                    const int si_ = (int)(mm_ - n_ * s.S);
+                    const float nrm_ = norm3(sm.dx, sm.dy, sm.dz);
+                    const float* zz_ = s.z + n_ * s.z_stride;
+                    const float zn0 = zz_[si_] * nrm_;
+                    const float dl = (si_ + 1 < s.S) ? (zz_[si_ + 1] * nrm_ - zn0) : 1e10f;
+                    dv[3] = h ? dl : zn0;
+                }
+                *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
             }
-            *reinterpret_cast<f32x4*>(smem + dir_lds) = dv;
             // lin_block1.0 : 63 -> 256
             dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
-                [&](int kg) -> BReg { return enc[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+                [&](int kg, int t) -> BReg { return enc[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
         }
         // lin_block1.{2,4,6} : 256 -> 256
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
             dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
 #pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
         }
         // lin_block2.0 : cat(enc 63, h 256) -> 256
         dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
-            [&](int kg) -> BReg { if (kg < 4) return P::unstash(enc_lds + kg * P::BREG_LDS); return a[kg >= 4 ? kg - 4 : 0]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+            [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(enc_lds(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
+            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = b[k];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
         // lin_block2.{2,4}
 #pragma unroll 1
         for (int l = 5; l <= 6; ++l) {
             dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
 #pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
         }
         // opacity_head.0 : 256 -> 1 (raw sigma)
-        float sigma = 0.0f;
+        float sigma[NT];
         dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4,
-            [&](int kg) -> BReg { return a[kg]; },
-            [&](int, const f32x16& acc) { sigma = acc[0]; });
+            [&](int kg, int t) -> BReg { return a[t][kg]; },
+            [&](int, int t, const f32x16& acc) { sigma[t] = acc[0]; });
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
-        BReg denc[2];
-        {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds);
+        BReg denc[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds(t));
             const float nrm = norm3(dv[0], dv[1], dv[2]);
-            encode<P, 4, 2>(dv[0] / nrm, dv[1] / nrm, dv[2] / nrm, h, denc);
+            encode<P, 4, 2>(dv[0] / nrm, dv[1] / nrm, dv[2] / nrm, h, denc[t]);
         }
         // rgb_layer.0 with bottle_neck.0 folded in (mlp_layout.h): cat(g 256, dir 27) -> 128, ReLU
-        BReg c[8];
+        BReg c[NT][8];
         dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
-            [&](int kg) -> BReg { if (kg < 16) return a[kg < 16 ? kg : 0]; return denc[kg >= 16 ? kg - 16 : 0]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, c[2 * fb], c[2 * fb + 1]); });
+            [&](int kg, int t) -> BReg { if (kg < 16) return a[t][kg < 16 ? kg : 0]; return denc[t][kg >= 16 ? kg - 16 : 0]; },
+            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, c[t][2 * fb], c[t][2 * fb + 1]); });
         // rgb_layer.2 : 128 -> 3, sigmoid
-        float r = 0.0f, g = 0.0f, bl = 0.0f;
+        float r[NT], g[NT], bl[NT];
         dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
-            [&](int kg) -> BReg { return c[kg]; },
-            [&](int, const f32x16& acc) { r = acc[0]; g = acc[1]; bl = acc[2]; });
+            [&](int kg, int t) -> BReg { return c[t][kg]; },
+            [&](int, int t, const f32x16& acc) { r[t] = acc[0]; g[t] = acc[1]; bl[t] = acc[2]; });
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
         f32x4 o;
-        o[0] = 1.0f / (1.0f + expf(-r));
-        o[1] = 1.0f / (1.0f + expf(-g));
-        o[2] = 1.0f / (1.0f + expf(-bl));
-        o[3] = sigma;
+        o[0] = 1.0f / (1.0f + expf(-r[t]));
+        o[1] = 1.0f / (1.0f + expf(-g[t]));
+        o[2] = 1.0f / (1.0f + expf(-bl[t]));
+        o[3] = sigma[t];
         if (fc.rgb == nullptr) {
-            if (h == 0 && m < s.M) *reinterpret_cast<f32x4*>(rgbo + m * 4) = o;
+            if (h == 0 && m[t] < s.M) *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o;
         } else {
-            // ---- fused compositing epilogue (S in {32, 64, 128} divides the tile: a ray = S/32 consecutive waves) ----
-            // Every wave parks (rgb, sigma, z|d|, delta) of its 32 samples in LDS and takes an LDS ticket; the LAST wave of
+            // ---- fused compositing epilogue (S in {32, 64, 128} divides the tile: a ray = S/32 consecutive subtiles) ----
+            // Every subtile parks (rgb, sigma, z|d|, delta) of its 32 samples in LDS and takes an LDS ticket; the LAST subtile of
             // the ray to arrive composites it: sigma -> alpha, wave prefix product of the transmittance (fp64, like torch's CPU
             // cumprod), weighted sums.  Nobody waits for anybody, and nothing here touches global memory except the outputs.
             const int S = s.S;
-            const int wpr = S >> 5;                                        // wavefronts per ray
-            const int ray_in_tile = wave / wpr;
+            const int spr = S >> 5;                                        // subtiles per ray
+            const int sub = wave * NT + t;
+            const int ray_in_tile = sub / spr;
             const int64_t n = (tile * TS) / S + ray_in_tile;
             char* tb = smem + lds_tile<P>();
             f32x4* t_rgbo = reinterpret_cast<f32x4*>(tb);                               // [TS] rgb + sigma
             f32x2* t_zd = reinterpret_cast<f32x2*>(tb + TS * 16);                       // [TS] z|d|, delta
             unsigned* tickets = reinterpret_cast<unsigned*>(tb + TS * 24);
             {
-                const float keep3 = (*reinterpret_cast<const f32x4*>(smem + dir_lds))[3];      // half 0: z|d|, half 1: delta (tile start)
+                const float keep3 = (*reinterpret_cast<const f32x4*>(smem + dir_lds(t)))[3];   // half 0: z|d|, half 1: delta (tile start)
                 const float dl = __shfl(keep3, j + 32, 64);
                 if (h == 0) {
-                    t_rgbo[wave * 32 + j] = o;
+                    t_rgbo[sub * 32 + j] = o;
                     f32x2 zd = {keep3, dl};
-                    t_zd[wave * 32 + j] = zd;
+                    t_zd[sub * 32 + j] = zd;
                 }
             }
             // LDS executes one wavefront's DS instructions in order, so the ticket is ordered behind the record writes without
@@ -659,7 +715,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             if (lane == 0) old = __hip_atomic_fetch_add(&tickets[ray_in_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             old = __builtin_amdgcn_readfirstlane(old);
             asm volatile("" ::: "memory");
-            if (((old + 1) % (unsigned)wpr) == 0 && n * S < s.M) {         // last arriver of this ray (tickets only ever grow)
+            if (((old + 1) % (unsigned)spr) == 0 && n * S < s.M) {         // last arriver of this ray (tickets only ever grow)
                 const f32x4* px = t_rgbo + ray_in_tile * S;
                 const f32x2* pz = t_zd + ray_in_tile * S;
                 float ar = 0.0f, ag = 0.0f, abl = 0.0f, aw = 0.0f, ad = 0.0f;
@@ -669,11 +725,11 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                     const int q = base + lane;
                     float w = 0.0f;
                     double p = 1.0;
-                    f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+                    f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
                     f32x2 zd = {0.0f, 0.0f};
                     if (q < S) {
-                        c = px[q]; zd = pz[q];
-                        const float mm = expf(-fmaxf(c[3], 0.0f) * zd[1]);
+                        c4 = px[q]; zd = pz[q];
+                        const float mm = expf(-fmaxf(c4[3], 0.0f) * zd[1]);
                         w = 1.0f - mm;
                         p = (double)(mm + 1e-10f);
                     }
@@ -683,7 +739,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                     w *= (float)(carry * excl);
                     carry *= __shfl(incl, 63, 64);
                     if (q < S) {
-                        ar += w * c[0]; ag += w * c[1]; abl += w * c[2]; aw += w; ad += w * zd[0];
+                        ar += w * c4[0]; ag += w * c4[1]; abl += w * c4[2]; aw += w; ad += w * zd[0];
                         if (wout) wout[q] = w;
                     }
                 }
@@ -695,8 +751,16 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                 }
             }
         }
+        }
     }
     ws.drain();
+#ifdef MLP_CLOCKPROBE
+    // diagnostic build: shader cycles vs 100 MHz real-time ticks of workgroup 0 overwrite the first output record
+    if (blockIdx.x == 0 && threadIdx.x == 0 && rgbo != nullptr) {
+        reinterpret_cast<uint64_t*>(rgbo)[0] = __builtin_readcyclecounter() - probe_c0;
+        reinterpret_cast<uint64_t*>(rgbo)[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+    }
+#endif
 }
 
 
@@ -705,7 +769,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 // ================================================================================================
 constexpr uint32_t REF_LDS_BIAS = MLP_CHUNK_BYTES * MLP_NSLOT_REF;
 constexpr uint32_t REF_LDS_STASH = REF_LDS_BIAS + RefLayout::N_BIAS * 4;          // 16-byte aligned (4288 floats)
-template <class P> constexpr uint32_t ref_lds_total() { return REF_LDS_STASH + P::NW * 11 * P::BREG_LDS; }
+template <class P> constexpr uint32_t ref_lds_total() { return REF_LDS_STASH + P::NW * P::NT * 11 * P::BREG_LDS; }
 
 // Integrated directional encoding (ref_func.py:76-108) of the reflected direction, straight into B-operand slots:
 // lane half 0 produces the real parts, half 1 the imaginary parts of the 19 (m,l) terms; slot 19 of half 0 = n.d
@@ -751,117 +815,127 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
-    constexpr int TS = P::NW * 32;
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = REF_LDS_BIAS;
-    const uint32_t stash = REF_LDS_STASH + wave * 11 * P::BREG_LDS + lane * 16;       // 11 per-wave blocks of one K group each
-    const uint32_t dir_lds = stash + 10 * P::BREG_LDS;                                 // block 10 doubles as the direction slot
+    const uint32_t stash0 = REF_LDS_STASH + wave * NT * 11 * P::BREG_LDS + lane * 16;  // 11 per-subtile blocks of one K group each
+    auto stash = [&](int t) -> uint32_t { return stash0 + t * 11 * P::BREG_LDS; };
+    auto dir_lds = [&](int t) -> uint32_t { return stash(t) + 10 * P::BREG_LDS; };         // block 10 doubles as the direction slot
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t m = tile * TS + wave * 32 + j;
-        BReg a[16], b[16];
+        int64_t m[NT];
+        BReg a[NT][16], b[NT][16];
         {
-            const Sample sm = fetch_sample(s, m < s.M ? m : s.M - 1, true);
-            BReg enc[4];
-            encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc);
+            BReg enc[NT][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) P::stash(stash + k * P::BREG_LDS, enc[k]);
-            f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
-            *reinterpret_cast<f32x4*>(smem + dir_lds) = dv;
+            for (int t = 0; t < NT; ++t) {
+                m[t] = tile * TS + (wave * NT + t) * 32 + j;
+                const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, true);
+                encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) P::stash(stash(t) + k * P::BREG_LDS, enc[t][k]);
+                f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
+                *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+            }
             dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                      // spa_block1.0
-                [&](int kg) -> BReg { return enc[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+                [&](int kg, int t) -> BReg { return enc[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
         }
+        auto copy_back = [&]() {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
+        };
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {                                                        // spa_block1.{2,4,6}
             dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            copy_back();
         }
         dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                          // spa_block2.0 (skip)
-            [&](int kg) -> BReg { if (kg < 4) return P::unstash(stash + kg * P::BREG_LDS); return a[kg >= 4 ? kg - 4 : 0]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = b[k];
+            [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
+            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+        copy_back();
 #pragma unroll 1
         for (int l = 5; l <= 7; ++l) {                                                        // spa_block2.{2,4,6}
             dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            copy_back();
         }
         // heads: bottle_neck (4 blocks, no activation) + [normal | roughness || diffuse | density || tint]
-        BReg bn[8];
-        f32x16 hd;
+        BReg bn[NT][8];
+        f32x16 hd[NT];
         dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
-            [&](int kg) -> BReg { return a[kg]; },
-            [&](int fb, const f32x16& acc) {
-                if (fb < 4) to_breg<P, false>(acc, bn[2 * (fb < 4 ? fb : 0)], bn[2 * (fb < 4 ? fb : 0) + 1]);
-                else hd = acc;
+            [&](int kg, int t) -> BReg { return a[t][kg]; },
+            [&](int fb, int t, const f32x16& acc) {
+                if (fb < 4) to_breg<P, false>(acc, bn[t][2 * (fb < 4 ? fb : 0)], bn[t][2 * (fb < 4 ? fb : 0) + 1]);
+                else hd[t] = acc;
             });
         // half 0 holds rows 0-3 (normal, roughness) in hd[0..3] and rows 8-10 (tint) in hd[4..6]; half 1 rows 4-7 (diffuse, density) in hd[0..3]
-        float keep[4];
-        BReg ide[3];
-        {
-            const float nx0 = __shfl(hd[0], j, 64), ny0 = __shfl(hd[1], j, 64), nz0 = __shfl(hd[2], j, 64);
-            const float rough = softplus_f(__shfl(hd[3], j, 64) - 1.0f);                      // ref_model.py:82
+        float keep[NT][4];
+        BReg ide[NT][3];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float nx0 = __shfl(hd[t][0], j, 64), ny0 = __shfl(hd[t][1], j, 64), nz0 = __shfl(hd[t][2], j, 64);
+            const float rough = softplus_f(__shfl(hd[t][3], j, 64) - 1.0f);                   // ref_model.py:82
             const float nn = norm3(nx0, ny0, nz0) + 1e-7f;                                    // ref_model.py:87
             const float nx = -nx0 / nn, ny = -ny0 / nn, nz = -nz0 / nn;
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds(t));
             const float dot = (dv[0] * nx + dv[1] * ny) + dv[2] * nz;
             const float t2 = 2.0f * dot;
             const float rx = dv[0] - t2 * nx, ry = dv[1] - t2 * ny, rz = dv[2] - t2 * nz;    // ref_model.py:90
-            ide_encode<P>(rx, ry, rz, rough, dot, h, ide_mat, ide);
-            if (normal_out && h == 0 && m < s.M) { normal_out[m * 3] = nx; normal_out[m * 3 + 1] = ny; normal_out[m * 3 + 2] = nz; }
-            keep[0] = h ? hd[0] : hd[4]; keep[1] = h ? hd[1] : hd[5]; keep[2] = h ? hd[2] : hd[6]; keep[3] = hd[3];
+            ide_encode<P>(rx, ry, rz, rough, dot, h, ide_mat, ide[t]);
+            if (normal_out && h == 0 && m[t] < s.M) { normal_out[m[t] * 3] = nx; normal_out[m[t] * 3 + 1] = ny; normal_out[m[t] * 3 + 2] = nz; }
+            keep[t][0] = h ? hd[t][0] : hd[t][4]; keep[t][1] = h ? hd[t][1] : hd[t][5]; keep[t][2] = h ? hd[t][2] : hd[t][6]; keep[t][3] = hd[t][3];
+            // all_inputs = [bottle_neck 128 | ide 38 | n.d]: needed again by dir_block2.0 -> park in the stash (blocks 0..10)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) P::stash(stash(t) + k * P::BREG_LDS, bn[t][k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) P::stash(stash(t) + (8 + k) * P::BREG_LDS, ide[t][k]);
         }
-        // all_inputs = [bottle_neck 128 | ide 38 | n.d]: needed again by dir_block2.0 -> park in the stash (blocks 0..10)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) P::stash(stash + k * P::BREG_LDS, bn[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) P::stash(stash + (8 + k) * P::BREG_LDS, ide[k]);
         dense<P, 11, 8, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,                          // dir_block1.0
-            [&](int kg) -> BReg { if (kg < 8) return bn[kg < 8 ? kg : 0]; return ide[kg >= 8 ? kg - 8 : 0]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, a[2 * fb], a[2 * fb + 1]); });
+            [&](int kg, int t) -> BReg { if (kg < 8) return bn[t][kg < 8 ? kg : 0]; return ide[t][kg >= 8 ? kg - 8 : 0]; },
+            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
 #pragma unroll 1
         for (int l = 10; l <= 12; ++l) {                                                      // dir_block1.{2,4,6}
             dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + (l - 10) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            copy_back();
         }
         dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                        // dir_block2.0 (skip)
-            [&](int kg) -> BReg { if (kg < 11) return P::unstash(stash + kg * P::BREG_LDS); return a[kg >= 11 ? kg - 11 : 0]; },
-            [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = b[k];
+            [&](int kg, int t) -> BReg { if (kg < 11) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 11 ? kg - 11 : 0]; },
+            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+        copy_back();
 #pragma unroll 1
         for (int l = 14; l <= 16; ++l) {                                                      // dir_block2.{2,4,6}
             dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + (l - 14) * 256) * 4,
-                [&](int kg) -> BReg { return a[kg]; },
-                [&](int fb, const f32x16& acc) { to_breg<P, true>(acc, b[2 * fb], b[2 * fb + 1]); });
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = b[k];
+                [&](int kg, int t) -> BReg { return a[t][kg]; },
+                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            copy_back();
         }
-        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+        float sr[NT], sg[NT], sb[NT];
         dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4,                        // spec_rgb_head.0
-            [&](int kg) -> BReg { return a[kg]; },
-            [&](int, const f32x16& acc) { sr = acc[0]; sg = acc[1]; sb = acc[2]; });
-        // half 1's keep[] = (diffuse, density); fetch it into half 0, which holds spec and tint (ref_model.py:98-105)
-        const float d0 = __shfl(keep[0], j + 32, 64), d1 = __shfl(keep[1], j + 32, 64), d2 = __shfl(keep[2], j + 32, 64),
-                    dens = __shfl(keep[3], j + 32, 64);
-        if (h == 0 && m < s.M) {
-            auto sig = [](float v) { return 1.0f / (1.0f + expf(-v)); };
-            f32x4 o;
-            o[0] = sig(sr) * sig(keep[0]) + sig(d0);
-            o[1] = sig(sg) * sig(keep[1]) + sig(d1);
-            o[2] = sig(sb) * sig(keep[2]) + sig(d2);
-            o[3] = dens;
-            *reinterpret_cast<f32x4*>(rgbo + m * 4) = o;
+            [&](int kg, int t) -> BReg { return a[t][kg]; },
+            [&](int, int t, const f32x16& acc) { sr[t] = acc[0]; sg[t] = acc[1]; sb[t] = acc[2]; });
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // half 1's keep[] = (diffuse, density); fetch it into half 0, which holds spec and tint (ref_model.py:98-105)
+            const float d0 = __shfl(keep[t][0], j + 32, 64), d1 = __shfl(keep[t][1], j + 32, 64), d2 = __shfl(keep[t][2], j + 32, 64),
+                        dens = __shfl(keep[t][3], j + 32, 64);
+            if (h == 0 && m[t] < s.M) {
+                auto sig = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+                f32x4 o;
+                o[0] = sig(sr[t]) * sig(keep[t][0]) + sig(d0);
+                o[1] = sig(sg[t]) * sig(keep[t][1]) + sig(d1);
+                o[2] = sig(sb[t]) * sig(keep[t][2]) + sig(d2);
+                o[3] = dens;
+                *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o;
+            }
         }
     }
     ws.drain();
@@ -880,7 +954,7 @@ int grid_for(int64_t n_tiles) {
 
 template <class P, class Lay, class K, class... Extra>
 int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st, Extra... extra) {
-    constexpr int TS = P::NW * 32;
+    constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = lds_total<P>();
@@ -894,29 +968,35 @@ int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, 
     return (int)hipGetLastError();
 }
 
+#ifdef MLP_BF16_WIDE
+using PB16 = PBF16W;
+#else
+using PB16 = PBF16;
+#endif
+
 }  // namespace
 
 // host-visible launchers (capi.hip)
 int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch<PBF16, PropLayout>(proposal_kernel<PBF16>, packed, s, density, st);
+    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16>, packed, s, density, st);
     return launch<PF32, PropLayout>(proposal_kernel<PF32>, packed, s, density, st);
 }
 int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
-    if (precision == NERF_AMD_BF16) return launch<PBF16, MipLayout>(mip_kernel<PBF16>, packed, s, rgbo, st, off);
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16>, packed, s, rgbo, st, off);
     return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, rgbo, st, off);
 }
 // fine MLP + compositing in one launch; requires mode 1 (rays + z) and S in {32, 64, 128}
 int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_samples& s, float* rgb, float* depth, float* weights,
                              int white_bkg, float near, float far, hipStream_t st) {
     const FusedComposite fc{rgb, depth, weights, white_bkg, near, far};
-    if (precision == NERF_AMD_BF16) return launch<PBF16, MipLayout>(mip_kernel<PBF16>, packed, s, (float*)nullptr, st, fc);
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16>, packed, s, (float*)nullptr, st, fc);
     return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, (float*)nullptr, st, fc);
 }
 
 template <class P>
 static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, hipStream_t st) {
-    constexpr int TS = P::NW * 32;
+    constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = ref_lds_total<P>();
@@ -930,6 +1010,6 @@ static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo
     return (int)hipGetLastError();
 }
 int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch_ref<PBF16>(packed, s, rgbo, normal, st);
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16>(packed, s, rgbo, normal, st);
     return launch_ref<PF32>(packed, s, rgbo, normal, st);
 }
