@@ -59,9 +59,16 @@ struct PBF16 {
     // max with 0 (negative floats have the sign bit set): 8 v_cvt_pk + 4 v_pk_max_i16 instead of 8 v_max + ... per group
     template <bool RELU>
     static DEVINL BReg from_acc(const f32x16& acc, int off) {
+        // pairwise vector conversion: one v_cvt_pk_bf16_f32 per two values (element-wise casts compile to a single-lane
+        // convert each plus a v_perm_b32 to merge the halves -- three instructions instead of one)
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
         BReg r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (__bf16)acc[off + e];
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 v = {acc[off + 2 * e], acc[off + 2 * e + 1]};
+            const bf16x2 p = __builtin_convertvector(v, bf16x2);
+            r[2 * e] = p[0]; r[2 * e + 1] = p[1];
+        }
         if (RELU) {
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             s16x8 v = __builtin_bit_cast(s16x8, r);
@@ -287,18 +294,76 @@ struct WeightStream {
 };
 
 // ------------------------------------------------------------------------------------------------
-// One dense layer for this wavefront's 32 samples:  out[fb] = act(W[fb] . in + bias[fb]).
-//   NKG    K groups (16 input features each) consumed;  in(kg) returns the B registers of group kg
-//   NFB    32-row output feature blocks;  out(fb, acc) receives the 16 accumulators of block fb
+// One dense layer for this wavefront's NT x 32 samples:  out[fb] = act(W[fb] . in + bias[fb]).
+//   NKG    K groups (16 input features each) consumed;  in(kg, t) returns the B registers of group kg, column tile t
+//   NFB    32-row output feature blocks;  out(fb, t, acc, half) converts accumulators 8*half .. 8*half+7 of block fb
+//          (= K group 2*fb + half of the next layer) for column tile t
 //   START  fragment index of the layer inside the stream modulo FPC (chunk phase)
 // ------------------------------------------------------------------------------------------------
-// Feature blocks are processed two at a time with their MFMAs alternating between two independent accumulators.
+// Feature blocks are processed two at a time with their MFMAs alternating between independent accumulators.
 // Why: on gfx950 any instruction issued between two MFMAs that chain through the SAME accumulator (here: the
 // ds_read of the next A fragment) costs ~+43 cycles on the dependent MFMA (MI355X_MICROARCH.md, per-instruction
-// constants) -- measured here as 59% -> ~95% MFMA-pipe occupancy between "with" and "without" the A reads.
-// Alternating accumulators puts a full MFMA between dependent ones.  The stream stores a pair's fragments
+// constants).  Alternating accumulators puts a full MFMA between dependent ones.  The stream stores a pair's fragments
 // interleaved (kg-major), so the B registers of K group kg are fetched once and feed both blocks.
-// A single trailing block (odd NFB) splits K over the two accumulators instead and adds them at the end.
+// A single trailing block (odd NFB) splits K over two accumulators instead and adds them at the end.
+//
+// Deferred epilogues (software pipelining by hand): the conversion of a block pair's accumulators (bias is already in,
+// so: fp32 -> bf16, ReLU) is NOT done when the pair's MFMA chain ends but sliced into the first K steps of the NEXT
+// pair -- of the same layer, or of the next layer, whose first K groups never read the last pair's features (kg 12..15
+// are consumed at K steps >= 12).  The VALU work then sits between MFMAs that do not depend on it instead of in one
+// clump during which the MFMA pipe idles (one wave per SIMD cannot hide it behind a partner).
+template <int S> struct IC { static constexpr int value = S; };
+
+// accumulators 8*half .. 8*half+7 of a feature block -> the B register group they form for the next layer
+template <class P, bool RELU>
+DEVINL typename P::BReg to_breg_half(const f32x16& acc, int half) {
+#ifdef ABL_NOEPI
+    if constexpr (sizeof(typename P::BReg) == 16) {
+        f32x4 l = {acc[8 * half], acc[8 * half + 1], acc[8 * half + 2], acc[8 * half + 3]};
+        return __builtin_bit_cast(typename P::BReg, l);
+    }
+#endif
+    return P::template from_acc<RELU>(acc, 8 * half);
+}
+
+// the not-yet-converted accumulators of NB (1 or 2) feature blocks starting at block FB0
+template <class P, int FB0, int NB>
+struct Deferred {
+    static constexpr int NSL = NB * 2 * P::NT;                   // slices: (block, half, tile)
+    f32x16 acc[NB][P::NT];
+    template <int S, class OutF>
+    DEVINL void emit(OutF& out) const {
+        constexpr int blk = S / (2 * P::NT), half = (S % (2 * P::NT)) / P::NT, t = S % P::NT;
+        out(FB0 + blk, t, acc[blk][t], half);
+    }
+    template <class OutF, int S = 0>
+    DEVINL void flush(OutF&& out) const {
+        if constexpr (S < NSL) { emit<S>(out); flush<OutF, S + 1>(static_cast<OutF&&>(out)); }
+    }
+};
+struct NoPrev {
+    static constexpr int NSL = 0;
+    template <int S> DEVINL void emit() const {}
+};
+template <class D, class OutF>
+struct PrevOf {
+    static constexpr int NSL = D::NSL;
+    const D& d;
+    OutF& out;
+    template <int S> DEVINL void emit() const { d.template emit<S>(out); }
+};
+template <class D, class OutF> DEVINL PrevOf<D, OutF> prev_of(const D& d, OutF& out) { return PrevOf<D, OutF>{d, out}; }
+// slices of the pending epilogue that belong to K step KG of an NKG-step chain: everything is out within the first half
+template <int NKG, int KG, class Prev, int I = 0>
+DEVINL void emit_step(const Prev& prev) {
+    constexpr int STEPS = (NKG / 2 > 0) ? NKG / 2 : 1;
+    constexpr int PER = (Prev::NSL + STEPS - 1) / STEPS;
+    if constexpr (I < PER && KG * PER + I < Prev::NSL) {
+        prev.template emit<KG * PER + I>();
+        emit_step<NKG, KG, Prev, I + 1>(prev);
+    }
+}
+
 // bias of one 32-row feature block in accumulator layout (acc[r] <- bias[(r&3) + 8(r>>2) + 4h]); it enters the chain
 // as the C operand of the block's first MFMA, so the epilogue needs no adds
 DEVINL f32x16 load_bias(uint32_t addr) {
@@ -310,8 +375,8 @@ DEVINL f32x16 load_bias(uint32_t addr) {
     }
     return v;
 }
-template <class P, int NKG, int FRAG0, int KG, bool MORE, class WS, class InF>
-DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 (&nb)[2], uint32_t next_bias, InF& in) {
+template <class P, int NKG, int FRAG0, int KG, bool MORE, class WS, class InF, class Prev>
+DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 (&nb)[2], uint32_t next_bias, InF& in, const Prev& prev) {
     if constexpr (KG < NKG) {
         typename P::BReg b[P::NT];
 #pragma unroll
@@ -323,15 +388,16 @@ DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 
         const typename P::AReg a1 = ws.template next<FRAG0 + 2 * KG + 1>();
 #pragma unroll
         for (int t = 0; t < P::NT; ++t) acc1[t] = P::template mma_pos<POS>(a1, b[t], acc1[t]);
+        emit_step<NKG, KG>(prev);
         if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
             nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
             nb[1] = load_bias(next_bias + 128);
         }
-        pair_k<P, NKG, FRAG0, KG + 1, MORE>(ws, acc0, acc1, nb, next_bias, in);
+        pair_k<P, NKG, FRAG0, KG + 1, MORE>(ws, acc0, acc1, nb, next_bias, in, prev);
     }
 }
-template <class P, int NKG, int FRAG0, int KG, class WS, class InF>
-DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& in) {
+template <class P, int NKG, int FRAG0, int KG, class WS, class InF, class Prev>
+DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& in, const Prev& prev) {
     if constexpr (KG < NKG) {
         const typename P::AReg a = ws.template next<FRAG0 + KG>();
         constexpr int LAST_EVEN = ((NKG - 1) / 2) * 2, LAST_ODD = (NKG % 2 == 0) ? NKG - 1 : NKG - 2;
@@ -340,60 +406,47 @@ DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& 
             if constexpr (KG % 2 == 0) acc0[t] = P::template mma_pos<(KG == 0) ? 0 : ((KG == LAST_EVEN) ? 2 : 1)>(a, in(KG, t), acc0[t]);
             else acc1[t] = P::template mma_pos<(KG == 1) ? 4 : ((KG == LAST_ODD) ? 2 : 1)>(a, in(KG, t), acc1[t]);
         }
-        single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in);
+        emit_step<NKG, KG>(prev);
+        single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in, prev);
     }
 }
-template <class P, int NKG, int NFB, int START, int G, class WS, class InF, class OutF>
-DEVINL void dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out) {
-    if constexpr (2 * G < NFB) {
-        constexpr int FRAG0 = START + 2 * G * NKG;
-        if constexpr (2 * G + 1 < NFB) {
-            f32x16 acc0[P::NT], acc1[P::NT];
+// Runs feature-block groups G, G+1, ... of the layer; `prev` is the pending epilogue that the FIRST K steps of group G
+// work off.  Returns the layer's last group, unconverted.
+template <class P, int NKG, int NFB, int START, int G, class WS, class InF, class OutF, class Prev>
+DEVINL auto dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out, const Prev& prev) {
+    static_assert(2 * G < NFB, "group index");
+    constexpr int FRAG0 = START + 2 * G * NKG;
+    if constexpr (2 * G + 1 < NFB) {
+        Deferred<P, 2 * G, 2> d;
 #pragma unroll
-            for (int t = 0; t < P::NT; ++t) { acc0[t] = cb[0]; acc1[t] = cb[1]; }
-            f32x16 nb[2];
-            constexpr bool MORE = 2 * (G + 1) < NFB;
-            pair_k<P, NKG, FRAG0, 0, MORE>(ws, acc0, acc1, nb, bias_lane + 256 * (G + 1), in);
+        for (int t = 0; t < P::NT; ++t) { d.acc[0][t] = cb[0]; d.acc[1][t] = cb[1]; }
+        f32x16 nb[2];
+        constexpr bool MORE = 2 * (G + 1) < NFB;
+        pair_k<P, NKG, FRAG0, 0, MORE>(ws, d.acc[0], d.acc[1], nb, bias_lane + 256 * (G + 1), in, prev);
+        if constexpr (MORE) return dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lane, nb, in, out, prev_of(d, out));
+        else return d;
+    } else {
+        constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        Deferred<P, 2 * G, 1> d;
+        f32x16 acc1[P::NT];
 #pragma unroll
-            for (int t = 0; t < P::NT; ++t) { out(2 * G, t, acc0[t]); out(2 * G + 1, t, acc1[t]); }
-            if constexpr (MORE) dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lane, nb, in, out);
-        } else {
-            constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            f32x16 acc0[P::NT], acc1[P::NT];
+        for (int t = 0; t < P::NT; ++t) { d.acc[0][t] = cb[0]; acc1[t] = zero; }
+        single_k<P, NKG, FRAG0, 0>(ws, d.acc[0], acc1, in, prev);
 #pragma unroll
-            for (int t = 0; t < P::NT; ++t) { acc0[t] = cb[0]; acc1[t] = zero; }
-            single_k<P, NKG, FRAG0, 0>(ws, acc0, acc1, in);
+        for (int t = 0; t < P::NT; ++t)
 #pragma unroll
-            for (int t = 0; t < P::NT; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[t][r] += acc1[t][r];
-                out(2 * G, t, acc0[t]);
-            }
-        }
+            for (int r = 0; r < 16; ++r) d.acc[0][t][r] += acc1[t][r];
+        return d;
     }
 }
-template <class P, int NKG, int NFB, int START, class WS, class InF, class OutF>
-DEVINL void dense(WS& ws, uint32_t bias_lds, InF&& in, OutF&& out) {
+template <class P, int NKG, int NFB, int START, class WS, class InF, class OutF, class Prev>
+DEVINL auto dense(WS& ws, uint32_t bias_lds, InF&& in, OutF&& out, const Prev& prev) {
     static_assert(START % P::DEPTH == 0 && (NKG * NFB) % P::DEPTH == 0, "layers must start on a prefetch-queue boundary");
     const uint32_t bias_lane = bias_lds + 16 * (lane_id() >> 5);
     f32x16 cb[2];
     cb[0] = load_bias(bias_lane);
     if constexpr (NFB > 1) cb[1] = load_bias(bias_lane + 128);
-    dense_group<P, NKG, NFB, START, 0>(ws, bias_lane, cb, in, out);
-}
-
-// accumulators of feature block fb -> B registers of K groups 2fb, 2fb+1 of the next layer
-template <class P, bool RELU>
-DEVINL void to_breg(const f32x16& acc, typename P::BReg& lo, typename P::BReg& hi) {
-#ifdef ABL_NOEPI
-    if constexpr (sizeof(typename P::BReg) == 16) {
-        f32x4 l = {acc[0], acc[1], acc[2], acc[3]}, h2 = {acc[8], acc[9], acc[10], acc[11]};
-        lo = __builtin_bit_cast(typename P::BReg, l); hi = __builtin_bit_cast(typename P::BReg, h2);
-        return;
-    }
-#endif
-    lo = P::template from_acc<RELU>(acc, 0);
-    hi = P::template from_acc<RELU>(acc, 8);
+    return dense_group<P, NKG, NFB, START, 0>(ws, bias_lane, cb, in, out, prev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,23 +578,24 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
         }
         BReg a[NT][16], b[NT][16];
-        dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
-            [&](int kg, int t) -> BReg { return enc[t][kg]; },
-            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
+        // into `a` during the first K steps of whatever runs next
+        Deferred<P, 6, 2> d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
+            [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
-            dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
+                for (int k = 0; k < 12; ++k) a[t][k] = b[t][k];
         }
         float dens[NT];
-        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
-            [&](int kg, int t) -> BReg { return a[t][kg]; },
-            [&](int, int t, const f32x16& acc) { dens[t] = acc[0]; });
+        auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
+        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_A, OH, prev_of(d, OA)).flush(OH);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
@@ -591,6 +645,18 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg a[NT][16], b[NT][16];
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto copy_back = [&]() {                                    // K groups 12..15 arrive through the deferred epilogue
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a[t][k] = b[t][k];
+        };
+        // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
+        // into `a` during the first K steps of whatever runs next
+        Deferred<P, 6, 2> d;
         {
             BReg enc[NT][4];
 #pragma unroll
@@ -618,45 +684,32 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                 *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
             }
             // lin_block1.0 : 63 -> 256
-            dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
-                [&](int kg, int t) -> BReg { return enc[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
+            d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
+                [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
         }
-        // lin_block1.{2,4,6} : 256 -> 256
+        // lin_block1.{2,4,6} : 256 -> 256.  (A loop may only reuse one code instance for layers whose first chunk has the
+        // same parity -- the early/late barrier assignment is compiled in -- hence the assert.)
+        static_assert(L::START[1] % (2 * FPC) == L::START[2] % (2 * FPC) && L::START[5] % (2 * FPC) == L::START[6] % (2 * FPC), "chunk parity");
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
-            dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
+            copy_back();
         }
         // lin_block2.0 : cat(enc 63, h 256) -> 256
-        dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
+        d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
             [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(enc_lds(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
-            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
+            OB, prev_of(d, OA));
+        copy_back();
         // lin_block2.{2,4}
 #pragma unroll 1
         for (int l = 5; l <= 6; ++l) {
-            dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
+            d = dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4, IN_A, OB, prev_of(d, OA));
+            copy_back();
         }
         // opacity_head.0 : 256 -> 1 (raw sigma)
         float sigma[NT];
-        dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4,
-            [&](int kg, int t) -> BReg { return a[t][kg]; },
-            [&](int, int t, const f32x16& acc) { sigma[t] = acc[0]; });
+        auto OSIG = [&](int, int t, const f32x16& acc, int half) { if (half == 0) sigma[t] = acc[0]; };
+        const auto dsig = dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4, IN_A, OSIG, prev_of(d, OA));
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
         BReg denc[NT][2];
 #pragma unroll
@@ -667,14 +720,15 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         }
         // rgb_layer.0 with bottle_neck.0 folded in (mlp_layout.h): cat(g 256, dir 27) -> 128, ReLU
         BReg c[NT][8];
-        dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
+        auto OC = [&](int fb, int t, const f32x16& acc, int half) { c[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        const auto dc = dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
             [&](int kg, int t) -> BReg { if (kg < 16) return a[t][kg < 16 ? kg : 0]; return denc[t][kg >= 16 ? kg - 16 : 0]; },
-            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, c[t][2 * fb], c[t][2 * fb + 1]); });
+            OC, prev_of(dsig, OSIG));
         // rgb_layer.2 : 128 -> 3, sigmoid
         float r[NT], g[NT], bl[NT];
+        auto ORGB = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { r[t] = acc[0]; g[t] = acc[1]; bl[t] = acc[2]; } };
         dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
-            [&](int kg, int t) -> BReg { return c[t][kg]; },
-            [&](int, int t, const f32x16& acc) { r[t] = acc[0]; g[t] = acc[1]; bl[t] = acc[2]; });
+            [&](int kg, int t) -> BReg { return c[t][kg]; }, ORGB, prev_of(dc, OC)).flush(ORGB);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
         f32x4 o;
@@ -826,6 +880,16 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg a[NT][16], b[NT][16];
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto copy_back = [&]() {                                    // K groups 12..15 arrive through the deferred epilogue
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a[t][k] = b[t][k];
+        };
+        Deferred<P, 6, 2> d;                                        // see mip_kernel
         {
             BReg enc[NT][4];
 #pragma unroll
@@ -838,43 +902,32 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                 f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
                 *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
             }
-            dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                      // spa_block1.0
-                [&](int kg, int t) -> BReg { return enc[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
+            d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                  // spa_block1.0
+                [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
         }
-        auto copy_back = [&]() {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) a[t][k] = b[t][k];
-        };
+        static_assert(L::START[1] % (2 * FPC) == L::START[2] % (2 * FPC) && L::START[5] % (2 * FPC) == L::START[6] % (2 * FPC), "chunk parity");
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {                                                        // spa_block1.{2,4,6}
-            dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
-        dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                          // spa_block2.0 (skip)
+        d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                      // spa_block2.0 (skip)
             [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
-            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            OB, prev_of(d, OA));
         copy_back();
 #pragma unroll 1
         for (int l = 5; l <= 7; ++l) {                                                        // spa_block2.{2,4,6}
-            dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            d = dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
         // heads: bottle_neck (4 blocks, no activation) + [normal | roughness || diffuse | density || tint]
         BReg bn[NT][8];
         f32x16 hd[NT];
-        dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
-            [&](int kg, int t) -> BReg { return a[t][kg]; },
-            [&](int fb, int t, const f32x16& acc) {
-                if (fb < 4) to_breg<P, false>(acc, bn[t][2 * (fb < 4 ? fb : 0)], bn[t][2 * (fb < 4 ? fb : 0) + 1]);
-                else hd[t] = acc;
-            });
+        auto OHD = [&](int fb, int t, const f32x16& acc, int half) {
+            if (fb < 4) bn[t][2 * (fb < 4 ? fb : 0) + half] = to_breg_half<P, false>(acc, half);
+            else if (half == 0) hd[t] = acc;
+        };
+        dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4, IN_A, OHD, prev_of(d, OA)).flush(OHD);
         // half 0 holds rows 0-3 (normal, roughness) in hd[0..3] and rows 8-10 (tint) in hd[4..6]; half 1 rows 4-7 (diffuse, density) in hd[0..3]
         float keep[NT][4];
         BReg ide[NT][3];
@@ -897,31 +950,27 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
 #pragma unroll
             for (int k = 0; k < 3; ++k) P::stash(stash(t) + (8 + k) * P::BREG_LDS, ide[t][k]);
         }
-        dense<P, 11, 8, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,                          // dir_block1.0
+        d = dense<P, 11, 8, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,                      // dir_block1.0
             [&](int kg, int t) -> BReg { if (kg < 8) return bn[t][kg < 8 ? kg : 0]; return ide[t][kg >= 8 ? kg - 8 : 0]; },
-            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, a[t][2 * fb], a[t][2 * fb + 1]); });
+            OA, NoPrev{});
+        static_assert(L::START[10] % (2 * FPC) == L::START[11] % (2 * FPC) && L::START[14] % (2 * FPC) == L::START[15] % (2 * FPC), "chunk parity");
 #pragma unroll 1
         for (int l = 10; l <= 12; ++l) {                                                      // dir_block1.{2,4,6}
-            dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + (l - 10) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            d = dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + (l - 10) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
-        dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                        // dir_block2.0 (skip)
+        d = dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                    // dir_block2.0 (skip)
             [&](int kg, int t) -> BReg { if (kg < 11) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 11 ? kg - 11 : 0]; },
-            [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            OB, prev_of(d, OA));
         copy_back();
 #pragma unroll 1
         for (int l = 14; l <= 16; ++l) {                                                      // dir_block2.{2,4,6}
-            dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + (l - 14) * 256) * 4,
-                [&](int kg, int t) -> BReg { return a[t][kg]; },
-                [&](int fb, int t, const f32x16& acc) { to_breg<P, true>(acc, b[t][2 * fb], b[t][2 * fb + 1]); });
+            d = dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + (l - 14) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
         float sr[NT], sg[NT], sb[NT];
-        dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4,                        // spec_rgb_head.0
-            [&](int kg, int t) -> BReg { return a[t][kg]; },
-            [&](int, int t, const f32x16& acc) { sr[t] = acc[0]; sg[t] = acc[1]; sb[t] = acc[2]; });
+        auto OSPEC = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { sr[t] = acc[0]; sg[t] = acc[1]; sb[t] = acc[2]; } };
+        dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4, IN_A, OSPEC, prev_of(d, OA)).flush(OSPEC);     // spec_rgb_head.0
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             // half 1's keep[] = (diffuse, density); fetch it into half 0, which holds spec and tint (ref_model.py:98-105)
@@ -968,10 +1017,12 @@ int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, 
     return (int)hipGetLastError();
 }
 
-#ifdef MLP_BF16_WIDE
-using PB16 = PBF16W;
-#else
+// bf16 policy of the shipped library: the wide tile (measured 2.5 % faster end to end);
+// -DMLP_BF16_NARROW selects the 8-wave x 32-sample tile for A/B runs
+#ifdef MLP_BF16_NARROW
 using PB16 = PBF16;
+#else
+using PB16 = PBF16W;
 #endif
 
 }  // namespace
