@@ -3,16 +3,18 @@
 // ever writing an activation to HBM.
 //
 // Design:
-//   * one workgroup = NW wavefronts; each wavefront owns 32 samples (the N dimension of a 32x32 MFMA
-//     tile) and computes ALL output features of every layer for them:  D[feature][sample] = W . X.
+//   * one workgroup = NW wavefronts; each wavefront owns NT x 32 samples (NT column tiles, each the N dimension of a
+//     32x32 MFMA tile) and computes ALL output features of every layer for them:  D[feature][sample] = W . X.
+//     Shipped policies: bf16 4 waves x 64 samples (PBF16W), fp32 4 waves x 32 samples (PF32).
 //   * the products are computed "transposed" (A operand = weights, B operand = activations) so that
 //     the C/D register layout of layer l (lane = sample, registers = features) IS the B-operand layout
 //     of layer l+1 once the weight K-order is permuted at pack time: activations stay in VGPRs for
 //     the whole network, there is no LDS/shuffle traffic between layers.
 //   * weights are pre-packed in MFMA-fragment order (pack_kernels.hip) and streamed
-//     L2 -> LDS with global_load_lds (16 B/lane, lane-linear = conflict-free) through a 4 x 16 KiB ring
-//     shared by all wavefronts of the workgroup, one raw s_barrier per 16 KiB chunk, counted vmcnt so
-//     that two chunks stay in flight across every barrier.
+//     L2 -> LDS with global_load_lds (16 B/lane, lane-linear = conflict-free) through an 8 x 8 KiB ring
+//     shared by all wavefronts of the workgroup, one raw s_barrier per two chunks, counted vmcnt so
+//     that three chunks stay in flight across every barrier.
+//   * epilogues (fp32 -> bf16, ReLU) are deferred: sliced into the first K steps of the next block pair / layer.
 //   * positional encoding is computed in-register straight into B-operand layout (lane half 0
 //     evaluates the sin terms, half 1 the cos terms -- same instruction stream).
 //   * workgroups are persistent: grid = #CUs, each loops over sample tiles; the weight stream
@@ -27,7 +29,8 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 // Ablation switches (diagnostic builds only: `make ablate`; results are wrong by construction, only timing matters)
 //   ABL_NOEPI  skip bias/ReLU/convert epilogues     ABL_NOPE    skip the sin/cos encodings
 //   ABL_NOBAR  no s_barrier in the chunk protocol    ABL_NOLDSA  A fragments not re-read from LDS
-//   ABL_NOGLDS no global_load_lds refills
+//   ABL_NOGLDS no global_load_lds refills         ABL_NOVMWAIT no vmcnt wait at chunk boundaries
+// MLP_CLOCKPROBE: workgroup 0 overwrites output record 0 with (shader cycles, 100 MHz ticks) -- scripts/gpu_clockprobe.sh
 namespace {
 
 // ------------------------------------------------------------------------------------------------
