@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference measurement (roofline.gemm_ref)")
     p.add_argument("--fused", action="store_true",
                    help="fine MLP with the fused compositing epilogue (one launch for rows 8-10) instead of two launches; A/B switch")
     p.add_argument("--model", default="mip", choices=["mip", "ref"],
@@ -92,6 +93,31 @@ def cpu_baseline(n_rays: int):
     return {"value": n_tiles * tile / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d rays (%d tiles of 2500) of the same 800x800, 64+128 workload, torch CPU fp32, %d threads (best of 16/32/64/128 on a %d-CPU host), %.1f s"
                       % (n_tiles * tile, n_tiles, cores, ncpu, dt)}
+
+
+def gemm_reference(dev):
+    """the nominal 2.5 PFLOP/s next to what the library GEMM (hipBLASLt through torch.matmul) sustains on this box on
+    random bf16 data, after the timed region: (i) a large square GEMM = the power-limited practical ceiling of the MFMA pipe,
+    (ii) one 256-wide NeRF layer applied to a full launch's samples UNFUSED (activations read from / written to HBM) = what a
+    layer-by-layer implementation of the hot path gets."""
+    out = {}
+    for name, (m, k, n) in (("square_8192", (8192, 8192, 8192)), ("layer_256_unfused", (1 << 23, 256, 256))):
+        x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
+        w = torch.randn(k, n, device=dev, dtype=torch.bfloat16)
+        for _ in range(3):
+            y = x @ w
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        s.record()
+        for _ in range(reps):
+            y = x @ w
+        e.record()
+        torch.cuda.synchronize()
+        out[name + "_tflops"] = 2.0 * m * k * n * reps / (s.elapsed_time(e) * 1e-3) / 1e12
+        del x, w, y
+    out["note"] = "torch.matmul (hipBLASLt) bf16 on random data, measured on this box after the timed region"
+    return out
 
 
 def main():
@@ -236,6 +262,8 @@ def main():
                          "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": traffic},
             "whole_path_tflops": world * a.steps * n_rays * flop_per_ray / dt / 1e12,
         }
+        if world == 1 and not a.no_gemm_ref and prec == ops.BF16:
+            rec["roofline"]["gemm_ref"] = gemm_reference(dev)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
         print(json.dumps(rec), flush=True)
