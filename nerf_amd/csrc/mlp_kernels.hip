@@ -588,17 +588,18 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         // into `a` during the first K steps of whatever runs next
         Deferred<P, 6, 2> d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
             [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
+        // layers.2/4/6 ping-pong between the two register buffers (a -> b -> a -> b): no copies; the two a->b layers
+        // share one code instance through the loop (same chunk parity, asserted)
+        static_assert(L::START[1] % (2 * FPC) == L::START[3] % (2 * FPC), "chunk parity");
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
 #pragma unroll 1
-        for (int l = 1; l <= 3; ++l) {
-            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < 12; ++k) a[t][k] = b[t][k];
+        for (int r = 0; r < 2; ++r) {
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + r * 512) * 4, IN_A, OB, prev_of(d, OA));
+            if (r == 0) d = dense<P, 16, 8, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB));
         }
         float dens[NT];
         auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
-        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_A, OH, prev_of(d, OA)).flush(OH);
+        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB)).flush(OH);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
@@ -651,12 +652,6 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
         auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
-        auto copy_back = [&]() {                                    // K groups 12..15 arrive through the deferred epilogue
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < 12; ++k) a[t][k] = b[t][k];
-        };
         // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
         // into `a` during the first K steps of whatever runs next
         Deferred<P, 6, 2> d;
@@ -690,24 +685,24 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
                 [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
         }
-        // lin_block1.{2,4,6} : 256 -> 256.  (A loop may only reuse one code instance for layers whose first chunk has the
-        // same parity -- the early/late barrier assignment is compiled in -- hence the assert.)
-        static_assert(L::START[1] % (2 * FPC) == L::START[2] % (2 * FPC) && L::START[5] % (2 * FPC) == L::START[6] % (2 * FPC), "chunk parity");
+        // lin_block1.{2,4,6}, lin_block2.{0,2,4}: the layers ping-pong between the two register buffers
+        //   l1.2 a->b, l1.4 b->a, l1.6 a->b, l2.0 (skip: cat(enc 63, h 256)) b->a, l2.2 a->b, l2.4 b->a
+        // so nothing is ever copied; three loop rounds of (a->b layer, then the skip layer or a b->a layer) keep it at three code
+        // instances.  A loop may only reuse an instance for layers whose first chunk has the same parity (the early/late
+        // barrier assignment is compiled in) and whose biases are evenly spaced -- asserted.
+        static_assert(L::START[1] % (2 * FPC) == L::START[3] % (2 * FPC) && L::START[1] % (2 * FPC) == L::START[5] % (2 * FPC) &&
+                      L::START[2] % (2 * FPC) == L::START[6] % (2 * FPC) && L::BIAS_OFF[6] == 6 * 256, "uniform layer loop");
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
 #pragma unroll 1
-        for (int l = 1; l <= 3; ++l) {
-            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
-            copy_back();
-        }
-        // lin_block2.0 : cat(enc 63, h 256) -> 256
-        d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
-            [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(enc_lds(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
-            OB, prev_of(d, OA));
-        copy_back();
-        // lin_block2.{2,4}
-#pragma unroll 1
-        for (int l = 5; l <= 6; ++l) {
-            d = dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4, IN_A, OB, prev_of(d, OA));
-            copy_back();
+        for (int r = 0; r < 3; ++r) {
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (1 + 2 * r) * 256 * 4, IN_A, OB, prev_of(d, OA));
+            if (r == 1) {
+                d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
+                    [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(enc_lds(t) + kg * P::BREG_LDS); return b[t][kg >= 4 ? kg - 4 : 0]; },
+                    OA, prev_of(d, OB));
+            } else {
+                d = dense<P, 16, 8, L::START[2]>(ws, bias0 + (2 + 2 * r) * 256 * 4, IN_B, OA, prev_of(d, OB));
+            }
         }
         // opacity_head.0 : 256 -> 1 (raw sigma)
         float sigma[NT];
