@@ -196,7 +196,11 @@ struct WeightStream {
     //     every wave holds chunks <= 2b-1 in registers, so those ring slots may be refilled.  Early waves issue chunk
     //     i+NSLOT-2 at boundary i, late waves chunk i+NSLOT-3: both groups issue the same chunk within the same barrier
     //     interval, and NSLOT-5 chunks per wave stay in flight across every wait.
-    static constexpr int INFLIGHT = (NSLOT - 5) * LPW;
+    //   * with a single wave group (NW <= 4: no late waves) the barrier falls on even boundaries only, so only those need the
+    //     wait, and NSLOT-4 chunks may stay in flight: issued before the wait at boundary 2b are chunks <= 2b+NSLOT-3, needed
+    //     complete are chunks <= 2b+1 (read until barrier b+1).
+    static constexpr bool TWO_GROUPS = P::NW > 4;
+    static constexpr int INFLIGHT = (TWO_GROUPS ? NSLOT - 5 : NSLOT - 4) * LPW;
     uint32_t late;
 
     DEVINL void init(const void* packed, uint32_t nchunks) {
@@ -279,6 +283,10 @@ struct WeightStream {
 #endif
     template <int PARITY>
     DEVINL void boundary() {
+        if constexpr (!TWO_GROUPS && PARITY != 0) {      // single group, odd boundary: nothing to wait for, no barrier
+            issue();
+            return;
+        }
 #ifndef ABL_NOVMWAIT
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
 #endif
