@@ -22,7 +22,9 @@
 #include "../../include/nerf_amd.h"
 
 #define MLP_CHUNK_BYTES 8192
+#ifndef MLP_NSLOT
 #define MLP_NSLOT 8          /* ring slots of the proposal / MipNeRF kernels */
+#endif
 #define MLP_NSLOT_REF 6      /* Ref-NeRF needs the LDS for its 11 KiB/wave activation stash */
 #define MLP_RING_BYTES (MLP_CHUNK_BYTES * MLP_NSLOT)
 #define MLP_NW_BF16 8
