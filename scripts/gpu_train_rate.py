@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Training-step rate of the nerf_amd surface (HIP forward + autograd bridge, SURVEY 8f-1 baseline): the body of the
+reference's train.py:164-199 (proposal -> weights -> blur -> inverse sampling -> fine -> composite -> losses -> backward -> Adam)
+on synthetic rays, for a few batch sizes.  Prints rays/s (fwd+bwd+step)."""
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import nerf_amd
+from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+from nerf_amd.mip_methods import maxBlurFilter
+from nerf_amd.mip_model import MipNeRF
+from nerf_amd.nerf_base import NeRF
+from nerf_amd.utils import inverseSample
+
+NEAR, FAR = 2.0, 6.0
+
+
+def run(n_rays, c_n, f_n, precision, iters=20, warm=5):
+    nerf_amd.set_precision(precision)
+    torch.manual_seed(0)
+    prop, mip = ProposalNetwork(10, 256).cuda().train(), MipNeRF(10, 4, 256).cuda().train()
+    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
+    d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
+    rays = torch.cat((o, d), -1).cuda().contiguous()
+    tgt = torch.rand(n_rays, 3).cuda()
+    res = (FAR - NEAR) / c_n
+    base = torch.linspace(NEAR, FAR - res, c_n).cuda()
+
+    def step():
+        z_c = base + torch.rand((n_rays, c_n), device="cuda") * res
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
+        dens = F.softplus(prop.forward(pts))
+        pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
+        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True)
+        z_f = z_f[..., :-1].contiguous()
+        rgbo = mip.forward(NeRF.length2pts(rays, z_f))
+        rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
+        loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    print("train step  %5d rays  %3d+%3d samples  %s : %7.2f ms/iter  %9.0f rays/s" % (n_rays, c_n, f_n, precision, dt * 1e3, n_rays / dt), flush=True)
+
+
+if __name__ == "__main__":
+    for prec in ("bf16", "fp32"):
+        for n in (512, 4096, 16384):
+            run(n, 64, 128, prec)
+    run(512, 32, 64, "bf16")
