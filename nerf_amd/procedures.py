@@ -106,6 +106,58 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     return result
 
 
+def render_only(args, model_path: str, opt_level: str, dataset_root: str = "../dataset/", output_root: str = "./output/"):
+    """Render-only entry point (procedures.py:99-164): load `<model_path><name>_{mip,prop}.pth`, render either the test-set poses
+    (`-e`: with loss / PSNR against the ground truth) or a 120-view orbit `pose_spherical(angle, -30, 4)`, and write one PNG
+    per view to `<output_root>{given,sphere}/result_%03d.png` (rgb [, depth, normal, ground truth] side by side).
+    `opt_level` (apex) is accepted and ignored: `opt_mode == "native"` or `-s` select the bf16 kernels, anything else fp32.
+    `dataset_root` / `output_root` default to the reference's hard-coded locations."""
+    from tqdm import tqdm
+
+    from .addtional import LossPSNR, SoftL1Loss
+    from .dataset import AdaptiveResize, CustomDataSet, save_image, to_tensor
+    from .utils import fov2Focal, pose_spherical
+    resize = AdaptiveResize(args.img_scale)
+    testset = CustomDataSet("%s%s/" % (dataset_root, args.dataset_name), lambda im: to_tensor(resize(im)), args.scene_scale, False, use_alpha=False)
+    cam_fov_test, _ = testset.getCameraParam()
+    r_c = testset.r_c()
+    eval_poses = args.eval_poses
+    render_normal = args.render_normal and not eval_poses
+    render_depth = args.render_depth and not eval_poses
+    if eval_poses:
+        all_poses = testset.tfs.cuda()
+        loss_func, psnr_func = SoftL1Loss(), LossPSNR()
+    else:
+        all_poses = torch.stack([pose_spherical(float(angle), -30.0, 4.0) for angle in torch.linspace(-180, 180, 120 + 1)[:-1]], 0).cuda()
+    test_focal = fov2Focal(cam_fov_test, r_c)
+    if args.ref_nerf:
+        from .ref_model import RefNeRF
+        mip_net = RefNeRF(10, args.ide_level, hidden_unit=args.nerf_net_width, perturb_bottle_neck_w=args.bottle_neck_noise, use_srgb=args.use_srgb).cuda()
+    else:
+        from .mip_model import MipNeRF
+        mip_net = MipNeRF(10, 4, hidden_unit=args.nerf_net_width).cuda()
+    prop_net = ProposalNetwork(10, hidden_unit=args.prop_net_width).cuda()
+    mip_net.loadFromFile(model_path + args.name + "_mip.pth", False)
+    prop_net.loadFromFile(model_path + args.name + "_prop.pth", False)
+    mip_net.eval()
+    prop_net.eval()
+    low_precision = bool(args.use_scaler) or args.opt_mode == "native"
+    with torch.no_grad():
+        for i, pose in tqdm(list(enumerate(all_poses))):
+            pose = pose.clone()
+            pose[:3, -1] *= args.scene_scale
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=low_precision):
+                result = render_image(mip_net, prop_net, pose[:3, :], r_c, test_focal, args.near, args.far, 128, white_bkg=args.white_bkg,
+                                      render_normal=render_normal, render_depth=render_depth)
+            if eval_poses:
+                gt_img = testset[i][0].cuda()
+                loss = loss_func(result["rgb"], gt_img)
+                print("Image loss:%.6f\tPSNR:%.4f" % (loss.item(), psnr_func(loss).item()))
+                result["gt_img"] = gt_img
+            save_image(list(result.values()), "%s%s/result_%03d.png" % (output_root, "given" if eval_poses else "sphere", i),
+                       nrow=1 + render_depth + render_depth + eval_poses)                  # (the reference counts render_depth twice)
+
+
 def get_parser():
     """The reference's flag set (procedures.py:166-213) so that its entry scripts parse unchanged."""
     p = argparse.ArgumentParser()

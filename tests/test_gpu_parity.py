@@ -9,6 +9,7 @@ Tolerances (north_star: <= 1e-4 abs fp32 on RGB / depth / weights):
     accumulate), 5e-3 x output scale; bf16 end-to-end is judged on image error / PSNR, not on 1e-4.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -541,3 +542,40 @@ def test_error_reporting(A):
                                     torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
     with pytest.raises(NotImplementedError):
         A.addtional.ProposalNetwork(10).cuda().forward(torch.rand(2, 3, 3).cuda())          # width 128: no kernel instance
+
+
+def test_render_only_cli(A, tmp_path):
+    """procedures.render_only (procedures.py:99-164): checkpoint files -> test-set poses -> PNGs (rgb | ground truth)."""
+    import json
+    import numpy as np
+    from PIL import Image
+    from nerf_amd.nerf_helper import saveModel
+    from nerf_amd.procedures import get_parser, render_only
+    root = str(tmp_path)
+    scene = os.path.join(root, "data", "toy")
+    os.makedirs(os.path.join(scene, "test"))
+    frames = []
+    for k in range(2):
+        Image.fromarray(np.full((50, 50, 3), 255, np.uint8)).save(os.path.join(scene, "test", "r_%d.png" % k))
+        pose = A.utils.pose_spherical(40.0 * k, -30.0, 4.0)
+        frames.append({"file_path": "./test/r_%d" % k, "transform_matrix": pose.tolist()})
+    json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, open(os.path.join(scene, "transforms_test.json"), "w"))
+    prop, mip = build_nets(A, "small")
+    os.makedirs(os.path.join(root, "model"))
+    saveModel(mip, os.path.join(root, "model", "toy_mip.pth"))
+    saveModel(prop, os.path.join(root, "model", "toy_prop.pth"))
+    args = get_parser().parse_args(["--name", "toy", "--dataset_name", "toy", "--img_scale", "1.0", "--opt_mode", "none", "-e", "-w"])
+    torch.manual_seed(3)
+    render_only(args, os.path.join(root, "model") + "/", "O1", dataset_root=os.path.join(root, "data") + "/", output_root=os.path.join(root, "out") + "/")
+    for k in range(2):
+        im = np.asarray(Image.open(os.path.join(root, "out", "given", "result_%03d.png" % k)))
+        assert im.shape == (54, 2 * 52 + 2, 3)                               # rgb | gt with 2-pixel padding
+        assert (im[2:52, 54:104] == 255).all()                               # the ground-truth panel
+    # the rgb panel equals a direct render_image call with the same RNG state
+    torch.manual_seed(3)
+    with torch.no_grad():
+        focal = A.utils.fov2Focal(0.6911112070083618, (50, 50))
+        direct = A.procedures.render_image(mip.eval(), prop.eval(), torch.tensor(frames[0]["transform_matrix"])[:3].cuda(), (50, 50), focal, 2.0, 6.0,
+                                           128, white_bkg=True)["rgb"]
+    first = torch.from_numpy(np.asarray(Image.open(os.path.join(root, "out", "given", "result_000.png")))[2:52, 2:52].astype(np.float32) / 255.0)
+    assert (first.permute(2, 0, 1) - direct.cpu().clamp(0, 1)).abs().max() <= 0.5 / 255 + 1e-4
