@@ -155,11 +155,7 @@ struct WeightStream {
     uint32_t cur;           // LDS byte offset of the chunk the register prefetch reads from (+ lane*16)
     uint32_t cur_slot;
     uint32_t wave_lds;      // wave-uniform LDS offset of this wave's pieces inside a slot
-#ifdef MLP_BURST
-    typename P::AReg q[2][P::DEPTH];   // double-buffered groups of DEPTH A fragments: one being multiplied, one in flight from LDS
-#else
     typename P::AReg q[P::DEPTH];   // A fragments f .. f+DEPTH-1 already in registers (f = next fragment to multiply)
-#endif
 
     static DEVINL void dummy_sink(const bf16x8& d) { asm volatile("" ::"v"(d)); }
     template <class T> static DEVINL void dummy_sink(const T& d) { asm volatile("" ::"v"(d.lo), "v"(d.hi)); }
@@ -220,11 +216,7 @@ struct WeightStream {
         __builtin_amdgcn_s_barrier();                                        // ... and everybody else's
         asm volatile("" ::: "memory");
 #pragma unroll
-#ifdef MLP_BURST
-        for (int i = 0; i < P::DEPTH; ++i) q[0][i] = P::load_a(cur + i * P::FRAG_BYTES);
-#else
         for (int i = 0; i < P::DEPTH; ++i) q[i] = P::load_a(cur + i * P::FRAG_BYTES);
-#endif
         if (!late) {                                                         // boundary 0 of the early waves
             __builtin_amdgcn_s_barrier();                                    // barrier 0 (late waves: at their boundary 1)
             asm volatile("" ::: "memory");
@@ -234,33 +226,6 @@ struct WeightStream {
     // Fragment F of the stream (compile-time index, F mod DEPTH == queue slot): hand out its registers and
     // start the LDS read of fragment F+DEPTH into the same slot.  The boundary work therefore runs DEPTH
     // fragments BEFORE the first MFMA that needs the new chunk: the MFMA pipe keeps draining the register queue.
-#ifdef MLP_BURST
-    // Burst form: the LDS reads of a whole group of DEPTH fragments are issued together, then the DEPTH MFMAs of the
-    // previous group run back to back with nothing issued between them.
-    template <int F>
-    DEVINL typename P::AReg next() {
-        constexpr int R = F / P::DEPTH, S = F % P::DEPTH;
-        if constexpr (S == 0) {
-            constexpr int G = F + P::DEPTH;
-            static_assert(P::FPC % P::DEPTH == 0, "a group may not straddle chunks");
-            if (G % P::FPC == 0) {
-                cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
-                cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
-                boundary<(G / P::FPC) & 1>();
-            }
-#pragma unroll
-            for (int i = 0; i < P::DEPTH; ++i) q[(R + 1) & 1][i] = P::load_a(cur + ((G + i) % P::FPC) * P::FRAG_BYTES);
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef MLP_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-        }
-#ifdef MLP_SETPRIO
-        if constexpr (S == P::DEPTH - 1) __builtin_amdgcn_s_setprio(0);
-#endif
-        return q[R & 1][S];
-    }
-#else
     template <int F>
     DEVINL typename P::AReg next() {
         const typename P::AReg a = q[F % P::DEPTH];
@@ -280,7 +245,6 @@ struct WeightStream {
 #endif
         return a;
     }
-#endif
     template <int PARITY>
     DEVINL void boundary() {
         if constexpr (!TWO_GROUPS && PARITY != 0) {      // single group, odd boundary: nothing to wait for, no barrier
