@@ -321,9 +321,88 @@ struct CompositeArgs {
     float* rgb; float* weights; float* depth; float* normal_img;
 };
 
+// Fast path of the compositing kernel for S <= 128 without normals (the render path): a ray is two 64-lane chunks; all of
+// its loads (one 16-byte rgbo record and one z per lane and chunk) are issued up front -- the neighbour z of the transmittance
+// step comes from a lane shuffle instead of a second load -- and the NEXT ray of this wavefront is loaded before the current
+// one is reduced, so two rays' worth of HBM requests are in flight per wave.  Same arithmetic, same order as the generic path.
+struct RayRecs { f32x4 c0, c1; float z0, z1, dx, dy, dz; };
+DEVINL RayRecs load_ray(const CompositeArgs& a, int64_t n, int lane) {
+    RayRecs r;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4* px = reinterpret_cast<const f32x4*>(a.rgbo) + n * a.S;
+    const float* zz = a.z + n * a.z_stride;
+    const float* dd = a.dirs + n * a.dirs_stride;
+    r.c0 = (lane < a.S) ? px[lane] : zero;
+    r.c1 = (64 + lane < a.S) ? px[64 + lane] : zero;
+    r.z0 = (lane < a.S) ? zz[lane] : 0.0f;
+    r.z1 = (64 + lane < a.S) ? zz[64 + lane] : 0.0f;
+    r.dx = dd[0]; r.dy = dd[1]; r.dz = dd[2];
+    return r;
+}
+DEVINL void composite_ray_fast(const CompositeArgs& a, int64_t n, const RayRecs& r, int lane) {
+    const int S = a.S;
+    const bool mul = (a.flags & 1) != 0;
+    const float nrm = mul ? norm3(r.dx, r.dy, r.dz) : 1.0f;
+    const float zn0 = mul ? r.z0 * nrm : r.z0, zn1 = mul ? r.z1 * nrm : r.z1;
+    float nx0 = __shfl_down(zn0, 1, 64);
+    const float first1 = __shfl(zn1, 0, 64);
+    if (lane == 63) nx0 = first1;
+    const float nx1 = __shfl_down(zn1, 1, 64);
+    float w0 = 0.0f, w1 = 0.0f;
+    double p0 = 1.0, p1 = 1.0;
+    if (lane < S) {
+        const float delta = (lane + 1 < S) ? (nx0 - zn0) : 1e10f;
+        const float m = expf(-density_act(r.c0[3] + a.sigma_shift, a.act) * delta);
+        w0 = 1.0f - m; p0 = (double)(m + 1e-10f);
+    }
+    if (64 + lane < S) {
+        const float delta = (64 + lane + 1 < S) ? (nx1 - zn1) : 1e10f;
+        const float m = expf(-density_act(r.c1[3] + a.sigma_shift, a.act) * delta);
+        w1 = 1.0f - m; p1 = (double)(m + 1e-10f);
+    }
+    const double i0 = wave_incl_scan_mul(p0);
+    double e0 = __shfl_up(i0, 1, 64);
+    if (lane == 0) e0 = 1.0;
+    const double carry = __shfl(i0, 63, 64);                  // 1.0 * product of chunk 0
+    w0 *= (float)(1.0 * e0);
+    float accr = 0.0f, accg = 0.0f, accb = 0.0f, accw = 0.0f, accd = 0.0f;
+    if (lane < S) { accr += w0 * r.c0[0]; accg += w0 * r.c0[1]; accb += w0 * r.c0[2]; accw += w0; accd += w0 * zn0; }
+    if (S > 64) {
+        const double i1 = wave_incl_scan_mul(p1);
+        double e1 = __shfl_up(i1, 1, 64);
+        if (lane == 0) e1 = 1.0;
+        w1 *= (float)(carry * e1);
+        if (64 + lane < S) { accr += w1 * r.c1[0]; accg += w1 * r.c1[1]; accb += w1 * r.c1[2]; accw += w1; accd += w1 * zn1; }
+    }
+    if (a.weights) {
+        float* wout = a.weights + n * S;
+        if (lane < S) wout[lane] = w0;
+        if (64 + lane < S) wout[64 + lane] = w1;
+    }
+    accr = wave_sum(accr); accg = wave_sum(accg); accb = wave_sum(accb); accw = wave_sum(accw); accd = wave_sum(accd);
+    if (lane == 0) {
+        if (a.flags & 2) { const float bg = 1.0f - accw; accr += bg; accg += bg; accb += bg; }
+        a.rgb[n * 3] = accr; a.rgb[n * 3 + 1] = accg; a.rgb[n * 3 + 2] = accb;
+        if (a.depth) a.depth[n] = (accd - a.near) / (a.far - a.near);
+    }
+}
+
 __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     const int S = a.S;
     const int lane = lane_id();
+    if (S <= 128 && a.normal == nullptr && a.normal_img == nullptr) {
+        const int64_t stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+        int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block();
+        if (n >= a.N) return;
+        RayRecs cur = load_ray(a, n, lane);
+        for (; n < a.N; n += stride) {
+            RayRecs nxt = cur;
+            if (n + stride < a.N) nxt = load_ray(a, n + stride, lane);
+            composite_ray_fast(a, n, cur, lane);
+            cur = nxt;
+        }
+        return;
+    }
     for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         const float* dd = a.dirs + n * a.dirs_stride;
         const bool mul = (a.flags & 1) != 0;

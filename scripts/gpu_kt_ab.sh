@@ -1,0 +1,11 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for v in OLD BASE; do
+  if [ $v = BASE ]; then unset NERF_AMD_LIB; else export NERF_AMD_LIB=$R/nerf_amd/ablate/libnerf_amd_$v.so; fi
+  rm -rf /tmp/kt_$v; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$v -o kt -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-ref > /tmp/kt_$v.log 2>&1
+  echo "== $v"; python - <<PY
+import csv
+for r in csv.DictReader(open('/tmp/kt_$v/kt_kernel_stats.csv')):
+    if any(k in r['Name'] for k in ('composite','resample','proposal','mip_kernel')): print('%-28s %9.3f ms' % (r['Name'].split('(')[0][-28:], float(r['AverageNs'])/1e6))
+PY
+done
