@@ -130,8 +130,10 @@ DEVINL void lds_wave_sync() {
 constexpr int SORT_NB = 256, SORT_CAP = 6;
 constexpr int SORT_LDS_FLOATS = 2 * SORT_NB + SORT_NB * SORT_CAP / 2;      // cnt, pre (int) + members (uint16)
 
+// uf(i, k) = the uniform of sample k = lane + 64 i (a global pointer, or registers loaded one ray ahead)
+template <class UF>
 DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, float* cdf, float* samp, int* bel, int* sortbuf,
-                                const float* __restrict__ u, int K, int sort, float* __restrict__ z_out,
+                                UF&& uf, int K, int sort, float* __restrict__ z_out,
                                 int64_t* __restrict__ below_out, int64_t* __restrict__ above_out) {
     const int lane = lane_id();
     const int nb = nw + 1;           // bins == cdf entries incl. the leading 0
@@ -150,8 +152,8 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
         carry += __shfl(incl, 63, 64);
     }
     lds_wave_sync();
-    for (int k = lane; k < K; k += 64) {
-        const float uu = u[k];
+    for (int k = lane, i = 0; k < K; k += 64, ++i) {
+        const float uu = uf(i, k);
         int lo = 0, hi = nb;                         // searchsorted(right=True): count of entries <= uu
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -184,8 +186,8 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
     for (int b = lane; b < SORT_NB; b += 64) cnt[b] = 0;
     lds_wave_sync();
     int overflow = 0;
-    for (int k = lane; k < K; k += 64) {
-        int b = (int)(u[k] * (float)SORT_NB);
+    for (int k = lane, i = 0; k < K; k += 64, ++i) {
+        int b = (int)(uf(i, k) * (float)SORT_NB);
         b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
         const int pos = atomicAdd(&cnt[b], 1);
         if (pos < SORT_CAP) mem[b * SORT_CAP + pos] = (unsigned short)k; else overflow = 1;
@@ -216,8 +218,8 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
         for (int i = 0; i < 4; ++i) { pre[lane * 4 + i] = run; run += c[i]; }
     }
     lds_wave_sync();
-    for (int k = lane; k < K; k += 64) {
-        int b = (int)(u[k] * (float)SORT_NB);
+    for (int k = lane, i = 0; k < K; k += 64, ++i) {
+        int b = (int)(uf(i, k) * (float)SORT_NB);
         b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
         const float v = samp[k];
         int rank = pre[b];
@@ -258,8 +260,9 @@ __global__ __launch_bounds__(256) void inverse_sample_kernel(const float* __rest
             for (int j = lane; j < nw + 1; j += 64) bins[j] = z[n * C + j];
         }
         lds_wave_sync();
-        wave_inverse_sample(pw, bins, nw, cdf, samp, bel, sortbuf, u + n * K, K, sort, z_out + n * K, below ? below + n * K : nullptr,
-                            above ? above + n * K : nullptr);
+        const float* un = u + n * K;
+        wave_inverse_sample(pw, bins, nw, cdf, samp, bel, sortbuf, [&](int, int k) { return un[k]; }, K, sort, z_out + n * K,
+                            below ? below + n * K : nullptr, above ? above + n * K : nullptr);
     }
 }
 
@@ -282,20 +285,58 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     float* zl = reinterpret_cast<float*>(sortbuf + SORT_LDS_FLOATS);
     float* wraw = zl + C;
     const int lane = lane_id();
-    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
-        lds_wave_sync();
+    // All global inputs of a ray (direction, depths or their uniforms, densities, the K inverse-CDF uniforms) are loaded ONE RAY
+    // AHEAD into registers: the ray's own phases then never wait for HBM (three exposed round trips per ray before).
+    struct RayIn { float dx, dy, dz, zv[2], dens[2], u[3]; };
+    const bool fits = C <= 128 && K <= 192;
+    auto load_in = [&](int64_t n) -> RayIn {
+        RayIn r;
         const float* dd = a.dirs + n * a.dirs_stride;
-        const float nrm = norm3(dd[0], dd[1], dd[2]);
-        for (int j = lane; j < C; j += 64) {
-            const float zv = a.z ? a.z[n * C + j] : (a.z_base[j] + a.u_strat[n * C + j] * a.z_jitter);
-            zl[j] = zv;
-            if (a.z_coarse) a.z_coarse[n * C + j] = zv;
+        r.dx = dd[0]; r.dy = dd[1]; r.dz = dd[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = lane + 64 * i;
+            r.zv[i] = 0.0f; r.dens[i] = 0.0f;
+            if (j < C) {
+                r.zv[i] = a.z ? a.z[n * C + j] : (a.z_base[j] + a.u_strat[n * C + j] * a.z_jitter);
+                r.dens[i] = a.density[n * C + j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int k = lane + 64 * i; r.u[i] = (k < K) ? a.u_inv[n * K + k] : 0.0f; }
+        return r;
+    };
+    const int64_t stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block();
+    if (n >= a.N) return;
+    RayIn cur = {};
+    if (fits) cur = load_in(n);
+    for (; n < a.N; n += stride) {
+        RayIn nxt = cur;
+        if (fits && n + stride < a.N) nxt = load_in(n + stride);
+        lds_wave_sync();
+        float nrm;
+        if (fits) {
+            nrm = norm3(cur.dx, cur.dy, cur.dz);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = lane + 64 * i;
+                if (j < C) { zl[j] = cur.zv[i]; if (a.z_coarse) a.z_coarse[n * C + j] = cur.zv[i]; }
+            }
+        } else {
+            const float* dd = a.dirs + n * a.dirs_stride;
+            nrm = norm3(dd[0], dd[1], dd[2]);
+            for (int j = lane; j < C; j += 64) {
+                const float zv = a.z ? a.z[n * C + j] : (a.z_base[j] + a.u_strat[n * C + j] * a.z_jitter);
+                zl[j] = zv;
+                if (a.z_coarse) a.z_coarse[n * C + j] = zv;
+            }
         }
         lds_wave_sync();
         const float* sg = a.density + n * C;
         const int soft = a.softplus;
         wave_sigma_to_weights(C, NERF_AMD_ACT_RELU,
-                              [&](int s) { const float d = sg[s]; return soft ? softplus_f(d) : d; },
+                              [&](int s) { const float d = fits ? ((s >> 6) ? cur.dens[1] : cur.dens[0]) : sg[s]; return soft ? softplus_f(d) : d; },
                               [&](int s) { return zl[s] * nrm; },
                               [&](int s, float wv, float) { wraw[s] = wv; });
         lds_wave_sync();
@@ -309,8 +350,11 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         }
         for (int j = lane; j < C - 1; j += 64) bins[j] = 0.5f * (zl[j + 1] + zl[j]);   // mid-points of the RAW depths
         lds_wave_sync();
-        wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, sortbuf, a.u_inv + n * K, K, 1, a.z_fine + n * K,
-                            a.below ? a.below + n * K : nullptr, nullptr);
+        const float* un = a.u_inv + n * K;
+        wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, sortbuf,
+                            [&](int i, int k) { return fits ? (i == 0 ? cur.u[0] : (i == 1 ? cur.u[1] : cur.u[2])) : un[k]; },
+                            K, 1, a.z_fine + n * K, a.below ? a.below + n * K : nullptr, nullptr);
+        cur = nxt;
     }
 }
 
