@@ -182,6 +182,23 @@ int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const fl
 int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).
+ * One wavefront per ray; S <= 256.  Depths and directions are not differentiated (the reference detaches them too).
+ * ------------------------------------------------------------------------------------------------ */
+/* d(get_weights)/d(density) (addtional.py:100-107, nerf_base.py:80-86): d_weights (N,S) -> d_sigma (N,S). */
+int nerf_amd_sigma_to_weights_backward(const float* sigma, const float* z, const float* dirs, int64_t N, int S, int act,
+                                       const float* d_weights, float* d_sigma, void* stream);
+/* d(NeRF.render)/d(rgbo) (nerf_base.py:91-113): d_rgb (N,3), optional d_weights (N,S) and d_depth (N) -> d_rgbo (N,S,4);
+ * same flags / act / sigma_shift / near / far as nerf_amd_composite. */
+int nerf_amd_composite_backward(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int S,
+                                int flags, int act, float sigma_shift, float near, float far, const float* d_rgb,
+                                const float* d_weights, const float* d_depth, float* d_rgbo, void* stream);
+/* d(maxBlurFilter)/d(weights) (mip_methods.py:61-66); ties of torch.maximum split the gradient in halves. */
+int nerf_amd_max_blur_backward(const float* weights, const float* d_out, int64_t N, int S, float* d_weights, void* stream);
+/* d(getBounds)/d(w_prop) (addtional.py:14-18): d_bounds (N,K-1) -> d_w_prop (N,C). */
+int nerf_amd_get_bounds_backward(const int64_t* below, const float* d_bounds, int64_t N, int C, int K, float* d_w_prop, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The whole tile body of render_image (procedures.py:64-85, non-Ref) for N rays in four launches:
  *   proposal MLP (stratified z fused) -> resample -> fine MLP (length2pts fused) -> composite.
  * rays: (N,6) device, or NULL to generate them in-kernel from `camera` (mode 2 of nerf_amd_samples;

@@ -53,6 +53,11 @@ SIGNATURES = {
     "nerf_amd_composite": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_get_bounds": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
+    "nerf_amd_sigma_to_weights_backward": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void]),
+    "nerf_amd_composite_backward": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              C.c_float, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_max_blur_backward": (C.c_int, [c_void, c_void, i64, C.c_int, c_void, c_void]),
+    "nerf_amd_get_bounds_backward": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_render_workspace_bytes": (C.c_size_t, [i64, C.c_int]),
     "nerf_amd_render_rays": (C.c_int, [c_void, c_void, C.c_int, c_void, C.POINTER(Samples), i64, c_void, c_void, c_void, i64,
                                        C.c_int, C.c_float, C.c_float, C.c_int, c_void, c_void, c_void, c_void, c_void]),

@@ -13,7 +13,8 @@ from .nerf_helper import makeMLP
 def getBounds(weights: torch.Tensor, inds: torch.Tensor):
     """Proposal weight mass covering each fine interval (addtional.py:14-18, index quirk included)."""
     if ab.needs_grad(weights):
-        return ab.HipOp.apply(lambda w, i: ops.get_bounds(w, i), ab.bounds_expr, 0, weights, inds)
+        expr = ab.with_hip_backward(lambda w, i: ab.bounds_expr(w, i), lambda g, w, i: (ops.get_bounds_backward(i, g, w.shape[-1]), None))
+        return ab.HipOp.apply(lambda w, i: ops.get_bounds(w, i), expr, 0, weights, inds)
     return ops.get_bounds(weights, inds)
 
 
@@ -103,6 +104,7 @@ class ProposalNetwork(nn.Module, PackedWeightsMixin):
         if ab.needs_grad(density, zvals):
             if ray_dirs is not None:
                 zvals = zvals * ray_dirs.norm(dim=-1, keepdim=True)
-            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, ops.ACT_RELU),
-                                  lambda s, z: ab.weights_expr(s, z, ops.ACT_RELU), 0, density, zvals)
+            expr = ab.with_hip_backward(lambda s, z: ab.weights_expr(s, z, ops.ACT_RELU), lambda g, s, z: (
+                (ops.sigma_to_weights_backward(s, z, None, ops.ACT_RELU, g), None) if s.shape[-1] <= ops.BWD_MAX_SAMPLES else None))
+            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, ops.ACT_RELU), expr, 0, density, zvals)
         return ops.sigma_to_weights(density, zvals, ray_dirs, ops.ACT_RELU)

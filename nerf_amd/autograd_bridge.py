@@ -71,9 +71,17 @@ def bounds_expr(w, inds):
     return torch.gather(sat, -1, inds[:, 1:] + 1) - torch.gather(sat, -1, inds[:, :-1])
 
 
+def with_hip_backward(expr_fn: Callable, hip_bwd: Callable) -> Callable:
+    """Attach a HIP backward to an expression: hip_bwd(grad, *args) -> one gradient (or None) per argument.  HipOp then calls it
+    instead of re-evaluating `expr_fn` (which stays as the specification the HIP backward is tested against)."""
+    expr_fn.hip_bwd = hip_bwd
+    return expr_fn
+
+
 class HipOp(torch.autograd.Function):
-    """forward = `hip_fn(*tensors)` (HIP kernels);  backward = VJP of `expr_fn(*tensors)` (torch, on the device).
-    Only the first output of hip_fn is differentiable; extra outputs are returned as-is (non-differentiable)."""
+    """forward = `hip_fn(*tensors)` (HIP kernels);  backward = `expr_fn.hip_bwd` (HIP kernels) when the op has one, else the VJP
+    of `expr_fn(*tensors)` (torch, on the device).  Only the first output of hip_fn is differentiable; extra outputs are
+    returned as-is (non-differentiable)."""
 
     @staticmethod
     def forward(ctx, hip_fn: Callable, expr_fn: Callable, n_extra: int, *tensors):
@@ -95,6 +103,14 @@ class HipOp(torch.autograd.Function):
     def backward(ctx, grad, *unused):
         saved = list(ctx.saved_tensors)
         consts = list(ctx.consts)
+        hip_bwd = getattr(ctx.expr_fn, "hip_bwd", None)
+        if hip_bwd is not None:
+            it_t, it_c = iter(saved), iter(consts)
+            full = [next(it_t) if is_t else next(it_c) for is_t in ctx.is_tensor]
+            with torch.no_grad():
+                grads = hip_bwd(grad.contiguous(), *full)
+            if grads is not None:                                   # None = "not supported for these sizes": fall through to the VJP
+                return (None, None, None, *grads)
         args, leaves = [], []
         for is_t in ctx.is_tensor:
             if is_t:

@@ -27,6 +27,10 @@ int sk_resample(const float*, const float*, const float*, const float*, float, c
 int sk_composite(const float*, const float*, int, const float*, int, int64_t, int, int, int, float, float, float, const float*,
                  const float*, float*, float*, float*, float*, hipStream_t);
 int sk_get_bounds(const float*, const int64_t*, int64_t, int, int, float*, hipStream_t);
+int sk_weights_backward(const float*, int, int, const float*, int, const float*, int, int64_t, int, int, int, float, const float*, const float*,
+                        const float*, const float*, int, float, float, float*, int, int, float*, hipStream_t);
+int sk_max_blur_backward(const float*, const float*, int64_t, int, float*, hipStream_t);
+int sk_get_bounds_backward(const int64_t*, const float*, int64_t, int, int, float*, hipStream_t);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -218,6 +222,34 @@ int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, in
     if (N < 0 || C < 1 || C > 4096 || K < 2) return fail(NERF_AMD_EINVAL, "bad size");
     if (N && (!w_prop || !below || !bounds)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_get_bounds(w_prop, below, N, C, K, bounds, S(stream)), "nerf_amd_get_bounds");
+}
+
+// ---- backward of the sampling / compositing rows ----
+int nerf_amd_sigma_to_weights_backward(const float* sigma, const float* z, const float* dirs, int64_t N, int Sn, int act,
+                                       const float* d_weights, float* d_sigma, void* stream) {
+    if (N < 0 || Sn < 1 || Sn > 256) return fail(NERF_AMD_EINVAL, "bad size (S must be 1..256)");
+    if (N && (!sigma || !z || !d_weights || !d_sigma)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_weights_backward(sigma, 1, 0, z, Sn, dirs, 3, N, Sn, dirs ? 1 : 0, act, 0.0f, nullptr, nullptr, d_weights, nullptr, 0, 0.0f,
+                                          1.0f, d_sigma, 1, 0, nullptr, S(stream)), "nerf_amd_sigma_to_weights_backward");
+}
+int nerf_amd_composite_backward(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int Sn,
+                                int flags, int act, float sigma_shift, float near, float far, const float* d_rgb,
+                                const float* d_weights, const float* d_depth, float* d_rgbo, void* stream) {
+    if (N < 0 || Sn < 1 || Sn > 256 || z_stride < Sn) return fail(NERF_AMD_EINVAL, "bad size (S must be 1..256)");
+    if (N && (!rgbo || !z || !dirs || !d_rgbo)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (N && !d_rgb) return fail(NERF_AMD_EINVAL, "d_rgb is required (pass zeros when only the weights carry a gradient)");
+    return hip_status(sk_weights_backward(rgbo, 4, 3, z, z_stride, dirs, dirs_stride, N, Sn, flags & 1, act, sigma_shift, rgbo, d_rgb, d_weights,
+                                          d_depth, (flags >> 1) & 1, near, far, d_rgbo, 4, 3, d_rgbo, S(stream)), "nerf_amd_composite_backward");
+}
+int nerf_amd_max_blur_backward(const float* weights, const float* d_out, int64_t N, int Sn, float* d_weights, void* stream) {
+    if (N < 0 || Sn < 1) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N && (!weights || !d_out || !d_weights)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_max_blur_backward(weights, d_out, N, Sn, d_weights, S(stream)), "nerf_amd_max_blur_backward");
+}
+int nerf_amd_get_bounds_backward(const int64_t* below, const float* d_bounds, int64_t N, int C, int K, float* d_w_prop, void* stream) {
+    if (N < 0 || C < 1 || C > 4096 || K < 2) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N && (!below || !d_bounds || !d_w_prop)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_get_bounds_backward(below, d_bounds, N, C, K, d_w_prop, S(stream)), "nerf_amd_get_bounds_backward");
 }
 
 // workspace: density (N,64) | z_fine (N, n_fine+1) | rgbo (N, n_fine, 4) | rays (N, 6)

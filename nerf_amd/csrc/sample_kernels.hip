@@ -505,6 +505,146 @@ __global__ __launch_bounds__(256) void get_bounds_kernel(const float* __restrict
     }
 }
 
+// ================================================================================================
+// Backward kernels of the sampling / compositing rows: one wavefront per ray, the transmittance
+// product's adjoint is a suffix sum.  Up to 256 samples per ray (4 register chunks).
+//   forward:  m_i = exp(-act(sigma_i + shift) * delta_i),  q_i = m_i + 1e-10,  T_i = prod_{j<i} q_j,  w_i = (1 - m_i) T_i
+//   given G_i = dL/dw_i:   dL/dm_j = -G_j T_j + (sum_{i>j} G_i w_i) / q_j,   dL/dsigma_j = dL/dm_j * (-delta_j m_j) * act'(sigma_j + shift)
+// ================================================================================================
+constexpr int BWD_CHUNKS = 4;
+struct WeightsBwdArgs {
+    const float* sigma; int sigma_stride;      // sigma of sample s of ray n at sigma[(n*S + s) * sigma_stride + sigma_off]
+    int sigma_off;
+    const float* z; int z_stride; const float* dirs; int dirs_stride; int64_t N; int S; int mul_norm; int act; float sigma_shift;
+    // composite extras (rgbo != nullptr): colours come from rgbo[(n*S+s)*4 + 0..2]
+    const float* rgbo; const float* d_rgb; const float* d_weights; const float* d_depth; int white_bkg; float near, far;
+    float* d_sigma; int d_sigma_stride; int d_sigma_off; float* d_rgbo;
+};
+DEVINL float density_act_grad(float x, int act) {
+    if (act == 0) return x > 0.0f ? 1.0f : 0.0f;
+    if (act == 2) return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+    return 1.0f;
+}
+__global__ __launch_bounds__(256) void weights_backward_kernel(WeightsBwdArgs a) {
+    const int S = a.S;
+    const int lane = lane_id();
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        float nrm = 1.0f;
+        if (a.mul_norm && a.dirs) { const float* dd = a.dirs + n * a.dirs_stride; nrm = norm3(dd[0], dd[1], dd[2]); }
+        const float* zz = a.z + n * a.z_stride;
+        float dr = 0.0f, dg = 0.0f, db = 0.0f, dd_ = 0.0f;
+        if (a.d_rgb) { dr = a.d_rgb[n * 3]; dg = a.d_rgb[n * 3 + 1]; db = a.d_rgb[n * 3 + 2]; }
+        if (a.d_depth) dd_ = a.d_depth[n] / (a.far - a.near);
+        const float bg = (a.white_bkg && a.d_rgb) ? ((dr + dg) + db) : 0.0f;       // rgb += 1 - sum w
+        float m[BWD_CHUNKS], T[BWD_CHUNKS], G[BWD_CHUNKS], delta[BWD_CHUNKS], x[BWD_CHUNKS];
+        double carry = 1.0, gw_carry = 0.0;
+        double P[BWD_CHUNKS];                                                       // inclusive prefix of G_i w_i
+#pragma unroll
+        for (int c = 0; c < BWD_CHUNKS; ++c) {
+            const int s = c * 64 + lane;
+            const bool ok = s < S;
+            m[c] = 1.0f; T[c] = 0.0f; G[c] = 0.0f; delta[c] = 0.0f; x[c] = 0.0f;
+            double p = 1.0;
+            float zn0 = 0.0f;
+            if (c * 64 < S) {
+                if (ok) {
+                    zn0 = zz[s] * nrm;
+                    delta[c] = (s + 1 < S) ? (zz[s + 1] * nrm - zn0) : 1e10f;
+                    x[c] = a.sigma[(n * S + s) * a.sigma_stride + a.sigma_off] + a.sigma_shift;
+                    m[c] = expf(-density_act(x[c], a.act) * delta[c]);
+                    p = (double)(m[c] + 1e-10f);
+                }
+                const double incl = wave_incl_scan_mul(p);
+                double excl = __shfl_up(incl, 1, 64);
+                if (lane == 0) excl = 1.0;
+                T[c] = (float)(carry * excl);
+                carry *= __shfl(incl, 63, 64);
+                float g = 0.0f;
+                if (ok) {
+                    if (a.d_weights) g += a.d_weights[n * S + s];
+                    if (a.rgbo) {
+                        const float* cc = a.rgbo + (n * S + s) * 4;
+                        g += ((dr * cc[0] + dg * cc[1]) + db * cc[2]) - bg;
+                    }
+                    g += dd_ * zn0;
+                }
+                G[c] = g;
+                const float w = (1.0f - m[c]) * T[c];
+                const double gi = wave_incl_scan_add(ok ? (double)(g * w) : 0.0);
+                P[c] = gw_carry + gi;
+                gw_carry += __shfl(gi, 63, 64);
+                if (ok && a.d_rgbo) {                                               // dL/dc_i = w_i * d_rgb
+                    float* o = a.d_rgbo + (n * S + s) * 4;
+                    o[0] = w * dr; o[1] = w * dg; o[2] = w * db;
+                }
+            }
+        }
+        const double total = gw_carry;
+#pragma unroll
+        for (int c = 0; c < BWD_CHUNKS; ++c) {
+            const int s = c * 64 + lane;
+            if (s < S) {
+                const float suffix = (float)(total - P[c]);                         // sum_{i>s} G_i w_i
+                const float dm = -G[c] * T[c] + suffix / (m[c] + 1e-10f);
+                const float ds = dm * (-delta[c] * m[c]) * density_act_grad(x[c], a.act);
+                a.d_sigma[(n * S + s) * a.d_sigma_stride + a.d_sigma_off] = ds;
+            }
+        }
+    }
+}
+
+// maxBlurFilter backward (mip_methods.py:61-66): torch.maximum sends the gradient to the larger argument, half to each on a tie
+__global__ void max_blur_backward_kernel(const float* __restrict__ w, const float* __restrict__ g, int64_t N, int S, float* __restrict__ dw) {
+    const int64_t total = N * S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i % S);
+        const float c = w[i];
+        float acc = 0.0f;
+        if (s == 0) acc += 0.5f * g[i];
+        if (s == S - 1) acc += 0.5f * g[i];
+        if (s + 1 < S) {                                    // mx_s = max(w_s, w_{s+1}) feeds rear_s and front_{s+1}
+            const float o = w[i + 1];
+            const float share = c > o ? 1.0f : (c == o ? 0.5f : 0.0f);
+            acc += share * (0.5f * g[i] + 0.5f * g[i + 1]);
+        }
+        if (s >= 1) {                                       // mx_{s-1} = max(w_{s-1}, w_s) feeds rear_{s-1} and front_s
+            const float o = w[i - 1];
+            const float share = c > o ? 1.0f : (c == o ? 0.5f : 0.0f);
+            acc += share * (0.5f * g[i - 1] + 0.5f * g[i]);
+        }
+        dw[i] = acc;
+    }
+}
+
+// getBounds backward (addtional.py:14-18): bounds_k = sum_{j = below_k .. below_{k+1}} w_j  ->  dw = running sum of a
+// difference array built with LDS atomics
+__global__ __launch_bounds__(256) void get_bounds_backward_kernel(const int64_t* __restrict__ below, const float* __restrict__ g, int64_t N, int C,
+                                                                  int K, float* __restrict__ dw) {
+    float* diff = reinterpret_cast<float*>(smem) + wave_in_block() * (C + 2);
+    const int lane = lane_id();
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        for (int j = lane; j < C + 2; j += 64) diff[j] = 0.0f;
+        lds_wave_sync();
+        const int64_t* bl = below + n * K;
+        for (int k = lane; k < K - 1; k += 64) {
+            const float gk = g[n * (K - 1) + k];
+            int st = (int)bl[k], en = (int)bl[k + 1] + 1;
+            st = st < 0 ? 0 : (st > C ? C : st); en = en < 0 ? 0 : (en > C ? C : en);
+            atomicAdd(&diff[st], gk);                       // sat[en] - sat[st]: +g on [st, en)  (negative when en < st, like the reference)
+            atomicAdd(&diff[en], -gk);
+        }
+        lds_wave_sync();
+        double carry = 0.0;
+        for (int base = 0; base < C; base += 64) {
+            const int j = base + lane;
+            const double incl = wave_incl_scan_add(j < C ? (double)diff[j] : 0.0);
+            if (j < C) dw[n * C + j] = (float)(carry + incl);
+            carry += __shfl(incl, 63, 64);
+        }
+    }
+}
+
 int blocks_for(int64_t work, int per_block) {
     int64_t b = (work + per_block - 1) / per_block;
     const int64_t cap = 256 * 8;
@@ -587,5 +727,30 @@ int sk_get_bounds(const float* w, const int64_t* below, int64_t N, int C, int K,
     if (N == 0 || K < 2) return 0;
     const size_t lds = WAVES_PER_BLOCK * ((size_t)C + 1) * 4;
     hipLaunchKernelGGL(get_bounds_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, w, below, N, C, K, bounds);
+    return (int)hipGetLastError();
+}
+
+// ---- backward launchers ----
+int sk_weights_backward(const float* sigma, int sigma_stride, int sigma_off, const float* z, int z_stride, const float* dirs, int dirs_stride,
+                        int64_t N, int S, int mul_norm, int act, float sigma_shift, const float* rgbo, const float* d_rgb,
+                        const float* d_weights, const float* d_depth, int white_bkg, float near, float far, float* d_sigma,
+                        int d_sigma_stride, int d_sigma_off, float* d_rgbo, hipStream_t st) {
+    if (N * S == 0) return 0;
+    if (S > BWD_CHUNKS * 64) return (int)hipErrorInvalidValue;
+    WeightsBwdArgs a{sigma, sigma_stride, sigma_off, z, z_stride, dirs, dirs_stride, N, S, mul_norm, act, sigma_shift, rgbo, d_rgb, d_weights,
+                     d_depth, white_bkg, near, far, d_sigma, d_sigma_stride, d_sigma_off, d_rgbo};
+    hipLaunchKernelGGL(weights_backward_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int sk_max_blur_backward(const float* w, const float* g, int64_t N, int S, float* dw, hipStream_t st) {
+    if (N * S == 0) return 0;
+    hipLaunchKernelGGL(max_blur_backward_kernel, dim3(blocks_for(N * S, 256)), dim3(256), 0, st, w, g, N, S, dw);
+    return (int)hipGetLastError();
+}
+int sk_get_bounds_backward(const int64_t* below, const float* g, int64_t N, int C, int K, float* dw, hipStream_t st) {
+    if (N == 0) return 0;
+    if (K < 2) { return (int)hipMemsetAsync(dw, 0, (size_t)N * C * 4, st); }
+    const size_t lds = WAVES_PER_BLOCK * ((size_t)C + 2) * 4;
+    hipLaunchKernelGGL(get_bounds_backward_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, below, g, N, C, K, dw);
     return (int)hipGetLastError();
 }

@@ -82,8 +82,9 @@ class NeRF(nn.Module):
         if pre is not None:
             opacity = pre(opacity)
         if ab.needs_grad(opacity, depth):
-            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, code), lambda s, z: ab.weights_expr(s, z, code),
-                                  0, opacity, depth)
+            expr = ab.with_hip_backward(lambda s, z: ab.weights_expr(s, z, code), lambda g, s, z: (
+                (ops.sigma_to_weights_backward(s, z, None, code, g), None) if s.shape[-1] <= ops.BWD_MAX_SAMPLES else None))
+            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, code), expr, 0, opacity, depth)
         return ops.sigma_to_weights(opacity, depth, None, code)
 
     @staticmethod
@@ -106,6 +107,9 @@ class NeRF(nn.Module):
                 w_ = ab.weights_expr(r[..., 3], zz, code)
                 c = torch.sum(w_[:, :, None] * r[..., :3], dim=-2)
                 return c + (1.0 - torch.sum(w_, -1)[..., None]) if white_bkg else c
+            ab.with_hip_backward(expr, lambda g, r, z, dd: (
+                (ops.composite_backward(r, z, dd, mul_norm == True, bool(white_bkg), code, None, g, None, None), None, None)
+                if r.shape[1] <= ops.BWD_MAX_SAMPLES else None))
             rgb, w = ab.HipOp.apply(hip, expr, 1, rgbo, depth, ray_dirs)
             extras = dict()
             if render_depth is not None or normal_info is not None:

@@ -314,3 +314,58 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
                                    _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(rgb), _ptr(depth),
                                    _ptr(w), _ptr(workspace), _stream()), "nerf_amd_render_rays")
     return rgb, depth, w, workspace
+
+
+# ------------------------------------------------------------------------------------------------ backward
+BWD_MAX_SAMPLES = 256          # the backward kernels keep a ray in four 64-lane register chunks
+
+
+def sigma_to_weights_backward(sigma: torch.Tensor, z: torch.Tensor, dirs: Optional[torch.Tensor], act: int, d_weights: torch.Tensor) -> torch.Tensor:
+    sigma, z, d_weights = _dev(sigma, "density"), _dev(z, "zvals"), _dev(d_weights, "d_weights")
+    dirs = _dev(dirs, "ray_dirs") if dirs is not None else None
+    N, S = sigma.shape
+    out = torch.empty_like(sigma)
+    check(lib.nerf_amd_sigma_to_weights_backward(_ptr(sigma), _ptr(z), _ptr(dirs), N, S, act, _ptr(d_weights), _ptr(out), _stream()),
+          "nerf_amd_sigma_to_weights_backward")
+    return out
+
+
+def composite_backward(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm: bool, white_bkg: bool, act: int, near_far,
+                       d_rgb: Optional[torch.Tensor], d_weights: Optional[torch.Tensor], d_depth: Optional[torch.Tensor],
+                       sigma_shift: float = 0.0) -> torch.Tensor:
+    rgbo, z = _dev(rgbo, "rgbo"), _dev(z, "depth")
+    N, S = rgbo.shape[0], rgbo.shape[1]
+    if dirs.shape[-1] == 6:
+        dirs = _dev(dirs, "rays")
+        dirs_ptr, dirs_stride = C.c_void_p(dirs.data_ptr() + 12), 6
+    else:
+        dirs = _dev(dirs, "ray_dirs")
+        dirs_ptr, dirs_stride = _ptr(dirs), 3
+    d_rgb = _dev(d_rgb, "d_rgb") if d_rgb is not None else torch.zeros((N, 3), dtype=torch.float32, device=rgbo.device)
+    d_weights = _dev(d_weights, "d_weights") if d_weights is not None else None
+    d_depth = _dev(d_depth, "d_depth") if d_depth is not None else None
+    near, far = (near_far if near_far is not None else (0.0, 1.0))
+    out = torch.empty_like(rgbo)
+    flags = (1 if mul_norm else 0) | (2 if white_bkg else 0)
+    check(lib.nerf_amd_composite_backward(_ptr(rgbo), _ptr(z), z.shape[-1], dirs_ptr, dirs_stride, N, S, flags, act, float(sigma_shift),
+                                          float(near), float(far), _ptr(d_rgb), _ptr(d_weights), _ptr(d_depth), _ptr(out), _stream()),
+          "nerf_amd_composite_backward")
+    return out
+
+
+def max_blur_backward(weights: torch.Tensor, d_out: torch.Tensor) -> torch.Tensor:
+    weights, d_out = _dev(weights, "weights"), _dev(d_out, "d_out")
+    S = weights.shape[-1]
+    out = torch.empty_like(weights)
+    check(lib.nerf_amd_max_blur_backward(_ptr(weights), _ptr(d_out), weights.numel() // S, S, _ptr(out), _stream()), "nerf_amd_max_blur_backward")
+    return out
+
+
+def get_bounds_backward(below: torch.Tensor, d_bounds: torch.Tensor, n_coarse: int) -> torch.Tensor:
+    d_bounds = _dev(d_bounds, "d_bounds")
+    below = below.to(torch.int64).contiguous()
+    N, K = below.shape
+    out = torch.empty((N, n_coarse), dtype=torch.float32, device=d_bounds.device)
+    check(lib.nerf_amd_get_bounds_backward(_ptr(below), _ptr(d_bounds), N, n_coarse, K, _ptr(out), _stream()), "nerf_amd_get_bounds_backward")
+    return out
+
