@@ -246,6 +246,7 @@ def main():
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("%s_%s" % (a.model, a.precision))
         peak = PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA
+        executed_flops = n_rays * ((N_FINE + C_COARSE) * 2 * 2128 * 512 if is_ref else N_FINE * 2 * 928 * 512)   # mlp_layout.h N_FRAGS
         achieved = fine_flops / (fine_ms * 1e-3)
         rec = {
             "metric": "rays/s (64+128 samples), 800x800" if not is_ref else "rays/s (64+192 samples, Ref-NeRF), 800x800", "value": world * a.steps * n_rays / dt, "unit": "rays/s",
@@ -259,7 +260,9 @@ def main():
                        if prec == ops.BF16 else "fp32 MFMA", "parallelism": "ray-sharded replicas (dp%d)" % world},
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": traffic},
+                         "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": traffic,
+                         # MFMA work actually issued (512 MAC per 32x16 fragment and sample; padded K, bottle_neck folded away)
+                         "executed_tflops": executed_flops / (fine_ms * 1e-3) / 1e12, "executed_frac": executed_flops / (fine_ms * 1e-3) / peak},
             "whole_path_tflops": world * a.steps * n_rays * flop_per_ray / dt / 1e12,
         }
         if world == 1 and not a.no_gemm_ref and prec == ops.BF16:
