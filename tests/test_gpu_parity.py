@@ -648,3 +648,34 @@ def test_blur_and_bounds_backward_vs_autograd(A):
     unsorted = torch.randint(0, 62, (53, 129), generator=gen).cuda()               # the reference never sorts `below` itself
     want, = _vjp(lambda x: ab.bounds_expr(x, unsorted), gb, w)
     assert max_abs(A.ops.get_bounds_backward(unsorted, gb, 64).cpu(), want.cpu()) <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_integration_md_ctypes_stub_runs(A):
+    """The ctypes stub printed in INTEGRATION.md (section B) is executed as is against the built library and must agree with
+    the package's own bindings -- the document cannot drift from the C-ABI."""
+    import re
+    from nerf_amd._lib import LIB_PATH
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "ctypes stub" in b][0]
+    ns = {}
+    exec(block.replace('C.CDLL("libnerf_amd.so")', "C.CDLL(%r)" % LIB_PATH), ns)
+    gen = torch.Generator().manual_seed(21)
+    N, S = 19, 64
+    rgbo = torch.cat((torch.rand(N, S, 3, generator=gen), torch.randn(N, S, 1, generator=gen)), -1).cuda()
+    z = torch.sort(torch.rand(N, S, generator=gen) * 4 + 2, dim=-1)[0].cuda()
+    d = torch.randn(N, 3, generator=gen).cuda()
+    rgb, w, extras = ns["render"](rgbo, z, d, True, True, (2.0, 6.0))
+    rgb2, w2, dep2, _ = A.ops.composite(rgbo, z, d, True, True, A.ops.ACT_RELU, (2.0, 6.0))
+    assert torch.equal(rgb, rgb2) and torch.equal(w, w2) and torch.equal(extras["depth_img"], dep2)
+    g = torch.randn(N, 3, generator=gen).cuda()
+    assert torch.equal(ns["render_backward"](rgbo, z, d, g, True, True), A.ops.composite_backward(rgbo, z, d, True, True, A.ops.ACT_RELU, None, g, None, None))
+    wts, u = torch.rand(N, S, generator=gen).cuda(), torch.rand(N, 33, generator=gen).cuda()
+    zs, below = ns["inverse_sample"](wts, z, u, True)
+    zs2, below2 = A.ops.inverse_sample(wts, z, u, True)
+    assert torch.equal(zs, zs2) and torch.equal(below, below2)
+    _, mip = build_nets(A, "small")
+    pts = torch.randn(5, 40, 6, generator=gen).cuda()
+    blob = ns["pack_mip"](mip, A.ops.F32)
+    with torch.no_grad():
+        A.pkg.set_precision("fp32")
+        assert torch.equal(ns["mip_forward"](blob, A.ops.F32, pts), mip.forward(pts))
