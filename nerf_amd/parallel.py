@@ -30,6 +30,8 @@ def shard_range(n_items: int, rank: int, world: int, align: int = 1) -> Tuple[in
 def gather_shards(local: torch.Tensor, n_items: int, align: int = 1, group=None) -> torch.Tensor:
     """all_gather of ragged per-rank slices (dim 0) back into the full (n_items, ...) tensor on every rank."""
     world = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":        # gloo has no device all_gather: stage through the host
+        return gather_shards(local.cpu(), n_items, align, group).to(local.device)
     sizes = [shard_range(n_items, r, world, align) for r in range(world)]
     longest = max(e - s for s, e in sizes)
     pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
