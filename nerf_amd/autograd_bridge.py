@@ -16,11 +16,10 @@ from . import ops
 
 
 def _pe(x: torch.Tensor, L: int) -> torch.Tensor:
-    out = []
-    for f in range(L):
-        a = (2.0 ** f) * x
-        out += [torch.sin(a), torch.cos(a)]
-    return torch.cat(out, dim=-1)
+    """[sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (nerf_helper.py:38-48) in five device ops instead of 4L + 1."""
+    freq = torch.pow(2.0, torch.arange(L, dtype=x.dtype, device=x.device))
+    a = x.unsqueeze(-2) * freq[:, None]                              # (..., L, 3)
+    return torch.stack((torch.sin(a), torch.cos(a)), dim=-2).reshape(x.shape[:-1] + (6 * L,))
 
 
 def proposal_expr(pts, w, b):
@@ -111,27 +110,28 @@ class HipOp(torch.autograd.Function):
                 grads = hip_bwd(grad.contiguous(), *full)
             if grads is not None:                                   # None = "not supported for these sizes": fall through to the VJP
                 return (None, None, None, *grads)
-        args, leaves = [], []
-        for is_t in ctx.is_tensor:
+        # only the inputs autograd actually asks for become leaves: e.g. the sample positions of MipNeRF carry no gradient, which
+        # spares the VJP the first layer's dgrad and the whole sin/cos backward
+        args, leaves, wanted = [], [], []
+        for k, is_t in enumerate(ctx.is_tensor):
             if is_t:
                 t = saved.pop(0)
-                if t.is_floating_point():
+                want = t.is_floating_point() and ctx.needs_input_grad[3 + k]
+                if want:
                     t = t.detach().requires_grad_(True)
                     leaves.append(t)
+                wanted.append(want)
                 args.append(t)
             else:
+                wanted.append(False)
                 args.append(consts.pop(0))
+        if not leaves:
+            return (None, None, None, *[None] * len(args))
         with torch.enable_grad():
             y = ctx.expr_fn(*args)
-        need = [i for i, l in enumerate(leaves)]
         grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
-        out, gi = [], iter(grads)
-        for is_t, a in zip(ctx.is_tensor, args):
-            if is_t and a.is_floating_point():
-                out.append(next(gi))
-            else:
-                out.append(None)
-        return (None, None, None, *out)
+        gi = iter(grads)
+        return (None, None, None, *[next(gi) if w else None for w in wanted])
 
 
 def needs_grad(*tensors) -> bool:
