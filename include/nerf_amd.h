@@ -182,6 +182,23 @@ int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const fl
 int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training forward of the MLPs: same kernels and results as nerf_amd_{proposal,mip}_forward, and in
+ * addition every hidden layer's post-ReLU activations are written to `dump` (nerf_amd_train_dump_bytes bytes, device) in the
+ * kernels' fragment order.  nerf_amd_train_dump_to_rows turns one layer of a dump into a row-major (M, n_features) matrix
+ * (bf16 for NERF_AMD_BF16, fp32 for NERF_AMD_F32) for the dgrad / wgrad GEMMs.
+ * Layers: proposal 0..3 = layers.{0,2,4,6} outputs (256 wide); MipNeRF 0..3 = lin_block1.{0,2,4,6}, 4..6 = lin_block2.{0,2,4}
+ * (256 wide), 7 = rgb_layer.0 output (128 wide).
+ * ------------------------------------------------------------------------------------------------ */
+size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M);
+int nerf_amd_proposal_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* dump,
+                                    void* stream);
+int nerf_amd_mip_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* dump, void* stream);
+int nerf_amd_train_dump_to_rows(const void* dump, int net, int precision, int64_t M, int layer, int n_features, void* out,
+                                void* stream);
+/* ReLU adjoint of the dgrad chain, in place: delta[i] = act[i] > 0 ? delta[i] : 0 over n elements (bf16 / fp32 as above). */
+int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).
  * One wavefront per ray; S <= 256.  Depths and directions are not differentiated (the reference detaches them too).
  * ------------------------------------------------------------------------------------------------ */

@@ -92,9 +92,24 @@ class ProposalNetwork(nn.Module, PackedWeightsMixin):
         layers = self._linear_layers()
         params = [l.weight for l in layers] + [l.bias for l in layers]
         if ab.needs_grad(pts, *params):
-            hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p)
             expr = lambda p, *wb: ab.proposal_expr(p, wb[:5], wb[5:])
-            return ab.HipOp.apply(hip, expr, 0, pts, *params)
+            if pts.requires_grad or pts.numel() == 0:                      # (gradients w.r.t. positions: torch VJP of the expression)
+                hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p)
+                return ab.HipOp.apply(hip, expr, 0, pts, *params)
+            # parameter gradients: the training forward dumps the hidden activations, the backward is a GEMM chain on them
+            from . import mlp_backward
+            held = {}
+
+            def hip(p, *wb):
+                out, held["dump"] = ops.proposal_forward_train(self.packed(prec), prec, p)
+                return out
+
+            def bwd(g, p, *wb):
+                if "dump" not in held:
+                    raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
+                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5])
+                return (None, *gW, *gb)
+            return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts)
 
     @staticmethod

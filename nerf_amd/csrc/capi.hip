@@ -11,6 +11,11 @@ int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipSt
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
 int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, hipStream_t);
+size_t mlp_train_layer_stride(int, int64_t);
+int mlp_launch_proposal_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
+int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
+int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t);
+int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
@@ -222,6 +227,41 @@ int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, in
     if (N < 0 || C < 1 || C > 4096 || K < 2) return fail(NERF_AMD_EINVAL, "bad size");
     if (N && (!w_prop || !below || !bounds)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_get_bounds(w_prop, below, N, C, K, bounds, S(stream)), "nerf_amd_get_bounds");
+}
+
+// ---- training forward: the MLP kernels also dump their hidden activations ----
+static int train_layers(int net) { return net == NERF_AMD_NET_PROPOSAL ? 4 : (net == NERF_AMD_NET_MIP ? 8 : 0); }
+size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M) {
+    if (M < 0 || !train_layers(net) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return 0;
+    return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M);
+}
+int nerf_amd_proposal_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* dump, void* stream) {
+    if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
+    if (src->M && !density) return fail(NERF_AMD_EINVAL, "NULL output");
+    return hip_status(mlp_launch_proposal_train(packed, precision, *src, density, dump, S(stream)), "nerf_amd_proposal_forward_train");
+}
+int nerf_amd_mip_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* dump, void* stream) {
+    if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
+    if (src->M && !rgbo) return fail(NERF_AMD_EINVAL, "NULL output");
+    return hip_status(mlp_launch_mip_train(packed, precision, *src, rgbo, dump, S(stream)), "nerf_amd_mip_forward_train");
+}
+int nerf_amd_train_dump_to_rows(const void* dump, int net, int precision, int64_t M, int layer, int n_features, void* out, void* stream) {
+    if (M < 0 || layer < 0 || layer >= train_layers(net) || n_features < 16 || n_features > 256 || (n_features & 15))
+        return fail(NERF_AMD_EINVAL, "bad layer or feature count");
+    if (M && (!dump || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    const size_t stride = mlp_train_layer_stride(precision, M);
+    const int elem = precision == NERF_AMD_BF16 ? 2 : 4;
+    const int64_t n_sub = (int64_t)(stride / (16 * (size_t)512 * elem));
+    return hip_status(sk_frag_to_rows(reinterpret_cast<const char*>(dump) + (size_t)layer * stride, elem, n_sub, n_features / 16, M, out, S(stream)),
+                      "nerf_amd_train_dump_to_rows");
+}
+
+int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, void* stream) {
+    if (n < 0 || (precision == NERF_AMD_BF16 && (n & 1))) return fail(NERF_AMD_EINVAL, "bad element count (bf16: even)");
+    if (n && (!delta || !act)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_relu_mask(delta, act, precision == NERF_AMD_BF16 ? 2 : 4, n, S(stream)), "nerf_amd_relu_mask");
 }
 
 // ---- backward of the sampling / compositing rows ----

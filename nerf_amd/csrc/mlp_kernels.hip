@@ -86,6 +86,8 @@ struct PBF16 {
     static constexpr int BREG_LDS = 1024;
     static DEVINL void stash(uint32_t addr, const BReg& r) { *reinterpret_cast<bf16x8*>(smem + addr) = r; }
     static DEVINL BReg unstash(uint32_t addr) { return *reinterpret_cast<const bf16x8*>(smem + addr); }
+    // training dump: one B register group of a subtile = a 64 x BREG_LDS/64-byte block in fragment order (lane-linear, coalesced)
+    static DEVINL void store_global(char* block, int lane, const BReg& r) { *reinterpret_cast<bf16x8*>(block + lane * 16) = r; }
 };
 
 // bf16, wide tile: 4 wavefronts x 64 samples.  Every A fragment read from LDS feeds TWO MFMAs (one per 32-sample column
@@ -140,12 +142,19 @@ struct PF32 {
         BReg r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return r;
     }
+    static DEVINL void store_global(char* block, int lane, const BReg& r) {
+        f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
+        *reinterpret_cast<f32x4*>(block + lane * 16) = lo;
+        *reinterpret_cast<f32x4*>(block + 1024 + lane * 16) = hi;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
 // weight stream: L2 -> LDS ring, consumed in lock step by all wavefronts of the workgroup
 // ------------------------------------------------------------------------------------------------
-template <class P, int NSLOT = MLP_NSLOT>
+// SAFE (training kernels): they also issue activation stores; loads and stores may complete out of order with respect to each
+// other, so a counted vmcnt no longer identifies the ring pieces -- wait for everything (vmcnt(0)) at every barrier instead.
+template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false>
 struct WeightStream {
     static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk
     const char* src;        // packed stream + this lane's offset inside a chunk
@@ -196,7 +205,7 @@ struct WeightStream {
     //     wait, and NSLOT-4 chunks may stay in flight: issued before the wait at boundary 2b are chunks <= 2b+NSLOT-3, needed
     //     complete are chunks <= 2b+1 (read until barrier b+1).
     static constexpr bool TWO_GROUPS = P::NW > 4;
-    static constexpr int INFLIGHT = (TWO_GROUPS ? NSLOT - 5 : NSLOT - 4) * LPW;
+    static constexpr int INFLIGHT = SAFE ? 0 : (TWO_GROUPS ? NSLOT - 5 : NSLOT - 4) * LPW;
     uint32_t late;
 
     DEVINL void init(const void* packed, uint32_t nchunks) {
@@ -247,7 +256,7 @@ struct WeightStream {
     }
     template <int PARITY>
     DEVINL void boundary() {
-        if constexpr (!TWO_GROUPS && PARITY != 0) {      // single group, odd boundary: nothing to wait for, no barrier
+        if constexpr (!TWO_GROUPS && PARITY != 0 && !SAFE) { // single group, odd boundary: nothing to wait for, no barrier
             issue();
             return;
         }
@@ -524,17 +533,30 @@ DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias, uin
     __syncthreads();
 }
 
+// Training forward: the TRAIN instantiations also write every hidden layer's post-ReLU activations to
+// HBM, in FRAGMENT order -- block (layer, subtile, K group) = the 64 lanes' B register group, 1 KiB (bf16) / 2 KiB (fp32), i.e.
+// one fully coalesced 16-byte store per lane and register group.  The backward reads them back as row-major matrices through
+// frag_to_rows_kernel.  Layer slots are `layer_stride` bytes apart, every slot holds 16 K groups per subtile.
+struct ActDump {
+    char* base;
+    unsigned long long layer_stride;
+};
+template <class P>
+DEVINL void dump_breg(const ActDump& d, int layer, int64_t subtile, int kg, int lane, const typename P::BReg& r) {
+    P::store_global(d.base + (size_t)layer * d.layer_stride + ((size_t)subtile * 16 + kg) * (size_t)P::BREG_LDS, lane, r);
+}
+
 // ================================================================================================
 // ProposalNetwork
 // ================================================================================================
-template <class P>
+template <class P, bool TRAIN>
 __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __restrict__ packed, nerf_amd_samples s,
-                                                              float* __restrict__ density) {
+                                                              float* __restrict__ density, ActDump dump) {
     using L = PropLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P> ws;
+    WeightStream<P, MLP_NSLOT, TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
@@ -553,8 +575,18 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
         }
         BReg a[NT][16], b[NT][16];
-        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
-        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        // (layer indices for the training dump: `lay` = the layer whose block pairs are being computed, `lay_pend` = the layer
+        // that owns the deferred pair -- the deferred slices run while the NEXT layer is computed)
+        int lay = 0, lay_pend = 0;
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
+            buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+        };
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay, fb, t, acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay, fb, t, acc, half); };
+        auto OA_pend = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay_pend, fb, t, acc, half); };
+        auto OB_pend = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay_pend, fb, t, acc, half); };
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
         // into `a` during the first K steps of whatever runs next
@@ -566,12 +598,17 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + r * 512) * 4, IN_A, OB, prev_of(d, OA));
-            if (r == 0) d = dense<P, 16, 8, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB));
+            lay_pend = lay; lay = 1 + 2 * r;
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + r * 512) * 4, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                lay_pend = lay; lay = 2;
+                d = dense<P, 16, 8, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB_pend));
+            }
         }
+        lay_pend = lay;
         float dens[NT];
         auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
-        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB)).flush(OH);
+        dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB_pend)).flush(OH);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
@@ -593,9 +630,9 @@ struct FusedComposite {
     float near, far;
 };
 
-template <class P>
+template <class P, bool TRAIN>
 __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict__ packed, nerf_amd_samples s,
-                                                         float* __restrict__ rgbo, FusedComposite fc) {
+                                                         float* __restrict__ rgbo, FusedComposite fc, ActDump dump) {
     using L = MipLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
@@ -604,7 +641,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #endif
     if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 24)[threadIdx.x] = 0u;   // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P> ws;
+    WeightStream<P, MLP_NSLOT, TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
@@ -621,8 +658,16 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg a[NT][16], b[NT][16];
-        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
-        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        int lay = 0, lay_pend = 0;                                  // training dump: see proposal_kernel
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
+            buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+        };
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay, fb, t, acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay, fb, t, acc, half); };
+        auto OA_pend = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay_pend, fb, t, acc, half); };
+        auto OB_pend = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay_pend, fb, t, acc, half); };
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
         // into `a` during the first K steps of whatever runs next
@@ -667,19 +712,22 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
 #pragma unroll 1
         for (int r = 0; r < 3; ++r) {
-            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (1 + 2 * r) * 256 * 4, IN_A, OB, prev_of(d, OA));
+            lay_pend = lay; lay = 1 + 2 * r;
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (1 + 2 * r) * 256 * 4, IN_A, OB, prev_of(d, OA_pend));
+            lay_pend = lay; lay = 2 + 2 * r;
             if (r == 1) {
                 d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
                     [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(enc_lds(t) + kg * P::BREG_LDS); return b[t][kg >= 4 ? kg - 4 : 0]; },
-                    OA, prev_of(d, OB));
+                    OA, prev_of(d, OB_pend));
             } else {
-                d = dense<P, 16, 8, L::START[2]>(ws, bias0 + (2 + 2 * r) * 256 * 4, IN_B, OA, prev_of(d, OB));
+                d = dense<P, 16, 8, L::START[2]>(ws, bias0 + (2 + 2 * r) * 256 * 4, IN_B, OA, prev_of(d, OB_pend));
             }
         }
+        lay_pend = lay;
         // opacity_head.0 : 256 -> 1 (raw sigma)
         float sigma[NT];
         auto OSIG = [&](int, int t, const f32x16& acc, int half) { if (half == 0) sigma[t] = acc[0]; };
-        const auto dsig = dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4, IN_A, OSIG, prev_of(d, OA));
+        const auto dsig = dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4, IN_A, OSIG, prev_of(d, OA_pend));
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
         BReg denc[NT][2];
 #pragma unroll
@@ -690,7 +738,10 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         }
         // rgb_layer.0 with bottle_neck.0 folded in (mlp_layout.h): cat(g 256, dir 27) -> 128, ReLU
         BReg c[NT][8];
-        auto OC = [&](int fb, int t, const f32x16& acc, int half) { c[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OC = [&](int fb, int t, const f32x16& acc, int half) {
+            c[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) dump_breg<P>(dump, 7, sub0 + t, 2 * fb + half, lane, c[t][2 * fb + half]);     // slot 7: rgb_layer.0 output
+        };
         const auto dc = dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
             [&](int kg, int t) -> BReg { if (kg < 16) return a[t][kg < 16 ? kg : 0]; return denc[t][kg >= 16 ? kg - 16 : 0]; },
             OC, prev_of(dsig, OSIG));
@@ -986,6 +1037,7 @@ int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, 
     hipLaunchKernelGGL(kernel, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, out, extra...);
     return (int)hipGetLastError();
 }
+const ActDump NO_DUMP{nullptr, 0ull};
 
 // bf16 policy of the shipped library: the wide tile (measured 2.5 % faster end to end);
 // -DMLP_BF16_NARROW selects the 8-wave x 32-sample tile for A/B runs
@@ -999,20 +1051,37 @@ using PB16 = PBF16W;
 
 // host-visible launchers (capi.hip)
 int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16>, packed, s, density, st);
-    return launch<PF32, PropLayout>(proposal_kernel<PF32>, packed, s, density, st);
+    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16, false>, packed, s, density, st, NO_DUMP);
+    return launch<PF32, PropLayout>(proposal_kernel<PF32, false>, packed, s, density, st, NO_DUMP);
 }
 int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
-    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16>, packed, s, rgbo, st, off);
-    return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, rgbo, st, off);
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, rgbo, st, off, NO_DUMP);
+    return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, rgbo, st, off, NO_DUMP);
 }
 // fine MLP + compositing in one launch; requires mode 1 (rays + z) and S in {32, 64, 128}
 int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_samples& s, float* rgb, float* depth, float* weights,
                              int white_bkg, float near, float far, hipStream_t st) {
     const FusedComposite fc{rgb, depth, weights, white_bkg, near, far};
-    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16>, packed, s, (float*)nullptr, st, fc);
-    return launch<PF32, MipLayout>(mip_kernel<PF32>, packed, s, (float*)nullptr, st, fc);
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
+    return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
+}
+// training forwards: the same kernels, also dumping the hidden activations (ActDump) for the backward
+size_t mlp_train_layer_stride(int precision, int64_t M) {
+    const int64_t ts = (precision == NERF_AMD_BF16) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;
+    const int64_t n_sub = ((M + ts - 1) / ts) * (ts / 32);
+    return (size_t)n_sub * 16 * (precision == NERF_AMD_BF16 ? 1024 : 2048);
+}
+int mlp_launch_proposal_train(const void* packed, int precision, const nerf_amd_samples& s, float* density, void* dump, hipStream_t st) {
+    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M)};
+    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16, true>, packed, s, density, st, d);
+    return launch<PF32, PropLayout>(proposal_kernel<PF32, true>, packed, s, density, st, d);
+}
+int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, void* dump, hipStream_t st) {
+    const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
+    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M)};
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, true>, packed, s, rgbo, st, off, d);
+    return launch<PF32, MipLayout>(mip_kernel<PF32, true>, packed, s, rgbo, st, off, d);
 }
 
 template <class P>

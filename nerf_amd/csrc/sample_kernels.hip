@@ -645,6 +645,50 @@ __global__ __launch_bounds__(256) void get_bounds_backward_kernel(const int64_t*
     }
 }
 
+// Training dump (mlp_kernels.hip ActDump) -> row-major activations.  Block (subtile, K group) of the dump holds, for lane
+// (h = lane >> 5, j = lane & 31), the 8 features 16 kg + 8 (e >> 2) + 4 h + (e & 3), e = 0..7, of sample 32 subtile + j
+// (mlp_layout.h dmap_feature): two runs of four consecutive features.  ELEM = 2 (bf16) or 4 (fp32, halves 1 KiB apart).
+template <int ELEM>
+__global__ __launch_bounds__(256) void frag_to_rows_kernel(const char* __restrict__ frag, int64_t n_sub, int n_kg, int64_t M,
+                                                           char* __restrict__ out, int ld) {
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    constexpr int BLOCK = 512 * ELEM;                           // bytes per (subtile, K group)
+    for (int64_t sub = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); sub < n_sub; sub += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t row = sub * 32 + j;
+        if (row >= M) continue;
+        char* orow = out + (size_t)row * ld * ELEM;
+        for (int kg = 0; kg < n_kg; ++kg) {
+            const char* blk = frag + ((size_t)sub * 16 + kg) * BLOCK;
+            if constexpr (ELEM == 2) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(blk + lane * 16);          // 8 bf16
+                f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                *reinterpret_cast<f32x2*>(orow + (16 * kg + 4 * h) * 2) = lo;
+                *reinterpret_cast<f32x2*>(orow + (16 * kg + 8 + 4 * h) * 2) = hi;
+            } else {
+                *reinterpret_cast<f32x4*>(orow + (16 * kg + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + lane * 16);
+                *reinterpret_cast<f32x4*>(orow + (16 * kg + 8 + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + 1024 + lane * 16);
+            }
+        }
+    }
+}
+
+// delta[i] = act[i] > 0 ? delta[i] : 0 -- the ReLU adjoint of the dgrad chain, in place (ELEM = 2: bf16 pairs, 4: fp32)
+template <int ELEM>
+__global__ void relu_mask_kernel(uint32_t* __restrict__ delta, const uint32_t* __restrict__ act, int64_t n_words) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = act[i];
+        uint32_t d = delta[i];
+        if constexpr (ELEM == 4) {
+            if (!(__builtin_bit_cast(float, a) > 0.0f)) d = 0u;
+        } else {                                             // two bf16: positive <=> sign bit clear and not (+)zero
+            const uint32_t lo = a & 0xFFFFu, hi = a >> 16;
+            if (!(lo != 0u && lo < 0x8000u)) d &= 0xFFFF0000u;
+            if (!(hi != 0u && hi < 0x8000u)) d &= 0x0000FFFFu;
+        }
+        delta[i] = d;
+    }
+}
+
 int blocks_for(int64_t work, int per_block) {
     int64_t b = (work + per_block - 1) / per_block;
     const int64_t cap = 256 * 8;
@@ -754,3 +798,19 @@ int sk_get_bounds_backward(const int64_t* below, const float* g, int64_t N, int 
     hipLaunchKernelGGL(get_bounds_backward_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, below, g, N, C, K, dw);
     return (int)hipGetLastError();
 }
+int sk_frag_to_rows(const void* frag, int elem_bytes, int64_t n_sub, int n_kg, int64_t M, void* out, hipStream_t st) {
+    if (n_sub == 0 || M == 0) return 0;
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(frag_to_rows_kernel<2>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), 0, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
+    else
+        hipLaunchKernelGGL(frag_to_rows_kernel<4>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), 0, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
+    return (int)hipGetLastError();
+}
+int sk_relu_mask(void* delta, const void* act, int elem_bytes, int64_t n, hipStream_t st) {
+    if (n == 0) return 0;
+    const int64_t words = elem_bytes == 2 ? n / 2 : n;
+    if (elem_bytes == 2) hipLaunchKernelGGL(relu_mask_kernel<2>, dim3(blocks_for(words, 256)), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, words);
+    else hipLaunchKernelGGL(relu_mask_kernel<4>, dim3(blocks_for(words, 256)), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, words);
+    return (int)hipGetLastError();
+}
+

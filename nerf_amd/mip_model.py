@@ -48,9 +48,26 @@ class MipNeRF(NeRF, PackedWeightsMixin):
         params = [l.weight for l in layers] + [l.bias for l in layers]
         if ab.needs_grad(pts, *params):
             n = len(layers)
-            hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p)
             expr = lambda p, *wb: ab.mip_expr(p, wb[:n], wb[n:])
-            return ab.HipOp.apply(hip, expr, 0, pts, *params)
+            if pts.requires_grad or pts.numel() == 0:                      # (gradients w.r.t. positions: torch VJP of the expression)
+                hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p)
+                return ab.HipOp.apply(hip, expr, 0, pts, *params)
+            # parameter gradients: the training forward dumps the hidden activations, the backward is a GEMM chain on them
+            from . import mlp_backward
+            held = {}
+
+            def hip(p, *wb):
+                out, held["dump"] = ops.mip_forward_train(self.packed(prec), prec, p)
+                held["out"] = out
+                return out
+
+            def bwd(g, p, *wb):
+                if "dump" not in held:
+                    raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
+                gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), p.reshape(-1, 6), held.pop("dump"), prec,
+                                                   wb[:n], wb[n:])
+                return (None, *gW, *gb)
+            return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.mip_forward(self.packed(prec), prec, pts)
 
     def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int) -> torch.Tensor:

@@ -1,0 +1,132 @@
+"""Backward of the two MLPs from the HIP training forward's activation dump.
+
+The forward kernels (nerf_amd_{proposal,mip}_forward_train) leave every hidden layer's post-ReLU activations in HBM; the
+gradient is then a chain of plain GEMMs -- dgrad `delta @ W`, wgrad `delta^T @ activation` -- which are library GEMMs
+(hipBLASLt through torch.matmul) in the kernels' own arithmetic (bf16 operands with fp32 accumulation, or fp32), plus ReLU masks
+taken from the stored activations.  Nothing of the forward is re-evaluated except the positional encodings (elementwise) and,
+for MipNeRF, the bottle-neck vector the folded forward kernel never materialises (one GEMM).
+
+Reference semantics: what torch.autograd computes for addtional.py:88-96 and mip_model.py:41-60.
+Tensor order of `weights` / returned gradients = the modules' `_linear_layers()` order (weights first, then biases).
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+
+def _pe(x: torch.Tensor, L: int) -> torch.Tensor:
+    freq = torch.pow(2.0, torch.arange(L, dtype=x.dtype, device=x.device))
+    a = x.unsqueeze(-2) * freq[:, None]
+    return torch.stack((torch.sin(a), torch.cos(a)), dim=-2).reshape(x.shape[:-1] + (6 * L,))
+
+
+_SPLIT = 4096        # rows per split-K slice of a wgrad GEMM
+
+
+def _pad16(t: torch.Tensor) -> torch.Tensor:
+    """(M, O < 16) -> (M, 16) with zero columns: the library has no efficient kernels for 1- or 3-wide operands."""
+    out = torch.zeros((t.shape[0], 16), dtype=t.dtype, device=t.device)
+    out[:, : t.shape[1]] = t
+    return out
+
+
+def _encode(x: torch.Tensor, L: int, dt) -> torch.Tensor:
+    """[x | PE_L(x)] zero-padded to a multiple of 8 columns (the library's bf16 kernels want aligned leading dimensions; odd ones
+    fall into a path with milliseconds of host-side search per call)."""
+    n = 3 + 6 * L
+    out = torch.zeros((x.shape[0], (n + 7) // 8 * 8), dtype=dt, device=x.device)
+    out[:, :3] = x
+    out[:, 3:n] = _pe(x, L)
+    return out
+
+
+def _wgrad(delta: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    """delta^T @ act with the sample dimension as K.  The library picks a 16-workgroup kernel for a (256 x M) @ (M x 256) product, so
+    K is split by hand: one batched GEMM over slices of _SPLIT rows, partial products summed in fp32 (also the better rounding)."""
+    M, O = delta.shape
+    n = M // _SPLIT
+    if n < 2:
+        return torch.mm(delta.t(), act).float()
+    if O < 16:                                            # the 1- and 3-wide head gradients: pad to a real GEMM shape
+        return _wgrad(_pad16(delta), act)[:O]
+    main = n * _SPLIT
+    out = torch.bmm(delta[:main].view(n, _SPLIT, -1).transpose(1, 2), act[:main].view(n, _SPLIT, -1)).sum(0, dtype=torch.float32)
+    if main < M:
+        out += torch.mm(delta[main:].t(), act[main:]).float()
+    return out
+
+
+def _masked(delta: torch.Tensor, act: torch.Tensor, precision: int) -> torch.Tensor:
+    return ops.relu_mask_(delta.contiguous(), act, precision)
+
+
+def _bgrad(delta: torch.Tensor) -> torch.Tensor:
+    return delta.sum(0, dtype=torch.float32)
+
+
+def proposal_backward(g_density: torch.Tensor, pts: torch.Tensor, dump: torch.Tensor, precision: int,
+                      weights: Sequence[torch.Tensor]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """g_density (M,), pts (M,3), weights = [layers.0, .2, .4, .6, .8].weight -> ([dW]*5, [db]*5)"""
+    M = pts.shape[0]
+    dt = torch.bfloat16 if precision == ops.BF16 else torch.float32
+    W = [w.detach().to(dt) for w in weights]
+    rows = lambda l: ops.train_dump_rows(dump, ops.NET_PROPOSAL, precision, M, l, 256)
+    gW, gb = [None] * 5, [None] * 5
+    g = g_density.reshape(M, 1).to(dt)
+    h = rows(3)
+    gW[4], gb[4] = _wgrad(g, h), g_density.sum().reshape(1)
+    delta = _masked(g * W[4], h, precision)
+    for l in (3, 2, 1):
+        prev = rows(l - 1)
+        gW[l], gb[l] = _wgrad(delta, prev), _bgrad(delta)
+        delta = _masked(torch.mm(delta, W[l]), prev, precision)
+    gW[0], gb[0] = _wgrad(delta, _encode(pts, 10, dt))[:, :63], _bgrad(delta)
+    return gW, gb
+
+
+def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, dump: torch.Tensor, precision: int,
+                 weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """g_rgbo, rgbo (M,4), pts (M,6); weights/biases in MipNeRF._linear_layers() order (lin_block1.{0,2,4,6}, lin_block2.{0,2,4},
+    bottle_neck.0, opacity_head.0, rgb_layer.{0,2}) -> ([dW]*11, [db]*11)"""
+    M = pts.shape[0]
+    dt = torch.bfloat16 if precision == ops.BF16 else torch.float32
+    W = [w.detach().to(dt) for w in weights]
+    rows = lambda l, n=256: ops.train_dump_rows(dump, ops.NET_MIP, precision, M, l, n)
+    gW, gb = [None] * 11, [None] * 11
+    x, d = pts[:, :3], pts[:, 3:6]
+    d = d / d.norm(dim=-1, keepdim=True)
+    ed = _encode(d, 4, dt)                                                          # (M, 27 -> 32)
+    # colour head: rgb = sigmoid(rgb_layer.2(c)), c = relu(rgb_layer.0(cat(bottle_neck(g6), ed)))
+    rgb = rgbo[:, :3]
+    d10 = (g_rgbo[:, :3] * rgb * (1.0 - rgb)).to(dt)
+    c = rows(7, 128)
+    gW[10], gb[10] = _wgrad(d10, c), _bgrad(d10)
+    w10 = torch.zeros((16, W[10].shape[1]), dtype=dt, device=W[10].device)
+    w10[:3] = W[10]
+    dc = _masked(torch.mm(_pad16(d10), w10), c, precision)
+    g6 = rows(6)
+    bott = torch.addmm(biases[7].detach().to(dt), g6, W[7].t())                   # the folded forward never forms it
+    gW[9], gb[9] = torch.cat((_wgrad(dc, bott), _wgrad(dc, ed)[:, :27]), dim=1), _bgrad(dc)   # cat(bottle_neck, dir_enc) column blocks
+    dbott = torch.mm(dc, W[9][:, :256].contiguous())
+    gW[7], gb[7] = _wgrad(dbott, g6), _bgrad(dbott)
+    dsig = g_rgbo[:, 3:4].to(dt)
+    gW[8], gb[8] = _wgrad(dsig, g6), g_rgbo[:, 3].sum().reshape(1)
+    delta = _masked(torch.addmm(dsig * W[8], dbott, W[7]), g6, precision)
+    del bott, dbott, dc, c
+    for l in (6, 5):
+        prev = rows(l - 1)
+        gW[l], gb[l] = _wgrad(delta, prev), _bgrad(delta)
+        delta = _masked(torch.mm(delta, W[l]), prev, precision)
+    ex = _encode(x.contiguous(), 10, dt)                                            # (M, 63 -> 64)
+    h3 = rows(3)
+    gW[4], gb[4] = torch.cat((_wgrad(delta, ex)[:, :63], _wgrad(delta, h3)), dim=1), _bgrad(delta)   # skip layer: cat(encoded_x, h)
+    delta = _masked(torch.mm(delta, W[4][:, 63:].contiguous()), h3, precision)
+    del h3
+    for l in (3, 2, 1):
+        prev = rows(l - 1)
+        gW[l], gb[l] = _wgrad(delta, prev), _bgrad(delta)
+        delta = _masked(torch.mm(delta, W[l]), prev, precision)
+    gW[0], gb[0] = _wgrad(delta, ex)[:, :63], _bgrad(delta)
+    return gW, gb

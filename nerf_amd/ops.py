@@ -369,3 +369,42 @@ def get_bounds_backward(below: torch.Tensor, d_bounds: torch.Tensor, n_coarse: i
     check(lib.nerf_amd_get_bounds_backward(_ptr(below), _ptr(d_bounds), N, n_coarse, K, _ptr(out), _stream()), "nerf_amd_get_bounds_backward")
     return out
 
+
+# ------------------------------------------------------------------------------------------------ training forward
+NET_PROPOSAL, NET_MIP = 0, 1
+
+
+def _train_forward(net: int, packed: torch.Tensor, precision: int, pts: torch.Tensor, width: int, out_shape):
+    pts = _dev(pts, "pts")
+    M = pts.numel() // width
+    out = torch.empty(out_shape, dtype=torch.float32, device=pts.device)
+    dump = torch.empty((lib.nerf_amd_train_dump_bytes(net, precision, M),), dtype=torch.uint8, device=pts.device)
+    if M:
+        s = _samples_pts(pts, width)
+        fn = lib.nerf_amd_proposal_forward_train if net == NET_PROPOSAL else lib.nerf_amd_mip_forward_train
+        check(fn(_ptr(packed), precision, C.byref(s), _ptr(out), _ptr(dump), _stream()), "nerf_amd_*_forward_train")
+    return out, dump
+
+
+def proposal_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor):
+    """Same result as proposal_forward plus the activation dump the backward needs."""
+    return _train_forward(NET_PROPOSAL, packed, precision, pts, 3, pts.shape[:-1])
+
+
+def mip_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor):
+    return _train_forward(NET_MIP, packed, precision, pts, 6, pts.shape[:-1] + (4,))
+
+
+def train_dump_rows(dump: torch.Tensor, net: int, precision: int, M: int, layer: int, n_features: int) -> torch.Tensor:
+    """Layer `layer` of a training dump as a row-major (M, n_features) matrix (bf16 / fp32 like the kernels' activations)."""
+    out = torch.empty((M, n_features), dtype=torch.bfloat16 if precision == BF16 else torch.float32, device=dump.device)
+    check(lib.nerf_amd_train_dump_to_rows(_ptr(dump), net, precision, M, layer, n_features, _ptr(out), _stream()), "nerf_amd_train_dump_to_rows")
+    return out
+
+
+def relu_mask_(delta: torch.Tensor, act: torch.Tensor, precision: int) -> torch.Tensor:
+    """In place: delta = where(act > 0, delta, 0); both contiguous, same shape and dtype (bf16 for BF16, fp32 for F32)."""
+    assert delta.is_contiguous() and act.is_contiguous() and delta.shape == act.shape and delta.dtype == act.dtype
+    check(lib.nerf_amd_relu_mask(_ptr(delta), _ptr(act), precision, delta.numel(), _stream()), "nerf_amd_relu_mask")
+    return delta
+

@@ -57,6 +57,9 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                  # one configuration (for profiling): n_rays precision
+        run(int(sys.argv[1]), 64, 128, sys.argv[2], iters=5, warm=2)
+        sys.exit(0)
     for prec in ("bf16", "fp32"):
         for n in (512, 4096, 16384):
             run(n, 64, 128, prec)

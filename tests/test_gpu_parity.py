@@ -679,3 +679,71 @@ def test_integration_md_ctypes_stub_runs(A):
     with torch.no_grad():
         A.pkg.set_precision("fp32")
         assert torch.equal(ns["mip_forward"](blob, A.ops.F32, pts), mip.forward(pts))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mlp_training_forward_and_backward(A, prec):
+    """nerf_amd_*_forward_train == the inference kernels; the activation dump read back as rows == the torch layer outputs; the
+    GEMM-chain backward == torch.autograd of the reference expressions (fp32 tight; bf16 within operand rounding)."""
+    from nerf_amd import autograd_bridge as ab, mlp_backward
+    prop, mip = build_nets(A, "he" if prec == "fp32" else "small")     # stress weights where the comparison is exact arithmetic
+    A.pkg.set_precision(prec)
+    P = A.ops.current_precision()
+    gen = torch.Generator().manual_seed(31)
+    M = 1000                                                                       # not a multiple of the 256-sample tile
+    pts3 = (torch.rand(M, 3, generator=gen) * 2 - 1).cuda()
+    pts6 = torch.cat((pts3, torch.randn(M, 3, generator=gen).cuda()), -1).contiguous()
+    tol = 2e-4 if prec == "fp32" else 4e-2
+    with torch.no_grad():
+        dens, dump_p = A.ops.proposal_forward_train(prop.packed(P), P, pts3)
+        assert torch.equal(dens, A.ops.proposal_forward(prop.packed(P), P, pts3))
+        rgbo, dump_m = A.ops.mip_forward_train(mip.packed(P), P, pts6)
+        assert torch.equal(rgbo, A.ops.mip_forward(mip.packed(P), P, pts6))
+        # hidden activations of the proposal net, layer by layer, against torch
+        wl = [l.weight for l in prop._linear_layers()]
+        bl = [l.bias for l in prop._linear_layers()]
+        h = torch.cat((pts3, ab._pe(pts3, 10)), -1)
+        for l in range(4):
+            h = F.relu(F.linear(h, wl[l], bl[l]))
+            got = A.ops.train_dump_rows(dump_p, A.ops.NET_PROPOSAL, P, M, l, 256).float()
+            assert max_abs(got.cpu(), h.cpu()) <= tol * max(1.0, h.abs().max().item()), l
+    # parameter gradients through the module surface (HipOp + mlp_backward) vs torch.autograd on the expressions
+    g1 = torch.randn(M, generator=gen).cuda()
+    g4 = torch.randn(M, 4, generator=gen).cuda()
+    for net, pts, g, expr, n in ((prop, pts3, g1, ab.proposal_expr, 5), (mip, pts6, g4, ab.mip_expr, 11)):
+        layers = net._linear_layers()
+        params = [l.weight for l in layers] + [l.bias for l in layers]
+        for p_ in params:
+            p_.grad = None
+        net.train()
+        out = net.forward(pts.view(M // 8, 8, -1))
+        out.backward(g.view(out.shape))
+        got = [p_.grad.clone() for p_ in params]
+        leaves = [p_.detach().clone().requires_grad_(True) for p_ in params]
+        y = expr(pts, leaves[:n], leaves[n:])
+        want = torch.autograd.grad(y, leaves, g.view(y.shape))
+        for k, (a_, b_) in enumerate(zip(got, want)):
+            scale = max(1e-6, b_.abs().max().item())
+            # (fp32: reduction order of the M-long wgrad sums; the first layer's gradient is the difference of large terms)
+            if prec == "fp32":
+                assert max_abs(a_.cpu(), b_.cpu()) <= 5e-3 * scale, (type(net).__name__, k, max_abs(a_.cpu(), b_.cpu()), scale)
+            else:
+                # bf16 vs an fp32 forward: ReLU masks near zero flip (a forward-precision effect), which alone moves bias sums by >10 %:
+                # only the direction of every gradient tensor is checked here; the arithmetic of the chain itself is checked below
+                cos = F.cosine_similarity(a_.reshape(1, -1), b_.reshape(1, -1)).item()
+                assert cos >= 0.97, (type(net).__name__, k, cos)
+    if prec == "bf16":
+        # the bf16 GEMM chain against the same chain in fp32 ON THE SAME DUMP (identical masks): operand rounding only
+        wl = [l.weight.detach() for l in prop._linear_layers()]
+        acts = [A.ops.train_dump_rows(dump_p, A.ops.NET_PROPOSAL, P, M, l, 256).float() for l in range(4)]
+        delta = (g1[:, None] * wl[4]) * (acts[3] > 0)
+        want_w = [None] * 4
+        for l in (3, 2, 1):
+            want_w[l] = delta.t() @ acts[l - 1]
+            delta = (delta @ wl[l]) * (acts[l - 1] > 0)
+        want_w[0] = delta.t() @ torch.cat((pts3, ab._pe(pts3, 10)), -1)
+        gW, _ = mlp_backward.proposal_backward(g1, pts3, dump_p, P, wl)
+        for l in range(4):
+            rel = ((gW[l] - want_w[l]).norm() / want_w[l].norm()).item()
+            assert rel <= 2e-2, (l, rel)
+    A.pkg.set_precision("fp32")

@@ -1,5 +1,5 @@
 """PSNR at equal iterations (north_star): train the SAME small problem through (a) the CPU oracle with torch autograd
-and (b) the nerf_amd surface on the GPU (HIP forward + autograd bridge), with identical initial weights, optimiser, ray
+and (b) the nerf_amd surface on the GPU (HIP training forward + GEMM-chain backward on its activation dump, HIP backward of the sampling/compositing rows), with identical initial weights, optimiser, ray
 batches and uniforms (one seeded CPU generator drives both, in the reference's draw order), and compare PSNR.
 
 No dataset exists on the box, so the scene is synthetic and analytic (a shaded sphere in front of a white background, 8
@@ -142,8 +142,9 @@ def test_psnr_at_equal_iterations():
     print("\ntrain PSNR (last 40 it): cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB;  held-out view: cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB"
           % (tail(h_ref), tail(h_f32), tail(h_b16), psnr(t_ref), psnr(t_f32), psnr(t_b16)))
     assert h_ref[-1] < h_ref[0]                                      # it does learn
-    # the gate is the rendered held-out view (image PSNR, 0.1 dB); the training-loss tail is a noisy proxy -- every backward that is
-    # not bit-identical to torch's (the HIP backward kernels differ from it at the 1e-5 level) decorrelates the mini-batch losses
-    # within ~30 Adam steps -- and only has to stay in the same band
+    # the gate is the rendered held-out view (image PSNR, 0.1 dB) in both modes.  The training-loss tail is a noisier proxy: the fp32
+    # mode (exact-fp32 MFMA forward, fp32 GEMM-chain backward) tracks the CPU run within 0.1 dB there too; in the bf16 mode every
+    # gradient carries bf16 operand rounding (like the reference's fp16 AMP), which decorrelates the mini-batch losses within ~30 Adam
+    # steps, so its tail only has to stay in the same band
     assert abs(psnr(t_f32) - psnr(t_ref)) <= 0.1 and abs(psnr(t_b16) - psnr(t_ref)) <= 0.1
-    assert abs(tail(h_f32) - tail(h_ref)) <= 0.25 and abs(tail(h_b16) - tail(h_ref)) <= 0.25
+    assert abs(tail(h_f32) - tail(h_ref)) <= 0.1 and abs(tail(h_b16) - tail(h_ref)) <= 0.5
