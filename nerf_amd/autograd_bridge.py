@@ -1,9 +1,11 @@
 """Autograd bridge: makes the forward-only HIP ops usable under ``loss.backward()``.
 
-Forward is ALWAYS the HIP kernel.  Backward (the HIP dgrad/wgrad kernels are the next
-milestone) is obtained by re-evaluating the same op with torch expressions ON THE DEVICE under ``enable_grad`` and
-asking torch.autograd for the vector-Jacobian product.  This is not a fallback of the forward path: it never runs
-unless ``backward`` is called, never touches the CPU, and raises if the tensors are not on the HIP device.
+Forward is ALWAYS the HIP kernel.  Backward: ops that have a HIP backward (`with_hip_backward`: the
+sampling/compositing kernels, the MLPs' GEMM-chain backward on the training forward's activation dump) use it; the torch
+expressions below are their specification -- what the tests compare them with -- and the remaining path: gradients w.r.t. sample
+positions are obtained by re-evaluating the expression ON THE DEVICE under ``enable_grad`` and asking torch.autograd for the
+vector-Jacobian product.  That is not a fallback of the forward path: it never runs unless ``backward`` is called, never touches
+the CPU, and raises if the tensors are not on the HIP device.
 
 Gradient parity with the reference is pinned by golden G14 (tests/test_gpu_parity.py::test_train_step_gradients).
 """
