@@ -101,9 +101,13 @@ class RefNeRF(NeRF, PackedWeightsMixin):
 
     @staticmethod
     def get_grad(func_val: torch.Tensor, inputs: torch.Tensor) -> torch.Tensor:
-        """Normalised d(func)/d(inputs) (ref_model.py:119-125).  Needs autograd through the network: not available on
-        the forward-only HIP path."""
-        raise NotImplementedError("nerf_amd: RefNeRF.get_grad needs the HIP backward (SURVEY.md section 8f-1)")
+        """Normalised d(func)/d(inputs) (ref_model.py:119-125): first-order only, like the reference (no create_graph).  Works for
+        every differentiable op of this package -- e.g. the proposal density w.r.t. its sample positions (train.py:165-168,
+        `prop_normal`), whose position gradient comes from the device-side VJP of autograd_bridge.py.  RefNeRF's own training
+        forward is not built (see forward)."""
+        grad, = torch.autograd.grad(func_val, inputs, torch.ones_like(func_val), retain_graph=True)
+        grad_norm = grad.norm(dim=-1, keepdim=True)
+        return grad / torch.maximum(torch.full_like(grad_norm, 1e-5), grad_norm)
 
 
 class WeightedNormalLoss(nn.Module):

@@ -747,3 +747,31 @@ def test_mlp_training_forward_and_backward(A, prec):
             rel = ((gW[l] - want_w[l]).norm() / want_w[l].norm()).item()
             assert rel <= 2e-2, (l, rel)
     A.pkg.set_precision("fp32")
+
+
+def test_get_grad_of_proposal_density_then_parameter_backward(A):
+    """train.py:165-168 with prop_normal: positions require grad, RefNeRF.get_grad(density, positions) is taken with
+    retain_graph, and the SAME graph is backpropagated to the parameters afterwards."""
+    from nerf_amd import autograd_bridge as ab
+    prop, _ = build_nets(A, "small")
+    A.pkg.set_precision("fp32")
+    prop.train()
+    gen = torch.Generator().manual_seed(41)
+    pts = (torch.rand(12, 16, 3, generator=gen) * 2 - 1).cuda().requires_grad_(True)
+    dens = prop.forward(pts)
+    from nerf_amd.ref_model import RefNeRF
+    normals = RefNeRF.get_grad(dens, pts)
+    layers = prop._linear_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    for p_ in params:
+        p_.grad = None
+    F.softplus(dens).sum().backward()
+    leaves = [p_.detach().clone().requires_grad_(True) for p_ in params]
+    x = pts.detach().clone().requires_grad_(True)
+    y = ab.proposal_expr(x, leaves[:5], leaves[5:])
+    g, = torch.autograd.grad(y, x, torch.ones_like(y), retain_graph=True)
+    want_n = g / torch.maximum(torch.full_like(g[..., :1], 1e-5), g.norm(dim=-1, keepdim=True))
+    assert max_abs(normals.cpu(), want_n.cpu()) <= 1e-4
+    want = torch.autograd.grad(F.softplus(y).sum(), leaves)
+    for a_, b_ in zip([p_.grad for p_ in params], want):
+        assert max_abs(a_.cpu(), b_.cpu()) <= 1e-4 * max(1.0, b_.abs().max().item())
