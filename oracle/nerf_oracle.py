@@ -486,9 +486,10 @@ def ref_shapes(Lp: int = 10, deg: int = 4, hidden: int = 256, bottle: int = 128,
 
 
 def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = None, Lp: int = 10, deg: int = 4,
-                emulate_bf16: bool = False):
-    """RefNeRF.forward in eval mode, use_srgb=False (ref_model.py:68-106).  pts (N,S,6) [or (N,S,3) + ray_d] ->
-    ((N,S,4) = [rgb | raw density], normal (N,S,3))."""
+                emulate_bf16: bool = False, noise: Optional[Tensor] = None):
+    """RefNeRF.forward, use_srgb=False (ref_model.py:68-106).  pts (N,S,6) [or (N,S,3) + ray_d] ->
+    ((N,S,4) = [rgb | raw density], normal (N,S,3)).  `noise` = the train-mode perturbation of the bottle-neck vector
+    (ref_model.py:84-85: torch.normal(0, perturb_bottle_neck_w, shape)); None = eval mode."""
     lin = lambda name, t: _linear(t, sd[name + ".weight"], sd[name + ".bias"], emulate_bf16)
     x = pts[..., :3]
     ex = torch.cat((x, positional_encoding(x, Lp)), dim=-1)
@@ -504,6 +505,8 @@ def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = No
     rough, density = rt[..., 0:1], rt[..., 1:2]
     rough = F.softplus(rough - 1.0)
     b = lin("bottle_neck", g)
+    if noise is not None:
+        b = b + noise
     normal = -normal / (normal.norm(dim=-1, keepdim=True) + 1e-7)
     d = pts[..., 3:] if ray_d is None else ray_d
     refl = d - 2.0 * torch.sum(d * normal, dim=-1, keepdim=True) * normal
@@ -519,6 +522,57 @@ def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = No
     spec = torch.sigmoid(lin("spec_rgb_head.0", r)) * torch.sigmoid(tint)
     rgb = spec + torch.sigmoid(diffuse)
     return torch.cat((rgb, density), dim=-1), normal
+
+
+def get_grad(func_val: Tensor, inputs: Tensor) -> Tensor:
+    """RefNeRF.get_grad (ref_model.py:119-125): first-order d(func)/d(inputs), normalised, norm clamped at 1e-5."""
+    grad, = torch.autograd.grad(func_val, inputs, torch.ones_like(func_val), retain_graph=True)
+    n = grad.norm(dim=-1, keepdim=True)
+    return grad / torch.maximum(torch.full_like(n, 1e-5), n)
+
+
+def coarse_grad_select(fine_grads: Tensor, sort_inds: Tensor, c_pnum: int) -> Tensor:
+    """ref_model.py:108-117: after cat(fine, coarse) + sort, pick the rows that came from the coarse samples."""
+    n, total, _ = fine_grads.shape
+    sel = torch.cat((torch.zeros(n, total - c_pnum, dtype=torch.bool), torch.ones(n, c_pnum, dtype=torch.bool)), dim=-1)
+    return fine_grads[torch.gather(sel, -1, sort_inds)].reshape(n, c_pnum, -1)
+
+
+def weighted_normal_loss(weight: Tensor, d_norm: Tensor, p_norm: Tensor) -> Tensor:
+    return torch.sum(weight * (1.0 - torch.sum(d_norm * p_norm, dim=-1)))          # ref_model.py:127-135 (size_average False)
+
+
+def back_face_loss(weight: Tensor, normal: Tensor, ray_d: Tensor) -> Tensor:
+    return torch.mean(weight * F.relu(torch.sum(normal * ray_d, dim=-1)))           # ref_model.py:137-143
+
+
+def ref_train_step(prop_sd, ref_sd, rays: Tensor, z_coarse: Tensor, u_inv: Tensor, noise: Tensor, rgb_tgt: Tensor, n_fine: int):
+    """The Ref-NeRF branch of the training step with prop_normal on (train.py:164-199).  prop_sd / ref_sd hold leaf tensors
+    (requires_grad) when parameter gradients are wanted.  Returns a dict of every intermediate the golden G17 pins."""
+    C = z_coarse.shape[-1]
+    pts = (rays[:, None, :3] + rays[:, None, 3:] * z_coarse[:, :, None]).detach().requires_grad_(True)
+    dens = proposal_forward(prop_sd, pts)
+    coarse_grad = -get_grad(dens, pts)
+    pw = max_blur(sigma_to_weights(F.softplus(dens), z_coarse, rays[:, 3:]), 0.01)
+    z_fine, below = inverse_sample(pw, z_coarse, u_inv, sort=True)
+    samples, z_all, below_all, sort_ids = coarse_fine_merge(rays, z_coarse, z_fine, below)
+    pos = samples[..., :3].detach().requires_grad_(True)
+    d = samples[..., 3:]
+    rgbo, normal = ref_forward(ref_sd, pos, d, noise=noise)
+    density_grad = -get_grad(rgbo[..., -1], pos)
+    rgbo_act = torch.cat((rgbo[..., :3], F.softplus(rgbo[..., 3:] + 0.5)), dim=-1)
+    # train.py:182 passes mip_net.density_act positionally into `mul_norm`: a truthy object that is not `== True`, so the
+    # depths are NOT scaled by |d| and the default ReLU is the density activation (SURVEY.md 8a row 10 quirk)
+    rendered, weights, _ = composite(rgbo_act, z_all, rays[:, 3:], mul_norm=False)
+    n_loss = weighted_normal_loss(weights, density_grad, normal)
+    bf = back_face_loss(weights, normal, d)
+    cn_loss = weighted_normal_loss(pw, coarse_grad_select(density_grad, sort_ids, C).detach(), coarse_grad)
+    img = torch.mean((rendered - rgb_tgt) ** 2)
+    pl = proposal_loss(get_bounds(pw, below_all), weights.detach())
+    loss = pl + img + 4e-4 * (n_loss + 0.1 * cn_loss) + 0.1 * bf
+    return dict(z_fine=z_fine, z_merged=z_all, below_merged=below_all, sort_ids=sort_ids, rgbo_raw=rgbo, pred_normal=normal,
+                density_grad=density_grad, coarse_grad=coarse_grad, weights=weights, rendered=rendered, normal_loss=n_loss, bf_loss=bf,
+                coarse_normal_loss=cn_loss, img_loss=img, prop_loss=pl, loss=loss)
 
 
 def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float, sample_num: int = 128,

@@ -311,6 +311,54 @@ def main():
     steps = np.array([0, 1, 250, 499, 500, 501, 10000, 100500, 500000, 2000000])
     npz("g15_lr", steps=steps, lr=np.array([sch.update_opt_lr(int(s))[1] for s in steps]))
 
+    # ---------------- G17 Ref-NeRF train step (train.py:164-199, ref branch, prop_normal on) ----------------
+    # (kept LAST so that the generator stream of G1..G15 is unchanged; torch.normal is replaced by a recorded tensor)
+    N17, C17, F17 = 16, 16, 32
+    prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state("small")); prop.train()
+    net = ref_model.RefNeRF(10, 4); net.load_state_dict(W.ref_state("small")); net.train()
+    rays17 = rays[:N17].clone() if rays.shape[0] >= N17 else torch.cat([rays] * 2)[:N17].clone()
+    tgt17 = torch.rand(N17, 3, generator=g)
+    res17 = (far - near) / C17
+    zc17 = torch.linspace(near, far - res17, C17) + torch.rand(N17, C17, generator=g) * res17
+    pts17 = (rays17[:, None, :3] + rays17[:, None, 3:] * zc17[:, :, None]).clone()
+    u17 = torch.rand(N17, F17 + 1, generator=g)
+    noise17 = torch.randn(N17, C17 + F17, 128, generator=g) * 0.1
+    real_normal, real_rand = torch.normal, torch.rand
+    torch.normal = lambda *a, **k: noise17
+    torch.rand = lambda *a, **k: u17                                                    # the one draw inside sample_pdf
+    try:
+        pts17.requires_grad = True
+        dens17 = prop.forward(pts17)
+        coarse_grad = -ref_model.RefNeRF.get_grad(dens17, pts17)
+        dens17 = F.softplus(dens17)
+        pw17 = mip_methods.maxBlurFilter(addtional.ProposalNetwork.get_weights(dens17, zc17, rays17[:, 3:]), 0.01)
+        fl17, below17 = utils.inverseSample(pw17, zc17, F17 + 1, sort=True)
+        samples17, fl17m, below17m, sort17 = nerf_base.NeRF.coarseFineMerge(rays17, zc17, fl17, below17)
+        pos17, dir17 = samples17.split((3, 3), dim=-1)
+        pos17.requires_grad = True
+        rgbo17, nrm17 = net.forward(pos17, dir17)
+        dgrad17 = -ref_model.RefNeRF.get_grad(rgbo17[..., -1], pos17)
+        rgbo17_raw = rgbo17.detach().clone()
+        rgbo17[..., -1] = F.softplus(rgbo17[..., -1] + 0.5)
+        rend17, wts17, _ = nerf_base.NeRF.render(rgbo17, fl17m, rays17[:, 3:], net.density_act)   # (the reference's positional quirk)
+        nl17 = ref_model.WeightedNormalLoss()(wts17, dgrad17, nrm17)
+        bf17 = ref_model.BackFaceLoss()(wts17, nrm17, dir17)
+        cg17 = ref_model.RefNeRF.coarse_grad_select(dgrad17, sort17, C17)
+        cnl17 = ref_model.WeightedNormalLoss()(pw17, cg17.detach(), coarse_grad)
+        bounds17 = addtional.getBounds(pw17, below17m)
+        img17 = torch.nn.MSELoss()(rend17, tgt17)
+        pl17 = addtional.ProposalLoss()(bounds17, wts17.detach())
+        loss17 = pl17 + img17 + 4e-4 * (nl17 + 0.1 * cnl17) + 0.1 * bf17
+        loss17.backward()
+    finally:
+        torch.normal, torch.rand = real_normal, real_rand
+    npz("g17_ref_train_step", rays=rays17, rgb_tgt=tgt17, z_coarse=zc17, u_inv=u17, noise=noise17, z_fine=fl17, z_merged=fl17m,
+        below_merged=below17m, sort_ids=sort17, rgbo_raw=rgbo17_raw, pred_normal=nrm17, density_grad=dgrad17, coarse_grad=coarse_grad,
+        weights=wts17, rendered=rend17, normal_loss=nl17, bf_loss=bf17, coarse_normal_loss=cnl17, img_loss=img17, prop_loss=pl17,
+        loss=loss17, g_spa0=net.spa_block1[0].weight.grad[:8, :], g_rho_tau=net.rho_tau_head.weight.grad,
+        g_nct=net.norm_col_tint_head.weight.grad, g_bottle=net.bottle_neck.weight.grad[:8, :], g_dir0=net.dir_block1[0].weight.grad[:8, :],
+        g_spec=net.spec_rgb_head[0].weight.grad, g_prop_l0=prop.layers[0].weight.grad[:8, :], g_prop_head=prop.layers[8].weight.grad)
+
 
 if __name__ == "__main__":
     main()

@@ -199,3 +199,26 @@ def test_g13_render_image_refnerf(golden):
     assert max_abs(rgb.view(50, 50, 3).permute(2, 0, 1), g["img_rgb"]) <= 2e-6
     assert max_abs(ex["depth_img"].view(50, 50), g["img_depth"]) <= 2e-6
     assert max_abs(ex["normal_img"].view(50, 50), g["img_normal"]) <= 2e-6
+
+
+def test_g17_ref_train_step(golden):
+    """Ref-NeRF training step with prop_normal (train.py:164-199): the oracle restatement reproduces the reference's
+    intermediates, losses and parameter gradients from the same inputs / recorded bottle-neck noise."""
+    g = golden("g17_ref_train_step")
+    prop = {k: v.clone().requires_grad_(True) for k, v in W.proposal_state("small").items()}
+    ref = {k: v.clone().requires_grad_(True) for k, v in W.ref_state("small").items()}
+    out = O.ref_train_step(prop, ref, g["rays"], g["z_coarse"], g["u_inv"], g["noise"], g["rgb_tgt"], 32)
+    assert torch.equal(out["sort_ids"], g["sort_ids"]) and torch.equal(out["below_merged"], g["below_merged"])
+    for k in ("z_fine", "z_merged", "rgbo_raw", "pred_normal", "weights", "rendered"):
+        assert max_abs(out[k], g[k]) <= 2e-6, k
+    for k in ("density_grad", "coarse_grad"):
+        assert max_abs(out[k], g[k]) <= 2e-4, k                                   # unit vectors of tiny gradients (norm clamp 1e-5)
+    for k in ("normal_loss", "bf_loss", "coarse_normal_loss", "img_loss", "prop_loss", "loss"):
+        assert abs(float(out[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), k
+    out["loss"].backward()
+    for key, name, rows in (("g_spa0", "spa_block1.0.weight", 8), ("g_rho_tau", "rho_tau_head.weight", None), ("g_nct", "norm_col_tint_head.weight", None),
+                            ("g_bottle", "bottle_neck.weight", 8), ("g_dir0", "dir_block1.0.weight", 8), ("g_spec", "spec_rgb_head.0.weight", None)):
+        got = ref[name].grad if rows is None else ref[name].grad[:rows]
+        assert max_abs(got, g[key]) <= 2e-5 * max(1.0, g[key].abs().max().item()), key
+    assert max_abs(prop["layers.0.weight"].grad[:8], g["g_prop_l0"]) <= 5e-4 * max(1.0, g["g_prop_l0"].abs().max().item())
+    assert max_abs(prop["layers.8.weight"].grad, g["g_prop_head"]) <= 2e-5 * max(1.0, g["g_prop_head"].abs().max().item())
