@@ -118,6 +118,10 @@ int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf
  * normal (M,3) (NULL to skip).  Samples need a direction (pts_stride >= 6 in mode 0). */
 int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src,
                          float* rgbo, float* normal, void* stream);
+/* Training-mode forward (ref_model.py:84-85): the same kernel with the bottle-neck perturbation `bn_noise` (M,128), which the
+ * caller draws (torch.normal(0, perturb_bottle_neck_w)) so that the backward can re-evaluate with the same noise. */
+int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo,
+                               float* normal, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling / compositing kernels (one 64-lane wavefront per ray; HBM-bound).

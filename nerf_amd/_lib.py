@@ -39,6 +39,7 @@ SIGNATURES = {
     "nerf_amd_mip_forward_composite": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, C.c_float, C.c_float, c_void, c_void, c_void,
                                                  c_void]),
     "nerf_amd_ref_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void]),
+    "nerf_amd_ref_forward_train": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void, c_void]),
     "nerf_amd_positional_encoding": (C.c_int, [c_void, i64, C.c_int, c_void, c_void]),
     "nerf_amd_generate_rays": (C.c_int, [c_float_p, C.c_int, C.c_int, C.c_float, C.c_float, i64, i64, c_void, c_void]),
     "nerf_amd_length2pts": (C.c_int, [c_void, c_void, i64, C.c_int, c_void, c_void]),

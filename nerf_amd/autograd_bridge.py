@@ -51,6 +51,36 @@ def mip_expr(pts, w, b):
     return torch.cat((rgb, sigma), dim=-1)
 
 
+def ref_expr(pos, d, noise, P, ide_fn):
+    """RefNeRF.forward as torch ops (ref_model.py:68-106, use_srgb off); P = {state_dict key: tensor}; `noise` = the train-mode
+    perturbation of the bottle-neck vector or None.  Returns cat(rgb, density, normal) (..., 7)."""
+    lin = lambda name, t: F.linear(t, P[name + ".weight"], P[name + ".bias"])
+    ex = torch.cat((pos, _pe(pos, 10)), dim=-1)
+    h = ex
+    for i in (0, 2, 4, 6):
+        h = F.relu(lin("spa_block1.%d" % i, h))
+    g = torch.cat((ex, h), dim=-1)
+    for i in (0, 2, 4, 6):
+        g = F.relu(lin("spa_block2.%d" % i, g))
+    normal, diffuse, tint = lin("norm_col_tint_head", g).split((3, 3, 3), dim=-1)
+    rough, density = lin("rho_tau_head", g).split((1, 1), dim=-1)
+    rough = F.softplus(rough - 1.0)
+    b = lin("bottle_neck", g)
+    if noise is not None:
+        b = b + noise
+    normal = -normal / (normal.norm(dim=-1, keepdim=True) + 1e-7)
+    refl = d - 2.0 * torch.sum(d * normal, dim=-1, keepdim=True) * normal
+    allin = torch.cat((b, ide_fn(refl, rough), torch.sum(normal * d, dim=-1, keepdim=True)), dim=-1)
+    r = allin
+    for i in (0, 2, 4, 6):
+        r = F.relu(lin("dir_block1.%d" % i, r))
+    r = torch.cat((allin, r), dim=-1)
+    for i in (0, 2, 4, 6):
+        r = F.relu(lin("dir_block2.%d" % i, r))
+    rgb = torch.sigmoid(lin("spec_rgb_head.0", r)) * torch.sigmoid(tint) + torch.sigmoid(diffuse)
+    return torch.cat((rgb, density, normal), dim=-1)
+
+
 def weights_expr(sigma, z, act_code: int):
     """sigma -> alpha -> exclusive transmittance product (nerf_base.py:80-86); z already scaled."""
     big = torch.full((z.shape[0], 1), 1e10, dtype=z.dtype, device=z.device)

@@ -10,7 +10,7 @@
 int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
-int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, hipStream_t);
+int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, const float*, hipStream_t);
 size_t mlp_train_layer_stride(int, int64_t);
 int mlp_launch_proposal_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
 int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
@@ -142,7 +142,15 @@ int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_sampl
     if (int c = check_samples(src, true)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, S(stream)), "nerf_amd_ref_forward");
+    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, nullptr, S(stream)), "nerf_amd_ref_forward");
+}
+int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo,
+                               float* normal, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (int c = check_samples(src, true)) return c;
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !rgbo || !bn_noise) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, bn_noise, S(stream)), "nerf_amd_ref_forward_train");
 }
 
 int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, void* stream) {

@@ -878,9 +878,11 @@ DEVINL void ide_encode(float x, float y, float z, float kappa_inv, float nv_dot,
     for (int e = 4; e < 8; ++e) P::set(out[2], e, 0.0f);
 }
 
+// bn_noise (training forward, ref_model.py:84-85): (M, 128) row-major perturbation added to the bottle-neck vector, or nullptr
 template <class P>
 __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict__ packed, nerf_amd_samples s,
-                                                         float* __restrict__ rgbo, float* __restrict__ normal_out) {
+                                                         float* __restrict__ rgbo, float* __restrict__ normal_out,
+                                                         const float* __restrict__ bn_noise) {
     using L = RefLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
@@ -945,8 +947,18 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
         BReg bn[NT][8];
         f32x16 hd[NT];
         auto OHD = [&](int fb, int t, const f32x16& acc, int half) {
-            if (fb < 4) bn[t][2 * (fb < 4 ? fb : 0) + half] = to_breg_half<P, false>(acc, half);
-            else if (half == 0) hd[t] = acc;
+            if (fb < 4) {
+                f32x16 v = acc;
+                if (bn_noise != nullptr) {
+                    // accumulators 8*half + e of block fb are features 32 fb + 16 half + 8 (e >> 2) + 4 h + (e & 3): two runs of four
+                    const int64_t mm = m[t] < s.M ? m[t] : s.M - 1;
+                    const float* np_ = bn_noise + mm * 128 + 32 * (fb < 4 ? fb : 0) + 16 * half + 4 * h;
+                    const f32x4 n0 = *reinterpret_cast<const f32x4*>(np_), n1 = *reinterpret_cast<const f32x4*>(np_ + 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[8 * half + e] += n0[e]; v[8 * half + 4 + e] += n1[e]; }
+                }
+                bn[t][2 * (fb < 4 ? fb : 0) + half] = to_breg_half<P, false>(v, half);
+            } else if (half == 0) hd[t] = acc;
         };
         dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4, IN_A, OHD, prev_of(d, OA)).flush(OHD);
         // half 0 holds rows 0-3 (normal, roughness) in hd[0..3] and rows 8-10 (tint) in hd[4..6]; half 1 rows 4-7 (diffuse, density) in hd[0..3]
@@ -1085,7 +1097,7 @@ int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_sampl
 }
 
 template <class P>
-static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, hipStream_t st) {
+static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise, hipStream_t st) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
@@ -1096,10 +1108,11 @@ static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(ref_kernel<P>, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal);
+    hipLaunchKernelGGL(ref_kernel<P>, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise);
     return (int)hipGetLastError();
 }
-int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch_ref<PB16>(packed, s, rgbo, normal, st);
-    return launch_ref<PF32>(packed, s, rgbo, normal, st);
+int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
+                   hipStream_t st) {
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16>(packed, s, rgbo, normal, bn_noise, st);
+    return launch_ref<PF32>(packed, s, rgbo, normal, bn_noise, st);
 }

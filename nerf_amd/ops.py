@@ -138,14 +138,22 @@ def _ref_out(shape, device, want_normal):
     return rgbo, normal
 
 
-def ref_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, want_normal: bool = True):
-    """pts (..., 6) = [position | direction] -> (rgbo (..., 4), normal (..., 3))   [ref_model.py:68-106, eval mode]"""
+def ref_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, want_normal: bool = True, noise: Optional[torch.Tensor] = None):
+    """pts (..., 6) = [position | direction] -> (rgbo (..., 4), normal (..., 3))   [ref_model.py:68-106]; `noise` (..., 128) = the
+    train-mode bottle-neck perturbation (ref_model.py:84-85), None = eval mode"""
     pts = _dev(pts, "pts")
     rgbo, normal = _ref_out(pts.shape[:-1], pts.device, want_normal)
     if rgbo.numel() == 0:
         return rgbo, normal
     s = _samples_pts(pts, 6)
-    check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
+    if noise is None:
+        check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
+    else:
+        noise = _dev(noise, "noise")
+        if noise.numel() != s.M * 128:
+            raise ValueError("nerf_amd: bottle-neck noise must be (..., 128) over the same samples")
+        check(lib.nerf_amd_ref_forward_train(_ptr(packed), precision, C.byref(s), _ptr(noise), _ptr(rgbo), _ptr(normal), _stream()),
+              "nerf_amd_ref_forward_train")
     return rgbo, normal
 
 

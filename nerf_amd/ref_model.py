@@ -7,6 +7,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import autograd_bridge as ab
 from . import ops
 from ._packed import PackedWeightsMixin, require_no_grad
 from .nerf_base import NeRF
@@ -52,8 +53,6 @@ class RefNeRF(NeRF, PackedWeightsMixin):
               and self.output_dim == 256 and self.cat_origin and not self.use_srgb)
         if not ok:
             raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, 4, 128, 256, 256, use_srgb=False)")
-        if self.training:
-            raise NotImplementedError("nerf_amd: Ref-NeRF train-mode forward (bottle-neck noise, density gradients) is not built; call .eval()")
 
     def _pack_tensors(self):
         nct, rt = self.norm_col_tint_head, self.rho_tau_head
@@ -84,11 +83,25 @@ class RefNeRF(NeRF, PackedWeightsMixin):
     def forward(self, pts: torch.Tensor, ray_d: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """pts (N,S,6) [or (N,S,3) + ray_d (N,S,3)] -> ((N,S,4) = [rgb | raw density], normal (N,S,3))  (ref_model.py:68-106)."""
         self._check_config()
-        require_no_grad(pts, ray_d, *self.parameters())
-        if ray_d is not None:
-            pts = torch.cat((pts[..., :3], ray_d), dim=-1)
+        pos, d = pts[..., :3], (pts[..., 3:6] if ray_d is None else ray_d)
         prec = ops.current_precision()
-        return ops.ref_forward(self.packed(prec), prec, pts)
+        noise = None
+        if self.training and self.perturb_bottle_neck_w > 0:                      # ref_model.py:84-85 (drawn here, given to the kernel)
+            noise = torch.normal(0, self.perturb_bottle_neck_w, pos.shape[:-1] + (self.bottle_neck_dim,), device=pos.device)
+        named = list(self.named_parameters())
+        params = [p for _, p in named]
+        if ab.needs_grad(pos, d, *params):
+            # training (train.py:176-186): HIP forward; gradients (w.r.t. parameters AND positions -- RefNeRF.get_grad) from the
+            # device-side VJP of the same expression with the same noise
+            names = [n for n, _ in named]
+
+            def hip(p, dd, *wb):
+                rgbo, normal = ops.ref_forward(self.packed(prec), prec, torch.cat((p, dd), dim=-1).contiguous(), noise=noise)
+                return torch.cat((rgbo, normal), dim=-1)
+            expr = lambda p, dd, *wb: ab.ref_expr(p, dd, noise, dict(zip(names, wb)), self.integrated_dir_enc)
+            out = ab.HipOp.apply(hip, expr, 0, pos, d, *params)
+            return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
+        return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise)
 
     @staticmethod
     def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum: int) -> torch.Tensor:

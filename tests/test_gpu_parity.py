@@ -775,3 +775,60 @@ def test_get_grad_of_proposal_density_then_parameter_backward(A):
     want = torch.autograd.grad(F.softplus(y).sum(), leaves)
     for a_, b_ in zip([p_.grad for p_ in params], want):
         assert max_abs(a_.cpu(), b_.cpu()) <= 1e-4 * max(1.0, b_.abs().max().item())
+
+
+def test_refnerf_train_step_vs_reference_golden(A, golden):
+    """G17: the Ref-NeRF branch of the training step with prop_normal (train.py:164-199) written against the nerf_amd surface --
+    train-mode forward with the recorded bottle-neck noise, RefNeRF.get_grad of the density w.r.t. the positions, normal /
+    back-face / coarse-normal losses, backward to every parameter -- against the REAL reference's numbers."""
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
+    from nerf_amd.utils import inverseSample
+    g = golden("g17_ref_train_step")
+    A.pkg.set_precision("fp32")
+    prop = ProposalNetwork(10, 256)
+    prop.load_state_dict(W.proposal_state("small"))
+    net = RefNeRF(10, 4)
+    net.load_state_dict(W.ref_state("small"))
+    prop, net = prop.cuda().train(), net.cuda().train()
+    rays, zc, tgt = dev(g["rays"]), dev(g["z_coarse"]), dev(g["rgb_tgt"])
+    noise = dev(g["noise"])
+    C17 = zc.shape[-1]
+    real_normal = torch.normal
+    torch.normal = lambda *a, **k: noise
+    try:
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * zc[:, :, None]).contiguous().requires_grad_(True)
+        dens = prop.forward(pts)
+        coarse_grad = -RefNeRF.get_grad(dens, pts)
+        dens = F.softplus(dens)
+        pw = maxBlurFilter(ProposalNetwork.get_weights(dens, zc, rays[:, 3:]), 0.01)
+        fl, below = inverseSample(pw, zc, g["u_inv"].shape[-1], sort=True, u=g["u_inv"])
+        samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, zc, fl, below)
+        pos, d = samples.split((3, 3), dim=-1)
+        pos = pos.contiguous().requires_grad_(True)
+        rgbo, nrm = net.forward(pos, d.contiguous())
+        dgrad = -RefNeRF.get_grad(rgbo[..., -1], pos)
+        rgbo_raw = rgbo.detach().clone()
+        rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
+        rend, wts, _ = NeRF.render(rgbo, fl, rays[:, 3:], net.density_act)        # the reference's positional quirk (train.py:182)
+        nl = WeightedNormalLoss()(wts, dgrad, nrm)
+        bf = BackFaceLoss()(wts, nrm, d)
+        cnl = WeightedNormalLoss()(pw, RefNeRF.coarse_grad_select(dgrad, sort_ids, C17).detach(), coarse_grad)
+        img = torch.mean((rend - tgt) ** 2)
+        pl = ProposalLoss()(getBounds(pw, below), wts.detach())
+        loss = pl + img + 4e-4 * (nl + 0.1 * cnl) + 0.1 * bf
+        loss.backward()
+    finally:
+        torch.normal = real_normal
+    assert torch.equal(sort_ids.cpu(), g["sort_ids"]) and torch.equal(below.cpu(), g["below_merged"])
+    assert max_abs(fl.cpu(), g["z_merged"]) <= 2e-5 and max_abs(rgbo_raw.cpu(), g["rgbo_raw"]) <= 2e-5 and max_abs(nrm.detach().cpu(), g["pred_normal"]) <= 2e-5
+    assert max_abs(wts.detach().cpu(), g["weights"]) <= 2e-5 and max_abs(rend.detach().cpu(), g["rendered"]) <= 2e-5
+    assert max_abs(dgrad.cpu(), g["density_grad"]) <= 2e-3 and max_abs(coarse_grad.cpu(), g["coarse_grad"]) <= 2e-3
+    for name, val in (("normal_loss", nl), ("bf_loss", bf), ("coarse_normal_loss", cnl), ("img_loss", img), ("prop_loss", pl), ("loss", loss)):
+        assert abs(val.item() - float(g[name])) <= 2e-4 * max(1.0, abs(float(g[name]))), name
+    for key, got in (("g_spa0", net.spa_block1[0].weight.grad[:8]), ("g_rho_tau", net.rho_tau_head.weight.grad), ("g_nct", net.norm_col_tint_head.weight.grad),
+                     ("g_bottle", net.bottle_neck.weight.grad[:8]), ("g_dir0", net.dir_block1[0].weight.grad[:8]), ("g_spec", net.spec_rgb_head[0].weight.grad),
+                     ("g_prop_l0", prop.layers[0].weight.grad[:8]), ("g_prop_head", prop.layers[8].weight.grad)):
+        assert max_abs(got.cpu(), g[key]) <= 2e-3 * max(1.0, g[key].abs().max().item()), key
