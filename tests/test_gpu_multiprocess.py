@@ -84,3 +84,77 @@ def test_two_rank_sharded_render_and_gradient_allreduce(tmp_path):
     want = torch.cat(parts_rgb).view(H, H, 3).permute(2, 0, 1).cpu()
     assert torch.equal(got["rgb"], want)
     assert torch.equal(got["depth"][0], torch.cat(parts_depth).view(H, H).cpu())
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel training step
+N_TRAIN, C_TRAIN, F_TRAIN = 64, 32, 64
+
+
+def _train_grads(prop, mip, rays, tgt, u1, u2):
+    """Body of train.py:164-199 (non-Ref) -> parameter gradients of the summed loss, through the nerf_amd training path."""
+    import torch.nn.functional as F
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.utils import inverseSample
+    res = (FAR - NEAR) / C_TRAIN
+    z_c = torch.linspace(NEAR, FAR - res, C_TRAIN).cuda() + u1 * res
+    pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
+    pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(prop.forward(pts)), z_c, rays[:, 3:]), 0.01)
+    z_f, below = inverseSample(pw, z_c, F_TRAIN + 1, sort=True, u=u2)
+    z_f = z_f[..., :-1].contiguous()
+    rend, wts, _ = NeRF.render(mip.forward(NeRF.length2pts(rays, z_f)), z_f, rays[:, 3:])
+    loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+    for p in list(mip.parameters()) + list(prop.parameters()):
+        p.grad = None
+    loss.backward()
+    return [p.grad.clone() for p in list(mip.parameters()) + list(prop.parameters())]
+
+
+def _train_inputs(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    d = torch.nn.functional.normalize(torch.randn(N_TRAIN, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
+    rays = torch.cat((torch.tensor([0.0, 0.0, 4.0]).expand(N_TRAIN, 3), d), -1).cuda().contiguous()
+    return rays, torch.rand(N_TRAIN, 3, generator=g).cuda(), torch.rand(N_TRAIN, C_TRAIN, generator=g).cuda(), torch.rand(N_TRAIN, F_TRAIN + 1, generator=g).cuda()
+
+
+def _train_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import nerf_amd
+    from nerf_amd import parallel
+    nerf_amd.set_precision("fp32")
+    prop, mip = _nets()
+    prop.train(); mip.train()
+    parallel.broadcast_parameters([mip, prop])
+    _train_grads(prop, mip, *_train_inputs(rank))
+    parallel.allreduce_gradients([mip, prop])                      # mean over the ranks = gradient of the mean loss over all rays
+    if rank == 0:
+        torch.save([p.grad.cpu() for p in list(mip.parameters()) + list(prop.parameters())], out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_gradients(tmp_path):
+    """ddp_train.py's step: every rank its own rays, one flat all-reduce; the reduced gradient equals the mean of the two ranks'
+    single-process gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    out_path = str(tmp_path / "grads.pt")
+    mp.spawn(_train_worker, args=(2, 29541, out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+    sys.path.insert(0, ROOT)
+    import nerf_amd
+    nerf_amd.set_precision("fp32")
+    prop, mip = _nets()
+    prop.train(); mip.train()
+    g0 = _train_grads(prop, mip, *_train_inputs(0))
+    g1 = _train_grads(prop, mip, *_train_inputs(1))
+    for a, b0, b1 in zip(got, g0, g1):
+        want = (0.5 * (b0 + b1)).cpu()
+        assert (a - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+
