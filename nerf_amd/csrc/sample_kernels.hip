@@ -651,23 +651,37 @@ __global__ __launch_bounds__(256) void get_bounds_backward_kernel(const int64_t*
 template <int ELEM>
 __global__ __launch_bounds__(256) void frag_to_rows_kernel(const char* __restrict__ frag, int64_t n_sub, int n_kg, int64_t M,
                                                            char* __restrict__ out, int ld) {
+    // One wavefront per subtile: the 32 x (16 n_kg) tile is transposed through LDS (row pitch padded by 16 bytes against bank
+    // conflicts), so that the global side is 16-byte lane-linear on the way in AND on the way out (the subtile's 32 rows are one
+    // contiguous block of the row-major matrix).
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     constexpr int BLOCK = 512 * ELEM;                           // bytes per (subtile, K group)
+    const int row_bytes = n_kg * 16 * ELEM;
+    const int pitch = row_bytes + 16;
+    char* tile = smem + (size_t)wave_in_block() * 32 * pitch;
     for (int64_t sub = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); sub < n_sub; sub += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
-        const int64_t row = sub * 32 + j;
-        if (row >= M) continue;
-        char* orow = out + (size_t)row * ld * ELEM;
+        lds_wave_sync();
+        char* trow = tile + j * pitch;
         for (int kg = 0; kg < n_kg; ++kg) {
             const char* blk = frag + ((size_t)sub * 16 + kg) * BLOCK;
             if constexpr (ELEM == 2) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(blk + lane * 16);          // 8 bf16
                 f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-                *reinterpret_cast<f32x2*>(orow + (16 * kg + 4 * h) * 2) = lo;
-                *reinterpret_cast<f32x2*>(orow + (16 * kg + 8 + 4 * h) * 2) = hi;
+                *reinterpret_cast<f32x2*>(trow + (16 * kg + 4 * h) * 2) = lo;
+                *reinterpret_cast<f32x2*>(trow + (16 * kg + 8 + 4 * h) * 2) = hi;
             } else {
-                *reinterpret_cast<f32x4*>(orow + (16 * kg + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + lane * 16);
-                *reinterpret_cast<f32x4*>(orow + (16 * kg + 8 + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + 1024 + lane * 16);
+                *reinterpret_cast<f32x4*>(trow + (16 * kg + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + lane * 16);
+                *reinterpret_cast<f32x4*>(trow + (16 * kg + 8 + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + 1024 + lane * 16);
             }
+        }
+        lds_wave_sync();
+        const int chunks_per_row = row_bytes / 16;
+        const int total = 32 * chunks_per_row;
+        char* obase = out + (size_t)sub * 32 * ld * ELEM;
+        for (int c = lane; c < total; c += 64) {
+            const int r = c / chunks_per_row, q = c - r * chunks_per_row;
+            if (sub * 32 + r < M)
+                *reinterpret_cast<f32x4*>(obase + (size_t)r * ld * ELEM + q * 16) = *reinterpret_cast<const f32x4*>(tile + r * pitch + q * 16);
         }
     }
 }
@@ -800,10 +814,18 @@ int sk_get_bounds_backward(const int64_t* below, const float* g, int64_t N, int 
 }
 int sk_frag_to_rows(const void* frag, int elem_bytes, int64_t n_sub, int n_kg, int64_t M, void* out, hipStream_t st) {
     if (n_sub == 0 || M == 0) return 0;
-    if (elem_bytes == 2)
-        hipLaunchKernelGGL(frag_to_rows_kernel<2>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), 0, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
-    else
-        hipLaunchKernelGGL(frag_to_rows_kernel<4>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), 0, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * 32 * ((size_t)n_kg * 16 * elem_bytes + 16);
+    if (elem_bytes == 2) {
+        hipLaunchKernelGGL(frag_to_rows_kernel<2>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), lds, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frag_to_rows_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(frag_to_rows_kernel<4>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), lds, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
+    }
     return (int)hipGetLastError();
 }
 int sk_relu_mask(void* delta, const void* act, int elem_bytes, int64_t n, hipStream_t st) {
