@@ -201,6 +201,11 @@ int nerf_amd_train_dump_to_rows(const void* dump, int net, int precision, int64_
                                 void* stream);
 /* ReLU adjoint of the dgrad chain, in place: delta[i] = act[i] > 0 ? delta[i] : 0 over n elements (bf16 / fp32 as above). */
 int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, void* stream);
+/* The same over a (rows, cols) matrix with the bias gradient fused in: `col_sum` receives nerf_amd_relu_mask_bias_partials(...) rows of
+ * `cols` fp32 partial column sums of the masked delta (written, not accumulated: no atomics, reproducible); their sum over the rows is
+ * the bias gradient.  cols * element size / 4 must divide 256. */
+int64_t nerf_amd_relu_mask_bias_partials(int precision, int64_t rows, int cols);
+int nerf_amd_relu_mask_bias(void* delta, const void* act, int precision, int64_t rows, int cols, float* col_sum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).

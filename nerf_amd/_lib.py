@@ -59,6 +59,8 @@ SIGNATURES = {
     "nerf_amd_mip_forward_train": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void]),
     "nerf_amd_train_dump_to_rows": (C.c_int, [c_void, C.c_int, C.c_int, i64, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_relu_mask": (C.c_int, [c_void, c_void, C.c_int, i64, c_void]),
+    "nerf_amd_relu_mask_bias_partials": (i64, [C.c_int, i64, C.c_int]),
+    "nerf_amd_relu_mask_bias": (C.c_int, [c_void, c_void, C.c_int, i64, C.c_int, c_void, c_void]),
     "nerf_amd_sigma_to_weights_backward": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_composite_backward": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_float, c_void, c_void, c_void, c_void, c_void]),

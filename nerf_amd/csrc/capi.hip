@@ -16,6 +16,7 @@ int mlp_launch_proposal_train(const void*, int, const nerf_amd_samples&, float*,
 int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
 int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t);
 int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
+int sk_relu_mask_bias(void*, const void*, int, int64_t, int, float*, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
@@ -270,6 +271,20 @@ int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, v
     if (n < 0 || (precision == NERF_AMD_BF16 && (n & 1))) return fail(NERF_AMD_EINVAL, "bad element count (bf16: even)");
     if (n && (!delta || !act)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_relu_mask(delta, act, precision == NERF_AMD_BF16 ? 2 : 4, n, S(stream)), "nerf_amd_relu_mask");
+}
+
+int64_t nerf_amd_relu_mask_bias_partials(int precision, int64_t rows, int cols) {
+    const int W = cols * (precision == NERF_AMD_BF16 ? 2 : 4) / 4;
+    if (rows <= 0 || W < 1 || W > 256 || (256 % W) != 0) return 0;
+    const int rpb = 256 / W;
+    int64_t blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 1024) blocks = 1024;
+    return blocks * rpb;
+}
+int nerf_amd_relu_mask_bias(void* delta, const void* act, int precision, int64_t rows, int cols, float* col_sum, void* stream) {
+    if (rows < 0 || cols < 2 || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return fail(NERF_AMD_EINVAL, "bad size or precision");
+    if (rows && (!delta || !act || !col_sum)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_relu_mask_bias(delta, act, precision == NERF_AMD_BF16 ? 2 : 4, rows, cols, col_sum, S(stream)), "nerf_amd_relu_mask_bias");
 }
 
 // ---- backward of the sampling / compositing rows ----

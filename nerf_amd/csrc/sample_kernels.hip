@@ -616,31 +616,32 @@ __global__ void max_blur_backward_kernel(const float* __restrict__ w, const floa
     }
 }
 
-// getBounds backward (addtional.py:14-18): bounds_k = sum_{j = below_k .. below_{k+1}} w_j  ->  dw = running sum of a
-// difference array built with LDS atomics
+// getBounds backward (addtional.py:14-18): bounds_k = sat[below_{k+1} + 1] - sat[below_k] = +sum of w over [below_k, below_{k+1}] (or minus the
+// sum over the gap when the indices are not ascending)  ->  dw_j = sum_k g_k * ([st_k <= j < en_k] - [en_k <= j < st_k]).
+// Every lane gathers its own j in ascending k: no atomics, reproducible.
 __global__ __launch_bounds__(256) void get_bounds_backward_kernel(const int64_t* __restrict__ below, const float* __restrict__ g, int64_t N, int C,
                                                                   int K, float* __restrict__ dw) {
-    float* diff = reinterpret_cast<float*>(smem) + wave_in_block() * (C + 2);
+    int* bl_lds = reinterpret_cast<int*>(smem) + wave_in_block() * (2 * K);
+    float* g_lds = reinterpret_cast<float*>(bl_lds + K);
     const int lane = lane_id();
     for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         lds_wave_sync();
-        for (int j = lane; j < C + 2; j += 64) diff[j] = 0.0f;
-        lds_wave_sync();
-        const int64_t* bl = below + n * K;
-        for (int k = lane; k < K - 1; k += 64) {
-            const float gk = g[n * (K - 1) + k];
-            int st = (int)bl[k], en = (int)bl[k + 1] + 1;
-            st = st < 0 ? 0 : (st > C ? C : st); en = en < 0 ? 0 : (en > C ? C : en);
-            atomicAdd(&diff[st], gk);                       // sat[en] - sat[st]: +g on [st, en)  (negative when en < st, like the reference)
-            atomicAdd(&diff[en], -gk);
+        for (int k = lane; k < K; k += 64) {
+            int b = (int)below[n * K + k];
+            bl_lds[k] = b < 0 ? 0 : (b > C ? C : b);
+            g_lds[k] = (k < K - 1) ? g[n * (K - 1) + k] : 0.0f;
         }
         lds_wave_sync();
-        double carry = 0.0;
-        for (int base = 0; base < C; base += 64) {
-            const int j = base + lane;
-            const double incl = wave_incl_scan_add(j < C ? (double)diff[j] : 0.0);
-            if (j < C) dw[n * C + j] = (float)(carry + incl);
-            carry += __shfl(incl, 63, 64);
+        for (int j = lane; j < C; j += 64) {
+            float acc = 0.0f;
+            for (int k = 0; k < K - 1; ++k) {
+                const int st = bl_lds[k];
+                int en = bl_lds[k + 1] + 1;
+                en = en > C ? C : en;
+                if (j >= st && j < en) acc += g_lds[k];
+                else if (j >= en && j < st) acc -= g_lds[k];
+            }
+            dw[n * C + j] = acc;
         }
     }
 }
@@ -700,6 +701,38 @@ __global__ void relu_mask_kernel(uint32_t* __restrict__ delta, const uint32_t* _
             if (!(hi != 0u && hi < 0x8000u)) d &= 0x0000FFFFu;
         }
         delta[i] = d;
+    }
+}
+
+// The same with the bias gradient fused in: partial column sums of the MASKED delta, one fp32 row per (block, row group) -- no atomics,
+// so that the result is reproducible; the caller adds the partial rows up.
+// Thread t of a 256-thread block owns 32-bit word (t % W) of rows (t / W), (t / W) + 256 / W, ...; W = words per row <= 256.
+template <int ELEM>
+__global__ __launch_bounds__(256) void relu_mask_bias_kernel(uint32_t* __restrict__ delta, const uint32_t* __restrict__ act, int64_t rows, int W,
+                                                             float* __restrict__ col_sum) {
+    const int wc = threadIdx.x % W, r0 = threadIdx.x / W, rpb = 256 / W;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + r0; r < rows; r += (int64_t)gridDim.x * rpb) {
+        const int64_t i = r * W + wc;
+        const uint32_t a = act[i];
+        uint32_t d = delta[i];
+        if constexpr (ELEM == 4) {
+            if (!(__builtin_bit_cast(float, a) > 0.0f)) d = 0u;
+            s0 += __builtin_bit_cast(float, d);
+        } else {
+            const uint32_t lo = a & 0xFFFFu, hi = a >> 16;
+            if (!(lo != 0u && lo < 0x8000u)) d &= 0xFFFF0000u;
+            if (!(hi != 0u && hi < 0x8000u)) d &= 0x0000FFFFu;
+            s0 += __builtin_bit_cast(float, d << 16);           // bf16 -> fp32: the same bits in the upper half
+            s1 += __builtin_bit_cast(float, d & 0xFFFF0000u);
+        }
+        delta[i] = d;
+    }
+    // deterministic: every (block, row group) writes its own partial row; the host sums the (gridDim.x * rpb, cols) partials
+    if (threadIdx.x < rpb * W) {
+        float* prow = col_sum + ((size_t)blockIdx.x * rpb + r0) * (size_t)(ELEM == 4 ? W : 2 * W);
+        if constexpr (ELEM == 4) prow[wc] = s0;
+        else { prow[2 * wc] = s0; prow[2 * wc + 1] = s1; }
     }
 }
 
@@ -808,7 +841,7 @@ int sk_max_blur_backward(const float* w, const float* g, int64_t N, int S, float
 int sk_get_bounds_backward(const int64_t* below, const float* g, int64_t N, int C, int K, float* dw, hipStream_t st) {
     if (N == 0) return 0;
     if (K < 2) { return (int)hipMemsetAsync(dw, 0, (size_t)N * C * 4, st); }
-    const size_t lds = WAVES_PER_BLOCK * ((size_t)C + 2) * 4;
+    const size_t lds = WAVES_PER_BLOCK * (size_t)(2 * K) * 4;
     hipLaunchKernelGGL(get_bounds_backward_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, below, g, N, C, K, dw);
     return (int)hipGetLastError();
 }
@@ -833,6 +866,17 @@ int sk_relu_mask(void* delta, const void* act, int elem_bytes, int64_t n, hipStr
     const int64_t words = elem_bytes == 2 ? n / 2 : n;
     if (elem_bytes == 2) hipLaunchKernelGGL(relu_mask_kernel<2>, dim3(blocks_for(words, 256)), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, words);
     else hipLaunchKernelGGL(relu_mask_kernel<4>, dim3(blocks_for(words, 256)), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, words);
+    return (int)hipGetLastError();
+}
+int sk_relu_mask_bias(void* delta, const void* act, int elem_bytes, int64_t rows, int cols, float* col_sum, hipStream_t st) {
+    if (rows == 0) return 0;
+    const int W = cols * elem_bytes / 4;
+    if (W < 1 || W > 256 || (256 % W) != 0) return (int)hipErrorInvalidValue;
+    const int rpb = 256 / W;
+    int64_t blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 1024) blocks = 1024;                            // = nerf_amd_relu_mask_bias_partials() / rpb rows of partial sums
+    if (elem_bytes == 2) hipLaunchKernelGGL(relu_mask_bias_kernel<2>, dim3((int)blocks), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, rows, W, col_sum);
+    else hipLaunchKernelGGL(relu_mask_bias_kernel<4>, dim3((int)blocks), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, rows, W, col_sum);
     return (int)hipGetLastError();
 }
 

@@ -58,8 +58,9 @@ def _wgrad(delta: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _masked(delta: torch.Tensor, act: torch.Tensor, precision: int) -> torch.Tensor:
-    return ops.relu_mask_(delta.contiguous(), act, precision)
+def _masked(delta: torch.Tensor, act: torch.Tensor, precision: int):
+    """(delta * [act > 0] in place, its fp32 column sums) -- the ReLU adjoint and, for free, the bias gradient of that layer."""
+    return ops.relu_mask_bias_(delta.contiguous(), act, precision)
 
 
 def _bgrad(delta: torch.Tensor) -> torch.Tensor:
@@ -77,12 +78,12 @@ def proposal_backward(g_density: torch.Tensor, pts: torch.Tensor, dump: torch.Te
     g = g_density.reshape(M, 1).to(dt)
     h = rows(3)
     gW[4], gb[4] = _wgrad(g, h), g_density.sum().reshape(1)
-    delta = _masked(g * W[4], h, precision)
+    delta, gb[3] = _masked(g * W[4], h, precision)
     for l in (3, 2, 1):
         prev = rows(l - 1)
-        gW[l], gb[l] = _wgrad(delta, prev), _bgrad(delta)
-        delta = _masked(torch.mm(delta, W[l]), prev, precision)
-    gW[0], gb[0] = _wgrad(delta, _encode(pts, 10, dt))[:, :63], _bgrad(delta)
+        gW[l] = _wgrad(delta, prev)
+        delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
+    gW[0] = _wgrad(delta, _encode(pts, 10, dt))[:, :63]
     return gW, gb
 
 
@@ -105,28 +106,28 @@ def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, du
     gW[10], gb[10] = _wgrad(d10, c), _bgrad(d10)
     w10 = torch.zeros((16, W[10].shape[1]), dtype=dt, device=W[10].device)
     w10[:3] = W[10]
-    dc = _masked(torch.mm(_pad16(d10), w10), c, precision)
+    dc, gb[9] = _masked(torch.mm(_pad16(d10), w10), c, precision)
     g6 = rows(6)
     bott = torch.addmm(biases[7].detach().to(dt), g6, W[7].t())                   # the folded forward never forms it
-    gW[9], gb[9] = torch.cat((_wgrad(dc, bott), _wgrad(dc, ed)[:, :27]), dim=1), _bgrad(dc)   # cat(bottle_neck, dir_enc) column blocks
+    gW[9] = torch.cat((_wgrad(dc, bott), _wgrad(dc, ed)[:, :27]), dim=1)          # cat(bottle_neck, dir_enc) column blocks
     dbott = torch.mm(dc, W[9][:, :256].contiguous())
     gW[7], gb[7] = _wgrad(dbott, g6), _bgrad(dbott)
     dsig = g_rgbo[:, 3:4].to(dt)
     gW[8], gb[8] = _wgrad(dsig, g6), g_rgbo[:, 3].sum().reshape(1)
-    delta = _masked(torch.addmm(dsig * W[8], dbott, W[7]), g6, precision)
+    delta, gb[6] = _masked(torch.addmm(dsig * W[8], dbott, W[7]), g6, precision)
     del bott, dbott, dc, c
     for l in (6, 5):
         prev = rows(l - 1)
-        gW[l], gb[l] = _wgrad(delta, prev), _bgrad(delta)
-        delta = _masked(torch.mm(delta, W[l]), prev, precision)
+        gW[l] = _wgrad(delta, prev)
+        delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
     ex = _encode(x.contiguous(), 10, dt)                                            # (M, 63 -> 64)
     h3 = rows(3)
-    gW[4], gb[4] = torch.cat((_wgrad(delta, ex)[:, :63], _wgrad(delta, h3)), dim=1), _bgrad(delta)   # skip layer: cat(encoded_x, h)
-    delta = _masked(torch.mm(delta, W[4][:, 63:].contiguous()), h3, precision)
+    gW[4] = torch.cat((_wgrad(delta, ex)[:, :63], _wgrad(delta, h3)), dim=1)      # skip layer: cat(encoded_x, h)
+    delta, gb[3] = _masked(torch.mm(delta, W[4][:, 63:].contiguous()), h3, precision)
     del h3
     for l in (3, 2, 1):
         prev = rows(l - 1)
-        gW[l], gb[l] = _wgrad(delta, prev), _bgrad(delta)
-        delta = _masked(torch.mm(delta, W[l]), prev, precision)
-    gW[0], gb[0] = _wgrad(delta, ex)[:, :63], _bgrad(delta)
+        gW[l] = _wgrad(delta, prev)
+        delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
+    gW[0] = _wgrad(delta, ex)[:, :63]
     return gW, gb

@@ -416,3 +416,12 @@ def relu_mask_(delta: torch.Tensor, act: torch.Tensor, precision: int) -> torch.
     check(lib.nerf_amd_relu_mask(_ptr(delta), _ptr(act), precision, delta.numel(), _stream()), "nerf_amd_relu_mask")
     return delta
 
+
+def relu_mask_bias_(delta: torch.Tensor, act: torch.Tensor, precision: int):
+    """In place delta = where(act > 0, delta, 0) over a (rows, cols) matrix AND its column sums (fp32) = the bias gradient."""
+    assert delta.is_contiguous() and act.is_contiguous() and delta.shape == act.shape and delta.dtype == act.dtype and delta.dim() == 2
+    n_part = lib.nerf_amd_relu_mask_bias_partials(precision, delta.shape[0], delta.shape[1])
+    part = torch.empty((n_part, delta.shape[1]), dtype=torch.float32, device=delta.device)
+    check(lib.nerf_amd_relu_mask_bias(_ptr(delta), _ptr(act), precision, delta.shape[0], delta.shape[1], _ptr(part), _stream()), "nerf_amd_relu_mask_bias")
+    return delta, part.sum(0)
+

@@ -147,4 +147,4 @@ def test_psnr_at_equal_iterations():
     # gradient carries bf16 operand rounding (like the reference's fp16 AMP), which decorrelates the mini-batch losses within ~30 Adam
     # steps, so its tail only has to stay in the same band
     assert abs(psnr(t_f32) - psnr(t_ref)) <= 0.1 and abs(psnr(t_b16) - psnr(t_ref)) <= 0.1
-    assert abs(tail(h_f32) - tail(h_ref)) <= 0.1 and abs(tail(h_b16) - tail(h_ref)) <= 0.5
+    assert abs(tail(h_f32) - tail(h_ref)) <= 0.1 and abs(tail(h_b16) - tail(h_ref)) <= 0.3
