@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-train-rate", action="store_true", help="skip the training-step rate (train_step)")
     p.add_argument("--no-gemm-ref", action="store_true", help="skip the hipBLASLt GEMM reference measurement (roofline.gemm_ref)")
     p.add_argument("--fused", action="store_true",
                    help="fine MLP with the fused compositing epilogue (one launch for rows 8-10) instead of two launches; A/B switch")
@@ -117,6 +118,22 @@ def gemm_reference(dev):
         out[name + "_tflops"] = 2.0 * m * k * n * reps / (s.elapsed_time(e) * 1e-3) / 1e12
         del x, w, y
     out["note"] = "torch.matmul (hipBLASLt) bf16 on random data, measured on this box after the timed region"
+    return out
+
+
+def train_rate(precision):
+    """Optional second figure of SURVEY 8d: rays/s of a whole training step (train.py:164-199 body + Adam: HIP training forward,
+    GEMM-chain / HIP backward, optimizer) on synthetic rays, measured after the timed region; never part of `value`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_train_rate", os.path.join(ROOT, "scripts", "gpu_train_rate.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {"unit": "rays/s (fwd + bwd + Adam step, 64+128 samples)", "precision": precision}
+    for n in (512, 4096):
+        dt = mod.run(n, 64, 128, precision, iters=10, warm=3, quiet=True)
+        out["rays_%d" % n] = {"rays_per_s": n / dt, "ms_per_iter": dt * 1e3}
+    import nerf_amd
+    nerf_amd.set_precision(precision)
     return out
 
 
@@ -267,6 +284,8 @@ def main():
         }
         if world == 1 and not a.no_gemm_ref and prec == ops.BF16:
             rec["roofline"]["gemm_ref"] = gemm_reference(dev)
+        if world == 1 and not a.no_train_rate and not is_ref:
+            rec["train_step"] = train_rate(a.precision)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
         print(json.dumps(rec), flush=True)

@@ -19,7 +19,7 @@ from nerf_amd.utils import inverseSample
 NEAR, FAR = 2.0, 6.0
 
 
-def run(n_rays, c_n, f_n, precision, iters=20, warm=5):
+def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False):
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, mip = ProposalNetwork(10, 256).cuda().train(), MipNeRF(10, 4, 256).cuda().train()
@@ -53,7 +53,9 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    print("train step  %5d rays  %3d+%3d samples  %s : %7.2f ms/iter  %9.0f rays/s" % (n_rays, c_n, f_n, precision, dt * 1e3, n_rays / dt), flush=True)
+    if not quiet:
+        print("train step  %5d rays  %3d+%3d samples  %s : %7.2f ms/iter  %9.0f rays/s" % (n_rays, c_n, f_n, precision, dt * 1e3, n_rays / dt), flush=True)
+    return dt
 
 
 if __name__ == "__main__":
