@@ -43,7 +43,7 @@ for p in ("p1", "p2", "p3", "p4"):
         if p == "p1" and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             agg[k]["ns_p1"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
-lines = ["# %s -- rocprofv3 summary of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` on MI355X" % prefix,
+lines = ["# %s -- rocprofv3 summary of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-ref --no-train-rate` on MI355X" % prefix,
          "Source: `scripts/gpu_round_profile.sh` (one `--kernel-trace --stats` run + four separate `--pmc` passes), condensed by "
          "`scripts/summarize_round_profile.py`. Native rocprofv3 stats: `%s_kernel_stats.csv`; counter rows: `%s_pmc_p1..4.csv`." % (prefix, prefix), "",
          "| kernel | avg ms (kernel-trace) | MFMA busy cycles/launch | MFMA pipe busy | clock GHz (profiled pass) | WAIT_ANY | WAIT_INST | FETCH_SIZE KiB | WRITE_SIZE KiB | LDS bank conflicts |",
