@@ -832,3 +832,26 @@ def test_refnerf_train_step_vs_reference_golden(A, golden):
                      ("g_bottle", net.bottle_neck.weight.grad[:8]), ("g_dir0", net.dir_block1[0].weight.grad[:8]), ("g_spec", net.spec_rgb_head[0].weight.grad),
                      ("g_prop_l0", prop.layers[0].weight.grad[:8]), ("g_prop_head", prop.layers[8].weight.grad)):
         assert max_abs(got.cpu(), g[key]) <= 2e-3 * max(1.0, g[key].abs().max().item()), key
+
+
+def test_backward_kernels_full_size_linearity(A):
+    """BASELINE size (640 000 rays x 128 samples): the backward kernels are linear in the upstream gradient and agree with the
+    forward through a directional derivative -- size-independent properties, no oracle needed."""
+    N, S = 640000, 128
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    rgbo = torch.cat((torch.rand(N, S, 3, device="cuda", generator=gen), torch.randn(N, S, 1, device="cuda", generator=gen)), -1)
+    z = torch.sort(torch.rand(N, S, device="cuda", generator=gen) * 4 + 2, dim=-1)[0]
+    dirs = torch.randn(N, 3, device="cuda", generator=gen)
+    g1, g2 = torch.randn(N, 3, device="cuda", generator=gen), torch.randn(N, 3, device="cuda", generator=gen)
+    bwd = lambda g: A.ops.composite_backward(rgbo, z, dirs, True, True, A.ops.ACT_RELU, None, g, None, None)
+    b1, b2, b12 = bwd(g1), bwd(g2), bwd(2.0 * g1 - 0.5 * g2)
+    lin = 2.0 * b1 - 0.5 * b2
+    assert (b12 - lin).abs().max().item() <= 1e-4 * max(1.0, lin.abs().max().item())
+    # <g, J v> = <J^T g, v> with a finite-difference J v of the forward (colour channels only: the map is linear in them)
+    v = torch.zeros_like(rgbo)
+    v[..., :3] = torch.randn(N, S, 3, device="cuda", generator=gen)
+    f0 = A.ops.composite(rgbo, z, dirs, True, True, A.ops.ACT_RELU, None, want_weights=False)[0]
+    f1 = A.ops.composite(rgbo + v, z, dirs, True, True, A.ops.ACT_RELU, None, want_weights=False)[0]
+    lhs = ((f1 - f0) * g1).sum(dtype=torch.float64).item()
+    rhs = (b1 * v).sum(dtype=torch.float64).item()
+    assert abs(lhs - rhs) <= 2e-4 * max(1.0, abs(rhs))
