@@ -822,6 +822,16 @@ def test_refnerf_train_step_vs_reference_golden(A, golden):
         loss.backward()
     finally:
         torch.normal = real_normal
+    # the same train-mode forward through the bf16 kernels (noise path included): close to the reference's fp32 numbers
+    A.pkg.set_precision("bf16")
+    torch.normal = lambda *a, **k: noise
+    try:
+        with torch.no_grad():
+            rgbo16, nrm16 = net.forward(pos.detach(), d.contiguous())
+    finally:
+        torch.normal = real_normal
+        A.pkg.set_precision("fp32")
+    assert max_abs(rgbo16.cpu(), g["rgbo_raw"]) <= 3e-2 * max(1.0, g["rgbo_raw"].abs().max().item()) and max_abs(nrm16.cpu(), g["pred_normal"]) <= 5e-2
     assert torch.equal(sort_ids.cpu(), g["sort_ids"]) and torch.equal(below.cpu(), g["below_merged"])
     assert max_abs(fl.cpu(), g["z_merged"]) <= 2e-5 and max_abs(rgbo_raw.cpu(), g["rgbo_raw"]) <= 2e-5 and max_abs(nrm.detach().cpu(), g["pred_normal"]) <= 2e-5
     assert max_abs(wts.detach().cpu(), g["weights"]) <= 2e-5 and max_abs(rend.detach().cpu(), g["rendered"]) <= 2e-5
