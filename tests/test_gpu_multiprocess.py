@@ -158,3 +158,50 @@ def test_two_rank_training_step_gradients(tmp_path):
         want = (0.5 * (b0 + b1)).cpu()
         assert (a - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
 
+
+
+def test_native_amp_flow_matches_plain_bf16():
+    """train.py's `opt_mode native` flow -- torch.autocast around the step, GradScaler around backward -- selects the bf16 kernels and
+    gives the same parameter gradients as the plain bf16 path (a power-of-two loss scale is exact in bf16/fp32 arithmetic)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import torch.nn.functional as F
+    import nerf_amd
+    from nerf_amd import ops
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.utils import inverseSample
+    rays, tgt, u1, u2 = _train_inputs(3)
+    res = (FAR - NEAR) / C_TRAIN
+
+    def loss_of(prop, mip):
+        z_c = torch.linspace(NEAR, FAR - res, C_TRAIN).cuda() + u1 * res
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
+        pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(prop.forward(pts)), z_c, rays[:, 3:]), 0.01)
+        z_f, below = inverseSample(pw, z_c, F_TRAIN + 1, sort=True, u=u2)
+        z_f = z_f[..., :-1].contiguous()
+        rend, wts, _ = NeRF.render(mip.forward(NeRF.length2pts(rays, z_f)), z_f, rays[:, 3:])
+        return ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+
+    grads = []
+    for amp in (False, True):
+        nerf_amd.set_precision("bf16" if not amp else None)          # None: follow torch.autocast, like the reference's layers
+        prop, mip = _nets()
+        prop.train(); mip.train()
+        params = list(mip.parameters()) + list(prop.parameters())
+        if amp:
+            scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+            opt = torch.optim.SGD(params, lr=0.0)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                assert ops.current_precision() == ops.BF16
+                loss = loss_of(prop, mip)
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+        else:
+            loss_of(prop, mip).backward()
+        grads.append([p.grad.clone() for p in params])
+    nerf_amd.set_precision("fp32")
+    for a, b in zip(*grads):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
