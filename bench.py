@@ -50,7 +50,7 @@ def parse():
                    help="mip = BASELINE configs[1] (the headline); ref = Ref-NeRF render path (configs[3] shape: 64 + 192 merged samples)")
     p.add_argument("--weights", default="small", choices=["small", "he", "zero"],
                    help="closed-form test weights; 'zero' is a power/DVFS diagnostic, never a reported number")
-    p.add_argument("--cpu-rays", type=int, default=5000, help="rays of the same workload timed on the host cores")
+    p.add_argument("--cpu-rays", type=int, default=20000, help="rays of the same workload timed on the host cores (~14 s of CPU work)")
     return p.parse_args()
 
 
