@@ -127,7 +127,11 @@ DEVINL void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-constexpr int SORT_NB = 256, SORT_CAP = 6;
+#ifndef SORT_NB_DEF
+#define SORT_NB_DEF 256
+#define SORT_CAP_DEF 6
+#endif
+constexpr int SORT_NB = SORT_NB_DEF, SORT_CAP = SORT_CAP_DEF, SORT_PER_LANE = SORT_NB / 64;
 constexpr int SORT_LDS_FLOATS = 2 * SORT_NB + SORT_NB * SORT_CAP / 2;      // cnt, pre (int) + members (uint16)
 
 // uf(i, k) = the uniform of sample k = lane + 64 i (a global pointer, or registers loaded one ray ahead)
@@ -206,16 +210,16 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
         }
         return;
     }
-    {   // exclusive prefix sum of the 256 bucket counts: 4 per lane
-        int c[4], tot = 0;
+    {   // exclusive prefix sum of the SORT_NB bucket counts: SORT_NB / 64 per lane (128 x 8, 128 x 6 and 64 x 12 layouts measured slower: more rank work per bucket than the extra occupancy pays)
+        int c[SORT_PER_LANE], tot = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = cnt[lane * 4 + i]; tot += c[i]; }
+        for (int i = 0; i < SORT_PER_LANE; ++i) { c[i] = cnt[lane * SORT_PER_LANE + i]; tot += c[i]; }
         int incl = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
         int run = incl - tot;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { pre[lane * 4 + i] = run; run += c[i]; }
+        for (int i = 0; i < SORT_PER_LANE; ++i) { pre[lane * SORT_PER_LANE + i] = run; run += c[i]; }
     }
     lds_wave_sync();
     for (int k = lane, i = 0; k < K; k += 64, ++i) {
