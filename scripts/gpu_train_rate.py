@@ -19,11 +19,11 @@ from nerf_amd.utils import inverseSample
 NEAR, FAR = 2.0, 6.0
 
 
-def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False):
+def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False):
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, mip = ProposalNetwork(10, 256).cuda().train(), MipNeRF(10, 4, 256).cuda().train()
-    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4)
+    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4, capturable=graph)
     o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
     rays = torch.cat((o, d), -1).cuda().contiguous()
@@ -36,7 +36,7 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False):
         pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
         dens = F.softplus(prop.forward(pts))
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
-        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True)
+        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda") if graph else None)
         z_f = z_f[..., :-1].contiguous()
         rgbo = mip.forward(NeRF.length2pts(rays, z_f))
         rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
@@ -48,6 +48,14 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False):
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
+    if graph:
+        # whole step (forward, backward, Adam, re-pack) as ONE hipGraph: the 512-ray step is launch-bound (~200 launches)
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            step()
+        step_eager, step = step, g.replay
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
@@ -59,8 +67,8 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:                                  # one configuration (for profiling): n_rays precision
-        run(int(sys.argv[1]), 64, 128, sys.argv[2], iters=5, warm=2)
+    if len(sys.argv) > 1:                                  # one configuration (for profiling): n_rays precision [graph]
+        run(int(sys.argv[1]), 64, 128, sys.argv[2], iters=5 if len(sys.argv) < 4 else 50, warm=2 if len(sys.argv) < 4 else 5, graph=len(sys.argv) > 3)
         sys.exit(0)
     for prec in ("bf16", "fp32"):
         for n in (512, 4096, 16384):

@@ -205,3 +205,59 @@ def test_native_amp_flow_matches_plain_bf16():
     nerf_amd.set_precision("fp32")
     for a, b in zip(*grads):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+def test_training_step_captured_in_a_hipgraph():
+    """The whole step (HIP training forwards, GEMM-chain / HIP backward, Adam, weight re-pack) can be captured once and replayed:
+    nothing in it synchronises or allocates outside torch's graph pool, and the ctypes-launched kernels land on the capture stream.
+    Three replays == three eager steps from the same state on the same batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import torch.nn.functional as F
+    import nerf_amd
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.utils import inverseSample
+    nerf_amd.set_precision("fp32")
+    rays, tgt, u1, u2 = _train_inputs(5)
+    res = (FAR - NEAR) / C_TRAIN
+    base = torch.linspace(NEAR, FAR - res, C_TRAIN).cuda()
+
+    def make():
+        prop, mip = _nets()
+        prop.train(); mip.train()
+        opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-3, capturable=True)
+
+        def step():
+            z_c = base + u1 * res
+            pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
+            pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(prop.forward(pts)), z_c, rays[:, 3:]), 0.01)
+            z_f, below = inverseSample(pw, z_c, F_TRAIN + 1, sort=True, u=u2)
+            z_f = z_f[..., :-1].contiguous()
+            rend, wts, _ = NeRF.render(mip.forward(NeRF.length2pts(rays, z_f)), z_f, rays[:, 3:])
+            loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        return prop, mip, step
+
+    prop_e, mip_e, step_e = make()
+    for _ in range(4):                                                # 1 warm-up + 3
+        step_e()
+    prop_g, mip_g, step_g = make()
+    step_g()                                                          # warm-up (lazy kernel attributes, optimizer state) outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step_g()                                                      # (capture does not execute)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(list(mip_g.parameters()) + list(prop_g.parameters()), list(mip_e.parameters()) + list(prop_e.parameters())):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+    # and the re-pack inside the graph followed the updated weights: the captured forward renders what an eager forward renders now
+    with torch.no_grad():
+        probe = torch.rand(64, 8, 6).cuda()
+        assert torch.allclose(mip_g.eval().forward(probe), mip_e.eval().forward(probe), atol=1e-5)
