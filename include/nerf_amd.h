@@ -80,6 +80,9 @@ typedef struct nerf_amd_samples {
     int32_t      H, W;         /* mode 2                                       */
     float        fx, fy;       /* mode 2: x is divided by fx, y by fy          */
     float        pose[12];     /* mode 2: row-major 3x4 camera-to-world (host) */
+    int32_t      contract;     /* != 0: Mip-NeRF 360 scene contraction of the sample POSITION before it is encoded
+                                  (Barron et al. 2022, eq. 10): x -> x if |x| <= 1 else (2 - 1/|x|) x/|x|.  Not in the
+                                  reference (BASELINE config 5 only); occupies former tail padding, 0 = off.        */
 } nerf_amd_samples;
 
 /* ------------------------------------------------------------------------------------------------

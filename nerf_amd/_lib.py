@@ -24,7 +24,7 @@ class Samples(C.Structure):
     _fields_ = [("mode", C.c_int32), ("S", C.c_int32), ("M", C.c_int64), ("pts", c_void), ("pts_stride", C.c_int32),
                 ("z_stride", C.c_int32), ("rays", c_void), ("z", c_void), ("z_base", c_void), ("u", c_void),
                 ("z_jitter", C.c_float), ("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
-                ("pose", C.c_float * 12)]
+                ("pose", C.c_float * 12), ("contract", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/nerf_amd.h one to one (tests check the two agree)

@@ -357,12 +357,14 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     nerf_amd_samples sc{};                                  // rows 2-4: stratified z fused into the proposal MLP
     sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
     sc.z_jitter = jitter; sc.z_stride = C;
+    sc.contract = camera ? camera->contract : 0;           // (the descriptor may accompany explicit rays just to carry this flag)
     if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7: weights -> max-blur(0.01) -> inverse sampling of n_fine+1 sorted depths (procedures.py:68-70)
     if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, z_fine,
                             nullptr, nullptr, nullptr, st)) return hip_status(e, "resample");
     nerf_amd_samples sf{};                                  // rows 8-9: drop the last depth, length2pts fused into the MLP
     sf.mode = 1; sf.rays = rays; sf.S = n_fine; sf.M = N * n_fine; sf.z = z_fine; sf.z_stride = n_fine + 1;
+    sf.contract = sc.contract;
     // rows 9 and 10 as two launches: measured 2-3 % faster than the fused epilogue of nerf_amd_mip_forward_composite on
     // MI355X, and the composite kernel's HBM rate stays individually measurable
     if (int e = mlp_launch_mip(packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");

@@ -490,12 +490,22 @@ DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG])
 // ------------------------------------------------------------------------------------------------
 struct Sample { float x, y, z, dx, dy, dz; };
 
+// Mip-NeRF 360 scene contraction (Barron et al. 2022, eq. 10) of a position; the direction is left alone
+DEVINL void contract_position(Sample& r) {
+    const float n = norm3(r.x, r.y, r.z);
+    if (n > 1.0f) {
+        const float k = (2.0f - 1.0f / n) / n;
+        r.x *= k; r.y *= k; r.z *= k;
+    }
+}
+
 DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) {
     Sample r;
     if (s.mode == 0) {
         const float* p = s.pts + m * s.pts_stride;
         r.x = p[0]; r.y = p[1]; r.z = p[2];
         if (want_dir) { r.dx = p[3]; r.dy = p[4]; r.dz = p[5]; } else { r.dx = r.dy = r.dz = 0.0f; }
+        if (s.contract) contract_position(r);
         return r;
     }
     const int64_t n = m / s.S;
@@ -517,6 +527,7 @@ DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) 
     if (s.z) zv = s.z[n * s.z_stride + si];
     else     zv = s.z_base[si] + s.u[n * s.S + si] * s.z_jitter;                 // procedures.py:65
     r.x = ox + zv * r.dx; r.y = oy + zv * r.dy; r.z = oz + zv * r.dz;           // procedures.py:66
+    if (s.contract) contract_position(r);
     return r;
 }
 

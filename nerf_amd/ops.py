@@ -57,18 +57,21 @@ def pack_weights(net: int, precision: int, weights: Sequence[torch.Tensor], bias
 
 
 # ------------------------------------------------------------------------------------------------ MLPs
-def _samples_pts(pts: torch.Tensor, stride: int) -> Samples:
+def _samples_pts(pts: torch.Tensor, stride: int, contract: bool = False) -> Samples:
     s = Samples()
     s.mode = 0
     s.M = pts.numel() // stride
     s.pts = pts.data_ptr()
     s.pts_stride = stride
+    s.contract = int(bool(contract))
     return s
 
 
 def samples_rays(rays: torch.Tensor, S: int, z: Optional[torch.Tensor] = None, z_base: Optional[torch.Tensor] = None,
-                 u: Optional[torch.Tensor] = None, z_jitter: float = 0.0) -> Samples:
+                 u: Optional[torch.Tensor] = None, z_jitter: float = 0.0, contract: bool = False) -> Samples:
+    """`contract`: Mip-NeRF 360 scene contraction of the sample positions before encoding (not in the reference; BASELINE config 5)."""
     s = Samples()
+    s.contract = int(bool(contract))
     s.mode = 1
     s.S = S
     s.M = rays.shape[0] * S
@@ -84,13 +87,13 @@ def samples_rays(rays: torch.Tensor, S: int, z: Optional[torch.Tensor] = None, z
     return s
 
 
-def proposal_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor) -> torch.Tensor:
+def proposal_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
     """pts (..., 3) -> density (...)   [addtional.py:88-96]"""
     pts = _dev(pts, "pts")
     out = torch.empty(pts.shape[:-1], dtype=torch.float32, device=pts.device)
     if out.numel() == 0:
         return out
-    s = _samples_pts(pts, 3)
+    s = _samples_pts(pts, 3, contract)
     check(lib.nerf_amd_proposal_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
     return out
 
@@ -101,13 +104,13 @@ def proposal_forward_samples(packed, precision, s: Samples, shape, device) -> to
     return out
 
 
-def mip_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor) -> torch.Tensor:
+def mip_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
     """pts (..., 6) -> rgbo (..., 4)   [mip_model.py:41-60]"""
     pts = _dev(pts, "pts")
     out = torch.empty(pts.shape[:-1] + (4,), dtype=torch.float32, device=pts.device)
     if out.numel() == 0:
         return out
-    s = _samples_pts(pts, 6)
+    s = _samples_pts(pts, 6, contract)
     check(lib.nerf_amd_mip_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
     return out
 
@@ -307,9 +310,14 @@ def resample(density, z, z_base, u_strat, z_jitter, rays, u_inv, K, softplus=Fal
 
 def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                 want_depth=True, want_weights=False, workspace: Optional[torch.Tensor] = None, camera: Optional[Samples] = None,
-                ray_offset: int = 0, n_rays: Optional[int] = None):
-    """The tile body of render_image (procedures.py:64-85) for all given rays in four launches."""
+                ray_offset: int = 0, n_rays: Optional[int] = None, contract: bool = False):
+    """The tile body of render_image (procedures.py:64-85) for all given rays in four launches.  `contract`: Mip-NeRF 360 scene
+    contraction of every sample position (proposal and fine) before encoding."""
     dev = u_strat.device
+    if contract and camera is None:
+        camera = Samples()                                   # carries only the flag next to explicit rays
+    if camera is not None:
+        camera.contract = int(bool(contract))
     N = u_strat.shape[0] if n_rays is None else n_rays
     need = lib.nerf_amd_render_workspace_bytes(N, n_fine)
     if workspace is None or workspace.numel() < need:

@@ -44,9 +44,11 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
                  near: float, far: float, sample_num: int = 128, white_bkg: bool = False, render_depth=False,
-                 render_normal=False, rng: str = "reference") -> dict:
+                 render_normal=False, rng: str = "reference", contract: bool = False) -> dict:
     """Whole-image inference (procedures.py:34-97) -> {"rgb" (3,H,W) [, "depth_img" (3,H,W)]} on
-    ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference."""
+    ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference.
+    ``rng`` and ``contract`` are additions: ``contract=True`` applies the Mip-NeRF 360 scene contraction to every sample
+    position before the networks encode it (unbounded scenes, BASELINE config 5; not available for Ref-NeRF)."""
     if not isinstance(image_size, Iterable):
         image_size = (image_size, image_size)
     is_ref_model = type(network).__name__ == "RefNeRF"
@@ -72,8 +74,10 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     normal_px = None
     if not is_ref_model:
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
-                                           sample_num, near, far, white_bkg, want_depth=bool(render_depth))
+                                           sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract)
     else:
+        if contract:
+            raise NotImplementedError("nerf_amd: scene contraction is wired for the MipNeRF render path only")
         # Ref-NeRF branch (procedures.py:71-74): coarse and fine depths are merged and sorted, the last one dropped,
         # sigma -> softplus(sigma + 0.5) before compositing.  The merge sort is a device torch.sort (index plumbing).
         jitter = (far - near) / sample_num

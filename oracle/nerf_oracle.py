@@ -371,19 +371,33 @@ def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float):
 # --------------------------------------------------------------------------------------------
 # the per-batch pipeline = body of the render_image tile loop (procedures.py:64-85), non-ref
 # --------------------------------------------------------------------------------------------
+def contract(x: Tensor) -> Tensor:
+    """Mip-NeRF 360 scene contraction (Barron et al. 2022, eq. 10): x if |x| <= 1 else (2 - 1/|x|) x/|x|.  NOT in the reference
+    (BASELINE config 5 names it; parity unpinned): this is the build's own definition, which the HIP kernels are tested against."""
+    n = x.norm(dim=-1, keepdim=True)
+    k = torch.where(n > 1.0, (2.0 - 1.0 / n.clamp_min(1e-30)) / n.clamp_min(1e-30), torch.ones_like(n))
+    return x * k
+
+
 def render_rays(prop_sd, mip_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float,
                 sample_num: int = 128, white_bkg: bool = False, emulate_bf16: bool = False,
-                stages: Optional[dict] = None):
+                stages: Optional[dict] = None, contracted: bool = False):
     """rays (N,6), u_strat (N,64), u_inv (N,sample_num+1) -> rgb (N,3), weights (N,S), depth (N,).
-    ``stages`` (optional dict) receives every intermediate for stage-by-stage parity tests."""
+    ``stages`` (optional dict) receives every intermediate for stage-by-stage parity tests.  ``contracted`` (not in the
+    reference): every sample position goes through contract() before the networks see it; depths stay metric."""
     z_c = stratified_render(near, far, sample_num, u_strat)
     pts_c = rays[:, None, :3] + z_c[..., None] * rays[:, None, 3:]
+    if contracted:
+        pts_c = contract(pts_c)
     density = proposal_forward(prop_sd, pts_c, emulate_bf16=emulate_bf16)       # no softplus here (:67-68)
     w_raw = sigma_to_weights(density, z_c, rays[:, 3:])
     w_prop = max_blur(w_raw, 0.01)
     z_f, below = inverse_sample(w_prop, z_c, u_inv, sort=True)
     z_f = z_f[..., :-1]
-    rgbo = mip_forward(mip_sd, length2pts(rays, z_f), emulate_bf16=emulate_bf16)
+    pts_f = length2pts(rays, z_f)
+    if contracted:
+        pts_f = torch.cat((contract(pts_f[..., :3]), pts_f[..., 3:]), dim=-1)
+    rgbo = mip_forward(mip_sd, pts_f, emulate_bf16=emulate_bf16)
     rgb, w, extras = composite(rgbo, z_f, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far))
     if stages is not None:
         stages.update(z_coarse=z_c, density=density, w_raw=w_raw, w_prop=w_prop, z_fine=z_f, below=below,

@@ -36,7 +36,7 @@ def test_struct_layout_matches_header():
     # 8-byte alignment of the pointer members, 12 floats of pose at the end
     assert ctypes.sizeof(_lib.Samples) == 8 + 8 + 8 + 4 + 4 + 8 * 4 + 4 + 4 + 4 + 4 + 4 + 48 + 4
     assert _lib.Samples.M.offset == 8 and _lib.Samples.pts.offset == 16 and _lib.Samples.rays.offset == 32
-    assert _lib.Samples.pose.offset == 84
+    assert _lib.Samples.pose.offset == 84 and _lib.Samples.contract.offset == 132      # the flag sits in the former tail padding
 
 
 def test_pure_queries_without_gpu():

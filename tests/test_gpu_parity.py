@@ -865,3 +865,30 @@ def test_backward_kernels_full_size_linearity(A):
     lhs = ((f1 - f0) * g1).sum(dtype=torch.float64).item()
     rhs = (b1 * v).sum(dtype=torch.float64).item()
     assert abs(lhs - rhs) <= 2e-4 * max(1.0, abs(rhs))
+
+
+def test_scene_contraction_flag(A):
+    """`contract` in the samples descriptor (Mip-NeRF 360 eq. 10; BASELINE config 5, parity unpinned -- own definition in
+    oracle.contract): MLP kernels on contracted positions and the whole render path, against the oracle; off by default."""
+    prop, mip = build_nets(A, "small")
+    A.pkg.set_precision("fp32")
+    gen = torch.Generator().manual_seed(77)
+    pts = torch.cat((torch.randn(300, 3, generator=gen) * torch.logspace(-1, 2, 300)[:, None], torch.randn(300, 3, generator=gen)), -1)
+    with torch.no_grad():
+        got = A.ops.mip_forward(mip.packed(A.ops.F32), A.ops.F32, pts.cuda(), contract=True).cpu()
+        want = O.mip_forward(W.mip_state("small"), torch.cat((O.contract(pts[:, :3]), pts[:, 3:]), -1))
+        assert max_abs(got, want) <= 2e-5
+        assert max_abs(A.ops.proposal_forward(prop.packed(A.ops.F32), A.ops.F32, pts[:, :3].contiguous().cuda(), contract=True).cpu(),
+                       O.proposal_forward(W.proposal_state("small"), O.contract(pts[:, :3]))) <= 2e-5
+        assert not torch.equal(got, A.ops.mip_forward(mip.packed(A.ops.F32), A.ops.F32, pts.cuda()).cpu())
+        # render path: unbounded-style rays (far = 40) through both networks
+        N = 96
+        o = torch.tensor([0.0, 0.0, 0.5]).expand(N, 3)
+        d = F.normalize(torch.randn(N, 3, generator=gen), dim=-1)
+        rays = torch.cat((o, d), -1).contiguous()
+        u1, u2 = torch.rand(N, 64, generator=gen), torch.rand(N, 129, generator=gen)
+        near, far = 0.1, 40.0
+        rgb, depth, w, _ = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, rays.cuda(), torch.linspace(near, far, 64).cuda(),
+                                             u1.cuda(), u2.cuda(), 128, near, far, True, want_depth=True, want_weights=True, contract=True)
+        r_rgb, r_w, r_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), rays, u1, u2, near, far, 128, white_bkg=True, contracted=True)
+        assert max_abs(rgb.cpu(), r_rgb) <= 1e-4 and max_abs(w.cpu(), r_w) <= 1e-4 and max_abs(depth.cpu(), r_depth) <= 1e-3

@@ -222,3 +222,19 @@ def test_g17_ref_train_step(golden):
         assert max_abs(got, g[key]) <= 2e-5 * max(1.0, g[key].abs().max().item()), key
     assert max_abs(prop["layers.0.weight"].grad[:8], g["g_prop_l0"]) <= 5e-4 * max(1.0, g["g_prop_l0"].abs().max().item())
     assert max_abs(prop["layers.8.weight"].grad, g["g_prop_head"]) <= 2e-5 * max(1.0, g["g_prop_head"].abs().max().item())
+
+
+def test_contraction_definition():
+    """contract() (Mip-NeRF 360 eq. 10; the build's own definition, parity unpinned): identity inside the unit ball, continuous at
+    the boundary, image inside radius 2, direction preserved, monotone in |x|."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4000, 3, generator=g) * torch.logspace(-2, 4, 4000)[:, None]
+    c = O.contract(x)
+    n, cn = x.norm(dim=-1), c.norm(dim=-1)
+    inside = n <= 1.0
+    assert torch.equal(c[inside], x[inside])
+    assert (cn[~inside] < 2.0).all() and (cn[~inside] >= 1.0 - 1e-6).all()
+    assert torch.allclose(cn[~inside], 2.0 - 1.0 / n[~inside], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(c / cn[:, None], x / n[:, None], atol=1e-5)
+    edge = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0000001, 0.0]])
+    assert torch.allclose(O.contract(edge), edge, atol=1e-6)
