@@ -892,3 +892,26 @@ def test_scene_contraction_flag(A):
                                              u1.cuda(), u2.cuda(), 128, near, far, True, want_depth=True, want_weights=True, contract=True)
         r_rgb, r_w, r_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), rays, u1, u2, near, far, 128, white_bkg=True, contracted=True)
         assert max_abs(rgb.cpu(), r_rgb) <= 1e-4 and max_abs(w.cpu(), r_w) <= 1e-4 and max_abs(depth.cpu(), r_depth) <= 1e-3
+
+
+def test_render_image_config5_shape_untiled_contracted(A):
+    """BASELINE config 5's shape class: a non-square image whose width no reference tile size divides (the reference raises there;
+    this build renders un-tiled), unbounded near/far with scene contraction, tuple focal -- render_image vs the oracle on the same
+    CPU-generator uniforms."""
+    prop, mip = build_nets(A, "small")
+    A.pkg.set_precision("fp32")
+    H, Wd, near, far, n_f = 41, 67, 0.2, 30.0, 64
+    pose = O.pose_spherical(25.0, -20.0, 1.5)[:3]
+    focal = (55.0, 48.0)                                                            # (fy, fx) tuple form (procedures.py:45-47)
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        res = A.procedures.render_image(mip.eval(), prop.eval(), pose.cuda(), (H, Wd), focal, near, far, n_f, white_bkg=True, render_depth=True,
+                                        contract=True)
+    torch.manual_seed(2024)
+    u1, u2 = torch.rand((H * Wd, 64)), torch.rand((H * Wd, n_f + 1))
+    dirs = O.ray_dirs_image(pose, H, Wd, focal).reshape(-1, 3)
+    rays = torch.cat((pose[:, -1].expand(H * Wd, -1), dirs), -1)
+    rgb, _, depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), rays, u1, u2, near, far, n_f, white_bkg=True, contracted=True)
+    assert res["rgb"].shape == (3, H, Wd) and res["depth_img"].shape == (3, H, Wd)
+    assert max_abs(res["rgb"].cpu(), rgb.view(H, Wd, 3).permute(2, 0, 1)) <= 1e-4
+    assert max_abs(res["depth_img"][0].cpu(), depth.view(H, Wd)) <= 1e-3
