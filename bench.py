@@ -196,10 +196,9 @@ def main():
         rays = ops.generate_rays(pose, H, W, fx, fy, dev)                                            # row 1
         sc = ops.samples_rays(rays, C_COARSE, z_base=z_base, u=u_strat, z_jitter=jitter)            # rows 2-4
         dens = ops.proposal_forward_samples(pk_prop, prec, sc, (n_rays, C_COARSE), dev)
-        z_fine, _, _, _ = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1)   # rows 5-7
+        z_fine, _, _, z_c = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1, want_zc=is_ref)   # rows 5-7
         if is_ref:                                                                                    # procedures.py:71-74
-            z_fine, _, _, z_c = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1, want_zc=True)
-            z_all = torch.sort(torch.cat((z_fine, z_c), dim=-1), dim=-1)[0][:, :-1].contiguous()
+            z_all = ops.merge_depths(z_fine, z_c)
             if timed_idx is not None:
                 ev[timed_idx][0].record()
             rgbo, _ = ops.ref_forward_samples(pk_mip, prec, ops.samples_rays(rays, z_all.shape[-1], z=z_all), (n_rays, z_all.shape[-1]), dev,

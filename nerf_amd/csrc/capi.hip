@@ -16,6 +16,7 @@ int mlp_launch_proposal_train(const void*, int, const nerf_amd_samples&, float*,
 int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
 int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t);
 int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
+int sk_merge_sorted(const float*, const float*, int64_t, int, int, float*, hipStream_t);
 int sk_relu_mask_bias(void*, const void*, int, int64_t, int, float*, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
@@ -236,6 +237,12 @@ int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, in
     if (N < 0 || C < 1 || C > 4096 || K < 2) return fail(NERF_AMD_EINVAL, "bad size");
     if (N && (!w_prop || !below || !bounds)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_get_bounds(w_prop, below, N, C, K, bounds, S(stream)), "nerf_amd_get_bounds");
+}
+
+int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N, int K, int C, float* z_out, void* stream) {
+    if (N < 0 || K < 1 || C < 1 || K + C > 8192) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N && (!z_fine || !z_coarse || !z_out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_merge_sorted(z_fine, z_coarse, N, K, C, z_out, S(stream)), "nerf_amd_merge_depths");
 }
 
 // ---- training forward: the MLP kernels also dump their hidden activations ----

@@ -740,6 +740,38 @@ __global__ __launch_bounds__(256) void relu_mask_bias_kernel(uint32_t* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------- row 8 (Ref-NeRF render path)
+// coarseFineMerge's sort (nerf_base.py:59-73) for the render path: both inputs are already ascending (the K fine depths come
+// sorted out of the resampling, the C coarse ones are stratified), so the sort of their concatenation is a MERGE: element i of
+// `a` goes to i + #(b < a_i), element j of `b` to j + #(a <= b_j) (binary searches in LDS).  The last merged depth is dropped.
+// Sorted VALUES are independent of how ties are ordered, so z_out equals torch.sort(cat(a, b))[0][:, :-1] bit for bit.
+__global__ __launch_bounds__(256) void merge_sorted_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t N, int K, int C,
+                                                           float* __restrict__ out) {
+    float* la = reinterpret_cast<float*>(smem) + wave_in_block() * (K + C);
+    float* lb = la + K;
+    const int lane = lane_id();
+    const int T = K + C - 1;
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        for (int i = lane; i < K; i += 64) la[i] = a[n * K + i];
+        for (int j = lane; j < C; j += 64) lb[j] = b[n * C + j];
+        lds_wave_sync();
+        float* o = out + n * T;
+        for (int i = lane; i < K; i += 64) {
+            const float v = la[i];
+            int lo = 0, hi = C;                                 // #(b < v)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (lb[mid] < v) lo = mid + 1; else hi = mid; }
+            if (i + lo < T) o[i + lo] = v;
+        }
+        for (int j = lane; j < C; j += 64) {
+            const float v = lb[j];
+            int lo = 0, hi = K;                                 // #(a <= v)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (la[mid] <= v) lo = mid + 1; else hi = mid; }
+            if (j + lo < T) o[j + lo] = v;
+        }
+    }
+}
+
 int blocks_for(int64_t work, int per_block) {
     int64_t b = (work + per_block - 1) / per_block;
     const int64_t cap = 256 * 8;
@@ -881,6 +913,12 @@ int sk_relu_mask_bias(void* delta, const void* act, int elem_bytes, int64_t rows
     if (blocks > 1024) blocks = 1024;                            // = nerf_amd_relu_mask_bias_partials() / rpb rows of partial sums
     if (elem_bytes == 2) hipLaunchKernelGGL(relu_mask_bias_kernel<2>, dim3((int)blocks), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, rows, W, col_sum);
     else hipLaunchKernelGGL(relu_mask_bias_kernel<4>, dim3((int)blocks), dim3(256), 0, st, (uint32_t*)delta, (const uint32_t*)act, rows, W, col_sum);
+    return (int)hipGetLastError();
+}
+int sk_merge_sorted(const float* a, const float* b, int64_t N, int K, int C, float* out, hipStream_t st) {
+    if (N == 0) return 0;
+    const size_t lds = WAVES_PER_BLOCK * (size_t)(K + C) * 4;
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a, b, N, K, C, out);
     return (int)hipGetLastError();
 }
 

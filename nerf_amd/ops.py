@@ -280,6 +280,16 @@ def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm:
     return rgb, w, depth, nimg
 
 
+def merge_depths(z_fine: torch.Tensor, z_coarse: torch.Tensor) -> torch.Tensor:
+    """sort(cat(z_fine, z_coarse))[..., :-1] for two ASCENDING depth sets (the render path of coarseFineMerge), as a merge."""
+    z_fine, z_coarse = _dev(z_fine, "z_fine"), _dev(z_coarse, "z_coarse")
+    N, K = z_fine.shape
+    Cn = z_coarse.shape[-1]
+    out = torch.empty((N, K + Cn - 1), dtype=torch.float32, device=z_fine.device)
+    check(lib.nerf_amd_merge_depths(_ptr(z_fine), _ptr(z_coarse), N, K, Cn, _ptr(out), _stream()), "nerf_amd_merge_depths")
+    return out
+
+
 def get_bounds(w_prop: torch.Tensor, below: torch.Tensor) -> torch.Tensor:
     w_prop = _dev(w_prop, "weights")
     if not below.is_cuda:

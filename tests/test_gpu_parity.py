@@ -915,3 +915,22 @@ def test_render_image_config5_shape_untiled_contracted(A):
     assert res["rgb"].shape == (3, H, Wd) and res["depth_img"].shape == (3, H, Wd)
     assert max_abs(res["rgb"].cpu(), rgb.view(H, Wd, 3).permute(2, 0, 1)) <= 1e-4
     assert max_abs(res["depth_img"][0].cpu(), depth.view(H, Wd)) <= 1e-3
+
+
+@pytest.mark.parametrize("K,C", [(129, 64), (65, 64), (7, 3), (1, 1), (300, 200)])
+def test_merge_depths_equals_sort_of_concatenation(K, C):
+    """Render-path sort of coarseFineMerge (nerf_base.py:59-73, procedures.py:72) as a merge: bit-identical values, ties included."""
+    from nerf_amd import ops
+    g = torch.Generator().manual_seed(K * 1000 + C)
+    N = 777
+    a = torch.sort(torch.rand(N, K, generator=g) * 4 + 2, dim=-1)[0]
+    b = torch.sort(torch.rand(N, C, generator=g) * 4 + 2, dim=-1)[0]
+    if K > 2 and C > 2:                                   # exact ties within and across the two sets
+        b[:, 1] = a[:, 2]
+        a[::2, 1] = a[::2, 2]
+        b[::3, C - 1] = b[::3, C - 2]
+    a, b = torch.sort(a, dim=-1)[0].cuda(), torch.sort(b, dim=-1)[0].cuda()
+    want = torch.sort(torch.cat((a, b), dim=-1), dim=-1)[0][:, :-1]
+    got = ops.merge_depths(a, b)
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert ops.merge_depths(a[:0], b[:0]).shape == (0, K + C - 1)
