@@ -214,6 +214,11 @@ int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, v
 int64_t nerf_amd_relu_mask_bias_partials(int precision, int64_t rows, int cols);
 int nerf_amd_relu_mask_bias(void* delta, const void* act, int precision, int64_t rows, int cols, float* col_sum, void* stream);
 
+/* Input operand of the first-layer / skip-layer weight gradients: row m = [x | positional_encoding_L(x) (nerf_helper.py:38-48) | 0 ...]
+ * with 3 + 6L columns rounded up to a multiple of 8, bf16 (NERF_AMD_BF16) or fp32 rows.  x (M, >=3) with row stride x_stride floats;
+ * normalize != 0 divides x by its norm first (the view direction, mip_model.py:52).  L = 4 or 10. */
+int nerf_amd_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize, int precision, void* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).
  * One wavefront per ray; S <= 256.  Depths and directions are not differentiated (the reference detaches them too).

@@ -17,6 +17,7 @@ int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void
 int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t);
 int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
 int sk_merge_sorted(const float*, const float*, int64_t, int, int, float*, hipStream_t);
+int sk_encode_rows(const float*, int, int64_t, int, int, int, void*, hipStream_t);
 int sk_relu_mask_bias(void*, const void*, int, int64_t, int, float*, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
@@ -292,6 +293,12 @@ int nerf_amd_relu_mask_bias(void* delta, const void* act, int precision, int64_t
     if (rows < 0 || cols < 2 || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return fail(NERF_AMD_EINVAL, "bad size or precision");
     if (rows && (!delta || !act || !col_sum)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_relu_mask_bias(delta, act, precision == NERF_AMD_BF16 ? 2 : 4, rows, cols, col_sum, S(stream)), "nerf_amd_relu_mask_bias");
+}
+
+int nerf_amd_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize, int precision, void* out, void* stream) {
+    if (M < 0 || x_stride < 3 || (L != 4 && L != 10) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return fail(NERF_AMD_EINVAL, "bad size, L (4 or 10) or precision");
+    if (M && (!x || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_encode_rows(x, x_stride, M, L, normalize, precision == NERF_AMD_BF16 ? 2 : 4, out, S(stream)), "nerf_amd_encode_rows");
 }
 
 // ---- backward of the sampling / compositing rows ----

@@ -691,6 +691,55 @@ __global__ __launch_bounds__(256) void frag_to_rows_kernel(const char* __restric
     }
 }
 
+// First-layer / skip-layer operand of the wgrad GEMMs: row m = [x | positional_encoding_L(x) | 0 pad] (nerf_helper.py:38-48 order:
+// per octave k the three sines, then the three cosines), NCOL = 3 + 6 L rounded up to 8, as bf16 (ELEM 2) or fp32 (ELEM 4).
+// `normalize` divides x by its norm first (the view direction of mip_model.py:52).  bf16 rows take octave 0 from sincosf and the
+// higher octaves by angle doubling like the forward kernels (error <= 2^9 * 1e-7, far below a bf16 ulp); fp32 rows call sincosf
+// per octave.
+template <int L, int ELEM>
+__global__ __launch_bounds__(256) void encode_rows_kernel(const float* __restrict__ x, int x_stride, int64_t M, int normalize,
+                                                          char* __restrict__ out) {
+    constexpr int NCOL = (3 + 6 * L + 7) / 8 * 8;
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+        const float* px = x + m * x_stride;
+        float c[3] = {px[0], px[1], px[2]};
+        if (normalize) { const float n = norm3(c[0], c[1], c[2]); c[0] /= n; c[1] /= n; c[2] /= n; }
+        float v[NCOL];
+#pragma unroll
+        for (int q = 0; q < NCOL; ++q) v[q] = 0.0f;
+        float sv[3], cv[3];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (ELEM == 4 || k == 0) sincosf(c[i] * (float)(1 << k), &sv[i], &cv[i]);
+                else { const float s2 = 2.0f * sv[i]; const float ns = s2 * cv[i]; cv[i] = __builtin_fmaf(-s2, sv[i], 1.0f); sv[i] = ns; }
+                v[3 + 6 * k + i] = sv[i];
+                v[3 + 6 * k + 3 + i] = cv[i];
+            }
+        }
+        v[0] = c[0]; v[1] = c[1]; v[2] = c[2];
+        char* o = out + (size_t)m * NCOL * ELEM;
+        if constexpr (ELEM == 4) {
+#pragma unroll
+            for (int q = 0; q < NCOL; q += 4) { f32x4 w = {v[q], v[q + 1], v[q + 2], v[q + 3]}; *reinterpret_cast<f32x4*>(o + q * 4) = w; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NCOL; q += 8) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = __builtin_bit_cast(uint32_t, v[q + 2 * e]), hi = __builtin_bit_cast(uint32_t, v[q + 2 * e + 1]);
+                    const uint32_t rl = (lo + 0x7fffu + ((lo >> 16) & 1u)) >> 16, rh = (hi + 0x7fffu + ((hi >> 16) & 1u)) >> 16;   // RNE (finite inputs)
+                    w[e] = rl | (rh << 16);
+                }
+                f32x4 pk = {__builtin_bit_cast(float, w[0]), __builtin_bit_cast(float, w[1]), __builtin_bit_cast(float, w[2]), __builtin_bit_cast(float, w[3])};
+                *reinterpret_cast<f32x4*>(o + q * 2) = pk;
+            }
+        }
+    }
+}
+
 // delta[i] = act[i] > 0 ? delta[i] : 0 -- the ReLU adjoint of the dgrad chain, in place (ELEM = 2: bf16 pairs, 4: fp32)
 template <int ELEM>
 __global__ void relu_mask_kernel(uint32_t* __restrict__ delta, const uint32_t* __restrict__ act, int64_t n_words) {
@@ -919,6 +968,17 @@ int sk_merge_sorted(const float* a, const float* b, int64_t N, int K, int C, flo
     if (N == 0) return 0;
     const size_t lds = WAVES_PER_BLOCK * (size_t)(K + C) * 4;
     hipLaunchKernelGGL(merge_sorted_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a, b, N, K, C, out);
+    return (int)hipGetLastError();
+}
+int sk_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize, int elem_bytes, void* out, hipStream_t st) {
+    if (M == 0) return 0;
+    const dim3 grid(blocks_for(M, 256)), block(256);
+    char* o = (char*)out;
+    if (L == 10 && elem_bytes == 2) hipLaunchKernelGGL((encode_rows_kernel<10, 2>), grid, block, 0, st, x, x_stride, M, normalize, o);
+    else if (L == 10) hipLaunchKernelGGL((encode_rows_kernel<10, 4>), grid, block, 0, st, x, x_stride, M, normalize, o);
+    else if (L == 4 && elem_bytes == 2) hipLaunchKernelGGL((encode_rows_kernel<4, 2>), grid, block, 0, st, x, x_stride, M, normalize, o);
+    else if (L == 4) hipLaunchKernelGGL((encode_rows_kernel<4, 4>), grid, block, 0, st, x, x_stride, M, normalize, o);
+    else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 

@@ -16,12 +16,6 @@ import torch
 from . import ops
 
 
-def _pe(x: torch.Tensor, L: int) -> torch.Tensor:
-    freq = torch.pow(2.0, torch.arange(L, dtype=x.dtype, device=x.device))
-    a = x.unsqueeze(-2) * freq[:, None]
-    return torch.stack((torch.sin(a), torch.cos(a)), dim=-2).reshape(x.shape[:-1] + (6 * L,))
-
-
 _SPLIT = 4096        # rows per split-K slice of a wgrad GEMM
 
 
@@ -32,14 +26,21 @@ def _pad16(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _encode(x: torch.Tensor, L: int, dt) -> torch.Tensor:
+def _encode(x: torch.Tensor, L: int, precision: int, normalize: bool = False) -> torch.Tensor:
     """[x | PE_L(x)] zero-padded to a multiple of 8 columns (the library's bf16 kernels want aligned leading dimensions; odd ones
-    fall into a path with milliseconds of host-side search per call)."""
-    n = 3 + 6 * L
-    out = torch.zeros((x.shape[0], (n + 7) // 8 * 8), dtype=dt, device=x.device)
-    out[:, :3] = x
-    out[:, 3:n] = _pe(x, L)
-    return out
+    fall into a path with milliseconds of host-side search per call) -- one HIP kernel (nerf_amd_encode_rows)."""
+    return ops.encode_rows(x, L, precision, normalize)
+
+
+def _bgrad_narrow(d16: torch.Tensor, n: int) -> torch.Tensor:
+    """Column sums of an (M, 16) matrix whose first n columns matter: summed as (M/16, 256) so that the reduction runs over
+    full-width rows (a 3- or 16-wide column reduce of millions of rows is a millisecond on its own)."""
+    M = d16.shape[0]
+    main = M // 16 * 16
+    out = d16[:main].view(-1, 256).sum(0, dtype=torch.float32).view(16, 16).sum(0)
+    if main < M:
+        out = out + d16[main:].sum(0, dtype=torch.float32)
+    return out[:n]
 
 
 def _wgrad(delta: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
@@ -83,7 +84,7 @@ def proposal_backward(g_density: torch.Tensor, pts: torch.Tensor, dump: torch.Te
         prev = rows(l - 1)
         gW[l] = _wgrad(delta, prev)
         delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
-    gW[0] = _wgrad(delta, _encode(pts, 10, dt))[:, :63]
+    gW[0] = _wgrad(delta, _encode(pts, 10, precision))[:, :63]
     return gW, gb
 
 
@@ -96,17 +97,16 @@ def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, du
     W = [w.detach().to(dt) for w in weights]
     rows = lambda l, n=256: ops.train_dump_rows(dump, ops.NET_MIP, precision, M, l, n)
     gW, gb = [None] * 11, [None] * 11
-    x, d = pts[:, :3], pts[:, 3:6]
-    d = d / d.norm(dim=-1, keepdim=True)
-    ed = _encode(d, 4, dt)                                                          # (M, 27 -> 32)
+    ed = _encode(pts[:, 3:6], 4, precision, normalize=True)                         # (M, 27 -> 32), d / |d| first (mip_model.py:52)
     # colour head: rgb = sigmoid(rgb_layer.2(c)), c = relu(rgb_layer.0(cat(bottle_neck(g6), ed)))
     rgb = rgbo[:, :3]
     d10 = (g_rgbo[:, :3] * rgb * (1.0 - rgb)).to(dt)
     c = rows(7, 128)
-    gW[10], gb[10] = _wgrad(d10, c), _bgrad(d10)
+    d10p = _pad16(d10)
+    gW[10], gb[10] = _wgrad(d10p, c)[:3], _bgrad_narrow(d10p, 3)
     w10 = torch.zeros((16, W[10].shape[1]), dtype=dt, device=W[10].device)
     w10[:3] = W[10]
-    dc, gb[9] = _masked(torch.mm(_pad16(d10), w10), c, precision)
+    dc, gb[9] = _masked(torch.mm(d10p, w10), c, precision)
     g6 = rows(6)
     bott = torch.addmm(biases[7].detach().to(dt), g6, W[7].t())                   # the folded forward never forms it
     gW[9] = torch.cat((_wgrad(dc, bott), _wgrad(dc, ed)[:, :27]), dim=1)          # cat(bottle_neck, dir_enc) column blocks
@@ -120,7 +120,7 @@ def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, du
         prev = rows(l - 1)
         gW[l] = _wgrad(delta, prev)
         delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
-    ex = _encode(x.contiguous(), 10, dt)                                            # (M, 63 -> 64)
+    ex = _encode(pts[:, :3], 10, precision)                                         # (M, 63 -> 64)
     h3 = rows(3)
     gW[4] = torch.cat((_wgrad(delta, ex)[:, :63], _wgrad(delta, h3)), dim=1)      # skip layer: cat(encoded_x, h)
     delta, gb[3] = _masked(torch.mm(delta, W[4][:, 63:].contiguous()), h3, precision)

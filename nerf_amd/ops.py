@@ -428,6 +428,19 @@ def train_dump_rows(dump: torch.Tensor, net: int, precision: int, M: int, layer:
     return out
 
 
+def encode_rows(x: torch.Tensor, L: int, precision: int, normalize: bool = False) -> torch.Tensor:
+    """[x | PE_L(x)] zero-padded to a multiple of 8 columns, as bf16 / fp32 rows: the wgrad operand of the first and skip layers.
+    x: (M, >=3) float32 with unit inner stride (a column slice of the (M,6) sample matrix is fine)."""
+    if not x.is_cuda:
+        raise RuntimeError("nerf_amd: 'x' must live on the HIP device (got %s); there is no CPU path" % x.device)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < 3:
+        x = x.reshape(-1, x.shape[-1]).float().contiguous()
+    M = x.shape[0]
+    out = torch.empty((M, (3 + 6 * L + 7) // 8 * 8), dtype=torch.bfloat16 if precision == BF16 else torch.float32, device=x.device)
+    check(lib.nerf_amd_encode_rows(_ptr(x), max(x.stride(0), 3), M, L, int(normalize), precision, _ptr(out), _stream()), "nerf_amd_encode_rows")
+    return out
+
+
 def relu_mask_(delta: torch.Tensor, act: torch.Tensor, precision: int) -> torch.Tensor:
     """In place: delta = where(act > 0, delta, 0); both contiguous, same shape and dtype (bf16 for BF16, fp32 for F32)."""
     assert delta.is_contiguous() and act.is_contiguous() and delta.shape == act.shape and delta.dtype == act.dtype

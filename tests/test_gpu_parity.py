@@ -934,3 +934,27 @@ def test_merge_depths_equals_sort_of_concatenation(K, C):
     got = ops.merge_depths(a, b)
     assert got.shape == want.shape and torch.equal(got, want)
     assert ops.merge_depths(a[:0], b[:0]).shape == (0, K + C - 1)
+
+
+@pytest.mark.parametrize("L,normalize", [(10, False), (4, True)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_encode_rows_matches_positional_encoding(L, normalize, prec):
+    """nerf_amd_encode_rows = [x | positional_encoding (nerf_helper.py:38-48) | 0 pad]: the wgrad operand of the first / skip layers."""
+    from nerf_amd import ops
+    g = torch.Generator().manual_seed(5 + L)
+    pts = (torch.rand(3001, 6, generator=g) * 8 - 4).cuda()
+    x = pts[:, 3:6] if normalize else pts[:, :3]                    # strided column slices of the (M,6) sample matrix
+    precision = ops.BF16 if prec == "bf16" else ops.F32
+    got = ops.encode_rows(x, L, precision, normalize)
+    xr = (x / x.norm(dim=-1, keepdim=True) if normalize else x).cpu()
+    pe = O.positional_encoding(xr, L)
+    ncol = (3 + 6 * L + 7) // 8 * 8
+    want = torch.zeros(x.shape[0], ncol)
+    want[:, :3] = xr
+    want[:, 3:3 + 6 * L] = pe
+    assert got.shape == want.shape and got.dtype == (torch.bfloat16 if prec == "bf16" else torch.float32)
+    if prec == "fp32":
+        assert max_abs(got.cpu(), want) <= (2e-6 * 2 ** L if normalize else 2e-6)   # a 1-ulp difference of the normalised direction scales with the octave
+    else:
+        assert max_abs(got.float().cpu(), want.bfloat16().float()) <= 2 ** -7   # one bf16 ulp at |v| <= 4
+    assert ops.encode_rows(x[:0], L, precision, normalize).shape == (0, ncol)
