@@ -214,6 +214,14 @@ int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, v
 int64_t nerf_amd_relu_mask_bias_partials(int precision, int64_t rows, int cols);
 int nerf_amd_relu_mask_bias(void* delta, const void* act, int precision, int64_t rows, int cols, float* col_sum, void* stream);
 
+/* nerf_amd_train_dump_to_rows and nerf_amd_relu_mask_bias of ONE layer in one pass: act_out (M, n_features) = the layer's activations
+ * row-major, delta (M, n_features, same element type) masked in place by [act > 0], and col_sum = nerf_amd_train_dump_rows_mask_partials()
+ * rows of n_features fp32 partial column sums of the masked delta (all rows written; their sum is the bias gradient).
+ * n_features = 128 or 256. */
+int64_t nerf_amd_train_dump_rows_mask_partials(void);
+int nerf_amd_train_dump_rows_mask(const void* dump, int net, int precision, int64_t M, int layer, int n_features, void* act_out, void* delta,
+                                  float* col_sum, void* stream);
+
 /* Input operand of the first-layer / skip-layer weight gradients: row m = [x | positional_encoding_L(x) (nerf_helper.py:38-48) | 0 ...]
  * with 3 + 6L columns rounded up to a multiple of 8, bf16 (NERF_AMD_BF16) or fp32 rows.  x (M, >=3) with row stride x_stride floats;
  * normalize != 0 divides x by its norm first (the view direction, mip_model.py:52).  L = 4 or 10. */

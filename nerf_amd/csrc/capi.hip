@@ -18,6 +18,8 @@ int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t)
 int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
 int sk_merge_sorted(const float*, const float*, int64_t, int, int, float*, hipStream_t);
 int sk_encode_rows(const float*, int, int64_t, int, int, int, void*, hipStream_t);
+int sk_frag_rows_mask_blocks();
+int sk_frag_rows_mask(const void*, int, int64_t, int, int64_t, void*, void*, float*, hipStream_t);
 int sk_relu_mask_bias(void*, const void*, int, int64_t, int, float*, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
@@ -273,6 +275,20 @@ int nerf_amd_train_dump_to_rows(const void* dump, int net, int precision, int64_
     const int64_t n_sub = (int64_t)(stride / (16 * (size_t)512 * elem));
     return hip_status(sk_frag_to_rows(reinterpret_cast<const char*>(dump) + (size_t)layer * stride, elem, n_sub, n_features / 16, M, out, S(stream)),
                       "nerf_amd_train_dump_to_rows");
+}
+
+int64_t nerf_amd_train_dump_rows_mask_partials(void) { return (int64_t)sk_frag_rows_mask_blocks() * 4; }
+int nerf_amd_train_dump_rows_mask(const void* dump, int net, int precision, int64_t M, int layer, int n_features, void* act_out, void* delta,
+                                  float* col_sum, void* stream) {
+    if (M < 0 || layer < 0 || layer >= train_layers(net) || (n_features != 128 && n_features != 256))
+        return fail(NERF_AMD_EINVAL, "bad layer or feature count (128 or 256)");
+    if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
+    if (!col_sum || (M && (!dump || !act_out || !delta))) return fail(NERF_AMD_EINVAL, "NULL argument");
+    const size_t stride = mlp_train_layer_stride(precision, M);
+    const int elem = precision == NERF_AMD_BF16 ? 2 : 4;
+    const int64_t n_sub = (int64_t)(stride / (16 * (size_t)512 * elem));
+    return hip_status(sk_frag_rows_mask(reinterpret_cast<const char*>(dump) + (size_t)layer * stride, elem, n_sub, n_features / 16, M, act_out, delta, col_sum,
+                                        S(stream)), "nerf_amd_train_dump_rows_mask");
 }
 
 int nerf_amd_relu_mask(void* delta, const void* act, int precision, int64_t n, void* stream) {

@@ -691,6 +691,85 @@ __global__ __launch_bounds__(256) void frag_to_rows_kernel(const char* __restric
     }
 }
 
+// frag_to_rows_kernel + relu_mask_bias_kernel in one pass over a layer: the subtile's activations go dump -> LDS -> row-major
+// `act_out`, and while they sit in LDS the same 32 rows of `delta` (row-major, same shape) are masked in place by [act > 0] and
+// summed per column.  Saves re-reading the activation matrix (4 instead of 5 matrix passes per layer).  Column sums: lane c owns
+// 16-byte chunk c % cpr of rows c / cpr + (64 / cpr) i, i.e. a fixed set of columns; each wavefront writes ONE partial row of
+// fp32 sums (deterministic, no atomics), `col_sum` has gridDim.x * WAVES_PER_BLOCK rows.
+template <int ELEM>
+__global__ __launch_bounds__(256) void frag_rows_mask_kernel(const char* __restrict__ frag, int64_t n_sub, int n_kg, int64_t M,
+                                                             char* __restrict__ act_out, char* __restrict__ delta, float* __restrict__ col_sum) {
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    constexpr int BLOCK = 512 * ELEM;
+    constexpr int NV = 16 / ELEM;                                // values per 16-byte chunk
+    const int row_bytes = n_kg * 16 * ELEM;
+    const int pitch = row_bytes + 16;
+    const int ld = n_kg * 16;
+    char* tile = smem + (size_t)wave_in_block() * 32 * pitch;
+    const int cpr = row_bytes / 16;                              // 16, 32 or 64: divides the wave size
+    const int q = lane % cpr, r0 = lane / cpr, rstep = 64 / cpr;
+    float acc[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = 0.0f;
+    for (int64_t sub = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); sub < n_sub; sub += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        char* trow = tile + j * pitch;
+        for (int kg = 0; kg < n_kg; ++kg) {
+            const char* blk = frag + ((size_t)sub * 16 + kg) * BLOCK;
+            if constexpr (ELEM == 2) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(blk + lane * 16);
+                f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+                *reinterpret_cast<f32x2*>(trow + (16 * kg + 4 * h) * 2) = lo;
+                *reinterpret_cast<f32x2*>(trow + (16 * kg + 8 + 4 * h) * 2) = hi;
+            } else {
+                *reinterpret_cast<f32x4*>(trow + (16 * kg + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + lane * 16);
+                *reinterpret_cast<f32x4*>(trow + (16 * kg + 8 + 4 * h) * 4) = *reinterpret_cast<const f32x4*>(blk + 1024 + lane * 16);
+            }
+        }
+        lds_wave_sync();
+        const size_t base = (size_t)sub * 32 * ld * ELEM;
+        for (int r = r0; r < 32; r += rstep) {
+            if (sub * 32 + r >= M) break;
+            const size_t off = base + (size_t)r * ld * ELEM + q * 16;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            if constexpr (ELEM == 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(tile + r * pitch + q * 16);
+                f32x4 d = *reinterpret_cast<const f32x4*>(delta + off);
+                *reinterpret_cast<f32x4*>(act_out + off) = a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if (!(a[e] > 0.0f)) d[e] = 0.0f; acc[e] += d[e]; }
+                *reinterpret_cast<f32x4*>(delta + off) = d;
+            } else {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(tile + r * pitch + q * 16);
+                const u32x4 d = *reinterpret_cast<const u32x4*>(delta + off);
+                *reinterpret_cast<u32x4*>(act_out + off) = a;
+                uint32_t w[4] = {d[0], d[1], d[2], d[3]};
+                const uint32_t aw[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = aw[e] & 0xFFFFu, hi = aw[e] >> 16;
+                    if (!(lo != 0u && lo < 0x8000u)) w[e] &= 0xFFFF0000u;
+                    if (!(hi != 0u && hi < 0x8000u)) w[e] &= 0x0000FFFFu;
+                    acc[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+                    acc[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xFFFF0000u);
+                }
+                const u32x4 o = {w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<u32x4*>(delta + off) = o;
+            }
+        }
+    }
+    // lanes with equal q (lane bits >= log2 cpr) hold sums of the same columns: fold them, then lanes 0 .. cpr-1 write the partial row
+    for (int m = cpr; m < 64; m <<= 1) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] += __shfl_xor(acc[e], m, 64);
+    }
+    if (lane < cpr) {
+        float* prow = col_sum + ((size_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block()) * (size_t)ld + q * NV;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) prow[e] = acc[e];
+    }
+}
+
 // First-layer / skip-layer operand of the wgrad GEMMs: row m = [x | positional_encoding_L(x) | 0 pad] (nerf_helper.py:38-48 order:
 // per octave k the three sines, then the three cosines), NCOL = 3 + 6 L rounded up to 8, as bf16 (ELEM 2) or fp32 (ELEM 4).
 // `normalize` divides x by its norm first (the view direction of mip_model.py:52).  bf16 rows take octave 0 from sincosf and the
@@ -979,6 +1058,23 @@ int sk_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize
     else if (L == 4 && elem_bytes == 2) hipLaunchKernelGGL((encode_rows_kernel<4, 2>), grid, block, 0, st, x, x_stride, M, normalize, o);
     else if (L == 4) hipLaunchKernelGGL((encode_rows_kernel<4, 4>), grid, block, 0, st, x, x_stride, M, normalize, o);
     else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+int sk_frag_rows_mask_blocks() { return 512; }                   // partial rows = blocks * WAVES_PER_BLOCK
+int sk_frag_rows_mask(const void* frag, int elem_bytes, int64_t n_sub, int n_kg, int64_t M, void* act_out, void* delta, float* col_sum, hipStream_t st) {
+    const size_t lds = (size_t)WAVES_PER_BLOCK * 32 * ((size_t)n_kg * 16 * elem_bytes + 16);
+    const dim3 grid(sk_frag_rows_mask_blocks()), block(256);     // fixed grid: every wavefront writes its partial row (zeros without work)
+    if (elem_bytes == 2) {
+        hipLaunchKernelGGL(frag_rows_mask_kernel<2>, grid, block, lds, st, (const char*)frag, n_sub, n_kg, M, (char*)act_out, (char*)delta, col_sum);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frag_rows_mask_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(frag_rows_mask_kernel<4>, grid, block, lds, st, (const char*)frag, n_sub, n_kg, M, (char*)act_out, (char*)delta, col_sum);
+    }
     return (int)hipGetLastError();
 }
 

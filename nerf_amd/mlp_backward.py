@@ -59,11 +59,6 @@ def _wgrad(delta: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _masked(delta: torch.Tensor, act: torch.Tensor, precision: int):
-    """(delta * [act > 0] in place, its fp32 column sums) -- the ReLU adjoint and, for free, the bias gradient of that layer."""
-    return ops.relu_mask_bias_(delta.contiguous(), act, precision)
-
-
 def _bgrad(delta: torch.Tensor) -> torch.Tensor:
     return delta.sum(0, dtype=torch.float32)
 
@@ -74,16 +69,16 @@ def proposal_backward(g_density: torch.Tensor, pts: torch.Tensor, dump: torch.Te
     M = pts.shape[0]
     dt = torch.bfloat16 if precision == ops.BF16 else torch.float32
     W = [w.detach().to(dt) for w in weights]
-    rows = lambda l: ops.train_dump_rows(dump, ops.NET_PROPOSAL, precision, M, l, 256)
+    # one pass per hidden layer: its activations as rows (the wgrad operand) + the ReLU mask of the incoming delta + the bias gradient
+    rows_mask = lambda l, d: ops.train_dump_rows_mask_(dump, ops.NET_PROPOSAL, precision, l, d)
     gW, gb = [None] * 5, [None] * 5
     g = g_density.reshape(M, 1).to(dt)
-    h = rows(3)
+    h, delta, gb[3] = rows_mask(3, g * W[4])
     gW[4], gb[4] = _wgrad(g, h), g_density.sum().reshape(1)
-    delta, gb[3] = _masked(g * W[4], h, precision)
     for l in (3, 2, 1):
-        prev = rows(l - 1)
+        prev, nxt, gb[l - 1] = rows_mask(l - 1, torch.mm(delta, W[l]))
         gW[l] = _wgrad(delta, prev)
-        delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
+        delta = nxt
     gW[0] = _wgrad(delta, _encode(pts, 10, precision))[:, :63]
     return gW, gb
 
@@ -95,39 +90,36 @@ def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, du
     M = pts.shape[0]
     dt = torch.bfloat16 if precision == ops.BF16 else torch.float32
     W = [w.detach().to(dt) for w in weights]
-    rows = lambda l, n=256: ops.train_dump_rows(dump, ops.NET_MIP, precision, M, l, n)
+    rows_mask = lambda l, d: ops.train_dump_rows_mask_(dump, ops.NET_MIP, precision, l, d)
     gW, gb = [None] * 11, [None] * 11
     ed = _encode(pts[:, 3:6], 4, precision, normalize=True)                         # (M, 27 -> 32), d / |d| first (mip_model.py:52)
     # colour head: rgb = sigmoid(rgb_layer.2(c)), c = relu(rgb_layer.0(cat(bottle_neck(g6), ed)))
     rgb = rgbo[:, :3]
-    d10 = (g_rgbo[:, :3] * rgb * (1.0 - rgb)).to(dt)
-    c = rows(7, 128)
-    d10p = _pad16(d10)
-    gW[10], gb[10] = _wgrad(d10p, c)[:3], _bgrad_narrow(d10p, 3)
+    d10p = _pad16((g_rgbo[:, :3] * rgb * (1.0 - rgb)).to(dt))
     w10 = torch.zeros((16, W[10].shape[1]), dtype=dt, device=W[10].device)
     w10[:3] = W[10]
-    dc, gb[9] = _masked(torch.mm(d10p, w10), c, precision)
-    g6 = rows(6)
+    c, dc, gb[9] = rows_mask(7, torch.mm(d10p, w10))                                # 128 features
+    gW[10], gb[10] = _wgrad(d10p, c)[:3], _bgrad_narrow(d10p, 3)
+    dbott = torch.mm(dc, W[9][:, :256].contiguous())
+    dsig = g_rgbo[:, 3:4].to(dt)
+    g6, delta, gb[6] = rows_mask(6, torch.addmm(dsig * W[8], dbott, W[7]))
     bott = torch.addmm(biases[7].detach().to(dt), g6, W[7].t())                   # the folded forward never forms it
     gW[9] = torch.cat((_wgrad(dc, bott), _wgrad(dc, ed)[:, :27]), dim=1)          # cat(bottle_neck, dir_enc) column blocks
-    dbott = torch.mm(dc, W[9][:, :256].contiguous())
     gW[7], gb[7] = _wgrad(dbott, g6), _bgrad(dbott)
-    dsig = g_rgbo[:, 3:4].to(dt)
     gW[8], gb[8] = _wgrad(dsig, g6), g_rgbo[:, 3].sum().reshape(1)
-    delta, gb[6] = _masked(torch.addmm(dsig * W[8], dbott, W[7]), g6, precision)
-    del bott, dbott, dc, c
+    del bott, dbott, dc, c, g6
     for l in (6, 5):
-        prev = rows(l - 1)
+        prev, nxt, gb[l - 1] = rows_mask(l - 1, torch.mm(delta, W[l]))
         gW[l] = _wgrad(delta, prev)
-        delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
+        delta = nxt
     ex = _encode(pts[:, :3], 10, precision)                                         # (M, 63 -> 64)
-    h3 = rows(3)
+    h3, nxt, gb[3] = rows_mask(3, torch.mm(delta, W[4][:, 63:].contiguous()))
     gW[4] = torch.cat((_wgrad(delta, ex)[:, :63], _wgrad(delta, h3)), dim=1)      # skip layer: cat(encoded_x, h)
-    delta, gb[3] = _masked(torch.mm(delta, W[4][:, 63:].contiguous()), h3, precision)
+    delta = nxt
     del h3
     for l in (3, 2, 1):
-        prev = rows(l - 1)
+        prev, nxt, gb[l - 1] = rows_mask(l - 1, torch.mm(delta, W[l]))
         gW[l] = _wgrad(delta, prev)
-        delta, gb[l - 1] = _masked(torch.mm(delta, W[l]), prev, precision)
+        delta = nxt
     gW[0] = _wgrad(delta, ex)[:, :63]
     return gW, gb

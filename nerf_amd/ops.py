@@ -428,6 +428,17 @@ def train_dump_rows(dump: torch.Tensor, net: int, precision: int, M: int, layer:
     return out
 
 
+def train_dump_rows_mask_(dump: torch.Tensor, net: int, precision: int, layer: int, delta: torch.Tensor):
+    """train_dump_rows + relu_mask_bias_ of one layer in a single pass: -> (act rows (M, F), delta masked IN PLACE, fp32 column sums)."""
+    assert delta.is_contiguous() and delta.dim() == 2 and delta.dtype == (torch.bfloat16 if precision == BF16 else torch.float32)
+    M, F = delta.shape
+    act = torch.empty_like(delta)
+    part = torch.empty((lib.nerf_amd_train_dump_rows_mask_partials(), F), dtype=torch.float32, device=delta.device)
+    check(lib.nerf_amd_train_dump_rows_mask(_ptr(dump), net, precision, M, layer, F, _ptr(act), _ptr(delta), _ptr(part), _stream()),
+          "nerf_amd_train_dump_rows_mask")
+    return act, delta, part.sum(0)
+
+
 def encode_rows(x: torch.Tensor, L: int, precision: int, normalize: bool = False) -> torch.Tensor:
     """[x | PE_L(x)] zero-padded to a multiple of 8 columns, as bf16 / fp32 rows: the wgrad operand of the first and skip layers.
     x: (M, >=3) float32 with unit inner stride (a column slice of the (M,6) sample matrix is fine)."""

@@ -958,3 +958,28 @@ def test_encode_rows_matches_positional_encoding(L, normalize, prec):
     else:
         assert max_abs(got.float().cpu(), want.bfloat16().float()) <= 2 ** -7   # one bf16 ulp at |v| <= 4
     assert ops.encode_rows(x[:0], L, precision, normalize).shape == (0, ncol)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_train_dump_rows_mask_equals_the_two_separate_passes(A, prec):
+    """nerf_amd_train_dump_rows_mask == nerf_amd_train_dump_to_rows followed by nerf_amd_relu_mask_bias (rows and masked delta bit
+    for bit, column sums to summation order), for 256- and 128-wide layers and a sample count that is no multiple of a tile."""
+    prop, mip = build_nets(A, "he")
+    A.pkg.set_precision(prec)
+    P = A.ops.current_precision()
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(77)
+    M = 4099
+    pts6 = torch.cat((torch.rand(M, 3, generator=gen) * 2 - 1, torch.randn(M, 3, generator=gen)), -1).cuda().contiguous()
+    with torch.no_grad():
+        _, dump = A.ops.mip_forward_train(mip.packed(P), P, pts6)
+        for layer, width in ((2, 256), (6, 256), (7, 128)):
+            delta = torch.randn(M, width, generator=gen).cuda().to(dt)
+            rows = A.ops.train_dump_rows(dump, A.ops.NET_MIP, P, M, layer, width)
+            want_d, want_s = A.ops.relu_mask_bias_(delta.clone(), rows, P)
+            act, got_d, got_s = A.ops.train_dump_rows_mask_(dump, A.ops.NET_MIP, P, layer, delta.clone())
+            assert torch.equal(act, rows) and torch.equal(got_d, want_d), (layer, width)
+            assert 0.05 < (rows > 0).float().mean().item() < 0.95                 # the mask is not trivial
+            assert max_abs(got_s.cpu(), want_s.cpu()) <= 1e-3 * max(1.0, want_s.abs().max().item())
+            assert max_abs(got_s.cpu(), want_d.float().sum(0).cpu()) <= 1e-3 * max(1.0, want_s.abs().max().item())
+    A.pkg.set_precision("fp32")

@@ -5,7 +5,8 @@ batches and uniforms (one seeded CPU generator drives both, in the reference's d
 No dataset exists on the box, so the scene is synthetic and analytic (a shaded sphere in front of a white background, 8
 orbit views of 40x40); the quantity under test is the DIFFERENCE between the two paths, not the absolute PSNR.
 
-The held-out view is the gate (0.1 dB); the tail of the training loss is reported and loosely bounded.
+Gates (0.1 dB each): the held-out view's PSNR and the PSNR of the training-loss tail, averaged over three seeds; a run's held-out PSNR is its median
+over five checkpoints (single renders have heavy-tailed noise in every path, see the comment at the asserts).
 
 Note on conditioning: early NeRF training is chaotic at aggressive learning rates (with lr = 5e-4 an fp32-ulp perturbation
 already produces an isolated loss spike within 25 iterations, and the bf16 run tips into the well-known empty-density
@@ -22,6 +23,7 @@ from oracle import nerf_oracle as O
 
 pytestmark = pytest.mark.gpu
 NEAR, FAR, H, C_N, F_N, RAYS, ITERS = 2.0, 6.0, 40, 32, 64, 256, 150
+CHECKPOINTS = (110, 120, 130, 140, 150)   # iterations at which the held-out view is rendered
 LR = 1.5e-4 * RAYS / 512            # the reference's rule: args.lr * sample_ray_num / 512 (train.py:56)
 
 
@@ -54,7 +56,7 @@ def run_oracle(views, seed):
     mip = {k: v.clone().requires_grad_(True) for k, v in W.mip_state("small").items()}
     opt = torch.optim.Adam(list(mip.values()) + list(prop.values()), lr=LR)
     res = (FAR - NEAR) / C_N
-    hist = []
+    hist, held = [], []
     for it in range(ITERS):
         rays_all, rgb_all = views[it % (len(views) - 1)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,))
@@ -73,14 +75,15 @@ def run_oracle(views, seed):
         loss.backward()
         opt.step()
         hist.append(loss_img.item())
-    with torch.no_grad():                                            # held-out view, fixed uniforms
-        rays, tgt = views[-1]
-        g = torch.Generator().manual_seed(99)
-        u1, u2 = torch.rand(rays.shape[0], 64, generator=g), torch.rand(rays.shape[0], F_N + 1, generator=g)
-        rgb, _, _ = O.render_rays({k: v.detach() for k, v in prop.items()}, {k: v.detach() for k, v in mip.items()}, rays, u1, u2,
-                                  NEAR, FAR, F_N, white_bkg=True)
-        test_mse = torch.mean((rgb - tgt) ** 2).item()
-    return hist, test_mse
+        if it + 1 in CHECKPOINTS:
+            with torch.no_grad():                                        # held-out view, fixed uniforms
+                rays_h, tgt_h = views[-1]
+                g = torch.Generator().manual_seed(99)
+                u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g), torch.rand(rays_h.shape[0], F_N + 1, generator=g)
+                rgb, _, _ = O.render_rays({k: v.detach() for k, v in prop.items()}, {k: v.detach() for k, v in mip.items()}, rays_h, u1, u2,
+                                          NEAR, FAR, F_N, white_bkg=True)
+                held.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+    return hist, held
 
 
 def run_hip(views, seed, precision):
@@ -99,7 +102,7 @@ def run_hip(views, seed, precision):
     prop, mip = prop.cuda().train(), mip.cuda().train()
     opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=LR)
     res = (FAR - NEAR) / C_N
-    hist = []
+    hist, held = [], []
     gviews = [(r.cuda(), c.cuda()) for r, c in views]
     for it in range(ITERS):
         rays_all, rgb_all = gviews[it % (len(views) - 1)]
@@ -119,15 +122,19 @@ def run_hip(views, seed, precision):
         loss.backward()
         opt.step()
         hist.append(loss_img.item())
-    with torch.no_grad():
-        rays, tgt = gviews[-1]
-        g = torch.Generator().manual_seed(99)
-        u1, u2 = torch.rand(rays.shape[0], 64, generator=g).cuda(), torch.rand(rays.shape[0], F_N + 1, generator=g).cuda()
-        P = ops.current_precision()
-        rgb, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P), P, rays, torch.linspace(NEAR, FAR, 64).cuda(), u1, u2, F_N, NEAR, FAR, True)
-        test_mse = torch.mean((rgb - tgt) ** 2).item()
+        if it + 1 in CHECKPOINTS:
+            with torch.no_grad():
+                rays_h, tgt_h = gviews[-1]
+                g = torch.Generator().manual_seed(99)
+                u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g).cuda(), torch.rand(rays_h.shape[0], F_N + 1, generator=g).cuda()
+                P = ops.current_precision()
+                rgb, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P), P, rays_h, torch.linspace(NEAR, FAR, 64).cuda(), u1, u2, F_N, NEAR, FAR, True)
+                held.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
     nerf_amd.set_precision("fp32")
-    return hist, test_mse
+    return hist, held
+
+
+SEEDS = (7, 8, 9)
 
 
 def test_psnr_at_equal_iterations():
@@ -135,16 +142,26 @@ def test_psnr_at_equal_iterations():
         pytest.skip("no GPU")
     torch.set_num_threads(min(32, torch.get_num_threads()))       # torch CPU GEMMs of this size do not scale past ~32 threads
     views = analytic_scene()
-    h_ref, t_ref = run_oracle(views, 7)
-    h_f32, t_f32 = run_hip(views, 7, "fp32")
-    h_b16, t_b16 = run_hip(views, 7, "bf16")
     tail = lambda h: psnr(sum(h[-40:]) / 40)
-    print("\ntrain PSNR (last 40 it): cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB;  held-out view: cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB"
-          % (tail(h_ref), tail(h_f32), tail(h_b16), psnr(t_ref), psnr(t_f32), psnr(t_b16)))
-    assert h_ref[-1] < h_ref[0]                                      # it does learn
-    # the gate is the rendered held-out view (image PSNR, 0.1 dB) in both modes.  The training-loss tail is a noisier proxy: the fp32
-    # mode (exact-fp32 MFMA forward, fp32 GEMM-chain backward) tracks the CPU run within 0.1 dB there too; in the bf16 mode every
-    # gradient carries bf16 operand rounding (like the reference's fp16 AMP), which decorrelates the mini-batch losses within ~30 Adam
-    # steps, so its tail only has to stay in the same band
-    assert abs(psnr(t_f32) - psnr(t_ref)) <= 0.1 and abs(psnr(t_b16) - psnr(t_ref)) <= 0.1
-    assert abs(tail(h_f32) - tail(h_ref)) <= 0.1 and abs(tail(h_b16) - tail(h_ref)) <= 0.3
+    med = lambda v: sorted(v)[len(v) // 2]
+    mean = lambda v: sum(v) / len(v)
+    held = {"cpu": [], "fp32": [], "bf16": []}
+    tails = {"cpu": [], "fp32": [], "bf16": []}
+    for seed in SEEDS:
+        runs = {"cpu": run_oracle(views, seed), "fp32": run_hip(views, seed, "fp32"), "bf16": run_hip(views, seed, "bf16")}
+        for k, (h, t) in runs.items():
+            held[k].append(med(t))
+            tails[k].append(tail(h))
+        assert runs["cpu"][0][-1] < runs["cpu"][0][0]               # it does learn
+        print("\nseed %2d  held-out view: cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB;  train PSNR (last 40 it): cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB"
+              % (seed, held["cpu"][-1], held["fp32"][-1], held["bf16"][-1], tails["cpu"][-1], tails["fp32"][-1], tails["bf16"][-1]))
+        print("         held-out at it %s: cpu %s | fp32 %s | bf16 %s" % (CHECKPOINTS, *(" ".join("%.2f" % v for v in runs[k][1]) for k in ("cpu", "fp32", "bf16"))))
+    print("mean     held-out view: cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB;  train PSNR: cpu %.3f  hip-fp32 %.3f  hip-bf16 %.3f dB"
+          % (mean(held["cpu"]), mean(held["fp32"]), mean(held["bf16"]), mean(tails["cpu"]), mean(tails["fp32"]), mean(tails["bf16"])))
+    # Gates (0.1 dB): image PSNR of the rendered held-out view and PSNR of the training-loss tail, averaged over the seeds.  The held-out
+    # PSNR of ONE run is its median over the five checkpoints: this early in training the held-out render shows isolated one-checkpoint
+    # dips of 1-3 dB in EVERY path (the CPU run included) whose timing an fp32-ulp perturbation -- e.g. another summation order of a bias
+    # gradient -- shifts, so a single end-of-run render is not a usable statistic while the checkpoint median is stable to ~0.05 dB.
+    for k in ("fp32", "bf16"):
+        assert abs(mean(held[k]) - mean(held["cpu"])) <= 0.1, (k, held)
+        assert abs(mean(tails[k]) - mean(tails["cpu"])) <= 0.1, (k, tails)
