@@ -186,7 +186,7 @@ int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const fl
                        float* rgb, float* weights, float* depth, float* normal_img, void* stream);
 
 /* The depth sort of NeRF.coarseFineMerge (nerf_base.py:59-73) for the render path (procedures.py:72): z_fine (N,K) and z_coarse
- * (N,C), BOTH ascending along the last dimension -> z_out (N, K+C-1) = sort(cat(z_fine, z_coarse))[..., :-1], as a merge. */
+ * (N,C), BOTH ascending along the last dimension -> z_out (N, K+C-1) = sort(cat(z_fine, z_coarse))[..., :-1], as a merge.  K + C <= 4096. */
 int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N, int K, int C, float* z_out, void* stream);
 
 /* getBounds (addtional.py:14-18): w_prop (N,C), below (N,K) int64 -> bounds (N,K-1). */

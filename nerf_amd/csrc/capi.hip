@@ -243,7 +243,7 @@ int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, in
 }
 
 int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N, int K, int C, float* z_out, void* stream) {
-    if (N < 0 || K < 1 || C < 1 || K + C > 8192) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N < 0 || K < 1 || C < 1 || K + C > 4096) return fail(NERF_AMD_EINVAL, "bad size (K + C <= 4096: four rays of depths per workgroup live in 64 KiB of LDS)");
     if (N && (!z_fine || !z_coarse || !z_out)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_merge_sorted(z_fine, z_coarse, N, K, C, z_out, S(stream)), "nerf_amd_merge_depths");
 }

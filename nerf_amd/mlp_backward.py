@@ -16,7 +16,8 @@ import torch
 from . import ops
 
 
-_SPLIT = 4096        # rows per split-K slice of a wgrad GEMM
+_SPLIT = 4096        # minimum rows per split-K slice of a wgrad GEMM
+_SLICES = 128        # ... and the number of slices aimed at for large M (128 slices x 2 output tiles fill the 256 CUs)
 
 
 def _pad16(t: torch.Tensor) -> torch.Tensor:
@@ -45,15 +46,16 @@ def _bgrad_narrow(d16: torch.Tensor, n: int) -> torch.Tensor:
 
 def _wgrad(delta: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
     """delta^T @ act with the sample dimension as K.  The library picks a 16-workgroup kernel for a (256 x M) @ (M x 256) product, so
-    K is split by hand: one batched GEMM over slices of _SPLIT rows, partial products summed in fp32 (also the better rounding)."""
+    K is split by hand: one batched GEMM over slices of >= _SPLIT rows (about _SLICES of them for large M), partial products summed in fp32 (also the better rounding)."""
     M, O = delta.shape
-    n = M // _SPLIT
+    split = max(_SPLIT, M // _SLICES // _SPLIT * _SPLIT)
+    n = M // split
     if n < 2:
         return torch.mm(delta.t(), act).float()
     if O < 16:                                            # the 1- and 3-wide head gradients: pad to a real GEMM shape
         return _wgrad(_pad16(delta), act)[:O]
-    main = n * _SPLIT
-    out = torch.bmm(delta[:main].view(n, _SPLIT, -1).transpose(1, 2), act[:main].view(n, _SPLIT, -1)).sum(0, dtype=torch.float32)
+    main = n * split
+    out = torch.bmm(delta[:main].view(n, split, -1).transpose(1, 2), act[:main].view(n, split, -1)).sum(0, dtype=torch.float32)
     if main < M:
         out += torch.mm(delta[main:].t(), act[main:]).float()
     return out
