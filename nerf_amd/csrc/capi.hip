@@ -340,7 +340,7 @@ int nerf_amd_max_blur_backward(const float* weights, const float* d_out, int64_t
     return hip_status(sk_max_blur_backward(weights, d_out, N, Sn, d_weights, S(stream)), "nerf_amd_max_blur_backward");
 }
 int nerf_amd_get_bounds_backward(const int64_t* below, const float* d_bounds, int64_t N, int C, int K, float* d_w_prop, void* stream) {
-    if (N < 0 || C < 1 || C > 4096 || K < 2) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N < 0 || C < 1 || C > 4096 || K < 2 || K > 2048) return fail(NERF_AMD_EINVAL, "bad size (C <= 4096, 2 <= K <= 2048)");
     if (N && (!below || !d_bounds || !d_w_prop)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_get_bounds_backward(below, d_bounds, N, C, K, d_w_prop, S(stream)), "nerf_amd_get_bounds_backward");
 }
