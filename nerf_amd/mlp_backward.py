@@ -46,18 +46,19 @@ def _bgrad_narrow(d16: torch.Tensor, n: int) -> torch.Tensor:
 
 def _wgrad(delta: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
     """delta^T @ act with the sample dimension as K.  The library picks a 16-workgroup kernel for a (256 x M) @ (M x 256) product, so
-    K is split by hand: one batched GEMM over slices of >= _SPLIT rows (about _SLICES of them for large M), partial products summed in fp32 (also the better rounding)."""
+    K is split by hand: one batched GEMM over slices of >= _SPLIT rows (about _SLICES of them for large M), partial products leave the GEMM in fp32 and are summed in fp32."""
     M, O = delta.shape
     split = max(_SPLIT, M // _SLICES // _SPLIT * _SPLIT)
     n = M // split
+    f32 = {} if delta.dtype == torch.float32 else {"out_dtype": torch.float32}    # bf16 operands: products leave the GEMM unrounded
     if n < 2:
-        return torch.mm(delta.t(), act).float()
+        return torch.mm(delta.t(), act, **f32)
     if O < 16:                                            # the 1- and 3-wide head gradients: pad to a real GEMM shape
         return _wgrad(_pad16(delta), act)[:O]
     main = n * split
-    out = torch.bmm(delta[:main].view(n, split, -1).transpose(1, 2), act[:main].view(n, split, -1)).sum(0, dtype=torch.float32)
+    out = torch.bmm(delta[:main].view(n, split, -1).transpose(1, 2), act[:main].view(n, split, -1), **f32).sum(0)
     if main < M:
-        out += torch.mm(delta[main:].t(), act[main:]).float()
+        out += torch.mm(delta[main:].t(), act[main:], **f32)
     return out
 
 
