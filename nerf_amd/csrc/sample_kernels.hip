@@ -369,63 +369,61 @@ struct CompositeArgs {
     float* rgb; float* weights; float* depth; float* normal_img;
 };
 
-// Fast path of the compositing kernel for S <= 128 without normals (the render path): a ray is two 64-lane chunks; all of
-// its loads (one 16-byte rgbo record and one z per lane and chunk) are issued up front -- the neighbour z of the transmittance
+// Fast path of the compositing kernel for S <= 64 NCH (NCH = 2 or 4) without normals (the render path): a ray is NCH 64-lane chunks;
+// all of its loads (one 16-byte rgbo record and one z per lane and chunk) are issued up front -- the neighbour z of the transmittance
 // step comes from a lane shuffle instead of a second load -- and the NEXT ray of this wavefront is loaded before the current
 // one is reduced, so two rays' worth of HBM requests are in flight per wave.  Same arithmetic, same order as the generic path.
-struct RayRecs { f32x4 c0, c1; float z0, z1, dx, dy, dz; };
-DEVINL RayRecs load_ray(const CompositeArgs& a, int64_t n, int lane) {
-    RayRecs r;
+template <int NCH>
+struct RayRecs { f32x4 c[NCH]; float z[NCH]; float dx, dy, dz; };
+template <int NCH>
+DEVINL RayRecs<NCH> load_ray(const CompositeArgs& a, int64_t n, int lane) {
+    RayRecs<NCH> r;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     const f32x4* px = reinterpret_cast<const f32x4*>(a.rgbo) + n * a.S;
     const float* zz = a.z + n * a.z_stride;
     const float* dd = a.dirs + n * a.dirs_stride;
-    r.c0 = (lane < a.S) ? px[lane] : zero;
-    r.c1 = (64 + lane < a.S) ? px[64 + lane] : zero;
-    r.z0 = (lane < a.S) ? zz[lane] : 0.0f;
-    r.z1 = (64 + lane < a.S) ? zz[64 + lane] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int s = 64 * k + lane;
+        r.c[k] = (s < a.S) ? px[s] : zero;
+        r.z[k] = (s < a.S) ? zz[s] : 0.0f;
+    }
     r.dx = dd[0]; r.dy = dd[1]; r.dz = dd[2];
     return r;
 }
-DEVINL void composite_ray_fast(const CompositeArgs& a, int64_t n, const RayRecs& r, int lane) {
+template <int NCH>
+DEVINL void composite_ray_fast(const CompositeArgs& a, int64_t n, const RayRecs<NCH>& r, int lane) {
     const int S = a.S;
     const bool mul = (a.flags & 1) != 0;
     const float nrm = mul ? norm3(r.dx, r.dy, r.dz) : 1.0f;
-    const float zn0 = mul ? r.z0 * nrm : r.z0, zn1 = mul ? r.z1 * nrm : r.z1;
-    float nx0 = __shfl_down(zn0, 1, 64);
-    const float first1 = __shfl(zn1, 0, 64);
-    if (lane == 63) nx0 = first1;
-    const float nx1 = __shfl_down(zn1, 1, 64);
-    float w0 = 0.0f, w1 = 0.0f;
-    double p0 = 1.0, p1 = 1.0;
-    if (lane < S) {
-        const float delta = (lane + 1 < S) ? (nx0 - zn0) : 1e10f;
-        const float m = expf(-density_act(r.c0[3] + a.sigma_shift, a.act) * delta);
-        w0 = 1.0f - m; p0 = (double)(m + 1e-10f);
-    }
-    if (64 + lane < S) {
-        const float delta = (64 + lane + 1 < S) ? (nx1 - zn1) : 1e10f;
-        const float m = expf(-density_act(r.c1[3] + a.sigma_shift, a.act) * delta);
-        w1 = 1.0f - m; p1 = (double)(m + 1e-10f);
-    }
-    const double i0 = wave_incl_scan_mul(p0);
-    double e0 = __shfl_up(i0, 1, 64);
-    if (lane == 0) e0 = 1.0;
-    const double carry = __shfl(i0, 63, 64);                  // 1.0 * product of chunk 0
-    w0 *= (float)(1.0 * e0);
+    float zn[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) zn[k] = mul ? r.z[k] * nrm : r.z[k];
     float accr = 0.0f, accg = 0.0f, accb = 0.0f, accw = 0.0f, accd = 0.0f;
-    if (lane < S) { accr += w0 * r.c0[0]; accg += w0 * r.c0[1]; accb += w0 * r.c0[2]; accw += w0; accd += w0 * zn0; }
-    if (S > 64) {
-        const double i1 = wave_incl_scan_mul(p1);
-        double e1 = __shfl_up(i1, 1, 64);
-        if (lane == 0) e1 = 1.0;
-        w1 *= (float)(carry * e1);
-        if (64 + lane < S) { accr += w1 * r.c1[0]; accg += w1 * r.c1[1]; accb += w1 * r.c1[2]; accw += w1; accd += w1 * zn1; }
-    }
-    if (a.weights) {
-        float* wout = a.weights + n * S;
-        if (lane < S) wout[lane] = w0;
-        if (64 + lane < S) wout[64 + lane] = w1;
+    double carry = 1.0;
+    float* wout = a.weights ? a.weights + n * S : nullptr;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (k > 0 && 64 * k >= S) break;                        // wave-uniform
+        const int s = 64 * k + lane;
+        float nx = __shfl_down(zn[k], 1, 64);                   // z of sample s + 1: the next lane, or lane 0 of the next chunk
+        if (k + 1 < NCH) { const float first = __shfl(zn[k + 1 < NCH ? k + 1 : k], 0, 64); if (lane == 63) nx = first; }
+        float w = 0.0f;
+        double p = 1.0;
+        if (s < S) {
+            const float delta = (s + 1 < S) ? (nx - zn[k]) : 1e10f;
+            const float m = expf(-density_act(r.c[k][3] + a.sigma_shift, a.act) * delta);
+            w = 1.0f - m; p = (double)(m + 1e-10f);
+        }
+        const double incl = wave_incl_scan_mul(p);
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        w *= (float)(carry * excl);
+        carry *= __shfl(incl, 63, 64);
+        if (s < S) {
+            accr += w * r.c[k][0]; accg += w * r.c[k][1]; accb += w * r.c[k][2]; accw += w; accd += w * zn[k];
+            if (wout) wout[s] = w;
+        }
     }
     accr = wave_sum(accr); accg = wave_sum(accg); accb = wave_sum(accb); accw = wave_sum(accw); accd = wave_sum(accd);
     if (lane == 0) {
@@ -434,21 +432,26 @@ DEVINL void composite_ray_fast(const CompositeArgs& a, int64_t n, const RayRecs&
         if (a.depth) a.depth[n] = (accd - a.near) / (a.far - a.near);
     }
 }
+template <int NCH>
+DEVINL void composite_rays_fast(const CompositeArgs& a, int lane) {
+    const int64_t stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block();
+    if (n >= a.N) return;
+    RayRecs<NCH> cur = load_ray<NCH>(a, n, lane);
+    for (; n < a.N; n += stride) {
+        RayRecs<NCH> nxt = cur;
+        if (n + stride < a.N) nxt = load_ray<NCH>(a, n + stride, lane);
+        composite_ray_fast<NCH>(a, n, cur, lane);
+        cur = nxt;
+    }
+}
 
 __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     const int S = a.S;
     const int lane = lane_id();
-    if (S <= 128 && a.normal == nullptr && a.normal_img == nullptr) {
-        const int64_t stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
-        int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block();
-        if (n >= a.N) return;
-        RayRecs cur = load_ray(a, n, lane);
-        for (; n < a.N; n += stride) {
-            RayRecs nxt = cur;
-            if (n + stride < a.N) nxt = load_ray(a, n + stride, lane);
-            composite_ray_fast(a, n, cur, lane);
-            cur = nxt;
-        }
+    if (S <= 256 && a.normal == nullptr && a.normal_img == nullptr) {
+        if (S <= 128) composite_rays_fast<2>(a, lane);
+        else composite_rays_fast<4>(a, lane);
         return;
     }
     for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < a.N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {

@@ -983,3 +983,20 @@ def test_train_dump_rows_mask_equals_the_two_separate_passes(A, prec):
             assert max_abs(got_s.cpu(), want_s.cpu()) <= 1e-3 * max(1.0, want_s.abs().max().item())
             assert max_abs(got_s.cpu(), want_d.float().sum(0).cpu()) <= 1e-3 * max(1.0, want_s.abs().max().item())
     A.pkg.set_precision("fp32")
+
+
+@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300])
+def test_composite_sample_count_sweep(A, S):
+    """Compositing (nerf_base.py:75-113) across the kernel's paths: register fast path with 2 chunks (S <= 128) and 4 chunks (S <= 256),
+    generic path beyond -- rgb, weights and depth against the oracle, with and without the |d| scaling / white background."""
+    gen = torch.Generator().manual_seed(100 + S)
+    N = 333
+    rgbo = torch.randn(N, S, 4, generator=gen)
+    z = torch.sort(torch.rand(N, S, generator=gen) * 4 + 2, dim=-1)[0]
+    d = torch.randn(N, 3, generator=gen)
+    for mn, wb in ((True, True), (False, False)):
+        rgb, w, ex = A.nerf_base.NeRF.render(dev(rgbo), dev(z), dev(d), mul_norm=mn, white_bkg=wb, render_depth=(NEAR, FAR))
+        want_rgb, want_w, want_ex = O.composite(rgbo, z, d, mul_norm=mn, white_bkg=wb, render_depth=(NEAR, FAR))
+        # (the oracle's transmittance is an fp32 cumprod of S terms, the kernel's a double-precision scan: the gap grows with S)
+        assert max_abs(rgb.cpu(), want_rgb) <= 1e-5 and max_abs(w.cpu(), want_w) <= 3e-6, (S, mn, wb)
+        assert max_abs(ex["depth_img"].cpu(), want_ex["depth_img"]) <= 1e-5, (S, mn, wb)
