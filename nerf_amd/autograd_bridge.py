@@ -24,12 +24,77 @@ def _pe(x: torch.Tensor, L: int) -> torch.Tensor:
     return torch.stack((torch.sin(a), torch.cos(a)), dim=-2).reshape(x.shape[:-1] + (6 * L,))
 
 
+class _VJP:
+    """State of the device-side VJP (HipOp.backward): `active` while an expression is re-evaluated for its vector-Jacobian
+    product (the Linear layers then use _Linear's backward), `inputs_only` while RefNeRF.get_grad asks for d(out)/d(positions)
+    (parameter gradients are then not formed at all)."""
+    active = False
+    inputs_only = False
+
+
+class inputs_only_grad:
+    """with inputs_only_grad(): torch.autograd.grad(y, positions, ...) -- HipOp backward passes inside differentiate the non-parameter
+    inputs only (the density-gradient normals of ref_model.py:119-125 need no parameter gradient)."""
+
+    def __enter__(self):
+        self.prev, _VJP.inputs_only = _VJP.inputs_only, True
+
+    def __exit__(self, *exc):
+        _VJP.inputs_only = self.prev
+
+
+_WG_SPLIT, _WG_SLICES = 4096, 128
+
+
+class _Linear(torch.autograd.Function):
+    """F.linear for the VJP pass.  torch's own backward hands delta^T @ x -- a (O x M) @ (M x I) product with millions of rows as the
+    reduction dimension -- to a library kernel that runs on a few dozen workgroups, and sums the bias gradient with a
+    one-row-per-thread reduction; here the reduction dimension is split into ~128 slices (one batched GEMM, partial products summed)
+    and the bias gradient is a full-width reduction.  First order only (like every use in this package)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ w).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            M = g2.shape[0]
+            split = max(_WG_SPLIT, M // _WG_SLICES // _WG_SPLIT * _WG_SPLIT)
+            n = M // split
+            if n < 2:
+                gw = g2.t() @ x2
+            else:
+                main = n * split
+                gw = torch.bmm(g2[:main].view(n, split, -1).transpose(1, 2), x2[:main].view(n, split, -1)).sum(0)
+                if main < M:
+                    gw = gw + g2[main:].t() @ x2[main:]
+        if ctx.needs_input_grad[2]:
+            M, O = g2.shape
+            k = 256 // O if O <= 256 and 256 % O == 0 else 1          # narrow heads: fold k rows into one 256-wide row
+            main = M // k * k
+            gb = g2[:main].reshape(-1, k * O).sum(0).view(k, O).sum(0)
+            if main < M:
+                gb = gb + g2[main:].sum(0)
+        return gx, gw, gb
+
+
+def _lin(x, w, b):
+    return _Linear.apply(x, w, b) if _VJP.active else F.linear(x, w, b)
+
+
 def proposal_expr(pts, w, b):
     """ProposalNetwork.forward as torch ops (addtional.py:88-96); w, b = lists in state_dict order."""
     h = torch.cat((pts, _pe(pts, 10)), dim=-1)
     for i in range(4):
-        h = F.relu(F.linear(h, w[i], b[i]))
-    return F.linear(h, w[4], b[4]).squeeze(-1)
+        h = F.relu(_lin(h, w[i], b[i]))
+    return _lin(h, w[4], b[4]).squeeze(-1)
 
 
 def mip_expr(pts, w, b):
@@ -40,21 +105,21 @@ def mip_expr(pts, w, b):
     ed = torch.cat((d, _pe(d, 4)), dim=-1)
     h = ex
     for i in range(4):
-        h = F.relu(F.linear(h, w[i], b[i]))
+        h = F.relu(_lin(h, w[i], b[i]))
     g = torch.cat((ex, h), dim=-1)
     for i in range(4, 7):
-        g = F.relu(F.linear(g, w[i], b[i]))
-    bott = F.linear(g, w[7], b[7])
-    sigma = F.linear(g, w[8], b[8])
-    c = F.relu(F.linear(torch.cat((bott, ed), dim=-1), w[9], b[9]))
-    rgb = torch.sigmoid(F.linear(c, w[10], b[10]))
+        g = F.relu(_lin(g, w[i], b[i]))
+    bott = _lin(g, w[7], b[7])
+    sigma = _lin(g, w[8], b[8])
+    c = F.relu(_lin(torch.cat((bott, ed), dim=-1), w[9], b[9]))
+    rgb = torch.sigmoid(_lin(c, w[10], b[10]))
     return torch.cat((rgb, sigma), dim=-1)
 
 
 def ref_expr(pos, d, noise, P, ide_fn):
     """RefNeRF.forward as torch ops (ref_model.py:68-106, use_srgb off); P = {state_dict key: tensor}; `noise` = the train-mode
     perturbation of the bottle-neck vector or None.  Returns cat(rgb, density, normal) (..., 7)."""
-    lin = lambda name, t: F.linear(t, P[name + ".weight"], P[name + ".bias"])
+    lin = lambda name, t: _lin(t, P[name + ".weight"], P[name + ".bias"])
     ex = torch.cat((pos, _pe(pos, 10)), dim=-1)
     h = ex
     for i in (0, 2, 4, 6):
@@ -122,6 +187,7 @@ class HipOp(torch.autograd.Function):
         ctx.expr_fn = expr_fn
         ctx.save_for_backward(*[t for t in tensors if isinstance(t, torch.Tensor)])
         ctx.is_tensor = [isinstance(t, torch.Tensor) for t in tensors]
+        ctx.is_param = [isinstance(t, torch.nn.Parameter) for t in tensors]
         ctx.consts = [t for t in tensors if not isinstance(t, torch.Tensor)]
         with torch.no_grad():
             out = hip_fn(*[t.detach() if isinstance(t, torch.Tensor) else t for t in tensors])
@@ -148,7 +214,7 @@ class HipOp(torch.autograd.Function):
         for k, is_t in enumerate(ctx.is_tensor):
             if is_t:
                 t = saved.pop(0)
-                want = t.is_floating_point() and ctx.needs_input_grad[3 + k]
+                want = t.is_floating_point() and ctx.needs_input_grad[3 + k] and not (_VJP.inputs_only and ctx.is_param[k])
                 if want:
                     t = t.detach().requires_grad_(True)
                     leaves.append(t)
@@ -159,9 +225,13 @@ class HipOp(torch.autograd.Function):
                 args.append(consts.pop(0))
         if not leaves:
             return (None, None, None, *[None] * len(args))
-        with torch.enable_grad():
-            y = ctx.expr_fn(*args)
-        grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
+        prev, _VJP.active = _VJP.active, True
+        try:
+            with torch.enable_grad():
+                y = ctx.expr_fn(*args)
+            grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
+        finally:
+            _VJP.active = prev
         gi = iter(grads)
         return (None, None, None, *[next(gi) if w else None for w in wanted])
 

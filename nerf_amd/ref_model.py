@@ -118,7 +118,8 @@ class RefNeRF(NeRF, PackedWeightsMixin):
         every differentiable op of this package -- e.g. the proposal density w.r.t. its sample positions (train.py:165-168,
         `prop_normal`), whose position gradient comes from the device-side VJP of autograd_bridge.py.  RefNeRF's own training
         forward is not built (see forward)."""
-        grad, = torch.autograd.grad(func_val, inputs, torch.ones_like(func_val), retain_graph=True)
+        with ab.inputs_only_grad():                              # no parameter gradient is needed for d(func)/d(inputs)
+            grad, = torch.autograd.grad(func_val, inputs, torch.ones_like(func_val), retain_graph=True)
         grad_norm = grad.norm(dim=-1, keepdim=True)
         return grad / torch.maximum(torch.full_like(grad_norm, 1e-5), grad_norm)
 

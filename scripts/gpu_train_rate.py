@@ -66,7 +66,61 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False)
     return dt
 
 
+def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False):
+    """The Ref-NeRF branch of the step with prop_normal (train.py:164-199): train-mode forward, density-gradient normals from
+    RefNeRF.get_grad on both networks, normal / back-face / coarse-normal losses, backward, Adam."""
+    from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
+    nerf_amd.set_precision(precision)
+    torch.manual_seed(0)
+    prop, net = ProposalNetwork(10, 256).cuda().train(), RefNeRF(10, 4).cuda().train()
+    opt = torch.optim.Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-4)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
+    d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
+    rays = torch.cat((o, d), -1).cuda().contiguous()
+    tgt = torch.rand(n_rays, 3).cuda()
+    res = (FAR - NEAR) / c_n
+    base = torch.linspace(NEAR, FAR - res, c_n).cuda()
+
+    def step():
+        z_c = base + torch.rand((n_rays, c_n), device="cuda") * res
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous().requires_grad_(True)
+        dens = prop.forward(pts)
+        coarse_grad = -RefNeRF.get_grad(dens, pts)
+        dens = F.softplus(dens)
+        pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
+        fl, below = inverseSample(pw, z_c, f_n + 1, sort=True)
+        samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, fl, below)
+        pos, dd = samples.split((3, 3), dim=-1)
+        pos = pos.contiguous().requires_grad_(True)
+        rgbo, nrm = net.forward(pos, dd.contiguous())
+        dgrad = -RefNeRF.get_grad(rgbo[..., -1], pos)
+        rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
+        rend, wts, _ = NeRF.render(rgbo, fl, rays[:, 3:], net.density_act)
+        nl = WeightedNormalLoss()(wts, dgrad, nrm)
+        bf = BackFaceLoss()(wts, nrm, dd)
+        cnl = WeightedNormalLoss()(pw, RefNeRF.coarse_grad_select(dgrad, sort_ids, c_n).detach(), coarse_grad)
+        loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2) + 4e-4 * (nl + 0.1 * cnl) + 0.1 * bf
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    if not quiet:
+        print("Ref-NeRF train step  %5d rays  %3d+%3d samples  %s : %7.2f ms/iter  %9.0f rays/s" % (n_rays, c_n, f_n, precision, dt * 1e3, n_rays / dt), flush=True)
+    return dt
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":         # Ref-NeRF step: ref n_rays precision
+        run_ref(int(sys.argv[2]), 64, 128, sys.argv[3])
+        sys.exit(0)
     if len(sys.argv) > 1:                                  # one configuration (for profiling): n_rays precision [graph]
         run(int(sys.argv[1]), 64, 128, sys.argv[2], iters=5 if len(sys.argv) < 4 else 50, warm=2 if len(sys.argv) < 4 else 5, graph=len(sys.argv) > 3)
         sys.exit(0)
