@@ -30,6 +30,7 @@ class _VJP:
     (parameter gradients are then not formed at all)."""
     active = False
     inputs_only = False
+    bf16 = False          # the op ran in BF16 precision: the re-evaluated Linear layers use bf16 operands with fp32 accumulation too
 
 
 class inputs_only_grad:
@@ -54,27 +55,23 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.k = x.shape[-1]
+        if _VJP.bf16 and w.shape[0] >= 16:                    # the kernels' arithmetic: bf16 operands, fp32 accumulate, fp32 elementwise
+            x, w = x.to(torch.bfloat16), w.to(torch.bfloat16)   # (narrow heads stay fp32: the library has no good bf16 kernels for them)
+            if ctx.k % 8:                                     # ... nor for odd leading dimensions: zero-pad the reduction dimension
+                x, w = F.pad(x, (0, 8 - ctx.k % 8)), F.pad(w, (0, 8 - ctx.k % 8))
+            ctx.save_for_backward(x, w)
+            return torch.mm(x.reshape(-1, x.shape[-1]), w.t(), out_dtype=torch.float32).reshape(x.shape[:-1] + (w.shape[0],)) + b
         ctx.save_for_backward(x, w)
         return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        low = x.dtype == torch.bfloat16
+        f32 = {"out_dtype": torch.float32} if low else {}
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = (g2 @ w).reshape(x.shape)
-        if ctx.needs_input_grad[1]:
-            M = g2.shape[0]
-            split = max(_WG_SPLIT, M // _WG_SLICES // _WG_SPLIT * _WG_SPLIT)
-            n = M // split
-            if n < 2:
-                gw = g2.t() @ x2
-            else:
-                main = n * split
-                gw = torch.bmm(g2[:main].view(n, split, -1).transpose(1, 2), x2[:main].view(n, split, -1)).sum(0)
-                if main < M:
-                    gw = gw + g2[main:].t() @ x2[main:]
         if ctx.needs_input_grad[2]:
             M, O = g2.shape
             k = 256 // O if O <= 256 and 256 % O == 0 else 1          # narrow heads: fold k rows into one 256-wide row
@@ -82,6 +79,25 @@ class _Linear(torch.autograd.Function):
             gb = g2[:main].reshape(-1, k * O).sum(0).view(k, O).sum(0)
             if main < M:
                 gb = gb + g2[main:].sum(0)
+        if low:
+            g2 = g2.to(torch.bfloat16)
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g2, w, **f32).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            M = g2.shape[0]
+            split = max(_WG_SPLIT, M // _WG_SLICES // _WG_SPLIT * _WG_SPLIT)
+            n = M // split
+            if n < 2:
+                gw = torch.mm(g2.t(), x2, **f32)
+            else:
+                main = n * split
+                gw = torch.bmm(g2[:main].view(n, split, -1).transpose(1, 2), x2[:main].view(n, split, -1), **f32).sum(0)
+                if main < M:
+                    gw = gw + torch.mm(g2[main:].t(), x2[main:], **f32)
+        if gx is not None and gx.shape[-1] != ctx.k:
+            gx = gx[..., :ctx.k]
+        if gw is not None and gw.shape[-1] != ctx.k:
+            gw = gw[:, :ctx.k]
         return gx, gw, gb
 
 
@@ -188,6 +204,7 @@ class HipOp(torch.autograd.Function):
         ctx.save_for_backward(*[t for t in tensors if isinstance(t, torch.Tensor)])
         ctx.is_tensor = [isinstance(t, torch.Tensor) for t in tensors]
         ctx.is_param = [isinstance(t, torch.nn.Parameter) for t in tensors]
+        ctx.bf16 = ops.current_precision() == ops.BF16
         ctx.consts = [t for t in tensors if not isinstance(t, torch.Tensor)]
         with torch.no_grad():
             out = hip_fn(*[t.detach() if isinstance(t, torch.Tensor) else t for t in tensors])
@@ -225,13 +242,14 @@ class HipOp(torch.autograd.Function):
                 args.append(consts.pop(0))
         if not leaves:
             return (None, None, None, *[None] * len(args))
-        prev, _VJP.active = _VJP.active, True
+        prev, prev16 = _VJP.active, _VJP.bf16
+        _VJP.active, _VJP.bf16 = True, ctx.bf16
         try:
             with torch.enable_grad():
                 y = ctx.expr_fn(*args)
             grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
         finally:
-            _VJP.active = prev
+            _VJP.active, _VJP.bf16 = prev, prev16
         gi = iter(grads)
         return (None, None, None, *[next(gi) if w else None for w in wanted])
 

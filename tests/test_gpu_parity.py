@@ -1000,3 +1000,49 @@ def test_composite_sample_count_sweep(A, S):
         # (the oracle's transmittance is an fp32 cumprod of S terms, the kernel's a double-precision scan: the gap grows with S)
         assert max_abs(rgb.cpu(), want_rgb) <= 1e-5 and max_abs(w.cpu(), want_w) <= 3e-6, (S, mn, wb)
         assert max_abs(ex["depth_img"].cpu(), want_ex["depth_img"]) <= 1e-5, (S, mn, wb)
+
+
+def test_vjp_in_bf16_mode_uses_the_kernels_arithmetic(A):
+    """In BF16 precision the device-side VJP (position gradients / Ref-NeRF training) re-evaluates its Linear layers with bf16 operands
+    and fp32 accumulation like the forward kernels: density-gradient normals and parameter gradients keep the direction of the
+    fp32 autograd result, and RefNeRF.get_grad forms no parameter gradient."""
+    from nerf_amd import autograd_bridge as ab
+    from nerf_amd.ref_model import RefNeRF
+    prop, _ = build_nets(A, "small")
+    prop.train()
+    gen = torch.Generator().manual_seed(43)
+    pts0 = (torch.rand(64, 64, 3, generator=gen) * 2 - 1).cuda()
+    layers = prop._linear_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    res = {}
+    for prec in ("fp32", "bf16"):
+        A.pkg.set_precision(prec)
+        for p_ in params:
+            p_.grad = None
+        pts = pts0.clone().requires_grad_(True)
+        dens = prop.forward(pts)
+        normals = RefNeRF.get_grad(dens, pts)
+        assert all(p_.grad is None for p_ in params)                 # autograd.grad leaves .grad alone ...
+        F.softplus(dens).sum().backward()
+        res[prec] = (normals.detach(), [p_.grad.clone() for p_ in params])
+    A.pkg.set_precision("fp32")
+    cos_n = F.cosine_similarity(res["bf16"][0].reshape(-1, 3), res["fp32"][0].reshape(-1, 3), dim=-1)
+    assert cos_n.median().item() >= 0.999 and (cos_n >= 0.9).float().mean().item() >= 0.97, (cos_n.median().item(), (cos_n >= 0.9).float().mean().item())
+    for k, (a_, b_) in enumerate(zip(res["bf16"][1], res["fp32"][1])):
+        cos = F.cosine_similarity(a_.reshape(1, -1), b_.reshape(1, -1)).item()
+        assert cos >= 0.97, (k, cos)
+    # ... and the pass itself is told to skip them: inside inputs_only_grad() a parameter never becomes a VJP leaf
+    seen = []
+    real = torch.autograd.grad
+    def spy(y, leaves, *a, **k):
+        seen.append(len(leaves))
+        return real(y, leaves, *a, **k)
+    pts = pts0.clone().requires_grad_(True)
+    dens = prop.forward(pts)
+    torch.autograd.grad = spy
+    try:
+        with ab.inputs_only_grad():
+            real(dens, pts, torch.ones_like(dens), retain_graph=True)
+    finally:
+        torch.autograd.grad = real
+    assert seen == [1], seen                                          # the VJP inside HipOp.backward differentiated the positions only
