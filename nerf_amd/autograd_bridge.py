@@ -73,7 +73,7 @@ class _Linear(torch.autograd.Function):
         f32 = {"out_dtype": torch.float32} if low else {}
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         gx = gw = gb = None
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and not _VJP.inputs_only:
             M, O = g2.shape
             k = 256 // O if O <= 256 and 256 % O == 0 else 1          # narrow heads: fold k rows into one 256-wide row
             main = M // k * k
@@ -84,7 +84,7 @@ class _Linear(torch.autograd.Function):
             g2 = g2.to(torch.bfloat16)
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g2, w, **f32).reshape(x.shape)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _VJP.inputs_only:
             M = g2.shape[0]
             split = max(_WG_SPLIT, M // _WG_SLICES // _WG_SPLIT * _WG_SPLIT)
             n = M // split
@@ -131,7 +131,7 @@ class _LinearReLU(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.mm(g2, w2, **({} if ctx.xdtype == y.dtype else f32))[:, :ctx.k].reshape(ctx.xshape)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _VJP.inputs_only:
             M = g2.shape[0]
             split = max(_WG_SPLIT, M // _WG_SLICES // _WG_SPLIT * _WG_SPLIT)
             n = M // split
@@ -143,7 +143,7 @@ class _LinearReLU(torch.autograd.Function):
                 if main < M:
                     gw = gw + torch.mm(g2[main:].t(), x2[main:], **f32)
             gw = gw[:, :ctx.k]
-        return gx, gw, (gb if ctx.needs_input_grad[2] else None)
+        return gx, gw, (gb if ctx.needs_input_grad[2] and not _VJP.inputs_only else None)
 
 
 def _lin(x, w, b):
@@ -281,26 +281,41 @@ class HipOp(torch.autograd.Function):
                 return (None, None, None, *grads)
         # only the inputs autograd actually asks for become leaves: e.g. the sample positions of MipNeRF carry no gradient, which
         # spares the VJP the first layer's dgrad and the whole sin/cos backward
-        args, leaves, wanted = [], [], []
-        for k, is_t in enumerate(ctx.is_tensor):
-            if is_t:
-                t = saved.pop(0)
-                want = t.is_floating_point() and ctx.needs_input_grad[3 + k] and not (_VJP.inputs_only and ctx.is_param[k])
-                if want:
-                    t = t.detach().requires_grad_(True)
-                    leaves.append(t)
-                wanted.append(want)
-                args.append(t)
-            else:
-                wanted.append(False)
-                args.append(consts.pop(0))
-        if not leaves:
-            return (None, None, None, *[None] * len(args))
+        cache = getattr(ctx, "vjp_cache", None)
+        ctx.vjp_cache = None
         prev, prev16 = _VJP.active, _VJP.bf16
         _VJP.active, _VJP.bf16 = True, ctx.bf16
         try:
-            with torch.enable_grad():
-                y = ctx.expr_fn(*args)
+            if cache is None:
+                args, leaves, wanted = [], [], []
+                for k, is_t in enumerate(ctx.is_tensor):
+                    if is_t:
+                        t = saved.pop(0)
+                        want = t.is_floating_point() and ctx.needs_input_grad[3 + k]
+                        if want:
+                            t = t.detach().requires_grad_(True)
+                            leaves.append(t)
+                        wanted.append(want)
+                        args.append(t)
+                    else:
+                        wanted.append(False)
+                        args.append(consts.pop(0))
+                if not leaves:
+                    return (None, None, None, *[None] * len(args))
+                with torch.enable_grad():
+                    y = ctx.expr_fn(*args)
+            else:
+                y, leaves, wanted = cache
+            if _VJP.inputs_only:
+                # RefNeRF.get_grad (retain_graph): differentiate the non-parameter inputs only -- the Linear layers skip their weight
+                # and bias gradients -- and keep the re-evaluated graph: the loss backward that follows on the same op re-uses it
+                # instead of evaluating the expression a second time
+                sel = [w and not p_ for w, p_ in zip(wanted, ctx.is_param)]
+                it = iter(leaves)
+                sub = [t for w, s_ in zip(wanted, sel) for t in ([next(it)] if w else []) if s_]
+                part = iter(torch.autograd.grad(y, sub, grad.contiguous(), allow_unused=True, retain_graph=True)) if sub else iter(())
+                ctx.vjp_cache = (y, leaves, wanted)
+                return (None, None, None, *[next(part) if s_ else None for s_ in sel])
             grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
         finally:
             _VJP.active, _VJP.bf16 = prev, prev16
