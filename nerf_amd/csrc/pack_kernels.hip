@@ -21,8 +21,14 @@ struct PackLayer {
     int seg_kind[3], seg_nkg[3], seg_col[3], seg_L[3], seg_width[3];
 };
 
+// all layers of a network in ONE launch (blockIdx.y = layer): re-packing after every optimiser step is part of the training step,
+// where the 5 + 10 separate launches were ~3 % of a 512-ray step
+constexpr int PACK_MAX_LAYERS = 18;
+struct PackBatch { PackLayer L[PACK_MAX_LAYERS]; };
+
 template <bool BF16>
-__global__ void pack_layer_kernel(PackLayer L, char* __restrict__ stream, float* __restrict__ bias) {
+__global__ void pack_layer_kernel(PackBatch B, char* __restrict__ stream, float* __restrict__ bias) {
+    const PackLayer& L = B.L[blockIdx.y];
     const int n_elem = L.nfb * L.nkg * 512;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_elem; i += gridDim.x * blockDim.x) {
         const int e = i & 7, lane = (i >> 3) & 63, frag = i >> 9;
@@ -85,11 +91,14 @@ __global__ void fold_bottleneck_kernel(const float* __restrict__ w8, const float
     }
 }
 
-int launch_pack(const PackLayer& L, int precision, char* stream, float* bias, hipStream_t st) {
-    const int n = L.nfb * L.nkg * 512;
-    const int blocks = (n + 255) / 256;
-    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL(pack_layer_kernel<true>, dim3(blocks), dim3(256), 0, st, L, stream, bias);
-    else hipLaunchKernelGGL(pack_layer_kernel<false>, dim3(blocks), dim3(256), 0, st, L, stream, bias);
+int launch_pack(const PackBatch& B, int n_layers, int precision, char* stream, float* bias, hipStream_t st) {
+    int blocks = 1;
+    for (int l = 0; l < n_layers; ++l) {
+        const int n = B.L[l].nfb * B.L[l].nkg * 512;
+        blocks = ((n + 255) / 256 > blocks) ? (n + 255) / 256 : blocks;
+    }
+    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL(pack_layer_kernel<true>, dim3(blocks, n_layers), dim3(256), 0, st, B, stream, bias);
+    else hipLaunchKernelGGL(pack_layer_kernel<false>, dim3(blocks, n_layers), dim3(256), 0, st, B, stream, bias);
     return (int)hipGetLastError();
 }
 
@@ -101,13 +110,12 @@ int pack_proposal(int precision, const float* const* w, const float* const* b, v
     float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
     const int rows[5] = {256, 256, 256, 256, 1};
     const int inf[5] = {63, 256, 256, 256, 256};
+    PackBatch B = {};
     for (int l = 0; l < 5; ++l) {
-        PackLayer L = make_layer(w[l], b[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        PackLayer& L = B.L[l] = make_layer(w[l], b[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
         if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
-        int e = launch_pack(L, precision, stream, bias, st);
-        if (e) return e;
     }
-    return 0;
+    return launch_pack(B, 5, precision, stream, bias, st);
 }
 
 int pack_mip(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
@@ -123,8 +131,9 @@ int pack_mip(int precision, const float* const* w, const float* const* b, void* 
     const float* lb[10] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[8], bf, b[10]};
     const int rows[10] = {256, 256, 256, 256, 256, 256, 256, 1, 128, 3};
     const int inf[10] = {63, 256, 256, 256, 319, 256, 256, 256, 256, 128};
+    PackBatch B = {};
     for (int l = 0; l < 10; ++l) {
-        PackLayer L = make_layer(lw[l], lb[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        PackLayer& L = B.L[l] = make_layer(lw[l], lb[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
         if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
         if (l == 4) { set_seg(L, 0, SEG_PE, 4, 0, 10, 63); set_seg(L, 1, SEG_DMAP, 16, 63, 0, 256); }
         if (l == 8) {                                 // K = [folded 256 | direction encoding 27 from rgb_layer.0[:, 256:]]
@@ -132,10 +141,8 @@ int pack_mip(int precision, const float* const* w, const float* const* b, void* 
             set_seg(L, 1, SEG_PE, 2, 256, 4, 27);
             L.seg_w[1] = w[9]; L.seg_stride[1] = 283;
         }
-        int e = launch_pack(L, precision, stream, bias, st);
-        if (e) return e;
     }
-    return 0;
+    return launch_pack(B, 10, precision, stream, bias, st);
 }
 
 // tensors: 0-3 spa_block1.{0,2,4,6}; 4-7 spa_block2.{0,2,4,6}; 8 bottle_neck; 9 heads (11,256); 10-13 dir_block1.{0,2,4,6};
@@ -147,17 +154,17 @@ int pack_ref(int precision, const float* const* w, const float* const* b, void* 
     const int tensor_of[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18};
     const int rows[18] = {256, 256, 256, 256, 256, 256, 256, 256, 128, 256, 256, 256, 256, 256, 256, 256, 256, 3};
     const int inf[18] = {63, 256, 256, 256, 319, 256, 256, 256, 256, 167, 256, 256, 256, 423, 256, 256, 256, 256};
+    PackBatch B = {};
     for (int l = 0; l < 18; ++l) {
         const int t = tensor_of[l];
-        PackLayer L = make_layer(w[t], b[t], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        PackLayer& L = B.L[l] = make_layer(w[t], b[t], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
         if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
         if (l == 4) { set_seg(L, 0, SEG_PE, 4, 0, 10, 63); set_seg(L, 1, SEG_DMAP, 16, 63, 0, 256); }
         if (l == 8) { L.w2 = w[9]; L.b2 = b[9]; L.rows2 = 11; L.stride2 = 256; }              // bottle_neck rows + the 11 head rows
         if (l == 9) { set_seg(L, 0, SEG_DMAP, 8, 0, 0, 128); set_seg(L, 1, SEG_IDE, 3, 128, 0, 39); }
         if (l == 13) { set_seg(L, 0, SEG_DMAP, 8, 0, 0, 128); set_seg(L, 1, SEG_IDE, 3, 128, 0, 39); set_seg(L, 2, SEG_DMAP, 16, 167, 0, 256); }
-        int e = launch_pack(L, precision, stream, bias, st);
-        if (e) return e;
     }
+    if (int e = launch_pack(B, 18, precision, stream, bias, st)) return e;
     if (int e = (int)hipMemcpyAsync(bias + Lay::N_BIAS, w[19], 9 * 19 * sizeof(float), hipMemcpyDeviceToDevice, st)) return e;
     return 0;
 }
