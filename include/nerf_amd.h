@@ -186,7 +186,9 @@ int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const fl
                        float* rgb, float* weights, float* depth, float* normal_img, void* stream);
 
 /* The depth sort of NeRF.coarseFineMerge (nerf_base.py:59-73) for the render path (procedures.py:72): z_fine (N,K) and z_coarse
- * (N,C), BOTH ascending along the last dimension -> z_out (N, K+C-1) = sort(cat(z_fine, z_coarse))[..., :-1], as a merge.  K + C <= 4096. */
+ * (N,C) -> z_out (N, K+C-1) = sort(cat(z_fine, z_coarse))[..., :-1].  Both inputs are normally ascending along the last dimension
+ * (then this is a merge); a ray whose input is out of order -- stratified depths with a jitter above the bin spacing, n_fine < 63 --
+ * is sorted first, so the result always equals the sort.  K + C <= 2048. */
 int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N, int K, int C, float* z_out, void* stream);
 
 /* getBounds (addtional.py:14-18): w_prop (N,C), below (N,K) int64 -> bounds (N,K-1). */
@@ -260,6 +262,16 @@ int    nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int
                             const float* z_base, const float* u_strat, const float* u_inv, int64_t N, int n_fine,
                             float near, float far, int white_bkg,
                             float* rgb, float* depth, float* weights, void* workspace, void* stream);
+
+/* The same tile body for a Ref-NeRF fine network (procedures.py:64-85 with the is_ref_model branch, lines 71-74): proposal pass,
+ * resampling, the n_fine+1 fine and 64 coarse depths merged (the last one dropped), Ref-NeRF MLP on the n_fine+64 samples,
+ * compositing with sigma -> softplus(sigma + 0.5).  normal_img (N) and cam_dir (3 floats on the device: render_pose[:, -2]) are
+ * both given or both NULL (procedures.py:79-81).  Six launches.  Workspace: nerf_amd_render_ref_workspace_bytes(N, n_fine). */
+size_t nerf_amd_render_ref_workspace_bytes(int64_t N, int n_fine);
+int    nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, int precision, const float* rays,
+                                const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
+                                const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, const float* cam_dir,
+                                float* rgb, float* depth, float* normal_img, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,9 @@ SIGNATURES = {
                                      C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_train_dump_rows_mask_partials": (i64, []),
     "nerf_amd_train_dump_rows_mask": (C.c_int, [c_void, C.c_int, C.c_int, i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
+    "nerf_amd_render_ref_workspace_bytes": (C.c_size_t, [i64, C.c_int]),
+    "nerf_amd_render_rays_ref": (C.c_int, [c_void, c_void, C.c_int, c_void, C.POINTER(Samples), i64, c_void, c_void, c_void, i64, C.c_int,
+                                          C.c_float, C.c_float, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_encode_rows": (C.c_int, [c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_merge_depths": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_get_bounds": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),

@@ -243,7 +243,7 @@ int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, in
 }
 
 int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N, int K, int C, float* z_out, void* stream) {
-    if (N < 0 || K < 1 || C < 1 || K + C > 4096) return fail(NERF_AMD_EINVAL, "bad size (K + C <= 4096: four rays of depths per workgroup live in 64 KiB of LDS)");
+    if (N < 0 || K < 1 || C < 1 || K + C > 2048) return fail(NERF_AMD_EINVAL, "bad size (K + C <= 2048: four rays of depths and their sort scratch per workgroup live in 64 KiB of LDS)");
     if (N && (!z_fine || !z_coarse || !z_out)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_merge_sorted(z_fine, z_coarse, N, K, C, z_out, S(stream)), "nerf_amd_merge_depths");
 }
@@ -401,6 +401,65 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     const int flags = 1 | (white_bkg ? 2 : 0);              // row 10
     if (int e = sk_composite(rgbo, z_fine, n_fine + 1, rays + 3, 6, N, n_fine, flags, NERF_AMD_ACT_RELU, 0.0f, near, far, nullptr,
                              nullptr, rgb, weights, depth, nullptr, st)) return hip_status(e, "composite");
+    return NERF_AMD_OK;
+}
+
+// workspace of nerf_amd_render_rays_ref: density (N,64) | z_fine (N, n_fine+1) | z_coarse (N,64) | z_all (N, n_fine+64) | rgbo (N, n_fine+64, 4)
+//                                        | normals (N, n_fine+64, 3) | rays (N, 6)
+static size_t ref_ws_part(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+size_t nerf_amd_render_ref_workspace_bytes(int64_t N, int n_fine) {
+    if (N < 0 || n_fine < 1) return 0;
+    const size_t n = (size_t)N, S = (size_t)n_fine + 64;
+    return ref_ws_part(n * 64 * 4) * 2 + ref_ws_part(n * (n_fine + 1) * 4) + ref_ws_part(n * S * 4) + ref_ws_part(n * S * 16) + ref_ws_part(n * S * 12) +
+           n * 24 + 256;
+}
+
+int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, int precision, const float* rays,
+                             const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
+                             const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, const float* cam_dir,
+                             float* rgb, float* depth, float* normal_img, void* workspace, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
+    if (N == 0) return NERF_AMD_OK;
+    if (!packed_prop || !packed_ref || !z_base || !u_strat || !u_inv || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (!rays && !camera) return fail(NERF_AMD_EINVAL, "need rays or camera");
+    if ((normal_img != nullptr) != (cam_dir != nullptr)) return fail(NERF_AMD_EINVAL, "normal_img and cam_dir go together");
+    if (camera && camera->contract) return fail(NERF_AMD_EINVAL, "scene contraction is wired for the MipNeRF path only");
+    constexpr int C = 64;                                   // procedures.py:22 RENDER_COARSE_PNUM
+    const int S_all = n_fine + C;                           // (n_fine + 1) fine + 64 coarse depths, the last one dropped
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    auto take = [&](size_t bytes) { float* p = reinterpret_cast<float*>(ws); ws += ref_ws_part(bytes); return p; };
+    float* density = take((size_t)N * C * 4);
+    float* z_fine = take((size_t)N * (n_fine + 1) * 4);
+    float* z_coarse = take((size_t)N * C * 4);
+    float* z_all = take((size_t)N * S_all * 4);
+    float* rgbo = take((size_t)N * S_all * 16);
+    float* normals = take((size_t)N * S_all * 12);
+    hipStream_t st = S(stream);
+    if (!rays) {                                            // row 1: procedures.py:43-51,64
+        if (camera->H <= 0 || camera->W <= 0 || ray_offset < 0 || ray_offset + N > (int64_t)camera->H * camera->W)
+            return fail(NERF_AMD_EINVAL, "ray range outside the camera image");
+        float* gen = reinterpret_cast<float*>(ws);
+        if (int e = sk_generate_rays(camera->pose, camera->H, camera->W, camera->fx, camera->fy, ray_offset, N, gen, st))
+            return hip_status(e, "ray generation");
+        rays = gen;
+    }
+    const float jitter = (far - near) / (float)n_fine;      // procedures.py:59
+    nerf_amd_samples sc{};                                  // rows 2-4
+    sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
+    sc.z_jitter = jitter; sc.z_stride = C;
+    if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
+    // rows 5-7 (procedures.py:68-70), also returning the stratified depths the proposal pass used
+    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, z_fine,
+                            nullptr, nullptr, z_coarse, st)) return hip_status(e, "resample");
+    // row 8, Ref-NeRF branch (procedures.py:71-74): fine and coarse depths merged, the last one dropped
+    if (int e = sk_merge_sorted(z_fine, z_coarse, N, n_fine + 1, C, z_all, st)) return hip_status(e, "depth merge");
+    nerf_amd_samples sf{};                                  // row 13
+    sf.mode = 1; sf.rays = rays; sf.S = S_all; sf.M = N * S_all; sf.z = z_all; sf.z_stride = S_all;
+    if (int e = mlp_launch_ref(packed_ref, precision, sf, rgbo, normal_img ? normals : nullptr, nullptr, st)) return hip_status(e, "Ref-NeRF MLP");
+    const int flags = 1 | (white_bkg ? 2 : 0);              // row 10 with sigma -> softplus(sigma + 0.5) (procedures.py:73)
+    if (int e = sk_composite(rgbo, z_all, S_all, rays + 3, 6, N, S_all, flags, NERF_AMD_ACT_SOFTPLUS, 0.5f, near, far,
+                             normal_img ? normals : nullptr, cam_dir, rgb, nullptr, depth, normal_img, st)) return hip_status(e, "composite");
     return NERF_AMD_OK;
 }
 

@@ -872,14 +872,31 @@ __global__ __launch_bounds__(256) void relu_mask_bias_kernel(uint32_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------- row 8 (Ref-NeRF render path)
-// coarseFineMerge's sort (nerf_base.py:59-73) for the render path: both inputs are already ascending (the K fine depths come
-// sorted out of the resampling, the C coarse ones are stratified), so the sort of their concatenation is a MERGE: element i of
-// `a` goes to i + #(b < a_i), element j of `b` to j + #(a <= b_j) (binary searches in LDS).  The last merged depth is dropped.
-// Sorted VALUES are independent of how ties are ordered, so z_out equals torch.sort(cat(a, b))[0][:, :-1] bit for bit.
+// coarseFineMerge's sort (nerf_base.py:59-73) for the render path: the K fine depths come sorted out of the resampling and the C
+// coarse ones are stratified, so the sort of their concatenation is normally a MERGE: element i of `a` goes to i + #(b < a_i),
+// element j of `b` to j + #(a <= b_j) (binary searches in LDS).  The last merged depth is dropped.  Sorted VALUES are independent of
+// how ties are ordered, so z_out equals torch.sort(cat(a, b))[0][:, :-1] bit for bit.  The stratified depths are only ascending
+// while the jitter (far - near) / n_fine does not exceed the spacing of the 64 bins, i.e. for n_fine >= 63: a wave that finds one
+// of its inputs out of order first sorts it in LDS (stable rank sort, O(n^2 / 64) per lane -- the rare path).
+DEVINL void wave_sort_if_needed(float* v, float* tmp, int n, int lane) {
+    int bad = 0;
+    for (int i = lane; i + 1 < n; i += 64) bad |= (v[i] > v[i + 1]) ? 1 : 0;
+    if (!__any(bad)) return;
+    for (int i = lane; i < n; i += 64) {
+        const float x = v[i];
+        int r = 0;
+        for (int k = 0; k < n; ++k) { const float y = v[k]; r += (y < x || (y == x && k < i)) ? 1 : 0; }
+        tmp[r] = x;
+    }
+    lds_wave_sync();
+    for (int i = lane; i < n; i += 64) v[i] = tmp[i];
+    lds_wave_sync();
+}
 __global__ __launch_bounds__(256) void merge_sorted_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t N, int K, int C,
                                                            float* __restrict__ out) {
-    float* la = reinterpret_cast<float*>(smem) + wave_in_block() * (K + C);
+    float* la = reinterpret_cast<float*>(smem) + wave_in_block() * 2 * (K + C);
     float* lb = la + K;
+    float* tmp = lb + C;                                        // K + C floats of scratch for the rare sorting path
     const int lane = lane_id();
     const int T = K + C - 1;
     for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
@@ -887,6 +904,8 @@ __global__ __launch_bounds__(256) void merge_sorted_kernel(const float* __restri
         for (int i = lane; i < K; i += 64) la[i] = a[n * K + i];
         for (int j = lane; j < C; j += 64) lb[j] = b[n * C + j];
         lds_wave_sync();
+        wave_sort_if_needed(la, tmp, K, lane);
+        wave_sort_if_needed(lb, tmp, C, lane);
         float* o = out + n * T;
         for (int i = lane; i < K; i += 64) {
             const float v = la[i];
@@ -1048,7 +1067,7 @@ int sk_relu_mask_bias(void* delta, const void* act, int elem_bytes, int64_t rows
 }
 int sk_merge_sorted(const float* a, const float* b, int64_t N, int K, int C, float* out, hipStream_t st) {
     if (N == 0) return 0;
-    const size_t lds = WAVES_PER_BLOCK * (size_t)(K + C) * 4;
+    const size_t lds = WAVES_PER_BLOCK * (size_t)(K + C) * 2 * 4;
     hipLaunchKernelGGL(merge_sorted_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a, b, N, K, C, out);
     return (int)hipGetLastError();
 }

@@ -281,7 +281,8 @@ def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm:
 
 
 def merge_depths(z_fine: torch.Tensor, z_coarse: torch.Tensor) -> torch.Tensor:
-    """sort(cat(z_fine, z_coarse))[..., :-1] for two ASCENDING depth sets (the render path of coarseFineMerge), as a merge."""
+    """sort(cat(z_fine, z_coarse))[..., :-1] (the render path of coarseFineMerge): a merge when both sets are ascending, which they
+    normally are; rays with an out-of-order input are sorted first."""
     z_fine, z_coarse = _dev(z_fine, "z_fine"), _dev(z_coarse, "z_coarse")
     N, K = z_fine.shape
     Cn = z_coarse.shape[-1]
@@ -340,6 +341,27 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
                                    _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(rgb), _ptr(depth),
                                    _ptr(w), _ptr(workspace), _stream()), "nerf_amd_render_rays")
     return rgb, depth, w, workspace
+
+
+def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
+                    want_depth=True, cam_dir: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                    camera: Optional[Samples] = None, ray_offset: int = 0, n_rays: Optional[int] = None):
+    """The tile body of render_image for a Ref-NeRF fine network (procedures.py:64-85, is_ref_model branch) in six launches.
+    `cam_dir` (3,) = render_pose[:, -2] asks for the normal image (procedures.py:79-81)."""
+    dev = u_strat.device
+    N = u_strat.shape[0] if n_rays is None else n_rays
+    need = lib.nerf_amd_render_ref_workspace_bytes(N, n_fine)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
+    cam_dir = _dev(cam_dir, "cam_dir") if cam_dir is not None else None
+    normal_img = torch.empty((N,), dtype=torch.float32, device=dev) if cam_dir is not None else None
+    check(lib.nerf_amd_render_rays_ref(_ptr(packed_prop), _ptr(packed_ref), precision, _ptr(rays),
+                                       C.byref(camera) if camera is not None else None, ray_offset, _ptr(z_base), _ptr(u_strat),
+                                       _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(cam_dir), _ptr(rgb),
+                                       _ptr(depth), _ptr(normal_img), _ptr(workspace), _stream()), "nerf_amd_render_rays_ref")
+    return rgb, depth, normal_img, workspace
 
 
 # ------------------------------------------------------------------------------------------------ backward (SURVEY 8f-1)

@@ -79,19 +79,11 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         if contract:
             raise NotImplementedError("nerf_amd: scene contraction is wired for the MipNeRF render path only")
         # Ref-NeRF branch (procedures.py:71-74): coarse and fine depths are merged and sorted, the last one dropped,
-        # sigma -> softplus(sigma + 0.5) before compositing.  The sort is a merge of two ascending sets (HIP kernel).
-        jitter = (far - near) / sample_num
-        sc = ops.samples_rays(rays, RENDER_COARSE_PNUM, z_base=z_base, u=u_strat, z_jitter=jitter)
-        dens = ops.proposal_forward_samples(prop_net.packed(prec), prec, sc, (rays.shape[0], RENDER_COARSE_PNUM), dev)
-        z_fine, _, _, z_coarse = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, sample_num + 1, want_zc=True)
-        z_all = ops.merge_depths(z_fine, z_coarse)                  # = sort(cat(fine, coarse))[:, :-1]: both inputs are ascending
-        n_all = z_all.shape[-1]
-        rgbo, normal = ops.ref_forward_samples(network.packed(prec), prec, ops.samples_rays(rays, n_all, z=z_all),
-                                               (rays.shape[0], n_all), dev, want_normal=render_normal)
-        rgb, _, depth, normal_px = ops.composite(rgbo, z_all, rays, True, white_bkg, ops.ACT_SOFTPLUS,
-                                                 (near, far) if render_depth else None,
-                                                 normal if render_normal else None, render_pose[:, -2] if render_normal else None,
-                                                 want_weights=False, sigma_shift=0.5)
+        # sigma -> softplus(sigma + 0.5) before compositing (nerf_amd_render_rays_ref: six launches; the sort is a merge of two
+        # ascending sets).
+        rgb, depth, normal_px, _ = ops.render_rays_ref(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
+                                                       sample_num, near, far, white_bkg, want_depth=bool(render_depth),
+                                                       cam_dir=render_pose[:, -2].contiguous() if render_normal else None)
 
     def to_image(t, ch):
         if sz is None:

@@ -934,6 +934,17 @@ def test_merge_depths_equals_sort_of_concatenation(K, C):
     got = ops.merge_depths(a, b)
     assert got.shape == want.shape and torch.equal(got, want)
     assert ops.merge_depths(a[:0], b[:0]).shape == (0, K + C - 1)
+    # stratified depths whose jitter exceeds the bin spacing (procedures.py:59 with fewer than 63 fine samples) are NOT ascending:
+    # rays with an out-of-order input take the sorting path and still equal the sort
+    b2 = b.clone()
+    if C > 3:
+        b2[::4, 1], b2[::4, 2] = b[::4, 2].clone(), b[::4, 1].clone()
+        b2[1::7] = b[1::7].flip(-1)
+    a2 = a.clone()
+    if K > 3:
+        a2[2::5, 0], a2[2::5, K - 1] = a[2::5, K - 1].clone(), a[2::5, 0].clone()
+    want2 = torch.sort(torch.cat((a2, b2), dim=-1), dim=-1)[0][:, :-1]
+    assert torch.equal(ops.merge_depths(a2, b2), want2)
 
 
 @pytest.mark.parametrize("L,normalize", [(10, False), (4, True)])
@@ -1046,3 +1057,57 @@ def test_vjp_in_bf16_mode_uses_the_kernels_arithmetic(A):
     finally:
         torch.autograd.grad = real
     assert seen == [1], seen                                          # the VJP inside HipOp.backward differentiated the positions only
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_render_rays_ref_equals_the_separate_entry_points(A, prec):
+    """nerf_amd_render_rays_ref (the Ref-NeRF tile body of procedures.py:64-85 in one C-ABI call) == proposal / resample / merge /
+    Ref-NeRF MLP / compositing called one by one -- bit for bit, with explicit rays and with rays generated from the camera descriptor
+    (a sub-range of the image), with and without the normal image; plus its argument checks."""
+    from nerf_amd._lib import Samples
+    from nerf_amd.ref_model import RefNeRF
+    ops = A.ops
+    prop, _ = build_nets(A, "small")
+    net = RefNeRF(10, 4)
+    net.load_state_dict(W.ref_state("small"))
+    net = net.cuda().eval()
+    A.pkg.set_precision(prec)
+    P = ops.current_precision()
+    H, Wd, fx, n_fine = 24, 20, 30.0, 48
+    gen = torch.Generator().manual_seed(3)
+    pose = torch.eye(4)[:3].clone()
+    pose[:, 3] = torch.tensor([0.1, -0.2, 4.0])
+    pose = pose.cuda()
+    rays_all = ops.generate_rays(pose, H, Wd, fx, fx, pose.device)
+    lo, N = 37, 300                                                   # a sub-range of the raster, no multiple of anything
+    rays = rays_all[lo:lo + N].contiguous()
+    u1, u2 = torch.rand(N, 64, generator=gen).cuda(), torch.rand(N, n_fine + 1, generator=gen).cuda()
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    cam_dir = pose[:, 2].contiguous()
+    with torch.no_grad():
+        jitter = (FAR - NEAR) / n_fine
+        sc = ops.samples_rays(rays, 64, z_base=z_base, u=u1, z_jitter=jitter)
+        dens = ops.proposal_forward_samples(prop.packed(P), P, sc, (N, 64), rays.device)
+        z_fine, _, _, z_c = ops.resample(dens, None, z_base, u1, jitter, rays, u2, n_fine + 1, want_zc=True)
+        z_all = ops.merge_depths(z_fine, z_c)
+        rgbo, normal = ops.ref_forward_samples(net.packed(P), P, ops.samples_rays(rays, n_fine + 64, z=z_all), (N, n_fine + 64), rays.device)
+        want_rgb, _, want_depth, want_nimg = ops.composite(rgbo, z_all, rays, True, True, ops.ACT_SOFTPLUS, (NEAR, FAR), normal, cam_dir,
+                                                           want_weights=False, sigma_shift=0.5)
+        rgb, depth, nimg, ws = ops.render_rays_ref(prop.packed(P), net.packed(P), P, rays, z_base, u1, u2, n_fine, NEAR, FAR, True, cam_dir=cam_dir)
+        assert torch.equal(rgb, want_rgb) and torch.equal(depth, want_depth) and torch.equal(nimg, want_nimg), (max_abs(rgb, want_rgb), max_abs(depth, want_depth), max_abs(nimg, want_nimg))
+        rgb2, depth2, nimg2, _ = ops.render_rays_ref(prop.packed(P), net.packed(P), P, rays, z_base, u1, u2, n_fine, NEAR, FAR, True, workspace=ws)
+        assert torch.equal(rgb2, want_rgb) and torch.equal(depth2, want_depth) and nimg2 is None
+        cam = Samples()
+        cam.H, cam.W, cam.fx, cam.fy = H, Wd, fx, fx
+        for i, v in enumerate(pose.cpu().reshape(-1).tolist()):
+            cam.pose[i] = v
+        rgb3, depth3, nimg3, _ = ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, cam_dir=cam_dir,
+                                                     camera=cam, ray_offset=lo, n_rays=N)
+        assert torch.equal(rgb3, want_rgb) and torch.equal(depth3, want_depth) and torch.equal(nimg3, want_nimg)
+        with pytest.raises(RuntimeError, match="ray range"):
+            ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, camera=cam, ray_offset=H * Wd - 10, n_rays=N)
+        cam.contract = 1
+        with pytest.raises(RuntimeError, match="contraction"):
+            ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, camera=cam, ray_offset=lo, n_rays=N)
+    assert (rgb.isfinite().all() and 0.0 < rgb.std().item())
+    A.pkg.set_precision("fp32")
