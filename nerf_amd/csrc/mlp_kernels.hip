@@ -1045,18 +1045,26 @@ int grid_for(int64_t n_tiles) {
     return (int)(n_tiles < n_cu ? n_tiles : n_cu);
 }
 
+// Dynamic LDS above 64 KiB is an opt-in per KERNEL FUNCTION (several kernels share one launcher instantiation: the inference and
+// training variants have the same function type), done once per function.
+int allow_dynamic_lds(const void* fn, size_t lds) {
+    static const void* done[16];
+    static int n_done = 0;
+    for (int i = 0; i < n_done; ++i)
+        if (done[i] == fn) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    if (n_done < 16) done[n_done++] = fn;
+    return 0;
+}
+
 template <class P, class Lay, class K, class... Extra>
 int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st, Extra... extra) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = lds_total<P>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
     hipLaunchKernelGGL(kernel, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, out, extra...);
     return (int)hipGetLastError();
 }
@@ -1113,12 +1121,7 @@ static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = ref_lds_total<P>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ref_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(ref_kernel<P>), lds)) return e;
     hipLaunchKernelGGL(ref_kernel<P>, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise);
     return (int)hipGetLastError();
 }
