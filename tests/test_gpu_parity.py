@@ -262,9 +262,12 @@ def _rays_and_u(n, n_fine, seed):
     return rays, torch.rand(n, 64, generator=gen), torch.rand(n, n_fine + 1, generator=gen)
 
 
-@pytest.mark.parametrize("tag,n,n_fine", [("small", 256, 64), ("small", 300, 128), ("he", 300, 128)])
+@pytest.mark.parametrize("tag,n,n_fine", [("small", 256, 64), ("small", 300, 128), ("he", 300, 128),
+                                          ("small", 200, 40), ("small", 150, 200), ("small", 100, 300)])
 def test_render_rays_fp32_parity(A, tag, n, n_fine):
-    """The north-star gate: RGB / depth / weights vs the CPU path on identical rays and uniforms, <= 1e-4 abs."""
+    """The north-star gate: RGB / depth / weights vs the CPU path on identical rays and uniforms, <= 1e-4 abs.  Sample counts beside the
+    headline ones: 40 (the stratified jitter exceeds the bin spacing, so the coarse depths are out of order -- the reference does not
+    sort them either), 200 (beyond the resampling kernel's register-prefetch shape, four-chunk compositing) and 300 (generic paths)."""
     prop, mip = build_nets(A, tag)
     rays, u1, u2 = _rays_and_u(n, n_fine, 17)
     stages = {}
@@ -1111,3 +1114,26 @@ def test_render_rays_ref_equals_the_separate_entry_points(A, prec):
             ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, camera=cam, ray_offset=lo, n_rays=N)
     assert (rgb.isfinite().all() and 0.0 < rgb.std().item())
     A.pkg.set_precision("fp32")
+
+
+@pytest.mark.parametrize("n_fine", [40, 64, 128])
+def test_render_rays_ref_fp32_parity_vs_oracle(A, n_fine):
+    """nerf_amd_render_rays_ref vs the CPU restatement of the reference's Ref-NeRF tile body (procedures.py:64-85) on identical rays and
+    uniforms: rgb / depth / normal image <= 1e-4.  n_fine = 40: the stratified depths are out of order and the reference's sort of
+    the merged depths really sorts."""
+    from nerf_amd.ref_model import RefNeRF
+    prop, _ = build_nets(A, "small")
+    net = RefNeRF(10, 4)
+    net.load_state_dict(W.ref_state("small"))
+    net = net.cuda().eval()
+    A.pkg.set_precision("fp32")
+    n = 160
+    rays, u1, u2 = _rays_and_u(n, n_fine, 23)
+    cam_z = torch.tensor([0.2, -0.3, 0.9])
+    with torch.no_grad():
+        want_rgb, _, ex = O.render_rays_ref(W.proposal_state("small"), W.ref_state("small"), rays, u1, u2, NEAR, FAR, n_fine, white_bkg=True, cam_z=cam_z)
+        rgb, depth, nimg, _ = A.ops.render_rays_ref(prop.packed(A.ops.F32), net.packed(A.ops.F32), A.ops.F32, dev(rays), torch.linspace(NEAR, FAR, 64).cuda(),
+                                                    dev(u1), dev(u2), n_fine, NEAR, FAR, True, cam_dir=dev(cam_z))
+    assert max_abs(rgb.cpu(), want_rgb) <= 1e-4
+    assert max_abs(depth.cpu(), ex["depth_img"]) <= 1e-4
+    assert max_abs(nimg.cpu(), ex["normal_img"]) <= 1e-4
