@@ -45,12 +45,15 @@ def generate_ide_fn(deg_view):
     ml = get_ml_array(deg_view)
     mat_cpu = ide_table(deg_view)
 
+    on_device = {}                                            # the two constant tables, uploaded once per device (not per call)
+
     def integrated_dir_enc_fn(xyz, kappa_inv):
-        mat = mat_cpu.to(xyz.device)
-        ml_t = torch.from_numpy(ml).to(xyz.device)
+        if xyz.device not in on_device:
+            on_device[xyz.device] = (mat_cpu.to(xyz.device), torch.from_numpy(ml).to(xyz.device))
+        mat, ml_t = on_device[xyz.device]
         x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
         vmz = torch.cat([z ** i for i in range(mat.shape[0])], dim=-1)
-        vmxy = torch.cat([(x + 1j * y) ** m for m in ml_t[0, :]], dim=-1)
+        vmxy = torch.cat([(x + 1j * y) ** m for m in ml_t[0, :]], dim=-1)       # (tensor exponents, like the reference)
         sph_harms = vmxy * (vmz @ mat)
         sigma = 0.5 * ml_t[1, :] * (ml_t[1, :] + 1)
         ide = sph_harms * torch.exp(-sigma * kappa_inv)
