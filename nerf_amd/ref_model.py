@@ -63,7 +63,10 @@ class RefNeRF(NeRF, PackedWeightsMixin):
                self.spa_block2[0], self.spa_block2[2], self.spa_block2[4], self.spa_block2[6], self.bottle_neck]
         tail = [self.dir_block1[0], self.dir_block1[2], self.dir_block1[4], self.dir_block1[6],
                 self.dir_block2[0], self.dir_block2[2], self.dir_block2[4], self.dir_block2[6], self.spec_rgb_head[0]]
-        table = ide_table(4).to(hw.device).contiguous()
+        tables = self.__dict__.setdefault("_ide_table_on", {})   # constant: built (float64 host loops) and uploaded once per device
+        if hw.device not in tables:
+            tables[hw.device] = ide_table(4).to(hw.device).contiguous()
+        table = tables[hw.device]
         ws = [l.weight for l in lin] + [hw] + [l.weight for l in tail] + [table]
         bs = [l.bias for l in lin] + [hb] + [l.bias for l in tail] + [hb]
         return ws, bs
@@ -110,7 +113,10 @@ class RefNeRF(NeRF, PackedWeightsMixin):
         sel = torch.cat((torch.zeros((n, total - c_pnum), dtype=torch.bool, device=fine_grads.device),
                          torch.ones((n, c_pnum), dtype=torch.bool, device=fine_grads.device)), dim=-1)
         sel = torch.gather(sel, -1, sort_inds)
-        return fine_grads[sel].reshape(n, c_pnum, -1)
+        # = fine_grads[sel].reshape(n, c_pnum, -1) without the boolean-mask gather (whose output size is data dependent: a device
+        # synchronisation, and not capturable in a hipGraph): every row has exactly c_pnum selected entries, in sorted order
+        pos = torch.sort(sel.to(torch.int8), dim=-1, descending=True, stable=True)[1][:, :c_pnum]
+        return torch.gather(fine_grads, 1, pos[:, :, None].expand(-1, -1, fine_grads.shape[-1]))
 
     @staticmethod
     def get_grad(func_val: torch.Tensor, inputs: torch.Tensor) -> torch.Tensor:

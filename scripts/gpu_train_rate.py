@@ -66,14 +66,14 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False)
     return dt
 
 
-def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False):
+def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False, graph=False):
     """The Ref-NeRF branch of the step with prop_normal (train.py:164-199): train-mode forward, density-gradient normals from
     RefNeRF.get_grad on both networks, normal / back-face / coarse-normal losses, backward, Adam."""
     from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, net = ProposalNetwork(10, 256).cuda().train(), RefNeRF(10, 4).cuda().train()
-    opt = torch.optim.Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-4)
+    opt = torch.optim.Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-4, capturable=graph)
     o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
     rays = torch.cat((o, d), -1).cuda().contiguous()
@@ -88,7 +88,7 @@ def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False):
         coarse_grad = -RefNeRF.get_grad(dens, pts)
         dens = F.softplus(dens)
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
-        fl, below = inverseSample(pw, z_c, f_n + 1, sort=True)
+        fl, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda") if graph else None)
         samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, fl, below)
         pos, dd = samples.split((3, 3), dim=-1)
         pos = pos.contiguous().requires_grad_(True)
@@ -107,6 +107,13 @@ def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False):
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            step()
+        step = g.replay
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
@@ -119,7 +126,7 @@ def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ref":         # Ref-NeRF step: ref n_rays precision
-        run_ref(int(sys.argv[2]), 64, 128, sys.argv[3])
+        run_ref(int(sys.argv[2]), 64, 128, sys.argv[3], graph=len(sys.argv) > 4, iters=50 if len(sys.argv) > 4 else 10)
         sys.exit(0)
     if len(sys.argv) > 1:                                  # one configuration (for profiling): n_rays precision [graph]
         run(int(sys.argv[1]), 64, 128, sys.argv[2], iters=5 if len(sys.argv) < 4 else 50, warm=2 if len(sys.argv) < 4 else 5, graph=len(sys.argv) > 3)

@@ -181,3 +181,20 @@ def test_checkpoint_roundtrip_with_reference_modules(tmp_path):
             del sys.modules[m]
         if "/root/reference" in sys.path:
             sys.path.remove("/root/reference")
+
+
+def test_coarse_grad_select_without_mask_gather():
+    """RefNeRF.coarse_grad_select (ref_model.py:108-117) is written without the boolean-mask gather (data-dependent size = a device
+    sync); it must still return exactly what the reference's formulation returns."""
+    import torch
+    from nerf_amd.ref_model import RefNeRF
+    from oracle import nerf_oracle as O
+    g = torch.Generator().manual_seed(9)
+    n, c, f = 37, 16, 40
+    fine = torch.randn(n, c + f, 3, generator=g)
+    sort_inds = torch.argsort(torch.rand(n, c + f, generator=g), dim=-1)
+    got = RefNeRF.coarse_grad_select(fine, sort_inds, c)
+    sel = torch.cat((torch.zeros(n, f, dtype=torch.bool), torch.ones(n, c, dtype=torch.bool)), dim=-1)
+    sel = torch.gather(sel, -1, sort_inds)
+    assert torch.equal(got, fine[sel].reshape(n, c, -1))
+    assert torch.equal(got, O.coarse_grad_select(fine, sort_inds, c))
