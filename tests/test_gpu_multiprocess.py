@@ -261,3 +261,80 @@ def test_training_step_captured_in_a_hipgraph():
     with torch.no_grad():
         probe = torch.rand(64, 8, 6).cuda()
         assert torch.allclose(mip_g.eval().forward(probe), mip_e.eval().forward(probe), atol=1e-5)
+
+
+def test_refnerf_training_step_captured_in_a_hipgraph():
+    """The Ref-NeRF step with prop_normal (train.py:164-199: get_grad normals on both networks, normal / back-face losses, Adam) is
+    sync-free too -- constant tables live on the device, coarse_grad_select has no data-dependent shape, the device-side VJP re-uses
+    its graph -- so it can be captured and replayed: three replays == three eager steps on the same batch and bottle-neck noise."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.nn.functional as F
+    import weights as W
+    import nerf_amd
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
+    from nerf_amd.utils import inverseSample
+    nerf_amd.set_precision("fp32")
+    rays, tgt, u1, u2 = _train_inputs(6)
+    res = (FAR - NEAR) / C_TRAIN
+    base = torch.linspace(NEAR, FAR - res, C_TRAIN).cuda()
+    real_normal = torch.normal
+    noise = {}
+
+    def fixed_normal(mean, std, size, **kw):                          # one tensor per shape, created by the eager warm-up steps
+        if tuple(size) not in noise:
+            noise[tuple(size)] = (torch.randn(tuple(size), generator=torch.Generator().manual_seed(8)) * 0.1).cuda()
+        return noise[tuple(size)]
+
+    def make():
+        prop, _ = _nets()
+        net = RefNeRF(10, 4)
+        net.load_state_dict(W.ref_state("small"))
+        prop, net = prop.train(), net.cuda().train()
+        opt = torch.optim.Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-3, capturable=True)
+
+        def step():
+            z_c = base + u1 * res
+            pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous().requires_grad_(True)
+            dens = prop.forward(pts)
+            coarse_grad = -RefNeRF.get_grad(dens, pts)
+            pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(dens), z_c, rays[:, 3:]), 0.01)
+            fl, below = inverseSample(pw, z_c, F_TRAIN + 1, sort=True, u=u2)
+            samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, fl, below)
+            pos, dd = samples.split((3, 3), dim=-1)
+            pos = pos.contiguous().requires_grad_(True)
+            rgbo, nrm = net.forward(pos, dd.contiguous())
+            dgrad = -RefNeRF.get_grad(rgbo[..., -1], pos)
+            rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
+            rend, wts, _ = NeRF.render(rgbo, fl, rays[:, 3:], net.density_act)
+            loss = (ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2) + 0.1 * BackFaceLoss()(wts, nrm, dd)
+                    + 4e-4 * (WeightedNormalLoss()(wts, dgrad, nrm)
+                              + 0.1 * WeightedNormalLoss()(pw, RefNeRF.coarse_grad_select(dgrad, sort_ids, C_TRAIN).detach(), coarse_grad)))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        return prop, net, step
+
+    torch.normal = fixed_normal
+    try:
+        prop_e, net_e, step_e = make()
+        for _ in range(4):                                            # 1 warm-up + 3
+            step_e()
+        prop_g, net_g, step_g = make()
+        step_g()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step_g()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        torch.normal = real_normal
+    for a, b in zip(list(net_g.parameters()) + list(prop_g.parameters()), list(net_e.parameters()) + list(prop_e.parameters())):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
