@@ -1082,6 +1082,9 @@ using PB16 = PBF16W;
 
 // host-visible launchers (capi.hip)
 int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
+#ifdef MLP_PROP_NARROW                                   // A/B knob: the 8-wave x 32-sample tile for the (inference) proposal kernel only
+    if (precision == NERF_AMD_BF16) return launch<PBF16, PropLayout>(proposal_kernel<PBF16, false>, packed, s, density, st, NO_DUMP);
+#endif
     if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16, false>, packed, s, density, st, NO_DUMP);
     return launch<PF32, PropLayout>(proposal_kernel<PF32, false>, packed, s, density, st, NO_DUMP);
 }
