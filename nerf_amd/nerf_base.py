@@ -24,14 +24,16 @@ def _act_code(density_act):
 class NeRF(nn.Module):
     @staticmethod
     def init_weight(m):
-        """trunc-normal(0.02) weights, zero biases (nerf_base.py:15-22)."""
-        if isinstance(m, nn.Linear):
-            nn.init.trunc_normal_(m.weight, std=.02)
-            if m.bias is not None:
-                nn.init.constant_(m.bias, 0)
-        elif isinstance(m, nn.BatchNorm1d):
-            nn.init.constant_(m.bias, 0)
-            nn.init.constant_(m.weight, 1.0)
+        """`module.apply` hook (nerf_base.py:15-22): Linear -> trunc-normal(std 0.02) weights and zero bias, BatchNorm1d -> (1, 0).
+        Only the trunc-normal draw consumes random numbers, so seeded initialisation matches the reference's."""
+        with torch.no_grad():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    m.bias.zero_()
+            elif isinstance(m, nn.BatchNorm1d):
+                m.weight.fill_(1.0)
+                m.bias.zero_()
 
     def __init__(self, position_flevel, cat_origin=True, density_act=F.relu) -> None:
         super().__init__()
@@ -139,13 +141,16 @@ class DecayLrScheduler:
         if warmup_step > 0:
             print("Warming up step: %d" % (warmup_step))
 
-    def update_opt_lr(self, train_cnt, opt: torch.optim.Optimizer = None):
+    def lr_at(self, train_cnt) -> float:
+        """Learning rate of iteration `train_cnt` (the reference's expressions, term for term, so that the floats agree)."""
         if train_cnt < self.warmup_step:
             r = train_cnt / self.warmup_step
-            new_lr = self.lr * (self.min_ratio * (1. - r) + r)
-        else:
-            new_lr = self.lr * max(self.decay_rate ** ((train_cnt - self.warmup_step) / self.decay_step), self.min_ratio)
-        if opt is not None:
-            for group in opt.param_groups:
-                group['lr'] = new_lr
+            return self.lr * (self.min_ratio * (1. - r) + r)
+        decayed = self.decay_rate ** ((train_cnt - self.warmup_step) / self.decay_step)
+        return self.lr * max(decayed, self.min_ratio)
+
+    def update_opt_lr(self, train_cnt, opt: torch.optim.Optimizer = None):
+        new_lr = self.lr_at(train_cnt)
+        for group in (opt.param_groups if opt is not None else ()):
+            group['lr'] = new_lr
         return opt, new_lr
