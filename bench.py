@@ -11,6 +11,12 @@ RESIDENT IN HBM before the timed region.
 
 N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL); every rank renders its own image
 per step (weak scaling, rays are independent: no data-path collective); value = total rays / max-over-ranks time.
+`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset) re-executes itself under torch.distributed.run
+with N ranks on 127.0.0.1 (ddp_train.py:307-323 does the same with mp.spawn); started BY a launcher it insists that
+WORLD_SIZE == N, and with the nccl backend that the box has N devices -- it never silently runs fewer ranks than asked.
+
+--mode train-ddp: one step = every rank's 16 384-ray training step (train.py:164-199 body) + ONE flat all_reduce of the
+744 069 gradient elements of both networks (ddp_train.py:98) + Adam; the collective is timed separately (bytes, us).
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,7 +57,55 @@ def parse():
     p.add_argument("--weights", default="small", choices=["small", "he", "zero"],
                    help="closed-form test weights; 'zero' is a power/DVFS diagnostic, never a reported number")
     p.add_argument("--cpu-rays", type=int, default=20000, help="rays of the same workload timed on the host cores (~14 s of CPU work)")
+    p.add_argument("--mode", default="render", choices=["render", "train-ddp"],
+                   help="render = the headline; train-ddp = per-rank training steps with the flat gradient all_reduce timed separately")
+    p.add_argument("--train-rays", type=int, default=16384, help="rays per rank and step in --mode train-ddp")
+    p.add_argument("--launch-check", action="store_true",
+                   help="control-flow check of the N-rank launch path only (rendezvous, world size, barrier, max-over-ranks): no GPU work")
     return p.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_or_verify(a):
+    """`--gpus N` is a promise about the number of ranks.  Under a launcher: WORLD_SIZE must equal N.  Stand-alone with N > 1:
+    become the launcher (one process per GPU, rendezvous on 127.0.0.1) and exit with the job's status."""
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != a.gpus:
+            sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    if a.gpus > 1 and backend == "nccl" and not a.launch_check and torch.cuda.device_count() < a.gpus:
+        sys.exit("bench.py: --gpus %d needs %d visible devices, this box has %d (one process per GPU; refusing to run fewer ranks)"
+                 % (a.gpus, a.gpus, torch.cuda.device_count()))
+    if "WORLD_SIZE" in os.environ or a.gpus == 1:
+        return
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def launch_check(a, world, rank):
+    """Everything the N-rank path does around the GPU work, on CPU tensors: process group, barriers, max-over-ranks."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == a.gpus
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_baseline(n_rays: int):
@@ -137,11 +191,100 @@ def train_rate(precision):
     return out
 
 
+def train_ddp(a, dist, world, rank, dev, backend):
+    """--mode train-ddp: what ddp_train.py's inner loop does per iteration (ddp_train.py:66-68,98: forward, backward, gradient
+    all-reduce, optimizer step), one rank per GPU, `--train-rays` rays per rank (weak scaling).  The ONE flat all_reduce of both
+    networks' gradients (nerf_amd/parallel.py) is bracketed by its own events and reported separately from the compute."""
+    import torch.nn.functional as F
+    import nerf_amd
+    from nerf_amd import parallel
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.utils import inverseSample
+    nerf_amd.set_precision(a.precision)
+    n_rays, c_n, f_n = a.train_rays, C_COARSE, N_FINE
+    torch.manual_seed(0)                                              # same initial weights on every rank ...
+    prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
+    if dist is not None:
+        parallel.broadcast_parameters([mip, prop], src=0)             # ... and made sure of (ddp_train.py:98 DDP does this at wrap time)
+    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)          # every rank draws its own rays
+    o = torch.tensor([0.0, 0.0, 4.0], device=dev).expand(n_rays, 3)
+    d = F.normalize(torch.randn(n_rays, 3, device=dev, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0], device=dev), dim=-1)
+    rays = torch.cat((o, d), -1).contiguous()
+    tgt = torch.rand(n_rays, 3, device=dev, generator=g)
+    res = (FAR - NEAR) / c_n
+    base = torch.linspace(NEAR, FAR - res, c_n).to(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    n_grad = sum(p.numel() for p in list(mip.parameters()) + list(prop.parameters()))
+
+    def step(timed_idx=None):
+        z_c = base + torch.rand((n_rays, c_n), device=dev, generator=g) * res
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
+        dens = F.softplus(prop.forward(pts))
+        pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
+        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device=dev, generator=g))
+        z_f = z_f[..., :-1].contiguous()
+        rgbo = mip.forward(NeRF.length2pts(rays, z_f))
+        rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
+        loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        if dist is not None:
+            if timed_idx is not None:
+                ev[timed_idx][0].record()
+            parallel.allreduce_gradients([mip, prop])
+            if timed_idx is not None:
+                ev[timed_idx][1].record()
+        opt.step()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ar_us = (sum(s.elapsed_time(e) for s, e in ev) / a.steps * 1e3) if dist is not None else 0.0
+        flop_per_ray = 3 * FLOP_PER_RAY                                  # forward + dgrad + wgrad
+        rec = {"metric": "training rays/s (64+128 samples, fwd + bwd + gradient all_reduce + Adam)", "value": world * a.steps * n_rays / dt,
+               "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
+               "data": "synthetic",
+               "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, MipNeRF(10,4,256) + ProposalNetwork(10,256)" % n_rays,
+                          "rays_per_step_per_gpu": n_rays, "parallelism": "ray-sharded replicas (dp%d), one flat gradient all_reduce per step" % world},
+               "allreduce": {"elements": n_grad, "bytes": 4 * n_grad, "us_per_step": ar_us, "backend": backend if dist is not None else None,
+                             "note": "torch.cat of the gradients + ONE all_reduce(SUM) + divide + copy back (nerf_amd/parallel.py), HIP events on the compute stream"},
+               "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flops)", "achieved": world * a.steps * n_rays * flop_per_ray / dt / 1e12 / world,
+                            "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s", "frac": a.steps * n_rays * flop_per_ray / dt / PEAK_BF16_DENSE, "traffic": None}}
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    launch_or_verify(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus
+    if a.launch_check:
+        return launch_check(a, world, rank)
     dist = None
     backend = os.environ.get("BENCH_BACKEND", "nccl")          # "gloo" only to smoke-test the N>1 control flow on a 1-GPU box
     n_dev = max(1, torch.cuda.device_count())
@@ -154,9 +297,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % n_dev))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == a.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    if a.mode == "train-ddp":
+        return train_ddp(a, dist, world, rank, dev, backend)
 
     import weights as Wt
     from nerf_amd import ops

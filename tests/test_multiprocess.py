@@ -83,3 +83,37 @@ def test_world_size_2_gloo():
     for rank, same_weights, n, ok_grad, ok_none, ok_gather in res:
         assert same_weights and ok_grad and ok_none and ok_gather
         assert n == 530052 + 214017
+
+
+# ------------------------------------------------------------------------------------------------ bench.py --gpus N launch path
+def _bench(*args, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), capture_output=True, text=True, env=e, timeout=240)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher becomes the launcher (torch.distributed.run, 127.0.0.1) and the ranks it
+    starts see world size 2 (ddp_train.py:307-323 spawns `gpus` processes the same way); --launch-check stops before GPU work."""
+    import json
+    r = _bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["max_over_ranks"] == 2.0
+
+
+def test_bench_refuses_fewer_ranks_than_asked():
+    """--gpus N must never silently run fewer ranks: a launcher that started a different world size, or (nccl) a box with fewer
+    devices than N, is an error."""
+    if torch.cuda.device_count() < 2:
+        r = _bench("--gpus", "2")
+        assert r.returncode != 0 and "needs 2 visible devices" in r.stderr
+    r = _bench("--gpus", "2", "--launch-check", env={"WORLD_SIZE": "4", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
