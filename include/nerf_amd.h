@@ -83,6 +83,12 @@ typedef struct nerf_amd_samples {
     int32_t      contract;     /* != 0: Mip-NeRF 360 scene contraction of the sample POSITION before it is encoded
                                   (Barron et al. 2022, eq. 10): x -> x if |x| <= 1 else (2 - 1/|x|) x/|x|.  Not in the
                                   reference (BASELINE config 5 only); occupies former tail padding, 0 = off.        */
+    int32_t      ipe;          /* != 0 (modes 1 with z only, MipNeRF kernels): integrated positional encoding.  Sample s of ray n is the
+                                  conical frustum between z[n*z_stride+s] and z[n*z_stride+s+1] (so z rows hold S+1 depths); the network
+                                  input is [mu | ipe_feature(mu, diag Sigma)] (mip_methods.py:15-58) instead of [x | PE(x)].        */
+    float        ipe_radius;   /* pixel radius r of coneParameters (mip_methods.py:15)                                              */
+    const float* ipe_dir_norm; /* DEVICE pointer to one float: norm of the whole (N,3) direction tensor (mip_methods.py:31;
+                                  nerf_amd_dirs_norm)                                                                              */
 } nerf_amd_samples;
 
 /* ------------------------------------------------------------------------------------------------
@@ -132,6 +138,18 @@ int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd
 
 /* positional_encoding (nerf_helper.py:38-48): x (M,3) -> out (M, 6L) = [sin 2^0 x, cos 2^0 x, sin 2^1 x, ...] */
 int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, void* stream);
+
+/* ipe_feature with its helpers coneParameters / coneMeanCov / multFreq (mip_methods.py:15-58): z (N, S+1) depths, rays (N,6),
+ * L frequency levels, pixel radius r -> feat (N, S, 6L) = per level [sin(2^l mu) e^(-4^l diag/2) xyz | cos(...) xyz], mu (N,S,3) or NULL,
+ * mu_t (N,S) or NULL.  `dir_norm` is a DEVICE pointer to the norm of the whole (N,3) direction tensor (the reference's `.norm()`
+ * without a dim, :31) -- nerf_amd_dirs_norm computes it.  The reference never calls ipe_feature from its entry scripts
+ * (SURVEY.md 8a row 12); golden G12 pins the function. */
+int nerf_amd_ipe_feature(const float* z, const float* rays, int64_t N, int S, int L, float r, const float* dir_norm,
+                         float* feat, float* mu, float* mu_t, void* stream);
+/* coneParameters (mip_methods.py:15-23): z (N, S+1) -> mu_t, sigma_t^2, sigma_r^2, each (N, S). */
+int nerf_amd_cone_parameters(const float* z, int64_t N, int S, float r, float* mu_t, float* var_t, float* var_r, void* stream);
+/* sqrt(sum of squares) of the direction halves of rays (N,6) -> out (1 float on the device); fp64 accumulation, fixed order. */
+int nerf_amd_dirs_norm(const float* rays, int64_t N, float* out, void* stream);
 
 /* Ray table of render_image (procedures.py:43-51,64): rays (N, 6) = [pose[:,3] | R.c] for pixels
  * n = row*W + col in [ray_offset, ray_offset+N); `pose_host` is a HOST row-major 3x4. */
@@ -256,6 +274,8 @@ int nerf_amd_get_bounds_backward(const int64_t* below, const float* d_bounds, in
  * Outputs rgb (N,3), depth (N) or NULL, weights (N,n_fine) or NULL.
  * workspace: nerf_amd_render_workspace_bytes(N, n_fine) bytes of device scratch.
  * ------------------------------------------------------------------------------------------------ */
+/* (With camera != NULL and camera->ipe != 0 -- the descriptor may accompany explicit rays just to carry flags -- the FINE pass uses
+ * the integrated positional encoding of the frusta between consecutive fine depths, radius camera->ipe_radius; `rays` must be given.) */
 size_t nerf_amd_render_workspace_bytes(int64_t N, int n_fine);
 int    nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int precision,
                             const float* rays, const nerf_amd_samples* camera, int64_t ray_offset,

@@ -24,7 +24,8 @@ class Samples(C.Structure):
     _fields_ = [("mode", C.c_int32), ("S", C.c_int32), ("M", C.c_int64), ("pts", c_void), ("pts_stride", C.c_int32),
                 ("z_stride", C.c_int32), ("rays", c_void), ("z", c_void), ("z_base", c_void), ("u", c_void),
                 ("z_jitter", C.c_float), ("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
-                ("pose", C.c_float * 12), ("contract", C.c_int32)]
+                ("pose", C.c_float * 12), ("contract", C.c_int32), ("ipe", C.c_int32), ("ipe_radius", C.c_float),
+                ("ipe_dir_norm", c_void)]
 
 
 # name -> (restype, argtypes); mirrors include/nerf_amd.h one to one (tests check the two agree)
@@ -41,6 +42,9 @@ SIGNATURES = {
     "nerf_amd_ref_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void]),
     "nerf_amd_ref_forward_train": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void, c_void]),
     "nerf_amd_positional_encoding": (C.c_int, [c_void, i64, C.c_int, c_void, c_void]),
+    "nerf_amd_ipe_feature": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_cone_parameters": (C.c_int, [c_void, i64, C.c_int, C.c_float, c_void, c_void, c_void, c_void]),
+    "nerf_amd_dirs_norm": (C.c_int, [c_void, i64, c_void, c_void]),
     "nerf_amd_generate_rays": (C.c_int, [c_float_p, C.c_int, C.c_int, C.c_float, C.c_float, i64, i64, c_void, c_void]),
     "nerf_amd_length2pts": (C.c_int, [c_void, c_void, i64, C.c_int, c_void, c_void]),
     "nerf_amd_sigma_to_weights": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),

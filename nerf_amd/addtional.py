@@ -42,7 +42,7 @@ class LossPSNR(nn.Module):
         return -10. * torch.log(x) / LossPSNR.__LOG_10__
 
 
-class ProposalNetwork(nn.Module, PackedWeightsMixin):
+class ProposalNetwork(PackedWeightsMixin, nn.Module):
     _net_id = ops.NET_PROPOSAL
 
     @staticmethod

@@ -246,8 +246,9 @@ def with_hip_backward(expr_fn: Callable, hip_bwd: Callable) -> Callable:
 
 class HipOp(torch.autograd.Function):
     """forward = `hip_fn(*tensors)` (HIP kernels);  backward = `expr_fn.hip_bwd` (HIP kernels) when the op has one, else the VJP
-    of `expr_fn(*tensors)` (torch, on the device).  Only the first output of hip_fn is differentiable; extra outputs are
-    returned as-is (non-differentiable)."""
+    of `expr_fn(*tensors)` (torch, on the device).  The first `expr_fn.n_diff` outputs of hip_fn (default 1) are differentiable --
+    `expr_fn` returns as many, hip_bwd then receives a tuple of gradients with None for outputs the loss does not reach --; further
+    outputs are returned as-is (non-differentiable)."""
 
     @staticmethod
     def forward(ctx, hip_fn: Callable, expr_fn: Callable, n_extra: int, *tensors):
@@ -260,15 +261,23 @@ class HipOp(torch.autograd.Function):
         ctx.is_param = [isinstance(t, torch.nn.Parameter) for t in tensors]
         ctx.bf16 = ops.current_precision() == ops.BF16
         ctx.consts = [t for t in tensors if not isinstance(t, torch.Tensor)]
+        ctx.n_diff = int(getattr(expr_fn, "n_diff", 1))
+        ctx.set_materialize_grads(False)                      # an output the loss does not reach arrives as None, not as zeros
         with torch.no_grad():
             out = hip_fn(*[t.detach() if isinstance(t, torch.Tensor) else t for t in tensors])
-        if n_extra:
-            ctx.mark_non_differentiable(*out[1:])
-            return out
+        if isinstance(out, tuple) and len(out) > ctx.n_diff:
+            ctx.mark_non_differentiable(*[o for o in out[ctx.n_diff:] if isinstance(o, torch.Tensor)])
         return out
 
     @staticmethod
-    def backward(ctx, grad, *unused):
+    def backward(ctx, *out_grads):
+        n_args = len(ctx.is_tensor)
+        if all(g is None for g in out_grads[:ctx.n_diff]):
+            return (None, None, None, *[None] * n_args)
+        if ctx.n_diff == 1:
+            grad = out_grads[0].contiguous()
+        else:
+            grad = tuple(g.contiguous() if g is not None else None for g in out_grads[:ctx.n_diff])
         saved = list(ctx.saved_tensors)
         consts = list(ctx.consts)
         hip_bwd = getattr(ctx.expr_fn, "hip_bwd", None)
@@ -276,7 +285,7 @@ class HipOp(torch.autograd.Function):
             it_t, it_c = iter(saved), iter(consts)
             full = [next(it_t) if is_t else next(it_c) for is_t in ctx.is_tensor]
             with torch.no_grad():
-                grads = hip_bwd(grad.contiguous(), *full)
+                grads = hip_bwd(grad, *full)
             if grads is not None:                                   # None = "not supported for these sizes": fall through to the VJP
                 return (None, None, None, *grads)
         # only the inputs autograd actually asks for become leaves: e.g. the sample positions of MipNeRF carry no gradient, which
@@ -306,6 +315,9 @@ class HipOp(torch.autograd.Function):
                     y = ctx.expr_fn(*args)
             else:
                 y, leaves, wanted = cache
+            if ctx.n_diff > 1:                                  # several differentiable outputs: keep the ones a gradient arrived for
+                pairs = [(yy, gg) for yy, gg in zip(y, grad) if gg is not None]
+                y, grad = tuple(p_[0] for p_ in pairs), tuple(p_[1] for p_ in pairs)
             if _VJP.inputs_only:
                 # RefNeRF.get_grad (retain_graph): differentiate the non-parameter inputs only -- the Linear layers skip their weight
                 # and bias gradients -- and keep the re-evaluated graph: the loss backward that follows on the same op re-uses it
@@ -313,10 +325,10 @@ class HipOp(torch.autograd.Function):
                 sel = [w and not p_ for w, p_ in zip(wanted, ctx.is_param)]
                 it = iter(leaves)
                 sub = [t for w, s_ in zip(wanted, sel) for t in ([next(it)] if w else []) if s_]
-                part = iter(torch.autograd.grad(y, sub, grad.contiguous(), allow_unused=True, retain_graph=True)) if sub else iter(())
+                part = iter(torch.autograd.grad(y, sub, grad, allow_unused=True, retain_graph=True)) if sub else iter(())
                 ctx.vjp_cache = (y, leaves, wanted)
                 return (None, None, None, *[next(part) if s_ else None for s_ in sel])
-            grads = torch.autograd.grad(y, leaves, grad.contiguous(), allow_unused=True)
+            grads = torch.autograd.grad(y, leaves, grad, allow_unused=True)
         finally:
             _VJP.active, _VJP.bf16 = prev, prev16
         gi = iter(grads)

@@ -25,6 +25,9 @@ int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
+int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
+int sk_dirs_norm(const float*, int64_t, float*, hipStream_t);
+int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
 int sk_length2pts(const float*, const float*, int64_t, int, float*, hipStream_t);
 int sk_sigma_to_weights(const float*, const float*, const float*, int64_t, int, int, float*, hipStream_t);
@@ -70,6 +73,11 @@ int check_samples(const nerf_amd_samples* s, bool need_dir) {
     } else {
         return fail(NERF_AMD_EINVAL, "unknown sample mode");
     }
+    if (s->ipe) {
+        if (!need_dir) return fail(NERF_AMD_EUNSUPPORTED, "integrated PE is wired for the MipNeRF kernel only");
+        if (s->mode != 1 || !s->z || s->z_stride < s->S + 1) return fail(NERF_AMD_EINVAL, "integrated PE needs mode 1 with S+1 depths per ray (z, z_stride > S)");
+        if (!s->ipe_dir_norm || !(s->ipe_radius > 0.0f)) return fail(NERF_AMD_EINVAL, "integrated PE needs ipe_dir_norm (device) and a positive ipe_radius");
+    }
     return NERF_AMD_OK;
 }
 bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
@@ -78,7 +86,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 100; }
+int nerf_amd_version(void) { return 110; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -135,6 +143,7 @@ int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (int c = check_samples(src, true)) return c;
     if (src->mode != 1 || !src->z) return fail(NERF_AMD_EUNSUPPORTED, "fused compositing needs mode 1 (rays + z)");
+    if (src->ipe) return fail(NERF_AMD_EUNSUPPORTED, "integrated PE: use nerf_amd_mip_forward + nerf_amd_composite");
     if (src->S != 32 && src->S != 64 && src->S != 128) return fail(NERF_AMD_EUNSUPPORTED, "fused compositing needs S in {32, 64, 128}");
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgb) return fail(NERF_AMD_EINVAL, "NULL argument");
@@ -162,6 +171,23 @@ int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, v
     if (M < 0 || L < 1 || L > 24) return fail(NERF_AMD_EINVAL, "bad M or L");
     if (M && (!x || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_positional_encoding(x, M, L, out, S(stream)), "nerf_amd_positional_encoding");
+}
+
+int nerf_amd_ipe_feature(const float* z, const float* rays, int64_t N, int Sn, int L, float r, const float* dir_norm, float* feat, float* mu,
+                         float* mu_t, void* stream) {
+    if (N < 0 || Sn < 0 || L < 1 || L > 15) return fail(NERF_AMD_EINVAL, "bad size or L (1..15)");
+    if (N * Sn && (!z || !rays || !dir_norm || !feat)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    const float r2 = (float)((double)r * (double)r);        // Python's `r ** 2` is a double, rounded when it meets the fp32 tensor
+    return hip_status(sk_ipe_feature(z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t, S(stream)), "nerf_amd_ipe_feature");
+}
+int nerf_amd_cone_parameters(const float* z, int64_t N, int Sn, float r, float* mu_t, float* var_t, float* var_r, void* stream) {
+    if (N < 0 || Sn < 0) return fail(NERF_AMD_EINVAL, "negative size");
+    if (N * Sn && (!z || !mu_t || !var_t || !var_r)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_cone_parameters(z, N, Sn, (float)((double)r * (double)r), mu_t, var_t, var_r, S(stream)), "nerf_amd_cone_parameters");
+}
+int nerf_amd_dirs_norm(const float* rays, int64_t N, float* out, void* stream) {
+    if (N < 0 || !out || (N && !rays)) return fail(NERF_AMD_EINVAL, "bad argument");
+    return hip_status(sk_dirs_norm(rays, N, out, S(stream)), "nerf_amd_dirs_norm");
 }
 
 int nerf_amd_generate_rays(const float* pose_host, int H, int W, float fx, float fy, int64_t ray_offset, int64_t N, float* rays,
@@ -264,6 +290,7 @@ int nerf_amd_mip_forward_train(const void* packed, int precision, const nerf_amd
     if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
     if (src->M && !rgbo) return fail(NERF_AMD_EINVAL, "NULL output");
+    if (src->ipe) return fail(NERF_AMD_EUNSUPPORTED, "integrated PE has no training forward");
     return hip_status(mlp_launch_mip_train(packed, precision, *src, rgbo, dump, S(stream)), "nerf_amd_mip_forward_train");
 }
 int nerf_amd_train_dump_to_rows(const void* dump, int net, int precision, int64_t M, int layer, int n_features, void* out, void* stream) {
@@ -351,8 +378,8 @@ size_t nerf_amd_render_workspace_bytes(int64_t N, int n_fine) {
     const size_t a = ((size_t)N * 64 * 4 + 255) & ~(size_t)255;
     const size_t b = ((size_t)N * (n_fine + 1) * 4 + 255) & ~(size_t)255;
     const size_t c = ((size_t)N * n_fine * 16 + 255) & ~(size_t)255;
-    const size_t d = (size_t)N * 24;
-    return a + b + c + d + 256;
+    const size_t d = ((size_t)N * 24 + 255) & ~(size_t)255;
+    return a + b + c + d + 512;                             // + alignment slack + one scalar slot (direction norm of the IPE mode)
 }
 
 int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int precision, const float* rays,
@@ -382,6 +409,13 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
             return hip_status(e, "ray generation");
         rays = gen;
     }
+    ws += ((size_t)N * 24 + 255) & ~(size_t)255;
+    float* dir_norm = reinterpret_cast<float*>(ws);
+    const bool ipe = camera && camera->ipe;
+    if (ipe) {                                              // row 12 inside the fine pass: the direction norm of this ray batch
+        if (!(camera->ipe_radius > 0.0f)) return fail(NERF_AMD_EINVAL, "integrated PE needs a positive ipe_radius");
+        if (int e = sk_dirs_norm(rays, N, dir_norm, st)) return hip_status(e, "direction norm");
+    }
     const float jitter = (far - near) / (float)n_fine;      // procedures.py:59
 
     nerf_amd_samples sc{};                                  // rows 2-4: stratified z fused into the proposal MLP
@@ -395,6 +429,7 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     nerf_amd_samples sf{};                                  // rows 8-9: drop the last depth, length2pts fused into the MLP
     sf.mode = 1; sf.rays = rays; sf.S = n_fine; sf.M = N * n_fine; sf.z = z_fine; sf.z_stride = n_fine + 1;
     sf.contract = sc.contract;
+    if (ipe) { sf.ipe = 1; sf.ipe_radius = camera->ipe_radius; sf.ipe_dir_norm = dir_norm; }   // frustum s = [z_fine[s], z_fine[s+1]]
     // rows 9 and 10 as two launches: measured 2-3 % faster than the fused epilogue of nerf_amd_mip_forward_composite on
     // MI355X, and the composite kernel's HBM rate stays individually measurable
     if (int e = mlp_launch_mip(packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");

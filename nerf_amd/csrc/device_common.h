@@ -47,6 +47,33 @@ DEVINL float sin_quadrant(float a, int quad) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Integrated positional encoding, per-frustum part (mip_methods.py:15-33): Gaussian moments of the conical frustum between depths
+// z0 < z1 along a ray of pixel radius r (r2 = fl(r*r) computed in double like Python's `r ** 2`), every operation in the reference's
+// order (no contraction: this file is compiled with -ffp-contract=off).
+// ------------------------------------------------------------------------------------------------
+struct ConeMoments { float mu_t, var_t, var_r; };
+DEVINL ConeMoments cone_moments(float z0, float z1, float r2) {
+    const float mid = (z1 + z0) / 2.0f;                                   // :16
+    const float hw = (z1 - z0) / 2.0f;
+    const float hw2 = hw * hw;                                            // :17
+    const float mid2 = mid * mid;
+    const float t1 = 3.0f * mid2 + hw2;                                   // :18
+    ConeMoments c;
+    c.mu_t = mid + ((2.0f * mid) * hw2) / t1;                             // :20
+    const float hw4 = hw2 * hw2;
+    c.var_t = hw2 / 3.0f - (((4.0f * hw4) * (12.0f * mid2 - hw2)) / 15.0f) / (t1 * t1);          // :21
+    c.var_r = r2 * ((0.25f * mid2 + 0.4166666567325592f * hw2) - (4.0f * hw4) / (15.0f * t1));   // :22  (fl(5/12))
+    return c;
+}
+// mean and diagonal covariance of the frustum in world space (coneMeanCov, :27-33); inv-free: dd / dir_norm like the reference,
+// where dir_norm is the norm of the WHOLE (N,3) direction tensor (the reference's `.norm()` without a dim, :31)
+DEVINL void cone_mean_cov(const ConeMoments& c, float o, float d, float dir_norm, float& mu, float& diag) {
+    mu = o + c.mu_t * d;
+    const float dd = d * d;
+    diag = c.var_t * dd + c.var_r * (1.0f - dd / dir_norm);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 64-lane inclusive scans (log-step shuffles).  fp64 versions mirror torch's CPU cumsum/cumprod,
 // which accumulate float inputs in double and round each prefix to float.
 // ------------------------------------------------------------------------------------------------

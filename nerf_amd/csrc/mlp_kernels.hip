@@ -22,6 +22,7 @@
 //
 // Reference semantics: addtional.py:88-96 (proposal), mip_model.py:41-60 (fine).
 #include "device_common.h"
+#include "host_common.h"
 #include "mlp_layout.h"
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -485,6 +486,45 @@ DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG])
     }
 }
 
+// Integrated positional encoding (mip_methods.py:36-58) into the same B-operand slots: slot (l, c) = sin|cos(2^l mu_c) * exp(-0.5 * 4^l var_c),
+// raw slots = mu (the cat_origin prefix).  bf16 mode: octaves by angle doubling, attenuation by att_{l+1} = att_l^4.
+template <class P, int L, int NKG>
+DEVINL void encode_ipe(const float (&mu)[3], const float (&var)[3], int h, typename P::BReg (&B)[NKG]) {
+    if constexpr (P::FAST_PE) {
+        float sv[3], cv[3], at[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sv[c] = sin_quadrant(mu[c], 0); cv[c] = sin_quadrant(mu[c], 1); at[c] = expf(-0.5f * var[c]); }
+#pragma unroll
+        for (int f = 0; f < L; ++f) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int q = 3 * f + c;
+                P::set(B[q >> 3], q & 7, (h ? cv[c] : sv[c]) * at[c]);
+                if (f + 1 < L) {
+                    const float s2 = 2.0f * sv[c];
+                    const float ns = s2 * cv[c];
+                    const float nc = __builtin_fmaf(-s2, sv[c], 1.0f);
+                    sv[c] = ns; cv[c] = nc;
+                    const float a2 = at[c] * at[c];
+                    at[c] = a2 * a2;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3 * L; ++q) {
+            const int c = q % 3, f = q / 3;
+            const float v = sin_quadrant(mu[c] * (float)(1 << f), h) * expf(-0.5f * (var[c] * (float)(1u << (2 * f))));
+            P::set(B[q >> 3], q & 7, v);
+        }
+    }
+#pragma unroll
+    for (int q = 3 * L; q < 8 * NKG; ++q) {
+        const float v = (q == 3 * L) ? (h ? mu[2] : mu[0]) : ((q == 3 * L + 1) ? (h ? 0.0f : mu[1]) : 0.0f);
+        P::set(B[q >> 3], q & 7, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // sample fetch: position (and raw direction) of sample m
 // ------------------------------------------------------------------------------------------------
@@ -528,6 +568,28 @@ DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) 
     else     zv = s.z_base[si] + s.u[n * s.S + si] * s.z_jitter;                 // procedures.py:65
     r.x = ox + zv * r.dx; r.y = oy + zv * r.dy; r.z = oz + zv * r.dz;           // procedures.py:66
     if (s.contract) contract_position(r);
+    return r;
+}
+
+// IPE sample (nerf_amd_samples.ipe; mode 1 with explicit depths): frustum si of ray n spans z[si] .. z[si+1]
+struct IpeSample { float mu[3], var[3], dx, dy, dz; };
+DEVINL IpeSample fetch_sample_ipe(const nerf_amd_samples& s, int64_t m) {
+    IpeSample r;
+    const int64_t n = m / s.S;
+    const int si = (int)(m - n * s.S);
+    const float* ry = s.rays + n * 6;
+    const float* zz = s.z + n * s.z_stride + si;
+    const float rr = s.ipe_radius;
+    const ConeMoments c = cone_moments(zz[0], zz[1], (float)((double)rr * (double)rr));
+    const float dn = s.ipe_dir_norm[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cone_mean_cov(c, ry[k], ry[3 + k], dn, r.mu[k], r.var[k]);
+    r.dx = ry[3]; r.dy = ry[4]; r.dz = ry[5];
+    if (s.contract) {                                      // (mean only; the covariance is left in metric space)
+        Sample p{r.mu[0], r.mu[1], r.mu[2], 0.0f, 0.0f, 0.0f};
+        contract_position(p);
+        r.mu[0] = p.x; r.mu[1] = p.y; r.mu[2] = p.z;
+    }
     return r;
 }
 
@@ -641,7 +703,7 @@ struct FusedComposite {
     float near, far;
 };
 
-template <class P, bool TRAIN>
+template <class P, bool TRAIN, bool IPE = false>
 __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                          float* __restrict__ rgbo, FusedComposite fc, ActDump dump) {
     using L = MipLayout;
@@ -688,8 +750,15 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 m[t] = tile * TS + (wave * NT + t) * 32 + j;
-                const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, true);
-                encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+                Sample sm;
+                if constexpr (IPE) {                        // integrated PE of the frustum (row 12) instead of the point PE (row 3)
+                    const IpeSample is = fetch_sample_ipe(s, m[t] < s.M ? m[t] : s.M - 1);
+                    encode_ipe<P, 10, 4>(is.mu, is.var, h, enc[t]);
+                    sm.dx = is.dx; sm.dy = is.dy; sm.dz = is.dz;
+                } else {
+                    sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, true);
+                    encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+                }
                 // the encoding is needed again by the skip layer and the direction by the colour head: park them in
                 // this wavefront's private LDS stash instead of holding 20+ VGPRs through six layers
 #pragma unroll
@@ -1035,28 +1104,12 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
 }
 
 int grid_for(int64_t n_tiles) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) n_cu = 256;
-        else n_cu = p.multiProcessorCount;
-    }
+    const int n_cu = nerf_host::cu_count();
     return (int)(n_tiles < n_cu ? n_tiles : n_cu);
 }
 
-// Dynamic LDS above 64 KiB is an opt-in per KERNEL FUNCTION (several kernels share one launcher instantiation: the inference and
-// training variants have the same function type), done once per function.
-int allow_dynamic_lds(const void* fn, size_t lds) {
-    static const void* done[16];
-    static int n_done = 0;
-    for (int i = 0; i < n_done; ++i)
-        if (done[i] == fn) return 0;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    if (n_done < 16) done[n_done++] = fn;
-    return 0;
-}
+// Dynamic LDS above 64 KiB is an opt-in per KERNEL FUNCTION and device (host_common.h)
+int allow_dynamic_lds(const void* fn, size_t lds) { return nerf_host::allow_dynamic_lds(fn, lds); }
 
 template <class P, class Lay, class K, class... Extra>
 int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st, Extra... extra) {
@@ -1090,6 +1143,10 @@ int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_sample
 }
 int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
+    if (s.ipe) {                                            // integrated positional encoding (validated by the C-ABI: mode 1, z, dir norm)
+        if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false, true>, packed, s, rgbo, st, off, NO_DUMP);
+        return launch<PF32, MipLayout>(mip_kernel<PF32, false, true>, packed, s, rgbo, st, off, NO_DUMP);
+    }
     if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, rgbo, st, off, NO_DUMP);
     return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, rgbo, st, off, NO_DUMP);
 }

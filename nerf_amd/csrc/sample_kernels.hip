@@ -6,6 +6,7 @@
 //   * position and depth arithmetic is separate mul + add (the file is built with -ffp-contract=off);
 //   * searchsorted(right=True) = number of CDF entries <= u.
 #include "device_common.h"
+#include "host_common.h"
 #include "../../include/nerf_amd.h"
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -25,6 +26,76 @@ __global__ void pe_kernel(const float* __restrict__ x, int64_t total, int L, flo
         const int f = k / 6, t = (k % 6) / 3, c = k % 3;
         out[i] = sin_quadrant(x[m * 3 + c] * (float)(1 << f), t);
     }
+}
+
+// ---------------------------------------------------------------------------------------- row 12
+// Integrated positional encoding (mip_methods.py:15-58).  A workgroup takes 256 frusta: phase 1 = one thread per frustum forms the
+// Gaussian moments (cone_moments / cone_mean_cov, device_common.h: the reference's operation order) and parks mean and diagonal
+// covariance in LDS; phase 2 = the 256 x 6L outputs are written fully coalesced, one sin/cos and one exp per element:
+//   out[.., 6 l + 3 t + c] = (t ? cos : sin)(2^l mu_c) * exp(-0.5 * (4^l diag_c))     (multFreq :36-45, ipe_feature :51-58)
+// HBM-bound: 24 L + 16 bytes written per frustum, ~8 read.
+__global__ __launch_bounds__(256) void ipe_feature_kernel(const float* __restrict__ z, const float* __restrict__ rays, int64_t N, int S, int L,
+                                                           float r2, const float* __restrict__ dir_norm, float* __restrict__ feat,
+                                                           float* __restrict__ mu_out, float* __restrict__ mu_t_out) {
+    __shared__ float mom[256][6];
+    const int64_t total = N * S;
+    const int width = 6 * L;
+    const float dn = dir_norm[0];
+    for (int64_t base = blockIdx.x * (int64_t)256; base < total; base += (int64_t)gridDim.x * 256) {
+        const int64_t m = base + threadIdx.x;
+        if (m < total) {
+            const int64_t n = m / S;
+            const int si = (int)(m - n * S);
+            const float* zz = z + n * (S + 1) + si;
+            const ConeMoments c = cone_moments(zz[0], zz[1], r2);
+            const float* ry = rays + n * 6;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cone_mean_cov(c, ry[k], ry[3 + k], dn, mom[threadIdx.x][k], mom[threadIdx.x][3 + k]);
+            if (mu_out) { mu_out[m * 3] = mom[threadIdx.x][0]; mu_out[m * 3 + 1] = mom[threadIdx.x][1]; mu_out[m * 3 + 2] = mom[threadIdx.x][2]; }
+            if (mu_t_out) mu_t_out[m] = c.mu_t;
+        }
+        __syncthreads();
+        const int64_t cnt = (total - base < 256 ? total - base : 256) * width;
+        float* o = feat + base * width;
+        for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+            const int sl = (int)(i / width);
+            const int k = (int)(i - (int64_t)sl * width);
+            const int l = k / 6, t = (k % 6) / 3, c = k % 3;
+            const float a = mom[sl][c] * (float)(1 << l);                              // exact scaling (P @ mu, :43)
+            const float v = mom[sl][3 + c] * (float)(1u << (2 * l));                   // diag_P * diag (:42)
+            o[i] = sin_quadrant(a, t) * expf(-0.5f * v);
+        }
+        __syncthreads();
+    }
+}
+
+// coneParameters alone (mip_methods.py:15-23): z (N, S+1) -> mu_t, sigma_t^2, sigma_r^2 (N, S)
+__global__ void cone_parameters_kernel(const float* __restrict__ z, int64_t N, int S, float r2, float* __restrict__ mu_t, float* __restrict__ var_t,
+                                       float* __restrict__ var_r) {
+    const int64_t total = N * S;
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < total; m += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = m / S;
+        const float* zz = z + n * (S + 1) + (m - n * S);
+        const ConeMoments c = cone_moments(zz[0], zz[1], r2);
+        mu_t[m] = c.mu_t; var_t[m] = c.var_t; var_r[m] = c.var_r;
+    }
+}
+
+// norm of the whole direction tensor (mip_methods.py:31 `cam_rays[:, 3:].norm()`): one workgroup, fp64 partial sums, fixed order
+__global__ __launch_bounds__(1024) void dirs_norm_kernel(const float* __restrict__ rays, int64_t N, float* __restrict__ out) {
+    __shared__ double part[1024];
+    double acc = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += 1024) {
+        const float* d = rays + n * 6 + 3;
+        acc += (double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sqrt(part[0]);
 }
 
 // ---------------------------------------------------------------------------------------- row 1
@@ -141,9 +212,39 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
                                 int64_t* __restrict__ below_out, int64_t* __restrict__ above_out) {
     const int lane = lane_id();
     const int nb = nw + 1;           // bins == cdf entries incl. the leading 0
-    float part = 0.0f;               // pdf normaliser
-    for (int j = lane; j < nw; j += 64) part += pw[j] + 1e-5f;
-    const float total = wave_sum(part);
+    // pdf normaliser torch.sum(weights + 1e-5, -1) (utils.py:110-111) in the summation ORDER of torch's CPU kernel, so that the CDF --
+    // and with it every searchsorted decision -- is bit-identical to the reference's.  ATen's cascade_sum over a contiguous row
+    // (SumKernel.cpp vectorized_inner_sum; verified against torch 2.10 for row lengths 14..255, tests/test_oracle_golden.py): the row is
+    // read as 8-float vectors, vector v goes to accumulator v % 4 while whole groups of four remain and to accumulator 0 afterwards,
+    // accumulators 1..3 are added to 0 in order; the scalar result is 0 + the < 8 tail elements in order + the 8 vector slots in order.
+    // (Rows of >= 512 elements add cascade levels; nw < 256 here.)
+    float* part8 = reinterpret_cast<float*>(sortbuf);             // the sort scratch is free until the sort
+    const int nv = nw >> 3;
+    if (lane < 8) {
+        const int n4 = nv >> 2;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int i = 0; i < n4; ++i) {
+            a0 += pw[32 * i + lane] + 1e-5f;
+            a1 += pw[32 * i + 8 + lane] + 1e-5f;
+            a2 += pw[32 * i + 16 + lane] + 1e-5f;
+            a3 += pw[32 * i + 24 + lane] + 1e-5f;
+        }
+        for (int v = 4 * n4; v < nv; ++v) a0 += pw[8 * v + lane] + 1e-5f;
+        a0 += a1; a0 += a2; a0 += a3;
+        part8[lane] = a0;
+    }
+    lds_wave_sync();
+    float total = 0.0f;              // every lane forms the same scalar (LDS broadcast reads)
+    if (nv > 0) {
+        for (int j = 8 * nv; j < nw; ++j) total += pw[j] + 1e-5f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) total += part8[c];
+    } else {                         // rows shorter than one vector: the scalar form (4 accumulators over single elements)
+        float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        if (nw >= 4) { total += pw[0] + 1e-5f; a1 += pw[1] + 1e-5f; a2 += pw[2] + 1e-5f; a3 += pw[3] + 1e-5f; }
+        for (int j = nw & ~3; j < nw; ++j) total += pw[j] + 1e-5f;
+        total += a1; total += a2; total += a3;
+    }
     // cdf: fp64 running sum of fp32 pdf values, rounded per element (torch CPU cumsum)
     double carry = 0.0;
     if (lane == 0) cdf[0] = 0.0f;
@@ -189,7 +290,10 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
     unsigned short* mem = reinterpret_cast<unsigned short*>(sortbuf + 2 * SORT_NB);
     for (int b = lane; b < SORT_NB; b += 64) cnt[b] = 0;
     lds_wave_sync();
+    // (the order-of-uniforms argument needs ascending bin edges; a ray whose edges are not -- unsorted depths passed to inverseSample,
+    // or stratified depths whose jitter exceeds the bin spacing -- takes the rank sort below, which sorts the VALUES like torch.sort)
     int overflow = 0;
+    for (int j = lane; j + 1 < nb; j += 64) overflow |= (bins[j + 1] < bins[j]) ? 1 : 0;
     for (int k = lane, i = 0; k < K; k += 64, ++i) {
         int b = (int)(uf(i, k) * (float)SORT_NB);
         b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
@@ -939,6 +1043,21 @@ int sk_positional_encoding(const float* x, int64_t M, int L, float* out, hipStre
     hipLaunchKernelGGL(pe_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, st, x, total, L, out);
     return (int)hipGetLastError();
 }
+int sk_ipe_feature(const float* z, const float* rays, int64_t N, int Sn, int L, float r2, const float* dir_norm, float* feat, float* mu,
+                   float* mu_t, hipStream_t st) {
+    if (N * Sn == 0) return 0;
+    hipLaunchKernelGGL(ipe_feature_kernel, dim3(blocks_for(N * Sn, 256)), dim3(256), 0, st, z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t);
+    return (int)hipGetLastError();
+}
+int sk_cone_parameters(const float* z, int64_t N, int Sn, float r2, float* mu_t, float* var_t, float* var_r, hipStream_t st) {
+    if (N * Sn == 0) return 0;
+    hipLaunchKernelGGL(cone_parameters_kernel, dim3(blocks_for(N * Sn, 256)), dim3(256), 0, st, z, N, Sn, r2, mu_t, var_t, var_r);
+    return (int)hipGetLastError();
+}
+int sk_dirs_norm(const float* rays, int64_t N, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(dirs_norm_kernel, dim3(1), dim3(1024), 0, st, rays, N, out);
+    return (int)hipGetLastError();
+}
 int sk_generate_rays(const float* pose, int H, int W, float fx, float fy, int64_t first, int64_t count, float* rays,
                      hipStream_t st) {
     Cam c; c.H = H; c.W = W; c.fx = fx; c.fy = fy;
@@ -1037,12 +1156,7 @@ int sk_frag_to_rows(const void* frag, int elem_bytes, int64_t n_sub, int n_kg, i
     if (elem_bytes == 2) {
         hipLaunchKernelGGL(frag_to_rows_kernel<2>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), lds, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frag_to_rows_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_done = true;
-        }
+        if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(frag_to_rows_kernel<4>), 140 * 1024)) return e;
         hipLaunchKernelGGL(frag_to_rows_kernel<4>, dim3(blocks_for(n_sub, WAVES_PER_BLOCK)), dim3(256), lds, st, (const char*)frag, n_sub, n_kg, M, (char*)out, n_kg * 16);
     }
     return (int)hipGetLastError();
@@ -1089,12 +1203,7 @@ int sk_frag_rows_mask(const void* frag, int elem_bytes, int64_t n_sub, int n_kg,
     if (elem_bytes == 2) {
         hipLaunchKernelGGL(frag_rows_mask_kernel<2>, grid, block, lds, st, (const char*)frag, n_sub, n_kg, M, (char*)act_out, (char*)delta, col_sum);
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frag_rows_mask_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_done = true;
-        }
+        if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(frag_rows_mask_kernel<4>), 140 * 1024)) return e;
         hipLaunchKernelGGL(frag_rows_mask_kernel<4>, grid, block, lds, st, (const char*)frag, n_sub, n_kg, M, (char*)act_out, (char*)delta, col_sum);
     }
     return (int)hipGetLastError();

@@ -3,6 +3,7 @@ import torch
 
 from . import ops
 from . import autograd_bridge as ab
+from ._packed import require_no_grad
 
 
 def maxBlurFilter(weights: torch.Tensor, alpha: float):
@@ -14,29 +15,14 @@ def maxBlurFilter(weights: torch.Tensor, alpha: float):
 
 
 def coneParameters(zvals: torch.Tensor, r: float):
-    """Conical-frustum Gaussian moments along the ray (mip_methods.py:15-23; dead code in the reference)."""
-    mid = (zvals[:, 1:] + zvals[:, :-1]) / 2
-    hw2 = ((zvals[:, 1:] - zvals[:, :-1]) / 2) ** 2
-    t = 3 * mid ** 2 + hw2
-    mu_t = mid + 2 * mid * hw2 / t
-    var_t = hw2 / 3 - 4 * (hw2 ** 2) * (12 * mid ** 2 - hw2) / 15 / (t ** 2)
-    var_r = (r ** 2) * (0.25 * mid ** 2 + 5 / 12 * hw2 - 4 * hw2 ** 2 / (15 * t))
-    return mu_t, var_t, var_r
+    """Conical-frustum Gaussian moments along the ray (mip_methods.py:15-23) -> (mu_t, sigma_t^2, sigma_r^2), each (N, S) -- HIP kernel."""
+    require_no_grad(zvals)
+    return ops.cone_parameters(zvals, r)
 
 
 def ipe_feature(zvals: torch.Tensor, cam_rays: torch.Tensor, freq_lvs: int, r: float):
-    """Integrated positional encoding with diagonal covariance (mip_methods.py:47-58).  The reference
-    never calls it; kept as device-agnostic torch expressions and pinned by golden G12."""
-    mu_t, var_t, var_r = coneParameters(zvals, r)
-    o, d = cam_rays[:, :3], cam_rays[:, 3:]
-    mu = o[:, None, :] + mu_t[:, :, None] * d[:, None, :]
-    dd = d * d
-    perp = torch.ones(3, device=zvals.device)[None, :] - dd / d.norm()            # whole-tensor norm, as in the reference
-    diag = var_t[:, :, None] * dd[:, None, :] + var_r[:, :, None] * perp[:, None, :]
-    f2 = torch.tensor([2.0 ** i for i in range(freq_lvs)], device=zvals.device)
-    f4 = torch.tensor([4.0 ** i for i in range(freq_lvs)], device=zvals.device)
-    mu_r = f2[None, None, :, None] * mu[:, :, None, :]
-    att = torch.exp(-0.5 * (f4[None, None, :, None] * diag[:, :, None, :]))
-    n, s = mu.shape[0], mu.shape[1]
-    feat = torch.cat((torch.sin(mu_r) * att, torch.cos(mu_r) * att), dim=-1).reshape(n, s, -1)
-    return feat, mu, mu_t
+    """Integrated positional encoding with diagonal covariance (mip_methods.py:47-58, helpers :15-45) -- HIP kernel
+    (nerf_amd_ipe_feature; the whole-tensor direction norm of :31 comes from nerf_amd_dirs_norm).  zvals (N, S+1), cam_rays (N, 6)
+    -> (feature (N, S, 6 freq_lvs), mu (N, S, 3), mu_t (N, S)).  Forward-only, like every encoding input of the reference."""
+    require_no_grad(zvals, cam_rays)
+    return ops.ipe_feature(zvals, cam_rays, freq_lvs, r)

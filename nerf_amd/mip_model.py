@@ -11,7 +11,7 @@ from .nerf_base import NeRF
 from .nerf_helper import makeMLP
 
 
-class MipNeRF(NeRF, PackedWeightsMixin):
+class MipNeRF(PackedWeightsMixin, NeRF):
     _net_id = ops.NET_MIP
 
     def __init__(self, position_flevel, direction_flevel, hidden_unit=256, cat_origin=True) -> None:

@@ -99,7 +99,8 @@ class NeRF(nn.Module):
             rgbo = torch.cat((rgbo[..., :3], pre(rgbo[..., 3:])), dim=-1)
         normal, cam_dir = (normal_info if normal_info is not None else (None, None))
         if ab.needs_grad(rgbo, depth):
-            # training path (train.py:190,196): differentiable w.r.t. the network output; extras stay forward-only
+            # training path (train.py:190,196): rgb AND weights are differentiable w.r.t. the network output (the Ref-NeRF step feeds
+            # the weights into WeightedNormalLoss / BackFaceLoss un-detached, train.py:183-184); extras stay forward-only
             def hip(r, z, dd):
                 rgb_, w_, _, _ = ops.composite(r, z, dd, mul_norm == True, bool(white_bkg), code, None)
                 return rgb_, w_
@@ -108,9 +109,10 @@ class NeRF(nn.Module):
                 zz = z * dd.norm(dim=-1, keepdim=True) if mul_norm == True else z
                 w_ = ab.weights_expr(r[..., 3], zz, code)
                 c = torch.sum(w_[:, :, None] * r[..., :3], dim=-2)
-                return c + (1.0 - torch.sum(w_, -1)[..., None]) if white_bkg else c
+                return (c + (1.0 - torch.sum(w_, -1)[..., None]) if white_bkg else c), w_
+            expr.n_diff = 2
             ab.with_hip_backward(expr, lambda g, r, z, dd: (
-                (ops.composite_backward(r, z, dd, mul_norm == True, bool(white_bkg), code, None, g, None, None), None, None)
+                (ops.composite_backward(r, z, dd, mul_norm == True, bool(white_bkg), code, None, g[0], g[1], None), None, None)
                 if r.shape[1] <= ops.BWD_MAX_SAMPLES else None))
             rgb, w = ab.HipOp.apply(hip, expr, 1, rgbo, depth, ray_dirs)
             extras = dict()

@@ -68,10 +68,17 @@ def _samples_pts(pts: torch.Tensor, stride: int, contract: bool = False) -> Samp
 
 
 def samples_rays(rays: torch.Tensor, S: int, z: Optional[torch.Tensor] = None, z_base: Optional[torch.Tensor] = None,
-                 u: Optional[torch.Tensor] = None, z_jitter: float = 0.0, contract: bool = False) -> Samples:
-    """`contract`: Mip-NeRF 360 scene contraction of the sample positions before encoding (not in the reference; BASELINE config 5)."""
+                 u: Optional[torch.Tensor] = None, z_jitter: float = 0.0, contract: bool = False, ipe_radius: Optional[float] = None,
+                 ipe_dir_norm: Optional[torch.Tensor] = None) -> Samples:
+    """`contract`: Mip-NeRF 360 scene contraction of the sample positions before encoding (not in the reference; BASELINE config 5).
+    `ipe_radius` (with explicit z of S+1 depths per ray): integrated PE of the frusta between consecutive depths (mip_methods.py:15-58);
+    `ipe_dir_norm` = ops.dirs_norm(rays) -- the caller keeps that tensor alive until the kernel has run."""
     s = Samples()
     s.contract = int(bool(contract))
+    if ipe_radius is not None:
+        if z is None or z.shape[-1] < S + 1 or ipe_dir_norm is None:
+            raise ValueError("nerf_amd: integrated PE needs explicit z with S+1 depths per ray and ipe_dir_norm")
+        s.ipe, s.ipe_radius, s.ipe_dir_norm = 1, float(ipe_radius), ipe_dir_norm.data_ptr()
     s.mode = 1
     s.S = S
     s.M = rays.shape[0] * S
@@ -172,6 +179,37 @@ def positional_encoding(x: torch.Tensor, L: int) -> torch.Tensor:
     out = torch.empty(x.shape[:-1] + (6 * L,), dtype=torch.float32, device=x.device)
     check(lib.nerf_amd_positional_encoding(_ptr(x), x.numel() // 3, L, _ptr(out), _stream()), "nerf_amd_positional_encoding")
     return out
+
+
+def dirs_norm(rays: torch.Tensor) -> torch.Tensor:
+    """Norm of the whole (N,3) direction tensor of a ray table (mip_methods.py:31's `.norm()` without a dim) -> (1,) on the device."""
+    rays = _dev(rays, "rays")
+    out = torch.empty((1,), dtype=torch.float32, device=rays.device)
+    check(lib.nerf_amd_dirs_norm(_ptr(rays), rays.shape[0], _ptr(out), _stream()), "nerf_amd_dirs_norm")
+    return out
+
+
+def cone_parameters(z: torch.Tensor, r: float):
+    """coneParameters (mip_methods.py:15-23): z (N,S+1) -> mu_t, sigma_t^2, sigma_r^2 (N,S)."""
+    z = _dev(z, "zvals")
+    N, S = z.shape[0], z.shape[1] - 1
+    out = [torch.empty((N, S), dtype=torch.float32, device=z.device) for _ in range(3)]
+    check(lib.nerf_amd_cone_parameters(_ptr(z), N, S, float(r), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream()), "nerf_amd_cone_parameters")
+    return tuple(out)
+
+
+def ipe_feature(z: torch.Tensor, rays: torch.Tensor, L: int, r: float, dir_norm: Optional[torch.Tensor] = None):
+    """ipe_feature (mip_methods.py:47-58): z (N,S+1), rays (N,6) -> feat (N,S,6L), mu (N,S,3), mu_t (N,S)."""
+    z, rays = _dev(z, "zvals"), _dev(rays, "cam_rays")
+    N, S = z.shape[0], z.shape[1] - 1
+    if dir_norm is None:
+        dir_norm = dirs_norm(rays)
+    feat = torch.empty((N, S, 6 * L), dtype=torch.float32, device=z.device)
+    mu = torch.empty((N, S, 3), dtype=torch.float32, device=z.device)
+    mu_t = torch.empty((N, S), dtype=torch.float32, device=z.device)
+    check(lib.nerf_amd_ipe_feature(_ptr(z), _ptr(rays), N, S, L, float(r), _ptr(dir_norm), _ptr(feat), _ptr(mu), _ptr(mu_t), _stream()),
+          "nerf_amd_ipe_feature")
+    return feat, mu, mu_t
 
 
 def generate_rays(pose: torch.Tensor, H: int, W: int, fx: float, fy: float, device, ray_offset: int = 0,
@@ -321,14 +359,19 @@ def resample(density, z, z_base, u_strat, z_jitter, rays, u_inv, K, softplus=Fal
 
 def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                 want_depth=True, want_weights=False, workspace: Optional[torch.Tensor] = None, camera: Optional[Samples] = None,
-                ray_offset: int = 0, n_rays: Optional[int] = None, contract: bool = False):
+                ray_offset: int = 0, n_rays: Optional[int] = None, contract: bool = False, ipe_radius: Optional[float] = None):
     """The tile body of render_image (procedures.py:64-85) for all given rays in four launches.  `contract`: Mip-NeRF 360 scene
-    contraction of every sample position (proposal and fine) before encoding."""
+    contraction of every sample position (proposal and fine) before encoding.  `ipe_radius`: the fine pass encodes the conical frusta
+    between consecutive fine depths with the integrated PE (mip_methods.py:15-58; explicit `rays` required)."""
     dev = u_strat.device
-    if contract and camera is None:
-        camera = Samples()                                   # carries only the flag next to explicit rays
+    if (contract or ipe_radius is not None) and camera is None:
+        camera = Samples()                                   # carries only the flags next to explicit rays
     if camera is not None:
         camera.contract = int(bool(contract))
+        if ipe_radius is not None:
+            if rays is None:
+                raise ValueError("nerf_amd: integrated PE needs an explicit ray table")
+            camera.ipe, camera.ipe_radius = 1, float(ipe_radius)
     N = u_strat.shape[0] if n_rays is None else n_rays
     need = lib.nerf_amd_render_workspace_bytes(N, n_fine)
     if workspace is None or workspace.numel() < need:

@@ -44,11 +44,15 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
                  near: float, far: float, sample_num: int = 128, white_bkg: bool = False, render_depth=False,
-                 render_normal=False, rng: str = "reference", contract: bool = False) -> dict:
+                 render_normal=False, rng: str = "reference", contract: bool = False, ipe=False) -> dict:
     """Whole-image inference (procedures.py:34-97) -> {"rgb" (3,H,W) [, "depth_img" (3,H,W)]} on
     ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference.
-    ``rng`` and ``contract`` are additions: ``contract=True`` applies the Mip-NeRF 360 scene contraction to every sample
-    position before the networks encode it (unbounded scenes, BASELINE config 5; not available for Ref-NeRF)."""
+    ``rng``, ``contract`` and ``ipe`` are additions: ``contract=True`` applies the Mip-NeRF 360 scene contraction to every sample
+    position before the networks encode it (unbounded scenes, BASELINE config 5; not available for Ref-NeRF).  ``ipe`` (BASELINE
+    config 3): the fine network reads the integrated positional encoding of the conical frustum between consecutive fine depths
+    (mip_methods.py:15-58: [mu | ipe_feature]) instead of the point encoding; True = the pixel radius 2/sqrt(12) pixel widths of
+    Mip-NeRF, a float = that radius.  The reference holds `ipe_feature` but never calls it: its use inside the loop is this build's
+    definition (oracle.render_rays(ipe_radius=...)), parity of the function itself is pinned by golden G12."""
     if not isinstance(image_size, Iterable):
         image_size = (image_size, image_size)
     is_ref_model = type(network).__name__ == "RefNeRF"
@@ -72,9 +76,15 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
     z_base = torch.linspace(near, far, RENDER_COARSE_PNUM, device="cpu").to(dev)   # procedures.py:52 (CPU linspace bits)
     normal_px = None
+    ipe_radius = None
+    if ipe:
+        if is_ref_model:
+            raise NotImplementedError("nerf_amd: the integrated PE is wired for the MipNeRF render path only")
+        ipe_radius = (2.0 / (12.0 ** 0.5) / fx) if ipe is True else float(ipe)
     if not is_ref_model:
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
-                                           sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract)
+                                           sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,
+                                           ipe_radius=ipe_radius)
     else:
         if contract:
             raise NotImplementedError("nerf_amd: scene contraction is wired for the MipNeRF render path only")

@@ -15,7 +15,7 @@ from .nerf_helper import makeMLP
 from .ref_func import generate_ide_fn, ide_table
 
 
-class RefNeRF(NeRF, PackedWeightsMixin):
+class RefNeRF(PackedWeightsMixin, NeRF):
     _net_id = ops.NET_REF
 
     def __init__(self, position_flevel, sh_max_level, bottle_neck_dim=128, hidden_unit=256, output_dim=256, use_srgb=False,
@@ -71,17 +71,9 @@ class RefNeRF(NeRF, PackedWeightsMixin):
         bs = [l.bias for l in lin] + [hb] + [l.bias for l in tail] + [hb]
         return ws, bs
 
-    def packed(self, precision: int) -> torch.Tensor:
-        params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        cache = self.__dict__.setdefault("_packed_cache", {})
-        hit = cache.get(precision)
-        if hit is None or hit[0] != key:
-            ws, bs = self._pack_tensors()
-            blob = ops.pack_weights(self._net_id, precision, ws, bs)
-            cache[precision] = (key, blob)
-            return blob
-        return hit[1]
+    def _pack_now(self, precision: int) -> torch.Tensor:
+        ws, bs = self._pack_tensors()
+        return ops.pack_weights(self._net_id, precision, ws, bs)
 
     def forward(self, pts: torch.Tensor, ray_d: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """pts (N,S,6) [or (N,S,3) + ray_d (N,S,3)] -> ((N,S,4) = [rgb | raw density], normal (N,S,3))  (ref_model.py:68-106)."""

@@ -165,13 +165,16 @@ def proposal_forward(sd: Dict[str, Tensor], pts: Tensor, L: int = 10, emulate_bf
     return _linear(h, sd["layers.8.weight"], sd["layers.8.bias"], emulate_bf16).squeeze(-1)
 
 
-def mip_forward(sd: Dict[str, Tensor], pts: Tensor, Lp: int = 10, Ld: int = 4, emulate_bf16: bool = False) -> Tensor:
+def mip_forward(sd: Dict[str, Tensor], pts: Tensor, Lp: int = 10, Ld: int = 4, emulate_bf16: bool = False,
+                encoded_x: Optional[Tensor] = None) -> Tensor:
     """MipNeRF.forward (mip_model.py:41-60).  pts (N, S, 6) = [position | raw direction] -> (N, S, 4)
-    = [sigmoid rgb | raw sigma].  Skip-cat order (enc, h) (:55); head-cat order (bottleneck, dir) (:59)."""
+    = [sigmoid rgb | raw sigma].  Skip-cat order (enc, h) (:55); head-cat order (bottleneck, dir) (:59).
+    ``encoded_x`` (not in the reference's forward): the 6 Lp encoding columns that follow the position, e.g. ipe_feature's output,
+    used instead of positional_encoding(x)."""
     x = pts[..., :3]
     d = pts[..., 3:6]
     d = d / d.norm(dim=-1, keepdim=True)
-    ex = torch.cat((x, positional_encoding(x, Lp)), dim=-1)
+    ex = torch.cat((x, positional_encoding(x, Lp) if encoded_x is None else encoded_x), dim=-1)
     ed = torch.cat((d, positional_encoding(d, Ld)), dim=-1)
     h = ex
     for i in (0, 2, 4, 6):
@@ -246,6 +249,55 @@ def max_blur(w: Tensor, alpha: float) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # row 7: inverse-transform sampling
 # --------------------------------------------------------------------------------------------
+def cascade_row_sum(x) -> "numpy.ndarray":
+    """The ORDER in which torch's CPU kernel sums a contiguous fp32 row (ATen SumKernel.cpp: cascade_sum -> vectorized_inner_sum ->
+    row_sum / multi_row_sum), restated in numpy for rows of < 512 elements: the row is read as 8-float vectors; vector v is added to
+    accumulator v % 4 while whole groups of four vectors remain, to accumulator 0 afterwards; accumulators 1..3 are then added to 0;
+    the scalar is 0 + the (< 8) tail elements in order + the 8 lanes of accumulator 0 in order.  Rows shorter than one vector take
+    the scalar form of the same scheme (scalar_inner_sum): element j goes to accumulator j % 4 while whole groups of four remain, to
+    accumulator 0 afterwards, then accumulators 1..3 are added to 0.  The HIP inverse-sampling kernels
+    use this order for the pdf normaliser of utils.py:110-111 so that their CDF is bit-identical to the reference's; this function
+    is what tests/test_oracle_golden.py checks against torch.sum itself (on the machine that runs the tests).  x: (N, n) float32."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float32)
+    N, n = x.shape
+    f32 = np.float32
+    if n < 8:
+        acc = [np.zeros(N, f32) for _ in range(4)]
+        for i in range(n // 4):
+            for k in range(4):
+                acc[k] = (acc[k] + x[:, 4 * i + k]).astype(f32)
+        for j in range(4 * (n // 4), n):
+            acc[0] = (acc[0] + x[:, j]).astype(f32)
+        for k in (1, 2, 3):
+            acc[0] = (acc[0] + acc[k]).astype(f32)
+        return acc[0]
+    nv, n4 = n // 8, (n // 8) // 4
+    vec = x[:, : nv * 8].reshape(N, nv, 8)
+    acc = [np.zeros((N, 8), f32) for _ in range(4)]
+    for i in range(n4):
+        for k in range(4):
+            acc[k] = (acc[k] + vec[:, 4 * i + k]).astype(f32)
+    for v in range(4 * n4, nv):
+        acc[0] = (acc[0] + vec[:, v]).astype(f32)
+    for k in (1, 2, 3):
+        acc[0] = (acc[0] + acc[k]).astype(f32)
+    s = np.zeros(N, f32)
+    for j in range(nv * 8, n):
+        s = (s + x[:, j]).astype(f32)
+    for c in range(8):
+        s = (s + acc[0][:, c]).astype(f32)
+    return s
+
+
+def pdf_cdf(weights: Tensor) -> Tensor:
+    """The CDF sample_pdf searches (utils.py:110-113): weights (N, B-1) -> (N, B) with the leading 0."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    return torch.cat((torch.zeros_like(cdf[..., :1]), cdf), -1)
+
+
 def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     """utils.py:108-133 with u explicit.  bins (N, B), weights (N, B-1), u (N, K) -> samples,
     below, above."""
@@ -344,9 +396,21 @@ def loss_psnr(mse: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # row 12: integrated PE (dead code in the reference; pinned by golden only)
 # --------------------------------------------------------------------------------------------
-def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float):
+def cone_parameters(z: Tensor, r: float):
+    """coneParameters (mip_methods.py:15-23): z (N, S+1) -> mu_t, sigma_t^2, sigma_r^2 (N, S)."""
+    mid = (z[:, 1:] + z[:, :-1]) / 2
+    hw2 = ((z[:, 1:] - z[:, :-1]) / 2) ** 2
+    t1 = 3 * mid ** 2 + hw2
+    mu_t = mid + 2 * mid * hw2 / t1
+    var_t = hw2 / 3 - 4 * (hw2 ** 2) * (12 * mid ** 2 - hw2) / 15 / (t1 ** 2)
+    var_r = (r ** 2) * (0.25 * mid ** 2 + 5 / 12 * hw2 - 4 * hw2 ** 2 / (15 * t1))
+    return mu_t, var_t, var_r
+
+
+def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float, dir_norm: Optional[Tensor] = None):
     """mip_methods.py:15-58.  z (N, S+1) -> (N, S, 6L) feature, mu (N,S,3), mu_t (N,S).
-    Quirk kept: ``.norm()`` at :31 is over the whole (N,3) direction tensor."""
+    Quirk kept: ``.norm()`` at :31 is over the whole (N,3) direction tensor; ``dir_norm`` (a test hook) substitutes the norm of a
+    larger batch these rays were cut from."""
     mid = (z[:, 1:] + z[:, :-1]) / 2
     hw2 = ((z[:, 1:] - z[:, :-1]) / 2) ** 2
     t1 = 3 * mid ** 2 + hw2
@@ -356,7 +420,7 @@ def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float):
     o, d = rays[:, :3], rays[:, 3:]
     mu = o[:, None, :] + mu_t[:, :, None] * d[:, None, :]
     dd = d * d
-    perp = torch.ones(3, device=z.device)[None, :] - dd / d.norm()
+    perp = torch.ones(3, device=z.device)[None, :] - dd / (d.norm() if dir_norm is None else dir_norm)
     diag = var_t[:, :, None] * dd[:, None, :] + var_r[:, :, None] * perp[:, None, :]
     N, S, _ = mu.shape
     f2 = torch.tensor([2.0 ** i for i in range(L)], device=z.device)
@@ -381,10 +445,15 @@ def contract(x: Tensor) -> Tensor:
 
 def render_rays(prop_sd, mip_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float,
                 sample_num: int = 128, white_bkg: bool = False, emulate_bf16: bool = False,
-                stages: Optional[dict] = None, contracted: bool = False):
+                stages: Optional[dict] = None, contracted: bool = False, ipe_radius: Optional[float] = None,
+                ipe_dir_norm: Optional[Tensor] = None):
     """rays (N,6), u_strat (N,64), u_inv (N,sample_num+1) -> rgb (N,3), weights (N,S), depth (N,).
     ``stages`` (optional dict) receives every intermediate for stage-by-stage parity tests.  ``contracted`` (not in the
-    reference): every sample position goes through contract() before the networks see it; depths stay metric."""
+    reference): every sample position goes through contract() before the networks see it; depths stay metric.
+    ``ipe_radius`` (BASELINE config 3; the reference holds ipe_feature but no caller, so this wiring is the build's own definition
+    -- parity of the LOOP unpinned, the function itself pinned by G12/G18): the fine network's input becomes [mu | ipe_feature] of
+    the conical frusta between consecutive fine depths z_f[s], z_f[s+1] (all sample_num+1 sorted depths are used: sample_num frusta);
+    the proposal pass and the compositing depths are unchanged."""
     z_c = stratified_render(near, far, sample_num, u_strat)
     pts_c = rays[:, None, :3] + z_c[..., None] * rays[:, None, 3:]
     if contracted:
@@ -393,11 +462,16 @@ def render_rays(prop_sd, mip_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, n
     w_raw = sigma_to_weights(density, z_c, rays[:, 3:])
     w_prop = max_blur(w_raw, 0.01)
     z_f, below = inverse_sample(w_prop, z_c, u_inv, sort=True)
+    z_all = z_f
     z_f = z_f[..., :-1]
     pts_f = length2pts(rays, z_f)
+    enc = None
+    if ipe_radius is not None:
+        enc, mu, _ = ipe_feature(z_all, rays, 10, ipe_radius, ipe_dir_norm)
+        pts_f = torch.cat((mu, pts_f[..., 3:]), dim=-1)
     if contracted:
         pts_f = torch.cat((contract(pts_f[..., :3]), pts_f[..., 3:]), dim=-1)
-    rgbo = mip_forward(mip_sd, pts_f, emulate_bf16=emulate_bf16)
+    rgbo = mip_forward(mip_sd, pts_f, emulate_bf16=emulate_bf16, encoded_x=enc)
     rgb, w, extras = composite(rgbo, z_f, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far))
     if stages is not None:
         stages.update(z_coarse=z_c, density=density, w_raw=w_raw, w_prop=w_prop, z_fine=z_f, below=below,

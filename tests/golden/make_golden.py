@@ -357,7 +357,20 @@ def main():
         weights=wts17, rendered=rend17, normal_loss=nl17, bf_loss=bf17, coarse_normal_loss=cnl17, img_loss=img17, prop_loss=pl17,
         loss=loss17, g_spa0=net.spa_block1[0].weight.grad[:8, :], g_rho_tau=net.rho_tau_head.weight.grad,
         g_nct=net.norm_col_tint_head.weight.grad, g_bottle=net.bottle_neck.weight.grad[:8, :], g_dir0=net.dir_block1[0].weight.grad[:8, :],
-        g_spec=net.spec_rgb_head[0].weight.grad, g_prop_l0=prop.layers[0].weight.grad[:8, :], g_prop_head=prop.layers[8].weight.grad)
+        g_spec=net.spec_rgb_head[0].weight.grad, g_prop_l0=prop.layers[0].weight.grad[:8, :], g_prop_head=prop.layers[8].weight.grad,
+        g_spa2_6=net.spa_block2[6].weight.grad[:8, :], g_rho_tau_bias=net.rho_tau_head.bias.grad)
+
+    # ---------------- G18 integrated PE at the network's size (L = 10) + coneParameters (mip_methods.py:15-58) ----------------
+    # (after G17: draws from the end of the generator stream, earlier fixtures unchanged)
+    z18, _ = torch.sort(near + (far - near) * torch.rand(48, 33, generator=g), dim=-1)
+    o18 = torch.randn(48, 3, generator=g) * 0.5 + T([0.0, 0.0, 4.0])
+    d18 = F.normalize(torch.randn(48, 3, generator=g) * 0.3 + T([0.0, 0.0, -1.0]), dim=-1) * (0.9 + 0.3 * torch.rand(48, 1, generator=g))
+    r18 = torch.cat((o18, d18), -1)
+    rad18 = 2.0 / (12.0 ** 0.5) / 1111.1
+    feat18, mu18, mu_t18 = mip_methods.ipe_feature(z18, r18, 10, rad18)
+    cp18 = mip_methods.coneParameters(z18, rad18)
+    npz("g18_ipe_l10", z=z18, rays=r18, radius=np.float64(rad18), feat=feat18, mu=mu18, mu_t=mu_t18, var_t=cp18[1], var_r=cp18[2],
+        dir_norm=r18[:, 3:].norm())
 
 
 if __name__ == "__main__":

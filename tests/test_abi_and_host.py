@@ -34,15 +34,16 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from nerf_amd import _lib
     # 8-byte alignment of the pointer members, 12 floats of pose at the end
-    assert ctypes.sizeof(_lib.Samples) == 8 + 8 + 8 + 4 + 4 + 8 * 4 + 4 + 4 + 4 + 4 + 4 + 48 + 4
+    assert ctypes.sizeof(_lib.Samples) == 8 + 8 + 8 + 4 + 4 + 8 * 4 + 4 + 4 + 4 + 4 + 4 + 48 + 4 + 4 + 4 + 8
     assert _lib.Samples.M.offset == 8 and _lib.Samples.pts.offset == 16 and _lib.Samples.rays.offset == 32
     assert _lib.Samples.pose.offset == 84 and _lib.Samples.contract.offset == 132      # the flag sits in the former tail padding
+    assert _lib.Samples.ipe.offset == 136 and _lib.Samples.ipe_radius.offset == 140 and _lib.Samples.ipe_dir_norm.offset == 144
 
 
 def test_pure_queries_without_gpu():
     from nerf_amd import _lib
     lib = _lib.lib
-    assert lib.nerf_amd_version() == 100
+    assert lib.nerf_amd_version() == 110
     assert lib.nerf_amd_packed_bytes(_lib.NET_PROPOSAL, _lib.BF16) == 432 * 1024 + 1056 * 4
     fold = (128 * 256 + 128) * 4                       # scratch of the bottle_neck -> rgb_layer.0 fold
     assert lib.nerf_amd_packed_bytes(_lib.NET_MIP, _lib.BF16) == 928 * 1024 + 1984 * 4 + fold
@@ -127,11 +128,15 @@ def test_lr_scheduler_and_losses(golden):
     assert abs(SoftL1Loss()(g14["rendered"], g14["rgb_tgt"]).item() - g14["img_loss"]) <= 1e-7
 
 
-def test_ipe_restatement_matches_golden(golden):
-    from nerf_amd.mip_methods import ipe_feature
+def test_ipe_is_a_hip_entry_point_without_cpu_path(golden):
+    """Row 12: ipe_feature / coneParameters are HIP kernels (nerf_amd_ipe_feature, nerf_amd_cone_parameters); CPU tensors are rejected
+    like everywhere else in the product (the CPU restatement lives in oracle/ and is pinned by G12 / G18)."""
+    from nerf_amd.mip_methods import coneParameters, ipe_feature
     g = golden("g12_ipe")
-    feat, mu, mu_t = ipe_feature(g["z"], g["rays"], 6, 0.0015)
-    assert (feat - g["feat"]).abs().max() <= 1e-6 and (mu - g["mu"]).abs().max() <= 1e-6 and (mu_t - g["mu_t"]).abs().max() <= 1e-6
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ipe_feature(g["z"], g["rays"], 6, 0.0015)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        coneParameters(g["z"], 0.0015)
 
 
 def test_checkpoint_roundtrip_with_reference_modules(tmp_path):

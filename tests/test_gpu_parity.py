@@ -124,24 +124,61 @@ def _below_mismatch(a, b):
     return (a != b).float().mean().item()
 
 
+def _assert_below_explained(got_below, want_below, u, cdf_want, cdf_got, what=""):
+    """`below` is index work: it must EQUAL the reference's except where the two sides searched CDFs that differ (upstream float
+    differences: the GPU's expf / MLP bits) and the uniform fell between the two versions of one edge.  Every mismatch must be off
+    by exactly one bin, and u must lie inside [min, max] of that edge's two CDF values, widened by one fp32 ulp.
+    got/want_below (N,K) in the order of `u` (N,K) -- pass u sorted when the samples were sorted; cdf_* (N,B)."""
+    got_below, want_below = got_below.cpu().long(), want_below.cpu().long()
+    bad = got_below != want_below
+    if not bool(bad.any()):
+        return 0
+    n_idx, k_idx = bad.nonzero(as_tuple=True)
+    g, w = got_below[n_idx, k_idx], want_below[n_idx, k_idx]
+    assert bool(((g - w).abs() == 1).all()), what + ": a `below` index is off by more than one bin"
+    edge = torch.maximum(g, w)                                   # the CDF entry the two searches disagree about
+    c1, c2 = cdf_want[n_idx, edge].double(), cdf_got[n_idx, edge].double()
+    uu = u.cpu()[n_idx, k_idx].double()
+    ulp = 2.0 ** -23
+    lo, hi = torch.minimum(c1, c2) - ulp, torch.maximum(c1, c2) + ulp
+    assert bool(((uu >= lo) & (uu <= hi)).all()), what + ": a `below` mismatch is not explained by the two CDFs' difference at that edge"
+    return int(bad.sum())
+
+
 def test_inverse_sampling(A, golden):
+    """Row 7 on identical inputs: the kernels sum the pdf normaliser in torch's CPU order (O.cascade_row_sum), accumulate the CDF in
+    fp64 like torch's cumsum and search it like searchsorted(right=True) -- so the INDICES equal the reference's exactly (index
+    work: bit-exact) and the depths agree to the last bits of the same fp32 expression."""
     g = golden("g07_inverse")
     z, below = A.utils.inverseSample(dev(g["w"]), dev(g["z"]), 129, sort=True, u=g["u"])
-    # conditioning of the inverse CDF: dz ~ bin_width * eps(cdf) / (cdf_hi - cdf_lo); the pdf normaliser is a
-    # float sum whose order differs between torch's vectorised CPU sum and a wavefront tree -> a few 1e-6
-    assert max_abs(z.cpu(), g["z_sorted"]) <= 2e-5
-    assert _below_mismatch(below.cpu(), g["below_sorted"]) <= 0.005
+    assert torch.equal(below.cpu(), g["below_sorted"])
+    assert max_abs(z.cpu(), g["z_sorted"]) <= 1e-6
     assert bool((z[:, 1:] >= z[:, :-1]).all())
     zr = A.utils.inverseSample(dev(g["w"]), dev(g["z"]), 129, sort=False, u=g["u"])
-    assert max_abs(zr.cpu(), g["z_raw"]) <= 2e-5
+    assert max_abs(zr.cpu(), g["z_raw"]) <= 1e-6
     mids = 0.5 * (g["z"][..., 1:] + g["z"][..., :-1])
     s, b, a = A.utils.sample_pdf(dev(mids), dev(g["w"][..., 1:-1].contiguous()), 33, u=g["u_pdf"])
-    assert max_abs(s.cpu(), g["s_pdf"]) <= 2e-5
-    assert _below_mismatch(b.cpu(), g["below_pdf"]) <= 0.005 and _below_mismatch(a.cpu(), g["above_pdf"]) <= 0.005
+    assert max_abs(s.cpu(), g["s_pdf"]) <= 1e-6
+    assert torch.equal(b.cpu(), g["below_pdf"]) and torch.equal(a.cpu(), g["above_pdf"])
     # the reference's own RNG protocol: a seeded CPU draw inside inverseSample
     torch.manual_seed(21)
     z2, _ = A.utils.inverseSample(dev(g["w"]), dev(g["z"]), 129, sort=True)
     assert torch.equal(z2, z)
+
+
+@pytest.mark.parametrize("C", [3, 5, 9, 10, 17, 34, 64, 130, 256])
+def test_inverse_sampling_indices_are_exact_for_every_row_length(A, C):
+    """The pdf-normaliser order has three regimes (rows < 8: scalar accumulators; whole vectors + tail; >= 4 vectors: 4-way
+    interleave); `below` must equal torch's searchsorted on the oracle's CDF in all of them."""
+    gen = torch.Generator().manual_seed(100 + C)
+    N, K = 53, 97
+    w = torch.rand(N, C, generator=gen) ** 3 + 0.01
+    z = torch.sort(NEAR + (FAR - NEAR) * torch.rand(N, C, generator=gen), dim=-1)[0]
+    u = torch.rand(N, K, generator=gen)
+    want_z, want_b = O.inverse_sample(w, z, u, sort=True)
+    got_z, got_b = A.utils.inverseSample(dev(w), dev(z), K, sort=True, u=u)
+    assert torch.equal(got_b.cpu(), want_b)
+    assert max_abs(got_z.cpu(), want_z) <= 2e-6
 
 
 def test_assembly(A, golden):
@@ -291,7 +328,13 @@ def test_render_rays_fp32_parity(A, tag, n, n_fine):
     assert torch.equal(z_c.cpu(), stages["z_coarse"])
     assert max_abs(w_prop.cpu(), stages["w_prop"]) <= 1e-5
     assert max_abs(z_f[:, :-1].cpu(), stages["z_fine"]) <= 2e-5
-    assert _below_mismatch(below.cpu(), stages["below"]) <= 0.01
+    # `below` (index work): equal to the reference's except where the GPU's own w_prop (expf / MLP bits) moved a CDF edge across u
+    if n_fine >= 63:                                          # (ascending bins: the sorted samples are in the order of their uniforms)
+        n_bad = _assert_below_explained(below, stages["below"], torch.sort(u2, dim=-1)[0], O.pdf_cdf(stages["w_prop"][:, 1:-1]),
+                                        O.pdf_cdf(w_prop.cpu()[:, 1:-1]), "resample")
+        assert n_bad <= 0.002 * below.numel()
+    else:
+        assert _below_mismatch(below.cpu(), stages["below"]) <= 0.01
 
 
 def test_render_rays_bf16_close(A):
@@ -504,8 +547,25 @@ def test_inverse_sampling_sort_paths(A, K, kind):
     want_z, want_b = O.inverse_sample(w, z, u, sort=True)
     got_z, got_b = A.utils.inverseSample(dev(w), dev(z), K, sort=True, u=u)
     assert bool((got_z[:, 1:] >= got_z[:, :-1]).all())
-    assert max_abs(got_z.cpu(), want_z) <= 1e-4          # irregular random bins up to 0.3 wide x eps(cdf)/pdf (see test_inverse_sampling)
-    assert _below_mismatch(got_b.cpu(), want_b) <= 0.01
+    assert max_abs(got_z.cpu(), want_z) <= 2e-6
+    if kind != "constant":
+        assert torch.equal(got_b.cpu(), want_b)
+    else:                                                     # all samples tie: any permutation of equal depths is a valid sort
+        assert torch.equal(torch.sort(got_b.cpu(), -1)[0], torch.sort(want_b, -1)[0])
+
+
+def test_inverse_sampling_with_unsorted_depths_sorts_the_values(A):
+    """inverseSample(sort=True) on depths that are NOT ascending (the reference's torch.sort does not care): the order of the samples
+    is then not the order of their uniforms, the kernel must detect it and sort the values."""
+    gen = torch.Generator().manual_seed(77)
+    N, C, K = 41, 64, 129
+    w = torch.rand(N, C, generator=gen) + 0.05
+    z = NEAR + (FAR - NEAR) * torch.rand(N, C, generator=gen)                 # unsorted bin edges
+    u = torch.rand(N, K, generator=gen)
+    want_z, _ = O.inverse_sample(w, z, u, sort=True)
+    got_z, _ = A.utils.inverseSample(dev(w), dev(z), K, sort=True, u=u)
+    assert bool((got_z[:, 1:] >= got_z[:, :-1]).all())
+    assert max_abs(got_z.cpu(), want_z) <= 2e-6
 
 
 # ------------------------------------------------------------------------------------------------ robustness
@@ -841,10 +901,16 @@ def test_refnerf_train_step_vs_reference_golden(A, golden):
     assert max_abs(dgrad.cpu(), g["density_grad"]) <= 2e-3 and max_abs(coarse_grad.cpu(), g["coarse_grad"]) <= 2e-3
     for name, val in (("normal_loss", nl), ("bf_loss", bf), ("coarse_normal_loss", cnl), ("img_loss", img), ("prop_loss", pl), ("loss", loss)):
         assert abs(val.item() - float(g[name])) <= 2e-4 * max(1.0, abs(float(g[name]))), name
-    for key, got in (("g_spa0", net.spa_block1[0].weight.grad[:8]), ("g_rho_tau", net.rho_tau_head.weight.grad), ("g_nct", net.norm_col_tint_head.weight.grad),
-                     ("g_bottle", net.bottle_neck.weight.grad[:8]), ("g_dir0", net.dir_block1[0].weight.grad[:8]), ("g_spec", net.spec_rgb_head[0].weight.grad),
-                     ("g_prop_l0", prop.layers[0].weight.grad[:8]), ("g_prop_head", prop.layers[8].weight.grad)):
-        assert max_abs(got.cpu(), g[key]) <= 2e-3 * max(1.0, g[key].abs().max().item()), key
+    # parameter gradients RELATIVE to each tensor's own size (they range from 1e-8 to 1e-3 with these weights, so an absolute gate
+    # would check nothing).  rho_tau_head and the last spa_block2 layer are where the gradient THROUGH THE WEIGHTS lands (normal /
+    # back-face losses on the un-detached weights, train.py:183-184): they fail if render's weights output is not differentiable.
+    for key, got, rel in (("g_rho_tau", net.rho_tau_head.weight.grad, 5e-3), ("g_rho_tau_bias", net.rho_tau_head.bias.grad, 5e-3),
+                          ("g_spa2_6", net.spa_block2[6].weight.grad[:8], 5e-3), ("g_nct", net.norm_col_tint_head.weight.grad, 5e-3),
+                          ("g_spec", net.spec_rgb_head[0].weight.grad, 5e-3), ("g_prop_head", prop.layers[8].weight.grad, 5e-3),
+                          ("g_bottle", net.bottle_neck.weight.grad[:8], 2e-2), ("g_dir0", net.dir_block1[0].weight.grad[:8], 2e-2),
+                          ("g_spa0", net.spa_block1[0].weight.grad[:8], 5e-2), ("g_prop_l0", prop.layers[0].weight.grad[:8], 5e-2)):
+        err, size = max_abs(got.cpu(), g[key]), g[key].abs().max().item()
+        assert err <= rel * size, "%s: |err| %.3e vs max|g| %.3e (rel %.2e > %.0e)" % (key, err, size, err / size, rel)
 
 
 def test_backward_kernels_full_size_linearity(A):
@@ -1137,3 +1203,145 @@ def test_render_rays_ref_fp32_parity_vs_oracle(A, n_fine):
     assert max_abs(rgb.cpu(), want_rgb) <= 1e-4
     assert max_abs(depth.cpu(), ex["depth_img"]) <= 1e-4
     assert max_abs(nimg.cpu(), ex["normal_img"]) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ row 12: integrated PE
+@pytest.mark.parametrize("name,L", [("g12_ipe", 6), ("g18_ipe_l10", 10)])
+def test_ipe_feature_vs_reference_golden(A, golden, name, L):
+    """nerf_amd_ipe_feature / nerf_amd_cone_parameters / nerf_amd_dirs_norm against the real reference's ipe_feature
+    (mip_methods.py:15-58), <= 1e-6 (features live in [-1, 1]; means and moments relative to their size)."""
+    g = golden(name)
+    r = 0.0015 if name == "g12_ipe" else g["radius"]
+    feat, mu, mu_t = A.mip_methods.ipe_feature(dev(g["z"]), dev(g["rays"]), L, r)
+    assert feat.shape == g["feat"].shape and mu.shape == g["mu"].shape and mu_t.shape == g["mu_t"].shape
+    assert max_abs(feat.cpu(), g["feat"]) <= 1e-6
+    assert max_abs(mu.cpu(), g["mu"]) <= 1e-6 * max(1.0, g["mu"].abs().max().item())
+    assert max_abs(mu_t.cpu(), g["mu_t"]) <= 1e-6 * max(1.0, g["mu_t"].abs().max().item())
+    if name == "g18_ipe_l10":
+        cp = A.mip_methods.coneParameters(dev(g["z"]), r)
+        assert torch.equal(cp[0].cpu(), mu_t.cpu())
+        assert max_abs(cp[1].cpu(), g["var_t"]) <= 1e-6 * g["var_t"].abs().max().item()
+        assert max_abs(cp[2].cpu(), g["var_r"]) <= 1e-6 * g["var_r"].abs().max().item()
+        assert abs(A.ops.dirs_norm(dev(g["rays"])).item() - g["dir_norm"]) <= 2e-7 * g["dir_norm"]
+
+
+def test_ipe_feature_ragged_and_empty(A):
+    gen = torch.Generator().manual_seed(4)
+    for N, S in ((1, 1), (3, 7), (257, 5), (2, 300)):
+        z = torch.sort(NEAR + (FAR - NEAR) * torch.rand(N, S + 1, generator=gen), -1)[0]
+        rays = torch.cat((torch.randn(N, 3, generator=gen), torch.randn(N, 3, generator=gen)), -1)
+        want = O.ipe_feature(z, rays, 10, 7e-4)
+        got = A.mip_methods.ipe_feature(dev(z), dev(rays), 10, 7e-4)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and max_abs(a.cpu(), b) <= 1e-6 * max(1.0, b.abs().max().item())
+    f, m, t = A.mip_methods.ipe_feature(torch.zeros(0, 9).cuda(), torch.zeros(0, 6).cuda(), 10, 1e-3)
+    assert f.shape == (0, 8, 60) and m.shape == (0, 8, 3) and t.shape == (0, 8)
+
+
+@pytest.mark.parametrize("tag,n,n_fine", [("small", 300, 128), ("he", 200, 128), ("small", 130, 64)])
+def test_render_rays_ipe_fp32_parity(A, tag, n, n_fine):
+    """BASELINE config 3 wiring (fine network on [mu | ipe_feature] of the frusta between consecutive fine depths; the build's own
+    definition of the loop, O.render_rays(ipe_radius=...)): the fused in-register IPE of mip_kernel<.., IPE> against the oracle on
+    identical rays and uniforms, <= 1e-4 abs on RGB / depth / weights."""
+    prop, mip = build_nets(A, tag)
+    rays, u1, u2 = _rays_and_u(n, n_fine, 23)
+    radius = 2.0 / math.sqrt(12.0) / 1111.0
+    with torch.no_grad():
+        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state(tag), W.mip_state(tag), rays, u1, u2, NEAR, FAR, n_fine,
+                                                     white_bkg=True, ipe_radius=radius)
+        plain_rgb, _, _ = O.render_rays(W.proposal_state(tag), W.mip_state(tag), rays, u1, u2, NEAR, FAR, n_fine, white_bkg=True)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    rgb, depth, w, _ = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2),
+                                         n_fine, NEAR, FAR, True, want_depth=True, want_weights=True, ipe_radius=radius)
+    tol = 1e-4 if tag == "small" else 5e-4
+    assert max_abs(rgb.cpu(), want_rgb) <= tol and max_abs(depth.cpu(), want_depth) <= tol and max_abs(w.cpu(), want_w) <= tol
+    assert max_abs(want_rgb, plain_rgb) > 10 * tol            # the encoding really changed the image (the test is not vacuous)
+    # the standalone entry points give the same fine-network input: mip_forward on the materialised [mu | ipe] is not available
+    # (the network builds its own encoding), so compare the kernel's fused encoding through a bf16 run of the same call instead
+    rgb16, _, _, _ = A.ops.render_rays(prop.packed(A.ops.BF16), mip.packed(A.ops.BF16), A.ops.BF16, dev(rays), z_base, dev(u1), dev(u2),
+                                       n_fine, NEAR, FAR, True, ipe_radius=radius)
+    assert torch.mean((rgb16.cpu() - want_rgb) ** 2).item() <= (1e-4 if tag == "small" else 2e-3)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_full_size_properties_ipe(A, prec):
+    """BASELINE config 3 at its size (Mip-NeRF with integrated PE, 800x800, 64+128; fp32 on a 200k-ray slab): scale-free properties
+    + an oracle spot check that uses the SAME whole-batch direction norm (mip_methods.py:31) as the full launch."""
+    prop, mip = build_nets(A, "small")
+    P = A.ops.F32 if prec == "fp32" else A.ops.BF16
+    H = Wd = 800
+    pose = O.pose_spherical(20.0, -30.0, 4.0)[:3]
+    f = O.fov2focal(0.6911112070083618, (H, Wd))
+    radius = 2.0 / math.sqrt(12.0) / float(f[1])
+    n = H * Wd if prec == "bf16" else 200_000
+    rays = A.ops.generate_rays(pose, H, Wd, f[1], f[0], "cuda", 0, n)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    u1 = torch.rand(n, 64, device="cuda", generator=gen)
+    u2 = torch.rand(n, 129, device="cuda", generator=gen)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    pk_p, pk_m = prop.packed(P), mip.packed(P)
+    rgb_w, depth, w, ws = A.ops.render_rays(pk_p, pk_m, P, rays, z_base, u1, u2, 128, NEAR, FAR, True, want_depth=True, want_weights=True,
+                                            ipe_radius=radius)
+    rgb_b, _, _, ws = A.ops.render_rays(pk_p, pk_m, P, rays, z_base, u1, u2, 128, NEAR, FAR, False, workspace=ws, ipe_radius=radius)
+    rgb_pe, _, _, ws = A.ops.render_rays(pk_p, pk_m, P, rays, z_base, u1, u2, 128, NEAR, FAR, True, workspace=ws)
+    acc = w.sum(-1)
+    assert bool(torch.isfinite(rgb_w).all()) and bool(torch.isfinite(depth).all())
+    assert float(acc.max()) <= 1.0 + 1e-4 and float(w.min()) >= 0.0
+    assert max_abs(rgb_w - rgb_b, (1.0 - acc)[:, None].expand(-1, 3)) <= 2e-6
+    assert float((rgb_w - rgb_pe).abs().max()) > 1e-3                                  # not the point-encoded image
+    dn = A.ops.dirs_norm(rays)
+    assert abs(dn.item() - rays[:, 3:].double().norm().item()) <= 1e-6 * dn.item()
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:192]
+    with torch.no_grad():
+        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), rays[pick].cpu(), u1[pick].cpu(),
+                                                     u2[pick].cpu(), NEAR, FAR, 128, white_bkg=True, ipe_radius=radius, ipe_dir_norm=dn.cpu()[0])
+    if prec == "fp32":
+        assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4 and max_abs(depth[pick].cpu(), want_depth) <= 1e-4
+        assert max_abs(w[pick].cpu(), want_w) <= 1e-4
+    else:
+        assert torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item() <= 1e-4
+
+
+def test_render_image_ipe_flag(A):
+    """Drop-in surface of config 3: render_image(..., ipe=True) = the reference's signature plus the flag; same tiling and RNG protocol."""
+    prop, mip = build_nets(A, "small")
+    A.pkg.set_precision("fp32")
+    pose = dev(O.pose_spherical(40.0, -30.0, 4.0)[:3])
+    f = O.fov2focal(0.6911112070083618, (100, 100))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        a = A.procedures.render_image(mip, prop, pose, 100, f, NEAR, FAR, 64, white_bkg=True, render_depth=True, ipe=True)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        b = A.procedures.render_image(mip, prop, pose, 100, f, NEAR, FAR, 64, white_bkg=True, render_depth=True)
+    assert list(a.keys()) == ["rgb", "depth_img"] and a["rgb"].shape == (3, 100, 100)
+    assert bool(torch.isfinite(a["rgb"]).all()) and float((a["rgb"] - b["rgb"]).abs().max()) > 1e-4
+    assert max_abs(a["depth_img"].cpu(), b["depth_img"].cpu()) <= 0.2          # same proposal pass, same sampling
+
+
+# ------------------------------------------------------------------------------------------------ weights are differentiable outputs of render
+def test_render_weights_carry_gradient(A):
+    """NeRF.render returns (rgb, weights, extras); the reference's Ref-NeRF step feeds the UN-detached weights into WeightedNormalLoss /
+    BackFaceLoss (train.py:183-184), so d(loss)/d(rgbo) has a path through them.  HIP backward (nerf_amd_composite_backward with
+    d_weights) against torch.autograd of the reference expression, for a loss that uses rgb only, weights only, and both."""
+    gen = torch.Generator().manual_seed(31)
+    N, S = 67, 96
+    rgbo0 = torch.cat((torch.rand(N, S, 3, generator=gen), torch.randn(N, S, 1, generator=gen) * 2), -1)
+    z = torch.sort(NEAR + (FAR - NEAR) * torch.rand(N, S, generator=gen), -1)[0]
+    d = F.normalize(torch.randn(N, 3, generator=gen), dim=-1) * 1.3
+    cw, cr = torch.rand(N, S, generator=gen), torch.rand(N, 3, generator=gen)
+    for use_rgb, use_w in ((True, False), (False, True), (True, True)):
+        ref = rgbo0.clone().requires_grad_(True)
+        rgb_r, w_r, _ = O.composite(ref, z, d, white_bkg=True)
+        ((rgb_r * cr).sum() * float(use_rgb) + (w_r * cw).sum() * float(use_w)).backward()
+        x = dev(rgbo0).requires_grad_(True)
+        rgb_g, w_g, _ = A.nerf_base.NeRF.render(x, dev(z), dev(d), white_bkg=True)
+        assert w_g.requires_grad
+        loss = 0.0
+        if use_rgb:
+            loss = loss + (rgb_g * dev(cr)).sum()
+        if use_w:
+            loss = loss + (w_g * dev(cw)).sum()
+        loss.backward()
+        scale = ref.grad.abs().max().item()
+        assert max_abs(x.grad.cpu(), ref.grad) <= 2e-5 * max(1.0, scale), (use_rgb, use_w)

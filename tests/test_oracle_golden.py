@@ -133,6 +133,26 @@ def test_g12_ipe(golden):
     assert max_abs(feat, g["feat"]) <= 1e-6 and max_abs(mu, g["mu"]) <= 1e-6 and max_abs(mu_t, g["mu_t"]) <= 1e-6
 
 
+def test_g18_ipe_at_network_size(golden):
+    """ipe_feature with L = 10 and coneParameters against the real reference (mip_methods.py:15-58), bit for bit."""
+    g = golden("g18_ipe_l10")
+    feat, mu, mu_t = O.ipe_feature(g["z"], g["rays"], 10, g["radius"])
+    assert torch.equal(feat, g["feat"]) and torch.equal(mu, g["mu"]) and torch.equal(mu_t, g["mu_t"])
+    cp = O.cone_parameters(g["z"], g["radius"])
+    assert torch.equal(cp[0], g["mu_t"]) and torch.equal(cp[1], g["var_t"]) and torch.equal(cp[2], g["var_r"])
+    assert float(g["rays"][:, 3:].norm()) == g["dir_norm"]
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 14, 30, 62, 63, 64, 127, 254, 255])
+def test_cascade_row_sum_is_torchs_cpu_summation_order(n):
+    """The HIP inverse-sampling kernels reproduce the ORDER of torch's CPU row sum for the pdf normaliser (utils.py:110-111) so that
+    every searchsorted decision matches the reference; O.cascade_row_sum restates that order -- here it is checked against
+    torch.sum itself, bit for bit, on the machine running the tests (the order is a property of the ATen build: 8-float vectors)."""
+    x = torch.rand(4000, n, generator=torch.Generator().manual_seed(n)) ** 2 + 1e-5
+    want = torch.sum(x, -1, keepdim=True)[:, 0].numpy()
+    assert (O.cascade_row_sum(x.numpy()) == want).all()
+
+
 def test_g14_train_step_forward_and_losses(golden):
     """Forward half of train.py:164-199 (non-ref): softplus'd proposal density, bounds, losses."""
     g1, g = golden("g01_raygen"), golden("g14_train_step")
