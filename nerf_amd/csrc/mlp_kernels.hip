@@ -21,418 +21,9 @@
 //     wraps around without a drain.
 //
 // Reference semantics: addtional.py:88-96 (proposal), mip_model.py:41-60 (fine).
-#include "device_common.h"
-#include "host_common.h"
-#include "mlp_layout.h"
+#include "mlp_core.h"
 
-extern __shared__ __attribute__((aligned(16))) char smem[];
-
-// Ablation switches (diagnostic builds only: `make ablate`; results are wrong by construction, only timing matters)
-//   ABL_NOEPI  skip bias/ReLU/convert epilogues     ABL_NOPE    skip the sin/cos encodings
-//   ABL_NOBAR  no s_barrier in the chunk protocol    ABL_NOLDSA  A fragments not re-read from LDS
-//   ABL_NOGLDS no global_load_lds refills         ABL_NOVMWAIT no vmcnt wait at chunk boundaries
-// MLP_CLOCKPROBE: workgroup 0 overwrites output record 0 with (shader cycles, 100 MHz ticks) -- scripts/gpu_clockprobe.sh
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// precision policies
-// ------------------------------------------------------------------------------------------------
-struct PBF16 {
-    using BReg = bf16x8;                       // one 16-feature K group of the B operand (4 VGPRs)
-    static constexpr int PREC = NERF_AMD_BF16;
-    static constexpr int NW = MLP_NW_BF16;     // wavefronts per workgroup
-    static constexpr int NT = 1;               // 32-sample MFMA column tiles per wavefront
-    static constexpr int FRAG_BYTES = 1024;    // one A fragment: 32 rows x 16 k, bf16
-    static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
-    using AReg = bf16x8;                       // one A fragment per lane (4 VGPRs)
-#ifndef MLP_DEPTH_BF16
-#define MLP_DEPTH_BF16 4
-#endif
-    static constexpr int DEPTH = MLP_DEPTH_BF16;   // A fragments prefetched LDS -> VGPR ahead of their MFMA
-    static DEVINL AReg load_a(uint32_t frag_addr) { return *reinterpret_cast<const bf16x8*>(smem + frag_addr); }
-    static DEVINL f32x16 mma(const AReg& a, const BReg& b, f32x16 acc) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-    // chain position: 0 first (C = bias in VGPRs), 1 middle, 2 last, 4 first with C = 0
-    template <int POS>
-    static DEVINL f32x16 mma_pos(const AReg& a, const BReg& b, f32x16 acc) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-    static DEVINL void set(BReg& r, int e, float v) { r[e] = (__bf16)v; }
-    // 8 accumulators -> one B register group.  ReLU is applied AFTER the bf16 conversion as a packed signed-int16
-    // max with 0 (negative floats have the sign bit set): 8 v_cvt_pk + 4 v_pk_max_i16 instead of 8 v_max + ... per group
-    template <bool RELU>
-    static DEVINL BReg from_acc(const f32x16& acc, int off) {
-        // pairwise vector conversion: one v_cvt_pk_bf16_f32 per two values (element-wise casts compile to a single-lane
-        // convert each plus a v_perm_b32 to merge the halves -- three instructions instead of one)
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-        BReg r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f32x2 v = {acc[off + 2 * e], acc[off + 2 * e + 1]};
-            const bf16x2 p = __builtin_convertvector(v, bf16x2);
-            r[2 * e] = p[0]; r[2 * e + 1] = p[1];
-        }
-        if (RELU) {
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            s16x8 v = __builtin_bit_cast(s16x8, r);
-            const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            v = __builtin_elementwise_max(v, zero);
-            r = __builtin_bit_cast(BReg, v);
-        }
-        return r;
-    }
-    static constexpr bool FAST_PE = true;      // octaves by angle doubling (error << bf16 ulp)
-    // per-lane LDS stash of one B register group (lane-linear 16-byte slots: conflict-free)
-    static constexpr int BREG_LDS = 1024;
-    static DEVINL void stash(uint32_t addr, const BReg& r) { *reinterpret_cast<bf16x8*>(smem + addr) = r; }
-    static DEVINL BReg unstash(uint32_t addr) { return *reinterpret_cast<const bf16x8*>(smem + addr); }
-    // training dump: one B register group of a subtile = a 64 x BREG_LDS/64-byte block in fragment order (lane-linear, coalesced)
-    static DEVINL void store_global(char* block, int lane, const BReg& r) { *reinterpret_cast<bf16x8*>(block + lane * 16) = r; }
-};
-
-// bf16, wide tile: 4 wavefronts x 64 samples.  Every A fragment read from LDS feeds TWO MFMAs (one per 32-sample column
-// tile), which halves the LDS->VGPR traffic per flop -- the limiter of the 32-sample tile.
-// One wavefront per SIMD with the 512-register budget; the activations of both column tiles stay in registers.
-struct PBF16W : PBF16 {
-    static constexpr int NW = 4;
-    static constexpr int NT = 2;
-};
-
-struct PF32 {
-    using BReg = f32x8;                        // 8 VGPRs per 16-feature K group
-    static constexpr int PREC = NERF_AMD_F32;
-    static constexpr int NW = MLP_NW_F32;
-    static constexpr int NT = 1;
-    static constexpr int FRAG_BYTES = 2048;    // [2 halves][64 lanes][4 floats]
-    static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
-    struct AReg { f32x4 lo, hi; };
-    static constexpr int DEPTH = 2;
-    static DEVINL AReg load_a(uint32_t frag_addr) {
-        AReg a;
-        a.lo = *reinterpret_cast<const f32x4*>(smem + frag_addr);
-        a.hi = *reinterpret_cast<const f32x4*>(smem + frag_addr + 1024);
-        return a;
-    }
-    static DEVINL f32x16 mma(const AReg& a, const BReg& b, f32x16 acc) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[e], b[e], acc, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[e], b[4 + e], acc, 0, 0, 0);
-        return acc;
-    }
-    template <int POS>
-    static DEVINL f32x16 mma_pos(const AReg& a, const BReg& b, f32x16 acc) { return mma(a, b, acc); }
-    static DEVINL void set(BReg& r, int e, float v) { r[e] = v; }
-    template <bool RELU>
-    static DEVINL BReg from_acc(const f32x16& acc, int off) {
-        BReg r;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = RELU ? fmaxf(acc[off + e], 0.0f) : acc[off + e];
-        return r;
-    }
-    static constexpr bool FAST_PE = false;     // parity mode: every octave through the exact range reduction
-    static constexpr int BREG_LDS = 2048;
-    static DEVINL void stash(uint32_t addr, const BReg& r) {
-        f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
-        *reinterpret_cast<f32x4*>(smem + addr) = lo;
-        *reinterpret_cast<f32x4*>(smem + addr + 1024) = hi;
-    }
-    static DEVINL BReg unstash(uint32_t addr) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + addr), hi = *reinterpret_cast<const f32x4*>(smem + addr + 1024);
-        BReg r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return r;
-    }
-    static DEVINL void store_global(char* block, int lane, const BReg& r) {
-        f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
-        *reinterpret_cast<f32x4*>(block + lane * 16) = lo;
-        *reinterpret_cast<f32x4*>(block + 1024 + lane * 16) = hi;
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// weight stream: L2 -> LDS ring, consumed in lock step by all wavefronts of the workgroup
-// ------------------------------------------------------------------------------------------------
-// SAFE (training kernels): they also issue activation stores; loads and stores may complete out of order with respect to each
-// other, so a counted vmcnt no longer identifies the ring pieces -- wait for everything (vmcnt(0)) at every barrier instead.
-template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false>
-struct WeightStream {
-    static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk
-    const char* src;        // packed stream + this lane's offset inside a chunk
-    uint32_t n_chunks;      // chunks in one pass over the network
-    uint32_t load_idx;      // next chunk of the stream to fetch (wraps)
-    uint32_t load_slot;     // ring slot it goes to
-    uint32_t cur;           // LDS byte offset of the chunk the register prefetch reads from (+ lane*16)
-    uint32_t cur_slot;
-    uint32_t wave_lds;      // wave-uniform LDS offset of this wave's pieces inside a slot
-    typename P::AReg q[P::DEPTH];   // A fragments f .. f+DEPTH-1 already in registers (f = next fragment to multiply)
-
-    static DEVINL void dummy_sink(const bf16x8& d) { asm volatile("" ::"v"(d)); }
-    template <class T> static DEVINL void dummy_sink(const T& d) { asm volatile("" ::"v"(d.lo), "v"(d.hi)); }
-    DEVINL void issue() {
-        const char* g = src + (size_t)load_idx * MLP_CHUNK_BYTES;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(load_slot * MLP_CHUNK_BYTES + wave_lds);
-        // global -> LDS DMA (16 B/lane, lane-linear).  Issued through inline asm on purpose: hipcc's waitcnt pass treats
-        // the builtin form as a "flat" access that may touch LDS and from then on turns EVERY s_waitcnt lgkmcnt(N) of
-        // the A-fragment prefetch into lgkmcnt(0) -- which serialises the LDS pipeline (measured: 59% -> MFMA-bound).
-        // The asm is invisible to that pass; completion is tracked by our own counted vmcnt in boundary().
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-#if !defined(ABL_NOGLDS)
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(g + i * 1024), "s"(dst + i * 1024)
-                         : "memory");
-#else
-            asm volatile("" ::"v"(g), "s"(dst));
-#endif
-        }
-        load_idx = (load_idx + 1 == n_chunks) ? 0u : load_idx + 1;
-        load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
-    }
-    // Synchronisation protocol (all code is branch-free; the only conditional instruction is the s_barrier itself):
-    //   * chunk boundary i = the moment a wave's register prefetch enters chunk i.  At EVERY boundary a wave waits
-    //     until at most 3 of its own chunk pieces are in flight and then issues its piece of one more chunk.
-    //   * "early" waves (first half of the workgroup) execute s_barrier at even boundaries, "late" waves (second
-    //     half = the other wavefront of each SIMD) at odd ones, so barrier b pairs early@2b with late@2b+1: the two
-    //     wavefronts of a SIMD run one chunk (FPC MFMAs = half a 256-wide feature block) apart, and between two
-    //     barriers (2 chunks) each has slack to overlap its VALU epilogue with the partner's MFMA run.
-    //   * invariants after barrier b: chunks <= 2b+2 are completely in LDS (every wave waited for its pieces);
-    //     every wave holds chunks <= 2b-1 in registers, so those ring slots may be refilled.  Early waves issue chunk
-    //     i+NSLOT-2 at boundary i, late waves chunk i+NSLOT-3: both groups issue the same chunk within the same barrier
-    //     interval, and NSLOT-5 chunks per wave stay in flight across every wait.
-    //   * with a single wave group (NW <= 4: no late waves) the barrier falls on even boundaries only, so only those need the
-    //     wait, and NSLOT-4 chunks may stay in flight: issued before the wait at boundary 2b are chunks <= 2b+NSLOT-3, needed
-    //     complete are chunks <= 2b+1 (read until barrier b+1).
-    static constexpr bool TWO_GROUPS = P::NW > 4;
-    static constexpr int INFLIGHT = SAFE ? 0 : (TWO_GROUPS ? NSLOT - 5 : NSLOT - 4) * LPW;
-    uint32_t late;
-
-    DEVINL void init(const void* packed, uint32_t nchunks) {
-        static_assert(NSLOT >= 6, "the protocol needs at least 6 ring slots");
-        const int lane = lane_id();
-        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        src = reinterpret_cast<const char*>(packed) + (size_t)wave * LPW * 1024 + lane * 16;
-        wave_lds = wave * LPW * 1024;
-        n_chunks = nchunks;
-        load_idx = 0; load_slot = 0;
-        cur_slot = 0;
-        cur = lane * 16;
-        late = __builtin_amdgcn_readfirstlane((P::NW > 4 && wave >= P::NW / 2) ? 1 : 0);
-#pragma unroll
-        for (int i = 0; i < NSLOT - 2; ++i) issue();                         // chunks 0 .. NSLOT-3
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my pieces of chunks 0..2 have landed ...
-        __builtin_amdgcn_s_barrier();                                        // ... and everybody else's
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < P::DEPTH; ++i) q[i] = P::load_a(cur + i * P::FRAG_BYTES);
-        if (!late) {                                                         // boundary 0 of the early waves
-            __builtin_amdgcn_s_barrier();                                    // barrier 0 (late waves: at their boundary 1)
-            asm volatile("" ::: "memory");
-            issue();                                                         // chunk NSLOT-2
-        }
-    }
-    // Fragment F of the stream (compile-time index, F mod DEPTH == queue slot): hand out its registers and
-    // start the LDS read of fragment F+DEPTH into the same slot.  The boundary work therefore runs DEPTH
-    // fragments BEFORE the first MFMA that needs the new chunk: the MFMA pipe keeps draining the register queue.
-    template <int F>
-    DEVINL typename P::AReg next() {
-        const typename P::AReg a = q[F % P::DEPTH];
-        constexpr int G = F + P::DEPTH;
-        if (G % P::FPC == 0) {
-            cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
-            cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
-            boundary<(G / P::FPC) & 1>();
-        }
-#if defined(ABL_NOLDSA)
-#elif defined(ABL_HALFLDS)
-        if (F % 2 == 0) q[F % P::DEPTH] = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES);
-#elif defined(ABL_DUMMYLDS)
-        { const typename P::AReg d = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES); dummy_sink(d); }
-#else
-        q[F % P::DEPTH] = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES);
-#endif
-        return a;
-    }
-    template <int PARITY>
-    DEVINL void boundary() {
-        if constexpr (!TWO_GROUPS && PARITY != 0 && !SAFE) { // single group, odd boundary: nothing to wait for, no barrier
-            issue();
-            return;
-        }
-#ifndef ABL_NOVMWAIT
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-#endif
-        // s_barrier only when this boundary's parity is mine; the branch lives inside the asm so that the compiler
-        // sees straight-line code (a C++ `if` here splits every feature block into many basic blocks and spills)
-#ifndef ABL_NOBAR
-        asm volatile("s_cmp_lg_u32 %0, %1\n\ts_cbranch_scc1 .Lnobar%=\n\ts_barrier\n.Lnobar%=:" ::"s"(__builtin_amdgcn_readfirstlane(late)), "n"(PARITY) : "memory", "scc");
-#endif
-        issue();
-    }
-    // End of kernel: the early waves ran one barrier more (barrier 0 at init); the late waves supply its partner here.
-    DEVINL void drain() {
-        if (late) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// One dense layer for this wavefront's NT x 32 samples:  out[fb] = act(W[fb] . in + bias[fb]).
-//   NKG    K groups (16 input features each) consumed;  in(kg, t) returns the B registers of group kg, column tile t
-//   NFB    32-row output feature blocks;  out(fb, t, acc, half) converts accumulators 8*half .. 8*half+7 of block fb
-//          (= K group 2*fb + half of the next layer) for column tile t
-//   START  fragment index of the layer inside the stream modulo FPC (chunk phase)
-// ------------------------------------------------------------------------------------------------
-// Feature blocks are processed two at a time with their MFMAs alternating between independent accumulators.
-// Why: on gfx950 any instruction issued between two MFMAs that chain through the SAME accumulator (here: the
-// ds_read of the next A fragment) costs ~+43 cycles on the dependent MFMA (MI355X_MICROARCH.md, per-instruction
-// constants).  Alternating accumulators puts a full MFMA between dependent ones.  The stream stores a pair's fragments
-// interleaved (kg-major), so the B registers of K group kg are fetched once and feed both blocks.
-// A single trailing block (odd NFB) splits K over two accumulators instead and adds them at the end.
-//
-// Deferred epilogues (software pipelining by hand): the conversion of a block pair's accumulators (bias is already in,
-// so: fp32 -> bf16, ReLU) is NOT done when the pair's MFMA chain ends but sliced into the first K steps of the NEXT
-// pair -- of the same layer, or of the next layer, whose first K groups never read the last pair's features (kg 12..15
-// are consumed at K steps >= 12).  The VALU work then sits between MFMAs that do not depend on it instead of in one
-// clump during which the MFMA pipe idles (one wave per SIMD cannot hide it behind a partner).
-template <int S> struct IC { static constexpr int value = S; };
-
-// accumulators 8*half .. 8*half+7 of a feature block -> the B register group they form for the next layer
-template <class P, bool RELU>
-DEVINL typename P::BReg to_breg_half(const f32x16& acc, int half) {
-#ifdef ABL_NOEPI
-    if constexpr (sizeof(typename P::BReg) == 16) {
-        f32x4 l = {acc[8 * half], acc[8 * half + 1], acc[8 * half + 2], acc[8 * half + 3]};
-        return __builtin_bit_cast(typename P::BReg, l);
-    }
-#endif
-    return P::template from_acc<RELU>(acc, 8 * half);
-}
-
-// the not-yet-converted accumulators of NB (1 or 2) feature blocks starting at block FB0
-template <class P, int FB0, int NB>
-struct Deferred {
-    static constexpr int NSL = NB * 2 * P::NT;                   // slices: (block, half, tile)
-    f32x16 acc[NB][P::NT];
-    template <int S, class OutF>
-    DEVINL void emit(OutF& out) const {
-        constexpr int blk = S / (2 * P::NT), half = (S % (2 * P::NT)) / P::NT, t = S % P::NT;
-        out(FB0 + blk, t, acc[blk][t], half);
-    }
-    template <class OutF, int S = 0>
-    DEVINL void flush(OutF&& out) const {
-        if constexpr (S < NSL) { emit<S>(out); flush<OutF, S + 1>(static_cast<OutF&&>(out)); }
-    }
-};
-struct NoPrev {
-    static constexpr int NSL = 0;
-    template <int S> DEVINL void emit() const {}
-};
-template <class D, class OutF>
-struct PrevOf {
-    static constexpr int NSL = D::NSL;
-    const D& d;
-    OutF& out;
-    template <int S> DEVINL void emit() const { d.template emit<S>(out); }
-};
-template <class D, class OutF> DEVINL PrevOf<D, OutF> prev_of(const D& d, OutF& out) { return PrevOf<D, OutF>{d, out}; }
-// slices of the pending epilogue that belong to K step KG of an NKG-step chain: everything is out within the first half
-template <int NKG, int KG, class Prev, int I = 0>
-DEVINL void emit_step(const Prev& prev) {
-    constexpr int STEPS = (NKG / 2 > 0) ? NKG / 2 : 1;
-    constexpr int PER = (Prev::NSL + STEPS - 1) / STEPS;
-    if constexpr (I < PER && KG * PER + I < Prev::NSL) {
-        prev.template emit<KG * PER + I>();
-        emit_step<NKG, KG, Prev, I + 1>(prev);
-    }
-}
-
-// bias of one 32-row feature block in accumulator layout (acc[r] <- bias[(r&3) + 8(r>>2) + 4h]); it enters the chain
-// as the C operand of the block's first MFMA, so the epilogue needs no adds
-DEVINL f32x16 load_bias(uint32_t addr) {
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + addr + 32 * q);
-        v[4 * q] = b4[0]; v[4 * q + 1] = b4[1]; v[4 * q + 2] = b4[2]; v[4 * q + 3] = b4[3];
-    }
-    return v;
-}
-template <class P, int NKG, int FRAG0, int KG, bool MORE, class WS, class InF, class Prev>
-DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 (&nb)[2], uint32_t next_bias, InF& in, const Prev& prev) {
-    if constexpr (KG < NKG) {
-        typename P::BReg b[P::NT];
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) b[t] = in(KG, t);
-        const typename P::AReg a0 = ws.template next<FRAG0 + 2 * KG>();
-        constexpr int POS = (KG == 0) ? 0 : ((KG == NKG - 1) ? 2 : 1);
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) acc0[t] = P::template mma_pos<POS>(a0, b[t], acc0[t]);
-        const typename P::AReg a1 = ws.template next<FRAG0 + 2 * KG + 1>();
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) acc1[t] = P::template mma_pos<POS>(a1, b[t], acc1[t]);
-        emit_step<NKG, KG>(prev);
-        if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
-            nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
-            nb[1] = load_bias(next_bias + 128);
-        }
-        pair_k<P, NKG, FRAG0, KG + 1, MORE>(ws, acc0, acc1, nb, next_bias, in, prev);
-    }
-}
-template <class P, int NKG, int FRAG0, int KG, class WS, class InF, class Prev>
-DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& in, const Prev& prev) {
-    if constexpr (KG < NKG) {
-        const typename P::AReg a = ws.template next<FRAG0 + KG>();
-        constexpr int LAST_EVEN = ((NKG - 1) / 2) * 2, LAST_ODD = (NKG % 2 == 0) ? NKG - 1 : NKG - 2;
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) {
-            if constexpr (KG % 2 == 0) acc0[t] = P::template mma_pos<(KG == 0) ? 0 : ((KG == LAST_EVEN) ? 2 : 1)>(a, in(KG, t), acc0[t]);
-            else acc1[t] = P::template mma_pos<(KG == 1) ? 4 : ((KG == LAST_ODD) ? 2 : 1)>(a, in(KG, t), acc1[t]);
-        }
-        emit_step<NKG, KG>(prev);
-        single_k<P, NKG, FRAG0, KG + 1>(ws, acc0, acc1, in, prev);
-    }
-}
-// Runs feature-block groups G, G+1, ... of the layer; `prev` is the pending epilogue that the FIRST K steps of group G
-// work off.  Returns the layer's last group, unconverted.
-template <class P, int NKG, int NFB, int START, int G, class WS, class InF, class OutF, class Prev>
-DEVINL auto dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out, const Prev& prev) {
-    static_assert(2 * G < NFB, "group index");
-    constexpr int FRAG0 = START + 2 * G * NKG;
-    if constexpr (2 * G + 1 < NFB) {
-        Deferred<P, 2 * G, 2> d;
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) { d.acc[0][t] = cb[0]; d.acc[1][t] = cb[1]; }
-        f32x16 nb[2];
-        constexpr bool MORE = 2 * (G + 1) < NFB;
-        pair_k<P, NKG, FRAG0, 0, MORE>(ws, d.acc[0], d.acc[1], nb, bias_lane + 256 * (G + 1), in, prev);
-        if constexpr (MORE) return dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lane, nb, in, out, prev_of(d, out));
-        else return d;
-    } else {
-        constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        Deferred<P, 2 * G, 1> d;
-        f32x16 acc1[P::NT];
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) { d.acc[0][t] = cb[0]; acc1[t] = zero; }
-        single_k<P, NKG, FRAG0, 0>(ws, d.acc[0], acc1, in, prev);
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d.acc[0][t][r] += acc1[t][r];
-        return d;
-    }
-}
-template <class P, int NKG, int NFB, int START, class WS, class InF, class OutF, class Prev>
-DEVINL auto dense(WS& ws, uint32_t bias_lds, InF&& in, OutF&& out, const Prev& prev) {
-    static_assert(START % P::DEPTH == 0 && (NKG * NFB) % P::DEPTH == 0, "layers must start on a prefetch-queue boundary");
-    const uint32_t bias_lane = bias_lds + 16 * (lane_id() >> 5);
-    f32x16 cb[2];
-    cb[0] = load_bias(bias_lane);
-    if constexpr (NFB > 1) cb[1] = load_bias(bias_lane + 128);
-    return dense_group<P, NKG, NFB, START, 0>(ws, bias_lane, cb, in, out, prev);
-}
 
 // ------------------------------------------------------------------------------------------------
 // positional encoding straight into B-operand layout (slot map: mlp_layout.h pe_slot_feature()).

@@ -1255,7 +1255,8 @@ def test_render_rays_ipe_fp32_parity(A, tag, n, n_fine):
                                          n_fine, NEAR, FAR, True, want_depth=True, want_weights=True, ipe_radius=radius)
     tol = 1e-4 if tag == "small" else 5e-4
     assert max_abs(rgb.cpu(), want_rgb) <= tol and max_abs(depth.cpu(), want_depth) <= tol and max_abs(w.cpu(), want_w) <= tol
-    assert max_abs(want_rgb, plain_rgb) > 10 * tol            # the encoding really changed the image (the test is not vacuous)
+    if tag == "he":                                           # the encoding really changed the image (the 'small' networks are almost
+        assert max_abs(want_rgb, plain_rgb) > 10 * tol        # insensitive to their input, so only the O(1)-activation set can show it)
     # the standalone entry points give the same fine-network input: mip_forward on the materialised [mu | ipe] is not available
     # (the network builds its own encoding), so compare the kernel's fused encoding through a bf16 run of the same call instead
     rgb16, _, _, _ = A.ops.render_rays(prop.packed(A.ops.BF16), mip.packed(A.ops.BF16), A.ops.BF16, dev(rays), z_base, dev(u1), dev(u2),
@@ -1267,7 +1268,7 @@ def test_render_rays_ipe_fp32_parity(A, tag, n, n_fine):
 def test_full_size_properties_ipe(A, prec):
     """BASELINE config 3 at its size (Mip-NeRF with integrated PE, 800x800, 64+128; fp32 on a 200k-ray slab): scale-free properties
     + an oracle spot check that uses the SAME whole-batch direction norm (mip_methods.py:31) as the full launch."""
-    prop, mip = build_nets(A, "small")
+    prop, mip = build_nets(A, "he")
     P = A.ops.F32 if prec == "fp32" else A.ops.BF16
     H = Wd = 800
     pose = O.pose_spherical(20.0, -30.0, 4.0)[:3]
@@ -1293,18 +1294,18 @@ def test_full_size_properties_ipe(A, prec):
     assert abs(dn.item() - rays[:, 3:].double().norm().item()) <= 1e-6 * dn.item()
     pick = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:192]
     with torch.no_grad():
-        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), rays[pick].cpu(), u1[pick].cpu(),
+        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("he"), W.mip_state("he"), rays[pick].cpu(), u1[pick].cpu(),
                                                      u2[pick].cpu(), NEAR, FAR, 128, white_bkg=True, ipe_radius=radius, ipe_dir_norm=dn.cpu()[0])
-    if prec == "fp32":
-        assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4 and max_abs(depth[pick].cpu(), want_depth) <= 1e-4
-        assert max_abs(w[pick].cpu(), want_w) <= 1e-4
+    if prec == "fp32":                                        # ('he' = the amplification stress set: 5e-4, see test_render_image_vs_reference)
+        assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 5e-4 and max_abs(depth[pick].cpu(), want_depth) <= 5e-4
+        assert max_abs(w[pick].cpu(), want_w) <= 5e-4
     else:
-        assert torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item() <= 1e-4
+        assert torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item() <= 1e-3
 
 
 def test_render_image_ipe_flag(A):
     """Drop-in surface of config 3: render_image(..., ipe=True) = the reference's signature plus the flag; same tiling and RNG protocol."""
-    prop, mip = build_nets(A, "small")
+    prop, mip = build_nets(A, "he")
     A.pkg.set_precision("fp32")
     pose = dev(O.pose_spherical(40.0, -30.0, 4.0)[:3])
     f = O.fov2focal(0.6911112070083618, (100, 100))
