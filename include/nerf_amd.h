@@ -217,8 +217,9 @@ int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, in
  * addition every hidden layer's post-ReLU activations are written to `dump` (nerf_amd_train_dump_bytes bytes, device) in the
  * kernels' fragment order.  nerf_amd_train_dump_to_rows turns one layer of a dump into a row-major (M, n_features) matrix
  * (bf16 for NERF_AMD_BF16, fp32 for NERF_AMD_F32) for the dgrad / wgrad GEMMs.
- * Layers: proposal 0..3 = layers.{0,2,4,6} outputs (256 wide); MipNeRF 0..3 = lin_block1.{0,2,4,6}, 4..6 = lin_block2.{0,2,4}
- * (256 wide), 7 = rgb_layer.0 output (128 wide).
+ * Layers: proposal 0..3 = layers.{0,2,4,6} outputs (256 wide), 4 = the input encoding [x | PE10(x)] in the kernels' slot order;
+ * MipNeRF 0..3 = lin_block1.{0,2,4,6}, 4..6 = lin_block2.{0,2,4} (256 wide), 7 = rgb_layer.0 output (128 wide), 8 = the position and
+ * direction encodings in slot order (operands of the first-layer / skip-layer / colour-head weight gradients).
  * ------------------------------------------------------------------------------------------------ */
 size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M);
 int nerf_amd_proposal_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* dump,
@@ -246,6 +247,37 @@ int nerf_amd_train_dump_rows_mask(const void* dump, int net, int precision, int6
  * with 3 + 6L columns rounded up to a multiple of 8, bf16 (NERF_AMD_BF16) or fp32 rows.  x (M, >=3) with row stride x_stride floats;
  * normalize != 0 divides x by its norm first (the view direction, mip_model.py:52).  L = 4 or 10. */
 int nerf_amd_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize, int precision, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the two MLPs (what torch.autograd computes for addtional.py:88-96 / mip_model.py:41-60 inside train.py:164-199, and the
+ * optimizer step of train.py:117-118,200-218) as hand-written kernels -- no library GEMM:
+ *   1. nerf_amd_pack_weights_backward: the TRANSPOSED weights in the kernels' fragment order (re-pack after every optimizer step,
+ *      like the forward blob; `weights` in the same order as nerf_amd_pack_weights);
+ *   2. nerf_amd_{proposal,mip}_backward_chain: the dgrad chain.  Inputs: the gradient w.r.t. the network output (g_density (M) /
+ *      g_rgbo (M,4) together with the forward output rgbo (M,4) for the sigmoid adjoint) and the activation dump of the training
+ *      forward; output: the "delta dump" (same size and fragment order as the activation dump: nerf_amd_train_dump_bytes);
+ *   3. nerf_amd_{proposal,mip}_weight_grads: delta^T . activations on the matrix cores, written as (out, in) row-major fp32 tensors
+ *      in the networks' tensor order (d_weights / d_biases: HOST arrays of DEVICE pointers, every tensor fully overwritten);
+ *      workspace: nerf_amd_weight_grads_workspace_bytes bytes of device scratch.  Deterministic (no atomics).
+ *   4. nerf_amd_adam_step: torch.optim.Adam (no weight decay, no amsgrad) over a table of tensors; `step` is a DEVICE float holding
+ *      the number of steps taken so far (incremented by the call, so that a captured graph replays correctly); grads are multiplied
+ *      by grad_scale first (1 = plain; 1/world_size after a summing all-reduce).
+ * Gradients w.r.t. the sample positions are not produced (the reference detaches them for these two networks).
+ * ------------------------------------------------------------------------------------------------ */
+size_t nerf_amd_packed_backward_bytes(int net, int precision);
+int    nerf_amd_pack_weights_backward(int net, int precision, const float* const* weights, int n_tensors, void* packed_bwd, void* stream);
+int    nerf_amd_proposal_backward_chain(const void* packed_bwd, int precision, const float* g_density, int64_t M, const void* act_dump,
+                                        void* delta_dump, void* stream);
+int    nerf_amd_mip_backward_chain(const void* packed_bwd, int precision, const float* g_rgbo, const float* rgbo, int64_t M,
+                                   const void* act_dump, void* delta_dump, void* stream);
+size_t nerf_amd_weight_grads_workspace_bytes(int net, int precision, int64_t M);
+int    nerf_amd_proposal_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, float* const* d_weights,
+                                      float* const* d_biases, void* workspace, void* stream);
+int    nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* weights,
+                                 const float* const* biases, float* const* d_weights, float* const* d_biases, void* workspace, void* stream);
+int    nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                          const int64_t* numel, int n_tensors, float* step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).

@@ -72,6 +72,16 @@ SIGNATURES = {
     "nerf_amd_relu_mask": (C.c_int, [c_void, c_void, C.c_int, i64, c_void]),
     "nerf_amd_relu_mask_bias_partials": (i64, [C.c_int, i64, C.c_int]),
     "nerf_amd_relu_mask_bias": (C.c_int, [c_void, c_void, C.c_int, i64, C.c_int, c_void, c_void]),
+    "nerf_amd_packed_backward_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "nerf_amd_pack_weights_backward": (C.c_int, [C.c_int, C.c_int, C.POINTER(c_void), C.c_int, c_void, c_void]),
+    "nerf_amd_proposal_backward_chain": (C.c_int, [c_void, C.c_int, c_void, i64, c_void, c_void, c_void]),
+    "nerf_amd_mip_backward_chain": (C.c_int, [c_void, C.c_int, c_void, c_void, i64, c_void, c_void, c_void]),
+    "nerf_amd_weight_grads_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, i64]),
+    "nerf_amd_proposal_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), c_void, c_void]),
+    "nerf_amd_mip_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void),
+                                           C.POINTER(c_void), c_void, c_void]),
+    "nerf_amd_adam_step": (C.c_int, [C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(i64), C.c_int, c_void,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_void]),
     "nerf_amd_sigma_to_weights_backward": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_composite_backward": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_float, c_void, c_void, c_void, c_void, c_void]),

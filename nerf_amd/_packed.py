@@ -28,6 +28,11 @@ class PackedWeightsMixin:
         layers = self._linear_layers()
         return ops.pack_weights(self._net_id, precision, [l.weight for l in layers], [l.bias for l in layers])
 
+    def packed_backward(self, precision: int) -> torch.Tensor:
+        """The transposed weights for the dgrad chain (nerf_amd_pack_weights_backward); packed when asked for -- the backward runs once
+        per training step, after which the weights change anyway."""
+        return ops.pack_weights_backward(self._net_id, precision, [l.weight for l in self._linear_layers()])
+
     def _packed_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 

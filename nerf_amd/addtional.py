@@ -107,7 +107,8 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
             def bwd(g, p, *wb):
                 if "dump" not in held:
                     raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
-                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5])
+                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5],
+                                                        packed_bwd=self.packed_backward(prec))
                 return (None, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts)

@@ -1,0 +1,762 @@
+// Backward of the two MLPs as hand-written gfx950 kernels (second stage): no library GEMM is involved.
+//
+//   1. dgrad chain  (prop_bwd_kernel / mip_bwd_kernel): the forward machinery of mlp_core.h run on TRANSPOSED packed weights
+//      (mlp_layout.h *BwdLayout).  delta stays in registers from the heads down to the first hidden layer exactly like the
+//      activations do in the forward: D[input feature][sample] = W^T . delta with A = weight fragments streamed through the LDS
+//      ring and B = delta in registers; the epilogue between two layers is the ReLU adjoint delta *= [y > 0], with y taken from
+//      the training forward's activation dump.  The mask blocks (1 KiB per 16 features x 32 samples: the dump's fragment order IS
+//      the B-operand layout, so masking is element-wise on registers) are LDS-DMA'd one feature-block pair ahead into a per-wave
+//      double buffer -- no VGPRs, no compiler-visible loads inside the MFMA stream.  Every layer's delta is written to HBM in
+//      the same fragment order (the "delta dump"): that is the operand of the weight gradients.
+//      HBM traffic per sample and 256-wide layer: 512 B of mask reads + 512 B of delta writes (bf16).
+//   2. wgrad (wgrad_kernel_bf16 / wgrad_kernel_f32): dW = delta^T . y contracts over SAMPLES, while both dumps hold samples along the
+//      lanes (lane = sample, registers = features).  The transposition is done by the matrix cores themselves: used as the A operand
+//      of a 32x32x16 MFMA against a constant 0/1 selection matrix, a fragment block comes out with lane = feature and registers =
+//      samples -- exactly the A / B operand layout of the contraction over samples (any sample permutation is fine as long as
+//      delta and y use the same one, and they do).  +12.5 % MFMAs, zero LDS traffic, no cross-wave exchange: every wave owns a
+//      rectangle of at most 16 32x32 output blocks (256 accumulator registers), streams the K groups of delta and y it needs straight
+//      from L2/HBM (16-byte coalesced loads, next subtile in flight while the current one is multiplied) and keeps its partial dW in
+//      registers over its whole sample range.  Workgroup partials go to HBM once; wgrad_finalize_kernel sums them in a fixed order
+//      (no atomics: a training run is bit-reproducible) straight into the reference's (out, in) layout.  Bias gradients are the row
+//      sums of the transposed delta blocks, accumulated on the side.
+//      HBM-bound by design: 1 KiB per sample and 256x256 layer against 131 kFLOP -> ~0.65 PFLOP/s at 5 TB/s.
+//   3. mip_fold_grads_kernel: bottle_neck.0 is folded into rgb_layer.0 by the forward (mlp_layout.h), so their gradients are recovered
+//      from the one data-dependent product G = dc^T . g6 by parameter-space algebra.
+//   4. adam_kernel: Adam (torch.optim.Adam semantics, train.py:117-118) over all parameters of both networks in one launch.
+//
+// Reference semantics: what torch.autograd computes for addtional.py:88-96 and mip_model.py:41-60 (train.py:164-218).
+#include "mlp_core.h"
+
+namespace {
+
+#ifdef MLP_BF16_NARROW
+using PB16 = PBF16;
+#else
+using PB16 = PBF16W;
+#endif
+
+struct Dump {               // a fragment-ordered dump: slot l, subtile s, K group kg -> base + l*layer_stride + (s*16 + kg) * BREG_LDS
+    char* base;
+    unsigned long long layer_stride;
+};
+
+// one 1 KiB global -> LDS DMA piece (16 B per lane, lane-linear); `lds_dst` must be wave-uniform (see WeightStream::issue for why asm)
+DEVINL void glds_piece(const char* gptr, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gptr), "s"(lds_dst)
+                 : "memory");
+}
+
+// delta *= [y > 0] on one B register group.  y is a post-ReLU activation: non-negative, +0 exactly where the unit was off.
+DEVINL bf16x8 relu_mask(const bf16x8& d, const bf16x8& y) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    const u16x8 one = {1, 1, 1, 1, 1, 1, 1, 1};
+    const u16x8 on = __builtin_elementwise_min(__builtin_bit_cast(u16x8, y), one);      // 0 / 1 per element (packed min)
+    return __builtin_bit_cast(bf16x8, (u16x8)(__builtin_bit_cast(u16x8, d) * on));        // packed 16-bit multiply
+}
+DEVINL f32x8 relu_mask(const f32x8& d, const f32x8& y) {
+    f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = y[e] > 0.0f ? d[e] : 0.0f;
+    return r;
+}
+
+constexpr uint32_t BWD_LDS_ZERO = MLP_RING_BYTES;                    // 1 KiB of zeros: the "bias" of every chain layer
+constexpr uint32_t BWD_LDS_MASK = MLP_RING_BYTES + 1024;
+template <class P> constexpr uint32_t bwd_pair_bytes() { return 4 * P::NT * P::BREG_LDS; }          // (2 blocks x 2 halves x NT tiles) mask groups
+template <class P> constexpr uint32_t bwd_lds_total() { return BWD_LDS_MASK + P::NW * 2 * bwd_pair_bytes<P>(); }
+
+// How many weight-ring pieces a wave is guaranteed to have issued AFTER the mask DMA of a feature-block pair of an NKG-step layer by
+// the time the next pair starts: one chunk boundary per FPC fragments, LPW pieces per boundary.  VMEM loads return in order, so
+// `s_waitcnt vmcnt(that many)` proves the masks have landed (stores in flight can only make the wait stricter, never weaker).
+template <class P> constexpr int mask_wait_count(int nkg) { return ((MLP_CHUNK_BYTES / 1024) / P::NW) * ((2 * nkg) / P::FPC); }
+template <int N> DEVINL void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Output functor of a chain layer with NKG_CUR K steps whose predecessor in the stream had NKG_PREV: convert, mask by the forward
+// activations of `layer`, keep in registers, dump.
+template <class P, int NKG_CUR, int NKG_PREV>
+struct MaskedOut {
+    typename P::BReg (&buf)[P::NT][16];
+    Dump act, dlt;
+    int layer;
+    int64_t sub0;
+    int lane;
+    uint32_t mask_lds;          // this wave's two pair buffers (wave-uniform byte offset)
+
+    // start of feature-block pair G: the previous pair's masks (consumed from now on by its deferred epilogue) must have landed; then
+    // this pair's masks start their way into the other buffer
+    DEVINL void begin_group(int G) const {
+        if (G == 0) vm_wait<mask_wait_count<P>(NKG_PREV)>(); else vm_wait<mask_wait_count<P>(NKG_CUR)>();
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int t = 0; t < P::NT; ++t) {
+                    const int kg = 2 * (2 * G + blk) + half;
+                    const char* src = act.base + (size_t)layer * act.layer_stride + ((size_t)(sub0 + t) * 16 + kg) * (size_t)P::BREG_LDS + lane * 16;
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(mask_lds + (G & 1) * bwd_pair_bytes<P>() + ((blk * 2 + half) * P::NT + t) * P::BREG_LDS);
+#pragma unroll
+                    for (int p = 0; p < P::BREG_LDS / 1024; ++p) glds_piece(src + p * 1024, dst + p * 1024);
+                }
+    }
+    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
+        const typename P::BReg d = to_breg_half<P, false>(acc, half);
+        const uint32_t at = mask_lds + ((fb >> 1) & 1) * bwd_pair_bytes<P>() + (((fb & 1) * 2 + half) * P::NT + t) * P::BREG_LDS + lane * 16;
+        const typename P::BReg v = relu_mask(d, P::unstash(at));
+        buf[t][2 * fb + half] = v;
+        P::store_global(dlt.base + (size_t)layer * dlt.layer_stride + ((size_t)(sub0 + t) * 16 + (2 * fb + half)) * (size_t)P::BREG_LDS, lane, v);
+    }
+};
+
+template <class P>
+DEVINL void bwd_prologue(WeightStream<P, MLP_NSLOT, false>& ws, const void* packed, int n_frags) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<float*>(smem + BWD_LDS_ZERO)[i] = 0.0f;
+    __syncthreads();
+    ws.init(packed, n_frags / P::FPC);
+}
+
+// ================================================================================================
+// ProposalNetwork dgrad chain: g_density (M) -> delta dump (slots 3..0, head in slot 4)
+// ================================================================================================
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __restrict__ packed, const float* __restrict__ g_density, int64_t M,
+                                                              Dump act, Dump dlt) {
+    using L = PropBwdLayout;
+    using BReg = typename P::BReg;
+    WeightStream<P, MLP_NSLOT, false> ws;
+    bwd_prologue<P>(ws, packed, L::N_FRAGS);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        BReg head[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t m = tile * TS + (wave * NT + t) * 32 + j;
+            const float g = (h == 0 && m < M) ? g_density[m] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) P::set(head[t], e, e == 0 ? g : 0.0f);          // slot feature 0 = lane half 0, element 0
+            P::store_global(dlt.base + 4 * dlt.layer_stride + ((size_t)(sub0 + t) * 16) * (size_t)P::BREG_LDS, lane, head[t]);
+        }
+        BReg a[NT][16], b[NT][16];
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        const MaskedOut<P, 1, 16> O3{a, act, dlt, 3, sub0, lane, mask_lds};
+        Deferred<P, 6, 2> d = dense<P, 1, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int, int t) -> BReg { return head[t]; }, O3, NoPrev{});
+        // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (same chunk parity)
+        static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk parity");
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const MaskedOut<P, 16, 1> OB{b, act, dlt, 2 - 2 * r, sub0, lane, mask_lds};        // (follows the 1-step head layer in round 0)
+            const MaskedOut<P, 16, 16> OA_pend{a, act, dlt, 3 - 2 * r, sub0, lane, mask_lds};
+            d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                const MaskedOut<P, 16, 16> OA{a, act, dlt, 1, sub0, lane, mask_lds};
+                d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            }
+        }
+        const MaskedOut<P, 16, 16> O0{b, act, dlt, 0, sub0, lane, mask_lds};
+        vm_wait<mask_wait_count<P>(16)>();                   // the last pair's masks
+        d.flush(O0);
+    }
+    ws.drain();
+}
+
+// ================================================================================================
+// MipNeRF dgrad chain: g_rgbo (M,4), rgbo (M,4) -> delta dump (slots 7..0, head in slot 8)
+// ================================================================================================
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restrict__ packed, const float* __restrict__ g_rgbo,
+                                                             const float* __restrict__ rgbo, int64_t M, Dump act, Dump dlt) {
+    using L = MipBwdLayout;
+    using BReg = typename P::BReg;
+    constexpr int FPC = P::FPC;
+    WeightStream<P, MLP_NSLOT, false> ws;
+    bwd_prologue<P>(ws, packed, L::N_FRAGS);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        BReg head[NT], zero_kg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) P::set(zero_kg, e, 0.0f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t m = tile * TS + (wave * NT + t) * 32 + j;
+            f32x4 hv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (h == 0 && m < M) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(g_rgbo + m * 4), o = *reinterpret_cast<const f32x4*>(rgbo + m * 4);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hv[c] = (g[c] * (1.0f - o[c])) * o[c];      // sigmoid adjoint (mip_model.py:60)
+                hv[3] = g[3];                                                            // raw sigma: no activation in the network
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) P::set(head[t], e, e < 4 ? hv[e] : 0.0f);       // slot features 0..3 = lane half 0, elements 0..3
+            P::store_global(dlt.base + 8 * dlt.layer_stride + ((size_t)(sub0 + t) * 16) * (size_t)P::BREG_LDS, lane, head[t]);
+        }
+        BReg a[NT][16], b[NT][16];
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        // dc = W_rgb2^T dpre, masked by c (activation slot 7) -> b[.][0..7]
+        const MaskedOut<P, 2, 16> OC{b, act, dlt, 7, sub0, lane, mask_lds};
+        const Deferred<P, 2, 2> dcp = dense<P, 2, 4, L::START[0]>(ws, BWD_LDS_ZERO,
+            [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OC, NoPrev{});
+        // d6 = [W_fold^T | W_sigma^T] [dc | head], masked by g6 (slot 6) -> a
+        const MaskedOut<P, 9, 2> O6{a, act, dlt, 6, sub0, lane, mask_lds};
+        Deferred<P, 6, 2> d = dense<P, 9, 8, L::START[1]>(ws, BWD_LDS_ZERO,
+            [&](int kg, int t) -> BReg { if (kg < 8) return b[t][kg < 8 ? kg : 0]; return head[t]; }, O6, prev_of(dcp, OC));
+        // d5 .. d0: six 256 x 256 layers ping-ponging between the register buffers (a -> b -> a ...), two code instances
+        static_assert(L::START[2] % (2 * FPC) == L::START[4] % (2 * FPC) && L::START[2] % (2 * FPC) == L::START[6] % (2 * FPC) &&
+                      L::START[3] % (2 * FPC) == L::START[5] % (2 * FPC) && L::START[3] % (2 * FPC) == L::START[7] % (2 * FPC), "uniform layer loop");
+#pragma unroll 1
+        for (int r = 0; r < 3; ++r) {
+            const MaskedOut<P, 16, 9> OB{b, act, dlt, 5 - 2 * r, sub0, lane, mask_lds};       // (follows the 9-step layer in round 0)
+            const MaskedOut<P, 16, 16> OA_pend{a, act, dlt, 6 - 2 * r, sub0, lane, mask_lds}, OA{a, act, dlt, 4 - 2 * r, sub0, lane, mask_lds};
+            d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[3]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+        }
+        const MaskedOut<P, 16, 16> O0{a, act, dlt, 0, sub0, lane, mask_lds};
+        vm_wait<mask_wait_count<P>(16)>();                   // the last pair's masks
+        d.flush(O0);
+    }
+    ws.drain();
+}
+
+// ================================================================================================
+// wgrad:  dW (32 NOB x 32 NIB) = X^T . Y over all samples;  X = delta dump K groups, Y = activation / encoding dump K groups
+// ================================================================================================
+struct FragMat { const char* base; unsigned long long sub_stride; };      // K group kg of subtile s: base + s*sub_stride + kg*BREG bytes
+struct WgradJob {
+    FragMat x0; int kgx0;       // X = K groups [0, kgx0) of x0 followed by the K groups of x1
+    FragMat x1;
+    FragMat y;
+    float* partial;             // [n_wg][32 NOB][32 NIB]
+    float* bias_partial;        // [n_wg][32 NOB] row sums of X (nullptr = skip)
+};
+constexpr int WG_MAX_JOBS = 8;
+struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
+
+enum { Y_DMAP = 0, Y_PE10 = 1, Y_PE4 = 2 };
+
+// slot (kg, h, e) of a Y operand -> feature (column of the reference weight matrix), or -1
+template <int YKIND> DEVINL int y_slot_feature(int kg, int h, int e) {
+    if (YKIND == Y_PE10) return pe_slot_column(8 * kg + e, h, 10);
+    if (YKIND == Y_PE4) return pe_slot_column(8 * kg + e, h, 4);
+    return dmap_feature(kg, h, e);
+}
+
+// KGX / KGY: K groups of X / Y;  WO: waves along the X (row) dimension, 4 / WO along Y
+template <int KGX, int KGY, int WO, int YKIND>
+__global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t n_sub) {
+    constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : (YKIND == Y_PE10 ? 2 : 1);
+    constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
+    static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
+    constexpr int NXK = 2 * OBW;                                          // X K groups a wave loads per subtile
+    constexpr int NYK = (YKIND == Y_DMAP) ? 2 * IBW : KGY;                // PE columns scatter over all K groups
+    constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const WgradJob& J = jobs.j[blockIdx.y];
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    const int wo = wave / WI, wi = wave % WI;
+    const int ob0 = wo * OBW, ib0 = wi * IBW;
+
+    // constant 0/1 selection operands of the transposing MFMAs
+    bf16x8 idx[2];                                                         // X (always the D map): K-group parity p, feature j of the block
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) idx[p][e] = (__bf16)((dmap_feature(p, h, e) == j) ? 1.0f : 0.0f);
+    bf16x8 idy[(YKIND == Y_DMAP) ? 1 : NYK][(YKIND == Y_DMAP) ? 1 : IBW];
+    if constexpr (YKIND != Y_DMAP) {
+#pragma unroll
+        for (int k = 0; k < NYK; ++k)
+#pragma unroll
+            for (int bi = 0; bi < IBW; ++bi)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) idy[k][bi][e] = (__bf16)((y_slot_feature<YKIND>(k, h, e) == 32 * (ib0 + bi) + j) ? 1.0f : 0.0f);
+    }
+
+    f32x16 acc[OBW][IBW];
+#pragma unroll
+    for (int a = 0; a < OBW; ++a)
+#pragma unroll
+        for (int b = 0; b < IBW; ++b) acc[a][b] = zero16;
+    float bsum[OBW];
+#pragma unroll
+    for (int a = 0; a < OBW; ++a) bsum[a] = 0.0f;
+
+    const int64_t per = (n_sub + gridDim.x - 1) / gridDim.x;
+    const int64_t s_begin = blockIdx.x * per, s_end = (s_begin + per < n_sub) ? s_begin + per : n_sub;
+
+    auto x_ptr = [&](int64_t s, int kg) -> const char* {                   // kg = K group index inside the concatenated X
+        return (kg < J.kgx0 ? J.x0.base + (size_t)s * J.x0.sub_stride + (size_t)kg * 1024
+                            : J.x1.base + (size_t)s * J.x1.sub_stride + (size_t)(kg - J.kgx0) * 1024) + lane * 16;
+    };
+    auto load_x = [&](int64_t s, bf16x8 (&xs)[NXK]) {
+#pragma unroll
+        for (int k = 0; k < NXK; ++k) {
+            const int kg = 2 * ob0 + k;
+            if (kg < KGX) xs[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, kg));
+        }
+    };
+    auto load_y = [&](int64_t s, bf16x8 (&ys)[NYK]) {
+#pragma unroll
+        for (int k = 0; k < NYK; ++k) {
+            const int kg = (YKIND == Y_DMAP) ? 2 * ib0 + k : k;
+            if (kg < KGY) ys[k] = *reinterpret_cast<const bf16x8*>(J.y.base + (size_t)s * J.y.sub_stride + (size_t)kg * 1024 + lane * 16);
+        }
+    };
+    auto cvt8 = [](const f32x16& v, int g) -> bf16x8 { return PBF16::from_acc<false>(v, 8 * g); };
+
+    bf16x8 xs[NXK], ys[NYK], xn[NXK], yn[NYK];
+    if (s_begin < s_end) { load_x(s_begin, xs); load_y(s_begin, ys); }
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) { load_x(s + 1, xn); load_y(s + 1, yn); }       // next subtile in flight while this one is multiplied
+        // X^T blocks of this wave: lane = row feature, 2 x 8 registers = the subtile's 32 samples
+        bf16x8 xf[OBW][2];
+#pragma unroll
+        for (int a = 0; a < OBW; ++a) {
+            f32x16 t = zero16;
+            if (2 * (ob0 + a) < KGX) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[2 * a], idx[0], t, 0, 0, 0);
+            if (2 * (ob0 + a) + 1 < KGX) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[2 * a + 1], idx[1], t, 0, 0, 0);
+            xf[a][0] = cvt8(t, 0); xf[a][1] = cvt8(t, 1);
+            if (J.bias_partial != nullptr && wi == 0) {
+                float r = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) r += t[q];
+                bsum[a] += r;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < IBW; ++b) {
+            f32x16 t = zero16;
+            if constexpr (YKIND == Y_DMAP) {
+                if (2 * (ib0 + b) < KGY) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[2 * b], idx[0], t, 0, 0, 0);
+                if (2 * (ib0 + b) + 1 < KGY) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[2 * b + 1], idx[1], t, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NYK; ++k) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[k], idy[k][b], t, 0, 0, 0);
+            }
+            const bf16x8 yf0 = cvt8(t, 0), yf1 = cvt8(t, 1);
+#pragma unroll
+            for (int a = 0; a < OBW; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][0], yf0, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < OBW; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][1], yf1, acc[a][b], 0, 0, 0);
+        }
+        if (s + 1 < s_end) {
+#pragma unroll
+            for (int k = 0; k < NXK; ++k) xs[k] = xn[k];
+#pragma unroll
+            for (int k = 0; k < NYK; ++k) ys[k] = yn[k];
+        }
+    }
+    // partial of this workgroup, row-major (32 NOB) x (32 NIB): register r of lane (j, h) = row 32 ob + (r&3) + 8 (r>>2) + 4 h, column 32 ib + j
+    float* out = J.partial + (size_t)blockIdx.x * (32 * NOB) * (32 * NIB);
+#pragma unroll
+    for (int a = 0; a < OBW; ++a)
+#pragma unroll
+        for (int b = 0; b < IBW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (ob0 + a) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)row * (32 * NIB) + 32 * (ib0 + b) + j] = acc[a][b][r];
+            }
+    if (J.bias_partial != nullptr && wi == 0) {
+#pragma unroll
+        for (int a = 0; a < OBW; ++a) {
+            const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + a) + j] = v;
+        }
+    }
+}
+
+// fp32 twin (parity mode): v_mfma_f32_32x32x2_f32 contracts two samples per instruction, and with K = 2 the operands ARE single
+// elements -- lane (feature i, k) reads dump element (sample 2 r + k, feature i) straight from the fragment-ordered dump (4-byte gathers
+// served by L2); no transposition at all.  Exact fp32 products and sums.
+template <int KGX, int KGY, int WO, int YKIND>
+__global__ __launch_bounds__(256) void wgrad_kernel_f32(WgradJobs jobs, int64_t n_sub) {
+    constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : (YKIND == Y_PE10 ? 2 : 1);
+    constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
+    static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
+    constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const WgradJob& J = jobs.j[blockIdx.y];
+    const int lane = lane_id(), hk = lane >> 5, j = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    const int wo = wave / WI, wi = wave % WI;
+    const int ob0 = wo * OBW, ib0 = wi * IBW;
+    // byte offset of (feature, sample 0) inside a subtile's fp32 fragment block [kg][e>>2][lane = sample + 32 h][e&3]; -1 = no such feature
+    auto slot_off = [](int kg, int hf, int e) -> int { return kg * 2048 + (e >> 2) * 1024 + (32 * hf) * 16 + (e & 3) * 4; };
+    int xoff[OBW], yoff[IBW];
+    bool xsec[OBW];
+#pragma unroll
+    for (int a = 0; a < OBW; ++a) {
+        const int f = 32 * (ob0 + a) + j;                                  // D map: f = 16 kg + 8 (e>>2) + 4 h + (e&3)
+        const int kg = f >> 4;
+        xoff[a] = (kg < KGX) ? slot_off(kg < J.kgx0 ? kg : kg - J.kgx0, (f >> 2) & 1, ((f >> 3) & 1) * 4 + (f & 3)) : -1;
+        xsec[a] = kg >= J.kgx0;
+    }
+#pragma unroll
+    for (int b = 0; b < IBW; ++b) {
+        const int f = 32 * (ib0 + b) + j;
+        if constexpr (YKIND == Y_DMAP) {
+            yoff[b] = ((f >> 4) < KGY) ? slot_off(f >> 4, (f >> 2) & 1, ((f >> 3) & 1) * 4 + (f & 3)) : -1;
+        } else {
+            constexpr int Lp = (YKIND == Y_PE10) ? 10 : 4;
+            int q = -1, hf = 0;                                            // inverse of pe_slot_column
+            if (f < 3) { q = 3 * Lp + (f == 1 ? 1 : 0); hf = (f == 2) ? 1 : 0; }
+            else if (f < 3 + 6 * Lp) { const int t = f - 3; hf = (t % 6) / 3; q = 3 * (t / 6) + (t % 3); }
+            yoff[b] = (q >= 0) ? slot_off(q >> 3, hf, q & 7) : -1;
+        }
+    }
+    f32x16 acc[OBW][IBW];
+#pragma unroll
+    for (int a = 0; a < OBW; ++a)
+#pragma unroll
+        for (int b = 0; b < IBW; ++b) acc[a][b] = zero16;
+    float bsum[OBW];
+#pragma unroll
+    for (int a = 0; a < OBW; ++a) bsum[a] = 0.0f;
+    const int64_t per = (n_sub + gridDim.x - 1) / gridDim.x;
+    const int64_t s_begin = blockIdx.x * per, s_end = (s_begin + per < n_sub) ? s_begin + per : n_sub;
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        const char* x0 = J.x0.base + (size_t)s * J.x0.sub_stride;
+        const char* x1 = J.x1.base ? J.x1.base + (size_t)s * J.x1.sub_stride : x0;
+        const char* yb = J.y.base + (size_t)s * J.y.sub_stride;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int so = (2 * r + hk) * 16;                              // sample 2 r + k of the subtile
+            float xa[OBW], yv[IBW];
+#pragma unroll
+            for (int a = 0; a < OBW; ++a) xa[a] = (xoff[a] >= 0) ? *reinterpret_cast<const float*>((xsec[a] ? x1 : x0) + xoff[a] + so) : 0.0f;
+#pragma unroll
+            for (int b = 0; b < IBW; ++b) yv[b] = (yoff[b] >= 0) ? *reinterpret_cast<const float*>(yb + yoff[b] + so) : 0.0f;
+#pragma unroll
+            for (int a = 0; a < OBW; ++a) {
+                bsum[a] += xa[a];
+#pragma unroll
+                for (int b = 0; b < IBW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[a], yv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    float* out = J.partial + (size_t)blockIdx.x * (32 * NOB) * (32 * NIB);
+    const int h = hk;
+#pragma unroll
+    for (int a = 0; a < OBW; ++a)
+#pragma unroll
+        for (int b = 0; b < IBW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (ob0 + a) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)row * (32 * NIB) + 32 * (ib0 + b) + j] = acc[a][b][r];
+            }
+    if (J.bias_partial != nullptr && wi == 0) {
+#pragma unroll
+        for (int a = 0; a < OBW; ++a) {
+            const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+            if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + a) + j] = v;
+        }
+    }
+}
+
+// sum of the workgroup partials (fixed order) into the reference's layout: dst[row * ld + col0 + col], row < rows, col < cols; and
+// the bias: bias_dst[row] for row in [brow0, brow0 + brows)
+struct FinalizeJob {
+    const float* partial; int prow, pcol;       // partial matrix shape (32 NOB, 32 NIB)
+    float* dst; int ld, col0, row0, rows, cols; // rows [row0, row0 + rows) of the partial -> dst rows 0..rows-1
+    const float* bias_partial; float* bias_dst; int bias_prow, brow0, brows;   // bias_prow = rows of the partial the bias sums belong to
+};
+constexpr int FIN_MAX_JOBS = 24;
+struct FinalizeJobs { FinalizeJob j[FIN_MAX_JOBS]; };
+
+__global__ void wgrad_finalize_kernel(FinalizeJobs jobs, int n_wg) {
+    const FinalizeJob& J = jobs.j[blockIdx.y];
+    const int total = J.rows * J.cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / J.cols, c = i - r * J.cols;
+        const float* p = J.partial + (size_t)(J.row0 + r) * J.pcol + c;
+        float s = 0.0f;
+        for (int w = 0; w < n_wg; ++w) s += p[(size_t)w * J.prow * J.pcol];
+        J.dst[(size_t)r * J.ld + J.col0 + c] = s;
+    }
+    if (J.bias_dst != nullptr) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.brows; i += gridDim.x * blockDim.x) {
+            float s = 0.0f;
+            for (int w = 0; w < n_wg; ++w) s += J.bias_partial[(size_t)w * J.bias_prow + J.brow0 + i];
+            J.bias_dst[i] = s;
+        }
+    }
+}
+
+// The forward folds bottle_neck.0 (Wb, bb) into rgb_layer.0 (W9 = [W9a 128x256 | W9d 128x27], b9):  pre_c = W9a (Wb g6 + bb) + W9d e + b9.
+// With G = dc^T g6 (128 x 256) and s = sum_m dc = db9:
+//   dW9a = dc^T (g6 Wb^T + 1 bb^T) = G Wb^T + s bb^T        dWb = W9a^T G        dbb = W9a^T s
+// one thread per output element; 256-term dot products in fp32
+__global__ void mip_fold_grads_kernel(const float* __restrict__ G, const float* __restrict__ s, const float* __restrict__ w9, const float* __restrict__ wb,
+                                      const float* __restrict__ bb, float* __restrict__ dw9, float* __restrict__ dwb, float* __restrict__ dbb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 128 * 256) {                                                   // dW9[:, :256]
+        const int r = i >> 8, c = i & 255;                                 // c = bottle-neck feature
+        float a = 0.0f;
+        for (int k = 0; k < 256; ++k) a = __builtin_fmaf(G[r * 256 + k], wb[c * 256 + k], a);
+        dw9[r * 283 + c] = a + s[r] * bb[c];
+    } else if (i < 128 * 256 + 256 * 256) {                                // dWb
+        const int t = i - 128 * 256, r = t >> 8, c = t & 255;              // r = bottle-neck feature, c = g6 feature
+        float a = 0.0f;
+        for (int k = 0; k < 128; ++k) a = __builtin_fmaf(w9[k * 283 + r], G[k * 256 + c], a);
+        dwb[r * 256 + c] = a;
+    } else if (i < 128 * 256 + 256 * 256 + 256) {                          // dbb
+        const int r = i - 128 * 256 - 256 * 256;
+        float a = 0.0f;
+        for (int k = 0; k < 128; ++k) a = __builtin_fmaf(w9[k * 283 + r], s[k], a);
+        dbb[r] = a;
+    }
+}
+
+// Adam over a table of tensors (torch.optim.Adam, no weight decay / amsgrad): in place on p, m, v.  `step` is a DEVICE scalar
+// (incremented by the last workgroup... no: by a separate one-thread launch) so that a captured graph replays correctly.
+struct AdamTensor { float* p; const float* g; float* m; float* v; long long n; };
+constexpr int ADAM_MAX = 48;
+struct AdamTable { AdamTensor t[ADAM_MAX]; };
+__global__ void adam_kernel(AdamTable tab, const float* __restrict__ step_ptr, float lr, float beta1, float beta2, float eps, float grad_scale) {
+    const AdamTensor& T = tab.t[blockIdx.y];
+    const float step = step_ptr[0];
+    const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < T.n; i += (long long)gridDim.x * blockDim.x) {
+        const float g = T.g[i] * grad_scale;
+        const float m = T.m[i] + (g - T.m[i]) * (1.0f - beta1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float v = T.v[i] * beta2 + (g * g) * (1.0f - beta2);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        T.m[i] = m; T.v[i] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        T.p[i] = T.p[i] - step_size * (m / denom);
+    }
+}
+__global__ void adam_step_kernel(float* step) { step[0] += 1.0f; }
+
+int bwd_grid(int64_t n_tiles) {
+    const int n_cu = nerf_host::cu_count();
+    return (int)(n_tiles < n_cu ? n_tiles : n_cu);
+}
+
+template <class P>
+int launch_prop_bwd(const void* packed, const float* g, int64_t M, Dump act, Dump dlt, hipStream_t st) {
+    constexpr int TS = P::NW * P::NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = bwd_lds_total<P>();
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(prop_bwd_kernel<P>), lds)) return e;
+    hipLaunchKernelGGL(prop_bwd_kernel<P>, dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, packed, g, M, act, dlt);
+    return (int)hipGetLastError();
+}
+template <class P>
+int launch_mip_bwd(const void* packed, const float* g, const float* rgbo, int64_t M, Dump act, Dump dlt, hipStream_t st) {
+    constexpr int TS = P::NW * P::NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = bwd_lds_total<P>();
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(mip_bwd_kernel<P>), lds)) return e;
+    hipLaunchKernelGGL(mip_bwd_kernel<P>, dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, packed, g, rgbo, M, act, dlt);
+    return (int)hipGetLastError();
+}
+
+template <int KGX, int KGY, int WO, int YKIND>
+int launch_wgrad(int precision, const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
+    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
+    else hipLaunchKernelGGL((wgrad_kernel_f32<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host-visible launchers (capi.hip)
+size_t mlp_train_layer_stride(int precision, int64_t M);
+
+int bwd_launch_prop_chain(const void* packed_bwd, int precision, const float* g_density, int64_t M, const void* act_dump, void* delta_dump,
+                          hipStream_t st) {
+    const unsigned long long ls = mlp_train_layer_stride(precision, M);
+    const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls}, dlt{reinterpret_cast<char*>(delta_dump), ls};
+    if (precision == NERF_AMD_BF16) return launch_prop_bwd<PB16>(packed_bwd, g_density, M, act, dlt, st);
+    return launch_prop_bwd<PF32>(packed_bwd, g_density, M, act, dlt, st);
+}
+int bwd_launch_mip_chain(const void* packed_bwd, int precision, const float* g_rgbo, const float* rgbo, int64_t M, const void* act_dump,
+                         void* delta_dump, hipStream_t st) {
+    const unsigned long long ls = mlp_train_layer_stride(precision, M);
+    const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls}, dlt{reinterpret_cast<char*>(delta_dump), ls};
+    if (precision == NERF_AMD_BF16) return launch_mip_bwd<PB16>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
+    return launch_mip_bwd<PF32>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients: orchestration
+namespace {
+struct Product { const char* x0; int kgx0; const char* x1; const char* y; float* partial; float* bias_partial; };
+
+// shape codes: 0 = 256 x 256 (D map), 1 = 256 x PE10, 2 = (128 + head) x 256, 3 = head x 128, 4 = 128 x PE4, 5 = head x 256
+int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, int64_t n_sub, hipStream_t st) {
+    if (n < 1 || n > WG_MAX_JOBS) return (int)hipErrorInvalidValue;
+    const size_t breg = precision == NERF_AMD_BF16 ? 1024 : 2048;
+    WgradJobs jobs = {};
+    for (int i = 0; i < n; ++i) {
+        WgradJob& J = jobs.j[i];
+        J.x0 = FragMat{prods[i].x0, 16 * breg};
+        J.kgx0 = prods[i].kgx0;
+        J.x1 = FragMat{prods[i].x1, 16 * breg};
+        J.y = FragMat{prods[i].y, 16 * breg};
+        J.partial = prods[i].partial; J.bias_partial = prods[i].bias_partial;
+    }
+    switch (shape) {
+        case 0: return launch_wgrad<16, 16, 2, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
+        case 1: return launch_wgrad<16, 4, 4, Y_PE10>(precision, jobs, n, n_wg, n_sub, st);      // 4 x 1 waves of 2 x 2 blocks
+        case 2: return launch_wgrad<9, 16, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // NOB 5 x NIB 8: 1 x 4 waves of 5 x 2 blocks
+        case 3: return launch_wgrad<1, 8, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);       // NOB 1 x NIB 4
+        case 4: return launch_wgrad<8, 2, 4, Y_PE4>(precision, jobs, n, n_wg, n_sub, st);        // NOB 4 x NIB 1
+        case 5: return launch_wgrad<1, 16, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // NOB 1 x NIB 8
+    }
+    return (int)hipErrorInvalidValue;
+}
+int run_finalize(const FinalizeJob* f, int n, int n_wg, hipStream_t st) {
+    if (n < 1 || n > FIN_MAX_JOBS) return (int)hipErrorInvalidValue;
+    FinalizeJobs jobs = {};
+    for (int i = 0; i < n; ++i) jobs.j[i] = f[i];
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(64, n), dim3(256), 0, st, jobs, n_wg);
+    return (int)hipGetLastError();
+}
+// every launch of a backward uses the same number of workgroups per product, so that one finalize launch can sum them all
+int wgrad_workgroups(int64_t n_sub) {
+    const int64_t n = nerf_host::cu_count() / 4;                           // 64 on MI355X: six batched 256 x 256 products fill the chip 1.5 x
+    return (int)(n_sub < n ? (n_sub < 1 ? 1 : n_sub) : n);
+}
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+struct Carver {
+    char* p;
+    float* take(size_t floats) { float* r = reinterpret_cast<float*>(p); p += align256(floats * 4); return r; }
+};
+}  // namespace
+
+int64_t bwd_n_sub(int precision, int64_t M) {
+    const int64_t ts = (precision == NERF_AMD_BF16) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;
+    return ((M + ts - 1) / ts) * (ts / 32);
+}
+
+// workspace: per-product workgroup partials (+ G and nothing else); sized for wgrad_workgroups() workgroups
+size_t bwd_wgrad_workspace_bytes(int net, int precision, int64_t M) {
+    const size_t w = (size_t)wgrad_workgroups(bwd_n_sub(precision, M));
+    if (net == NERF_AMD_NET_PROPOSAL)
+        return 3 * (align256(w * 256 * 256 * 4) + align256(w * 256 * 4)) + align256(w * 256 * 64 * 4) + align256(w * 256 * 4) +
+               align256(w * 32 * 256 * 4) + align256(w * 32 * 4) + 256;
+    if (net == NERF_AMD_NET_MIP)
+        return 6 * (align256(w * 256 * 256 * 4) + align256(w * 256 * 4)) + 2 * align256(w * 256 * 64 * 4) + align256(w * 256 * 4) +
+               align256(w * 160 * 256 * 4) + align256(w * 160 * 4) + align256(w * 32 * 128 * 4) + align256(w * 128 * 32 * 4) +
+               align256((size_t)128 * 256 * 4) + 256;
+    return 0;
+}
+
+// ProposalNetwork: d_w / d_b = gradients of layers.{0,2,4,6,8} (addtional.py:67-71), written in the reference's (out, in) layout
+int bwd_prop_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, float* const* d_w, float* const* d_b,
+                          void* workspace, hipStream_t st) {
+    const int64_t n_sub = bwd_n_sub(precision, M);
+    if (n_sub == 0) return 0;
+    const size_t breg = precision == NERF_AMD_BF16 ? 1024 : 2048, ls = mlp_train_layer_stride(precision, M);
+    const char* act = reinterpret_cast<const char*>(act_dump);
+    const char* dlt = reinterpret_cast<const char*>(delta_dump);
+    auto A = [&](int slot, int kg0 = 0) { return act + (size_t)slot * ls + (size_t)kg0 * breg; };
+    auto D = [&](int slot, int kg0 = 0) { return dlt + (size_t)slot * ls + (size_t)kg0 * breg; };
+    const int n_wg = wgrad_workgroups(n_sub);
+    Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
+    float *pw[3], *pb[3];
+    for (int i = 0; i < 3; ++i) { pw[i] = ws.take((size_t)n_wg * 256 * 256); pb[i] = ws.take((size_t)n_wg * 256); }
+    float* pe = ws.take((size_t)n_wg * 256 * 64); float* pe_b = ws.take((size_t)n_wg * 256);
+    float* ph = ws.take((size_t)n_wg * 32 * 256); float* ph_b = ws.take((size_t)n_wg * 32);
+    // layers.{2,4,6}: delta_L^T y_{L-1}
+    Product p0[3];
+    for (int i = 0; i < 3; ++i) p0[i] = Product{D(i + 1), 16, nullptr, A(i), pw[i], pb[i]};
+    if (int e = run_wgrad(0, precision, p0, 3, n_wg, n_sub, st)) return e;
+    const Product p1{D(0), 16, nullptr, A(4), pe, pe_b};                   // layers.0: delta_0^T [x | PE10(x)]
+    if (int e = run_wgrad(1, precision, &p1, 1, n_wg, n_sub, st)) return e;
+    const Product p5{D(4), 1, nullptr, A(3), ph, ph_b};                    // layers.8: g^T y_3 (slot feature 0 of the head K group)
+    if (int e = run_wgrad(5, precision, &p5, 1, n_wg, n_sub, st)) return e;
+    FinalizeJob f[5];
+    for (int i = 0; i < 3; ++i) f[i] = FinalizeJob{pw[i], 256, 256, d_w[i + 1], 256, 0, 0, 256, 256, pb[i], d_b[i + 1], 256, 0, 256};
+    f[3] = FinalizeJob{pe, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe_b, d_b[0], 256, 0, 256};
+    f[4] = FinalizeJob{ph, 32, 256, d_w[4], 256, 0, 0, 1, 256, ph_b, d_b[4], 32, 0, 1};
+    return run_finalize(f, 5, n_wg, st);
+}
+
+// MipNeRF: tensors in _linear_layers() order (0..3 lin_block1, 4..6 lin_block2, 7 bottle_neck.0, 8 opacity_head.0, 9, 10 rgb_layer.{0,2})
+int bwd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* w, const float* const* b,
+                         float* const* d_w, float* const* d_b, void* workspace, hipStream_t st) {
+    const int64_t n_sub = bwd_n_sub(precision, M);
+    if (n_sub == 0) return 0;
+    const size_t breg = precision == NERF_AMD_BF16 ? 1024 : 2048, ls = mlp_train_layer_stride(precision, M);
+    const char* act = reinterpret_cast<const char*>(act_dump);
+    const char* dlt = reinterpret_cast<const char*>(delta_dump);
+    auto A = [&](int slot, int kg0 = 0) { return act + (size_t)slot * ls + (size_t)kg0 * breg; };
+    auto D = [&](int slot, int kg0 = 0) { return dlt + (size_t)slot * ls + (size_t)kg0 * breg; };
+    const int n_wg = wgrad_workgroups(n_sub);
+    Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
+    float *pw[6], *pb[6];
+    for (int i = 0; i < 6; ++i) { pw[i] = ws.take((size_t)n_wg * 256 * 256); pb[i] = ws.take((size_t)n_wg * 256); }
+    float* pe0 = ws.take((size_t)n_wg * 256 * 64); float* pe4 = ws.take((size_t)n_wg * 256 * 64); float* pe0_b = ws.take((size_t)n_wg * 256);
+    float* pg = ws.take((size_t)n_wg * 160 * 256); float* pg_b = ws.take((size_t)n_wg * 160);
+    float* phc = ws.take((size_t)n_wg * 32 * 128);
+    float* pcd = ws.take((size_t)n_wg * 128 * 32);
+    float* G = ws.take((size_t)128 * 256);
+    // the six 256 x 256 products in one launch: layer L = delta_L^T y_{L-1} for L = 1, 2, 3, 5, 6 and the hidden columns of the skip layer 4
+    const int Ls[6] = {1, 2, 3, 4, 5, 6};
+    Product p0[6];
+    for (int i = 0; i < 6; ++i) p0[i] = Product{D(Ls[i]), 16, nullptr, A(Ls[i] - 1), pw[i], pb[i]};
+    if (int e = run_wgrad(0, precision, p0, 6, n_wg, n_sub, st)) return e;
+    // lin_block1.0 and the encoding columns of lin_block2.0: delta^T [x | PE10(x)]
+    const Product p1[2] = {Product{D(0), 16, nullptr, A(8), pe0, pe0_b}, Product{D(4), 16, nullptr, A(8), pe4, nullptr}};
+    if (int e = run_wgrad(1, precision, p1, 2, n_wg, n_sub, st)) return e;
+    // heads: [dc | dpre dsigma]^T g6 -> G (rows 0..127), rgb? no: rows 128..130 unused, row 131 = opacity_head.0
+    const Product p2{D(7), 8, D(8), A(6), pg, pg_b};
+    if (int e = run_wgrad(2, precision, &p2, 1, n_wg, n_sub, st)) return e;
+    const Product p3{D(8), 1, nullptr, A(7), phc, nullptr};                // rgb_layer.2: dpre^T c
+    if (int e = run_wgrad(3, precision, &p3, 1, n_wg, n_sub, st)) return e;
+    const Product p4{D(7), 8, nullptr, A(8, 4), pcd, nullptr};             // rgb_layer.0's direction columns: dc^T [d | PE4(d)]
+    if (int e = run_wgrad(4, precision, &p4, 1, n_wg, n_sub, st)) return e;
+    FinalizeJob f[12];
+    int n = 0;
+    for (int i = 0; i < 6; ++i) {
+        const int L = Ls[i];
+        if (L == 4) f[n++] = FinalizeJob{pw[i], 256, 256, d_w[4], 319, 63, 0, 256, 256, pb[i], d_b[4], 256, 0, 256};
+        else f[n++] = FinalizeJob{pw[i], 256, 256, d_w[L], 256, 0, 0, 256, 256, pb[i], d_b[L], 256, 0, 256};
+    }
+    f[n++] = FinalizeJob{pe4, 256, 64, d_w[4], 319, 0, 0, 256, 63, nullptr, nullptr, 0, 0, 0};
+    f[n++] = FinalizeJob{pe0, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe0_b, d_b[0], 256, 0, 256};
+    f[n++] = FinalizeJob{pg, 160, 256, G, 256, 0, 0, 128, 256, pg_b, d_b[9], 160, 0, 128};            // G and db9 = sum dc
+    f[n++] = FinalizeJob{pg, 160, 256, d_w[8], 256, 0, 131, 1, 256, pg_b, d_b[8], 160, 131, 1};       // opacity_head.0
+    f[n++] = FinalizeJob{phc, 32, 128, d_w[10], 128, 0, 0, 3, 128, pg_b, d_b[10], 160, 128, 3};       // rgb_layer.2 (bias: sum dpre)
+    f[n++] = FinalizeJob{pcd, 128, 32, d_w[9], 283, 256, 0, 128, 27, nullptr, nullptr, 0, 0, 0};
+    if (int e = run_finalize(f, n, n_wg, st)) return e;
+    // bottle_neck.0 and the folded columns of rgb_layer.0 from G (mip_fold_grads_kernel)
+    const int total = 128 * 256 + 256 * 256 + 256;
+    hipLaunchKernelGGL(mip_fold_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, G, d_b[9], w[9], w[7], b[7], d_w[9], d_w[7], d_b[7]);
+    return (int)hipGetLastError();
+}
+
+int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, int count, float* step, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, hipStream_t st) {
+    hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(1), 0, st, step);
+    for (int base = 0; base < count; base += ADAM_MAX) {
+        AdamTable tab = {};
+        const int c = (count - base < ADAM_MAX) ? count - base : ADAM_MAX;
+        for (int i = 0; i < c; ++i) tab.t[i] = AdamTensor{p[base + i], g[base + i], m[base + i], v[base + i], n[base + i]};
+        hipLaunchKernelGGL(adam_kernel, dim3(32, c), dim3(256), 0, st, tab, step, lr, beta1, beta2, eps, grad_scale);
+    }
+    return (int)hipGetLastError();
+}

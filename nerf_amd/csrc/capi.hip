@@ -22,6 +22,16 @@ int sk_frag_rows_mask_blocks();
 int sk_frag_rows_mask(const void*, int, int64_t, int, int64_t, void*, void*, float*, hipStream_t);
 int sk_relu_mask_bias(void*, const void*, int, int64_t, int, float*, hipStream_t);
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
+int pack_proposal_bwd(int, const float* const*, void*, hipStream_t);
+int pack_mip_bwd(int, const float* const*, void*, hipStream_t);
+int bwd_launch_prop_chain(const void*, int, const float*, int64_t, const void*, void*, hipStream_t);
+int bwd_launch_mip_chain(const void*, int, const float*, const float*, int64_t, const void*, void*, hipStream_t);
+size_t bwd_wgrad_workspace_bytes(int, int, int64_t);
+int bwd_prop_weight_grads(int, int64_t, const void*, const void*, float* const*, float* const*, void*, hipStream_t);
+int bwd_mip_weight_grads(int, int64_t, const void*, const void*, const float* const*, const float* const*, float* const*, float* const*, void*,
+                         hipStream_t);
+int bwd_launch_adam(float* const*, const float* const*, float* const*, float* const*, const long long*, int, float*, float, float, float, float,
+                    float, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
@@ -275,7 +285,7 @@ int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N,
 }
 
 // ---- training forward: the MLP kernels also dump their hidden activations ----
-static int train_layers(int net) { return net == NERF_AMD_NET_PROPOSAL ? 4 : (net == NERF_AMD_NET_MIP ? 8 : 0); }
+static int train_layers(int net) { return net == NERF_AMD_NET_PROPOSAL ? PROP_DUMP_SLOTS : (net == NERF_AMD_NET_MIP ? MIP_DUMP_SLOTS : 0); }
 size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M) {
     if (M < 0 || !train_layers(net) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return 0;
     return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M);
@@ -342,6 +352,73 @@ int nerf_amd_encode_rows(const float* x, int x_stride, int64_t M, int L, int nor
     if (M < 0 || x_stride < 3 || (L != 4 && L != 10) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return fail(NERF_AMD_EINVAL, "bad size, L (4 or 10) or precision");
     if (M && (!x || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_encode_rows(x, x_stride, M, L, normalize, precision == NERF_AMD_BF16 ? 2 : 4, out, S(stream)), "nerf_amd_encode_rows");
+}
+
+// ---- backward of the MLPs: dgrad chain on transposed packed weights, MFMA weight gradients, Adam (bwd_kernels.hip) ----
+size_t nerf_amd_packed_backward_bytes(int net, int precision) {
+    if (bad_prec(precision)) return 0;
+    if (net == NERF_AMD_NET_PROPOSAL) return PropBwdLayout::packed_bytes(precision);
+    if (net == NERF_AMD_NET_MIP) return MipBwdLayout::packed_bytes(precision);
+    return 0;
+}
+int nerf_amd_pack_weights_backward(int net, int precision, const float* const* weights, int n_tensors, void* packed_bwd, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (!weights || !packed_bwd) return fail(NERF_AMD_EINVAL, "NULL argument");
+    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : -1);
+    if (want < 0) return fail(NERF_AMD_EUNSUPPORTED, "the backward chain exists for the proposal and MipNeRF networks");
+    if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
+    for (int i = 0; i < want; ++i)
+        if (!weights[i]) return fail(NERF_AMD_EINVAL, "NULL weight tensor");
+    return hip_status(net == NERF_AMD_NET_PROPOSAL ? pack_proposal_bwd(precision, weights, packed_bwd, S(stream))
+                                                    : pack_mip_bwd(precision, weights, packed_bwd, S(stream)), "nerf_amd_pack_weights_backward");
+}
+int nerf_amd_proposal_backward_chain(const void* packed_bwd, int precision, const float* g_density, int64_t M, const void* act_dump,
+                                     void* delta_dump, void* stream) {
+    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (M == 0) return NERF_AMD_OK;
+    if (!packed_bwd || !g_density || !act_dump || !delta_dump) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(bwd_launch_prop_chain(packed_bwd, precision, g_density, M, act_dump, delta_dump, S(stream)), "nerf_amd_proposal_backward_chain");
+}
+int nerf_amd_mip_backward_chain(const void* packed_bwd, int precision, const float* g_rgbo, const float* rgbo, int64_t M, const void* act_dump,
+                                void* delta_dump, void* stream) {
+    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (M == 0) return NERF_AMD_OK;
+    if (!packed_bwd || !g_rgbo || !rgbo || !act_dump || !delta_dump) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(bwd_launch_mip_chain(packed_bwd, precision, g_rgbo, rgbo, M, act_dump, delta_dump, S(stream)), "nerf_amd_mip_backward_chain");
+}
+size_t nerf_amd_weight_grads_workspace_bytes(int net, int precision, int64_t M) {
+    if (bad_prec(precision) || M < 0) return 0;
+    return bwd_wgrad_workspace_bytes(net, precision, M);
+}
+int nerf_amd_proposal_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, float* const* d_weights,
+                                   float* const* d_biases, void* workspace, void* stream) {
+    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (!d_weights || !d_biases) return fail(NERF_AMD_EINVAL, "NULL argument");
+    for (int i = 0; i < 5; ++i)
+        if (!d_weights[i] || !d_biases[i]) return fail(NERF_AMD_EINVAL, "NULL gradient tensor");
+    if (M == 0) return fail(NERF_AMD_EINVAL, "no samples (the caller zero-fills the gradients of an empty batch)");
+    if (!act_dump || !delta_dump || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(bwd_prop_weight_grads(precision, M, act_dump, delta_dump, d_weights, d_biases, workspace, S(stream)), "nerf_amd_proposal_weight_grads");
+}
+int nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* weights,
+                              const float* const* biases, float* const* d_weights, float* const* d_biases, void* workspace, void* stream) {
+    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (!weights || !biases || !d_weights || !d_biases) return fail(NERF_AMD_EINVAL, "NULL argument");
+    for (int i = 0; i < 11; ++i)
+        if (!weights[i] || !biases[i] || !d_weights[i] || !d_biases[i]) return fail(NERF_AMD_EINVAL, "NULL tensor");
+    if (M == 0) return fail(NERF_AMD_EINVAL, "no samples (the caller zero-fills the gradients of an empty batch)");
+    if (!act_dump || !delta_dump || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(bwd_mip_weight_grads(precision, M, act_dump, delta_dump, weights, biases, d_weights, d_biases, workspace, S(stream)),
+                      "nerf_amd_mip_weight_grads");
+}
+int nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                       int n_tensors, float* step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (n_tensors < 0 || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) || !step) return fail(NERF_AMD_EINVAL, "NULL argument");
+    for (int i = 0; i < n_tensors; ++i)
+        if (numel[i] < 0 || (numel[i] && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))) return fail(NERF_AMD_EINVAL, "NULL tensor");
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+    return hip_status(bwd_launch_adam(params, grads, exp_avg, exp_avg_sq, reinterpret_cast<const long long*>(numel), n_tensors, step, lr, beta1,
+                                      beta2, eps, grad_scale, S(stream)), "nerf_amd_adam_step");
 }
 
 // ---- backward of the sampling / compositing rows ----

@@ -378,10 +378,16 @@ DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& 
 }
 // Runs feature-block groups G, G+1, ... of the layer; `prev` is the pending epilogue that the FIRST K steps of group G
 // work off.  Returns the layer's last group, unconverted.
+// optional hook of an output functor: out.begin_group(G) runs when the MFMAs of feature-block group G start (the backward chain issues
+// the LDS-DMA of the group's ReLU masks there, one whole group before its deferred epilogue needs them)
+template <class T, class = void> struct has_group_hook { static constexpr bool value = false; };
+template <class T> struct has_group_hook<T, decltype(void(static_cast<T*>(nullptr)->begin_group(0)))> { static constexpr bool value = true; };
+
 template <class P, int NKG, int NFB, int START, int G, class WS, class InF, class OutF, class Prev>
 DEVINL auto dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out, const Prev& prev) {
     static_assert(2 * G < NFB, "group index");
     constexpr int FRAG0 = START + 2 * G * NKG;
+    if constexpr (has_group_hook<OutF>::value) out.begin_group(G);
     if constexpr (2 * G + 1 < NFB) {
         Deferred<P, 2 * G, 2> d;
 #pragma unroll

@@ -237,6 +237,10 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             m[t] = tile * TS + (wave * NT + t) * 32 + j;
             const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, false);
             encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+            if constexpr (TRAIN) {                           // the first-layer weight gradient's operand: slot 4, K groups 0..3
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 4, tile * (TS / 32) + wave * NT + t, k, lane, enc[t][k]);
+            }
         }
         BReg a[NT][16], b[NT][16];
         // (layer indices for the training dump: `lay` = the layer whose block pairs are being computed, `lay_pend` = the layer
@@ -354,6 +358,10 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                 // this wavefront's private LDS stash instead of holding 20+ VGPRs through six layers
 #pragma unroll
                 for (int k = 0; k < 4; ++k) P::stash(enc_lds(t) + k * P::BREG_LDS, enc[t][k]);
+                if constexpr (TRAIN) {                       // operand of the first- and skip-layer weight gradients: slot 8, K groups 0..3
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 8, sub0 + t, k, lane, enc[t][k]);
+                }
                 f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
                 if (fc.rgb != nullptr) {
                     // fused compositing needs z|d| and the distance to the next sample at the END of the tile; fetch them now,
@@ -406,6 +414,10 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds(t));
             const float nrm = norm3(dv[0], dv[1], dv[2]);
             encode<P, 4, 2>(dv[0] / nrm, dv[1] / nrm, dv[2] / nrm, h, denc[t]);
+            if constexpr (TRAIN) {                           // operand of rgb_layer.0's direction columns: slot 8, K groups 4..5
+                dump_breg<P>(dump, 8, sub0 + t, 4, lane, denc[t][0]);
+                dump_breg<P>(dump, 8, sub0 + t, 5, lane, denc[t][1]);
+            }
         }
         // rgb_layer.0 with bottle_neck.0 folded in (mlp_layout.h): cat(g 256, dir 27) -> 128, ReLU
         BReg c[NT][8];

@@ -73,6 +73,43 @@ struct MipLayout {
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4 + FOLD_SCRATCH; }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Backward (dgrad) chains: the same stream format, carrying TRANSPOSED weights.  Layer "dL" turns delta_{L+1} (gradient w.r.t. the
+// pre-activation of forward layer L+1, K operand) into delta_L = (W_{L+1}^T delta_{L+1}) * [y_L > 0]: rows = the inputs of W_{L+1}.
+//   proposal: head (g_density in slot feature 0) -> d3 -> d2 -> d1 -> d0                       (layers.8, .6, .4, .2 transposed)
+//   MipNeRF : head K group = [d(rgb pre-sigmoid) 0..2 | d(sigma) 3]
+//             dc (128)  = W_rgb2^T head[0..2]                       (NKG 2: the second K group is zero padding to keep whole chunks)
+//             d6 (256)  = [W_fold^T | W_sigma^T] [dc | head]         (W_fold = rgb_layer.0[:, :256] . bottle_neck.0, as in the forward fold)
+//             d5, d4    = lin_block2.4^T, lin_block2.2^T;  d3 = lin_block2.0[:, 63:]^T (skip layer: the hidden part);  d2, d1, d0 = lin_block1.6/.4/.2^T
+// There are no biases (the chain is linear); the kernels point every layer at one zero block.
+// ------------------------------------------------------------------------------------------------
+struct PropBwdLayout {
+    static constexpr int N_LAYERS = 4;
+    static constexpr int NKG[4] = {1, 16, 16, 16};
+    static constexpr int NFB[4] = {8, 8, 8, 8};
+    static constexpr int START[4] = {0, 8, 136, 264};
+    static constexpr int N_FRAGS = 392;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec); }
+};
+struct MipBwdLayout {
+    static constexpr int N_LAYERS = 8;
+    static constexpr int NKG[8] = {2, 9, 16, 16, 16, 16, 16, 16};
+    static constexpr int NFB[8] = {4, 8, 8, 8, 8, 8, 8, 8};
+    static constexpr int START[8] = {0, 8, 80, 208, 336, 464, 592, 720};
+    static constexpr int N_FRAGS = 848;
+    static constexpr size_t FOLD_SCRATCH = (size_t)128 * 256 * 4;     // W_fold (fp32), rebuilt by every pack
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + FOLD_SCRATCH; }
+};
+// Dump slots (one slot = 16 K groups per 32-sample subtile, fragment order).  Activation dump of the training forward:
+//   proposal 0..3 = layers.{0,2,4,6} outputs, 4 = [PE10 encoding: K groups 0..3];
+//   MipNeRF  0..3 = lin_block1 outputs, 4..6 = lin_block2 outputs, 7 = rgb_layer.0 output (K groups 0..7),
+//            8 = [PE10 encoding of the position: K groups 0..3 | PE4 encoding of the direction: K groups 4..5].
+// Delta dump of the backward chain: slot L = delta of the layer whose activations sit in activation slot L; the head K group goes to
+// K group 0 of slot 4 (proposal) / slot 8 (MipNeRF).
+constexpr int PROP_DUMP_SLOTS = 5, MIP_DUMP_SLOTS = 9;
+
 // RefNeRF(10, 4, bottle_neck 128, hidden 256, output 256)  (ref_model.py:16-66), eval mode, use_srgb = False.
 //   spatial: S0 63->256, S1-3, S4 319->256 (skip), S5-7;  H: [bottle_neck 128 rows | 11 head rows];
 //   directional: D0 167->256, D1-3, D4 423->256 (skip), D5-7;  R: spec_rgb_head 256->3.

@@ -19,6 +19,10 @@ struct PackLayer {
     const float* seg_w[3];
     int seg_stride[3];
     int seg_kind[3], seg_nkg[3], seg_col[3], seg_L[3], seg_width[3];
+    // backward chains (TRANSPOSED weights): element (row i, slot feature f) = seg_w[(f - seg_first) * stride + seg_col + i] for
+    // seg_first <= f < seg_first + seg_width -- row i of the fragment is an INPUT column of the reference matrix, the K slot an output row
+    int trans;
+    int seg_first[3];
 };
 
 // all layers of a network in ONE launch (blockIdx.y = layer): re-packing after every optimiser step is part of the training step,
@@ -47,7 +51,10 @@ __global__ void pack_layer_kernel(PackBatch B, char* __restrict__ stream, float*
         else col = dmap_feature(lkg, h, e);
         if (col >= L.seg_width[seg]) col = -1;
         float v = 0.0f;
-        if (col >= 0) {
+        if (L.trans) {
+            const int f = dmap_feature(lkg, h, e) - L.seg_first[seg];
+            if (f >= 0 && f < L.seg_width[seg] && row < L.rows) v = L.seg_w[seg][(size_t)f * L.seg_stride[seg] + L.seg_col[seg] + row];
+        } else if (col >= 0) {
             if (row < L.rows) v = L.seg_w[seg][(size_t)row * L.seg_stride[seg] + L.seg_col[seg] + col];
             else if (row < L.rows + L.rows2) v = L.w2[(size_t)(row - L.rows) * L.stride2 + L.seg_col[seg] + col];
         }
@@ -55,7 +62,7 @@ __global__ void pack_layer_kernel(PackBatch B, char* __restrict__ stream, float*
         if (BF16) reinterpret_cast<__bf16*>(stream + f * 1024)[lane * 8 + e] = (__bf16)v;
         else reinterpret_cast<float*>(stream + f * 2048)[(e >> 2) * 256 + lane * 4 + (e & 3)] = v;
     }
-    const int n_b = 32 * L.nfb;
+    const int n_b = (bias != nullptr) ? 32 * L.nfb : 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_b; i += gridDim.x * blockDim.x) {
         bias[L.bias_off + i] = (i < L.rows) ? L.b[i] : ((i < L.rows + L.rows2) ? L.b2[i - L.rows] : 0.0f);
     }
@@ -167,4 +174,53 @@ int pack_ref(int precision, const float* const* w, const float* const* b, void* 
     if (int e = launch_pack(B, 18, precision, stream, bias, st)) return e;
     if (int e = (int)hipMemcpyAsync(bias + Lay::N_BIAS, w[19], 9 * 19 * sizeof(float), hipMemcpyDeviceToDevice, st)) return e;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ backward chains (mlp_layout.h *BwdLayout)
+namespace {
+// W_fold (128,256) = rgb_layer.0[:, :256] @ bottle_neck.0 (the same product as the forward fold, without the bias)
+__global__ void fold_weight_kernel(const float* __restrict__ w9, const float* __restrict__ wb, float* __restrict__ wf) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    float acc = 0.0f;
+    for (int k = 0; k < 256; ++k) acc = __builtin_fmaf(w9[i * 283 + k], wb[k * 256 + j], acc);
+    wf[i * 256 + j] = acc;
+}
+// one transposed layer: K = `nkg` groups of delta features (rows of w), fragment rows = `rows` input columns of w starting at `col0`
+PackLayer make_trans_layer(const float* w, int stride, int col0, int rows, int k_width, int nkg, int nfb, int start) {
+    PackLayer L{};
+    L.b = nullptr; L.rows = rows; L.nkg = nkg; L.nfb = nfb; L.frag_start = start; L.bias_off = 0; L.trans = 1;
+    for (int s = 0; s < 3; ++s) { L.seg_w[s] = w; L.seg_stride[s] = stride; L.seg_kind[s] = SEG_DMAP; L.seg_nkg[s] = 0; L.seg_col[s] = col0; L.seg_first[s] = 0; L.seg_width[s] = 0; }
+    L.seg_nkg[0] = nkg; L.seg_width[0] = k_width;
+    return L;
+}
+}  // namespace
+
+// proposal: w = layers.{0,2,4,6,8}.weight
+int pack_proposal_bwd(int precision, const float* const* w, void* packed, hipStream_t st) {
+    using Lay = PropBwdLayout;
+    PackBatch B = {};
+    B.L[0] = make_trans_layer(w[4], 256, 0, 256, 1, Lay::NKG[0], Lay::NFB[0], Lay::START[0]);       // d3 = layers.8^T g
+    for (int l = 1; l < 4; ++l) B.L[l] = make_trans_layer(w[4 - l], 256, 0, 256, 256, Lay::NKG[l], Lay::NFB[l], Lay::START[l]);
+    return launch_pack(B, 4, precision, reinterpret_cast<char*>(packed), nullptr, st);
+}
+
+// MipNeRF: w in _linear_layers() order (0..3 lin_block1, 4..6 lin_block2, 7 bottle_neck.0, 8 opacity_head.0, 9, 10 rgb_layer.{0,2})
+int pack_mip_bwd(int precision, const float* const* w, void* packed, hipStream_t st) {
+    using Lay = MipBwdLayout;
+    char* stream = reinterpret_cast<char*>(packed);
+    float* wf = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    hipLaunchKernelGGL(fold_weight_kernel, dim3(128), dim3(256), 0, st, w[9], w[7], wf);
+    if (int e = (int)hipGetLastError()) return e;
+    PackBatch B = {};
+    B.L[0] = make_trans_layer(w[10], 128, 0, 128, 3, Lay::NKG[0], Lay::NFB[0], Lay::START[0]);       // dc = rgb_layer.2^T dpre (slot features 0..2)
+    PackLayer& L1 = B.L[1] = make_trans_layer(wf, 256, 0, 256, 128, Lay::NKG[1], Lay::NFB[1], Lay::START[1]);   // d6 = W_fold^T dc ...
+    L1.seg_nkg[0] = 8;
+    L1.seg_w[1] = w[8]; L1.seg_stride[1] = 256; L1.seg_nkg[1] = 1; L1.seg_first[1] = 3; L1.seg_width[1] = 1; // ... + opacity_head^T dsigma (slot feature 3)
+    B.L[2] = make_trans_layer(w[6], 256, 0, 256, 256, 16, 8, Lay::START[2]);
+    B.L[3] = make_trans_layer(w[5], 256, 0, 256, 256, 16, 8, Lay::START[3]);
+    B.L[4] = make_trans_layer(w[4], 319, 63, 256, 256, 16, 8, Lay::START[4]);                        // skip layer: the hidden columns
+    B.L[5] = make_trans_layer(w[3], 256, 0, 256, 256, 16, 8, Lay::START[5]);
+    B.L[6] = make_trans_layer(w[2], 256, 0, 256, 256, 16, 8, Lay::START[6]);
+    B.L[7] = make_trans_layer(w[1], 256, 0, 256, 256, 16, 8, Lay::START[7]);
+    return launch_pack(B, 8, precision, stream, nullptr, st);
 }

@@ -65,7 +65,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
                 if "dump" not in held:
                     raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
                 gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), p.reshape(-1, 6), held.pop("dump"), prec,
-                                                   wb[:n], wb[n:])
+                                                   wb[:n], wb[n:], packed_bwd=self.packed_backward(prec))
                 return (None, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.mip_forward(self.packed(prec), prec, pts)

@@ -532,3 +532,80 @@ def relu_mask_bias_(delta: torch.Tensor, act: torch.Tensor, precision: int):
     check(lib.nerf_amd_relu_mask_bias(_ptr(delta), _ptr(act), precision, delta.shape[0], delta.shape[1], _ptr(part), _stream()), "nerf_amd_relu_mask_bias")
     return delta, part.sum(0)
 
+
+
+# ------------------------------------------------------------------------------------------------ MLP backward on the matrix cores
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def pack_weights_backward(net: int, precision: int, weights: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The TRANSPOSED weights of a network in the dgrad-chain kernels' fragment order (same tensor order as pack_weights)."""
+    ws = [_dev(w.detach(), "weight") for w in weights]
+    blob = torch.empty(lib.nerf_amd_packed_backward_bytes(net, precision), dtype=torch.uint8, device=ws[0].device)
+    check(lib.nerf_amd_pack_weights_backward(net, precision, _ptr_array(ws), len(ws), _ptr(blob), _stream()), "nerf_amd_pack_weights_backward")
+    return blob
+
+
+def proposal_backward_chain(packed_bwd: torch.Tensor, precision: int, g_density: torch.Tensor, dump: torch.Tensor) -> torch.Tensor:
+    """dgrad chain of the proposal network: g_density (M,) + the training forward's activation dump -> delta dump."""
+    g = _dev(g_density.reshape(-1), "g_density")
+    delta = torch.empty_like(dump)
+    check(lib.nerf_amd_proposal_backward_chain(_ptr(packed_bwd), precision, _ptr(g), g.numel(), _ptr(dump), _ptr(delta), _stream()),
+          "nerf_amd_proposal_backward_chain")
+    return delta
+
+
+def mip_backward_chain(packed_bwd: torch.Tensor, precision: int, g_rgbo: torch.Tensor, rgbo: torch.Tensor, dump: torch.Tensor) -> torch.Tensor:
+    g, o = _dev(g_rgbo.reshape(-1, 4), "g_rgbo"), _dev(rgbo.reshape(-1, 4), "rgbo")
+    delta = torch.empty_like(dump)
+    check(lib.nerf_amd_mip_backward_chain(_ptr(packed_bwd), precision, _ptr(g), _ptr(o), g.shape[0], _ptr(dump), _ptr(delta), _stream()),
+          "nerf_amd_mip_backward_chain")
+    return delta
+
+
+def _grad_buffers(shapes, device):
+    """One flat fp32 buffer, one view per tensor (the kernels overwrite every element)."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    out, off = [], 0
+    for s, n in zip(shapes, sizes):
+        out.append(flat[off: off + n].view(s))
+        off += n
+    return out
+
+
+def proposal_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Tensor):
+    """-> ([dW of layers.{0,2,4,6,8}], [db ...]) in the reference's (out, in) layout."""
+    dev = dump.device
+    gw = _grad_buffers([(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)], dev)
+    gb = _grad_buffers([(256,), (256,), (256,), (256,), (1,)], dev)
+    ws = torch.empty(lib.nerf_amd_weight_grads_workspace_bytes(NET_PROPOSAL, precision, M), dtype=torch.uint8, device=dev)
+    check(lib.nerf_amd_proposal_weight_grads(precision, M, _ptr(dump), _ptr(delta), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()),
+          "nerf_amd_proposal_weight_grads")
+    return gw, gb
+
+
+def mip_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
+    """-> ([dW], [db]) in MipNeRF._linear_layers() order; `weights` / `biases` are needed to un-fold bottle_neck.0 / rgb_layer.0."""
+    dev = dump.device
+    w = [_dev(t.detach(), "weight") for t in weights]
+    b = [_dev(t.detach(), "bias") for t in biases]
+    gw = _grad_buffers([tuple(t.shape) for t in w], dev)
+    gb = _grad_buffers([tuple(t.shape) for t in b], dev)
+    ws = torch.empty(lib.nerf_amd_weight_grads_workspace_bytes(NET_MIP, precision, M), dtype=torch.uint8, device=dev)
+    check(lib.nerf_amd_mip_weight_grads(precision, M, _ptr(dump), _ptr(delta), _ptr_array(w), _ptr_array(b), _ptr_array(gw), _ptr_array(gb),
+                                        _ptr(ws), _stream()), "nerf_amd_mip_weight_grads")
+    return gw, gb
+
+
+def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp_avg: Sequence[torch.Tensor], exp_avg_sq: Sequence[torch.Tensor],
+              step: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    """torch.optim.Adam's update (no weight decay / amsgrad) over all tensors in one launch; `step` = device float, incremented here."""
+    n = len(params)
+    for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("nerf_amd.adam_step: tensors must be contiguous fp32 on the HIP device")
+    numel = (C.c_int64 * n)(*[p.numel() for p in params])
+    check(lib.nerf_amd_adam_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), numel, n, _ptr(step),
+                                 float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), _stream()), "nerf_amd_adam_step")
