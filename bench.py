@@ -209,7 +209,8 @@ def train_ddp(a, dist, world, rank, dev, backend):
     prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
     if dist is not None:
         parallel.broadcast_parameters([mip, prop], src=0)             # ... and made sure of (ddp_train.py:98 DDP does this at wrap time)
-    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4)
+    from nerf_amd.optim import Adam                                   # torch.optim.Adam's update as one HIP launch
+    opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)          # every rank draws its own rays
     o = torch.tensor([0.0, 0.0, 4.0], device=dev).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3, device=dev, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0], device=dev), dim=-1)

@@ -261,7 +261,8 @@ int nerf_amd_encode_rows(const float* x, int x_stride, int64_t M, int L, int nor
  *      workspace: nerf_amd_weight_grads_workspace_bytes bytes of device scratch.  Deterministic (no atomics).
  *   4. nerf_amd_adam_step: torch.optim.Adam (no weight decay, no amsgrad) over a table of tensors; `step` is a DEVICE float holding
  *      the number of steps taken so far (incremented by the call, so that a captured graph replays correctly); grads are multiplied
- *      by grad_scale first (1 = plain; 1/world_size after a summing all-reduce).
+ *      by grad_scale first (1 = plain; 1/world_size after a summing all-reduce).  lr / betas / eps are doubles like torch's Python
+ *      scalars (the bias corrections 1 - beta^step are formed in double, as torch does).
  * Gradients w.r.t. the sample positions are not produced (the reference detaches them for these two networks).
  * ------------------------------------------------------------------------------------------------ */
 size_t nerf_amd_packed_backward_bytes(int net, int precision);
@@ -276,8 +277,8 @@ int    nerf_amd_proposal_weight_grads(int precision, int64_t M, const void* act_
 int    nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* weights,
                                  const float* const* biases, float* const* d_weights, float* const* d_biases, void* workspace, void* stream);
 int    nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                          const int64_t* numel, int n_tensors, float* step, float lr, float beta1, float beta2, float eps, float grad_scale,
-                          void* stream);
+                          const int64_t* numel, int n_tensors, float* step, double lr, double beta1, double beta2, double eps,
+                          float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).

@@ -81,7 +81,7 @@ SIGNATURES = {
     "nerf_amd_mip_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void),
                                            C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_adam_step": (C.c_int, [C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(i64), C.c_int, c_void,
-                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_void]),
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, c_void]),
     "nerf_amd_sigma_to_weights_backward": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_composite_backward": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_float, c_void, c_void, c_void, c_void, c_void]),

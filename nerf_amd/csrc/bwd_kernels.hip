@@ -264,13 +264,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : (YKIND == Y_PE10 ? 2 : 1);
     constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
     static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
+    // an odd K-group count leaves the last block half empty; the loads / MFMAs that skip the missing group must be decided at COMPILE
+    // time (a runtime "load or not" makes hipcc branch around every load and drain vmcnt each time: the loads of a subtile would run
+    // one L2 round trip after the other), so such a dimension is never split across waves
+    static_assert((KGX % 2 == 0 || WO == 1) && (YKIND != Y_DMAP || KGY % 2 == 0 || WI == 1), "odd K-group counts need an unsplit dimension");
     constexpr int NXK = 2 * OBW;                                          // X K groups a wave loads per subtile
     constexpr int NYK = (YKIND == Y_DMAP) ? 2 * IBW : KGY;                // PE columns scatter over all K groups
     constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const WgradJob& J = jobs.j[blockIdx.y];
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
-    const int wo = wave / WI, wi = wave % WI;
+    const int wo = (WO == 1) ? 0 : wave / WI, wi = (WI == 1) ? 0 : wave % WI;
     const int ob0 = wo * OBW, ib0 = wi * IBW;
 
     // constant 0/1 selection operands of the transposing MFMAs
@@ -308,15 +312,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     auto load_x = [&](int64_t s, bf16x8 (&xs)[NXK]) {
 #pragma unroll
         for (int k = 0; k < NXK; ++k) {
-            const int kg = 2 * ob0 + k;
-            if (kg < KGX) xs[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, kg));
+            if constexpr (KGX % 2 == 0) xs[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, 2 * ob0 + k));
+            else if (k < KGX) xs[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, k));           // (ob0 == 0: k is a constant after unrolling)
         }
     };
     auto load_y = [&](int64_t s, bf16x8 (&ys)[NYK]) {
 #pragma unroll
         for (int k = 0; k < NYK; ++k) {
-            const int kg = (YKIND == Y_DMAP) ? 2 * ib0 + k : k;
-            if (kg < KGY) ys[k] = *reinterpret_cast<const bf16x8*>(J.y.base + (size_t)s * J.y.sub_stride + (size_t)kg * 1024 + lane * 16);
+            const char* base = J.y.base + (size_t)s * J.y.sub_stride + lane * 16;
+            if constexpr (YKIND != Y_DMAP) ys[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)k * 1024);
+            else if constexpr (KGY % 2 == 0) ys[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)(2 * ib0 + k) * 1024);
+            else if (k < KGY) ys[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)k * 1024);
         }
     };
     auto cvt8 = [](const f32x16& v, int g) -> bf16x8 { return PBF16::from_acc<false>(v, 8 * g); };
@@ -324,14 +330,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     bf16x8 xs[NXK], ys[NYK], xn[NXK], yn[NYK];
     if (s_begin < s_end) { load_x(s_begin, xs); load_y(s_begin, ys); }
     for (int64_t s = s_begin; s < s_end; ++s) {
-        if (s + 1 < s_end) { load_x(s + 1, xn); load_y(s + 1, yn); }       // next subtile in flight while this one is multiplied
+        {   // next subtile in flight while this one is multiplied (the last iteration re-reads its own subtile: unconditional loads)
+            const int64_t sn = (s + 1 < s_end) ? s + 1 : s;
+            load_x(sn, xn); load_y(sn, yn);
+        }
         // X^T blocks of this wave: lane = row feature, 2 x 8 registers = the subtile's 32 samples
         bf16x8 xf[OBW][2];
 #pragma unroll
         for (int a = 0; a < OBW; ++a) {
-            f32x16 t = zero16;
-            if (2 * (ob0 + a) < KGX) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[2 * a], idx[0], t, 0, 0, 0);
-            if (2 * (ob0 + a) + 1 < KGX) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[2 * a + 1], idx[1], t, 0, 0, 0);
+            f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[2 * a], idx[0], zero16, 0, 0, 0);
+            if (KGX % 2 == 0 || 2 * a + 1 < KGX) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[2 * a + 1], idx[1], t, 0, 0, 0);
             xf[a][0] = cvt8(t, 0); xf[a][1] = cvt8(t, 1);
             if (J.bias_partial != nullptr && wi == 0) {
                 float r = 0.0f;
@@ -344,8 +352,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
         for (int b = 0; b < IBW; ++b) {
             f32x16 t = zero16;
             if constexpr (YKIND == Y_DMAP) {
-                if (2 * (ib0 + b) < KGY) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[2 * b], idx[0], t, 0, 0, 0);
-                if (2 * (ib0 + b) + 1 < KGY) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[2 * b + 1], idx[1], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[2 * b], idx[0], t, 0, 0, 0);
+                if (KGY % 2 == 0 || 2 * b + 1 < KGY) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[2 * b + 1], idx[1], t, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int k = 0; k < NYK; ++k) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ys[k], idy[k][b], t, 0, 0, 0);
@@ -356,12 +364,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
 #pragma unroll
             for (int a = 0; a < OBW; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][1], yf1, acc[a][b], 0, 0, 0);
         }
-        if (s + 1 < s_end) {
 #pragma unroll
-            for (int k = 0; k < NXK; ++k) xs[k] = xn[k];
+        for (int k = 0; k < NXK; ++k) xs[k] = xn[k];
 #pragma unroll
-            for (int k = 0; k < NYK; ++k) ys[k] = yn[k];
-        }
+        for (int k = 0; k < NYK; ++k) ys[k] = yn[k];
     }
     // partial of this workgroup, row-major (32 NOB) x (32 NIB): register r of lane (j, h) = row 32 ob + (r&3) + 8 (r>>2) + 4 h, column 32 ib + j
     float* out = J.partial + (size_t)blockIdx.x * (32 * NOB) * (32 * NIB);
@@ -477,25 +483,51 @@ struct FinalizeJob {
     const float* partial; int prow, pcol;       // partial matrix shape (32 NOB, 32 NIB)
     float* dst; int ld, col0, row0, rows, cols; // rows [row0, row0 + rows) of the partial -> dst rows 0..rows-1
     const float* bias_partial; float* bias_dst; int bias_prow, brow0, brows;   // bias_prow = rows of the partial the bias sums belong to
+    int n_wg;                                   // workgroup partials to sum
 };
 constexpr int FIN_MAX_JOBS = 24;
 struct FinalizeJobs { FinalizeJob j[FIN_MAX_JOBS]; };
 
-__global__ void wgrad_finalize_kernel(FinalizeJobs jobs, int n_wg) {
+// 256 threads = 64 elements x 4 slices of the workgroup range; every thread sums its slice with four independent accumulators (the
+// partials of one element are n_wg strided loads: one dependent chain would be a chain of L2 round trips), then the slices are
+// combined through LDS in a fixed order -- the result does not depend on the launch geometry of anything but n_wg.
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinalizeJobs jobs) {
+    __shared__ float red[4][64];
     const FinalizeJob& J = jobs.j[blockIdx.y];
+    const int n_wg = J.n_wg;
+    const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int per = (n_wg + 3) / 4;
+    const int w_lo = slice * per, w_hi = (w_lo + per < n_wg) ? w_lo + per : n_wg;
+    auto slice_sum = [&](const float* p, size_t stride) -> float {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int w = w_lo;
+        for (; w + 4 <= w_hi; w += 4) {
+            a0 += p[(size_t)w * stride]; a1 += p[(size_t)(w + 1) * stride]; a2 += p[(size_t)(w + 2) * stride]; a3 += p[(size_t)(w + 3) * stride];
+        }
+        for (; w < w_hi; ++w) a0 += p[(size_t)w * stride];
+        return (a0 + a1) + (a2 + a3);
+    };
     const int total = J.rows * J.cols;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int r = i / J.cols, c = i - r * J.cols;
-        const float* p = J.partial + (size_t)(J.row0 + r) * J.pcol + c;
+    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const int i = base + el;
         float s = 0.0f;
-        for (int w = 0; w < n_wg; ++w) s += p[(size_t)w * J.prow * J.pcol];
-        J.dst[(size_t)r * J.ld + J.col0 + c] = s;
+        int r = 0, c = 0;
+        if (i < total) {
+            r = i / J.cols; c = i - r * J.cols;
+            s = slice_sum(J.partial + (size_t)(J.row0 + r) * J.pcol + c, (size_t)J.prow * J.pcol);
+        }
+        red[slice][el] = s;
+        __syncthreads();
+        if (slice == 0 && i < total) J.dst[(size_t)r * J.ld + J.col0 + c] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        __syncthreads();
     }
     if (J.bias_dst != nullptr) {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.brows; i += gridDim.x * blockDim.x) {
-            float s = 0.0f;
-            for (int w = 0; w < n_wg; ++w) s += J.bias_partial[(size_t)w * J.bias_prow + J.brow0 + i];
-            J.bias_dst[i] = s;
+        for (int base = blockIdx.x * 64; base < J.brows; base += gridDim.x * 64) {
+            const int i = base + el;
+            red[slice][el] = (i < J.brows) ? slice_sum(J.bias_partial + J.brow0 + i, (size_t)J.bias_prow) : 0.0f;
+            __syncthreads();
+            if (slice == 0 && i < J.brows) J.bias_dst[i] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+            __syncthreads();
         }
     }
 }
@@ -530,19 +562,20 @@ __global__ void mip_fold_grads_kernel(const float* __restrict__ G, const float* 
 struct AdamTensor { float* p; const float* g; float* m; float* v; long long n; };
 constexpr int ADAM_MAX = 48;
 struct AdamTable { AdamTensor t[ADAM_MAX]; };
-__global__ void adam_kernel(AdamTable tab, const float* __restrict__ step_ptr, float lr, float beta1, float beta2, float eps, float grad_scale) {
+__global__ void adam_kernel(AdamTable tab, const float* __restrict__ step_ptr, double lr, double beta1, double beta2, double eps, float grad_scale) {
     const AdamTensor& T = tab.t[blockIdx.y];
-    const float step = step_ptr[0];
-    const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
-    const float step_size = lr / bc1;
-    const float bc2_sqrt = sqrtf(bc2);
+    // scalars the way torch forms them (Python doubles, rounded to fp32 where they meet the tensors)
+    const double step = (double)step_ptr[0];
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2), b2 = (float)beta2, epsf = (float)eps;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < T.n; i += (long long)gridDim.x * blockDim.x) {
         const float g = T.g[i] * grad_scale;
-        const float m = T.m[i] + (g - T.m[i]) * (1.0f - beta1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
-        const float v = T.v[i] * beta2 + (g * g) * (1.0f - beta2);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float m = T.m[i] + w1 * (g - T.m[i]);                        // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float v = T.v[i] * b2 + w2 * (g * g);                        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         T.m[i] = m; T.v[i] = v;
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        T.p[i] = T.p[i] - step_size * (m / denom);
+        const float denom = sqrtf(v) / bc2_sqrt + epsf;
+        T.p[i] = T.p[i] - step_size * (m / denom);                         // param.addcdiv_(exp_avg, denom, value=-step_size)
     }
 }
 __global__ void adam_step_kernel(float* step) { step[0] += 1.0f; }
@@ -627,17 +660,20 @@ int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, i
     }
     return (int)hipErrorInvalidValue;
 }
-int run_finalize(const FinalizeJob* f, int n, int n_wg, hipStream_t st) {
+int run_finalize(const FinalizeJob* f, int n, hipStream_t st) {
     if (n < 1 || n > FIN_MAX_JOBS) return (int)hipErrorInvalidValue;
     FinalizeJobs jobs = {};
     for (int i = 0; i < n; ++i) jobs.j[i] = f[i];
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(64, n), dim3(256), 0, st, jobs, n_wg);
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(128, n), dim3(256), 0, st, jobs);
     return (int)hipGetLastError();
 }
-// every launch of a backward uses the same number of workgroups per product, so that one finalize launch can sum them all
-int wgrad_workgroups(int64_t n_sub) {
-    const int64_t n = nerf_host::cu_count() / 4;                           // 64 on MI355X: six batched 256 x 256 products fill the chip 1.5 x
-    return (int)(n_sub < n ? (n_sub < 1 ? 1 : n_sub) : n);
+// workgroups per product of a launch that batches `n_jobs` products: the big-accumulator shapes (512 registers: one workgroup per CU)
+// get one round of the chip, the light shapes two
+int wgrad_workgroups(int64_t n_sub, int n_jobs, bool heavy) {
+    const int64_t total = (int64_t)nerf_host::cu_count() * (heavy ? 1 : 2);
+    int64_t n = total / n_jobs;
+    if (n > n_sub) n = n_sub;
+    return (int)(n < 1 ? 1 : n);
 }
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 struct Carver {
@@ -651,16 +687,21 @@ int64_t bwd_n_sub(int precision, int64_t M) {
     return ((M + ts - 1) / ts) * (ts / 32);
 }
 
-// workspace: per-product workgroup partials (+ G and nothing else); sized for wgrad_workgroups() workgroups
+// workspace: per-product workgroup partials (+ G for the un-fold)
 size_t bwd_wgrad_workspace_bytes(int net, int precision, int64_t M) {
-    const size_t w = (size_t)wgrad_workgroups(bwd_n_sub(precision, M));
-    if (net == NERF_AMD_NET_PROPOSAL)
-        return 3 * (align256(w * 256 * 256 * 4) + align256(w * 256 * 4)) + align256(w * 256 * 64 * 4) + align256(w * 256 * 4) +
-               align256(w * 32 * 256 * 4) + align256(w * 32 * 4) + 256;
-    if (net == NERF_AMD_NET_MIP)
-        return 6 * (align256(w * 256 * 256 * 4) + align256(w * 256 * 4)) + 2 * align256(w * 256 * 64 * 4) + align256(w * 256 * 4) +
-               align256(w * 160 * 256 * 4) + align256(w * 160 * 4) + align256(w * 32 * 128 * 4) + align256(w * 128 * 32 * 4) +
+    const int64_t n_sub = bwd_n_sub(precision, M);
+    if (net == NERF_AMD_NET_PROPOSAL) {
+        const size_t w0 = wgrad_workgroups(n_sub, 3, true), w1 = wgrad_workgroups(n_sub, 1, false);
+        return 3 * (align256(w0 * 256 * 256 * 4) + align256(w0 * 256 * 4)) + align256(w1 * 256 * 64 * 4) + align256(w1 * 256 * 4) +
+               align256(w1 * 32 * 256 * 4) + align256(w1 * 32 * 4) + 256;
+    }
+    if (net == NERF_AMD_NET_MIP) {
+        const size_t w0 = wgrad_workgroups(n_sub, 6, true), w1 = wgrad_workgroups(n_sub, 2, false), w2 = wgrad_workgroups(n_sub, 1, true),
+                     w3 = wgrad_workgroups(n_sub, 1, false);
+        return 6 * (align256(w0 * 256 * 256 * 4) + align256(w0 * 256 * 4)) + 2 * align256(w1 * 256 * 64 * 4) + align256(w1 * 256 * 4) +
+               align256(w2 * 160 * 256 * 4) + align256(w2 * 160 * 4) + align256(w3 * 32 * 128 * 4) + align256(w3 * 128 * 32 * 4) +
                align256((size_t)128 * 256 * 4) + 256;
+    }
     return 0;
 }
 
@@ -674,25 +715,25 @@ int bwd_prop_weight_grads(int precision, int64_t M, const void* act_dump, const 
     const char* dlt = reinterpret_cast<const char*>(delta_dump);
     auto A = [&](int slot, int kg0 = 0) { return act + (size_t)slot * ls + (size_t)kg0 * breg; };
     auto D = [&](int slot, int kg0 = 0) { return dlt + (size_t)slot * ls + (size_t)kg0 * breg; };
-    const int n_wg = wgrad_workgroups(n_sub);
+    const int w0 = wgrad_workgroups(n_sub, 3, true), w1 = wgrad_workgroups(n_sub, 1, false);
     Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
     float *pw[3], *pb[3];
-    for (int i = 0; i < 3; ++i) { pw[i] = ws.take((size_t)n_wg * 256 * 256); pb[i] = ws.take((size_t)n_wg * 256); }
-    float* pe = ws.take((size_t)n_wg * 256 * 64); float* pe_b = ws.take((size_t)n_wg * 256);
-    float* ph = ws.take((size_t)n_wg * 32 * 256); float* ph_b = ws.take((size_t)n_wg * 32);
+    for (int i = 0; i < 3; ++i) { pw[i] = ws.take((size_t)w0 * 256 * 256); pb[i] = ws.take((size_t)w0 * 256); }
+    float* pe = ws.take((size_t)w1 * 256 * 64); float* pe_b = ws.take((size_t)w1 * 256);
+    float* ph = ws.take((size_t)w1 * 32 * 256); float* ph_b = ws.take((size_t)w1 * 32);
     // layers.{2,4,6}: delta_L^T y_{L-1}
     Product p0[3];
     for (int i = 0; i < 3; ++i) p0[i] = Product{D(i + 1), 16, nullptr, A(i), pw[i], pb[i]};
-    if (int e = run_wgrad(0, precision, p0, 3, n_wg, n_sub, st)) return e;
+    if (int e = run_wgrad(0, precision, p0, 3, w0, n_sub, st)) return e;
     const Product p1{D(0), 16, nullptr, A(4), pe, pe_b};                   // layers.0: delta_0^T [x | PE10(x)]
-    if (int e = run_wgrad(1, precision, &p1, 1, n_wg, n_sub, st)) return e;
+    if (int e = run_wgrad(1, precision, &p1, 1, w1, n_sub, st)) return e;
     const Product p5{D(4), 1, nullptr, A(3), ph, ph_b};                    // layers.8: g^T y_3 (slot feature 0 of the head K group)
-    if (int e = run_wgrad(5, precision, &p5, 1, n_wg, n_sub, st)) return e;
+    if (int e = run_wgrad(5, precision, &p5, 1, w1, n_sub, st)) return e;
     FinalizeJob f[5];
-    for (int i = 0; i < 3; ++i) f[i] = FinalizeJob{pw[i], 256, 256, d_w[i + 1], 256, 0, 0, 256, 256, pb[i], d_b[i + 1], 256, 0, 256};
-    f[3] = FinalizeJob{pe, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe_b, d_b[0], 256, 0, 256};
-    f[4] = FinalizeJob{ph, 32, 256, d_w[4], 256, 0, 0, 1, 256, ph_b, d_b[4], 32, 0, 1};
-    return run_finalize(f, 5, n_wg, st);
+    for (int i = 0; i < 3; ++i) f[i] = FinalizeJob{pw[i], 256, 256, d_w[i + 1], 256, 0, 0, 256, 256, pb[i], d_b[i + 1], 256, 0, 256, w0};
+    f[3] = FinalizeJob{pe, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe_b, d_b[0], 256, 0, 256, w1};
+    f[4] = FinalizeJob{ph, 32, 256, d_w[4], 256, 0, 0, 1, 256, ph_b, d_b[4], 32, 0, 1, w1};
+    return run_finalize(f, 5, st);
 }
 
 // MipNeRF: tensors in _linear_layers() order (0..3 lin_block1, 4..6 lin_block2, 7 bottle_neck.0, 8 opacity_head.0, 9, 10 rgb_layer.{0,2})
@@ -705,52 +746,54 @@ int bwd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const v
     const char* dlt = reinterpret_cast<const char*>(delta_dump);
     auto A = [&](int slot, int kg0 = 0) { return act + (size_t)slot * ls + (size_t)kg0 * breg; };
     auto D = [&](int slot, int kg0 = 0) { return dlt + (size_t)slot * ls + (size_t)kg0 * breg; };
-    const int n_wg = wgrad_workgroups(n_sub);
+    const int w0 = wgrad_workgroups(n_sub, 6, true), w1 = wgrad_workgroups(n_sub, 2, false), w2 = wgrad_workgroups(n_sub, 1, true),
+              w3 = wgrad_workgroups(n_sub, 1, false);
     Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
     float *pw[6], *pb[6];
-    for (int i = 0; i < 6; ++i) { pw[i] = ws.take((size_t)n_wg * 256 * 256); pb[i] = ws.take((size_t)n_wg * 256); }
-    float* pe0 = ws.take((size_t)n_wg * 256 * 64); float* pe4 = ws.take((size_t)n_wg * 256 * 64); float* pe0_b = ws.take((size_t)n_wg * 256);
-    float* pg = ws.take((size_t)n_wg * 160 * 256); float* pg_b = ws.take((size_t)n_wg * 160);
-    float* phc = ws.take((size_t)n_wg * 32 * 128);
-    float* pcd = ws.take((size_t)n_wg * 128 * 32);
+    for (int i = 0; i < 6; ++i) { pw[i] = ws.take((size_t)w0 * 256 * 256); pb[i] = ws.take((size_t)w0 * 256); }
+    float* pe0 = ws.take((size_t)w1 * 256 * 64); float* pe4 = ws.take((size_t)w1 * 256 * 64); float* pe0_b = ws.take((size_t)w1 * 256);
+    float* pg = ws.take((size_t)w2 * 160 * 256); float* pg_b = ws.take((size_t)w2 * 160);
+    float* phc = ws.take((size_t)w3 * 32 * 128);
+    float* pcd = ws.take((size_t)w3 * 128 * 32);
     float* G = ws.take((size_t)128 * 256);
     // the six 256 x 256 products in one launch: layer L = delta_L^T y_{L-1} for L = 1, 2, 3, 5, 6 and the hidden columns of the skip layer 4
     const int Ls[6] = {1, 2, 3, 4, 5, 6};
     Product p0[6];
     for (int i = 0; i < 6; ++i) p0[i] = Product{D(Ls[i]), 16, nullptr, A(Ls[i] - 1), pw[i], pb[i]};
-    if (int e = run_wgrad(0, precision, p0, 6, n_wg, n_sub, st)) return e;
+    if (int e = run_wgrad(0, precision, p0, 6, w0, n_sub, st)) return e;
     // lin_block1.0 and the encoding columns of lin_block2.0: delta^T [x | PE10(x)]
     const Product p1[2] = {Product{D(0), 16, nullptr, A(8), pe0, pe0_b}, Product{D(4), 16, nullptr, A(8), pe4, nullptr}};
-    if (int e = run_wgrad(1, precision, p1, 2, n_wg, n_sub, st)) return e;
-    // heads: [dc | dpre dsigma]^T g6 -> G (rows 0..127), rgb? no: rows 128..130 unused, row 131 = opacity_head.0
+    if (int e = run_wgrad(1, precision, p1, 2, w1, n_sub, st)) return e;
+    // heads: [dc | dpre dsigma]^T g6 -> G (rows 0..127), rows 128..130 unused, row 131 = opacity_head.0
     const Product p2{D(7), 8, D(8), A(6), pg, pg_b};
-    if (int e = run_wgrad(2, precision, &p2, 1, n_wg, n_sub, st)) return e;
+    if (int e = run_wgrad(2, precision, &p2, 1, w2, n_sub, st)) return e;
     const Product p3{D(8), 1, nullptr, A(7), phc, nullptr};                // rgb_layer.2: dpre^T c
-    if (int e = run_wgrad(3, precision, &p3, 1, n_wg, n_sub, st)) return e;
+    if (int e = run_wgrad(3, precision, &p3, 1, w3, n_sub, st)) return e;
     const Product p4{D(7), 8, nullptr, A(8, 4), pcd, nullptr};             // rgb_layer.0's direction columns: dc^T [d | PE4(d)]
-    if (int e = run_wgrad(4, precision, &p4, 1, n_wg, n_sub, st)) return e;
-    FinalizeJob f[12];
+    if (int e = run_wgrad(4, precision, &p4, 1, w3, n_sub, st)) return e;
+    FinalizeJob f[13];
     int n = 0;
     for (int i = 0; i < 6; ++i) {
         const int L = Ls[i];
-        if (L == 4) f[n++] = FinalizeJob{pw[i], 256, 256, d_w[4], 319, 63, 0, 256, 256, pb[i], d_b[4], 256, 0, 256};
-        else f[n++] = FinalizeJob{pw[i], 256, 256, d_w[L], 256, 0, 0, 256, 256, pb[i], d_b[L], 256, 0, 256};
+        if (L == 4) f[n++] = FinalizeJob{pw[i], 256, 256, d_w[4], 319, 63, 0, 256, 256, pb[i], d_b[4], 256, 0, 256, w0};
+        else f[n++] = FinalizeJob{pw[i], 256, 256, d_w[L], 256, 0, 0, 256, 256, pb[i], d_b[L], 256, 0, 256, w0};
     }
-    f[n++] = FinalizeJob{pe4, 256, 64, d_w[4], 319, 0, 0, 256, 63, nullptr, nullptr, 0, 0, 0};
-    f[n++] = FinalizeJob{pe0, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe0_b, d_b[0], 256, 0, 256};
-    f[n++] = FinalizeJob{pg, 160, 256, G, 256, 0, 0, 128, 256, pg_b, d_b[9], 160, 0, 128};            // G and db9 = sum dc
-    f[n++] = FinalizeJob{pg, 160, 256, d_w[8], 256, 0, 131, 1, 256, pg_b, d_b[8], 160, 131, 1};       // opacity_head.0
-    f[n++] = FinalizeJob{phc, 32, 128, d_w[10], 128, 0, 0, 3, 128, pg_b, d_b[10], 160, 128, 3};       // rgb_layer.2 (bias: sum dpre)
-    f[n++] = FinalizeJob{pcd, 128, 32, d_w[9], 283, 256, 0, 128, 27, nullptr, nullptr, 0, 0, 0};
-    if (int e = run_finalize(f, n, n_wg, st)) return e;
+    f[n++] = FinalizeJob{pe4, 256, 64, d_w[4], 319, 0, 0, 256, 63, nullptr, nullptr, 0, 0, 0, w1};
+    f[n++] = FinalizeJob{pe0, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe0_b, d_b[0], 256, 0, 256, w1};
+    f[n++] = FinalizeJob{pg, 160, 256, G, 256, 0, 0, 128, 256, pg_b, d_b[9], 160, 0, 128, w2};            // G and db9 = sum dc
+    f[n++] = FinalizeJob{pg, 160, 256, d_w[8], 256, 0, 131, 1, 256, pg_b, d_b[8], 160, 131, 1, w2};       // opacity_head.0
+    f[n++] = FinalizeJob{phc, 32, 128, d_w[10], 128, 0, 0, 3, 128, nullptr, nullptr, 0, 0, 0, w3};        // rgb_layer.2
+    f[n++] = FinalizeJob{pg, 160, 256, G, 256, 0, 0, 0, 256, pg_b, d_b[10], 160, 128, 3, w2};             // its bias: sum dpre (no matrix rows)
+    f[n++] = FinalizeJob{pcd, 128, 32, d_w[9], 283, 256, 0, 128, 27, nullptr, nullptr, 0, 0, 0, w3};
+    if (int e = run_finalize(f, n, st)) return e;
     // bottle_neck.0 and the folded columns of rgb_layer.0 from G (mip_fold_grads_kernel)
     const int total = 128 * 256 + 256 * 256 + 256;
     hipLaunchKernelGGL(mip_fold_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, G, d_b[9], w[9], w[7], b[7], d_w[9], d_w[7], d_b[7]);
     return (int)hipGetLastError();
 }
 
-int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, int count, float* step, float lr,
-                    float beta1, float beta2, float eps, float grad_scale, hipStream_t st) {
+int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, int count, float* step, double lr,
+                    double beta1, double beta2, double eps, float grad_scale, hipStream_t st) {
     hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(1), 0, st, step);
     for (int base = 0; base < count; base += ADAM_MAX) {
         AdamTable tab = {};

@@ -30,8 +30,8 @@ size_t bwd_wgrad_workspace_bytes(int, int, int64_t);
 int bwd_prop_weight_grads(int, int64_t, const void*, const void*, float* const*, float* const*, void*, hipStream_t);
 int bwd_mip_weight_grads(int, int64_t, const void*, const void*, const float* const*, const float* const*, float* const*, float* const*, void*,
                          hipStream_t);
-int bwd_launch_adam(float* const*, const float* const*, float* const*, float* const*, const long long*, int, float*, float, float, float, float,
-                    float, hipStream_t);
+int bwd_launch_adam(float* const*, const float* const*, float* const*, float* const*, const long long*, int, float*, double, double, double,
+                    double, float, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
@@ -412,7 +412,7 @@ int nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, co
                       "nerf_amd_mip_weight_grads");
 }
 int nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                       int n_tensors, float* step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                       int n_tensors, float* step, double lr, double beta1, double beta2, double eps, float grad_scale, void* stream) {
     if (n_tensors < 0 || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) || !step) return fail(NERF_AMD_EINVAL, "NULL argument");
     for (int i = 0; i < n_tensors; ++i)
         if (numel[i] < 0 || (numel[i] && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))) return fail(NERF_AMD_EINVAL, "NULL tensor");

@@ -1,0 +1,76 @@
+"""Adam as ONE HIP launch over all parameters (nerf_amd_adam_step), with torch.optim.Adam's update rule, state layout and
+``state_dict`` format (train.py:117-118 builds ``optim.Adam`` over both networks; train.py:200-218 steps it and
+nerf_base.DecayLrScheduler rewrites ``param_groups[i]['lr']`` every iteration -- both work on this class unchanged, and a checkpoint's
+``'optimizer'`` entry written by either implementation loads into the other).
+
+torch's own foreach implementation is ~10 launches per step over the 32 parameter tensors; here the step counter lives on the device,
+so a training step captured in a hipGraph replays correctly (the learning rate is a launch argument: re-capture, or keep it constant,
+when it changes under a captured graph).
+"""
+from typing import Iterable, Optional
+
+import torch
+
+from . import ops
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False, grad_scale: float = 1.0):
+        if weight_decay != 0.0 or amsgrad:
+            raise NotImplementedError("nerf_amd.optim.Adam: weight_decay / amsgrad are not built (the reference uses neither)")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                        differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self.grad_scale = float(grad_scale)
+
+    def _group_state(self, group):
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            return None
+        dev = params[0].device
+        step = group.get("_step_dev")
+        for p in params:
+            st = self.state[p]
+            if len(st) == 0:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if step is None:
+                prev = st.get("step")
+                val = float(prev) if prev is not None else 0.0          # (a loaded torch.optim.Adam state keeps 'step' on the CPU)
+                step = torch.full((1,), val, dtype=torch.float32, device=dev)
+                group["_step_dev"] = step
+        for p in params:
+            self.state[p]["step"] = step                                 # one shared device counter (same value for every tensor)
+        return params, step
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            gs = self._group_state(group)
+            if gs is None:
+                continue
+            params, step = gs
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
+            b1, b2 = group["betas"]
+            ops.adam_step([p.data for p in params], grads, [self.state[p]["exp_avg"] for p in params],
+                          [self.state[p]["exp_avg_sq"] for p in params], step, group["lr"], b1, b2, group["eps"], self.grad_scale)
+            # the kernel wrote the parameters through raw pointers: bump their version counters, which the packed-weight caches
+            # (nerf_amd/_packed.py) and autograd's saved-tensor checks are keyed on
+            torch._C._autograd._unsafe_set_version_counter(tuple(params), tuple(p._version + 1 for p in params))
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd["param_groups"]:
+            g.pop("_step_dev", None)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            g.pop("_step_dev", None)

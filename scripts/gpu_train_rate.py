@@ -19,11 +19,13 @@ from nerf_amd.utils import inverseSample
 NEAR, FAR = 2.0, 6.0
 
 
-def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False):
+def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False, torch_adam=False):
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, mip = ProposalNetwork(10, 256).cuda().train(), MipNeRF(10, 4, 256).cuda().train()
-    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4, capturable=graph)
+    from nerf_amd.optim import Adam                        # one-launch Adam (nerf_amd_adam_step); torch_adam=True: torch.optim.Adam
+    params = list(mip.parameters()) + list(prop.parameters())
+    opt = torch.optim.Adam(params, lr=1e-4, capturable=graph) if torch_adam else Adam(params, lr=1e-4)
     o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
     rays = torch.cat((o, d), -1).cuda().contiguous()

@@ -1346,3 +1346,49 @@ def test_render_weights_carry_gradient(A):
         loss.backward()
         scale = ref.grad.abs().max().item()
         assert max_abs(x.grad.cpu(), ref.grad) <= 2e-5 * max(1.0, scale), (use_rgb, use_w)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_fused_adam_equals_torch_adam(A):
+    """nerf_amd.optim.Adam (one HIP launch over all tensors, device-side step counter) against torch.optim.Adam on identical
+    gradients: parameters and both moment tensors after several steps with a changing learning rate (nerf_base.DecayLrScheduler
+    rewrites param_groups['lr'] every iteration, train.py:200-218), and state_dict interchange in both directions."""
+    from nerf_amd.optim import Adam
+    gen = torch.Generator().manual_seed(8)
+    shapes = [(256, 63), (256,), (1, 256), (1,), (128, 283), (3,)]
+    init = [torch.randn(s, generator=gen) * 0.1 for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    oa, ob = Adam(pa, lr=3e-4), torch.optim.Adam(pb, lr=3e-4)
+    for it in range(7):
+        lr = 3e-4 * (0.5 + 0.1 * it)
+        for o in (oa, ob):
+            for gr in o.param_groups:
+                gr["lr"] = lr
+        for x, y in zip(pa, pb):
+            gq = (torch.randn(x.shape, generator=gen) * (10.0 ** ((it % 3) - 2))).cuda()
+            x.grad, y.grad = gq.clone(), gq.clone()
+        v0 = pa[0]._version
+        oa.step(); ob.step()
+        assert pa[0]._version > v0                              # the packed-weight caches see the update
+        for x, y in zip(pa, pb):
+            assert max_abs(x.detach().cpu(), y.detach().cpu()) <= 2e-6 * max(1.0, y.abs().max().item()), it
+    for x, y in zip(pa, pb):
+        assert max_abs(oa.state[x]["exp_avg"].cpu(), ob.state[y]["exp_avg"].cpu()) <= 1e-6 * max(1e-3, ob.state[y]["exp_avg"].abs().max().item())
+        assert max_abs(oa.state[x]["exp_avg_sq"].cpu(), ob.state[y]["exp_avg_sq"].cpu()) <= 1e-6 * max(1e-6, ob.state[y]["exp_avg_sq"].abs().max().item())
+        assert float(oa.state[x]["step"]) == float(ob.state[y]["step"]) == 7.0
+    # checkpoints travel both ways (nerf_helper.saveModel stores opt.state_dict(), nerf_base.loadFromFile restores it)
+    pc = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    pd = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    oc, od = Adam(pc, lr=1e-4), torch.optim.Adam(pd, lr=1e-4)
+    oc.load_state_dict(ob.state_dict()); od.load_state_dict(oa.state_dict())
+    with torch.no_grad():
+        for dst, src in ((pc, pb), (pd, pa)):
+            for x, y in zip(dst, src):
+                x.copy_(y)
+    for x, y in zip(pc, pd):
+        gq = torch.randn(x.shape, generator=gen).cuda() * 0.01
+        x.grad, y.grad = gq.clone(), gq.clone()
+    oc.step(); od.step()
+    for x, y in zip(pc, pd):
+        assert max_abs(x.detach().cpu(), y.detach().cpu()) <= 2e-6 * max(1.0, y.abs().max().item())
