@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--weights", default="small", choices=["small", "he", "zero"],
                    help="closed-form test weights; 'zero' is a power/DVFS diagnostic, never a reported number")
     p.add_argument("--cpu-rays", type=int, default=20000, help="rays of the same workload timed on the host cores (~14 s of CPU work)")
+    p.add_argument("--rng", default="philox", choices=["philox", "resident"],
+                   help="philox = every uniform drawn inside the kernels (no uniform tensor exists: what the drop-in render_image does by "
+                        "default); resident = pre-drawn (N,64) + (N,129) uniform tensors resident in HBM before the timed region (round 1)")
     p.add_argument("--mode", default="render", choices=["render", "train-ddp"],
                    help="render = the headline; train-ddp = per-rank training steps with the flat gradient all_reduce timed separately")
     p.add_argument("--train-rays", type=int, default=16384, help="rays per rank and step in --mode train-ddp")
@@ -331,19 +334,25 @@ def main():
     focal = fov2Focal(0.6911112070083618, (H, W))
     fx, fy = float(focal[1]), float(focal[0])
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    u_strat = torch.rand((n_rays, C_COARSE), device=dev, generator=g)    # resident in HBM before timing
-    u_inv = torch.rand((n_rays, N_FINE + 1), device=dev, generator=g)
+    u_strat = u_inv = None
+    if a.rng == "resident":
+        u_strat = torch.rand((n_rays, C_COARSE), device=dev, generator=g)    # resident in HBM before timing
+        u_inv = torch.rand((n_rays, N_FINE + 1), device=dev, generator=g)
     z_base = torch.linspace(NEAR, FAR, C_COARSE).to(dev)
     jitter = (FAR - NEAR) / N_FINE
     poses = [pose_spherical(float(th), -30.0, 4.0)[:3] for th in torch.linspace(-180, 180, 41)[:-1]]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
+    philox = a.rng == "philox"
+
     def step(i, timed_idx=None):
         pose = poses[(i + 7 * rank) % len(poses)]
         rays = ops.generate_rays(pose, H, W, fx, fy, dev)                                            # row 1
-        sc = ops.samples_rays(rays, C_COARSE, z_base=z_base, u=u_strat, z_jitter=jitter)            # rows 2-4
+        seed = 0x5EED0000 + 1000003 * rank + i                                                       # a fresh stream per image
+        us, ui = (None, None) if philox else (u_strat, u_inv)
+        sc = ops.samples_rays(rays, C_COARSE, z_base=z_base, u=us, z_jitter=jitter, seed=seed)      # rows 2-4
         dens = ops.proposal_forward_samples(pk_prop, prec, sc, (n_rays, C_COARSE), dev)
-        z_fine, _, _, z_c = ops.resample(dens, None, z_base, u_strat, jitter, rays, u_inv, N_FINE + 1, want_zc=is_ref)   # rows 5-7
+        z_fine, _, _, z_c = ops.resample(dens, None, z_base, us, jitter, rays, ui, N_FINE + 1, want_zc=is_ref, seed=seed)   # rows 5-7
         if is_ref:                                                                                    # procedures.py:71-74
             z_all = ops.merge_depths(z_fine, z_c)
             if timed_idx is not None:
@@ -417,7 +426,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic" if a.weights == "small" else "synthetic (DIAGNOSTIC weights=%s)" % a.weights,
             "config": {"workload": ("BASELINE configs[1]: NeRF render 800x800 (640000 rays/step/GPU), 64 proposal + 128 fine samples, "
-                                    "proposal MLP 63->256x4->1 + MipNeRF 8x256 MLP, rows 1-10 of SURVEY 8a, uniforms resident in HBM") if not is_ref else
+                                    "proposal MLP 63->256x4->1 + MipNeRF 8x256 MLP, rows 1-10 of SURVEY 8a, " +
+                                    ("uniforms drawn in-kernel (Philox4x32-10)" if a.rng == "philox" else "uniforms resident in HBM")) if not is_ref else
                                    ("Ref-NeRF render 800x800 (BASELINE configs[3] shape), 64 proposal + 192 merged samples, rows 1-8,10,13"),
                        "rays_per_step_per_gpu": n_rays, "samples": [C_COARSE, N_FINE], "mlp_arith": "bf16 MFMA, fp32 accumulate"
                        if prec == ops.BF16 else "fp32 MFMA", "parallelism": "ray-sharded replicas (dp%d)" % world},

@@ -59,7 +59,9 @@ int         nerf_amd_device_info(int* n_cu, int* arch_is_gfx950);
  *                                   procedures.py:66).  rays (N,6) = [o|d]; depth of sample s on ray n:
  *                                   z[n*z_stride + s]                         if z  != NULL
  *                                   z_base[s] + u[n*S + s] * z_jitter          otherwise (stratified
- *                                   draw of procedures.py:65 / utils.py:89 fused in)
+ *                                   draw of procedures.py:65 / utils.py:89 fused in); with u == NULL too
+ *                                   the uniform is drawn in the kernel: Philox4x32-10 keyed by rng_seed,
+ *                                   a pure function of (ray n + rng_ray_offset, s) -- see below
  *   mode 2  camera + depths         like mode 1 with o = pose[:,3] and d = R.((col-W/2+.5)/fx,
  *                                   (H/2-row+.5)/fy, -1) generated in-kernel for ray n = row*W + col
  *                                   (procedures.py:43-51)
@@ -89,6 +91,11 @@ typedef struct nerf_amd_samples {
     float        ipe_radius;   /* pixel radius r of coneParameters (mip_methods.py:15)                                              */
     const float* ipe_dir_norm; /* DEVICE pointer to one float: norm of the whole (N,3) direction tensor (mip_methods.py:31;
                                   nerf_amd_dirs_norm)                                                                              */
+    uint64_t     rng_seed;     /* in-kernel uniforms (z == NULL and u == NULL; modes 1, 2): the stratified draw of sample s of ray n is    */
+    int64_t      rng_ray_offset; /* word s&3 of Philox4x32-10(key = rng_seed, counter = (n + rng_ray_offset, s>>2, 'ST')), top 24 bits
+                                  * 2^-24.  The reference draws these on the CPU generator (procedures.py:65, utils.py:89); the
+                                  counter form needs no tensor, replays from the seed, and is independent of how rays are batched.
+                                  nerf_amd_resample / nerf_amd_render_rays regenerate the same values from the same (seed, offset). */
 } nerf_amd_samples;
 
 /* ------------------------------------------------------------------------------------------------
@@ -188,10 +195,12 @@ int nerf_amd_stratified_points(const float* rays, const float* z_base, const flo
 /* Fused proposal resampling of the render/train loop (procedures.py:68-70, train.py:169-172):
  * density -> [softplus] -> get_weights(|d| scaling, relu) -> maxBlur(alpha) -> inverse sample (sorted).
  * Depths as in nerf_amd_samples (z, or z_base + u_strat*z_jitter).  dirs row n at dirs[n*dirs_stride .. +3]
- * (pass rays+3 with stride 6).  Optional outputs (NULL to skip): w_prop (N,C), below (N,K) int64, z_coarse (N,C). */
+ * (pass rays+3 with stride 6).  Optional outputs (NULL to skip): w_prop (N,C), below (N,K) int64, z_coarse (N,C).
+ * A NULL u_strat (with z == NULL) / a NULL u_inv (K <= 256) is drawn in the kernel from (rng_seed, ray + rng_ray_offset) exactly like
+ * nerf_amd_samples describes: u_inv(n, k) = word k>>6 of Philox4x32-10(key = rng_seed, counter = (n + rng_ray_offset, k & 63, 'IN')). */
 int nerf_amd_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
                       const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K,
-                      int softplus_density, float blur_alpha,
+                      int softplus_density, float blur_alpha, uint64_t rng_seed, int64_t rng_ray_offset,
                       float* z_fine, int64_t* below, float* w_prop, float* z_coarse, void* stream);
 
 /* NeRF.render (nerf_base.py:91-113).  rgbo (N,S,4), z (N,z_stride) [first S used], dirs as above.
@@ -303,7 +312,8 @@ int nerf_amd_get_bounds_backward(const int64_t* below, const float* d_bounds, in
  * rays: (N,6) device, or NULL to generate them in-kernel from `camera` (mode 2 of nerf_amd_samples;
  * only H, W, fx, fy, pose are read; ray n = row*W + col, n in [ray_offset, ray_offset+N)).
  * z_base (64) = linspace(near, far, 64) (procedures.py:52; an input so that it is bit-identical to the
- * caller's torch.linspace), u_strat (N,64), u_inv (N, n_fine+1).
+ * caller's torch.linspace), u_strat (N,64), u_inv (N, n_fine+1) -- or both NULL: every uniform is then drawn inside the kernels
+ * (Philox4x32-10, camera->rng_seed / camera->rng_ray_offset; `camera` may accompany explicit rays just to carry them; n_fine <= 255).
  * Outputs rgb (N,3), depth (N) or NULL, weights (N,n_fine) or NULL.
  * workspace: nerf_amd_render_workspace_bytes(N, n_fine) bytes of device scratch.
  * ------------------------------------------------------------------------------------------------ */

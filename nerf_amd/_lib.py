@@ -25,7 +25,7 @@ class Samples(C.Structure):
                 ("z_stride", C.c_int32), ("rays", c_void), ("z", c_void), ("z_base", c_void), ("u", c_void),
                 ("z_jitter", C.c_float), ("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
                 ("pose", C.c_float * 12), ("contract", C.c_int32), ("ipe", C.c_int32), ("ipe_radius", C.c_float),
-                ("ipe_dir_norm", c_void)]
+                ("ipe_dir_norm", c_void), ("rng_seed", C.c_uint64), ("rng_ray_offset", C.c_int64)]
 
 
 # name -> (restype, argtypes); mirrors include/nerf_amd.h one to one (tests check the two agree)
@@ -54,7 +54,7 @@ SIGNATURES = {
     "nerf_amd_pixel_rays": (C.c_int, [c_float_p, C.c_float, C.c_float, c_void, i64, c_void, c_void]),
     "nerf_amd_stratified_points": (C.c_int, [c_void, c_void, c_void, C.c_float, i64, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_resample": (C.c_int, [c_void, c_void, c_void, c_void, C.c_float, c_void, C.c_int, c_void, i64, C.c_int,
-                                    C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
+                                    C.c_int, C.c_int, C.c_float, C.c_uint64, i64, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_composite": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_float, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_train_dump_rows_mask_partials": (i64, []),

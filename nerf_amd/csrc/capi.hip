@@ -46,7 +46,7 @@ int sk_inverse_sample(const float*, const float*, const float*, int64_t, int, in
 int sk_pixel_rays(const float*, float, float, const int64_t*, int64_t, float*, hipStream_t);
 int sk_stratified_points(const float*, const float*, const float*, float, int64_t, int, float*, float*, hipStream_t);
 int sk_resample(const float*, const float*, const float*, const float*, float, const float*, int, const float*, int64_t, int,
-                int, int, float, float*, int64_t*, float*, float*, hipStream_t);
+                int, int, float, uint64_t, int64_t, float*, int64_t*, float*, float*, hipStream_t);
 int sk_composite(const float*, const float*, int, const float*, int, int64_t, int, int, int, float, float, float, const float*,
                  const float*, float*, float*, float*, float*, hipStream_t);
 int sk_get_bounds(const float*, const int64_t*, int64_t, int, int, float*, hipStream_t);
@@ -79,7 +79,7 @@ int check_samples(const nerf_amd_samples* s, bool need_dir) {
         if (s->S <= 0) return fail(NERF_AMD_EINVAL, "S must be positive");
         if (s->mode == 1 && !s->rays && s->M) return fail(NERF_AMD_EINVAL, "mode 1 needs rays");
         if (s->mode == 2 && (s->H <= 0 || s->W <= 0)) return fail(NERF_AMD_EINVAL, "mode 2 needs H, W");
-        if (!s->z && !(s->z_base && s->u) && s->M) return fail(NERF_AMD_EINVAL, "need z, or z_base and u");
+        if (!s->z && !s->z_base && s->M) return fail(NERF_AMD_EINVAL, "need z, or z_base (with u, or without: in-kernel uniforms from rng_seed)");
     } else {
         return fail(NERF_AMD_EINVAL, "unknown sample mode");
     }
@@ -254,12 +254,14 @@ int nerf_amd_stratified_points(const float* rays, const float* z_base, const flo
 
 int nerf_amd_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
                       const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K, int softplus_density,
-                      float blur_alpha, float* z_fine, int64_t* below, float* w_prop, float* z_coarse, void* stream) {
+                      float blur_alpha, uint64_t rng_seed, int64_t rng_ray_offset, float* z_fine, int64_t* below, float* w_prop,
+                      float* z_coarse, void* stream) {
     if (N < 0 || C < 3 || C > 256 || K < 1 || K > 1024) return fail(NERF_AMD_EINVAL, "need 3 <= C <= 256 and 1 <= K <= 1024");
-    if (N && (!density || !dirs || !u_inv || !z_fine)) return fail(NERF_AMD_EINVAL, "NULL argument");
-    if (N && !z && !(z_base && u_strat)) return fail(NERF_AMD_EINVAL, "need z, or z_base and u_strat");
+    if (N && (!density || !dirs || !z_fine)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (N && !z && !z_base) return fail(NERF_AMD_EINVAL, "need z, or z_base (with u_strat, or without: in-kernel uniforms)");
+    if (!u_inv && K > 256) return fail(NERF_AMD_EINVAL, "in-kernel inverse-CDF uniforms cover K <= 256 (four Philox words per lane)");
     return hip_status(sk_resample(density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus_density,
-                                  blur_alpha, z_fine, below, w_prop, z_coarse, S(stream)), "nerf_amd_resample");
+                                  blur_alpha, rng_seed, rng_ray_offset, z_fine, below, w_prop, z_coarse, S(stream)), "nerf_amd_resample");
 }
 
 int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int Sn,
@@ -466,9 +468,12 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
     if (N == 0) return NERF_AMD_OK;
-    if (!packed_prop || !packed_mip || !z_base || !u_strat || !u_inv || !rgb || !workspace)
-        return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (!packed_prop || !packed_mip || !z_base || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if ((u_strat == nullptr) != (u_inv == nullptr)) return fail(NERF_AMD_EINVAL, "u_strat and u_inv are both given or both NULL (in-kernel uniforms)");
+    if (!u_strat && (!camera || n_fine > 255)) return fail(NERF_AMD_EINVAL, "in-kernel uniforms need the descriptor (rng_seed, rng_ray_offset) and n_fine <= 255");
     if (!rays && !camera) return fail(NERF_AMD_EINVAL, "need rays or camera");
+    const uint64_t seed = camera ? camera->rng_seed : 0;
+    const int64_t ray0 = camera ? camera->rng_ray_offset : 0;
     constexpr int C = 64;                                   // procedures.py:22 RENDER_COARSE_PNUM
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     float* density = reinterpret_cast<float*>(ws);
@@ -499,9 +504,10 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
     sc.z_jitter = jitter; sc.z_stride = C;
     sc.contract = camera ? camera->contract : 0;           // (the descriptor may accompany explicit rays just to carry this flag)
+    sc.rng_seed = seed; sc.rng_ray_offset = ray0;          // (read only when u_strat == NULL)
     if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7: weights -> max-blur(0.01) -> inverse sampling of n_fine+1 sorted depths (procedures.py:68-70)
-    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, z_fine,
+    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, seed, ray0, z_fine,
                             nullptr, nullptr, nullptr, st)) return hip_status(e, "resample");
     nerf_amd_samples sf{};                                  // rows 8-9: drop the last depth, length2pts fused into the MLP
     sf.mode = 1; sf.rays = rays; sf.S = n_fine; sf.M = N * n_fine; sf.z = z_fine; sf.z_stride = n_fine + 1;
@@ -562,7 +568,7 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     sc.z_jitter = jitter; sc.z_stride = C;
     if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7 (procedures.py:68-70), also returning the stratified depths the proposal pass used
-    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, z_fine,
+    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, 0, 0, z_fine,
                             nullptr, nullptr, z_coarse, st)) return hip_status(e, "resample");
     // row 8, Ref-NeRF branch (procedures.py:71-74): fine and coarse depths merged, the last one dropped
     if (int e = sk_merge_sorted(z_fine, z_coarse, N, n_fine + 1, C, z_all, st)) return hip_status(e, "depth merge");

@@ -47,6 +47,39 @@ DEVINL float sin_quadrant(float a, int quad) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Counter-based uniforms (Philox4x32-10, Salmon et al. 2011 -- the generator behind torch's device RNG, restated from the paper's
+// constants).  When a caller passes no uniform tensors, the kernels draw them as a PURE FUNCTION of (seed, ray, sample):
+//   u_strat(n, s) = word s & 3 of Philox(key = seed, counter = (n_lo, n_hi, s >> 2, 'ST'))        stratified jitter (procedures.py:65)
+//   u_inv(n, k)   = word k >> 6 of Philox(key = seed, counter = (n_lo, n_hi, k & 63, 'IN'))       inverse-CDF draws (utils.py:115), k < 256
+// so the proposal pass and the resampling pass regenerate the same depths without a tensor in between, a render is replayable from
+// its seed, and any sub-batch of rays reproduces the same bits (oracle twin: oracle/nerf_oracle.py philox_uniforms).
+// uint32 -> [0, 1): the top 24 bits times 2^-24 (torch's device convention).
+// ------------------------------------------------------------------------------------------------
+struct Philox4 { uint32_t w[4]; };
+DEVINL Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+DEVINL float u01_from_bits(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+constexpr uint32_t PHILOX_STREAM_STRAT = 0x5354u, PHILOX_STREAM_INV = 0x494Eu;
+DEVINL float philox_u_strat(uint64_t seed, int64_t n, int s) {
+    const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)(s >> 2), PHILOX_STREAM_STRAT, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int i = s & 3;
+    return u01_from_bits(i == 0 ? r.w[0] : (i == 1 ? r.w[1] : (i == 2 ? r.w[2] : r.w[3])));
+}
+// all (up to four) inverse-CDF uniforms of lane `lane` of ray n: k = lane, lane + 64, lane + 128, lane + 192
+DEVINL Philox4 philox_u_inv_lane(uint64_t seed, int64_t n, int lane) {
+    return philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)lane, PHILOX_STREAM_INV, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ------------------------------------------------------------------------------------------------
 // Integrated positional encoding, per-frustum part (mip_methods.py:15-33): Gaussian moments of the conical frustum between depths
 // z0 < z1 along a ray of pixel radius r (r2 = fl(r*r) computed in double like Python's `r ** 2`), every operation in the reference's
 // order (no contraction: this file is compiled with -ffp-contract=off).

@@ -156,7 +156,10 @@ DEVINL Sample fetch_sample(const nerf_amd_samples& s, int64_t m, bool want_dir) 
     }
     float zv;
     if (s.z) zv = s.z[n * s.z_stride + si];
-    else     zv = s.z_base[si] + s.u[n * s.S + si] * s.z_jitter;                 // procedures.py:65
+    else {                                                                       // procedures.py:65; the uniform from memory, or drawn here
+        const float uu = s.u ? s.u[n * s.S + si] : philox_u_strat(s.rng_seed, n + s.rng_ray_offset, si);
+        zv = s.z_base[si] + uu * s.z_jitter;
+    }
     r.x = ox + zv * r.dx; r.y = oy + zv * r.dy; r.z = oz + zv * r.dz;           // procedures.py:66
     if (s.contract) contract_position(r);
     return r;

@@ -381,6 +381,7 @@ struct ResampleArgs {
     const float* density; const float* z; const float* z_base; const float* u_strat; float z_jitter;
     const float* dirs; int dirs_stride; const float* u_inv; int64_t N; int C; int K; int softplus; float alpha;
     float* z_fine; int64_t* below; float* w_prop; float* z_coarse;
+    uint64_t rng_seed; int64_t rng_ray_offset;      // Philox source of u_strat / u_inv when the pointers are NULL (device_common.h)
 };
 
 __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
@@ -406,12 +407,19 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
             const int j = lane + 64 * i;
             r.zv[i] = 0.0f; r.dens[i] = 0.0f;
             if (j < C) {
-                r.zv[i] = a.z ? a.z[n * C + j] : (a.z_base[j] + a.u_strat[n * C + j] * a.z_jitter);
+                if (a.z) r.zv[i] = a.z[n * C + j];
+                else r.zv[i] = a.z_base[j] + (a.u_strat ? a.u_strat[n * C + j] : philox_u_strat(a.rng_seed, n + a.rng_ray_offset, j)) * a.z_jitter;
                 r.dens[i] = a.density[n * C + j];
             }
         }
+        if (a.u_inv) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const int k = lane + 64 * i; r.u[i] = (k < K) ? a.u_inv[n * K + k] : 0.0f; }
+            for (int i = 0; i < 3; ++i) { const int k = lane + 64 * i; r.u[i] = (k < K) ? a.u_inv[n * K + k] : 0.0f; }
+        } else {                                                       // one Philox call per lane = its (up to four) draws k = lane + 64 i
+            const Philox4 p = philox_u_inv_lane(a.rng_seed, n + a.rng_ray_offset, lane);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) r.u[i] = u01_from_bits(p.w[i]);
+        }
         return r;
     };
     const int64_t stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
@@ -435,7 +443,8 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
             const float* dd = a.dirs + n * a.dirs_stride;
             nrm = norm3(dd[0], dd[1], dd[2]);
             for (int j = lane; j < C; j += 64) {
-                const float zv = a.z ? a.z[n * C + j] : (a.z_base[j] + a.u_strat[n * C + j] * a.z_jitter);
+                const float zv = a.z ? a.z[n * C + j]
+                                     : (a.z_base[j] + (a.u_strat ? a.u_strat[n * C + j] : philox_u_strat(a.rng_seed, n + a.rng_ray_offset, j)) * a.z_jitter);
                 zl[j] = zv;
                 if (a.z_coarse) a.z_coarse[n * C + j] = zv;
             }
@@ -458,9 +467,16 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         }
         for (int j = lane; j < C - 1; j += 64) bins[j] = 0.5f * (zl[j + 1] + zl[j]);   // mid-points of the RAW depths
         lds_wave_sync();
-        const float* un = a.u_inv + n * K;
+        const float* un = a.u_inv ? a.u_inv + n * K : nullptr;
+        const uint64_t seed = a.rng_seed; const int64_t nn = n + a.rng_ray_offset;
         wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, sortbuf,
-                            [&](int i, int k) { return fits ? (i == 0 ? cur.u[0] : (i == 1 ? cur.u[1] : cur.u[2])) : un[k]; },
+                            [&](int i, int k) {
+                                if (fits) return i == 0 ? cur.u[0] : (i == 1 ? cur.u[1] : cur.u[2]);
+                                if (un) return un[k];
+                                const Philox4 p = philox_u_inv_lane(seed, nn, k & 63);             // generic shapes (K <= 256)
+                                const int q = k >> 6;
+                                return u01_from_bits(q == 0 ? p.w[0] : (q == 1 ? p.w[1] : (q == 2 ? p.w[2] : p.w[3])));
+                            },
                             K, 1, a.z_fine + n * K, a.below ? a.below + n * K : nullptr, nullptr);
         cur = nxt;
     }
@@ -1104,9 +1120,10 @@ int sk_inverse_sample(const float* w, const float* z, const float* u, int64_t N,
 }
 int sk_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
                 const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K, int softplus, float alpha,
-                float* z_fine, int64_t* below, float* w_prop, float* z_coarse, hipStream_t st) {
+                uint64_t rng_seed, int64_t rng_ray_offset, float* z_fine, int64_t* below, float* w_prop, float* z_coarse, hipStream_t st) {
     if (N == 0) return 0;
-    ResampleArgs a{density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus, alpha, z_fine, below, w_prop, z_coarse};
+    ResampleArgs a{density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus, alpha, z_fine, below, w_prop, z_coarse,
+                   rng_seed, rng_ray_offset};
     const size_t lds = WAVES_PER_BLOCK * ((size_t)5 * C + 2 * K + SORT_LDS_FLOATS) * 4;
     hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a);
     return (int)hipGetLastError();

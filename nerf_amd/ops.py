@@ -69,7 +69,7 @@ def _samples_pts(pts: torch.Tensor, stride: int, contract: bool = False) -> Samp
 
 def samples_rays(rays: torch.Tensor, S: int, z: Optional[torch.Tensor] = None, z_base: Optional[torch.Tensor] = None,
                  u: Optional[torch.Tensor] = None, z_jitter: float = 0.0, contract: bool = False, ipe_radius: Optional[float] = None,
-                 ipe_dir_norm: Optional[torch.Tensor] = None) -> Samples:
+                 ipe_dir_norm: Optional[torch.Tensor] = None, seed: int = 0, rng_ray_offset: int = 0) -> Samples:
     """`contract`: Mip-NeRF 360 scene contraction of the sample positions before encoding (not in the reference; BASELINE config 5).
     `ipe_radius` (with explicit z of S+1 depths per ray): integrated PE of the frusta between consecutive depths (mip_methods.py:15-58);
     `ipe_dir_norm` = ops.dirs_norm(rays) -- the caller keeps that tensor alive until the kernel has run."""
@@ -88,7 +88,10 @@ def samples_rays(rays: torch.Tensor, S: int, z: Optional[torch.Tensor] = None, z
         s.z_stride = z.shape[-1]
     else:
         s.z_base = z_base.data_ptr()
-        s.u = u.data_ptr()
+        if u is not None:
+            s.u = u.data_ptr()
+        else:                                                # stratified uniforms drawn in the kernel (Philox4x32-10)
+            s.rng_seed, s.rng_ray_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_ray_offset)
         s.z_jitter = z_jitter
         s.z_stride = S
     return s
@@ -342,8 +345,9 @@ def get_bounds(w_prop: torch.Tensor, below: torch.Tensor) -> torch.Tensor:
 
 
 def resample(density, z, z_base, u_strat, z_jitter, rays, u_inv, K, softplus=False, alpha=0.01, want_below=False,
-             want_w=False, want_zc=False):
-    """Fused rows 5-7 (procedures.py:68-70 / train.py:169-172).  rays (N,6)."""
+             want_w=False, want_zc=False, seed: int = 0, ray_offset: int = 0):
+    """Fused rows 5-7 (procedures.py:68-70 / train.py:169-172).  rays (N,6).  u_strat / u_inv = None: drawn in the kernel from
+    (seed, ray + ray_offset) (Philox4x32-10, include/nerf_amd.h)."""
     N, Cn = density.shape
     dev = density.device
     z_fine = torch.empty((N, K), dtype=torch.float32, device=dev)
@@ -352,19 +356,29 @@ def resample(density, z, z_base, u_strat, z_jitter, rays, u_inv, K, softplus=Fal
     zc = torch.empty((N, Cn), dtype=torch.float32, device=dev) if want_zc else None
     dirs_ptr = C.c_void_p(rays.data_ptr() + 12)
     check(lib.nerf_amd_resample(_ptr(density), _ptr(z), _ptr(z_base), _ptr(u_strat), float(z_jitter), dirs_ptr, 6, _ptr(u_inv),
-                                N, Cn, K, int(softplus), float(alpha), _ptr(z_fine), _ptr(below), _ptr(w), _ptr(zc), _stream()),
+                                N, Cn, K, int(softplus), float(alpha), int(seed) & 0xFFFFFFFFFFFFFFFF, int(ray_offset), _ptr(z_fine),
+                                _ptr(below), _ptr(w), _ptr(zc), _stream()),
           "nerf_amd_resample")
     return z_fine, below, w, zc
 
 
 def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                 want_depth=True, want_weights=False, workspace: Optional[torch.Tensor] = None, camera: Optional[Samples] = None,
-                ray_offset: int = 0, n_rays: Optional[int] = None, contract: bool = False, ipe_radius: Optional[float] = None):
+                ray_offset: int = 0, n_rays: Optional[int] = None, contract: bool = False, ipe_radius: Optional[float] = None,
+                seed: Optional[int] = None, rng_ray_offset: int = 0):
     """The tile body of render_image (procedures.py:64-85) for all given rays in four launches.  `contract`: Mip-NeRF 360 scene
     contraction of every sample position (proposal and fine) before encoding.  `ipe_radius`: the fine pass encodes the conical frusta
-    between consecutive fine depths with the integrated PE (mip_methods.py:15-58; explicit `rays` required)."""
-    dev = u_strat.device
-    if (contract or ipe_radius is not None) and camera is None:
+    between consecutive fine depths with the integrated PE (mip_methods.py:15-58; explicit `rays` required).
+    u_strat = u_inv = None with `seed`: every uniform is drawn inside the kernels (Philox4x32-10 keyed by `seed`, a pure function of
+    (ray index + rng_ray_offset, sample)); pass `n_rays` (or rays) for the ray count."""
+    in_kernel_rng = u_strat is None
+    if in_kernel_rng:
+        if u_inv is not None or seed is None:
+            raise ValueError("nerf_amd: u_strat and u_inv are both tensors, or both None with a `seed`")
+        dev = rays.device if rays is not None else z_base.device
+    else:
+        dev = u_strat.device
+    if (contract or ipe_radius is not None or in_kernel_rng) and camera is None:
         camera = Samples()                                   # carries only the flags next to explicit rays
     if camera is not None:
         camera.contract = int(bool(contract))
@@ -372,7 +386,12 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
             if rays is None:
                 raise ValueError("nerf_amd: integrated PE needs an explicit ray table")
             camera.ipe, camera.ipe_radius = 1, float(ipe_radius)
-    N = u_strat.shape[0] if n_rays is None else n_rays
+        if in_kernel_rng:
+            camera.rng_seed, camera.rng_ray_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_ray_offset)
+    if n_rays is None:
+        N = u_strat.shape[0] if not in_kernel_rng else rays.shape[0]
+    else:
+        N = n_rays
     need = lib.nerf_amd_render_workspace_bytes(N, n_fine)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -65,9 +65,15 @@ class Adam(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
+        """torch.optim.Adam's format: every parameter's state carries its own 0-d CPU `step` tensor (the live state shares ONE device
+        counter between all tensors; written out as-is, torch's foreach step would increment that shared tensor once per parameter)."""
         sd = super().state_dict()
         for g in sd["param_groups"]:
             g.pop("_step_dev", None)
+        sd["state"] = {k: dict(v) for k, v in sd["state"].items()}
+        for st in sd["state"].values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
         return sd
 
     def load_state_dict(self, state_dict):

@@ -44,10 +44,17 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
                  near: float, far: float, sample_num: int = 128, white_bkg: bool = False, render_depth=False,
-                 render_normal=False, rng: str = "reference", contract: bool = False, ipe=False) -> dict:
+                 render_normal=False, rng: str = "philox", contract: bool = False, ipe=False) -> dict:
     """Whole-image inference (procedures.py:34-97) -> {"rgb" (3,H,W) [, "depth_img" (3,H,W)]} on
     ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference.
-    ``rng``, ``contract`` and ``ipe`` are additions: ``contract=True`` applies the Mip-NeRF 360 scene contraction to every sample
+    ``rng``, ``contract`` and ``ipe`` are additions.  ``rng``: where the stratified / inverse-CDF uniforms come from --
+      "philox" (default): drawn INSIDE the kernels, Philox4x32-10 keyed by one 62-bit seed taken from torch's CPU generator (so
+                 ``torch.manual_seed`` makes a render reproducible); no uniform tensor exists, the drop-in call runs at the kernels' rate;
+      "reference": the reference's own stream -- per tile one (sz,sz,64) then one (sz*sz, n+1) draw from the CPU default generator
+                 (procedures.py:65, utils.py:115) copied to the device: a seeded run reproduces the reference's image bit for bit in
+                 its uniforms (0.5 GB over PCIe per 800x800 image: ~1.4 M rays/s);
+      "device":  two torch.rand draws on the device generator.
+    ``contract=True`` applies the Mip-NeRF 360 scene contraction to every sample
     position before the networks encode it (unbounded scenes, BASELINE config 5; not available for Ref-NeRF).  ``ipe`` (BASELINE
     config 3): the fine network reads the integrated positional encoding of the conical frustum between consecutive fine depths
     (mip_methods.py:15-58: [mu | ipe_feature]) instead of the point encoding; True = the pixel radius 2/sqrt(12) pixel widths of
@@ -73,7 +80,12 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     if sz is not None:                                                             # reorder rays tile by tile
         pr, pc = patch_num
         rays = rays.view(H, W, 6)[: pr * sz].reshape(pr, sz, pc, sz, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
-    u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
+    seed = None
+    if rng == "philox" and sample_num <= 255 and not is_ref_model:
+        u_strat = u_inv = None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())                         # one draw from the CPU generator: torch.manual_seed governs it
+    else:
+        u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, "device" if rng == "philox" else rng)
     z_base = torch.linspace(near, far, RENDER_COARSE_PNUM, device="cpu").to(dev)   # procedures.py:52 (CPU linspace bits)
     normal_px = None
     ipe_radius = None
@@ -84,7 +96,7 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     if not is_ref_model:
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
                                            sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,
-                                           ipe_radius=ipe_radius)
+                                           ipe_radius=ipe_radius, seed=seed)
     else:
         if contract:
             raise NotImplementedError("nerf_amd: scene contraction is wired for the MipNeRF render path only")

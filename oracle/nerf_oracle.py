@@ -247,6 +247,45 @@ def max_blur(w: Tensor, alpha: float) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# in-kernel uniforms: Philox4x32-10 (Salmon et al. 2011), the counter layout of nerf_amd/csrc/device_common.h
+# --------------------------------------------------------------------------------------------
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """numpy uint32 arrays (broadcastable) -> four uint32 arrays.  Ten rounds; multipliers 0xD2511F53 / 0xCD9E8D57, key increments
+    0x9E3779B9 / 0xBB67AE85 (the paper's constants)."""
+    import numpy as np
+    u32, u64 = np.uint32, np.uint64
+    c0, c1, c2, c3 = (np.asarray(c, dtype=u32) for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = u32(k0), u32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = u64(0xD2511F53) * c0.astype(u64)
+            p1 = u64(0xCD9E8D57) * c2.astype(u64)
+            hi0, lo0 = (p0 >> u64(32)).astype(u32), p0.astype(u32)
+            hi1, lo1 = (p1 >> u64(32)).astype(u32), p1.astype(u32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0, k1 = u32((int(k0) + 0x9E3779B9) & 0xFFFFFFFF), u32((int(k1) + 0xBB67AE85) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def philox_uniforms(seed: int, n_rays: int, ray_offset: int = 0, S: int = 64, K: int = 129):
+    """The uniforms the HIP kernels draw when none are passed (include/nerf_amd.h, nerf_amd_samples.rng_seed):
+    u_strat (N, S): word s & 3 of Philox(key = seed, counter = (ray, s >> 2, 'ST'));  u_inv (N, K <= 256): word k >> 6 of
+    Philox(key = seed, counter = (ray, k & 63, 'IN')); ray = n + ray_offset as a 64-bit counter; value = (word >> 8) * 2^-24."""
+    import numpy as np
+    n = np.arange(n_rays, dtype=np.uint64) + np.uint64(ray_offset)
+    nlo, nhi = (n & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None], (n >> np.uint64(32)).astype(np.uint32)[:, None]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    s = np.arange(S, dtype=np.uint32)[None, :]
+    w = philox4x32_10(nlo, nhi, s >> np.uint32(2), np.uint32(0x5354), k0, k1)
+    us = np.choose((s & np.uint32(3)).astype(np.int64) + np.zeros((n_rays, 1), np.int64), w)
+    k = np.arange(K, dtype=np.uint32)[None, :]
+    w = philox4x32_10(nlo, nhi, k & np.uint32(63), np.uint32(0x494E), k0, k1)
+    ui = np.choose((k >> np.uint32(6)).astype(np.int64) + np.zeros((n_rays, 1), np.int64), w)
+    to_f = lambda x: torch.from_numpy(((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)))
+    return to_f(us), to_f(ui)
+
+
+# --------------------------------------------------------------------------------------------
 # row 7: inverse-transform sampling
 # --------------------------------------------------------------------------------------------
 def cascade_row_sum(x) -> "numpy.ndarray":

@@ -34,10 +34,11 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from nerf_amd import _lib
     # 8-byte alignment of the pointer members, 12 floats of pose at the end
-    assert ctypes.sizeof(_lib.Samples) == 8 + 8 + 8 + 4 + 4 + 8 * 4 + 4 + 4 + 4 + 4 + 4 + 48 + 4 + 4 + 4 + 8
+    assert ctypes.sizeof(_lib.Samples) == 8 + 8 + 8 + 4 + 4 + 8 * 4 + 4 + 4 + 4 + 4 + 4 + 48 + 4 + 4 + 4 + 8 + 8 + 8
     assert _lib.Samples.M.offset == 8 and _lib.Samples.pts.offset == 16 and _lib.Samples.rays.offset == 32
     assert _lib.Samples.pose.offset == 84 and _lib.Samples.contract.offset == 132      # the flag sits in the former tail padding
     assert _lib.Samples.ipe.offset == 136 and _lib.Samples.ipe_radius.offset == 140 and _lib.Samples.ipe_dir_norm.offset == 144
+    assert _lib.Samples.rng_seed.offset == 152 and _lib.Samples.rng_ray_offset.offset == 160
 
 
 def test_pure_queries_without_gpu():

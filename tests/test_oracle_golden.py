@@ -153,6 +153,26 @@ def test_cascade_row_sum_is_torchs_cpu_summation_order(n):
     assert (O.cascade_row_sum(x.numpy()) == want).all()
 
 
+def test_philox_known_answers_and_counter_layout():
+    """The oracle twin of the kernels' in-kernel uniform stream: Philox4x32-10 against the published known-answer vectors of the
+    Random123 distribution (counter / key all zeros and all ones), and the (ray, sample) -> counter layout of include/nerf_amd.h."""
+    import numpy as np
+    z, f = np.uint32([0]), np.uint32([0xFFFFFFFF])
+    assert [int(x[0]) for x in O.philox4x32_10(z, z, z, z, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(x[0]) for x in O.philox4x32_10(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    seed, off = 0x0123456789ABCDEF, 5_000_000_000                          # a ray counter beyond 32 bits
+    us, ui = O.philox_uniforms(seed, 3, off, 64, 200)
+    for n, s in ((0, 0), (1, 7), (2, 63)):
+        w = O.philox4x32_10(np.uint32([(off + n) & 0xFFFFFFFF]), np.uint32([(off + n) >> 32]), np.uint32([s >> 2]), np.uint32([0x5354]),
+                            seed & 0xFFFFFFFF, seed >> 32)
+        assert float(us[n, s]) == float((int(w[s & 3][0]) >> 8) * 2.0 ** -24)
+    for n, k in ((0, 0), (1, 64), (2, 199)):
+        w = O.philox4x32_10(np.uint32([(off + n) & 0xFFFFFFFF]), np.uint32([(off + n) >> 32]), np.uint32([k & 63]), np.uint32([0x494E]),
+                            seed & 0xFFFFFFFF, seed >> 32)
+        assert float(ui[n, k]) == float((int(w[k >> 6][0]) >> 8) * 2.0 ** -24)
+    assert float(us.min()) >= 0.0 and float(us.max()) < 1.0
+
+
 def test_g14_train_step_forward_and_losses(golden):
     """Forward half of train.py:164-199 (non-ref): softplus'd proposal density, bounds, losses."""
     g1, g = golden("g01_raygen"), golden("g14_train_step")
