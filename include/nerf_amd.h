@@ -187,6 +187,15 @@ int nerf_amd_sample_pdf(const float* bins, const float* weights, const float* u,
  * (col - W//2, H//2 - row) from randomFromOneImage -> rays (N,6). */
 int nerf_amd_pixel_rays(const float* pose_host, float fx, float fy, const int64_t* coords, int64_t N, float* rays, void* stream);
 
+/* validSampler (utils.py:72-94) with every random number drawn in the kernel: N rays through uniformly drawn pixels of
+ * the flattened pixel table rgbs (n_pixels,3) / coords (n_pixels,2) int64 of randomFromOneImage, their ground-truth colours rgb (N,3),
+ * rays (N,6) = [pose[:,3] | R.c], and -- when pts / lengths are given -- C stratified depths lengths (N,C) = linspace(near, far - res, C)
+ * + u res, res = (far-near)/C, with the positions pts (N,C,3).  Uniforms: Philox4x32-10 keyed by rng_seed; pixel index of ray n =
+ * floor(n_pixels * u64 / 2^64) of counter (n, 0, 'IX'), depth uniform = word s&3 of counter (n, s>>2, 'TS'). */
+int nerf_amd_sample_training_rays(const float* rgbs, const int64_t* coords, int64_t n_pixels, const float* pose_host, float fx, float fy,
+                                  float near, float far, int64_t N, int C, uint64_t rng_seed, float* pts, float* lengths, float* rgb,
+                                  float* rays, void* stream);
+
 /* Stratified depths and points (utils.py:87-90, procedures.py:65-66): z = z_base[s] + u*z_jitter (N,S);
  * pts (N,S,3) = o + d*z, or NULL to skip. */
 int nerf_amd_stratified_points(const float* rays, const float* z_base, const float* u, float z_jitter, int64_t N, int S,

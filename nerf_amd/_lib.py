@@ -52,6 +52,8 @@ SIGNATURES = {
     "nerf_amd_inverse_sample": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_sample_pdf": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
     "nerf_amd_pixel_rays": (C.c_int, [c_float_p, C.c_float, C.c_float, c_void, i64, c_void, c_void]),
+    "nerf_amd_sample_training_rays": (C.c_int, [c_void, c_void, i64, c_float_p, C.c_float, C.c_float, C.c_float, C.c_float, i64, C.c_int, C.c_uint64,
+                                               c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_stratified_points": (C.c_int, [c_void, c_void, c_void, C.c_float, i64, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_resample": (C.c_int, [c_void, c_void, c_void, c_void, C.c_float, c_void, C.c_int, c_void, i64, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_uint64, i64, c_void, c_void, c_void, c_void, c_void]),

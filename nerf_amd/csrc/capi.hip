@@ -37,6 +37,8 @@ int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
 int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
 int sk_dirs_norm(const float*, int64_t, float*, hipStream_t);
+int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, float, float, float, float, int64_t, int, uint64_t, float*, float*, float*,
+                     float*, hipStream_t);
 int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
 int sk_length2pts(const float*, const float*, int64_t, int, float*, hipStream_t);
@@ -243,6 +245,16 @@ int nerf_amd_sample_pdf(const float* bins, const float* weights, const float* u,
 int nerf_amd_pixel_rays(const float* pose_host, float fx, float fy, const int64_t* coords, int64_t N, float* rays, void* stream) {
     if (!pose_host || N < 0 || (N && (!coords || !rays))) return fail(NERF_AMD_EINVAL, "bad argument");
     return hip_status(sk_pixel_rays(pose_host, fx, fy, coords, N, rays, S(stream)), "nerf_amd_pixel_rays");
+}
+
+int nerf_amd_sample_training_rays(const float* rgbs, const int64_t* coords, int64_t n_pixels, const float* pose_host, float fx, float fy,
+                                  float near, float far, int64_t N, int C, uint64_t rng_seed, float* pts, float* lengths, float* rgb, float* rays,
+                                  void* stream) {
+    if (N < 0 || C < 0 || n_pixels < 1) return fail(NERF_AMD_EINVAL, "bad size");
+    if (!pose_host || (N && (!rgbs || !coords || !rgb || !rays))) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if ((pts == nullptr) != (lengths == nullptr) || (pts && C < 1)) return fail(NERF_AMD_EINVAL, "pts and lengths go together (C >= 1)");
+    return hip_status(sk_train_sampler(rgbs, coords, n_pixels, pose_host, fx, fy, near, far, N, C, rng_seed, pts, lengths, rgb, rays, S(stream)),
+                      "nerf_amd_sample_training_rays");
 }
 
 int nerf_amd_stratified_points(const float* rays, const float* z_base, const float* u, float z_jitter, int64_t N, int Sn,

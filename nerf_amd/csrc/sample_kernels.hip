@@ -146,6 +146,54 @@ __global__ void stratified_points_kernel(const float* __restrict__ rays, const f
     }
 }
 
+// ---------------------------------------------------------------------------------------- training sampler
+// validSampler (utils.py:72-94) in ONE launch with every random number drawn in the kernel: pixel index of ray n = floor(P * u) from
+// Philox stream 'IX', ground-truth colour gather, ray through the pixel (utils.py:78-85), stratified depths z = base_s + u * res from
+// stream 'TS' (utils.py:87-89) and the sample positions o + d z (utils.py:90).  The reference draws both on the CPU generator and
+// copies them to the device every iteration (train.py:153-157).  One workgroup = 4 rays x C samples.
+constexpr uint32_t PHILOX_STREAM_INDEX = 0x4958u, PHILOX_STREAM_TRAIN = 0x5453u;
+__global__ __launch_bounds__(256) void train_sampler_kernel(const float* __restrict__ rgbs, const int64_t* __restrict__ coords, int64_t P, Cam cam,
+                                                            float near, float res, int64_t N, int C, uint64_t seed, float* __restrict__ pts,
+                                                            float* __restrict__ lengths, float* __restrict__ rgb, float* __restrict__ rays) {
+    __shared__ float ray_s[4][6];
+    for (int64_t n0 = blockIdx.x * (int64_t)4; n0 < N; n0 += (int64_t)gridDim.x * 4) {
+        __syncthreads();
+        if (threadIdx.x < 4 && n0 + threadIdx.x < N) {
+            const int64_t n = n0 + threadIdx.x;
+            const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), 0u, PHILOX_STREAM_INDEX, (uint32_t)seed, (uint32_t)(seed >> 32));
+            const uint64_t x = ((uint64_t)r.w[0] << 32) | r.w[1];
+            const int64_t idx = (int64_t)__umul64hi(x, (uint64_t)P);                     // uniform in [0, P)
+            const float cx = ((float)coords[idx * 2] + 0.5f) / cam.fx;                   // utils.py:78-81
+            const float cy = ((float)coords[idx * 2 + 1] + 0.5f) / cam.fy;
+            float* q = ray_s[threadIdx.x];
+            q[0] = cam.pose[3]; q[1] = cam.pose[7]; q[2] = cam.pose[11];
+            q[3] = (cx * cam.pose[0] + cy * cam.pose[1]) + (-1.0f) * cam.pose[2];
+            q[4] = (cx * cam.pose[4] + cy * cam.pose[5]) + (-1.0f) * cam.pose[6];
+            q[5] = (cx * cam.pose[8] + cy * cam.pose[9]) + (-1.0f) * cam.pose[10];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rays[n * 6 + k] = q[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgb[n * 3 + k] = rgbs[idx * 3 + k];
+        }
+        __syncthreads();
+        if (lengths == nullptr) continue;
+        const int64_t cnt = ((N - n0 < 4) ? N - n0 : 4) * C;
+        for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+            const int rl = (int)(i / C), sidx = (int)(i - (int64_t)rl * C);
+            const int64_t n = n0 + rl;
+            const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)(sidx >> 2), PHILOX_STREAM_TRAIN, (uint32_t)seed,
+                                            (uint32_t)(seed >> 32));
+            const int w = sidx & 3;
+            const float u = u01_from_bits(w == 0 ? r.w[0] : (w == 1 ? r.w[1] : (w == 2 ? r.w[2] : r.w[3])));
+            const float z = (near + (float)sidx * res) + u * res;                        // linspace(near, far - res, C)[s] + u res
+            lengths[n * C + sidx] = z;
+            const float* q = ray_s[rl];
+            float* o = pts + (n * C + sidx) * 3;
+            o[0] = q[0] + q[3] * z; o[1] = q[1] + q[4] * z; o[2] = q[2] + q[5] * z;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- row 8
 __global__ void length2pts_kernel(const float* __restrict__ rays, const float* __restrict__ z, int64_t N, int S,
                                   float* __restrict__ out) {
@@ -1072,6 +1120,15 @@ int sk_cone_parameters(const float* z, int64_t N, int Sn, float r2, float* mu_t,
 }
 int sk_dirs_norm(const float* rays, int64_t N, float* out, hipStream_t st) {
     hipLaunchKernelGGL(dirs_norm_kernel, dim3(1), dim3(1024), 0, st, rays, N, out);
+    return (int)hipGetLastError();
+}
+int sk_train_sampler(const float* rgbs, const int64_t* coords, int64_t P, const float* pose, float fx, float fy, float near, float far, int64_t N, int C,
+                     uint64_t seed, float* pts, float* lengths, float* rgb, float* rays, hipStream_t st) {
+    if (N == 0) return 0;
+    Cam c; c.H = 0; c.W = 0; c.fx = fx; c.fy = fy;
+    for (int i = 0; i < 12; ++i) c.pose[i] = pose[i];
+    hipLaunchKernelGGL(train_sampler_kernel, dim3(blocks_for(N, 4)), dim3(256), 0, st, rgbs, coords, P, c, near, C > 0 ? (far - near) / (float)C : 0.0f, N, C, seed,
+                       pts, lengths, rgb, rays);
     return (int)hipGetLastError();
 }
 int sk_generate_rays(const float* pose, int H, int W, float fx, float fy, int64_t first, int64_t count, float* rays,

@@ -282,6 +282,26 @@ def pixel_rays(coords: torch.Tensor, pose: torch.Tensor, fx: float, fy: float) -
     return rays
 
 
+def sample_training_rays(rgbs: torch.Tensor, coords: torch.Tensor, pose: torch.Tensor, fx: float, fy: float, near: float, far: float, n_rays: int,
+                         n_points: int, seed: int, want_samples: bool = True):
+    """validSampler (utils.py:72-94) in one launch, random numbers drawn in the kernel (Philox, `seed`).
+    -> (pts (N,C,3) | None, lengths (N,C) | None, rgb (N,3), rays (N,6))"""
+    rgbs = _dev(rgbs, "rgbs")
+    if not coords.is_cuda:
+        raise RuntimeError("nerf_amd: 'coords' must live on the HIP device")
+    coords = coords.to(torch.int64).contiguous()
+    dev = rgbs.device
+    host = (C.c_float * 12)(*pose.detach().float().cpu().reshape(-1).tolist()[:12])
+    pts = torch.empty((n_rays, n_points, 3), dtype=torch.float32, device=dev) if want_samples else None
+    z = torch.empty((n_rays, n_points), dtype=torch.float32, device=dev) if want_samples else None
+    rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    rays = torch.empty((n_rays, 6), dtype=torch.float32, device=dev)
+    check(lib.nerf_amd_sample_training_rays(_ptr(rgbs), _ptr(coords), coords.shape[0], host, float(fx), float(fy), float(near), float(far), n_rays,
+                                            n_points, int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(pts), _ptr(z), _ptr(rgb), _ptr(rays), _stream()),
+          "nerf_amd_sample_training_rays")
+    return pts, z, rgb, rays
+
+
 def stratified_points(rays: torch.Tensor, z_base: torch.Tensor, u: torch.Tensor, jitter: float, want_pts: bool = True):
     rays, z_base, u = _dev(rays, "rays"), _dev(z_base, "z_base"), _dev(u, "u")
     N, S = u.shape

@@ -50,30 +50,51 @@ def sample_pdf(bins, weights, N_samples, u: torch.Tensor = None):
     return ops.sample_pdf(bins, weights, u.to(bins.device))
 
 
+_COORD_TABLES = {}
+
+
 def randomFromOneImage(img: torch.Tensor, crop_xy: tuple):
     """Flattened pixel table and integer (col - W//2, H//2 - row) coordinates, optionally centre-cropped
-    (utils.py:47-69).  Pure indexing -- stays a torch gather on the image's device."""
+    (utils.py:47-69).  Pure indexing -- stays a torch gather on the image's device.  The coordinate table depends only on
+    (H, W, crop, device): it is built once and cached (the reference rebuilds a full H x W meshgrid on the CPU and copies it to the
+    device every training iteration, train.py:153-157)."""
     if img.dim() > 3:
         img = img.squeeze(0)
     H, W = img.shape[1], img.shape[2]
     hw, hh = W // 2, H // 2
     x0, x1 = (int(hw * (1. - crop_xy[0])), int(hw + hw * crop_xy[0])) if crop_xy[0] < 9.9e-1 else (0, W)
     y0, y1 = (int(hh * (1. - crop_xy[1])), int(hh + hh * crop_xy[1])) if crop_xy[1] < 9.9e-1 else (0, H)
-    rows, cols = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing='ij')
-    coords = torch.stack((cols - hw, hh - rows), dim=-1).to(img.device).view(-1, 2)
+    key = (H, W, x0, x1, y0, y1, str(img.device))
+    hit = _COORD_TABLES.get(key)
+    if hit is None:
+        rows, cols = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing='ij')
+        coords = torch.stack((cols - hw, hh - rows), dim=-1).to(img.device).view(-1, 2)
+        hit = (rows.to(img.device), cols.to(img.device), coords)
+        if len(_COORD_TABLES) > 64:
+            _COORD_TABLES.clear()
+        _COORD_TABLES[key] = hit
+    rows, cols, coords = hit
     if crop_xy[0] < 9.9e-1 or crop_xy[1] < 9.9e-1:
         return img[:, rows, cols].view(3, -1).transpose(0, 1).contiguous(), coords
     return img.view(3, -1).transpose(0, 1).contiguous(), coords
 
 
 def validSampler(rgbs: torch.Tensor, coords: torch.Tensor, cam_tf: torch.Tensor, ray_num: int, point_num: int, focal,
-                 near: float, far: float, output_samples=True):
+                 near: float, far: float, output_samples=True, rng: str = "philox"):
     """Random training rays + stratified coarse samples (utils.py:72-94).
-    -> (pts (N,C,3), lengths (N,C), rgb (N,3), rays (N,6)) or (rgb, rays)."""
+    -> (pts (N,C,3), lengths (N,C), rgb (N,3), rays (N,6)) or (rgb, rays).
+    ``rng`` (an addition): "philox" (default) = ONE kernel launch, pixel indices and depth jitter drawn inside it from a seed taken
+    off torch's CPU generator (reproducible under torch.manual_seed; nothing crosses PCIe); "reference" = the reference's own stream
+    (torch.randint then torch.rand on the CPU default generator, copied to the device) for seeded bit-comparisons with it."""
     dev = rgbs.device
+    fx, fy = _focal_xy(focal)
+    if rng == "philox":
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        pts, z, rgb, rays = ops.sample_training_rays(rgbs, coords, cam_tf, fx, fy, near, far, ray_num, point_num if output_samples else 0, seed,
+                                                     want_samples=bool(output_samples))
+        return (pts, z, rgb, rays) if output_samples else (rgb, rays)
     idx = torch.randint(0, coords.shape[0], (ray_num,)).to(dev)                  # CPU generator, like the reference
     rgb = rgbs[idx]
-    fx, fy = _focal_xy(focal)
     rays = ops.pixel_rays(coords[idx], cam_tf, fx, fy)
     if not output_samples:
         return rgb, rays

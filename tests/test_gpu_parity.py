@@ -78,14 +78,46 @@ def test_valid_sampler_matches_reference_rng(A, golden):
     g1, g = golden("g01_raygen"), golden("g02_stratified")
     torch.manual_seed(5)
     pts, z, rgb, rays = A.utils.validSampler(dev(g1["pix"]), dev(g1["coords"]), dev(g1["pose"]), 8, 32,
-                                             tuple(g1["focal_tuple"].tolist()), NEAR, FAR, True)
+                                             tuple(g1["focal_tuple"].tolist()), NEAR, FAR, True, rng="reference")
     assert torch.equal(z.cpu(), g["z_train"]) and torch.equal(rgb.cpu(), g["rgb_train"])
     assert max_abs(rays.cpu(), g["rays_train"]) <= 1e-6
     assert max_abs(pts.cpu(), g["pts_train"]) <= 1e-5
     torch.manual_seed(11)
     rgb2, rays2 = A.utils.validSampler(dev(g1["pix"]), dev(g1["coords"]), dev(g1["pose"]), 16, 32,
-                                       tuple(g1["focal_tuple"].tolist()), NEAR, FAR, False)
+                                       tuple(g1["focal_tuple"].tolist()), NEAR, FAR, False, rng="reference")
     assert torch.equal(rgb2.cpu(), g1["sampler_rgb"]) and max_abs(rays2.cpu(), g1["sampler_rays"]) <= 1e-6
+
+
+def test_valid_sampler_in_kernel_rng(A, golden):
+    """The default validSampler draws pixel indices and depth jitter inside ONE kernel (nerf_amd_sample_training_rays, Philox):
+    every output is consistent with the reference's definitions for the pixels it drew (utils.py:78-90) -- colour = that pixel's,
+    ray = the ray through it (same kernel arithmetic as the reference-stream path), depths stratified in their bins, pts = o + d z --
+    it replays under torch.manual_seed, and the pixel draw is uniform over the table."""
+    g1 = golden("g01_raygen")
+    pix, coords, pose = dev(g1["pix"]), dev(g1["coords"]), dev(g1["pose"])
+    focal = tuple(g1["focal_tuple"].tolist())
+    N, C = 3001, 48
+    torch.manual_seed(9)
+    pts, z, rgb, rays = A.utils.validSampler(pix, coords, pose, N, C, focal, NEAR, FAR, True)
+    torch.manual_seed(9)
+    pts2, z2, rgb2, rays2 = A.utils.validSampler(pix, coords, pose, N, C, focal, NEAR, FAR, True)
+    assert all(torch.equal(a, b) for a, b in ((pts, pts2), (z, z2), (rgb, rgb2), (rays, rays2)))
+    rgb3, rays3 = A.utils.validSampler(pix, coords, pose, N, C, focal, NEAR, FAR, False)
+    assert rgb3.shape == (N, 3) and rays3.shape == (N, 6) and not torch.equal(rays3, rays)          # (the next seed of the CPU stream)
+    # which pixel did ray n take?  invert the ray: the table's rays are distinct
+    table = A.ops.pixel_rays(coords, pose, float(focal[1]), float(focal[0]))
+    d2 = torch.cdist(rays[:, 3:].double(), table[:, 3:].double())
+    idx = d2.argmin(dim=1)
+    assert float(d2.gather(1, idx[:, None]).max()) == 0.0 and torch.equal(rays, table[idx]) and torch.equal(rgb, pix[idx])
+    res = (FAR - NEAR) / C
+    base = NEAR + res * torch.arange(C, device="cuda", dtype=torch.float32)
+    assert bool((z >= base - 1e-6).all()) and bool((z < base + res + 1e-6).all())
+    assert max_abs(pts, rays[:, None, :3] + rays[:, None, 3:] * z[:, :, None]) <= 1e-6
+    # uniformity of the pixel draw and of the jitter (chi-square over 16 index bins, KS on the jitter)
+    from scipy import stats
+    counts = torch.bincount((idx * 16 // coords.shape[0]).cpu(), minlength=16).double().numpy()
+    assert stats.chisquare(counts).pvalue > 1e-3
+    assert stats.kstest(((z - base) / res).clamp(0, 1).cpu().double().numpy().ravel(), "uniform").pvalue > 1e-3
 
 
 def test_positional_encoding(A, golden):

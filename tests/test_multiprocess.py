@@ -117,3 +117,91 @@ def test_bench_refuses_fewer_ranks_than_asked():
         assert r.returncode != 0 and "needs 2 visible devices" in r.stderr
     r = _bench("--gpus", "2", "--launch-check", env={"WORLD_SIZE": "4", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ model-averaging primitives (param_com)
+def _pc_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_amd import param_com as pc
+        from nerf_amd.addtional import ProposalNetwork
+
+        def model(fill):
+            m = ProposalNetwork(10, 256)
+            with torch.no_grad():
+                for i, p in enumerate(m.parameters()):
+                    p.fill_(fill + 0.001 * i)
+            return m
+        vals = lambda m: [float(p.flatten()[0]) for p in m.parameters()]
+        res = {}
+        m = model(float(rank + 1))
+        pc.param_broadcast(m, src_rank=1)
+        res["bcast"] = vals(m)
+        m = model(float(rank + 1))
+        pc.param_all_reduce(m)
+        res["allred"] = vals(m)
+        m = model(float(rank + 1))
+        pc.param_reduce(m, [0.25, 0.75], rank, dst_rank=0)
+        res["reduce"] = vals(m)
+        m, tmp = model(float(rank + 1)), model(0.0)
+        if rank == 0:
+            pc.param_recv_avg(m, tmp, [0.25, 0.75], [1], self_rank=0)
+            res["avg"], res["tmp"] = vals(m), vals(tmp)
+            pc.param_send(m, [1])
+        else:
+            pc.param_send(m, [0])
+            pc.param_recv(m, 0)
+            res["recv"] = vals(m)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_param_com_matches_the_references_per_tensor_semantics():
+    """param_com.py:13-54: every primitive moves a model as ONE flat message here; the resulting parameter values are those of the
+    reference's per-tensor calls (computed by hand below for 2 ranks whose parameter i is rank + 1 + 0.001 i)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    n = 10
+    base = lambda r: [r + 1 + 0.001 * i for i in range(n)]
+    close = lambda a, b: all(abs(x - y) < 1e-5 for x, y in zip(a, b))
+    for r in (0, 1):
+        assert close(out[r]["bcast"], base(1))
+        assert close(out[r]["allred"], [a + b for a, b in zip(base(0), base(1))])
+    assert close(out[0]["reduce"], [0.25 * a + 0.75 * b for a, b in zip(base(0), base(1))])       # dst holds the weighted sum
+    assert close(out[1]["reduce"][:1], [0.75 * base(1)[0]])                                        # a source keeps its weighted copy
+    avg = [0.25 * a + 0.75 * b for a, b in zip(base(0), base(1))]
+    assert close(out[0]["avg"], avg) and close(out[0]["tmp"], base(1)) and close(out[1]["recv"], avg)
+
+
+def test_local_shuffle_sampler_partitions():
+    """local_shuffler.py:19-92: contiguous equal parts (remainder to the last), seeded per-epoch shuffles of the rank's OWN part,
+    truncated to the smallest part."""
+    from nerf_amd.local_shuffler import LocalShuffleSampler
+    data = list(range(10))
+    s = [LocalShuffleSampler(data, 3, rank=r, seed=7) for r in range(3)]
+    assert [x.samples[x.rank] for x in s] == [[0, 1, 2], [3, 4, 5], [6, 7, 8, 9]]
+    assert all(len(x) == 3 for x in s)
+    e0 = [list(x) for x in s]
+    assert all(set(idx) <= set(x.samples[x.rank]) and len(idx) == 3 for idx, x in zip(e0, s))
+    assert [list(x) for x in s] == e0                                   # same epoch, same order
+    for x in s:
+        x.set_epoch(1)
+    assert [list(x) for x in s] != e0
+    t = LocalShuffleSampler(data, [0, 1, 1, 0, 1, 1, 1, 0, 1, 1], rank=1, allow_imbalance=True)
+    assert sorted(list(t)) == [1, 2, 4, 5, 6, 8, 9] and len(t) == 7
+    assert list(LocalShuffleSampler(data, 2, rank=0, shuffle=False)) == data
+    with pytest.raises(ValueError):
+        LocalShuffleSampler(data, 2, rank=2)
