@@ -294,6 +294,27 @@ int    nerf_amd_proposal_weight_grads(int precision, int64_t M, const void* act_
                                       float* const* d_biases, void* workspace, void* stream);
 int    nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* weights,
                                  const float* const* biases, float* const* d_weights, float* const* d_biases, void* workspace, void* stream);
+/* Ref-NeRF training (ref_model.py:68-143, train.py:176-199).
+ *   nerf_amd_ref_forward_train_dump: nerf_amd_ref_forward_train + the activation dump (nerf_amd_train_dump_bytes(NERF_AMD_NET_REF, ..))
+ *     and aux (M,16) fp32 = the pre-activation head values the backward's element-wise stage needs.
+ *   nerf_amd_density_grad: RefNeRF.get_grad's gradient (ref_model.py:119-125 before the normalisation) -- d density / d position of
+ *     every sample, times scale[m * scale_stride] when `scale` is given -- for the proposal network (train.py:165-168) or Ref-NeRF's
+ *     spatial network (train.py:178): a dgrad-only chain from the density row through the hidden layers (ReLU masks from the dump)
+ *     to the encoded position, then the positional encoding's derivative.  x (M, x_stride >= 3) = the sample positions.
+ *   nerf_amd_ref_backward: every parameter gradient.  g_out (M, g_stride >= 7) = the gradient w.r.t. [rgb 3 | raw density 1 |
+ *     predicted normal 3]; dirs = the view directions the forward saw; ide_table = the (9,19) table given to nerf_amd_pack_weights.
+ *     d_weights / d_biases: 20 tensors each -- 0..7 spa_block1.{0,2,4,6}, spa_block2.{0,2,4,6}; 8 bottle_neck; 9 norm_col_tint_head;
+ *     10 rho_tau_head; 11..18 dir_block1.{0,2,4,6}, dir_block2.{0,2,4,6}; 19 spec_rgb_head.0 -- (out, in) row-major, fully overwritten.
+ *   packed_bwd: nerf_amd_pack_weights_backward(NERF_AMD_NET_REF, ...) with the 20 tensors of nerf_amd_pack_weights. */
+int    nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo,
+                                       float* normal, void* dump, float* aux, void* stream);
+size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M);
+int    nerf_amd_density_grad(int net, const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* x, int x_stride,
+                             const float* scale, int scale_stride, float* grad, void* workspace, void* stream);
+size_t nerf_amd_ref_backward_workspace_bytes(int precision, int64_t M);
+int    nerf_amd_ref_backward(const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* aux, const float* dirs,
+                             int dir_stride, const float* g_out, int g_stride, const float* ide_table, float* const* d_weights,
+                             float* const* d_biases, void* workspace, void* stream);
 int    nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                           const int64_t* numel, int n_tensors, float* step, double lr, double beta1, double beta2, double eps,
                           float grad_scale, void* stream);

@@ -82,6 +82,12 @@ SIGNATURES = {
     "nerf_amd_proposal_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_mip_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void),
                                            C.POINTER(c_void), c_void, c_void]),
+    "nerf_amd_ref_forward_train_dump": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_density_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, i64]),
+    "nerf_amd_density_grad": (C.c_int, [C.c_int, c_void, C.c_int, i64, c_void, c_void, C.c_int, c_void, C.c_int, c_void, c_void, c_void]),
+    "nerf_amd_ref_backward_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
+    "nerf_amd_ref_backward": (C.c_int, [c_void, C.c_int, i64, c_void, c_void, c_void, C.c_int, c_void, C.c_int, c_void, C.POINTER(c_void),
+                                       C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_adam_step": (C.c_int, [C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(i64), C.c_int, c_void,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, c_void]),
     "nerf_amd_sigma_to_weights_backward": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void]),

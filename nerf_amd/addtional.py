@@ -93,10 +93,13 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         params = [l.weight for l in layers] + [l.bias for l in layers]
         if ab.needs_grad(pts, *params):
             expr = lambda p, *wb: ab.proposal_expr(p, wb[:5], wb[5:])
-            if pts.requires_grad or pts.numel() == 0:                      # (gradients w.r.t. positions: torch VJP of the expression)
+            if pts.numel() == 0:
                 hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p)
                 return ab.HipOp.apply(hip, expr, 0, pts, *params)
-            # parameter gradients: the training forward dumps the hidden activations, the backward is a GEMM chain on them
+            # the training forward dumps the hidden activations; the backward is hand-written kernels on them:
+            #   parameter gradients: fused dgrad chain + MFMA weight gradients (mlp_backward.py);
+            #   RefNeRF.get_grad (train.py:165-168 with prop_normal: d density / d position): a dgrad-only chain down to the encoded
+            #   position + the encoding's derivative (nerf_amd_density_grad).  The positions get a gradient only there.
             from . import mlp_backward
             held = {}
 
@@ -107,8 +110,12 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
             def bwd(g, p, *wb):
                 if "dump" not in held:
                     raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
-                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5],
-                                                        packed_bwd=self.packed_backward(prec))
+                if "bwd_blob" not in held:
+                    held["bwd_blob"] = self.packed_backward(prec)
+                if ab._VJP.inputs_only:
+                    gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1))
+                    return (gx.view(p.shape), *[None] * len(wb))
+                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5], packed_bwd=held["bwd_blob"])
                 return (None, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts)

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
     using L = PropBwdLayout;
     using BReg = typename P::BReg;
     WeightStream<P, MLP_NSLOT, false> ws;
-    bwd_prologue<P>(ws, packed, L::N_FRAGS);
+    bwd_prologue<P>(ws, packed, L::CHAIN_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
     constexpr int NT = P::NT;
@@ -236,6 +236,238 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
 }
 
 // ================================================================================================
+// One dgrad layer as its own launch (Ref-NeRF's backward and the density-gradient chains):
+//   out = W^T . x over all samples, x read from a fragment dump (or the constant "ones" head), W^T streamed through the LDS ring;
+//   MASK:  out *= [y > 0] with y from the training forward's dump, written as the next fragment dump (hidden layers);
+//   !MASK: out written (or accumulated) as row-major fp32 -- the gradient w.r.t. a layer INPUT that is not a hidden activation
+//          (the encoded position, Ref-NeRF's directional input vector), in the reference's column order.
+// The fused chains above keep delta in registers across layers; Ref-NeRF's backward has per-sample math between its stages (the
+// integrated directional encoding, normals, the heads), small batches, and two skip layers feeding side outputs, so it is built
+// from these single-layer launches: 1.5 KiB of HBM traffic per sample and layer instead of 1 KiB.
+// ================================================================================================
+struct LayerIO {
+    const char* x0; int kgx0; const char* x1;               // input K groups [0, kgx0) at x0 + kg*BREG, the rest at x1 + (kg - kgx0)*BREG
+    unsigned long long x_sub_stride;                         // bytes between subtiles of x0 / x1 (16 K groups)
+    int ones_head;                                           // != 0: the input is ONE K group whose slot feature 0 is `1` for every sample
+    const char* mask; char* out;                             // MASK: forward activations / delta out, K group kg at + kg*BREG, subtile stride below
+    unsigned long long io_sub_stride;
+    float* rows; int ld; int accumulate;                     // !MASK: rows[m * ld + feature] (= or +=), ld >= 32 NFB and a multiple of 4
+};
+
+template <class P, int NKG>
+struct StreamMaskedOut {                                     // MaskedOut without the register buffer (nothing follows in this launch)
+    const char* mask; char* out; unsigned long long sub_stride;
+    int64_t sub0; int lane; uint32_t mask_lds;
+    DEVINL void begin_group(int G) const {
+        if (G == 0) vm_wait<0>(); else vm_wait<mask_wait_count<P>(NKG)>();
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int t = 0; t < P::NT; ++t) {
+                    const int kg = 2 * (2 * G + blk) + half;
+                    const char* src = mask + (size_t)(sub0 + t) * sub_stride + (size_t)kg * P::BREG_LDS + lane * 16;
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(mask_lds + (G & 1) * bwd_pair_bytes<P>() + ((blk * 2 + half) * P::NT + t) * P::BREG_LDS);
+#pragma unroll
+                    for (int p = 0; p < P::BREG_LDS / 1024; ++p) glds_piece(src + p * 1024, dst + p * 1024);
+                }
+    }
+    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
+        const typename P::BReg d = to_breg_half<P, false>(acc, half);
+        const uint32_t at = mask_lds + ((fb >> 1) & 1) * bwd_pair_bytes<P>() + (((fb & 1) * 2 + half) * P::NT + t) * P::BREG_LDS + lane * 16;
+        const typename P::BReg v = relu_mask(d, P::unstash(at));
+        P::store_global(out + (size_t)(sub0 + t) * sub_stride + (size_t)(2 * fb + half) * P::BREG_LDS, lane, v);
+    }
+};
+struct RowsOut {                                             // accumulators 8 half .. 8 half + 7 of block fb = features 32 fb + 8 (2 half + q) + 4 h + 0..3
+    float* rows; int ld; int accumulate; int64_t m0; int j, h; int64_t M;
+    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
+        const int64_t m = m0 + t * 32 + j;
+        if (m >= M) return;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4* p = reinterpret_cast<f32x4*>(rows + m * ld + 32 * fb + 8 * (2 * half + q) + 4 * h);
+            f32x4 v = {acc[8 * half + 4 * q], acc[8 * half + 4 * q + 1], acc[8 * half + 4 * q + 2], acc[8 * half + 4 * q + 3]};
+            if (accumulate) { const f32x4 o = *p; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+            *p = v;
+        }
+    }
+};
+
+template <class P, int NKG, int NFB, bool MASK>
+__global__ __launch_bounds__(P::NW * 64) void dgrad_layer_kernel(const void* __restrict__ packed_layer, int n_frags, LayerIO io, int64_t M) {
+    using BReg = typename P::BReg;
+    WeightStream<P, MLP_NSLOT, false> ws;
+    bwd_prologue<P>(ws, packed_layer, n_frags);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        BReg x[NT][NKG];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) {
+                if (io.ones_head) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) P::set(x[t][k], e, (k == 0 && e == 0 && h == 0) ? 1.0f : 0.0f);
+                } else {
+                    const char* src = (k < io.kgx0 ? io.x0 + (size_t)k * P::BREG_LDS : io.x1 + (size_t)(k - io.kgx0) * P::BREG_LDS) +
+                                      (size_t)(sub0 + t) * io.x_sub_stride;
+                    x[t][k] = P::load_global(src, lane);
+                }
+            }
+        auto IN = [&](int kg, int t) -> BReg { return x[t][kg]; };
+        if constexpr (MASK) {
+            const StreamMaskedOut<P, NKG> O{io.mask, io.out, io.io_sub_stride, sub0, lane, mask_lds};
+            auto d = dense<P, NKG, NFB, 0>(ws, BWD_LDS_ZERO, IN, O, NoPrev{});
+            vm_wait<mask_wait_count<P>(NKG)>();
+            d.flush(O);
+        } else {
+            const RowsOut O{io.rows, io.ld, io.accumulate, sub0 * 32, j, h, M};
+            auto d = dense<P, NKG, NFB, 0>(ws, BWD_LDS_ZERO, IN, O, NoPrev{});
+            d.flush(O);
+        }
+    }
+    ws.drain();
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise stages of the chains
+// where slot feature f < 16 of a one-K-group fragment lives: lane j + 32 ((f % 8) / 4), element 4 (f / 8) + f % 4   (the D map, kg = 0)
+template <int ELEM>
+DEVINL void store_slot_feature(char* block, int j, int f, float v) {
+    const int lane = j + 32 * ((f & 7) >> 2), e = 4 * (f >> 3) + (f & 3);
+    if (ELEM == 2) reinterpret_cast<__bf16*>(block)[lane * 8 + e] = (__bf16)v;
+    else reinterpret_cast<float*>(block)[(e >> 2) * 256 + lane * 4 + (e & 3)] = v;
+}
+DEVINL float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// gradient of the positional encoding (nerf_helper.py:38-48 with cat_origin): d_enc (M, ld) in the reference's column order
+// [x y z | sin 2^0 xyz | cos 2^0 xyz | ...] -> dx_c = d[c] + sum_f 2^f (cos(2^f x_c) d_sin - sin(2^f x_c) d_cos), times scale[m]
+__global__ void pe_grad_kernel(const float* __restrict__ d_enc, int ld, const float* __restrict__ x, int x_stride, const float* __restrict__ scale, int scale_stride,
+                               int64_t M, int L, float* __restrict__ out) {
+    const int64_t total = M * 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / 3;
+        const int c = (int)(i - m * 3);
+        const float xv = x[m * x_stride + c];
+        const float* d = d_enc + m * ld;
+        float acc = d[c];
+        for (int f = 0; f < L; ++f) {
+            const float fr = (float)(1 << f), a = xv * fr;
+            acc += fr * (sin_quadrant(a, 1) * d[3 + 6 * f + c] - sin_quadrant(a, 0) * d[3 + 6 * f + 3 + c]);
+        }
+        out[i] = scale ? acc * scale[m * scale_stride] : acc;
+    }
+}
+
+// Ref-NeRF, stage 1 of the parameter backward: the spec head's delta.  rgb = sigmoid(spec) sigmoid(tint) + sigmoid(diffuse)
+// (ref_model.py:98-105, use_srgb off): d spec_raw = g_rgb sigmoid(tint) sigmoid'(spec), written as the head K group (slot features 0..2).
+template <int ELEM>
+__global__ void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, int64_t M, char* __restrict__ frag,
+                                      unsigned long long sub_stride) {
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+        const float* ax = aux + m * 16;
+        char* block = frag + (size_t)(m >> 5) * sub_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float sp = sigmoid_f(ax[11 + c]);
+            store_slot_feature<ELEM>(block, (int)(m & 31), c, g_out[m * g_stride + c] * sigmoid_f(ax[8 + c]) * (sp * (1.0f - sp)));
+        }
+    }
+}
+
+// Ref-NeRF, stage 2: everything between the directional network's input vector and the heads (ref_model.py:80-96 backwards).
+// Per sample: d_allin (167: [bottle-neck 128 | IDE re 19 | IDE im 19 | n.d]) from the directional chain, the loss gradients w.r.t.
+// the outputs (g_out (M,7) = [rgb 3, density 1, predicted normal 3]), the saved pre-activation heads (aux) and the view direction ->
+//   delta of the 11 head rows [normal 0-2, roughness 3, diffuse 4-6, density 7, tint 8-10] (K group 8 of the slot) and
+//   delta of the bottle-neck = d_allin[0:128] (K groups 0..7), both in fragment order for the heads' dgrad / wgrad.
+// IDE backward (ref_func.py:76-108): out_t = (x + i y)^m P_t(z) exp(-sigma_l k), P_t(z) = sum_k mat[k][t] z^k, sigma_l = l (l + 1) / 2.
+template <int ELEM>
+__global__ void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, const float* __restrict__ d_allin, int ld,
+                                       const float* __restrict__ dirs, int dir_stride, const float* __restrict__ mat, int64_t M,
+                                       char* __restrict__ frag, unsigned long long sub_stride) {
+    constexpr int TM[19] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 6, 7, 8};
+    constexpr int TL[19] = {1, 1, 2, 2, 2, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+    constexpr int BREG = ELEM == 2 ? 1024 : 2048;
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+        const float* ax = aux + m * 16;
+        const float* da = d_allin + m * ld;
+        const float* g = g_out + m * g_stride;
+        const float dx = dirs[m * dir_stride], dy = dirs[m * dir_stride + 1], dz = dirs[m * dir_stride + 2];
+        // forward quantities
+        const float n0x = ax[0], n0y = ax[1], n0z = ax[2];
+        const float len = norm3(n0x, n0y, n0z), nn = len + 1e-7f;
+        const float nx = -n0x / nn, ny = -n0y / nn, nz = -n0z / nn;
+        const float dot = (dx * nx + dy * ny) + dz * nz;
+        const float rx = dx - 2.0f * dot * nx, ry = dy - 2.0f * dot * ny, rz = dz - 2.0f * dot * nz;
+        const float kinv = softplus_f(ax[3] - 1.0f);
+        float zp[9], re[9], im[9];
+        zp[0] = 1.0f; re[0] = 1.0f; im[0] = 0.0f;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) { zp[k] = zp[k - 1] * rz; re[k] = re[k - 1] * rx - im[k - 1] * ry; im[k] = re[k - 1] * ry + im[k - 1] * rx; }
+        const float att[4] = {expf(-1.0f * kinv), expf(-3.0f * kinv), expf(-10.0f * kinv), expf(-36.0f * kinv)};
+        const float sig[4] = {1.0f, 3.0f, 10.0f, 36.0f};
+        // IDE backward
+        float d_re[9], d_im[9], d_rz = 0.0f, d_kinv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { d_re[k] = 0.0f; d_im[k] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < 19; ++t) {
+            const int mm = TM[t], l = TL[t];
+            const int li = (l == 1) ? 0 : ((l == 2) ? 1 : ((l == 4) ? 2 : 3));
+            float poly = 0.0f, dpoly = 0.0f;
+#pragma unroll
+            for (int k = 0; k <= l - mm; ++k) {
+                poly = __builtin_fmaf(mat[k * 19 + t], zp[k], poly);
+                if (k >= 1) dpoly = __builtin_fmaf((float)k * mat[k * 19 + t], zp[k - 1], dpoly);
+            }
+            const float gr = da[128 + t], gi = da[128 + 19 + t];
+            const float A = gr * re[mm] + gi * im[mm];
+            d_rz += A * att[li] * dpoly;
+            d_kinv -= A * poly * sig[li] * att[li];
+            d_re[mm] += gr * poly * att[li];
+            d_im[mm] += gi * poly * att[li];
+        }
+        float d_rx = 0.0f, d_ry = 0.0f;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {                        // d (x + i y)^k / dx = k (x + i y)^(k-1),  d / dy = i k (x + i y)^(k-1)
+            d_rx += (float)k * (d_re[k] * re[k - 1] + d_im[k] * im[k - 1]);
+            d_ry += (float)k * (d_im[k] * re[k - 1] - d_re[k] * im[k - 1]);
+        }
+        // normal: gradient from the loss (predicted normal output), from n.d and from the reflection r = d - 2 (d.n) n
+        const float g_nd = da[166];
+        const float rdotn = (d_rx * nx + d_ry * ny) + d_rz * nz;
+        float dnx = g[4] + g_nd * dx - 2.0f * (rdotn * dx + dot * d_rx);
+        float dny = g[5] + g_nd * dy - 2.0f * (rdotn * dy + dot * d_ry);
+        float dnz = g[6] + g_nd * dz - 2.0f * (rdotn * dz + dot * d_rz);
+        // n = -n0 / (|n0| + eps):  d n0 = -( dn / nn - n0 (n0 . dn) / (|n0| nn^2) )
+        const float n0dn = (n0x * dnx + n0y * dny) + n0z * dnz;
+        const float cden = n0dn / (fmaxf(len, 1e-30f) * nn * nn);
+        float dh[11];
+        dh[0] = -(dnx / nn - n0x * cden); dh[1] = -(dny / nn - n0y * cden); dh[2] = -(dnz / nn - n0z * cden);
+        dh[3] = d_kinv * sigmoid_f(ax[3] - 1.0f);                                           // softplus'(v) = sigmoid(v)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float sd = sigmoid_f(ax[4 + c]), st = sigmoid_f(ax[8 + c]), sp = sigmoid_f(ax[11 + c]);
+            dh[4 + c] = g[c] * (sd * (1.0f - sd));
+            dh[8 + c] = g[c] * sp * (st * (1.0f - st));
+        }
+        dh[7] = g[3];
+        char* sub = frag + (size_t)(m >> 5) * sub_stride;
+        const int j = (int)(m & 31);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) store_slot_feature<ELEM>(sub + 8 * BREG, j, f, f < 11 ? dh[f] : 0.0f);
+        for (int f = 0; f < 128; ++f) store_slot_feature<ELEM>(sub + (f >> 4) * BREG, j, f & 15, da[f]);
+    }
+}
+
+// ================================================================================================
 // wgrad:  dW (32 NOB x 32 NIB) = X^T . Y over all samples;  X = delta dump K groups, Y = activation / encoding dump K groups
 // ================================================================================================
 struct FragMat { const char* base; unsigned long long sub_stride; };      // K group kg of subtile s: base + s*sub_stride + kg*BREG bytes
@@ -249,19 +481,20 @@ struct WgradJob {
 constexpr int WG_MAX_JOBS = 8;
 struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 
-enum { Y_DMAP = 0, Y_PE10 = 1, Y_PE4 = 2 };
+enum { Y_DMAP = 0, Y_PE10 = 1, Y_PE4 = 2, Y_IDE = 3 };
 
 // slot (kg, h, e) of a Y operand -> feature (column of the reference weight matrix), or -1
 template <int YKIND> DEVINL int y_slot_feature(int kg, int h, int e) {
     if (YKIND == Y_PE10) return pe_slot_column(8 * kg + e, h, 10);
     if (YKIND == Y_PE4) return pe_slot_column(8 * kg + e, h, 4);
+    if (YKIND == Y_IDE) return ide_slot_column(8 * kg + e, h);
     return dmap_feature(kg, h, e);
 }
 
 // KGX / KGY: K groups of X / Y;  WO: waves along the X (row) dimension, 4 / WO along Y
 template <int KGX, int KGY, int WO, int YKIND>
 __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t n_sub) {
-    constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : (YKIND == Y_PE10 ? 2 : 1);
+    constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : ((YKIND == Y_PE10 || YKIND == Y_IDE) ? 2 : 1);
     constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
     static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
     // an odd K-group count leaves the last block half empty; the loads / MFMAs that skip the missing group must be decided at COMPILE
@@ -394,7 +627,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
 // served by L2); no transposition at all.  Exact fp32 products and sums.
 template <int KGX, int KGY, int WO, int YKIND>
 __global__ __launch_bounds__(256) void wgrad_kernel_f32(WgradJobs jobs, int64_t n_sub) {
-    constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : (YKIND == Y_PE10 ? 2 : 1);
+    constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : ((YKIND == Y_PE10 || YKIND == Y_IDE) ? 2 : 1);
     constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
     static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
     constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -419,6 +652,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel_f32(WgradJobs jobs, int64_t 
         const int f = 32 * (ib0 + b) + j;
         if constexpr (YKIND == Y_DMAP) {
             yoff[b] = ((f >> 4) < KGY) ? slot_off(f >> 4, (f >> 2) & 1, ((f >> 3) & 1) * 4 + (f & 3)) : -1;
+        } else if constexpr (YKIND == Y_IDE) {
+            int q = -1, hf = 0;                                            // inverse of ide_slot_column
+            if (f < 19) q = f; else if (f < 38) { q = f - 19; hf = 1; } else if (f == 38) q = 19;
+            yoff[b] = (q >= 0) ? slot_off(q >> 3, hf, q & 7) : -1;
         } else {
             constexpr int Lp = (YKIND == Y_PE10) ? 10 : 4;
             int q = -1, hf = 0;                                            // inverse of pe_slot_column
@@ -485,7 +722,7 @@ struct FinalizeJob {
     const float* bias_partial; float* bias_dst; int bias_prow, brow0, brows;   // bias_prow = rows of the partial the bias sums belong to
     int n_wg;                                   // workgroup partials to sum
 };
-constexpr int FIN_MAX_JOBS = 24;
+constexpr int FIN_MAX_JOBS = 40;
 struct FinalizeJobs { FinalizeJob j[FIN_MAX_JOBS]; };
 
 // 256 threads = 64 elements x 4 slices of the workgroup range; every thread sums its slice with four independent accumulators (the
@@ -657,6 +894,8 @@ int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, i
         case 3: return launch_wgrad<1, 8, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);       // NOB 1 x NIB 4
         case 4: return launch_wgrad<8, 2, 4, Y_PE4>(precision, jobs, n, n_wg, n_sub, st);        // NOB 4 x NIB 1
         case 5: return launch_wgrad<1, 16, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // NOB 1 x NIB 8
+        case 6: return launch_wgrad<16, 8, 2, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // 256 x 128 (Ref-NeRF: delta x bottle-neck)
+        case 7: return launch_wgrad<16, 3, 4, Y_IDE>(precision, jobs, n, n_wg, n_sub, st);       // 256 x [IDE 38 | n.d]
     }
     return (int)hipErrorInvalidValue;
 }
@@ -790,6 +1029,204 @@ int bwd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const v
     const int total = 128 * 256 + 256 * 256 + 256;
     hipLaunchKernelGGL(mip_fold_grads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, G, d_b[9], w[9], w[7], b[7], d_w[9], d_w[7], d_b[7]);
     return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ single-layer launches: host side
+namespace {
+template <class P, int NKG, int NFB, bool MASK>
+int launch_layer_t(const char* layer, int n_frags, const LayerIO& io, int64_t M, hipStream_t st) {
+    constexpr int TS = P::NW * P::NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = bwd_lds_total<P>();
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(dgrad_layer_kernel<P, NKG, NFB, MASK>), lds)) return e;
+    hipLaunchKernelGGL((dgrad_layer_kernel<P, NKG, NFB, MASK>), dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, layer, n_frags, io, M);
+    return (int)hipGetLastError();
+}
+template <int NKG, int NFB, bool MASK>
+int launch_layer(int precision, const void* blob, int start_frag, const LayerIO& io, int64_t M, hipStream_t st) {
+    const size_t fb = precision == NERF_AMD_BF16 ? 1024 : 2048;
+    const char* layer = reinterpret_cast<const char*>(blob) + (size_t)start_frag * fb;
+    if (precision == NERF_AMD_BF16) return launch_layer_t<PB16, NKG, NFB, MASK>(layer, NKG * NFB, io, M, st);
+    return launch_layer_t<PF32, NKG, NFB, MASK>(layer, NKG * NFB, io, M, st);
+}
+struct ChainCtx {                     // addressing of fragment dumps: slot l, K group kg
+    int precision; int64_t M; size_t breg, ls, sub;
+    ChainCtx(int prec, int64_t m) : precision(prec), M(m), breg(prec == NERF_AMD_BF16 ? 1024 : 2048), ls(mlp_train_layer_stride(prec, m)), sub(16 * breg) {}
+    const char* at(const void* dump, int slot, int kg = 0) const { return reinterpret_cast<const char*>(dump) + (size_t)slot * ls + (size_t)kg * breg; }
+    char* at(void* dump, int slot, int kg = 0) const { return reinterpret_cast<char*>(dump) + (size_t)slot * ls + (size_t)kg * breg; }
+};
+// hidden layer: delta_out(slot so of `dlt`) = W^T delta_in(slot si of `dlt`) * [act(slot so) > 0]
+template <int NKG>
+int hidden_layer(const ChainCtx& c, const void* blob, int start, const char* x0, int kgx0, const char* x1, int ones, const char* mask, char* out, hipStream_t st) {
+    LayerIO io{};
+    io.x0 = x0; io.kgx0 = kgx0; io.x1 = x1; io.x_sub_stride = c.sub; io.ones_head = ones;
+    io.mask = mask; io.out = out; io.io_sub_stride = c.sub;
+    return launch_layer<NKG, 8, true>(c.precision, blob, start, io, c.M, st);
+}
+template <int NFB>
+int rows_layer(const ChainCtx& c, const void* blob, int start, const char* x, float* rows, int ld, int accumulate, hipStream_t st) {
+    LayerIO io{};
+    io.x0 = x; io.kgx0 = 16; io.x1 = nullptr; io.x_sub_stride = c.sub; io.ones_head = 0;
+    io.rows = rows; io.ld = ld; io.accumulate = accumulate;
+    return launch_layer<16, NFB, false>(c.precision, blob, start, io, c.M, st);
+}
+int blocks_1d(int64_t work) { int64_t b = (work + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+}  // namespace
+
+// d density / d position, times scale[m] (RefNeRF.get_grad, ref_model.py:119-125; train.py:165-168,178) for the proposal network
+// (net 0: activation slots 0..3) and Ref-NeRF's spatial network (net 2: slots 0..7): a dgrad-only chain from the density row down to
+// the encoded position, then the encoding's derivative.  workspace: two delta buffers of one slot each + d_enc rows (M, 64) fp32.
+size_t bwd_density_grad_workspace_bytes(int precision, int64_t M) {
+    return 2 * align256(mlp_train_layer_stride(precision, M)) + align256((size_t)M * 64 * 4) + 256;
+}
+int bwd_density_grad(int net, const void* blob, int precision, int64_t M, const void* act, const float* x, int x_stride, const float* scale, int scale_stride,
+                     float* out, void* workspace, hipStream_t st) {
+    if (M == 0) return 0;
+    const ChainCtx c(precision, M);
+    Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
+    char* d[2] = {reinterpret_cast<char*>(ws.take(c.ls / 4)), reinterpret_cast<char*>(ws.take(c.ls / 4))};
+    float* denc = ws.take((size_t)M * 64);
+    int cur = 0;
+    if (net == NERF_AMD_NET_PROPOSAL) {
+        using L = PropBwdLayout;
+        if (int e = hidden_layer<1>(c, blob, L::START[0], nullptr, 1, nullptr, 1, c.at(act, 3), d[cur], st)) return e;        // delta_3 from the head row
+        for (int l = 1; l <= 3; ++l) {                                                                                       // delta_2, delta_1, delta_0
+            if (int e = hidden_layer<16>(c, blob, L::START[l], d[cur], 16, nullptr, 0, c.at(act, 3 - l), d[cur ^ 1], st)) return e;
+            cur ^= 1;
+        }
+        if (int e = rows_layer<2>(c, blob, L::ENC_START, d[cur], denc, 64, 0, st)) return e;
+    } else {
+        using L = RefBwdLayout;
+        if (int e = hidden_layer<1>(c, blob, L::START[20], nullptr, 1, nullptr, 1, c.at(act, 7), d[cur], st)) return e;       // delta_S7 from the density row
+        for (int l = 0; l < 3; ++l) {                                                                                        // S6, S5, S4
+            if (int e = hidden_layer<16>(c, blob, L::START[11 + l], d[cur], 16, nullptr, 0, c.at(act, 6 - l), d[cur ^ 1], st)) return e;
+            cur ^= 1;
+        }
+        if (int e = rows_layer<2>(c, blob, L::START[15], d[cur], denc, 64, 0, st)) return e;                                  // skip layer: its encoding columns
+        if (int e = hidden_layer<16>(c, blob, L::START[14], d[cur], 16, nullptr, 0, c.at(act, 3), d[cur ^ 1], st)) return e;  // ... and its hidden columns -> S3
+        cur ^= 1;
+        for (int l = 0; l < 3; ++l) {                                                                                        // S2, S1, S0
+            if (int e = hidden_layer<16>(c, blob, L::START[16 + l], d[cur], 16, nullptr, 0, c.at(act, 2 - l), d[cur ^ 1], st)) return e;
+            cur ^= 1;
+        }
+        if (int e = rows_layer<2>(c, blob, L::START[19], d[cur], denc, 64, 1, st)) return e;
+    }
+    hipLaunchKernelGGL(pe_grad_kernel, dim3(blocks_1d(M * 3)), dim3(256), 0, st, denc, 64, x, x_stride, scale, scale_stride, M, 10, out);
+    return (int)hipGetLastError();
+}
+
+// Ref-NeRF parameter backward (what autograd computes for ref_model.py:68-106 inside train.py:176-199).
+// workspace: delta dump (REF_DUMP_SLOTS slots) | d_allin rows (M,192) | wgrad partials
+size_t bwd_ref_workspace_bytes(int precision, int64_t M) {
+    const int64_t n_sub = bwd_n_sub(precision, M);
+    const size_t w7 = wgrad_workgroups(n_sub, 7, true), w2 = wgrad_workgroups(n_sub, 2, false), w1h = wgrad_workgroups(n_sub, 1, true),
+                 w1 = wgrad_workgroups(n_sub, 1, false);
+    size_t b = align256((size_t)REF_DUMP_SLOTS * mlp_train_layer_stride(precision, M)) + align256((size_t)M * 192 * 4);
+    b += 14 * (align256(w7 * 256 * 256 * 4) + align256(w7 * 256 * 4));                       // 2 x 7 hidden products
+    b += 2 * align256(w2 * 256 * 64 * 4) + align256(w2 * 256 * 4);                           // encoding columns
+    b += 2 * (align256(w2 * 256 * 128 * 4) + align256(w2 * 256 * 4)) + 2 * align256(w2 * 256 * 64 * 4);   // x bottle-neck, x IDE
+    b += align256(w1h * 160 * 256 * 4) + align256(w1h * 160 * 4) + align256(w1 * 32 * 256 * 4) + align256(w1 * 32 * 4);
+    return b + 512;
+}
+// w: the 20 tensors of nerf_amd_pack_weights(NET_REF) (only the ide_table, index 19, is read here).  d_w / d_b (20 each): 0..7 spatial,
+// 8 bottle_neck, 9 norm_col_tint_head (9 rows), 10 rho_tau_head (2 rows), 11..18 directional, 19 spec_rgb_head.0
+int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act, const float* aux, const float* dirs, int dir_stride,
+                     const float* g_out, int g_stride, const float* ide_table, float* const* d_w, float* const* d_b, void* workspace, hipStream_t st) {
+    if (M == 0) return 0;
+    using L = RefBwdLayout;
+    const ChainCtx c(precision, M);
+    const int64_t n_sub = bwd_n_sub(precision, M);
+    Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
+    char* dlt = reinterpret_cast<char*>(ws.take((size_t)REF_DUMP_SLOTS * c.ls / 4));
+    float* dallin = ws.take((size_t)M * 192);                // (M, 192): the 6 feature blocks of the 167-wide input vector
+    const int elem = precision == NERF_AMD_BF16 ? 2 : 4;
+    auto A = [&](int slot, int kg = 0) { return c.at(act, slot, kg); };
+    auto D = [&](int slot, int kg = 0) { return c.at((void*)dlt, slot, kg); };
+    // slot 8 of the delta dump: K groups 0..7 delta of the bottle-neck, 8 the head rows, 9 the spec head -- zero it (only a few
+    // features of the head K groups are written)
+    if (int e = (int)hipMemsetAsync(D(8), 0, c.ls, st)) return e;
+    // stage 1: spec head delta, then the directional network backwards
+    if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub);
+    else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub);
+    if (int e = hidden_layer<1>(c, blob, L::START[0], D(8, 9), 1, nullptr, 0, A(16), D(16), st)) return e;                    // D7
+    if (int e = hidden_layer<16>(c, blob, L::START[1], D(16), 16, nullptr, 0, A(15), D(15), st)) return e;                    // D6
+    if (int e = hidden_layer<16>(c, blob, L::START[2], D(15), 16, nullptr, 0, A(14), D(14), st)) return e;                    // D5
+    if (int e = hidden_layer<16>(c, blob, L::START[3], D(14), 16, nullptr, 0, A(13), D(13), st)) return e;                    // D4
+    if (int e = rows_layer<6>(c, blob, L::START[5], D(13), dallin, 192, 0, st)) return e;                                     // skip: its input-vector columns
+    if (int e = hidden_layer<16>(c, blob, L::START[4], D(13), 16, nullptr, 0, A(12), D(12), st)) return e;                    // ... hidden columns -> D3
+    if (int e = hidden_layer<16>(c, blob, L::START[6], D(12), 16, nullptr, 0, A(11), D(11), st)) return e;                    // D2
+    if (int e = hidden_layer<16>(c, blob, L::START[7], D(11), 16, nullptr, 0, A(10), D(10), st)) return e;                    // D1
+    if (int e = hidden_layer<16>(c, blob, L::START[8], D(10), 16, nullptr, 0, A(9), D(9), st)) return e;                      // D0
+    if (int e = rows_layer<6>(c, blob, L::START[9], D(9), dallin, 192, 1, st)) return e;
+    // stage 2: IDE / reflection / normal / head activations backwards -> delta of the heads and of the bottle-neck
+    if (elem == 2) hipLaunchKernelGGL(ref_heads_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M,
+                                      D(8), (unsigned long long)c.sub);
+    else hipLaunchKernelGGL(ref_heads_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, D(8),
+                            (unsigned long long)c.sub);
+    // stage 3: the spatial network backwards
+    if (int e = hidden_layer<9>(c, blob, L::START[10], D(8), 9, nullptr, 0, A(7), D(7), st)) return e;                        // S7 from [bottle-neck | heads]
+    if (int e = hidden_layer<16>(c, blob, L::START[11], D(7), 16, nullptr, 0, A(6), D(6), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[12], D(6), 16, nullptr, 0, A(5), D(5), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[13], D(5), 16, nullptr, 0, A(4), D(4), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[14], D(4), 16, nullptr, 0, A(3), D(3), st)) return e;                      // skip layer's hidden columns -> S3
+    if (int e = hidden_layer<16>(c, blob, L::START[16], D(3), 16, nullptr, 0, A(2), D(2), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[17], D(2), 16, nullptr, 0, A(1), D(1), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[18], D(1), 16, nullptr, 0, A(0), D(0), st)) return e;
+    // weight gradients
+    const int w7 = wgrad_workgroups(n_sub, 7, true), w2 = wgrad_workgroups(n_sub, 2, false), w1h = wgrad_workgroups(n_sub, 1, true),
+              w1 = wgrad_workgroups(n_sub, 1, false);
+    float *pS[7], *pSb[7], *pD[7], *pDb[7];
+    for (int i = 0; i < 7; ++i) { pS[i] = ws.take((size_t)w7 * 65536); pSb[i] = ws.take((size_t)w7 * 256); }
+    for (int i = 0; i < 7; ++i) { pD[i] = ws.take((size_t)w7 * 65536); pDb[i] = ws.take((size_t)w7 * 256); }
+    float* pe0 = ws.take((size_t)w2 * 256 * 64); float* pe4 = ws.take((size_t)w2 * 256 * 64); float* pe0b = ws.take((size_t)w2 * 256);
+    float *pb0 = ws.take((size_t)w2 * 256 * 128), *pb0b = ws.take((size_t)w2 * 256), *pb4 = ws.take((size_t)w2 * 256 * 128), *pb4b = ws.take((size_t)w2 * 256);
+    float *pi0 = ws.take((size_t)w2 * 256 * 64), *pi4 = ws.take((size_t)w2 * 256 * 64);
+    float *ph = ws.take((size_t)w1h * 160 * 256), *phb = ws.take((size_t)w1h * 160), *psp = ws.take((size_t)w1 * 32 * 256), *pspb = ws.take((size_t)w1 * 32);
+    const int SL[7] = {1, 2, 3, 4, 5, 6, 7};                 // spatial layer l: delta slot l x activation slot l-1 (layer 4: its hidden columns)
+    Product pj[7];
+    for (int i = 0; i < 7; ++i) pj[i] = Product{D(SL[i]), 16, nullptr, A(SL[i] - 1), pS[i], pSb[i]};
+    if (int e = run_wgrad(0, precision, pj, 7, w7, n_sub, st)) return e;
+    for (int i = 0; i < 7; ++i) pj[i] = Product{D(9 + SL[i]), 16, nullptr, A(9 + SL[i] - 1), pD[i], pDb[i]};                  // directional layers 1..7
+    if (int e = run_wgrad(0, precision, pj, 7, w7, n_sub, st)) return e;
+    const Product pe[2] = {Product{D(0), 16, nullptr, A(8, 11), pe0, pe0b}, Product{D(4), 16, nullptr, A(8, 11), pe4, nullptr}};
+    if (int e = run_wgrad(1, precision, pe, 2, w2, n_sub, st)) return e;
+    const Product pb[2] = {Product{D(9), 16, nullptr, A(8, 0), pb0, pb0b}, Product{D(13), 16, nullptr, A(8, 0), pb4, pb4b}};  // x bottle-neck
+    if (int e = run_wgrad(6, precision, pb, 2, w2, n_sub, st)) return e;
+    const Product pi[2] = {Product{D(9), 16, nullptr, A(8, 8), pi0, nullptr}, Product{D(13), 16, nullptr, A(8, 8), pi4, nullptr}};   // x [IDE | n.d]
+    if (int e = run_wgrad(7, precision, pi, 2, w2, n_sub, st)) return e;
+    const Product phd{D(8), 9, nullptr, A(7), ph, phb};                                                                      // [bottle-neck | heads]^T S7
+    if (int e = run_wgrad(2, precision, &phd, 1, w1h, n_sub, st)) return e;
+    const Product pspec{D(8, 9), 1, nullptr, A(16), psp, pspb};                                                              // spec head
+    if (int e = run_wgrad(5, precision, &pspec, 1, w1, n_sub, st)) return e;
+    FinalizeJob f[40];
+    int n = 0;
+    for (int i = 0; i < 7; ++i) {                            // spatial
+        const int l = SL[i];
+        if (l == 4) f[n++] = FinalizeJob{pS[i], 256, 256, d_w[4], 319, 63, 0, 256, 256, pSb[i], d_b[4], 256, 0, 256, w7};
+        else f[n++] = FinalizeJob{pS[i], 256, 256, d_w[l], 256, 0, 0, 256, 256, pSb[i], d_b[l], 256, 0, 256, w7};
+    }
+    f[n++] = FinalizeJob{pe0, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe0b, d_b[0], 256, 0, 256, w2};
+    f[n++] = FinalizeJob{pe4, 256, 64, d_w[4], 319, 0, 0, 256, 63, nullptr, nullptr, 0, 0, 0, w2};
+    for (int i = 0; i < 7; ++i) {                            // directional: tensors 11..18 = dir layers 0..7
+        const int l = SL[i];
+        if (l == 4) f[n++] = FinalizeJob{pD[i], 256, 256, d_w[15], 423, 167, 0, 256, 256, pDb[i], d_b[15], 256, 0, 256, w7};
+        else f[n++] = FinalizeJob{pD[i], 256, 256, d_w[11 + l], 256, 0, 0, 256, 256, pDb[i], d_b[11 + l], 256, 0, 256, w7};
+    }
+    f[n++] = FinalizeJob{pb0, 256, 128, d_w[11], 167, 0, 0, 256, 128, pb0b, d_b[11], 256, 0, 256, w2};
+    f[n++] = FinalizeJob{pi0, 256, 64, d_w[11], 167, 128, 0, 256, 39, nullptr, nullptr, 0, 0, 0, w2};
+    f[n++] = FinalizeJob{pb4, 256, 128, d_w[15], 423, 0, 0, 256, 128, nullptr, nullptr, 0, 0, 0, w2};
+    f[n++] = FinalizeJob{pi4, 256, 64, d_w[15], 423, 128, 0, 256, 39, nullptr, nullptr, 0, 0, 0, w2};
+    if (int e = run_finalize(f, n, st)) return e;
+    n = 0;
+    f[n++] = FinalizeJob{ph, 160, 256, d_w[8], 256, 0, 0, 128, 256, phb, d_b[8], 160, 0, 128, w1h};                          // bottle_neck
+    f[n++] = FinalizeJob{ph, 160, 256, d_w[9], 256, 0, 128, 3, 256, phb, d_b[9], 160, 128, 3, w1h};                          // norm_col_tint rows 0-2 (normal)
+    f[n++] = FinalizeJob{ph, 160, 256, d_w[9] + 3 * 256, 256, 0, 132, 3, 256, phb, d_b[9] + 3, 160, 132, 3, w1h};            //   rows 3-5 (diffuse)
+    f[n++] = FinalizeJob{ph, 160, 256, d_w[9] + 6 * 256, 256, 0, 136, 3, 256, phb, d_b[9] + 6, 160, 136, 3, w1h};            //   rows 6-8 (tint)
+    f[n++] = FinalizeJob{ph, 160, 256, d_w[10], 256, 0, 131, 1, 256, phb, d_b[10], 160, 131, 1, w1h};                        // rho_tau row 0 (roughness)
+    f[n++] = FinalizeJob{ph, 160, 256, d_w[10] + 256, 256, 0, 135, 1, 256, phb, d_b[10] + 1, 160, 135, 1, w1h};              //   row 1 (density)
+    f[n++] = FinalizeJob{psp, 32, 256, d_w[19], 256, 0, 0, 3, 256, pspb, d_b[19], 32, 0, 3, w1};                             // spec_rgb_head.0
+    return run_finalize(f, n, st);
 }
 
 int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, int count, float* step, double lr,

@@ -24,6 +24,13 @@ int sk_relu_mask_bias(void*, const void*, int, int64_t, int, float*, hipStream_t
 int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal_bwd(int, const float* const*, void*, hipStream_t);
 int pack_mip_bwd(int, const float* const*, void*, hipStream_t);
+int pack_ref_bwd(int, const float* const*, void*, hipStream_t);
+int mlp_launch_ref_train(const void*, int, const nerf_amd_samples&, float*, float*, const float*, void*, float*, hipStream_t);
+size_t bwd_density_grad_workspace_bytes(int, int64_t);
+int bwd_density_grad(int, const void*, int, int64_t, const void*, const float*, int, const float*, int, float*, void*, hipStream_t);
+size_t bwd_ref_workspace_bytes(int, int64_t);
+int bwd_ref_backward(const void*, int, int64_t, const void*, const float*, const float*, int, const float*, int, const float*, float* const*,
+                     float* const*, void*, hipStream_t);
 int bwd_launch_prop_chain(const void*, int, const float*, int64_t, const void*, void*, hipStream_t);
 int bwd_launch_mip_chain(const void*, int, const float*, const float*, int64_t, const void*, void*, hipStream_t);
 size_t bwd_wgrad_workspace_bytes(int, int, int64_t);
@@ -299,7 +306,9 @@ int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N,
 }
 
 // ---- training forward: the MLP kernels also dump their hidden activations ----
-static int train_layers(int net) { return net == NERF_AMD_NET_PROPOSAL ? PROP_DUMP_SLOTS : (net == NERF_AMD_NET_MIP ? MIP_DUMP_SLOTS : 0); }
+static int train_layers(int net) {
+    return net == NERF_AMD_NET_PROPOSAL ? PROP_DUMP_SLOTS : (net == NERF_AMD_NET_MIP ? MIP_DUMP_SLOTS : (net == NERF_AMD_NET_REF ? REF_DUMP_SLOTS : 0));
+}
 size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M) {
     if (M < 0 || !train_layers(net) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return 0;
     return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M);
@@ -373,18 +382,20 @@ size_t nerf_amd_packed_backward_bytes(int net, int precision) {
     if (bad_prec(precision)) return 0;
     if (net == NERF_AMD_NET_PROPOSAL) return PropBwdLayout::packed_bytes(precision);
     if (net == NERF_AMD_NET_MIP) return MipBwdLayout::packed_bytes(precision);
+    if (net == NERF_AMD_NET_REF) return RefBwdLayout::packed_bytes(precision);
     return 0;
 }
 int nerf_amd_pack_weights_backward(int net, int precision, const float* const* weights, int n_tensors, void* packed_bwd, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (!weights || !packed_bwd) return fail(NERF_AMD_EINVAL, "NULL argument");
-    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : -1);
-    if (want < 0) return fail(NERF_AMD_EUNSUPPORTED, "the backward chain exists for the proposal and MipNeRF networks");
+    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
+    if (want < 0) return fail(NERF_AMD_EINVAL, "unknown network");
     if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
     for (int i = 0; i < want; ++i)
         if (!weights[i]) return fail(NERF_AMD_EINVAL, "NULL weight tensor");
-    return hip_status(net == NERF_AMD_NET_PROPOSAL ? pack_proposal_bwd(precision, weights, packed_bwd, S(stream))
-                                                    : pack_mip_bwd(precision, weights, packed_bwd, S(stream)), "nerf_amd_pack_weights_backward");
+    const int e = net == NERF_AMD_NET_PROPOSAL ? pack_proposal_bwd(precision, weights, packed_bwd, S(stream))
+                  : (net == NERF_AMD_NET_MIP ? pack_mip_bwd(precision, weights, packed_bwd, S(stream)) : pack_ref_bwd(precision, weights, packed_bwd, S(stream)));
+    return hip_status(e, "nerf_amd_pack_weights_backward");
 }
 int nerf_amd_proposal_backward_chain(const void* packed_bwd, int precision, const float* g_density, int64_t M, const void* act_dump,
                                      void* delta_dump, void* stream) {
@@ -425,6 +436,43 @@ int nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, co
     return hip_status(bwd_mip_weight_grads(precision, M, act_dump, delta_dump, weights, biases, d_weights, d_biases, workspace, S(stream)),
                       "nerf_amd_mip_weight_grads");
 }
+int nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo, float* normal,
+                                    void* dump, float* aux, void* stream) {
+    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (int c = check_samples(src, true)) return c;
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !rgbo || !dump || !aux) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(mlp_launch_ref_train(packed, precision, *src, rgbo, normal, bn_noise, dump, aux, S(stream)), "nerf_amd_ref_forward_train_dump");
+}
+size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M) {
+    if (bad_prec(precision) || M < 0 || (net != NERF_AMD_NET_PROPOSAL && net != NERF_AMD_NET_REF)) return 0;
+    return bwd_density_grad_workspace_bytes(precision, M);
+}
+int nerf_amd_density_grad(int net, const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* x, int x_stride,
+                          const float* scale, int scale_stride, float* grad, void* workspace, void* stream) {
+    if (bad_prec(precision) || M < 0 || x_stride < 3) return fail(NERF_AMD_EINVAL, "bad precision, size or stride");
+    if (net != NERF_AMD_NET_PROPOSAL && net != NERF_AMD_NET_REF) return fail(NERF_AMD_EUNSUPPORTED, "density gradients exist for the proposal and Ref-NeRF networks");
+    if (M == 0) return NERF_AMD_OK;
+    if (!packed_bwd || !act_dump || !x || !grad || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(bwd_density_grad(net, packed_bwd, precision, M, act_dump, x, x_stride, scale, scale_stride, grad, workspace, S(stream)), "nerf_amd_density_grad");
+}
+size_t nerf_amd_ref_backward_workspace_bytes(int precision, int64_t M) {
+    if (bad_prec(precision) || M < 0) return 0;
+    return bwd_ref_workspace_bytes(precision, M);
+}
+int nerf_amd_ref_backward(const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* aux, const float* dirs, int dir_stride,
+                          const float* g_out, int g_stride, const float* ide_table, float* const* d_weights, float* const* d_biases, void* workspace,
+                          void* stream) {
+    if (bad_prec(precision) || M < 0 || dir_stride < 3 || g_stride < 7) return fail(NERF_AMD_EINVAL, "bad precision, size or stride");
+    if (!d_weights || !d_biases) return fail(NERF_AMD_EINVAL, "NULL argument");
+    for (int i = 0; i < 20; ++i)
+        if (!d_weights[i] || !d_biases[i]) return fail(NERF_AMD_EINVAL, "NULL gradient tensor");
+    if (M == 0) return fail(NERF_AMD_EINVAL, "no samples (the caller zero-fills the gradients of an empty batch)");
+    if (!packed_bwd || !act_dump || !aux || !dirs || !g_out || !ide_table || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(bwd_ref_backward(packed_bwd, precision, M, act_dump, aux, dirs, dir_stride, g_out, g_stride, ide_table, d_weights, d_biases, workspace,
+                                       S(stream)), "nerf_amd_ref_backward");
+}
+
 int nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                        int n_tensors, float* step, double lr, double beta1, double beta2, double eps, float grad_scale, void* stream) {
     if (n_tensors < 0 || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) || !step) return fail(NERF_AMD_EINVAL, "NULL argument");

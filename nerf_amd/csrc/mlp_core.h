@@ -70,6 +70,7 @@ struct PBF16 {
     static DEVINL BReg unstash(uint32_t addr) { return *reinterpret_cast<const bf16x8*>(smem + addr); }
     // training dump: one B register group of a subtile = a 64 x BREG_LDS/64-byte block in fragment order (lane-linear, coalesced)
     static DEVINL void store_global(char* block, int lane, const BReg& r) { *reinterpret_cast<bf16x8*>(block + lane * 16) = r; }
+    static DEVINL BReg load_global(const char* block, int lane) { return *reinterpret_cast<const bf16x8*>(block + lane * 16); }
 };
 
 // bf16, wide tile: 4 wavefronts x 64 samples.  Every A fragment read from LDS feeds TWO MFMAs (one per 32-sample column
@@ -128,6 +129,11 @@ struct PF32 {
         f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
         *reinterpret_cast<f32x4*>(block + lane * 16) = lo;
         *reinterpret_cast<f32x4*>(block + 1024 + lane * 16) = hi;
+    }
+    static DEVINL BReg load_global(const char* block, int lane) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(block + lane * 16), hi = *reinterpret_cast<const f32x4*>(block + 1024 + lane * 16);
+        BReg r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
     }
 };
 

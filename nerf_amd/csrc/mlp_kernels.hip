@@ -565,10 +565,14 @@ DEVINL void ide_encode(float x, float y, float z, float kappa_inv, float nv_dot,
 }
 
 // bn_noise (training forward, ref_model.py:84-85): (M, 128) row-major perturbation added to the bottle-neck vector, or nullptr
-template <class P>
+// TRAIN: additionally dumps, in fragment order, every hidden layer's activations (slots 0..7 spatial, 9..16
+// directional), the directional network's input vector and the position encoding (slot 8: K groups 0..7 bottle-neck incl. the
+// noise, 8..10 integrated directional encoding + n.d, 11..14 PE10 of the position), and per sample the 14 pre-activation head values
+// the backward's element-wise stage needs (aux (M,16) fp32: normal 0..2, roughness 3, diffuse 4..6, density 7, tint 8..10, spec 11..13).
+template <class P, bool TRAIN>
 __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                          float* __restrict__ rgbo, float* __restrict__ normal_out,
-                                                         const float* __restrict__ bn_noise) {
+                                                         const float* __restrict__ bn_noise, ActDump dump, float* __restrict__ aux) {
     using L = RefLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
@@ -589,8 +593,16 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg a[NT][16], b[NT][16];
-        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
-        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        int lay = 0, lay_pend = 0;                                  // training dump slots of the layer being computed / of the pending pair
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) {   // (the pending pair of the previous layer, or layer `lay` itself when it writes a)
+            a[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) dump_breg<P>(dump, lay_pend, sub0 + t, 2 * fb + half, lane, a[t][2 * fb + half]);
+        };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) {
+            b[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) dump_breg<P>(dump, lay, sub0 + t, 2 * fb + half, lane, b[t][2 * fb + half]);
+        };
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto copy_back = [&]() {                                    // K groups 12..15 arrive through the deferred epilogue
 #pragma unroll
@@ -608,27 +620,35 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                 encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) P::stash(stash(t) + k * P::BREG_LDS, enc[t][k]);
+                if constexpr (TRAIN) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 8, sub0 + t, 11 + k, lane, enc[t][k]);
+                }
                 f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
                 *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
             }
-            d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                  // spa_block1.0
+            d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                  // spa_block1.0 (lay = lay_pend = 0)
                 [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
         }
         static_assert(L::START[1] % (2 * FPC) == L::START[2] % (2 * FPC) && L::START[5] % (2 * FPC) == L::START[6] % (2 * FPC), "chunk parity");
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {                                                        // spa_block1.{2,4,6}
+            lay_pend = lay; lay = l;
             d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
+        lay_pend = lay; lay = 4;
         d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                      // spa_block2.0 (skip)
             [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
             OB, prev_of(d, OA));
         copy_back();
 #pragma unroll 1
         for (int l = 5; l <= 7; ++l) {                                                        // spa_block2.{2,4,6}
+            lay_pend = lay; lay = l;
             d = dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
+        lay_pend = lay;
         // heads: bottle_neck (4 blocks, no activation) + [normal | roughness || diffuse | density || tint]
         BReg bn[NT][8];
         f32x16 hd[NT];
@@ -644,6 +664,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                     for (int e = 0; e < 4; ++e) { v[8 * half + e] += n0[e]; v[8 * half + 4 + e] += n1[e]; }
                 }
                 bn[t][2 * (fb < 4 ? fb : 0) + half] = to_breg_half<P, false>(v, half);
+                if constexpr (TRAIN) dump_breg<P>(dump, 8, sub0 + t, 2 * (fb < 4 ? fb : 0) + half, lane, bn[t][2 * (fb < 4 ? fb : 0) + half]);
             } else if (half == 0) hd[t] = acc;
         };
         dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4, IN_A, OHD, prev_of(d, OA)).flush(OHD);
@@ -663,30 +684,48 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
             ide_encode<P>(rx, ry, rz, rough, dot, h, ide_mat, ide[t]);
             if (normal_out && h == 0 && m[t] < s.M) { normal_out[m[t] * 3] = nx; normal_out[m[t] * 3 + 1] = ny; normal_out[m[t] * 3 + 2] = nz; }
             keep[t][0] = h ? hd[t][0] : hd[t][4]; keep[t][1] = h ? hd[t][1] : hd[t][5]; keep[t][2] = h ? hd[t][2] : hd[t][6]; keep[t][3] = hd[t][3];
+            if constexpr (TRAIN) {                           // pre-activation heads for the backward: lane half 0 holds rows 0-3 and 8-10, half 1 rows 4-7
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dump_breg<P>(dump, 8, sub0 + t, 8 + k, lane, ide[t][k]);
+                if (m[t] < s.M) {
+                    float* ax = aux + m[t] * 16;
+                    if (h == 0) {
+                        *reinterpret_cast<f32x4*>(ax) = f32x4{hd[t][0], hd[t][1], hd[t][2], hd[t][3]};
+                        ax[8] = hd[t][4]; ax[9] = hd[t][5]; ax[10] = hd[t][6];
+                    } else {
+                        *reinterpret_cast<f32x4*>(ax + 4) = f32x4{hd[t][0], hd[t][1], hd[t][2], hd[t][3]};
+                    }
+                }
+            }
             // all_inputs = [bottle_neck 128 | ide 38 | n.d]: needed again by dir_block2.0 -> park in the stash (blocks 0..10)
 #pragma unroll
             for (int k = 0; k < 8; ++k) P::stash(stash(t) + k * P::BREG_LDS, bn[t][k]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) P::stash(stash(t) + (8 + k) * P::BREG_LDS, ide[t][k]);
         }
+        lay = lay_pend = 9;
         d = dense<P, 11, 8, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,                      // dir_block1.0
             [&](int kg, int t) -> BReg { if (kg < 8) return bn[t][kg < 8 ? kg : 0]; return ide[t][kg >= 8 ? kg - 8 : 0]; },
             OA, NoPrev{});
         static_assert(L::START[10] % (2 * FPC) == L::START[11] % (2 * FPC) && L::START[14] % (2 * FPC) == L::START[15] % (2 * FPC), "chunk parity");
 #pragma unroll 1
         for (int l = 10; l <= 12; ++l) {                                                      // dir_block1.{2,4,6}
+            lay_pend = lay; lay = l;
             d = dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + (l - 10) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
+        lay_pend = lay; lay = 13;
         d = dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                    // dir_block2.0 (skip)
             [&](int kg, int t) -> BReg { if (kg < 11) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 11 ? kg - 11 : 0]; },
             OB, prev_of(d, OA));
         copy_back();
 #pragma unroll 1
         for (int l = 14; l <= 16; ++l) {                                                      // dir_block2.{2,4,6}
+            lay_pend = lay; lay = l;
             d = dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + (l - 14) * 256) * 4, IN_A, OB, prev_of(d, OA));
             copy_back();
         }
+        lay_pend = lay;
         float sr[NT], sg[NT], sb[NT];
         auto OSPEC = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { sr[t] = acc[0]; sg[t] = acc[1]; sb[t] = acc[2]; } };
         dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4, IN_A, OSPEC, prev_of(d, OA)).flush(OSPEC);     // spec_rgb_head.0
@@ -703,6 +742,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                 o[2] = sig(sb[t]) * sig(keep[t][2]) + sig(d2);
                 o[3] = dens;
                 *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o;
+                if constexpr (TRAIN) { float* ax = aux + m[t] * 16; ax[11] = sr[t]; ax[12] = sg[t]; ax[13] = sb[t]; ax[14] = 0.0f; ax[15] = 0.0f; }
             }
         }
     }
@@ -781,18 +821,26 @@ int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_sampl
     return launch<PF32, MipLayout>(mip_kernel<PF32, true>, packed, s, rgbo, st, off, d);
 }
 
-template <class P>
-static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise, hipStream_t st) {
+template <class P, bool TRAIN>
+static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise, ActDump dump, float* aux,
+                      hipStream_t st) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = ref_lds_total<P>();
-    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(ref_kernel<P>), lds)) return e;
-    hipLaunchKernelGGL(ref_kernel<P>, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise);
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(ref_kernel<P, TRAIN>), lds)) return e;
+    hipLaunchKernelGGL((ref_kernel<P, TRAIN>), dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise, dump, aux);
     return (int)hipGetLastError();
 }
 int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
                    hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch_ref<PB16>(packed, s, rgbo, normal, bn_noise, st);
-    return launch_ref<PF32>(packed, s, rgbo, normal, bn_noise, st);
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16, false>(packed, s, rgbo, normal, bn_noise, NO_DUMP, nullptr, st);
+    return launch_ref<PF32, false>(packed, s, rgbo, normal, bn_noise, NO_DUMP, nullptr, st);
+}
+// training forward of Ref-NeRF: activation dump (REF_DUMP_SLOTS slots of mlp_train_layer_stride bytes) + aux (M,16)
+int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
+                         void* dump, float* aux, hipStream_t st) {
+    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M)};
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, st);
+    return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, st);
 }

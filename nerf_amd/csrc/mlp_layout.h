@@ -88,7 +88,9 @@ struct PropBwdLayout {
     static constexpr int NKG[4] = {1, 16, 16, 16};
     static constexpr int NFB[4] = {8, 8, 8, 8};
     static constexpr int START[4] = {0, 8, 136, 264};
-    static constexpr int N_FRAGS = 392;
+    static constexpr int CHAIN_FRAGS = 392;              // what the fused chain streams cyclically
+    static constexpr int ENC_START = 392;                // + layers.0^T (rows = the 63 input columns, 2 blocks): the gradient w.r.t. the
+    static constexpr int N_FRAGS = 424;                  //   encoded position, used by the density-gradient chain (RefNeRF.get_grad)
     LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec); }
 };
@@ -102,13 +104,30 @@ struct MipBwdLayout {
     LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + FOLD_SCRATCH; }
 };
+// Ref-NeRF backward: every layer is its own launch (bwd_kernels.hip dgrad_layer_kernel), so the blob is a table of independent
+// transposed layers, each starting on a chunk boundary.  (rows x K groups; "e" = a side output in the reference's column order)
+//    0 R    spec_rgb_head^T     256 x 1      1-3 D7,D6,D5  dir_block2.{6,4,2}^T        4 D4h  dir_block2.0[:, 167:]^T   256 x 16
+//    5 D4a  dir_block2.0[:, :167]^T  167 x 16 (e)           6-8 D3,D2,D1  dir_block1.{6,4,2}^T   9 D0a  dir_block1.0^T  167 x 16 (e)
+//   10 H    [bottle_neck ; heads]^T  256 x 9               11-13 S7,S6,S5 spa_block2.{6,4,2}^T  14 S4h  spa_block2.0[:, 63:]^T
+//   15 S4e  spa_block2.0[:, :63]^T    63 x 16 (e)          16-18 S3,S2,S1 spa_block1.{6,4,2}^T  19 S0e  spa_block1.0^T   63 x 16 (e)
+//   20 Hd   density row of the heads^T  256 x 1  (the density-gradient chain of RefNeRF.get_grad)
+struct RefBwdLayout {
+    static constexpr int N_LAYERS = 21;
+    static constexpr int NKG[21] = {1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 9, 16, 16, 16, 16, 16, 16, 16, 16, 16, 1};
+    static constexpr int NFB[21] = {8, 8, 8, 8, 8, 6, 8, 8, 8, 6, 8, 8, 8, 8, 8, 2, 8, 8, 8, 2, 8};
+    static constexpr int START[21] = {0, 8, 136, 264, 392, 520, 616, 744, 872, 1000, 1096, 1168, 1296, 1424, 1552, 1680, 1712, 1840, 1968, 2096, 2128};
+    static constexpr int N_FRAGS = 2136;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec); }
+};
+
 // Dump slots (one slot = 16 K groups per 32-sample subtile, fragment order).  Activation dump of the training forward:
 //   proposal 0..3 = layers.{0,2,4,6} outputs, 4 = [PE10 encoding: K groups 0..3];
 //   MipNeRF  0..3 = lin_block1 outputs, 4..6 = lin_block2 outputs, 7 = rgb_layer.0 output (K groups 0..7),
 //            8 = [PE10 encoding of the position: K groups 0..3 | PE4 encoding of the direction: K groups 4..5].
 // Delta dump of the backward chain: slot L = delta of the layer whose activations sit in activation slot L; the head K group goes to
 // K group 0 of slot 4 (proposal) / slot 8 (MipNeRF).
-constexpr int PROP_DUMP_SLOTS = 5, MIP_DUMP_SLOTS = 9;
+constexpr int PROP_DUMP_SLOTS = 5, MIP_DUMP_SLOTS = 9, REF_DUMP_SLOTS = 17;
 
 // RefNeRF(10, 4, bottle_neck 128, hidden 256, output 256)  (ref_model.py:16-66), eval mode, use_srgb = False.
 //   spatial: S0 63->256, S1-3, S4 319->256 (skip), S5-7;  H: [bottle_neck 128 rows | 11 head rows];

@@ -27,7 +27,7 @@ struct PackLayer {
 
 // all layers of a network in ONE launch (blockIdx.y = layer): re-packing after every optimiser step is part of the training step,
 // where the 5 + 10 separate launches were ~3 % of a 512-ray step
-constexpr int PACK_MAX_LAYERS = 18;
+constexpr int PACK_MAX_LAYERS = 24;
 struct PackBatch { PackLayer L[PACK_MAX_LAYERS]; };
 
 template <bool BF16>
@@ -201,7 +201,8 @@ int pack_proposal_bwd(int precision, const float* const* w, void* packed, hipStr
     PackBatch B = {};
     B.L[0] = make_trans_layer(w[4], 256, 0, 256, 1, Lay::NKG[0], Lay::NFB[0], Lay::START[0]);       // d3 = layers.8^T g
     for (int l = 1; l < 4; ++l) B.L[l] = make_trans_layer(w[4 - l], 256, 0, 256, 256, Lay::NKG[l], Lay::NFB[l], Lay::START[l]);
-    return launch_pack(B, 4, precision, reinterpret_cast<char*>(packed), nullptr, st);
+    B.L[4] = make_trans_layer(w[0], 63, 0, 63, 256, 16, 2, Lay::ENC_START);                        // d enc = layers.0^T delta_0 (density-gradient chain)
+    return launch_pack(B, 5, precision, reinterpret_cast<char*>(packed), nullptr, st);
 }
 
 // MipNeRF: w in _linear_layers() order (0..3 lin_block1, 4..6 lin_block2, 7 bottle_neck.0, 8 opacity_head.0, 9, 10 rgb_layer.{0,2})
@@ -223,4 +224,28 @@ int pack_mip_bwd(int precision, const float* const* w, void* packed, hipStream_t
     B.L[6] = make_trans_layer(w[2], 256, 0, 256, 256, 16, 8, Lay::START[6]);
     B.L[7] = make_trans_layer(w[1], 256, 0, 256, 256, 16, 8, Lay::START[7]);
     return launch_pack(B, 8, precision, stream, nullptr, st);
+}
+
+// Ref-NeRF: w = the 20 tensors of pack_ref (0-3 spa_block1, 4-7 spa_block2, 8 bottle_neck, 9 heads (11,256), 10-13 dir_block1,
+// 14-17 dir_block2, 18 spec_rgb_head.0, 19 ide_table); layer table: mlp_layout.h RefBwdLayout
+int pack_ref_bwd(int precision, const float* const* w, void* packed, hipStream_t st) {
+    using Lay = RefBwdLayout;
+    PackBatch B = {};
+    auto full = [&](int l, const float* m) { B.L[l] = make_trans_layer(m, 256, 0, 256, 256, 16, 8, Lay::START[l]); };
+    B.L[0] = make_trans_layer(w[18], 256, 0, 256, 3, 1, 8, Lay::START[0]);                          // spec head (slot features 0..2)
+    full(1, w[17]); full(2, w[16]); full(3, w[15]);
+    B.L[4] = make_trans_layer(w[14], 423, 167, 256, 256, 16, 8, Lay::START[4]);                     // dir_block2.0: hidden columns
+    B.L[5] = make_trans_layer(w[14], 423, 0, 167, 256, 16, 6, Lay::START[5]);                       //               input-vector columns
+    full(6, w[13]); full(7, w[12]); full(8, w[11]);
+    B.L[9] = make_trans_layer(w[10], 167, 0, 167, 256, 16, 6, Lay::START[9]);                       // dir_block1.0
+    PackLayer& H = B.L[10] = make_trans_layer(w[8], 256, 0, 256, 128, 9, 8, Lay::START[10]);        // [bottle_neck (K 0..127) | heads (K group 8)]
+    H.seg_nkg[0] = 8;
+    H.seg_w[1] = w[9]; H.seg_stride[1] = 256; H.seg_nkg[1] = 1; H.seg_first[1] = 0; H.seg_width[1] = 11;
+    full(11, w[7]); full(12, w[6]); full(13, w[5]);
+    B.L[14] = make_trans_layer(w[4], 319, 63, 256, 256, 16, 8, Lay::START[14]);                     // spa_block2.0: hidden columns
+    B.L[15] = make_trans_layer(w[4], 319, 0, 63, 256, 16, 2, Lay::START[15]);                       //               encoding columns
+    full(16, w[3]); full(17, w[2]); full(18, w[1]);
+    B.L[19] = make_trans_layer(w[0], 63, 0, 63, 256, 16, 2, Lay::START[19]);                        // spa_block1.0
+    B.L[20] = make_trans_layer(w[9] + 7 * 256, 256, 0, 256, 1, 1, 8, Lay::START[20]);               // the density row of the heads alone
+    return launch_pack(B, 21, precision, reinterpret_cast<char*>(packed), nullptr, st);
 }

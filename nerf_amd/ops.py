@@ -648,3 +648,57 @@ def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp
     numel = (C.c_int64 * n)(*[p.numel() for p in params])
     check(lib.nerf_amd_adam_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), numel, n, _ptr(step),
                                  float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), _stream()), "nerf_amd_adam_step")
+
+
+# ------------------------------------------------------------------------------------------------ Ref-NeRF training / density gradients
+def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, noise: Optional[torch.Tensor]):
+    """RefNeRF.forward in training (ref_model.py:68-106) + the activation dump and the pre-activation head values of the backward.
+    pts (..., 6) -> (rgbo (..., 4), normal (..., 3), dump, aux (M, 16))"""
+    pts = _dev(pts, "pts")
+    rgbo, normal = _ref_out(pts.shape[:-1], pts.device, True)
+    s = _samples_pts(pts, 6)
+    dump = torch.empty((lib.nerf_amd_train_dump_bytes(NET_REF, precision, s.M),), dtype=torch.uint8, device=pts.device)
+    aux = torch.empty((s.M, 16), dtype=torch.float32, device=pts.device)
+    if s.M:
+        noise = _dev(noise, "noise") if noise is not None else None
+        check(lib.nerf_amd_ref_forward_train_dump(_ptr(packed), precision, C.byref(s), _ptr(noise), _ptr(rgbo), _ptr(normal), _ptr(dump), _ptr(aux),
+                                                  _stream()), "nerf_amd_ref_forward_train_dump")
+    return rgbo, normal, dump, aux
+
+
+def density_grad(net: int, packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d density / d position of every sample (RefNeRF.get_grad before its normalisation), times `scale` (M,) -- proposal network or
+    Ref-NeRF's spatial network.  x (M, >= 3) contiguous rows; -> (M, 3)."""
+    x = _dev(x, "positions")
+    M = x.shape[0]
+    out = torch.empty((M, 3), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
+    ws = torch.empty(lib.nerf_amd_density_grad_workspace_bytes(net, precision, M), dtype=torch.uint8, device=x.device)
+    sc_stride = 0
+    if scale is not None:
+        if scale.dtype != torch.float32 or not scale.is_cuda or scale.dim() != 1:
+            scale = scale.reshape(-1).float().contiguous()
+        sc_stride = scale.stride(0)
+    check(lib.nerf_amd_density_grad(net, _ptr(packed_bwd), precision, M, _ptr(dump), _ptr(x), x.shape[1], _ptr(scale), sc_stride, _ptr(out), _ptr(ws),
+                                    _stream()), "nerf_amd_density_grad")
+    return out
+
+
+REF_GRAD_SHAPES = ([(256, 63)] + [(256, 256)] * 3 + [(256, 319)] + [(256, 256)] * 3 + [(128, 256), (9, 256), (2, 256), (256, 167)] + [(256, 256)] * 3 +
+                   [(256, 423)] + [(256, 256)] * 3 + [(3, 256)])
+
+
+def ref_backward(packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, aux: torch.Tensor, dirs: torch.Tensor, g_out: torch.Tensor,
+                 ide_table: torch.Tensor):
+    """Every parameter gradient of RefNeRF.forward.  g_out (M,7) = d loss / d [rgb | raw density | predicted normal]; dirs (M,3).
+    -> ([dW]*20, [db]*20): 0..7 spatial, 8 bottle_neck, 9 norm_col_tint_head, 10 rho_tau_head, 11..18 directional, 19 spec_rgb_head.0"""
+    g_out, dirs, aux = _dev(g_out, "g_out"), _dev(dirs, "dirs"), _dev(aux, "aux")
+    M = g_out.shape[0]
+    dev = g_out.device
+    gw = _grad_buffers(REF_GRAD_SHAPES, dev)
+    gb = _grad_buffers([(s[0],) for s in REF_GRAD_SHAPES], dev)
+    ws = torch.empty(lib.nerf_amd_ref_backward_workspace_bytes(precision, M), dtype=torch.uint8, device=dev)
+    check(lib.nerf_amd_ref_backward(_ptr(packed_bwd), precision, M, _ptr(dump), _ptr(aux), _ptr(dirs), dirs.shape[1], _ptr(g_out), g_out.shape[1],
+                                    _ptr(_dev(ide_table, "ide_table")), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()), "nerf_amd_ref_backward")
+    return gw, gb

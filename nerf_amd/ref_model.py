@@ -86,17 +86,62 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         named = list(self.named_parameters())
         params = [p for _, p in named]
         if ab.needs_grad(pos, d, *params):
-            # training (train.py:176-186): HIP forward; gradients (w.r.t. parameters AND positions -- RefNeRF.get_grad) from the
-            # device-side VJP of the same expression with the same noise
+            # training (train.py:176-186): HIP training forward (activation dump); the backward is hand-written kernels too --
+            #   RefNeRF.get_grad (d density / d position, inputs_only mode): a dgrad-only chain to the encoded position + the encoding's
+            #     derivative (nerf_amd_density_grad);
+            #   loss.backward(): single-layer dgrad launches, the element-wise IDE / normal / head stage, MFMA weight gradients
+            #     (nerf_amd_ref_backward).  Gradients w.r.t. the positions are only produced for get_grad (the reference discards the rest).
             names = [n for n, _ in named]
+            held = {}
+            shape = pos.shape[:-1]
 
             def hip(p, dd, *wb):
-                rgbo, normal = ops.ref_forward(self.packed(prec), prec, torch.cat((p, dd), dim=-1).contiguous(), noise=noise)
+                pts6 = torch.cat((p, dd), dim=-1).contiguous()
+                rgbo, normal, held["dump"], held["aux"] = ops.ref_forward_train(self.packed(prec), prec, pts6, noise)
+                held["pts"] = pts6.view(-1, 6)
                 return torch.cat((rgbo, normal), dim=-1)
+
+            def bwd(g, p, dd, *wb):
+                if "dump" not in held:
+                    raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
+                g2 = g.reshape(-1, 7)
+                if "bwd_blob" not in held:
+                    held["bwd_blob"] = self.packed_backward(prec)
+                if ab._VJP.inputs_only:                       # RefNeRF.get_grad: the density channel's gradient w.r.t. the positions
+                    gx = ops.density_grad(ops.NET_REF, held["bwd_blob"], prec, held["dump"], held["pts"], scale=g2[:, 3])
+                    return (gx.view(p.shape), None, *[None] * len(wb))
+                gw, gb = ops.ref_backward(held["bwd_blob"], prec, held.pop("dump"), held.pop("aux"), held["pts"][:, 3:], g2, self._ide_table(p.device))
+                by_name = self._grads_by_name(gw, gb)
+                return (None, None, *[by_name[n] for n in names])
             expr = lambda p, dd, *wb: ab.ref_expr(p, dd, noise, dict(zip(names, wb)), self.integrated_dir_enc)
-            out = ab.HipOp.apply(hip, expr, 0, pos, d, *params)
+            out = ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pos, d, *params)
             return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
         return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise)
+
+    def _ide_table(self, device):
+        tables = self.__dict__.setdefault("_ide_table_on", {})
+        if device not in tables:
+            tables[device] = ide_table(4).to(device).contiguous()
+        return tables[device]
+
+    def packed_backward(self, precision: int) -> torch.Tensor:
+        ws, _ = self._pack_tensors()
+        return ops.pack_weights_backward(self._net_id, precision, ws)
+
+    @staticmethod
+    def _grads_by_name(gw, gb):
+        """kernel tensor order (include/nerf_amd.h, nerf_amd_ref_backward) -> parameter names"""
+        out = {}
+        for i, l in enumerate((0, 2, 4, 6)):
+            out["spa_block1.%d.weight" % l], out["spa_block1.%d.bias" % l] = gw[i], gb[i]
+            out["spa_block2.%d.weight" % l], out["spa_block2.%d.bias" % l] = gw[4 + i], gb[4 + i]
+            out["dir_block1.%d.weight" % l], out["dir_block1.%d.bias" % l] = gw[11 + i], gb[11 + i]
+            out["dir_block2.%d.weight" % l], out["dir_block2.%d.bias" % l] = gw[15 + i], gb[15 + i]
+        out["bottle_neck.weight"], out["bottle_neck.bias"] = gw[8], gb[8]
+        out["norm_col_tint_head.weight"], out["norm_col_tint_head.bias"] = gw[9], gb[9]
+        out["rho_tau_head.weight"], out["rho_tau_head.bias"] = gw[10], gb[10]
+        out["spec_rgb_head.0.weight"], out["spec_rgb_head.0.bias"] = gw[19], gb[19]
+        return out
 
     @staticmethod
     def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum: int) -> torch.Tensor:

@@ -27,11 +27,20 @@ CHECKPOINTS = (110, 120, 130, 140, 150)   # iterations at which the held-out vie
 LR = 1.5e-4 * RAYS / 512            # the reference's rule: args.lr * sample_ray_num / 512 (train.py:56)
 
 
-def analytic_scene():
+N_VIEWS = 8                          # 7 training views + 1 held-out; scripts/gpu_psnr_long.py raises it for the long runs
+SCHED = None                         # optional it -> learning rate (the long runs use nerf_base.DecayLrScheduler's rule, train.py:133,200)
+
+
+def analytic_scene(n_views=None):
+    """A unit sphere at the origin, colour = 0.5 + 0.5 normal, white background, seen from `n_views` orbit poses (the last one is held
+    out).  With 8 views the poses are the 45-degree orbit at -30 degrees elevation; more views spiral over three elevations."""
+    n_views = N_VIEWS if n_views is None else n_views
     focal = O.fov2focal(0.6911112070083618, (H, H))
     views = []
-    for th in range(0, 360, 45):
-        pose = O.pose_spherical(float(th), -30.0, 4.0)[:3]
+    for i in range(n_views):
+        th = 360.0 * i / n_views
+        ph = -30.0 if n_views <= 8 else (-30.0, -10.0, -55.0)[i % 3]
+        pose = O.pose_spherical(float(th), ph, 4.0)[:3]
         d = O.ray_dirs_image(pose, H, H, focal).reshape(-1, 3)
         o = pose[:, -1].expand(H * H, -1)
         dn = d / d.norm(dim=-1, keepdim=True)
@@ -71,6 +80,9 @@ def run_oracle(views, seed):
         rend, wts, _ = O.composite(rgbo, z_f, rays[:, 3:], white_bkg=True)
         loss_img = torch.mean((rend - tgt) ** 2)
         loss = O.proposal_loss(O.get_bounds(pw, below), wts.detach()) + loss_img
+        if SCHED is not None:
+            for gr in opt.param_groups:
+                gr["lr"] = SCHED(it)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -118,6 +130,9 @@ def run_hip(views, seed, precision):
         rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
         loss_img = torch.mean((rend - tgt) ** 2)
         loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + loss_img
+        if SCHED is not None:
+            for gr in opt.param_groups:
+                gr["lr"] = SCHED(it)
         opt.zero_grad()
         loss.backward()
         opt.step()
