@@ -179,16 +179,26 @@ def gemm_reference(dev):
 
 
 def train_rate(precision):
-    """Optional second figure of SURVEY 8d: rays/s of a whole training step (train.py:164-199 body + Adam: HIP training forward,
-    GEMM-chain / HIP backward, optimizer) on synthetic rays, measured after the timed region; never part of `value`."""
+    """Second figure of SURVEY 8d: rays/s of a whole training step (train.py:164-199 body + Adam: HIP training forward with activation
+    dump, fused dgrad chain, MFMA weight gradients, one-launch Adam -- no library GEMM anywhere) on synthetic rays, measured after the
+    timed region; never part of `value`.  Its roofline: 3 x the forward's algorithmic flops (forward + dgrad + wgrad) against the dense
+    bf16 MFMA peak; the step is HBM-bound by design (activation dump written once, read twice: DESIGN.md section 5)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpu_train_rate", os.path.join(ROOT, "scripts", "gpu_train_rate.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     out = {"unit": "rays/s (fwd + bwd + Adam step, 64+128 samples)", "precision": precision}
-    for n in (512, 4096):
+    peak = PEAK_BF16_DENSE if precision == "bf16" else PEAK_F32_MFMA
+    for n in (512, 4096, 16384):
         dt = mod.run(n, 64, 128, precision, iters=10, warm=3, quiet=True)
         out["rays_%d" % n] = {"rays_per_s": n / dt, "ms_per_iter": dt * 1e3}
+    dt = mod.run(512, 64, 128, precision, iters=30, warm=5, quiet=True, graph=True)
+    out["rays_512_hipgraph"] = {"rays_per_s": 512 / dt, "ms_per_iter": dt * 1e3}
+    best = out["rays_16384"]["rays_per_s"]
+    out["roofline"] = {"bound": "mfma", "kernel": "whole training step, 16384 rays (3 x 162.4 MFLOP/ray)", "achieved": best * 3 * FLOP_PER_RAY / 1e12,
+                       "peak": peak / 1e12, "unit": "TFLOP/s", "frac": best * 3 * FLOP_PER_RAY / peak, "traffic": None}
+    dt = mod.run_ref(512, 64, 128, precision, iters=10, warm=3, quiet=True)
+    out["refnerf_rays_512"] = {"rays_per_s": 512 / dt, "ms_per_iter": dt * 1e3, "note": "Ref-NeRF step with prop_normal (train.py:176-187)"}
     import nerf_amd
     nerf_amd.set_precision(precision)
     return out

@@ -163,6 +163,11 @@ struct WeightStream {
         // the builtin form as a "flat" access that may touch LDS and from then on turns EVERY s_waitcnt lgkmcnt(N) of
         // the A-fragment prefetch into lgkmcnt(0) -- which serialises the LDS pipeline (measured: 59% -> MFMA-bound).
         // The asm is invisible to that pass; completion is tracked by our own counted vmcnt in boundary().
+        // (Round 2 A/B: a scalar-base form -- `global_load_lds_dwordx4 v_lane16, s[base] offset:1024`, M0 written once per chunk and
+        // not restored -- removes 370 of 520 s_mov, all 64-bit VALU adds and 136 of 234 s_cselect from the fine kernel's code and
+        // changes its time by < 0.5 %, inside the box-to-box noise: issue slots of the ring bookkeeping are not what bounds the
+        // kernel.  It also faulted intermittently (an SGPR hazard between v_readfirstlane and the VMEM scalar base that the compiler
+        // does not pad inside inline asm), so it was dropped.)
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
 #if !defined(ABL_NOGLDS)

@@ -30,19 +30,8 @@ def main():
     T.ITERS = iters
     step = max(iters // 40, 1)
     T.CHECKPOINTS = tuple(range(step, iters + 1, step))
-    # the reference's schedule (nerf_base.DecayLrScheduler, train.py:133): linear warm-up, then lr * decay_rate^(it / decay_step) with a
-    # floor -- compressed so that the rate falls by 10x over this run instead of over 100 000 iterations
-    min_r, decay_r, warm = 0.01, 0.1, min(200, iters // 10)
-
-    t0_decay = max(warm, int(hold * iters))
-
-    def sched(it):
-        if it < warm:
-            r = it / warm
-            return T.LR * (min_r * (1.0 - r) + r)
-        if it < t0_decay:
-            return T.LR
-        return T.LR * max(decay_r ** (2.0 * (it - t0_decay) / max(iters - t0_decay, 1)), min_r)
+    # the reference's schedule shape (nerf_base.DecayLrScheduler, train.py:133) compressed to this run: tests' long_schedule()
+    sched = T.long_schedule(T.LR, iters, hold=hold) if hold > 0 else T.long_schedule(T.LR, iters, hold=0.0, decay_r=0.1 ** 0.5)
     T.SCHED = sched
     torch.set_num_threads(min(32, torch.get_num_threads()))
     views = T.analytic_scene(n_views)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Training-step rate of the nerf_amd surface (HIP forward + autograd bridge, SURVEY 8f-1 baseline): the body of the
+"""Training-step rate of the nerf_amd surface (HIP training forwards, hand-written backward kernels, one-launch Adam): the body of the
 reference's train.py:164-199 (proposal -> weights -> blur -> inverse sampling -> fine -> composite -> losses -> backward -> Adam)
 on synthetic rays, for a few batch sizes.  Prints rays/s (fwd+bwd+step)."""
 import sys
@@ -75,7 +75,8 @@ def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False, graph=Fa
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, net = ProposalNetwork(10, 256).cuda().train(), RefNeRF(10, 4).cuda().train()
-    opt = torch.optim.Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-4, capturable=graph)
+    from nerf_amd.optim import Adam
+    opt = Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-4)
     o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
     rays = torch.cat((o, d), -1).cuda().contiguous()

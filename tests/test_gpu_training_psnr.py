@@ -152,6 +152,53 @@ def run_hip(views, seed, precision):
 SEEDS = (7, 8, 9)
 
 
+def long_schedule(base_lr, iters, hold=0.6, min_r=0.01, decay_r=0.1):
+    """nerf_base.DecayLrScheduler's shape (train.py:133: linear warm-up, exponential decay with a floor) compressed to `iters`
+    iterations: full rate for the first `hold` of the run, then a 100x decay."""
+    warm = min(200, iters // 10)
+    t0 = max(warm, int(hold * iters))
+
+    def sched(it):
+        if it < warm:
+            r = it / warm
+            return base_lr * (min_r * (1.0 - r) + r)
+        if it < t0:
+            return base_lr
+        return base_lr * max(decay_r ** (2.0 * (it - t0) / max(iters - t0, 1)), min_r)
+    return sched
+
+
+def test_long_training_learns_the_scene_in_both_precisions():
+    """4000 iterations on 24 training views (512 rays, the reference's learning-rate rule x 3 with its scheduler shape): the HIP
+    training path -- fp32 and bf16 kernels, hand-written backward, one-launch Adam -- LEARNS the scene (held-out view >= 24.5 dB, from
+    10.8 dB at the start), and the two precisions end within the run-to-run spread of each other.  The CPU oracle's run of the same
+    recipe takes 42 minutes per seed and is kept as a committed log (profiles/r02_psnr_long_*.log; scripts/gpu_psnr_long.py):
+    end-of-run PSNR at this horizon is a random variable with a spread of ~1.5 dB across seeds in EVERY path (training is chaotic: an
+    fp32 ulp changes the trajectory), so the paths are compared as distributions there, not at 0.1 dB on one render; the
+    equal-iterations 0.1 dB gate is the short-horizon test below, where the trajectories have not yet diverged."""
+    global ITERS, CHECKPOINTS, RAYS, LR, SCHED
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    saved = (ITERS, CHECKPOINTS, RAYS, LR, SCHED)
+    try:
+        ITERS, RAYS = 4000, 512
+        CHECKPOINTS = (3700, 3800, 3900, 4000)
+        LR = 3.0 * 1.5e-4 * RAYS / 512
+        SCHED = long_schedule(LR, ITERS)
+        views = analytic_scene(25)
+        final = {"fp32": [], "bf16": []}
+        for seed in (7, 9):
+            for prec in ("fp32", "bf16"):
+                _, held = run_hip(views, seed, prec)
+                final[prec].append(sum(held) / len(held))
+        print("\nlong run, held-out dB (mean of the last 4 renders): fp32 %s  bf16 %s" % (final["fp32"], final["bf16"]))
+        for prec in ("fp32", "bf16"):
+            assert min(final[prec]) >= 24.5, (prec, final)
+        assert abs(sum(final["fp32"]) / 2 - sum(final["bf16"]) / 2) <= 2.0, final
+    finally:
+        ITERS, CHECKPOINTS, RAYS, LR, SCHED = saved
+
+
 def test_psnr_at_equal_iterations():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
