@@ -38,6 +38,8 @@ using PB16 = PBF16W;
 struct Dump {               // a fragment-ordered dump: slot l, subtile s, K group kg -> base + l*layer_stride + (s*16 + kg) * BREG_LDS
     char* base;
     unsigned long long layer_stride;
+    const char* mask_base;  // the forward's ReLU bit masks: slot l, subtile s -> mask_base + l*mask_layer_stride + s*1024 (mlp_kernels.hip mask_or)
+    unsigned long long mask_layer_stride;
 };
 
 // one 1 KiB global -> LDS DMA piece (16 B per lane, lane-linear); `lds_dst` must be wave-uniform (see WeightStream::issue for why asm)
@@ -63,6 +65,28 @@ DEVINL f32x8 relu_mask(const f32x8& d, const f32x8& y) {
     return r;
 }
 
+// the same from the forward's bit masks: `w` = the lane's mask dword of K groups 4 (kg >> 2) .. + 3; element e of K group kg is bit
+// 4 (kg & 3) + (e >> 1) + 16 (e & 1)
+DEVINL bf16x8 relu_mask_bits(const bf16x8& d, uint32_t w, int kg) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+    u32x4 v = __builtin_bit_cast(u32x4, d);
+    const uint32_t ws = w >> (4 * (kg & 3));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t sel = (ws >> i) & 0x00010001u, x = v[i];   // (scalar copies: __builtin_bit_cast of a vector-element expression misreads)
+        v[i] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, sel)));
+    }
+    return __builtin_bit_cast(bf16x8, v);
+}
+DEVINL f32x8 relu_mask_bits(const f32x8& d, uint32_t w, int kg) {
+    const uint32_t ws = w >> (4 * (kg & 3));
+    f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = ((ws >> ((e >> 1) + 16 * (e & 1))) & 1u) ? d[e] : 0.0f;
+    return r;
+}
+
 constexpr uint32_t BWD_LDS_ZERO = MLP_RING_BYTES;                    // 1 KiB of zeros: the "bias" of every chain layer
 constexpr uint32_t BWD_LDS_MASK = MLP_RING_BYTES + 1024;
 template <class P> constexpr uint32_t bwd_pair_bytes() { return 4 * P::NT * P::BREG_LDS; }          // (2 blocks x 2 halves x NT tiles) mask groups
@@ -74,8 +98,9 @@ template <class P> constexpr uint32_t bwd_lds_total() { return BWD_LDS_MASK + P:
 template <class P> constexpr int mask_wait_count(int nkg) { return ((MLP_CHUNK_BYTES / 1024) / P::NW) * ((2 * nkg) / P::FPC); }
 template <int N> DEVINL void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Output functor of a chain layer with NKG_CUR K steps whose predecessor in the stream had NKG_PREV: convert, mask by the forward
-// activations of `layer`, keep in registers, dump.
+// Output functor of a layer of the fused chains (NKG_CUR K steps): convert, apply the ReLU adjoint from the forward's BIT masks of
+// `layer` (1 KiB per subtile and layer, LDS-DMA'd when the layer starts into the buffer of the layer's parity -- consecutive chain
+// layers have alternating slot parity, so the previous layer's pending pair still reads its own buffer), keep in registers, dump.
 template <class P, int NKG_CUR, int NKG_PREV>
 struct MaskedOut {
     typename P::BReg (&buf)[P::NT][16];
@@ -83,31 +108,26 @@ struct MaskedOut {
     int layer;
     int64_t sub0;
     int lane;
-    uint32_t mask_lds;          // this wave's two pair buffers (wave-uniform byte offset)
+    uint32_t mask_lds;          // this wave's two layer buffers of NT KiB each (wave-uniform byte offset)
 
-    // start of feature-block pair G: the previous pair's masks (consumed from now on by its deferred epilogue) must have landed; then
-    // this pair's masks start their way into the other buffer
     DEVINL void begin_group(int G) const {
-        if (G == 0) vm_wait<mask_wait_count<P>(NKG_PREV)>(); else vm_wait<mask_wait_count<P>(NKG_CUR)>();
+        if (G == 0) {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int t = 0; t < P::NT; ++t) {
-                    const int kg = 2 * (2 * G + blk) + half;
-                    const char* src = act.base + (size_t)layer * act.layer_stride + ((size_t)(sub0 + t) * 16 + kg) * (size_t)P::BREG_LDS + lane * 16;
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(mask_lds + (G & 1) * bwd_pair_bytes<P>() + ((blk * 2 + half) * P::NT + t) * P::BREG_LDS);
-#pragma unroll
-                    for (int p = 0; p < P::BREG_LDS / 1024; ++p) glds_piece(src + p * 1024, dst + p * 1024);
-                }
+            for (int t = 0; t < P::NT; ++t) {
+                const char* src = act.mask_base + (size_t)layer * act.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16;
+                glds_piece(src, __builtin_amdgcn_readfirstlane(mask_lds + ((layer & 1) * P::NT + t) * 1024));
+            }
+        } else if (G == 1) {
+            vm_wait<mask_wait_count<P>(NKG_CUR)>();          // pair 0's epilogue (the first reader) starts now
+        }
     }
     DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
+        const int kg = 2 * fb + half;
         const typename P::BReg d = to_breg_half<P, false>(acc, half);
-        const uint32_t at = mask_lds + ((fb >> 1) & 1) * bwd_pair_bytes<P>() + (((fb & 1) * 2 + half) * P::NT + t) * P::BREG_LDS + lane * 16;
-        const typename P::BReg v = relu_mask(d, P::unstash(at));
-        buf[t][2 * fb + half] = v;
-        P::store_global(dlt.base + (size_t)layer * dlt.layer_stride + ((size_t)(sub0 + t) * 16 + (2 * fb + half)) * (size_t)P::BREG_LDS, lane, v);
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + mask_lds + ((layer & 1) * P::NT + t) * 1024 + lane * 16 + (kg >> 2) * 4);
+        const typename P::BReg v = relu_mask_bits(d, w, kg);
+        buf[t][kg] = v;
+        P::store_global(dlt.base + (size_t)layer * dlt.layer_stride + ((size_t)(sub0 + t) * 16 + kg) * (size_t)P::BREG_LDS, lane, v);
     }
 };
 
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
-    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * NT * 1024);
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
-    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * NT * 1024);
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
@@ -854,18 +874,21 @@ int launch_wgrad(int precision, const WgradJobs& jobs, int n_jobs, int n_wg, int
 
 // ------------------------------------------------------------------------------------------------ host-visible launchers (capi.hip)
 size_t mlp_train_layer_stride(int precision, int64_t M);
+size_t mlp_train_mask_stride(int precision, int64_t M);
 
 int bwd_launch_prop_chain(const void* packed_bwd, int precision, const float* g_density, int64_t M, const void* act_dump, void* delta_dump,
                           hipStream_t st) {
-    const unsigned long long ls = mlp_train_layer_stride(precision, M);
-    const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls}, dlt{reinterpret_cast<char*>(delta_dump), ls};
+    const unsigned long long ls = mlp_train_layer_stride(precision, M), ms = mlp_train_mask_stride(precision, M);
+    const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls, reinterpret_cast<const char*>(act_dump) + (size_t)PROP_DUMP_SLOTS * ls, ms},
+               dlt{reinterpret_cast<char*>(delta_dump), ls, nullptr, 0ull};
     if (precision == NERF_AMD_BF16) return launch_prop_bwd<PB16>(packed_bwd, g_density, M, act, dlt, st);
     return launch_prop_bwd<PF32>(packed_bwd, g_density, M, act, dlt, st);
 }
 int bwd_launch_mip_chain(const void* packed_bwd, int precision, const float* g_rgbo, const float* rgbo, int64_t M, const void* act_dump,
                          void* delta_dump, hipStream_t st) {
-    const unsigned long long ls = mlp_train_layer_stride(precision, M);
-    const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls}, dlt{reinterpret_cast<char*>(delta_dump), ls};
+    const unsigned long long ls = mlp_train_layer_stride(precision, M), ms = mlp_train_mask_stride(precision, M);
+    const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls, reinterpret_cast<const char*>(act_dump) + (size_t)MIP_DUMP_SLOTS * ls, ms},
+               dlt{reinterpret_cast<char*>(delta_dump), ls, nullptr, 0ull};
     if (precision == NERF_AMD_BF16) return launch_mip_bwd<PB16>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
     return launch_mip_bwd<PF32>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
 }

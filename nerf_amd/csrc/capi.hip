@@ -12,6 +12,7 @@ int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_
 int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
 int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, const float*, hipStream_t);
 size_t mlp_train_layer_stride(int, int64_t);
+size_t mlp_train_mask_stride(int, int64_t);
 int mlp_launch_proposal_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
 int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
 int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t);
@@ -311,7 +312,9 @@ static int train_layers(int net) {
 }
 size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M) {
     if (M < 0 || !train_layers(net) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return 0;
-    return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M);
+    // activation slots + (proposal / MipNeRF) one ReLU bit per activation: 1 KiB per slot and 32-sample subtile
+    const size_t bits = net == NERF_AMD_NET_REF ? 0 : (size_t)train_layers(net) * mlp_train_mask_stride(precision, M);
+    return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M) + bits;
 }
 int nerf_amd_proposal_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* dump, void* stream) {
     if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");

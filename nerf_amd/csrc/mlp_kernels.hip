@@ -207,10 +207,62 @@ DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias, uin
 struct ActDump {
     char* base;
     unsigned long long layer_stride;
+    char* mask_base;                       // ReLU bit masks (proposal / MipNeRF): slot l, subtile s -> mask_base + l*mask_layer_stride + s*1024
+    unsigned long long mask_layer_stride;  //   one 16-byte record per lane = 128 bits: K group kg -> dword kg>>2, nibble pair 4*(kg&3)
 };
 template <class P>
 DEVINL void dump_breg(const ActDump& d, int layer, int64_t subtile, int kg, int lane, const typename P::BReg& r) {
     P::store_global(d.base + (size_t)layer * d.layer_stride + ((size_t)subtile * 16 + kg) * (size_t)P::BREG_LDS, lane, r);
+}
+
+// The backward's ReLU adjoint only needs [y > 0]: next to the activations (the weight gradients' operand) the training forwards
+// leave ONE BIT per activation -- 32 B per sample and layer instead of the 512 B the dgrad chain would otherwise re-read.
+// Bit layout of a B register group: element e -> bit (e >> 1) + 16 (e & 1) (i.e. the low / high halves of its four packed dwords),
+// shifted by 4 (kg & 3) inside dword kg >> 2 of the lane's 16-byte record.  The bits are OR-ed into a per-wave LDS record
+// (ds_or_b32: no registers held across the layer) and written out once per layer and subtile.
+template <class P> constexpr uint32_t lds_maskacc() { return lds_total<P>(); }
+template <class P> constexpr uint32_t lds_total_train() { return lds_total<P>() + P::NW * 2 * P::NT * 1024; }
+DEVINL uint32_t breg_bits(const bf16x8& v) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+    const u32x4 d = __builtin_bit_cast(u32x4, v);
+    const u16x2 one = {1, 1};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x = d[i];           // (a scalar copy: __builtin_bit_cast applied to a vector-element expression reads the wrong bytes)
+        m |= __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), one)) << i;
+    }
+    return m;
+}
+DEVINL uint32_t breg_bits(const f32x8& v) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m |= (v[e] > 0.0f ? 1u : 0u) << ((e >> 1) + 16 * (e & 1));
+    return m;
+}
+template <class P>
+DEVINL void mask_or(uint32_t acc_wave, int layer, int t, int kg, int lane, const typename P::BReg& v) {
+    unsigned* w = reinterpret_cast<unsigned*>(smem + acc_wave + ((layer & 1) * P::NT + t) * 1024 + lane * 16 + (kg >> 2) * 4);
+    __hip_atomic_fetch_or(w, breg_bits(v) << (4 * (kg & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the layer's records are complete (its last feature-block pair has been converted): write them out and clear the LDS copy
+template <class P>
+DEVINL void mask_flush(const ActDump& d, uint32_t acc_wave, int layer, int64_t sub0, int lane) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < P::NT; ++t) {
+        f32x4* rec = reinterpret_cast<f32x4*>(smem + acc_wave + ((layer & 1) * P::NT + t) * 1024 + lane * 16);
+        const f32x4 v = *rec;
+        *reinterpret_cast<f32x4*>(d.mask_base + (size_t)layer * d.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16) = v;
+        *rec = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    asm volatile("" ::: "memory");
+}
+template <class P>
+DEVINL void mask_acc_init(uint32_t acc_wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2 * P::NT; ++i) *reinterpret_cast<f32x4*>(smem + acc_wave + i * 1024 + lane * 16) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
 // ================================================================================================
@@ -231,6 +283,8 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = MLP_RING_BYTES;
+    const uint32_t macc = lds_maskacc<P>() + wave * 2 * NT * 1024;      // TRAIN: this wave's ReLU bit-mask records
+    if constexpr (TRAIN) mask_acc_init<P>(macc, lane);
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
@@ -252,7 +306,10 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
         auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
-            if constexpr (TRAIN) dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+            if constexpr (TRAIN) {
+                dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+                mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+            }
         };
         auto OA = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay, fb, t, acc, half); };
         auto OB = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay, fb, t, acc, half); };
@@ -271,15 +328,18 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         for (int r = 0; r < 2; ++r) {
             lay_pend = lay; lay = 1 + 2 * r;
             d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + r * 512) * 4, IN_A, OB, prev_of(d, OA_pend));
+            if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);        // (its last pair was converted during this layer)
             if (r == 0) {
                 lay_pend = lay; lay = 2;
                 d = dense<P, 16, 8, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB_pend));
+                if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);
             }
         }
         lay_pend = lay;
         float dens[NT];
         auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
         dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB_pend)).flush(OH);
+        if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
@@ -320,6 +380,8 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = LDS_BIAS;
+    const uint32_t macc = lds_maskacc<P>() + wave * 2 * NT * 1024;      // TRAIN: this wave's ReLU bit-mask records
+    if constexpr (TRAIN) mask_acc_init<P>(macc, lane);
     // per 32-sample column tile ("subtile" sub = wave*NT + t) LDS slots
     const uint32_t enc_lds0 = LDS_STASH + wave * NT * 4 * P::BREG_LDS + lane * 16;
     const uint32_t dir_lds0 = lds_dir<P>() + wave * NT * 1024 + lane * 16;
@@ -333,7 +395,10 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
         auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
-            if constexpr (TRAIN) dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+            if constexpr (TRAIN) {
+                dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+                mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+            }
         };
         auto OA = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay, fb, t, acc, half); };
         auto OB = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay, fb, t, acc, half); };
@@ -396,6 +461,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         for (int r = 0; r < 3; ++r) {
             lay_pend = lay; lay = 1 + 2 * r;
             d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (1 + 2 * r) * 256 * 4, IN_A, OB, prev_of(d, OA_pend));
+            if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);        // (its last pair was converted during this layer)
             lay_pend = lay; lay = 2 + 2 * r;
             if (r == 1) {
                 d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
@@ -404,12 +470,14 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             } else {
                 d = dense<P, 16, 8, L::START[2]>(ws, bias0 + (2 + 2 * r) * 256 * 4, IN_B, OA, prev_of(d, OB_pend));
             }
+            if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);
         }
         lay_pend = lay;
         // opacity_head.0 : 256 -> 1 (raw sigma)
         float sigma[NT];
         auto OSIG = [&](int, int t, const f32x16& acc, int half) { if (half == 0) sigma[t] = acc[0]; };
         const auto dsig = dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4, IN_A, OSIG, prev_of(d, OA_pend));
+        if constexpr (TRAIN) mask_flush<P>(dump, macc, 6, sub0, lane);
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
         BReg denc[NT][2];
 #pragma unroll
@@ -426,7 +494,10 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         BReg c[NT][8];
         auto OC = [&](int fb, int t, const f32x16& acc, int half) {
             c[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
-            if constexpr (TRAIN) dump_breg<P>(dump, 7, sub0 + t, 2 * fb + half, lane, c[t][2 * fb + half]);     // slot 7: rgb_layer.0 output
+            if constexpr (TRAIN) {                                                                       // slot 7: rgb_layer.0 output
+                dump_breg<P>(dump, 7, sub0 + t, 2 * fb + half, lane, c[t][2 * fb + half]);
+                mask_or<P>(macc, 7, t, 2 * fb + half, lane, c[t][2 * fb + half]);
+            }
         };
         const auto dc = dense<P, 18, 4, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4,
             [&](int kg, int t) -> BReg { if (kg < 16) return a[t][kg < 16 ? kg : 0]; return denc[t][kg >= 16 ? kg - 16 : 0]; },
@@ -436,6 +507,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         auto ORGB = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { r[t] = acc[0]; g[t] = acc[1]; bl[t] = acc[2]; } };
         dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
             [&](int kg, int t) -> BReg { return c[t][kg]; }, ORGB, prev_of(dc, OC)).flush(ORGB);
+        if constexpr (TRAIN) mask_flush<P>(dump, macc, 7, sub0, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
         f32x4 o;
@@ -757,17 +829,17 @@ int grid_for(int64_t n_tiles) {
 // Dynamic LDS above 64 KiB is an opt-in per KERNEL FUNCTION and device (host_common.h)
 int allow_dynamic_lds(const void* fn, size_t lds) { return nerf_host::allow_dynamic_lds(fn, lds); }
 
-template <class P, class Lay, class K, class... Extra>
+template <class P, class Lay, bool TRAIN = false, class K, class... Extra>
 int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st, Extra... extra) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
-    const size_t lds = lds_total<P>();
+    const size_t lds = TRAIN ? lds_total_train<P>() : lds_total<P>();
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
     hipLaunchKernelGGL(kernel, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, out, extra...);
     return (int)hipGetLastError();
 }
-const ActDump NO_DUMP{nullptr, 0ull};
+const ActDump NO_DUMP{nullptr, 0ull, nullptr, 0ull};
 
 // bf16 policy of the shipped library: the wide tile (measured 2.5 % faster end to end);
 // -DMLP_BF16_NARROW selects the 8-wave x 32-sample tile for A/B runs
@@ -809,16 +881,22 @@ size_t mlp_train_layer_stride(int precision, int64_t M) {
     const int64_t n_sub = ((M + ts - 1) / ts) * (ts / 32);
     return (size_t)n_sub * 16 * (precision == NERF_AMD_BF16 ? 1024 : 2048);
 }
+// the ReLU bit masks sit behind the `slots` activation slots of a dump: 1 KiB per slot and subtile
+size_t mlp_train_mask_stride(int precision, int64_t M) { return mlp_train_layer_stride(precision, M) / (16 * (precision == NERF_AMD_BF16 ? 1024 : 2048)) * 1024; }
+static ActDump make_dump(void* dump, int precision, int64_t M, int slots) {
+    const unsigned long long ls = mlp_train_layer_stride(precision, M);
+    return ActDump{reinterpret_cast<char*>(dump), ls, reinterpret_cast<char*>(dump) + (size_t)slots * ls, (unsigned long long)mlp_train_mask_stride(precision, M)};
+}
 int mlp_launch_proposal_train(const void* packed, int precision, const nerf_amd_samples& s, float* density, void* dump, hipStream_t st) {
-    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M)};
-    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16, true>, packed, s, density, st, d);
-    return launch<PF32, PropLayout>(proposal_kernel<PF32, true>, packed, s, density, st, d);
+    const ActDump d = make_dump(dump, precision, s.M, PROP_DUMP_SLOTS);
+    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout, true>(proposal_kernel<PB16, true>, packed, s, density, st, d);
+    return launch<PF32, PropLayout, true>(proposal_kernel<PF32, true>, packed, s, density, st, d);
 }
 int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, void* dump, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
-    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M)};
-    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, true>, packed, s, rgbo, st, off, d);
-    return launch<PF32, MipLayout>(mip_kernel<PF32, true>, packed, s, rgbo, st, off, d);
+    const ActDump d = make_dump(dump, precision, s.M, MIP_DUMP_SLOTS);
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout, true>(mip_kernel<PB16, true>, packed, s, rgbo, st, off, d);
+    return launch<PF32, MipLayout, true>(mip_kernel<PF32, true>, packed, s, rgbo, st, off, d);
 }
 
 template <class P, bool TRAIN>
@@ -840,7 +918,7 @@ int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s,
 // training forward of Ref-NeRF: activation dump (REF_DUMP_SLOTS slots of mlp_train_layer_stride bytes) + aux (M,16)
 int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
                          void* dump, float* aux, hipStream_t st) {
-    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M)};
+    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M), nullptr, 0ull};
     if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, st);
     return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, st);
 }
