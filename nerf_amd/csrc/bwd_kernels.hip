@@ -4,11 +4,12 @@
 //      (mlp_layout.h *BwdLayout).  delta stays in registers from the heads down to the first hidden layer exactly like the
 //      activations do in the forward: D[input feature][sample] = W^T . delta with A = weight fragments streamed through the LDS
 //      ring and B = delta in registers; the epilogue between two layers is the ReLU adjoint delta *= [y > 0], with y taken from
-//      the training forward's activation dump.  The mask blocks (1 KiB per 16 features x 32 samples: the dump's fragment order IS
-//      the B-operand layout, so masking is element-wise on registers) are LDS-DMA'd one feature-block pair ahead into a per-wave
-//      double buffer -- no VGPRs, no compiler-visible loads inside the MFMA stream.  Every layer's delta is written to HBM in
-//      the same fragment order (the "delta dump"): that is the operand of the weight gradients.
-//      HBM traffic per sample and 256-wide layer: 512 B of mask reads + 512 B of delta writes (bf16).
+//      the training forward's dump.  The forward records ONE BIT per activation next to the dump (it ORs the sign tests of its
+//      output registers into a per-wave LDS word table and writes 32 B per sample and layer); the chain LDS-DMAs a layer's 1 KiB of
+//      bits per 256-sample subtile when the layer starts into a per-wave double buffer and expands them on registers (the dump's
+//      fragment order IS the B-operand layout, so masking is element-wise) -- no VGPR-held loads inside the MFMA stream.  Every
+//      layer's delta is written to HBM in the same fragment order (the "delta dump"): the operand of the weight gradients.
+//      HBM traffic per sample and 256-wide layer: 32 B of mask bits + 512 B of delta writes (bf16).
 //   2. wgrad (wgrad_kernel_bf16 / wgrad_kernel_f32): dW = delta^T . y contracts over SAMPLES, while both dumps hold samples along the
 //      lanes (lane = sample, registers = features).  The transposition is done by the matrix cores themselves: used as the A operand
 //      of a 32x32x16 MFMA against a constant 0/1 selection matrix, a fragment block comes out with lane = feature and registers =

@@ -140,8 +140,13 @@ struct PF32 {
 // ------------------------------------------------------------------------------------------------
 // weight stream: L2 -> LDS ring, consumed in lock step by all wavefronts of the workgroup
 // ------------------------------------------------------------------------------------------------
-// SAFE (training kernels): they also issue activation stores; loads and stores may complete out of order with respect to each
-// other, so a counted vmcnt no longer identifies the ring pieces -- wait for everything (vmcnt(0)) at every barrier instead.
+// SAFE: wait for everything (vmcnt(0)) at every barrier instead of a counted wait.  It was the first form of the training kernels,
+// which also issue activation stores; it is not needed: VMEM loads return in order among themselves, so `vmcnt(N)` still proves that
+// all but the last N issued LOADS have landed -- stores in flight only add to the counter, i.e. make the wait stricter, never weaker.
+// Kept behind -DMLP_TRAIN_SAFE_STREAM=1 for A/B runs.
+#ifndef MLP_TRAIN_SAFE_STREAM
+#define MLP_TRAIN_SAFE_STREAM 0
+#endif
 template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false>
 struct WeightStream {
     static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk

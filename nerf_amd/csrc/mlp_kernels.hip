@@ -275,7 +275,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P, MLP_NSLOT, TRAIN> ws;
+    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #endif
     if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 24)[threadIdx.x] = 0u;   // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P, MLP_NSLOT, TRAIN> ws;
+    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = threadIdx.x >> 6;
