@@ -92,9 +92,9 @@ typedef struct nerf_amd_samples {
     const float* ipe_dir_norm; /* DEVICE pointer to one float: norm of the whole (N,3) direction tensor (mip_methods.py:31;
                                   nerf_amd_dirs_norm)                                                                              */
     uint64_t     rng_seed;     /* in-kernel uniforms (z == NULL and u == NULL; modes 1, 2): the stratified draw of sample s of ray n is    */
-    int64_t      rng_ray_offset; /* word s&3 of Philox4x32-10(key = rng_seed, counter = (n + rng_ray_offset, s>>2, 'ST')), top 24 bits
-                                  * 2^-24.  The reference draws these on the CPU generator (procedures.py:65, utils.py:89); the
-                                  counter form needs no tensor, replays from the seed, and is independent of how rays are batched.
+    int64_t      rng_ray_offset; /* word 0 of Philox4x32-10(key = rng_seed, counter = (n + rng_ray_offset [64 bit], s, 'RS' = 0x5253)),
+                                  top 24 bits * 2^-24.  The reference draws these on the CPU generator (procedures.py:65, utils.py:89);
+                                  the counter form needs no tensor, replays from the seed, and is independent of how rays are batched.
                                   nerf_amd_resample / nerf_amd_render_rays regenerate the same values from the same (seed, offset). */
 } nerf_amd_samples;
 
@@ -205,8 +205,10 @@ int nerf_amd_stratified_points(const float* rays, const float* z_base, const flo
  * density -> [softplus] -> get_weights(|d| scaling, relu) -> maxBlur(alpha) -> inverse sample (sorted).
  * Depths as in nerf_amd_samples (z, or z_base + u_strat*z_jitter).  dirs row n at dirs[n*dirs_stride .. +3]
  * (pass rays+3 with stride 6).  Optional outputs (NULL to skip): w_prop (N,C), below (N,K) int64, z_coarse (N,C).
- * A NULL u_strat (with z == NULL) / a NULL u_inv (K <= 256) is drawn in the kernel from (rng_seed, ray + rng_ray_offset) exactly like
- * nerf_amd_samples describes: u_inv(n, k) = word k>>6 of Philox4x32-10(key = rng_seed, counter = (n + rng_ray_offset, k & 63, 'IN')). */
+ * A NULL u_strat (with z == NULL) / a NULL u_inv is drawn in the kernel from (rng_seed, ray + rng_ray_offset) exactly like
+ * nerf_amd_samples describes; words 1..3 of the same blocks are the inverse-CDF draws: u_inv(n, k), k = 192 b + r (r < 192), is word
+ * 1 + r/64 of Philox4x32-10(key = rng_seed, counter = (n + rng_ray_offset, 64 b + r%64, 'RS')) -- at the render shapes one block per
+ * (ray, lane) carries everything that lane needs. */
 int nerf_amd_resample(const float* density, const float* z, const float* z_base, const float* u_strat, float z_jitter,
                       const float* dirs, int dirs_stride, const float* u_inv, int64_t N, int C, int K,
                       int softplus_density, float blur_alpha, uint64_t rng_seed, int64_t rng_ray_offset,

@@ -279,7 +279,6 @@ int nerf_amd_resample(const float* density, const float* z, const float* z_base,
     if (N < 0 || C < 3 || C > 256 || K < 1 || K > 1024) return fail(NERF_AMD_EINVAL, "need 3 <= C <= 256 and 1 <= K <= 1024");
     if (N && (!density || !dirs || !z_fine)) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (N && !z && !z_base) return fail(NERF_AMD_EINVAL, "need z, or z_base (with u_strat, or without: in-kernel uniforms)");
-    if (!u_inv && K > 256) return fail(NERF_AMD_EINVAL, "in-kernel inverse-CDF uniforms cover K <= 256 (four Philox words per lane)");
     return hip_status(sk_resample(density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus_density,
                                   blur_alpha, rng_seed, rng_ray_offset, z_fine, below, w_prop, z_coarse, S(stream)), "nerf_amd_resample");
 }

@@ -48,35 +48,44 @@ DEVINL float sin_quadrant(float a, int quad) {
 
 // ------------------------------------------------------------------------------------------------
 // Counter-based uniforms (Philox4x32-10, Salmon et al. 2011 -- the generator behind torch's device RNG, restated from the paper's
-// constants).  When a caller passes no uniform tensors, the kernels draw them as a PURE FUNCTION of (seed, ray, sample):
-//   u_strat(n, s) = word s & 3 of Philox(key = seed, counter = (n_lo, n_hi, s >> 2, 'ST'))        stratified jitter (procedures.py:65)
-//   u_inv(n, k)   = word k >> 6 of Philox(key = seed, counter = (n_lo, n_hi, k & 63, 'IN'))       inverse-CDF draws (utils.py:115), k < 256
-// so the proposal pass and the resampling pass regenerate the same depths without a tensor in between, a render is replayable from
+// constants).  When a caller passes no uniform tensors, the kernels draw them as a PURE FUNCTION of (seed, ray, sample).  One Philox
+// block per (ray, slot j) of stream 'RS' -- block(n, j) = Philox(key = seed, counter = (n_lo, n_hi, j, 'RS')) -- carries
+//   word 0      : u_strat(n, s = j)                                    stratified jitter (procedures.py:65)
+//   words 1..3  : u_inv(n, k) for k = 192 (j / 64) + (j % 64) + {0, 64, 128}   inverse-CDF draws (utils.py:115)
+// so in the resampling kernel lane j's ONE Philox call yields everything the lane needs of a ray at the render shapes (S <= 64,
+// K <= 192), the proposal pass regenerates the same depths from word 0 without a tensor in between, a render is replayable from
 // its seed, and any sub-batch of rays reproduces the same bits (oracle twin: oracle/nerf_oracle.py philox_uniforms).
 // uint32 -> [0, 1): the top 24 bits times 2^-24 (torch's device convention).
+// The two 32 x 32 -> 64 products of a round are one v_mad_u64_u32 each (hipcc otherwise emits v_mul_lo_u32 + v_mul_hi_u32: two
+// quarter-rate instructions instead of one); the multipliers live in SGPRs.
 // ------------------------------------------------------------------------------------------------
 struct Philox4 { uint32_t w[4]; };
+DEVINL uint64_t mul_wide_u32(uint32_t m, uint32_t x) {
+    uint64_t p, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(carry) : "s"(m), "v"(x));
+    return p;
+}
 DEVINL Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        const uint64_t p0 = mul_wide_u32(0xD2511F53u, c0), p1 = mul_wide_u32(0xCD9E8D57u, c2);
+        c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0; c1 = (uint32_t)p1;
+        c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return Philox4{{c0, c1, c2, c3}};
 }
 DEVINL float u01_from_bits(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
-constexpr uint32_t PHILOX_STREAM_STRAT = 0x5354u, PHILOX_STREAM_INV = 0x494Eu;
-DEVINL float philox_u_strat(uint64_t seed, int64_t n, int s) {
-    const Philox4 r = philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)(s >> 2), PHILOX_STREAM_STRAT, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const int i = s & 3;
-    return u01_from_bits(i == 0 ? r.w[0] : (i == 1 ? r.w[1] : (i == 2 ? r.w[2] : r.w[3])));
+constexpr uint32_t PHILOX_STREAM_RENDER = 0x5253u;
+DEVINL Philox4 philox_ray_block(uint64_t seed, int64_t n, int j) {
+    return philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)j, PHILOX_STREAM_RENDER, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
-// all (up to four) inverse-CDF uniforms of lane `lane` of ray n: k = lane, lane + 64, lane + 128, lane + 192
-DEVINL Philox4 philox_u_inv_lane(uint64_t seed, int64_t n, int lane) {
-    return philox4x32_10((uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)lane, PHILOX_STREAM_INV, (uint32_t)seed, (uint32_t)(seed >> 32));
+DEVINL float philox_u_strat(uint64_t seed, int64_t n, int s) { return u01_from_bits(philox_ray_block(seed, n, s).w[0]); }
+// inverse-CDF uniform k of ray n (generic shapes; the render shapes take the words of philox_ray_block directly)
+DEVINL float philox_u_inv(uint64_t seed, int64_t n, int k) {
+    const int b = k / 192, r = k - 192 * b, q = r >> 6;
+    const Philox4 p = philox_ray_block(seed, n, 64 * b + (r & 63));
+    return u01_from_bits(q == 0 ? p.w[1] : (q == 1 ? p.w[2] : p.w[3]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -107,26 +116,49 @@ DEVINL void cone_mean_cov(const ConeMoments& c, float o, float d, float dir_norm
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64-lane inclusive scans (log-step shuffles).  fp64 versions mirror torch's CPU cumsum/cumprod,
-// which accumulate float inputs in double and round each prefix to float.
+// 64-lane inclusive scans.  fp64 versions mirror torch's CPU cumsum/cumprod, which accumulate float inputs in double and round
+// each prefix to float.
+// Data movement is DPP (v_mov_b32 with a lane-select modifier, register-file latency), not ds_bpermute (LDS latency): four
+// Hillis-Steele steps inside each row of 16 lanes (row_shr), then row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3
+// (row_bcast:31).  Lanes without a source receive the operation's identity.  The scans sit on the per-ray critical path of the
+// wave-per-ray kernels (three per ray in resample_kernel), which are latency-bound, not bandwidth-bound.
 // ------------------------------------------------------------------------------------------------
-DEVINL double wave_incl_scan_mul(double v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double o = __shfl_up(v, d, 64);
-        if (lane >= d) v *= o;
-    }
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+template <int CTRL, int ROW_MASK>
+DEVINL int dpp_move(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK>
+DEVINL double dpp_move(double identity, double v) {
+    const int2 o = __builtin_bit_cast(int2, identity), x = __builtin_bit_cast(int2, v);
+    int2 r;
+    r.x = __builtin_amdgcn_update_dpp(o.x, x.x, CTRL, ROW_MASK, 0xF, false);
+    r.y = __builtin_amdgcn_update_dpp(o.y, x.y, CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, r);
+}
+template <class T, class OP>
+DEVINL T wave_incl_scan(T v, T identity, OP&& op) {
+    v = op(v, dpp_move<DPP_ROW_SHR + 1, 0xF>(identity, v));
+    v = op(v, dpp_move<DPP_ROW_SHR + 2, 0xF>(identity, v));
+    v = op(v, dpp_move<DPP_ROW_SHR + 4, 0xF>(identity, v));
+    v = op(v, dpp_move<DPP_ROW_SHR + 8, 0xF>(identity, v));
+    v = op(v, dpp_move<DPP_ROW_BCAST15, 0xA>(identity, v));
+    v = op(v, dpp_move<DPP_ROW_BCAST31, 0xC>(identity, v));
     return v;
 }
-DEVINL double wave_incl_scan_add(double v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
+DEVINL double wave_incl_scan_mul(double v) { return wave_incl_scan(v, 1.0, [](double a, double b) { return a * b; }); }
+DEVINL double wave_incl_scan_add(double v) { return wave_incl_scan(v, 0.0, [](double a, double b) { return a + b; }); }
+DEVINL int wave_incl_scan_add(int v) { return wave_incl_scan(v, 0, [](int a, int b) { return a + b; }); }
+DEVINL int wave_max_i(int v) {                  // maximum over the wave, as a wave-uniform scalar
+    v = wave_incl_scan(v, (int)0x80000000, [](int a, int b) { return a > b ? a : b; });
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// value of the lane below (lane 0 receives `first`): the exclusive form of a scan
+DEVINL double wave_shift_up1(double v, double first) { return dpp_move<DPP_WAVE_SHR1, 0xF>(first, v); }
+DEVINL double wave_last(double v) {             // lane 63's value, as a wave-uniform scalar
+    const int2 x = __builtin_bit_cast(int2, v);
+    int2 r;
+    r.x = __builtin_amdgcn_readlane(x.x, 63);
+    r.y = __builtin_amdgcn_readlane(x.y, 63);
+    return __builtin_bit_cast(double, r);
 }
 DEVINL float wave_sum(float v) {
 #pragma unroll
@@ -171,10 +203,9 @@ DEVINL void wave_sigma_to_weights(int S, int act, SigF&& sig, ZF&& zn, EmitF&& e
             p = (double)(m + 1e-10f);
         }
         const double incl = wave_incl_scan_mul(p);
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0;
+        const double excl = wave_shift_up1(incl, 1.0);
         const float T = (float)(carry * excl);
-        carry *= __shfl(incl, 63, 64);
+        carry *= wave_last(incl);
         if (ok) emit(s, w * T, z0);
     }
 }

@@ -567,10 +567,9 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                         p = (double)(mm + 1e-10f);
                     }
                     const double incl = wave_incl_scan_mul(p);
-                    double excl = __shfl_up(incl, 1, 64);
-                    if (lane == 0) excl = 1.0;
+                    const double excl = wave_shift_up1(incl, 1.0);
                     w *= (float)(carry * excl);
-                    carry *= __shfl(incl, 63, 64);
+                    carry *= wave_last(incl);
                     if (q < S) {
                         ar += w * c4[0]; ag += w * c4[1]; abl += w * c4[2]; aw += w; ad += w * zd[0];
                         if (wout) wout[q] = w;

@@ -302,29 +302,47 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
         if (j < nw) p = (double)((pw[j] + 1e-5f) / total);
         const double incl = wave_incl_scan_add(p);
         if (j < nw) cdf[1 + j] = (float)(carry + incl);
-        carry += __shfl(incl, 63, 64);
+        carry += wave_last(incl);
     }
     lds_wave_sync();
-    for (int k = lane, i = 0; k < K; k += 64, ++i) {
-        const float uu = uf(i, k);
-        int lo = 0, hi = nb;                         // searchsorted(right=True): count of entries <= uu
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+    // searchsorted(right=True): count of cdf entries <= u.  Three samples per lane (K <= 192: all of the ray's) are searched in
+    // lock step with a fixed trip count, so that their dependent LDS reads overlap instead of running back to back.
+    const int halvings = 32 - __builtin_clz((unsigned)nb);       // an interval of nb + 1 candidates is empty after that many steps
+    for (int k0 = 0, i0 = 0; k0 < K; k0 += 192, i0 += 3) {
+        float uu[3]; int lo[3], hi[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = k0 + 64 * q + lane;
+            uu[q] = (k < K) ? uf(i0 + q, k) : 0.0f;
+            lo[q] = 0; hi[q] = (k < K) ? nb : 0;
         }
-        const int below = lo - 1 > 0 ? lo - 1 : 0;
-        const int above = lo < nb - 1 ? lo : nb - 1;
-        const float c0 = cdf[below], c1 = cdf[above];
-        float denom = c1 - c0;
-        if (denom < 1e-5f) denom = 1.0f;
-        const float t = (uu - c0) / denom;
-        const float b0 = bins[below], b1 = bins[above];
-        const float v = b0 + t * (b1 - b0);
-        if (sort) { samp[k] = v; bel[k] = below; }
-        else {
-            z_out[k] = v;
-            if (below_out) below_out[k] = below;
-            if (above_out) above_out[k] = above;
+        for (int it = 0; it < halvings; ++it) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int mid = (lo[q] + hi[q]) >> 1;
+                const bool open_ = lo[q] < hi[q];
+                const float c = cdf[open_ ? mid : 0];
+                if (open_) { if (c <= uu[q]) lo[q] = mid + 1; else hi[q] = mid; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = k0 + 64 * q + lane;
+            if (k >= K) continue;
+            const int below = lo[q] - 1 > 0 ? lo[q] - 1 : 0;
+            const int above = lo[q] < nb - 1 ? lo[q] : nb - 1;
+            const float c0 = cdf[below], c1 = cdf[above];
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uu[q] - c0) / denom;
+            const float b0 = bins[below], b1 = bins[above];
+            const float v = b0 + t * (b1 - b0);
+            if (sort) { samp[k] = v; bel[k] = below; }
+            else {
+                z_out[k] = v;
+                if (below_out) below_out[k] = below;
+                if (above_out) above_out[k] = above;
+            }
         }
     }
     if (!sort) return;
@@ -366,27 +384,44 @@ DEVINL void wave_inverse_sample(const float* pw, const float* bins, int nw, floa
         int c[SORT_PER_LANE], tot = 0;
 #pragma unroll
         for (int i = 0; i < SORT_PER_LANE; ++i) { c[i] = cnt[lane * SORT_PER_LANE + i]; tot += c[i]; }
-        int incl = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-        int run = incl - tot;
+        int run = wave_incl_scan_add(tot) - tot;
 #pragma unroll
         for (int i = 0; i < SORT_PER_LANE; ++i) { pre[lane * SORT_PER_LANE + i] = run; run += c[i]; }
     }
     lds_wave_sync();
-    for (int k = lane, i = 0; k < K; k += 64, ++i) {
-        int b = (int)(uf(i, k) * (float)SORT_NB);
-        b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
-        const float v = samp[k];
-        int rank = pre[b];
-        const int nb_ = cnt[b];
-        for (int p = 0; p < nb_; ++p) {
-            const int jx = mem[b * SORT_CAP + p];
-            const float o = samp[jx];
-            rank += (o < v || (o == v && jx < k)) ? 1 : 0;
+    for (int k0 = 0, i0 = 0; k0 < K; k0 += 192, i0 += 3) {          // three elements per lane in lock step (dependent LDS reads overlap)
+        float v[3]; int rank[3], cntb[3], bb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = k0 + 64 * q + lane;
+            const bool ok = k < K;
+            int b = ok ? (int)(uf(i0 + q, k) * (float)SORT_NB) : 0;
+            b = b < 0 ? 0 : (b > SORT_NB - 1 ? SORT_NB - 1 : b);
+            bb[q] = b;
+            v[q] = samp[ok ? k : 0];
+            rank[q] = pre[b];
+            cntb[q] = ok ? cnt[b] : 0;
         }
-        z_out[rank] = v;
-        if (below_out) below_out[rank] = bel[k];
+        int most = cntb[0] > cntb[1] ? cntb[0] : cntb[1];
+        most = most > cntb[2] ? most : cntb[2];
+        const int trips = wave_max_i(most);                       // wave-uniform: the fullest bucket any lane looks at (typically 3..4 of SORT_CAP)
+        for (int p = 0; p < trips; ++p) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int k = k0 + 64 * q + lane;
+                const bool live = p < cntb[q];
+                const int jx = mem[bb[q] * SORT_CAP + p];
+                const float o = samp[live ? jx : 0];
+                rank[q] += (live && (o < v[q] || (o == v[q] && jx < k))) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = k0 + 64 * q + lane;
+            if (k >= K) continue;
+            z_out[rank[q]] = v[q];
+            if (below_out) below_out[rank[q]] = bel[k];
+        }
     }
 }
 
@@ -432,7 +467,10 @@ struct ResampleArgs {
     uint64_t rng_seed; int64_t rng_ray_offset;      // Philox source of u_strat / u_inv when the pointers are NULL (device_common.h)
 };
 
-__global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
+#ifndef RS_BLOCKS_PER_CU
+#define RS_BLOCKS_PER_CU 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RS_BLOCKS_PER_CU, RS_BLOCKS_PER_CU))) void resample_kernel(ResampleArgs a) {
     const int C = a.C, K = a.K;
     // per wave: pw[C] bins[C] cdf[C] samp[K] bel[K] | zl[C] wraw[C]
     float* base = reinterpret_cast<float*>(smem) + wave_in_block() * (inv_lds_floats(C, K) + 2 * C);
@@ -444,29 +482,31 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     const int lane = lane_id();
     // All global inputs of a ray (direction, depths or their uniforms, densities, the K inverse-CDF uniforms) are loaded ONE RAY
     // AHEAD into registers: the ray's own phases then never wait for HBM (three exposed round trips per ray before).
-    struct RayIn { float dx, dy, dz, zv[2], dens[2], u[3]; };
+    struct RayIn { float dx, dy, dz, zv0, zv1, dens0, dens1, u0, u1, u2; };      // scalars only: indexed members end up in scratch
     const bool fits = C <= 128 && K <= 192;
     auto load_in = [&](int64_t n) -> RayIn {
         RayIn r;
         const float* dd = a.dirs + n * a.dirs_stride;
         r.dx = dd[0]; r.dy = dd[1]; r.dz = dd[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = lane + 64 * i;
-            r.zv[i] = 0.0f; r.dens[i] = 0.0f;
-            if (j < C) {
-                if (a.z) r.zv[i] = a.z[n * C + j];
-                else r.zv[i] = a.z_base[j] + (a.u_strat ? a.u_strat[n * C + j] : philox_u_strat(a.rng_seed, n + a.rng_ray_offset, j)) * a.z_jitter;
-                r.dens[i] = a.density[n * C + j];
-            }
-        }
+        // Philox mode: lane j's one block of the ray carries u_strat(n, j) and u_inv(n, j + {0, 64, 128})   (device_common.h)
+        Philox4 blk = {{0u, 0u, 0u, 0u}};
+        const bool draw = !a.u_inv || (!a.z && !a.u_strat);
+        if (draw) blk = philox_ray_block(a.rng_seed, n + a.rng_ray_offset, lane);
+        auto depth_of = [&](int j, bool first) {
+            if (a.z) return a.z[n * C + j];
+            const float uu = a.u_strat ? a.u_strat[n * C + j] : (first ? u01_from_bits(blk.w[0]) : philox_u_strat(a.rng_seed, n + a.rng_ray_offset, j));
+            return a.z_base[j] + uu * a.z_jitter;
+        };
+        r.zv0 = r.zv1 = r.dens0 = r.dens1 = 0.0f;
+        if (lane < C) { r.zv0 = depth_of(lane, true); r.dens0 = a.density[n * C + lane]; }
+        if (lane + 64 < C) { r.zv1 = depth_of(lane + 64, false); r.dens1 = a.density[n * C + lane + 64]; }
         if (a.u_inv) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const int k = lane + 64 * i; r.u[i] = (k < K) ? a.u_inv[n * K + k] : 0.0f; }
-        } else {                                                       // one Philox call per lane = its (up to four) draws k = lane + 64 i
-            const Philox4 p = philox_u_inv_lane(a.rng_seed, n + a.rng_ray_offset, lane);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) r.u[i] = u01_from_bits(p.w[i]);
+            const float* un = a.u_inv + n * K;
+            r.u0 = (lane < K) ? un[lane] : 0.0f;
+            r.u1 = (lane + 64 < K) ? un[lane + 64] : 0.0f;
+            r.u2 = (lane + 128 < K) ? un[lane + 128] : 0.0f;
+        } else {
+            r.u0 = u01_from_bits(blk.w[1]); r.u1 = u01_from_bits(blk.w[2]); r.u2 = u01_from_bits(blk.w[3]);
         }
         return r;
     };
@@ -482,11 +522,8 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         float nrm;
         if (fits) {
             nrm = norm3(cur.dx, cur.dy, cur.dz);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int j = lane + 64 * i;
-                if (j < C) { zl[j] = cur.zv[i]; if (a.z_coarse) a.z_coarse[n * C + j] = cur.zv[i]; }
-            }
+            if (lane < C) { zl[lane] = cur.zv0; if (a.z_coarse) a.z_coarse[n * C + lane] = cur.zv0; }
+            if (lane + 64 < C) { zl[lane + 64] = cur.zv1; if (a.z_coarse) a.z_coarse[n * C + lane + 64] = cur.zv1; }
         } else {
             const float* dd = a.dirs + n * a.dirs_stride;
             nrm = norm3(dd[0], dd[1], dd[2]);
@@ -500,10 +537,11 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         lds_wave_sync();
         const float* sg = a.density + n * C;
         const int soft = a.softplus;
+        const float dens0 = cur.dens0, dens1 = cur.dens1, cu0 = cur.u0, cu1 = cur.u1, cu2 = cur.u2;   // by-value captures: a reference to `cur` pins it in scratch
         wave_sigma_to_weights(C, NERF_AMD_ACT_RELU,
-                              [&](int s) { const float d = fits ? ((s >> 6) ? cur.dens[1] : cur.dens[0]) : sg[s]; return soft ? softplus_f(d) : d; },
-                              [&](int s) { return zl[s] * nrm; },
-                              [&](int s, float wv, float) { wraw[s] = wv; });
+                              [=](int s) { const float d = fits ? ((s >> 6) ? dens1 : dens0) : sg[s]; return soft ? softplus_f(d) : d; },
+                              [=](int s) { return zl[s] * nrm; },
+                              [=](int s, float wv, float) { wraw[s] = wv; });
         lds_wave_sync();
         for (int j = lane; j < C; j += 64) {                                   // max-blur (mip_methods.py:61-66)
             const float c = wraw[j];
@@ -518,12 +556,10 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
         const float* un = a.u_inv ? a.u_inv + n * K : nullptr;
         const uint64_t seed = a.rng_seed; const int64_t nn = n + a.rng_ray_offset;
         wave_inverse_sample(pw, bins, C - 2, cdf, samp, bel, sortbuf,
-                            [&](int i, int k) {
-                                if (fits) return i == 0 ? cur.u[0] : (i == 1 ? cur.u[1] : cur.u[2]);
+                            [=](int i, int k) {
+                                if (fits) return i == 0 ? cu0 : (i == 1 ? cu1 : cu2);
                                 if (un) return un[k];
-                                const Philox4 p = philox_u_inv_lane(seed, nn, k & 63);             // generic shapes (K <= 256)
-                                const int q = k >> 6;
-                                return u01_from_bits(q == 0 ? p.w[0] : (q == 1 ? p.w[1] : (q == 2 ? p.w[2] : p.w[3])));
+                                return philox_u_inv(seed, nn, k);                                  // generic shapes
                             },
                             K, 1, a.z_fine + n * K, a.below ? a.below + n * K : nullptr, nullptr);
         cur = nxt;
@@ -584,10 +620,9 @@ DEVINL void composite_ray_fast(const CompositeArgs& a, int64_t n, const RayRecs<
             w = 1.0f - m; p = (double)(m + 1e-10f);
         }
         const double incl = wave_incl_scan_mul(p);
-        double excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0;
+        const double excl = wave_shift_up1(incl, 1.0);
         w *= (float)(carry * excl);
-        carry *= __shfl(incl, 63, 64);
+        carry *= wave_last(incl);
         if (s < S) {
             accr += w * r.c[k][0]; accg += w * r.c[k][1]; accb += w * r.c[k][2]; accw += w; accd += w * zn[k];
             if (wout) wout[s] = w;
@@ -669,7 +704,7 @@ __global__ __launch_bounds__(256) void get_bounds_kernel(const float* __restrict
             const double p = (j < C) ? (double)w[n * C + j] : 0.0;
             const double incl = wave_incl_scan_add(p);
             if (j < C) sat[1 + j] = (float)(carry + incl);
-            carry += __shfl(incl, 63, 64);
+            carry += wave_last(incl);
         }
         lds_wave_sync();
         const int64_t* bl = below + n * K;
@@ -730,10 +765,9 @@ __global__ __launch_bounds__(256) void weights_backward_kernel(WeightsBwdArgs a)
                     p = (double)(m[c] + 1e-10f);
                 }
                 const double incl = wave_incl_scan_mul(p);
-                double excl = __shfl_up(incl, 1, 64);
-                if (lane == 0) excl = 1.0;
+                const double excl = wave_shift_up1(incl, 1.0);
                 T[c] = (float)(carry * excl);
-                carry *= __shfl(incl, 63, 64);
+                carry *= wave_last(incl);
                 float g = 0.0f;
                 if (ok) {
                     if (a.d_weights) g += a.d_weights[n * S + s];
@@ -747,7 +781,7 @@ __global__ __launch_bounds__(256) void weights_backward_kernel(WeightsBwdArgs a)
                 const float w = (1.0f - m[c]) * T[c];
                 const double gi = wave_incl_scan_add(ok ? (double)(g * w) : 0.0);
                 P[c] = gw_carry + gi;
-                gw_carry += __shfl(gi, 63, 64);
+                gw_carry += wave_last(gi);
                 if (ok && a.d_rgbo) {                                               // dL/dc_i = w_i * d_rgb
                     float* o = a.d_rgbo + (n * S + s) * 4;
                     o[0] = w * dr; o[1] = w * dg; o[2] = w * db;
@@ -1182,7 +1216,12 @@ int sk_resample(const float* density, const float* z, const float* z_base, const
     ResampleArgs a{density, z, z_base, u_strat, z_jitter, dirs, dirs_stride, u_inv, N, C, K, softplus, alpha, z_fine, below, w_prop, z_coarse,
                    rng_seed, rng_ray_offset};
     const size_t lds = WAVES_PER_BLOCK * ((size_t)5 * C + 2 * K + SORT_LDS_FLOATS) * 4;
-    hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a);
+    // persistent over rays: exactly one resident round (RS_BLOCKS_PER_CU workgroups fit a CU by registers and LDS at the render shapes),
+    // so that no partially filled last round trails behind
+    int64_t blocks = (N + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const int64_t resident = (int64_t)nerf_host::cu_count() * RS_BLOCKS_PER_CU;
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a);
     return (int)hipGetLastError();
 }
 int sk_composite(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int S, int flags,

@@ -268,19 +268,20 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def philox_uniforms(seed: int, n_rays: int, ray_offset: int = 0, S: int = 64, K: int = 129):
-    """The uniforms the HIP kernels draw when none are passed (include/nerf_amd.h, nerf_amd_samples.rng_seed):
-    u_strat (N, S): word s & 3 of Philox(key = seed, counter = (ray, s >> 2, 'ST'));  u_inv (N, K <= 256): word k >> 6 of
-    Philox(key = seed, counter = (ray, k & 63, 'IN')); ray = n + ray_offset as a 64-bit counter; value = (word >> 8) * 2^-24."""
+    """The uniforms the HIP kernels draw when none are passed (include/nerf_amd.h, nerf_amd_samples.rng_seed).  One Philox block per
+    (ray, slot j): block(ray, j) = Philox(key = seed, counter = (ray_lo, ray_hi, j, 'RS' = 0x5253)), ray = n + ray_offset (64 bit);
+    u_strat (N, S) = word 0 of block j = s;  u_inv (N, K): k = 192 b + r, r < 192 -> word 1 + r // 64 of block j = 64 b + r % 64;
+    value = (word >> 8) * 2^-24."""
     import numpy as np
     n = np.arange(n_rays, dtype=np.uint64) + np.uint64(ray_offset)
     nlo, nhi = (n & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None], (n >> np.uint64(32)).astype(np.uint32)[:, None]
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     s = np.arange(S, dtype=np.uint32)[None, :]
-    w = philox4x32_10(nlo, nhi, s >> np.uint32(2), np.uint32(0x5354), k0, k1)
-    us = np.choose((s & np.uint32(3)).astype(np.int64) + np.zeros((n_rays, 1), np.int64), w)
-    k = np.arange(K, dtype=np.uint32)[None, :]
-    w = philox4x32_10(nlo, nhi, k & np.uint32(63), np.uint32(0x494E), k0, k1)
-    ui = np.choose((k >> np.uint32(6)).astype(np.int64) + np.zeros((n_rays, 1), np.int64), w)
+    us = philox4x32_10(nlo, nhi, s, np.uint32(0x5253), k0, k1)[0] + np.zeros((n_rays, 1), np.uint32)
+    k = np.arange(K, dtype=np.int64)[None, :]
+    blk, r = k // 192, k % 192
+    w = philox4x32_10(nlo, nhi, (64 * blk + r % 64).astype(np.uint32), np.uint32(0x5253), k0, k1)
+    ui = np.choose(1 + r // 64 + np.zeros((n_rays, 1), np.int64), w)
     to_f = lambda x: torch.from_numpy(((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)))
     return to_f(us), to_f(ui)
 

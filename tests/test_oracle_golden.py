@@ -162,14 +162,13 @@ def test_philox_known_answers_and_counter_layout():
     assert [int(x[0]) for x in O.philox4x32_10(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     seed, off = 0x0123456789ABCDEF, 5_000_000_000                          # a ray counter beyond 32 bits
     us, ui = O.philox_uniforms(seed, 3, off, 64, 200)
-    for n, s in ((0, 0), (1, 7), (2, 63)):
-        w = O.philox4x32_10(np.uint32([(off + n) & 0xFFFFFFFF]), np.uint32([(off + n) >> 32]), np.uint32([s >> 2]), np.uint32([0x5354]),
-                            seed & 0xFFFFFFFF, seed >> 32)
-        assert float(us[n, s]) == float((int(w[s & 3][0]) >> 8) * 2.0 ** -24)
-    for n, k in ((0, 0), (1, 64), (2, 199)):
-        w = O.philox4x32_10(np.uint32([(off + n) & 0xFFFFFFFF]), np.uint32([(off + n) >> 32]), np.uint32([k & 63]), np.uint32([0x494E]),
-                            seed & 0xFFFFFFFF, seed >> 32)
-        assert float(ui[n, k]) == float((int(w[k >> 6][0]) >> 8) * 2.0 ** -24)
+    def block(n, j):
+        return O.philox4x32_10(np.uint32([(off + n) & 0xFFFFFFFF]), np.uint32([(off + n) >> 32]), np.uint32([j]), np.uint32([0x5253]),
+                               seed & 0xFFFFFFFF, seed >> 32)
+    for n, s in ((0, 0), (1, 7), (2, 63)):                                 # u_strat(n, s) = word 0 of block s
+        assert float(us[n, s]) == float((int(block(n, s)[0][0]) >> 8) * 2.0 ** -24)
+    for n, k, j, w in ((0, 0, 0, 1), (1, 64, 0, 2), (2, 191, 63, 3), (2, 192, 64, 1), (2, 199, 71, 1)):   # u_inv: words 1..3
+        assert float(ui[n, k]) == float((int(block(n, j)[w][0]) >> 8) * 2.0 ** -24)
     assert float(us.min()) >= 0.0 and float(us.max()) < 1.0
 
 
