@@ -52,7 +52,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
             if pts.requires_grad or pts.numel() == 0:                      # (gradients w.r.t. positions: torch VJP of the expression)
                 hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p)
                 return ab.HipOp.apply(hip, expr, 0, pts, *params)
-            # parameter gradients: the training forward dumps the hidden activations, the backward is a GEMM chain on them
+            # parameter gradients: the training forward dumps the hidden activations, the backward is hand-written kernels on them (mlp_backward.py)
             from . import mlp_backward
             held = {}
 

@@ -774,6 +774,17 @@ def test_integration_md_ctypes_stub_runs(A):
     with torch.no_grad():
         A.pkg.set_precision("fp32")
         assert torch.equal(ns["mip_forward"](blob, A.ops.F32, pts), mip.forward(pts))
+        # second block of the document: training forward + hand-written backward through the C-ABI == the package's own path
+        from nerf_amd import mlp_backward
+        exec([b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def mip_train_forward" in b][0], ns)
+        out, dump = ns["mip_train_forward"](blob, A.ops.F32, pts)
+        assert torch.equal(out, mip.forward(pts))
+        layers = mip._linear_layers()
+        ws, bs = [l.weight.detach().contiguous() for l in layers], [l.bias.detach().contiguous() for l in layers]
+        g = torch.randn(5, 40, 4, generator=gen).cuda()
+        gw, gb = ns["mip_backward"](mip, A.ops.F32, g, out, dump, ws, bs)
+        gw2, gb2 = mlp_backward.mip_backward(g, out, pts, dump, A.ops.F32, ws, bs)
+        assert all(torch.equal(a, b) for a, b in zip(gw + gb, gw2 + gb2))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
