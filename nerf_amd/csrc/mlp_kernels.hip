@@ -286,6 +286,13 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     const uint32_t macc = lds_maskacc<P>() + wave * 2 * NT * 1024;      // TRAIN: this wave's ReLU bit-mask records
     if constexpr (TRAIN) mask_acc_init<P>(macc, lane);
 
+#ifdef MLP_PHASEPROBE
+    // diagnostic build: shader cycles of wave 0 of workgroup 0 per tile phase (fetch + encode | layer 0 | layers 1-3 | head + store)
+    uint64_t ph[4] = {0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#define PHASE_MARK(i) { const uint64_t now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_t; ph_t = now_; }
+#else
+#define PHASE_MARK(i)
+#endif
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg enc[NT][4];
@@ -318,8 +325,10 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
         // into `a` during the first K steps of whatever runs next
+        PHASE_MARK(0)
         Deferred<P, 6, 2> d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
             [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
+        PHASE_MARK(1)
         // layers.2/4/6 ping-pong between the two register buffers (a -> b -> a -> b): no copies; the two a->b layers
         // share one code instance through the loop (same chunk parity, asserted)
         static_assert(L::START[1] % (2 * FPC) == L::START[3] % (2 * FPC), "chunk parity");
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             }
         }
         lay_pend = lay;
+        PHASE_MARK(2)
         float dens[NT];
         auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
         dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB_pend)).flush(OH);
@@ -343,8 +353,14 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
+        PHASE_MARK(3)
     }
     ws.drain();
+#ifdef MLP_PHASEPROBE
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) reinterpret_cast<uint64_t*>(density)[i] = ph[i];
+#endif
+#undef PHASE_MARK
 }
 
 // ================================================================================================
