@@ -130,14 +130,16 @@ int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_sampl
 int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf_amd_samples* src, int white_bkg,
                                    float near, float far, float* rgb, float* depth, float* weights, void* stream);
 
-/* RefNeRF.forward in eval mode, use_srgb=False (ref_model.py:68-106): rgbo (M,4) = [rgb | raw density],
- * normal (M,3) (NULL to skip).  Samples need a direction (pts_stride >= 6 in mode 0). */
-int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src,
+/* RefNeRF.forward in eval mode (ref_model.py:68-106): rgbo (M,4) = [rgb | raw density], normal (M,3) (NULL to skip).  Samples need a
+ * direction (pts_stride >= 6 in mode 0).  ref_flags: NERF_AMD_REF_SRGB = the module's use_srgb (ref_model.py:100-102:
+ * rgb = linear_to_srgb(specular + sigmoid(diffuse - log 3))), 0 = ref_model.py:104-105.  The same flag goes to every Ref-NeRF entry point. */
+#define NERF_AMD_REF_SRGB 1
+int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags,
                          float* rgbo, float* normal, void* stream);
 /* Training-mode forward (ref_model.py:84-85): the same kernel with the bottle-neck perturbation `bn_noise` (M,128), which the
  * caller draws (torch.normal(0, perturb_bottle_neck_w)) so that the backward can re-evaluate with the same noise. */
-int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo,
-                               float* normal, void* stream);
+int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, const float* bn_noise,
+                               float* rgbo, float* normal, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling / compositing kernels (one 64-lane wavefront per ray; HBM-bound).
@@ -308,15 +310,15 @@ int    nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump,
  *     d_weights / d_biases: 20 tensors each -- 0..7 spa_block1.{0,2,4,6}, spa_block2.{0,2,4,6}; 8 bottle_neck; 9 norm_col_tint_head;
  *     10 rho_tau_head; 11..18 dir_block1.{0,2,4,6}, dir_block2.{0,2,4,6}; 19 spec_rgb_head.0 -- (out, in) row-major, fully overwritten.
  *   packed_bwd: nerf_amd_pack_weights_backward(NERF_AMD_NET_REF, ...) with the 20 tensors of nerf_amd_pack_weights. */
-int    nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo,
-                                       float* normal, void* dump, float* aux, void* stream);
+int    nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, const float* bn_noise,
+                                       float* rgbo, float* normal, void* dump, float* aux, void* stream);
 size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M);
 int    nerf_amd_density_grad(int net, const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* x, int x_stride,
                              const float* scale, int scale_stride, float* grad, void* workspace, void* stream);
 size_t nerf_amd_ref_backward_workspace_bytes(int precision, int64_t M);
-int    nerf_amd_ref_backward(const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* aux, const float* dirs,
-                             int dir_stride, const float* g_out, int g_stride, const float* ide_table, float* const* d_weights,
-                             float* const* d_biases, void* workspace, void* stream);
+int    nerf_amd_ref_backward(const void* packed_bwd, int precision, int ref_flags, int64_t M, const void* act_dump, const float* aux,
+                             const float* dirs, int dir_stride, const float* g_out, int g_stride, const float* ide_table,
+                             float* const* d_weights, float* const* d_biases, void* workspace, void* stream);
 int    nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                           const int64_t* numel, int n_tensors, float* step, double lr, double beta1, double beta2, double eps,
                           float grad_scale, void* stream);
@@ -363,7 +365,7 @@ int    nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int
  * compositing with sigma -> softplus(sigma + 0.5).  normal_img (N) and cam_dir (3 floats on the device: render_pose[:, -2]) are
  * both given or both NULL (procedures.py:79-81).  Six launches.  Workspace: nerf_amd_render_ref_workspace_bytes(N, n_fine). */
 size_t nerf_amd_render_ref_workspace_bytes(int64_t N, int n_fine);
-int    nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, int precision, const float* rays,
+int    nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, int precision, int ref_flags, const float* rays,
                                 const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
                                 const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, const float* cam_dir,
                                 float* rgb, float* depth, float* normal_img, void* workspace, void* stream);

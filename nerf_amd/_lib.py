@@ -39,8 +39,8 @@ SIGNATURES = {
     "nerf_amd_mip_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void]),
     "nerf_amd_mip_forward_composite": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, C.c_float, C.c_float, c_void, c_void, c_void,
                                                  c_void]),
-    "nerf_amd_ref_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void]),
-    "nerf_amd_ref_forward_train": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void, c_void]),
+    "nerf_amd_ref_forward": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, c_void, c_void, c_void]),
+    "nerf_amd_ref_forward_train": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, c_void, c_void, c_void, c_void]),
     "nerf_amd_positional_encoding": (C.c_int, [c_void, i64, C.c_int, c_void, c_void]),
     "nerf_amd_ipe_feature": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_cone_parameters": (C.c_int, [c_void, i64, C.c_int, C.c_float, c_void, c_void, c_void, c_void]),
@@ -62,7 +62,7 @@ SIGNATURES = {
     "nerf_amd_train_dump_rows_mask_partials": (i64, []),
     "nerf_amd_train_dump_rows_mask": (C.c_int, [c_void, C.c_int, C.c_int, i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
     "nerf_amd_render_ref_workspace_bytes": (C.c_size_t, [i64, C.c_int]),
-    "nerf_amd_render_rays_ref": (C.c_int, [c_void, c_void, C.c_int, c_void, C.POINTER(Samples), i64, c_void, c_void, c_void, i64, C.c_int,
+    "nerf_amd_render_rays_ref": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, C.POINTER(Samples), i64, c_void, c_void, c_void, i64, C.c_int,
                                           C.c_float, C.c_float, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_encode_rows": (C.c_int, [c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_merge_depths": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
@@ -82,11 +82,11 @@ SIGNATURES = {
     "nerf_amd_proposal_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_mip_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void),
                                            C.POINTER(c_void), c_void, c_void]),
-    "nerf_amd_ref_forward_train_dump": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), c_void, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_ref_forward_train_dump": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_density_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, i64]),
     "nerf_amd_density_grad": (C.c_int, [C.c_int, c_void, C.c_int, i64, c_void, c_void, C.c_int, c_void, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_ref_backward_workspace_bytes": (C.c_size_t, [C.c_int, i64]),
-    "nerf_amd_ref_backward": (C.c_int, [c_void, C.c_int, i64, c_void, c_void, c_void, C.c_int, c_void, C.c_int, c_void, C.POINTER(c_void),
+    "nerf_amd_ref_backward": (C.c_int, [c_void, C.c_int, C.c_int, i64, c_void, c_void, c_void, C.c_int, c_void, C.c_int, c_void, C.POINTER(c_void),
                                        C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_adam_step": (C.c_int, [C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(i64), C.c_int, c_void,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, c_void]),

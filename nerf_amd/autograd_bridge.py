@@ -11,6 +11,8 @@ Gradient parity with the reference is pinned by golden G14 (tests/test_gpu_parit
 """
 from typing import Callable, Sequence
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -185,8 +187,8 @@ def mip_expr(pts, w, b):
     return torch.cat((rgb, sigma), dim=-1)
 
 
-def ref_expr(pos, d, noise, P, ide_fn):
-    """RefNeRF.forward as torch ops (ref_model.py:68-106, use_srgb off); P = {state_dict key: tensor}; `noise` = the train-mode
+def ref_expr(pos, d, noise, P, ide_fn, use_srgb: bool = False):
+    """RefNeRF.forward as torch ops (ref_model.py:68-106); P = {state_dict key: tensor}; `noise` = the train-mode
     perturbation of the bottle-neck vector or None.  Returns cat(rgb, density, normal) (..., 7)."""
     lin = lambda name, t: _lin(t, P[name + ".weight"], P[name + ".bias"])
     lin_relu = lambda name, t: _lin_relu(t, P[name + ".weight"], P[name + ".bias"])
@@ -212,7 +214,12 @@ def ref_expr(pos, d, noise, P, ide_fn):
     r = torch.cat((allin, r), dim=-1)
     for i in (0, 2, 4, 6):
         r = lin_relu("dir_block2.%d" % i, r)
-    rgb = torch.sigmoid(lin("spec_rgb_head.0", r)) * torch.sigmoid(tint) + torch.sigmoid(diffuse)
+    spec = torch.sigmoid(lin("spec_rgb_head.0", r)) * torch.sigmoid(tint)
+    if use_srgb:                                                                   # ref_model.py:100-102
+        from .nerf_helper import linear_to_srgb
+        rgb = linear_to_srgb(spec + torch.sigmoid(diffuse - math.log(3.0)))
+    else:
+        rgb = spec + torch.sigmoid(diffuse)
     return torch.cat((rgb, density, normal), dim=-1)
 
 

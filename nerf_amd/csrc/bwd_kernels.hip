@@ -387,18 +387,23 @@ __global__ void pe_grad_kernel(const float* __restrict__ d_enc, int ld, const fl
     }
 }
 
-// Ref-NeRF, stage 1 of the parameter backward: the spec head's delta.  rgb = sigmoid(spec) sigmoid(tint) + sigmoid(diffuse)
-// (ref_model.py:98-105, use_srgb off): d spec_raw = g_rgb sigmoid(tint) sigmoid'(spec), written as the head K group (slot features 0..2).
+// Ref-NeRF, stage 1 of the parameter backward: the spec head's delta.  rgb = f(sigmoid(spec) sigmoid(tint) + sigmoid(diffuse - c))
+// (ref_model.py:98-105; f = identity, c = 0, or with use_srgb f = linear_to_srgb, c = log 3): d spec_raw = g_rgb f' sigmoid(tint) sigmoid'(spec),
+// written as the head K group (slot features 0..2).
+DEVINL float ref_rgb_slope(const float* ax, int c, int srgb) {            // f'(linear colour) of channel c from the saved pre-activations
+    if (!srgb) return 1.0f;
+    return srgb_slope(sigmoid_f(ax[11 + c]) * sigmoid_f(ax[8 + c]) + sigmoid_f(ax[4 + c] - SRGB_LOG3));
+}
 template <int ELEM>
 __global__ void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, int64_t M, char* __restrict__ frag,
-                                      unsigned long long sub_stride) {
+                                      unsigned long long sub_stride, int srgb) {
     for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
         const float* ax = aux + m * 16;
         char* block = frag + (size_t)(m >> 5) * sub_stride;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float sp = sigmoid_f(ax[11 + c]);
-            store_slot_feature<ELEM>(block, (int)(m & 31), c, g_out[m * g_stride + c] * sigmoid_f(ax[8 + c]) * (sp * (1.0f - sp)));
+            store_slot_feature<ELEM>(block, (int)(m & 31), c, (g_out[m * g_stride + c] * ref_rgb_slope(ax, c, srgb)) * sigmoid_f(ax[8 + c]) * (sp * (1.0f - sp)));
         }
     }
 }
@@ -412,7 +417,7 @@ __global__ void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_str
 template <int ELEM>
 __global__ void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, const float* __restrict__ d_allin, int ld,
                                        const float* __restrict__ dirs, int dir_stride, const float* __restrict__ mat, int64_t M,
-                                       char* __restrict__ frag, unsigned long long sub_stride) {
+                                       char* __restrict__ frag, unsigned long long sub_stride, int srgb) {
     constexpr int TM[19] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 6, 7, 8};
     constexpr int TL[19] = {1, 1, 2, 2, 2, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
     constexpr int BREG = ELEM == 2 ? 1024 : 2048;
@@ -475,9 +480,10 @@ __global__ void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_st
         dh[3] = d_kinv * sigmoid_f(ax[3] - 1.0f);                                           // softplus'(v) = sigmoid(v)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float sd = sigmoid_f(ax[4 + c]), st = sigmoid_f(ax[8 + c]), sp = sigmoid_f(ax[11 + c]);
-            dh[4 + c] = g[c] * (sd * (1.0f - sd));
-            dh[8 + c] = g[c] * sp * (st * (1.0f - st));
+            const float sd = sigmoid_f(srgb ? ax[4 + c] - SRGB_LOG3 : ax[4 + c]), st = sigmoid_f(ax[8 + c]), sp = sigmoid_f(ax[11 + c]);
+            const float gl = g[c] * ref_rgb_slope(ax, c, srgb);
+            dh[4 + c] = gl * (sd * (1.0f - sd));
+            dh[8 + c] = gl * sp * (st * (1.0f - st));
         }
         dh[7] = g[3];
         char* sub = frag + (size_t)(m >> 5) * sub_stride;
@@ -1156,9 +1162,10 @@ size_t bwd_ref_workspace_bytes(int precision, int64_t M) {
 // w: the 20 tensors of nerf_amd_pack_weights(NET_REF) (only the ide_table, index 19, is read here).  d_w / d_b (20 each): 0..7 spatial,
 // 8 bottle_neck, 9 norm_col_tint_head (9 rows), 10 rho_tau_head (2 rows), 11..18 directional, 19 spec_rgb_head.0
 int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act, const float* aux, const float* dirs, int dir_stride,
-                     const float* g_out, int g_stride, const float* ide_table, float* const* d_w, float* const* d_b, void* workspace, hipStream_t st) {
+                     const float* g_out, int g_stride, const float* ide_table, float* const* d_w, float* const* d_b, void* workspace, int flags, hipStream_t st) {
     if (M == 0) return 0;
     using L = RefBwdLayout;
+    const int srgb = (flags & NERF_AMD_REF_SRGB) ? 1 : 0;
     const ChainCtx c(precision, M);
     const int64_t n_sub = bwd_n_sub(precision, M);
     Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
@@ -1171,8 +1178,8 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
     // features of the head K groups are written)
     if (int e = (int)hipMemsetAsync(D(8), 0, c.ls, st)) return e;
     // stage 1: spec head delta, then the directional network backwards
-    if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub);
-    else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub);
+    if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
+    else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
     if (int e = hidden_layer<1>(c, blob, L::START[0], D(8, 9), 1, nullptr, 0, A(16), D(16), st)) return e;                    // D7
     if (int e = hidden_layer<16>(c, blob, L::START[1], D(16), 16, nullptr, 0, A(15), D(15), st)) return e;                    // D6
     if (int e = hidden_layer<16>(c, blob, L::START[2], D(15), 16, nullptr, 0, A(14), D(14), st)) return e;                    // D5
@@ -1185,9 +1192,9 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
     if (int e = rows_layer<6>(c, blob, L::START[9], D(9), dallin, 192, 1, st)) return e;
     // stage 2: IDE / reflection / normal / head activations backwards -> delta of the heads and of the bottle-neck
     if (elem == 2) hipLaunchKernelGGL(ref_heads_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M,
-                                      D(8), (unsigned long long)c.sub);
+                                      D(8), (unsigned long long)c.sub, srgb);
     else hipLaunchKernelGGL(ref_heads_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, D(8),
-                            (unsigned long long)c.sub);
+                            (unsigned long long)c.sub, srgb);
     // stage 3: the spatial network backwards
     if (int e = hidden_layer<9>(c, blob, L::START[10], D(8), 9, nullptr, 0, A(7), D(7), st)) return e;                        // S7 from [bottle-neck | heads]
     if (int e = hidden_layer<16>(c, blob, L::START[11], D(7), 16, nullptr, 0, A(6), D(6), st)) return e;

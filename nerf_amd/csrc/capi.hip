@@ -10,7 +10,7 @@
 int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
-int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, const float*, hipStream_t);
+int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, const float*, int, hipStream_t);
 size_t mlp_train_layer_stride(int, int64_t);
 size_t mlp_train_mask_stride(int, int64_t);
 int mlp_launch_proposal_train(const void*, int, const nerf_amd_samples&, float*, void*, hipStream_t);
@@ -26,12 +26,12 @@ int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal_bwd(int, const float* const*, void*, hipStream_t);
 int pack_mip_bwd(int, const float* const*, void*, hipStream_t);
 int pack_ref_bwd(int, const float* const*, void*, hipStream_t);
-int mlp_launch_ref_train(const void*, int, const nerf_amd_samples&, float*, float*, const float*, void*, float*, hipStream_t);
+int mlp_launch_ref_train(const void*, int, const nerf_amd_samples&, float*, float*, const float*, void*, float*, int, hipStream_t);
 size_t bwd_density_grad_workspace_bytes(int, int64_t);
 int bwd_density_grad(int, const void*, int, int64_t, const void*, const float*, int, const float*, int, float*, void*, hipStream_t);
 size_t bwd_ref_workspace_bytes(int, int64_t);
 int bwd_ref_backward(const void*, int, int64_t, const void*, const float*, const float*, int, const float*, int, const float*, float* const*,
-                     float* const*, void*, hipStream_t);
+                     float* const*, void*, int, hipStream_t);
 int bwd_launch_prop_chain(const void*, int, const float*, int64_t, const void*, void*, hipStream_t);
 int bwd_launch_mip_chain(const void*, int, const float*, const float*, int64_t, const void*, void*, hipStream_t);
 size_t bwd_wgrad_workspace_bytes(int, int, int64_t);
@@ -106,7 +106,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 110; }
+int nerf_amd_version(void) { return 111; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -171,20 +171,21 @@ int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf
                       "nerf_amd_mip_forward_composite");
 }
 
-int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, float* normal, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+static bool bad_ref_flags(int f) { return (f & ~NERF_AMD_REF_SRGB) != 0; }
+int nerf_amd_ref_forward(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, float* rgbo, float* normal, void* stream) {
+    if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
     if (int c = check_samples(src, true)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, nullptr, S(stream)), "nerf_amd_ref_forward");
+    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, nullptr, ref_flags, S(stream)), "nerf_amd_ref_forward");
 }
-int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo,
+int nerf_amd_ref_forward_train(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, const float* bn_noise, float* rgbo,
                                float* normal, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
     if (int c = check_samples(src, true)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo || !bn_noise) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, bn_noise, S(stream)), "nerf_amd_ref_forward_train");
+    return hip_status(mlp_launch_ref(packed, precision, *src, rgbo, normal, bn_noise, ref_flags, S(stream)), "nerf_amd_ref_forward_train");
 }
 
 int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, void* stream) {
@@ -438,13 +439,13 @@ int nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, co
     return hip_status(bwd_mip_weight_grads(precision, M, act_dump, delta_dump, weights, biases, d_weights, d_biases, workspace, S(stream)),
                       "nerf_amd_mip_weight_grads");
 }
-int nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, const float* bn_noise, float* rgbo, float* normal,
-                                    void* dump, float* aux, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+int nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, const float* bn_noise, float* rgbo,
+                                    float* normal, void* dump, float* aux, void* stream) {
+    if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
     if (int c = check_samples(src, true)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo || !dump || !aux) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_ref_train(packed, precision, *src, rgbo, normal, bn_noise, dump, aux, S(stream)), "nerf_amd_ref_forward_train_dump");
+    return hip_status(mlp_launch_ref_train(packed, precision, *src, rgbo, normal, bn_noise, dump, aux, ref_flags, S(stream)), "nerf_amd_ref_forward_train_dump");
 }
 size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M) {
     if (bad_prec(precision) || M < 0 || (net != NERF_AMD_NET_PROPOSAL && net != NERF_AMD_NET_REF)) return 0;
@@ -462,17 +463,17 @@ size_t nerf_amd_ref_backward_workspace_bytes(int precision, int64_t M) {
     if (bad_prec(precision) || M < 0) return 0;
     return bwd_ref_workspace_bytes(precision, M);
 }
-int nerf_amd_ref_backward(const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* aux, const float* dirs, int dir_stride,
-                          const float* g_out, int g_stride, const float* ide_table, float* const* d_weights, float* const* d_biases, void* workspace,
-                          void* stream) {
-    if (bad_prec(precision) || M < 0 || dir_stride < 3 || g_stride < 7) return fail(NERF_AMD_EINVAL, "bad precision, size or stride");
+int nerf_amd_ref_backward(const void* packed_bwd, int precision, int ref_flags, int64_t M, const void* act_dump, const float* aux, const float* dirs,
+                          int dir_stride, const float* g_out, int g_stride, const float* ide_table, float* const* d_weights, float* const* d_biases,
+                          void* workspace, void* stream) {
+    if (bad_prec(precision) || bad_ref_flags(ref_flags) || M < 0 || dir_stride < 3 || g_stride < 7) return fail(NERF_AMD_EINVAL, "bad precision, flags, size or stride");
     if (!d_weights || !d_biases) return fail(NERF_AMD_EINVAL, "NULL argument");
     for (int i = 0; i < 20; ++i)
         if (!d_weights[i] || !d_biases[i]) return fail(NERF_AMD_EINVAL, "NULL gradient tensor");
     if (M == 0) return fail(NERF_AMD_EINVAL, "no samples (the caller zero-fills the gradients of an empty batch)");
     if (!packed_bwd || !act_dump || !aux || !dirs || !g_out || !ide_table || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(bwd_ref_backward(packed_bwd, precision, M, act_dump, aux, dirs, dir_stride, g_out, g_stride, ide_table, d_weights, d_biases, workspace,
-                                       S(stream)), "nerf_amd_ref_backward");
+                                       ref_flags, S(stream)), "nerf_amd_ref_backward");
 }
 
 int nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
@@ -594,11 +595,11 @@ size_t nerf_amd_render_ref_workspace_bytes(int64_t N, int n_fine) {
            n * 24 + 256;
 }
 
-int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, int precision, const float* rays,
+int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, int precision, int ref_flags, const float* rays,
                              const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
                              const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, const float* cam_dir,
                              float* rgb, float* depth, float* normal_img, void* workspace, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
     if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
     if (N == 0) return NERF_AMD_OK;
     if (!packed_prop || !packed_ref || !z_base || !u_strat || !u_inv || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
@@ -636,7 +637,7 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     if (int e = sk_merge_sorted(z_fine, z_coarse, N, n_fine + 1, C, z_all, st)) return hip_status(e, "depth merge");
     nerf_amd_samples sf{};                                  // row 13
     sf.mode = 1; sf.rays = rays; sf.S = S_all; sf.M = N * S_all; sf.z = z_all; sf.z_stride = S_all;
-    if (int e = mlp_launch_ref(packed_ref, precision, sf, rgbo, normal_img ? normals : nullptr, nullptr, st)) return hip_status(e, "Ref-NeRF MLP");
+    if (int e = mlp_launch_ref(packed_ref, precision, sf, rgbo, normal_img ? normals : nullptr, nullptr, ref_flags, st)) return hip_status(e, "Ref-NeRF MLP");
     const int flags = 1 | (white_bkg ? 2 : 0);              // row 10 with sigma -> softplus(sigma + 0.5) (procedures.py:73)
     if (int e = sk_composite(rgbo, z_all, S_all, rays + 3, 6, N, S_all, flags, NERF_AMD_ACT_SOFTPLUS, 0.5f, near, far,
                              normal_img ? normals : nullptr, cam_dir, rgb, nullptr, depth, normal_img, st)) return hip_status(e, "composite");

@@ -171,6 +171,17 @@ DEVINL double wave_sum_d(double v) {
     return v;
 }
 
+// RefNeRF(use_srgb=True) output transform (ref_model.py:100-102, nerf_helper.py:50-56): linear -> sRGB, and its slope for the backward.
+// Arithmetic as torch evaluates it: fl32(323/25) * x;  (211 * max(eps, x)^fl32(5/12) - 11) / 200;  eps = 2^-23.
+constexpr float SRGB_KNEE = 0.0031308f, SRGB_EPS = 1.1920928955078125e-07f, SRGB_LOG3 = 1.0986122886681098f;
+DEVINL float srgb_from_linear(float x) {
+    const float s0 = 12.92f * x;
+    const float s1 = (211.0f * powf(fmaxf(SRGB_EPS, x), 0.4166666666666667f) - 11.0f) / 200.0f;
+    return x <= SRGB_KNEE ? s0 : s1;
+}
+DEVINL float srgb_slope(float x) {
+    return x <= SRGB_KNEE ? 12.92f : (211.0f / 200.0f) * 0.4166666666666667f * powf(fmaxf(SRGB_EPS, x), -0.5833333333333333f);
+}
 DEVINL float softplus_f(float x) {            // torch softplus: beta=1, threshold=20
     return x > 20.0f ? x : log1pf(expf(x));
 }

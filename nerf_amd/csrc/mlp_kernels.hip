@@ -659,7 +659,7 @@ DEVINL void ide_encode(float x, float y, float z, float kappa_inv, float nv_dot,
 template <class P, bool TRAIN>
 __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                          float* __restrict__ rgbo, float* __restrict__ normal_out,
-                                                         const float* __restrict__ bn_noise, ActDump dump, float* __restrict__ aux) {
+                                                         const float* __restrict__ bn_noise, ActDump dump, float* __restrict__ aux, int flags) {
     using L = RefLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
@@ -824,9 +824,15 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
             if (h == 0 && m[t] < s.M) {
                 auto sig = [](float v) { return 1.0f / (1.0f + expf(-v)); };
                 f32x4 o;
-                o[0] = sig(sr[t]) * sig(keep[t][0]) + sig(d0);
-                o[1] = sig(sg[t]) * sig(keep[t][1]) + sig(d1);
-                o[2] = sig(sb[t]) * sig(keep[t][2]) + sig(d2);
+                if (flags & NERF_AMD_REF_SRGB) {                                   // ref_model.py:100-102
+                    o[0] = srgb_from_linear(sig(sr[t]) * sig(keep[t][0]) + sig(d0 - SRGB_LOG3));
+                    o[1] = srgb_from_linear(sig(sg[t]) * sig(keep[t][1]) + sig(d1 - SRGB_LOG3));
+                    o[2] = srgb_from_linear(sig(sb[t]) * sig(keep[t][2]) + sig(d2 - SRGB_LOG3));
+                } else {                                                            // ref_model.py:104-105
+                    o[0] = sig(sr[t]) * sig(keep[t][0]) + sig(d0);
+                    o[1] = sig(sg[t]) * sig(keep[t][1]) + sig(d1);
+                    o[2] = sig(sb[t]) * sig(keep[t][2]) + sig(d2);
+                }
                 o[3] = dens;
                 *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o;
                 if constexpr (TRAIN) { float* ax = aux + m[t] * 16; ax[11] = sr[t]; ax[12] = sg[t]; ax[13] = sb[t]; ax[14] = 0.0f; ax[15] = 0.0f; }
@@ -916,24 +922,24 @@ int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_sampl
 
 template <class P, bool TRAIN>
 static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise, ActDump dump, float* aux,
-                      hipStream_t st) {
+                      int flags, hipStream_t st) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = ref_lds_total<P>();
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(ref_kernel<P, TRAIN>), lds)) return e;
-    hipLaunchKernelGGL((ref_kernel<P, TRAIN>), dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise, dump, aux);
+    hipLaunchKernelGGL((ref_kernel<P, TRAIN>), dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise, dump, aux, flags);
     return (int)hipGetLastError();
 }
 int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
-                   hipStream_t st) {
-    if (precision == NERF_AMD_BF16) return launch_ref<PB16, false>(packed, s, rgbo, normal, bn_noise, NO_DUMP, nullptr, st);
-    return launch_ref<PF32, false>(packed, s, rgbo, normal, bn_noise, NO_DUMP, nullptr, st);
+                   int flags, hipStream_t st) {
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16, false>(packed, s, rgbo, normal, bn_noise, NO_DUMP, nullptr, flags, st);
+    return launch_ref<PF32, false>(packed, s, rgbo, normal, bn_noise, NO_DUMP, nullptr, flags, st);
 }
 // training forward of Ref-NeRF: activation dump (REF_DUMP_SLOTS slots of mlp_train_layer_stride bytes) + aux (M,16)
 int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
-                         void* dump, float* aux, hipStream_t st) {
+                         void* dump, float* aux, int flags, hipStream_t st) {
     const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M), nullptr, 0ull};
-    if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, st);
-    return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, st);
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
+    return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
 }

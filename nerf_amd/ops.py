@@ -151,28 +151,32 @@ def _ref_out(shape, device, want_normal):
     return rgbo, normal
 
 
-def ref_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, want_normal: bool = True, noise: Optional[torch.Tensor] = None):
+REF_SRGB = 1          # NERF_AMD_REF_SRGB: RefNeRF(use_srgb=True) output transform (ref_model.py:100-102)
+
+
+def ref_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, want_normal: bool = True, noise: Optional[torch.Tensor] = None,
+                flags: int = 0):
     """pts (..., 6) = [position | direction] -> (rgbo (..., 4), normal (..., 3))   [ref_model.py:68-106]; `noise` (..., 128) = the
-    train-mode bottle-neck perturbation (ref_model.py:84-85), None = eval mode"""
+    train-mode bottle-neck perturbation (ref_model.py:84-85), None = eval mode; `flags`: REF_SRGB = the module's use_srgb"""
     pts = _dev(pts, "pts")
     rgbo, normal = _ref_out(pts.shape[:-1], pts.device, want_normal)
     if rgbo.numel() == 0:
         return rgbo, normal
     s = _samples_pts(pts, 6)
     if noise is None:
-        check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
+        check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), int(flags), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
     else:
         noise = _dev(noise, "noise")
         if noise.numel() != s.M * 128:
             raise ValueError("nerf_amd: bottle-neck noise must be (..., 128) over the same samples")
-        check(lib.nerf_amd_ref_forward_train(_ptr(packed), precision, C.byref(s), _ptr(noise), _ptr(rgbo), _ptr(normal), _stream()),
+        check(lib.nerf_amd_ref_forward_train(_ptr(packed), precision, C.byref(s), int(flags), _ptr(noise), _ptr(rgbo), _ptr(normal), _stream()),
               "nerf_amd_ref_forward_train")
     return rgbo, normal
 
 
-def ref_forward_samples(packed, precision, s: Samples, shape, device, want_normal: bool = True):
+def ref_forward_samples(packed, precision, s: Samples, shape, device, want_normal: bool = True, flags: int = 0):
     rgbo, normal = _ref_out(shape, device, want_normal)
-    check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
+    check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), int(flags), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
     return rgbo, normal
 
 
@@ -427,7 +431,7 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
 
 def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                     want_depth=True, cam_dir: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                    camera: Optional[Samples] = None, ray_offset: int = 0, n_rays: Optional[int] = None):
+                    camera: Optional[Samples] = None, ray_offset: int = 0, n_rays: Optional[int] = None, flags: int = 0):
     """The tile body of render_image for a Ref-NeRF fine network (procedures.py:64-85, is_ref_model branch) in six launches.
     `cam_dir` (3,) = render_pose[:, -2] asks for the normal image (procedures.py:79-81)."""
     dev = u_strat.device
@@ -439,7 +443,7 @@ def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u
     depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
     cam_dir = _dev(cam_dir, "cam_dir") if cam_dir is not None else None
     normal_img = torch.empty((N,), dtype=torch.float32, device=dev) if cam_dir is not None else None
-    check(lib.nerf_amd_render_rays_ref(_ptr(packed_prop), _ptr(packed_ref), precision, _ptr(rays),
+    check(lib.nerf_amd_render_rays_ref(_ptr(packed_prop), _ptr(packed_ref), precision, int(flags), _ptr(rays),
                                        C.byref(camera) if camera is not None else None, ray_offset, _ptr(z_base), _ptr(u_strat),
                                        _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(cam_dir), _ptr(rgb),
                                        _ptr(depth), _ptr(normal_img), _ptr(workspace), _stream()), "nerf_amd_render_rays_ref")
@@ -651,7 +655,7 @@ def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp
 
 
 # ------------------------------------------------------------------------------------------------ Ref-NeRF training / density gradients
-def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, noise: Optional[torch.Tensor]):
+def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, noise: Optional[torch.Tensor], flags: int = 0):
     """RefNeRF.forward in training (ref_model.py:68-106) + the activation dump and the pre-activation head values of the backward.
     pts (..., 6) -> (rgbo (..., 4), normal (..., 3), dump, aux (M, 16))"""
     pts = _dev(pts, "pts")
@@ -661,7 +665,7 @@ def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, n
     aux = torch.empty((s.M, 16), dtype=torch.float32, device=pts.device)
     if s.M:
         noise = _dev(noise, "noise") if noise is not None else None
-        check(lib.nerf_amd_ref_forward_train_dump(_ptr(packed), precision, C.byref(s), _ptr(noise), _ptr(rgbo), _ptr(normal), _ptr(dump), _ptr(aux),
+        check(lib.nerf_amd_ref_forward_train_dump(_ptr(packed), precision, C.byref(s), int(flags), _ptr(noise), _ptr(rgbo), _ptr(normal), _ptr(dump), _ptr(aux),
                                                   _stream()), "nerf_amd_ref_forward_train_dump")
     return rgbo, normal, dump, aux
 
@@ -690,7 +694,7 @@ REF_GRAD_SHAPES = ([(256, 63)] + [(256, 256)] * 3 + [(256, 319)] + [(256, 256)] 
 
 
 def ref_backward(packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, aux: torch.Tensor, dirs: torch.Tensor, g_out: torch.Tensor,
-                 ide_table: torch.Tensor):
+                 ide_table: torch.Tensor, flags: int = 0):
     """Every parameter gradient of RefNeRF.forward.  g_out (M,7) = d loss / d [rgb | raw density | predicted normal]; dirs (M,3).
     -> ([dW]*20, [db]*20): 0..7 spatial, 8 bottle_neck, 9 norm_col_tint_head, 10 rho_tau_head, 11..18 directional, 19 spec_rgb_head.0"""
     g_out, dirs, aux = _dev(g_out, "g_out"), _dev(dirs, "dirs"), _dev(aux, "aux")
@@ -699,6 +703,6 @@ def ref_backward(packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, a
     gw = _grad_buffers(REF_GRAD_SHAPES, dev)
     gb = _grad_buffers([(s[0],) for s in REF_GRAD_SHAPES], dev)
     ws = torch.empty(lib.nerf_amd_ref_backward_workspace_bytes(precision, M), dtype=torch.uint8, device=dev)
-    check(lib.nerf_amd_ref_backward(_ptr(packed_bwd), precision, M, _ptr(dump), _ptr(aux), _ptr(dirs), dirs.shape[1], _ptr(g_out), g_out.shape[1],
+    check(lib.nerf_amd_ref_backward(_ptr(packed_bwd), precision, int(flags), M, _ptr(dump), _ptr(aux), _ptr(dirs), dirs.shape[1], _ptr(g_out), g_out.shape[1],
                                     _ptr(_dev(ide_table, "ide_table")), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()), "nerf_amd_ref_backward")
     return gw, gb

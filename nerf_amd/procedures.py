@@ -105,7 +105,7 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         # ascending sets).
         rgb, depth, normal_px, _ = ops.render_rays_ref(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
                                                        sample_num, near, far, white_bkg, want_depth=bool(render_depth),
-                                                       cam_dir=render_pose[:, -2].contiguous() if render_normal else None)
+                                                       cam_dir=render_pose[:, -2].contiguous() if render_normal else None, flags=network.kernel_flags)
 
     def to_image(t, ch):
         if sz is None:

@@ -50,9 +50,14 @@ class RefNeRF(PackedWeightsMixin, NeRF):
 
     def _check_config(self):
         ok = (self.position_flevel == 10 and self.sh_max_level == 4 and self.bottle_neck_dim == 128 and self.hidden_unit == 256
-              and self.output_dim == 256 and self.cat_origin and not self.use_srgb)
+              and self.output_dim == 256 and self.cat_origin)
         if not ok:
-            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, 4, 128, 256, 256, use_srgb=False)")
+            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, 4, 128, 256, 256) (use_srgb on or off)")
+
+    @property
+    def kernel_flags(self) -> int:
+        """ref_flags of the C-ABI's Ref-NeRF entry points (NERF_AMD_REF_SRGB = use_srgb, ref_model.py:100-102)"""
+        return ops.REF_SRGB if self.use_srgb else 0
 
     def _pack_tensors(self):
         nct, rt = self.norm_col_tint_head, self.rho_tau_head
@@ -97,7 +102,7 @@ class RefNeRF(PackedWeightsMixin, NeRF):
 
             def hip(p, dd, *wb):
                 pts6 = torch.cat((p, dd), dim=-1).contiguous()
-                rgbo, normal, held["dump"], held["aux"] = ops.ref_forward_train(self.packed(prec), prec, pts6, noise)
+                rgbo, normal, held["dump"], held["aux"] = ops.ref_forward_train(self.packed(prec), prec, pts6, noise, self.kernel_flags)
                 held["pts"] = pts6.view(-1, 6)
                 return torch.cat((rgbo, normal), dim=-1)
 
@@ -110,13 +115,13 @@ class RefNeRF(PackedWeightsMixin, NeRF):
                 if ab._VJP.inputs_only:                       # RefNeRF.get_grad: the density channel's gradient w.r.t. the positions
                     gx = ops.density_grad(ops.NET_REF, held["bwd_blob"], prec, held["dump"], held["pts"], scale=g2[:, 3])
                     return (gx.view(p.shape), None, *[None] * len(wb))
-                gw, gb = ops.ref_backward(held["bwd_blob"], prec, held.pop("dump"), held.pop("aux"), held["pts"][:, 3:], g2, self._ide_table(p.device))
+                gw, gb = ops.ref_backward(held["bwd_blob"], prec, held.pop("dump"), held.pop("aux"), held["pts"][:, 3:], g2, self._ide_table(p.device), self.kernel_flags)
                 by_name = self._grads_by_name(gw, gb)
                 return (None, None, *[by_name[n] for n in names])
-            expr = lambda p, dd, *wb: ab.ref_expr(p, dd, noise, dict(zip(names, wb)), self.integrated_dir_enc)
+            expr = lambda p, dd, *wb: ab.ref_expr(p, dd, noise, dict(zip(names, wb)), self.integrated_dir_enc, self.use_srgb)
             out = ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pos, d, *params)
             return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
-        return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise)
+        return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise, flags=self.kernel_flags)
 
     def _ide_table(self, device):
         tables = self.__dict__.setdefault("_ide_table_on", {})

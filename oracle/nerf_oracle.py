@@ -613,9 +613,17 @@ def ref_shapes(Lp: int = 10, deg: int = 4, hidden: int = 256, bottle: int = 128,
     return s
 
 
+def linear_to_srgb(linear: Tensor) -> Tensor:
+    """nerf_helper.py:50-56 (from multinerf): 323/25 x below the knee, (211 max(eps, x)^(5/12) - 11) / 200 above."""
+    eps = torch.full((1,), torch.finfo(torch.float32).eps, dtype=linear.dtype, device=linear.device)
+    srgb0 = 323 / 25 * linear
+    srgb1 = (211 * torch.maximum(eps, linear) ** (5 / 12) - 11) / 200
+    return torch.where(linear <= 0.0031308, srgb0, srgb1)
+
+
 def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = None, Lp: int = 10, deg: int = 4,
-                emulate_bf16: bool = False, noise: Optional[Tensor] = None):
-    """RefNeRF.forward, use_srgb=False (ref_model.py:68-106).  pts (N,S,6) [or (N,S,3) + ray_d] ->
+                emulate_bf16: bool = False, noise: Optional[Tensor] = None, use_srgb: bool = False):
+    """RefNeRF.forward (ref_model.py:68-106; `use_srgb`: lines 100-102 instead of 104-105).  pts (N,S,6) [or (N,S,3) + ray_d] ->
     ((N,S,4) = [rgb | raw density], normal (N,S,3)).  `noise` = the train-mode perturbation of the bottle-neck vector
     (ref_model.py:84-85: torch.normal(0, perturb_bottle_neck_w, shape)); None = eval mode."""
     lin = lambda name, t: _linear(t, sd[name + ".weight"], sd[name + ".bias"], emulate_bf16)
@@ -648,7 +656,11 @@ def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = No
     for i in (0, 2, 4, 6):
         r = F.relu(lin(f"dir_block2.{i}", r))
     spec = torch.sigmoid(lin("spec_rgb_head.0", r)) * torch.sigmoid(tint)
-    rgb = spec + torch.sigmoid(diffuse)
+    if use_srgb:
+        import math
+        rgb = linear_to_srgb(spec + torch.sigmoid(diffuse - math.log(3.)))
+    else:
+        rgb = spec + torch.sigmoid(diffuse)
     return torch.cat((rgb, density), dim=-1), normal
 
 
@@ -704,7 +716,7 @@ def ref_train_step(prop_sd, ref_sd, rays: Tensor, z_coarse: Tensor, u_inv: Tenso
 
 
 def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float, sample_num: int = 128,
-                    white_bkg: bool = False, cam_z: Optional[Tensor] = None):
+                    white_bkg: bool = False, cam_z: Optional[Tensor] = None, use_srgb: bool = False):
     """Tile body of render_image for a RefNeRF (procedures.py:64-85, is_ref_model branch): coarse+fine merge, sigma ->
     softplus(sigma + 0.5), composite with relu (a no-op after softplus)."""
     z_c = stratified_render(near, far, sample_num, u_strat)
@@ -713,7 +725,7 @@ def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tenso
     w_prop = max_blur(sigma_to_weights(density, z_c, rays[:, 3:]), 0.01)
     z_f, _ = inverse_sample(w_prop, z_c, u_inv, sort=True)
     samples, z_all = coarse_fine_merge(rays, z_c, z_f)
-    rgbo, normal = ref_forward(ref_sd, samples)
+    rgbo, normal = ref_forward(ref_sd, samples, use_srgb=use_srgb)
     rgbo = torch.cat((rgbo[..., :3], F.softplus(rgbo[..., 3:] + 0.5)), dim=-1)
     rgb, w, extras = composite(rgbo, z_all, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far),
                                normal_info=(normal, cam_z) if cam_z is not None else None)

@@ -372,6 +372,26 @@ def main():
     npz("g18_ipe_l10", z=z18, rays=r18, radius=np.float64(rad18), feat=feat18, mu=mu18, mu_t=mu_t18, var_t=cp18[1], var_r=cp18[2],
         dir_norm=r18[:, 3:].norm())
 
+    # ---------------- G19 RefNeRF(use_srgb=True): forward + parameter gradients (ref_model.py:100-102, nerf_helper.py:50-56) ----------------
+    # (after G18: draws from the end of the generator stream, earlier fixtures unchanged)
+    zf19, _ = torch.sort(near + (far - near) * torch.rand(12, 20, generator=g), dim=-1)
+    pts19 = nerf_base.NeRF.length2pts(rays, zf19)
+    G19, Gn19 = torch.randn(12, 20, 4, generator=g), torch.randn(12, 20, 3, generator=g)
+    o19 = {"pts": pts19, "g_rgbo": G19, "g_normal": Gn19}
+    for tag in ("small", "he"):
+        net = ref_model.RefNeRF(10, 4, use_srgb=True); net.load_state_dict(W.ref_state(tag)); net.eval()
+        rgbo19, nrm19 = net.forward(pts19)
+        ((rgbo19 * G19).sum() + (nrm19 * Gn19).sum()).backward()
+        o19[tag + "_rgbo"], o19[tag + "_normal"] = rgbo19, nrm19
+        o19[tag + "_g_spec"] = net.spec_rgb_head[0].weight.grad
+        o19[tag + "_g_nct"] = net.norm_col_tint_head.weight.grad
+        o19[tag + "_g_nct_bias"] = net.norm_col_tint_head.bias.grad
+        o19[tag + "_g_rho_tau"] = net.rho_tau_head.weight.grad
+        o19[tag + "_g_dir2_6"] = net.dir_block2[6].weight.grad[:8, :]
+        o19[tag + "_g_spa2_6"] = net.spa_block2[6].weight.grad[:8, :]
+        o19[tag + "_g_spa0"] = net.spa_block1[0].weight.grad[:8, :]
+    npz("g19_refnerf_srgb", **o19)
+
 
 if __name__ == "__main__":
     main()

@@ -476,6 +476,52 @@ def test_refnerf_forward_vs_reference_golden(A, golden, tag):
     assert max_abs(rgbo16.cpu(), want16) <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("tag", ["small", "he"])
+def test_refnerf_use_srgb_forward_and_gradients(A, golden, tag):
+    """RefNeRF(use_srgb=True) (ref_model.py:100-102: sigmoid(diffuse - log 3), linear_to_srgb): the kernel's output transform and its
+    backward (NERF_AMD_REF_SRGB) against the real reference's forward and parameter gradients (golden G19); the render path passes the
+    flag too."""
+    from nerf_amd.ref_model import RefNeRF
+    g = golden("g19_refnerf_srgb")
+    net = RefNeRF(10, 4, use_srgb=True)
+    net.load_state_dict(W.ref_state(tag))
+    net = net.cuda().eval()
+    A.pkg.set_precision("fp32")
+    scale = max(1.0, g[tag + "_rgbo"].abs().max().item())
+    with torch.no_grad():
+        rgbo, normal = net.forward(dev(g["pts"]))
+    assert max_abs(rgbo.cpu(), g[tag + "_rgbo"]) <= 2e-5 * scale
+    assert max_abs(normal.cpu(), g[tag + "_normal"]) <= 2e-5
+    # gradients: forward with the activation dump, nerf_amd_ref_backward with the flag
+    rgbo_t, normal_t = net.forward(dev(g["pts"]))
+    assert max_abs(rgbo_t.detach().cpu(), g[tag + "_rgbo"]) <= 2e-5 * scale
+    ((rgbo_t * dev(g["g_rgbo"])).sum() + (normal_t * dev(g["g_normal"])).sum()).backward()
+    got = dict(net.named_parameters())
+    for key, name, rows in (("g_spec", "spec_rgb_head.0.weight", None), ("g_nct", "norm_col_tint_head.weight", None),
+                            ("g_nct_bias", "norm_col_tint_head.bias", None), ("g_rho_tau", "rho_tau_head.weight", None),
+                            ("g_dir2_6", "dir_block2.6.weight", 8), ("g_spa2_6", "spa_block2.6.weight", 8), ("g_spa0", "spa_block1.0.weight", 8)):
+        want = g[tag + "_" + key]
+        have = got[name].grad.cpu() if rows is None else got[name].grad[:rows].cpu()
+        assert max_abs(have, want) <= 3e-3 * max(1e-6, want.abs().max().item()), (tag, key, max_abs(have, want), want.abs().max().item())
+    # bf16 mode against the oracle's bf16-operand emulation
+    A.pkg.set_precision("bf16")
+    with torch.no_grad():
+        rgbo16, _ = net.forward(dev(g["pts"]))
+        want16, _ = O.ref_forward(W.ref_state(tag), g["pts"], emulate_bf16=True, use_srgb=True)
+    A.pkg.set_precision("fp32")
+    assert max_abs(rgbo16.cpu(), want16) <= 2e-2 * scale
+    if tag == "small":                                       # the whole-tile render entry (nerf_amd_render_rays_ref) takes the same flag
+        prop, _ = build_nets(A, "small")
+        rays, u1, u2 = _rays_and_u(300, 64, 19)
+        z_base = torch.linspace(NEAR, FAR, 64).cuda()
+        with torch.no_grad():
+            want_rgb, _, _ = O.render_rays_ref(W.proposal_state("small"), W.ref_state("small"), rays, u1, u2, NEAR, FAR, 64, white_bkg=True,
+                                               use_srgb=True)
+        rgb, _, _, _ = A.ops.render_rays_ref(prop.packed(A.ops.F32), net.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 64,
+                                             NEAR, FAR, True, flags=net.kernel_flags)
+        assert max_abs(rgb.cpu(), want_rgb) <= 1e-4
+
+
 @pytest.mark.parametrize("M", [1, 33, 129, 1000, 40001])
 def test_refnerf_ragged_sizes(A, M):
     net = build_ref(A, "small")

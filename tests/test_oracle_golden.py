@@ -222,6 +222,27 @@ def test_g13_ide_and_refnerf(golden):
         assert max_abs(normal, g[tag + "_normal"]) <= 2e-6
 
 
+def test_g19_refnerf_use_srgb(golden):
+    """RefNeRF(use_srgb=True) (ref_model.py:100-102, nerf_helper.py:50-56): forward and parameter gradients of the oracle restatement
+    against the real reference's."""
+    g = golden("g19_refnerf_srgb")
+    for tag in ("small", "he"):
+        sd = {k: v.clone().requires_grad_(True) for k, v in W.ref_state(tag).items()}
+        rgbo, normal = O.ref_forward(sd, g["pts"], use_srgb=True)
+        scale = max(1.0, g[tag + "_rgbo"].abs().max().item())
+        assert max_abs(rgbo.detach(), g[tag + "_rgbo"]) <= 2e-6 * scale
+        assert max_abs(normal.detach(), g[tag + "_normal"]) <= 2e-6
+        with torch.no_grad():                                               # it is not the use_srgb=False output
+            assert max_abs(O.ref_forward(W.ref_state(tag), g["pts"])[0][..., :3], g[tag + "_rgbo"][..., :3]) > 1e-2
+        ((rgbo * g["g_rgbo"]).sum() + (normal * g["g_normal"]).sum()).backward()
+        for key, name, rows in (("g_spec", "spec_rgb_head.0.weight", None), ("g_nct", "norm_col_tint_head.weight", None),
+                                ("g_nct_bias", "norm_col_tint_head.bias", None), ("g_rho_tau", "rho_tau_head.weight", None),
+                                ("g_dir2_6", "dir_block2.6.weight", 8), ("g_spa2_6", "spa_block2.6.weight", 8), ("g_spa0", "spa_block1.0.weight", 8)):
+            want = g[tag + "_" + key]
+            got = sd[name].grad if rows is None else sd[name].grad[:rows]
+            assert max_abs(got, want) <= 2e-4 * max(1e-6, want.abs().max().item()), (tag, key)
+
+
 def test_g13_render_image_refnerf(golden):
     """Reference render_image with a RefNeRF (coarse+fine merge, softplus(sigma+.5), normals), one 50x50 tile."""
     g = golden("g13_refnerf")
