@@ -197,10 +197,50 @@ def train_rate(precision):
     best = out["rays_16384"]["rays_per_s"]
     out["roofline"] = {"bound": "mfma", "kernel": "whole training step, 16384 rays (3 x 162.4 MFLOP/ray)", "achieved": best * 3 * FLOP_PER_RAY / 1e12,
                        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": best * 3 * FLOP_PER_RAY / peak, "traffic": None}
+    out["iteration_512"] = iteration_rate(precision)
     dt = mod.run_ref(512, 64, 128, precision, iters=10, warm=3, quiet=True)
     out["refnerf_rays_512"] = {"rays_per_s": 512 / dt, "ms_per_iter": dt * 1e3, "note": "Ref-NeRF step with prop_normal (train.py:176-187)"}
     import nerf_amd
     nerf_amd.set_precision(precision)
+    return out
+
+
+def iteration_rate(precision, n_rays=512, iters=200):
+    """The reference's whole training ITERATION (train.py:151-218: ray sampling from an 800x800 image included) through
+    nerf_amd.training.TrainStep -- pose, pixel table, seed, Adam step count and learning rate in device memory, every random number drawn
+    in kernels -- eager and replayed from a hipGraph, with the learning rate rewritten on the host every iteration like DecayLrScheduler."""
+    import nerf_amd
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.optim import Adam
+    from nerf_amd.training import TrainStep
+    from oracle import nerf_oracle as O                    # (pose / focal helpers only; nothing timed)
+    nerf_amd.set_precision(precision)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(0)
+    out = {}
+    img = torch.rand(3, H, W, device=dev)
+    pose = O.pose_spherical(30.0, -30.0, 4.0)[:3].contiguous().to(dev)
+    focal = O.fov2focal(0.6911112070083618, (H, W))
+    for mode in ("eager", "hipgraph"):
+        prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
+        opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11)
+        step.set_image(img, pose)
+        if mode == "hipgraph":
+            step.capture(warmup=3)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            for gr in opt.param_groups:
+                gr["lr"] = 5e-4 * (0.999 ** i)
+            step(img, pose)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[mode] = {"rays_per_s": n_rays / dt, "ms_per_iter": dt * 1e3}
+    out["note"] = "nerf_amd.training.TrainStep: sampler + forward + backward + Adam, image/pose copied in and lr rewritten every iteration"
     return out
 
 

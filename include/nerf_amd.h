@@ -197,6 +197,16 @@ int nerf_amd_pixel_rays(const float* pose_host, float fx, float fy, const int64_
 int nerf_amd_sample_training_rays(const float* rgbs, const int64_t* coords, int64_t n_pixels, const float* pose_host, float fx, float fy,
                                   float near, float far, int64_t N, int C, uint64_t rng_seed, float* pts, float* lengths, float* rgb,
                                   float* rays, void* stream);
+/* The same with the camera pose (3,4) and the seed read from DEVICE memory at run time: nothing about the step is baked into the launch
+ * arguments, so a training step captured once in a hipGraph sees a new image pose and fresh random numbers on every replay
+ * (nerf_amd/training.py).  nerf_amd_advance_seed replaces *seed_dev by an unrelated key (one thread; put it at the end of the step);
+ * nerf_amd_philox_uniforms fills u (N,K) with the inverse-CDF stream of nerf_amd_resample (key = rng_seed, or *seed_dev when given) for
+ * callers that keep inverseSample(weights, depths, u) as a separate op (utils.py:34-44, 115). */
+int nerf_amd_sample_training_rays_dev(const float* rgbs, const int64_t* coords, int64_t n_pixels, const float* pose_dev, float fx, float fy,
+                                      float near, float far, int64_t N, int C, const uint64_t* seed_dev, float* pts, float* lengths,
+                                      float* rgb, float* rays, void* stream);
+int nerf_amd_philox_uniforms(float* out, int64_t N, int K, uint64_t rng_seed, const uint64_t* seed_dev, void* stream);
+int nerf_amd_advance_seed(uint64_t* seed_dev, void* stream);
 
 /* Stratified depths and points (utils.py:87-90, procedures.py:65-66): z = z_base[s] + u*z_jitter (N,S);
  * pts (N,S,3) = o + d*z, or NULL to skip. */
@@ -284,7 +294,8 @@ int nerf_amd_encode_rows(const float* x, int x_stride, int64_t M, int L, int nor
  *   4. nerf_amd_adam_step: torch.optim.Adam (no weight decay, no amsgrad) over a table of tensors; `step` is a DEVICE float holding
  *      the number of steps taken so far (incremented by the call, so that a captured graph replays correctly); grads are multiplied
  *      by grad_scale first (1 = plain; 1/world_size after a summing all-reduce).  lr / betas / eps are doubles like torch's Python
- *      scalars (the bias corrections 1 - beta^step are formed in double, as torch does).
+ *      scalars (the bias corrections 1 - beta^step are formed in double, as torch does); a non-NULL lr_dev (one double on the device)
+ *      overrides lr when the kernel runs, so that a captured graph follows a learning-rate schedule.
  * Gradients w.r.t. the sample positions are not produced (the reference detaches them for these two networks).
  * ------------------------------------------------------------------------------------------------ */
 size_t nerf_amd_packed_backward_bytes(int net, int precision);
@@ -320,8 +331,8 @@ int    nerf_amd_ref_backward(const void* packed_bwd, int precision, int ref_flag
                              const float* dirs, int dir_stride, const float* g_out, int g_stride, const float* ide_table,
                              float* const* d_weights, float* const* d_biases, void* workspace, void* stream);
 int    nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                          const int64_t* numel, int n_tensors, float* step, double lr, double beta1, double beta2, double eps,
-                          float grad_scale, void* stream);
+                          const int64_t* numel, int n_tensors, float* step, double lr, const double* lr_dev, double beta1, double beta2,
+                          double eps, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).

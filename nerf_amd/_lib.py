@@ -54,6 +54,10 @@ SIGNATURES = {
     "nerf_amd_pixel_rays": (C.c_int, [c_float_p, C.c_float, C.c_float, c_void, i64, c_void, c_void]),
     "nerf_amd_sample_training_rays": (C.c_int, [c_void, c_void, i64, c_float_p, C.c_float, C.c_float, C.c_float, C.c_float, i64, C.c_int, C.c_uint64,
                                                c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_sample_training_rays_dev": (C.c_int, [c_void, c_void, i64, c_void, C.c_float, C.c_float, C.c_float, C.c_float, i64, C.c_int, c_void,
+                                                   c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_philox_uniforms": (C.c_int, [c_void, i64, C.c_int, C.c_uint64, c_void, c_void]),
+    "nerf_amd_advance_seed": (C.c_int, [c_void, c_void]),
     "nerf_amd_stratified_points": (C.c_int, [c_void, c_void, c_void, C.c_float, i64, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_resample": (C.c_int, [c_void, c_void, c_void, c_void, C.c_float, c_void, C.c_int, c_void, i64, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_uint64, i64, c_void, c_void, c_void, c_void, c_void]),
@@ -89,7 +93,7 @@ SIGNATURES = {
     "nerf_amd_ref_backward": (C.c_int, [c_void, C.c_int, C.c_int, i64, c_void, c_void, c_void, C.c_int, c_void, C.c_int, c_void, C.POINTER(c_void),
                                        C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_adam_step": (C.c_int, [C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void), C.POINTER(i64), C.c_int, c_void,
-                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, c_void]),
+                                    C.c_double, c_void, C.c_double, C.c_double, C.c_double, C.c_float, c_void]),
     "nerf_amd_sigma_to_weights_backward": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_composite_backward": (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                               C.c_float, c_void, c_void, c_void, c_void, c_void]),

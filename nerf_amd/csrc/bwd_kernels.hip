@@ -826,8 +826,10 @@ __global__ void mip_fold_grads_kernel(const float* __restrict__ G, const float* 
 struct AdamTensor { float* p; const float* g; float* m; float* v; long long n; };
 constexpr int ADAM_MAX = 48;
 struct AdamTable { AdamTensor t[ADAM_MAX]; };
-__global__ void adam_kernel(AdamTable tab, const float* __restrict__ step_ptr, double lr, double beta1, double beta2, double eps, float grad_scale) {
+__global__ void adam_kernel(AdamTable tab, const float* __restrict__ step_ptr, double lr, const double* __restrict__ lr_dev, double beta1, double beta2,
+                            double eps, float grad_scale) {
     const AdamTensor& T = tab.t[blockIdx.y];
+    if (lr_dev != nullptr) lr = lr_dev[0];                  // learning rate from device memory: a captured graph follows the schedule
     // scalars the way torch forms them (Python doubles, rounded to fp32 where they meet the tensors)
     const double step = (double)step_ptr[0];
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
@@ -1261,13 +1263,13 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
 }
 
 int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* n, int count, float* step, double lr,
-                    double beta1, double beta2, double eps, float grad_scale, hipStream_t st) {
+                    const double* lr_dev, double beta1, double beta2, double eps, float grad_scale, hipStream_t st) {
     hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(1), 0, st, step);
     for (int base = 0; base < count; base += ADAM_MAX) {
         AdamTable tab = {};
         const int c = (count - base < ADAM_MAX) ? count - base : ADAM_MAX;
         for (int i = 0; i < c; ++i) tab.t[i] = AdamTensor{p[base + i], g[base + i], m[base + i], v[base + i], n[base + i]};
-        hipLaunchKernelGGL(adam_kernel, dim3(32, c), dim3(256), 0, st, tab, step, lr, beta1, beta2, eps, grad_scale);
+        hipLaunchKernelGGL(adam_kernel, dim3(32, c), dim3(256), 0, st, tab, step, lr, lr_dev, beta1, beta2, eps, grad_scale);
     }
     return (int)hipGetLastError();
 }

@@ -38,15 +38,17 @@ size_t bwd_wgrad_workspace_bytes(int, int, int64_t);
 int bwd_prop_weight_grads(int, int64_t, const void*, const void*, float* const*, float* const*, void*, hipStream_t);
 int bwd_mip_weight_grads(int, int64_t, const void*, const void*, const float* const*, const float* const*, float* const*, float* const*, void*,
                          hipStream_t);
-int bwd_launch_adam(float* const*, const float* const*, float* const*, float* const*, const long long*, int, float*, double, double, double,
-                    double, float, hipStream_t);
+int bwd_launch_adam(float* const*, const float* const*, float* const*, float* const*, const long long*, int, float*, double, const double*, double,
+                    double, double, float, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
 int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
 int sk_dirs_norm(const float*, int64_t, float*, hipStream_t);
-int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, float, float, float, float, int64_t, int, uint64_t, float*, float*, float*,
-                     float*, hipStream_t);
+int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, const float*, float, float, float, float, int64_t, int, uint64_t, const uint64_t*,
+                     float*, float*, float*, float*, hipStream_t);
+int sk_philox_uniforms(float*, int64_t, int, uint64_t, const uint64_t*, hipStream_t);
+int sk_advance_seed(uint64_t*, hipStream_t);
 int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
 int sk_length2pts(const float*, const float*, int64_t, int, float*, hipStream_t);
@@ -262,8 +264,26 @@ int nerf_amd_sample_training_rays(const float* rgbs, const int64_t* coords, int6
     if (N < 0 || C < 0 || n_pixels < 1) return fail(NERF_AMD_EINVAL, "bad size");
     if (!pose_host || (N && (!rgbs || !coords || !rgb || !rays))) return fail(NERF_AMD_EINVAL, "NULL argument");
     if ((pts == nullptr) != (lengths == nullptr) || (pts && C < 1)) return fail(NERF_AMD_EINVAL, "pts and lengths go together (C >= 1)");
-    return hip_status(sk_train_sampler(rgbs, coords, n_pixels, pose_host, fx, fy, near, far, N, C, rng_seed, pts, lengths, rgb, rays, S(stream)),
+    return hip_status(sk_train_sampler(rgbs, coords, n_pixels, pose_host, nullptr, fx, fy, near, far, N, C, rng_seed, nullptr, pts, lengths, rgb, rays, S(stream)),
                       "nerf_amd_sample_training_rays");
+}
+int nerf_amd_sample_training_rays_dev(const float* rgbs, const int64_t* coords, int64_t n_pixels, const float* pose_dev, float fx, float fy,
+                                      float near, float far, int64_t N, int C, const uint64_t* seed_dev, float* pts, float* lengths, float* rgb,
+                                      float* rays, void* stream) {
+    if (N < 0 || C < 0 || n_pixels < 1) return fail(NERF_AMD_EINVAL, "bad size");
+    if (!pose_dev || !seed_dev || (N && (!rgbs || !coords || !rgb || !rays))) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if ((pts == nullptr) != (lengths == nullptr) || (pts && C < 1)) return fail(NERF_AMD_EINVAL, "pts and lengths go together (C >= 1)");
+    return hip_status(sk_train_sampler(rgbs, coords, n_pixels, nullptr, pose_dev, fx, fy, near, far, N, C, 0, seed_dev, pts, lengths, rgb, rays, S(stream)),
+                      "nerf_amd_sample_training_rays_dev");
+}
+int nerf_amd_philox_uniforms(float* out, int64_t N, int K, uint64_t rng_seed, const uint64_t* seed_dev, void* stream) {
+    if (N < 0 || K < 0) return fail(NERF_AMD_EINVAL, "negative size");
+    if (N * K && !out) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_philox_uniforms(out, N, K, rng_seed, seed_dev, S(stream)), "nerf_amd_philox_uniforms");
+}
+int nerf_amd_advance_seed(uint64_t* seed_dev, void* stream) {
+    if (!seed_dev) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_advance_seed(seed_dev, S(stream)), "nerf_amd_advance_seed");
 }
 
 int nerf_amd_stratified_points(const float* rays, const float* z_base, const float* u, float z_jitter, int64_t N, int Sn,
@@ -477,13 +497,14 @@ int nerf_amd_ref_backward(const void* packed_bwd, int precision, int ref_flags, 
 }
 
 int nerf_amd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                       int n_tensors, float* step, double lr, double beta1, double beta2, double eps, float grad_scale, void* stream) {
+                       int n_tensors, float* step, double lr, const double* lr_dev, double beta1, double beta2, double eps, float grad_scale,
+                       void* stream) {
     if (n_tensors < 0 || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) || !step) return fail(NERF_AMD_EINVAL, "NULL argument");
     for (int i = 0; i < n_tensors; ++i)
         if (numel[i] < 0 || (numel[i] && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))) return fail(NERF_AMD_EINVAL, "NULL tensor");
     static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-    return hip_status(bwd_launch_adam(params, grads, exp_avg, exp_avg_sq, reinterpret_cast<const long long*>(numel), n_tensors, step, lr, beta1,
-                                      beta2, eps, grad_scale, S(stream)), "nerf_amd_adam_step");
+    return hip_status(bwd_launch_adam(params, grads, exp_avg, exp_avg_sq, reinterpret_cast<const long long*>(numel), n_tensors, step, lr, lr_dev,
+                                      beta1, beta2, eps, grad_scale, S(stream)), "nerf_amd_adam_step");
 }
 
 // ---- backward of the sampling / compositing rows ----

@@ -152,10 +152,18 @@ __global__ void stratified_points_kernel(const float* __restrict__ rays, const f
 // stream 'TS' (utils.py:87-89) and the sample positions o + d z (utils.py:90).  The reference draws both on the CPU generator and
 // copies them to the device every iteration (train.py:153-157).  One workgroup = 4 rays x C samples.
 constexpr uint32_t PHILOX_STREAM_INDEX = 0x4958u, PHILOX_STREAM_TRAIN = 0x5453u;
+// `pose_dev` / `seed_dev` (both optional): the camera pose and the seed read from DEVICE memory instead of the launch arguments, so that
+// a captured hipGraph of the training step sees a new image pose and fresh random numbers on every replay.
 __global__ __launch_bounds__(256) void train_sampler_kernel(const float* __restrict__ rgbs, const int64_t* __restrict__ coords, int64_t P, Cam cam,
                                                             float near, float res, int64_t N, int C, uint64_t seed, float* __restrict__ pts,
-                                                            float* __restrict__ lengths, float* __restrict__ rgb, float* __restrict__ rays) {
+                                                            float* __restrict__ lengths, float* __restrict__ rgb, float* __restrict__ rays,
+                                                            const float* __restrict__ pose_dev, const uint64_t* __restrict__ seed_dev) {
     __shared__ float ray_s[4][6];
+    if (pose_dev != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cam.pose[i] = pose_dev[i];
+    }
+    if (seed_dev != nullptr) seed = seed_dev[0];
     for (int64_t n0 = blockIdx.x * (int64_t)4; n0 < N; n0 += (int64_t)gridDim.x * 4) {
         __syncthreads();
         if (threadIdx.x < 4 && n0 + threadIdx.x < N) {
@@ -1156,13 +1164,41 @@ int sk_dirs_norm(const float* rays, int64_t N, float* out, hipStream_t st) {
     hipLaunchKernelGGL(dirs_norm_kernel, dim3(1), dim3(1024), 0, st, rays, N, out);
     return (int)hipGetLastError();
 }
-int sk_train_sampler(const float* rgbs, const int64_t* coords, int64_t P, const float* pose, float fx, float fy, float near, float far, int64_t N, int C,
-                     uint64_t seed, float* pts, float* lengths, float* rgb, float* rays, hipStream_t st) {
+int sk_train_sampler(const float* rgbs, const int64_t* coords, int64_t P, const float* pose, const float* pose_dev, float fx, float fy, float near, float far,
+                     int64_t N, int C, uint64_t seed, const uint64_t* seed_dev, float* pts, float* lengths, float* rgb, float* rays, hipStream_t st) {
     if (N == 0) return 0;
     Cam c; c.H = 0; c.W = 0; c.fx = fx; c.fy = fy;
-    for (int i = 0; i < 12; ++i) c.pose[i] = pose[i];
+    for (int i = 0; i < 12; ++i) c.pose[i] = pose ? pose[i] : 0.0f;
     hipLaunchKernelGGL(train_sampler_kernel, dim3(blocks_for(N, 4)), dim3(256), 0, st, rgbs, coords, P, c, near, C > 0 ? (far - near) / (float)C : 0.0f, N, C, seed,
-                       pts, lengths, rgb, rays);
+                       pts, lengths, rgb, rays, pose_dev, seed_dev);
+    return (int)hipGetLastError();
+}
+
+// Philox uniforms as a tensor, u (N,K) = the inverse-CDF stream of device_common.h (philox_u_inv) -- for callers that keep the
+// reference's op-by-op structure (inverseSample(weights, depths, u)) but want the draw on the device and, with `seed_dev`, replayable
+// from a captured graph.  One thread per element.
+__global__ void philox_uniforms_kernel(float* __restrict__ out, int64_t N, int K, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed = seed_dev[0];
+    const int64_t total = N * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / K;
+        out[i] = philox_u_inv(seed, n, (int)(i - n * K));
+    }
+}
+// seed <- a new, unrelated key for the next step (golden-ratio increment + a xorshift-multiply mix); one thread
+__global__ void advance_seed_kernel(uint64_t* __restrict__ seed_dev) {
+    uint64_t x = seed_dev[0] + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    seed_dev[0] = x ^ (x >> 31);
+}
+int sk_philox_uniforms(float* out, int64_t N, int K, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
+    if (N * K == 0) return 0;
+    hipLaunchKernelGGL(philox_uniforms_kernel, dim3(blocks_for(N * K, 256)), dim3(256), 0, st, out, N, K, seed, seed_dev);
+    return (int)hipGetLastError();
+}
+int sk_advance_seed(uint64_t* seed_dev, hipStream_t st) {
+    hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, st, seed_dev);
     return (int)hipGetLastError();
 }
 int sk_generate_rays(const float* pose, int H, int W, float fx, float fy, int64_t first, int64_t count, float* rays,

@@ -306,6 +306,43 @@ def sample_training_rays(rgbs: torch.Tensor, coords: torch.Tensor, pose: torch.T
     return pts, z, rgb, rays
 
 
+def sample_training_rays_dev(rgbs: torch.Tensor, coords: torch.Tensor, pose_dev: torch.Tensor, fx: float, fy: float, near: float, far: float,
+                             n_rays: int, n_points: int, seed_dev: torch.Tensor, want_samples: bool = True):
+    """sample_training_rays with the pose (3,4) fp32 and the seed (1,) int64 read from device memory when the kernel RUNS: the launch is
+    replayable from a captured hipGraph with new images / fresh random numbers (nerf_amd/training.py)."""
+    rgbs = _dev(rgbs, "rgbs")
+    pose_dev = _dev(pose_dev, "pose_dev")
+    if not (coords.is_cuda and coords.dtype == torch.int64 and coords.is_contiguous()):
+        raise RuntimeError("nerf_amd: 'coords' must be a contiguous int64 tensor on the HIP device")
+    if not (seed_dev.is_cuda and seed_dev.dtype == torch.int64 and seed_dev.numel() == 1) or pose_dev.numel() < 12:
+        raise RuntimeError("nerf_amd: seed_dev = one int64 on the device, pose_dev = (3,4) fp32 on the device")
+    dev = rgbs.device
+    pts = torch.empty((n_rays, n_points, 3), dtype=torch.float32, device=dev) if want_samples else None
+    z = torch.empty((n_rays, n_points), dtype=torch.float32, device=dev) if want_samples else None
+    rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    rays = torch.empty((n_rays, 6), dtype=torch.float32, device=dev)
+    check(lib.nerf_amd_sample_training_rays_dev(_ptr(rgbs), _ptr(coords), coords.shape[0], _ptr(pose_dev), float(fx), float(fy), float(near), float(far),
+                                                n_rays, n_points, _ptr(seed_dev), _ptr(pts), _ptr(z), _ptr(rgb), _ptr(rays), _stream()),
+          "nerf_amd_sample_training_rays_dev")
+    return pts, z, rgb, rays
+
+
+def philox_uniforms(shape, seed: int = 0, seed_dev: Optional[torch.Tensor] = None, device=None) -> torch.Tensor:
+    """u (N,K) in [0,1): the kernels' inverse-CDF Philox stream as a tensor (key = seed, or *seed_dev read at run time)."""
+    N, K = int(shape[0]), int(shape[1])
+    dev = seed_dev.device if seed_dev is not None else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    check(lib.nerf_amd_philox_uniforms(_ptr(out), N, K, int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(seed_dev), _stream()), "nerf_amd_philox_uniforms")
+    return out
+
+
+def advance_seed(seed_dev: torch.Tensor) -> None:
+    """*seed_dev <- an unrelated key for the next step (in place, on the current stream)."""
+    if not (seed_dev.is_cuda and seed_dev.dtype == torch.int64 and seed_dev.numel() == 1):
+        raise RuntimeError("nerf_amd: seed_dev = one int64 on the device")
+    check(lib.nerf_amd_advance_seed(_ptr(seed_dev), _stream()), "nerf_amd_advance_seed")
+
+
 def stratified_points(rays: torch.Tensor, z_base: torch.Tensor, u: torch.Tensor, jitter: float, want_pts: bool = True):
     rays, z_base, u = _dev(rays, "rays"), _dev(z_base, "z_base"), _dev(u, "u")
     N, S = u.shape
@@ -643,15 +680,19 @@ def mip_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Te
 
 
 def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp_avg: Sequence[torch.Tensor], exp_avg_sq: Sequence[torch.Tensor],
-              step: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
-    """torch.optim.Adam's update (no weight decay / amsgrad) over all tensors in one launch; `step` = device float, incremented here."""
+              step: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0,
+              lr_dev: Optional[torch.Tensor] = None) -> None:
+    """torch.optim.Adam's update (no weight decay / amsgrad) over all tensors in one launch; `step` = device float, incremented here.
+    `lr_dev` (one float64 on the device) overrides `lr` when the kernel runs: a captured graph then follows a learning-rate schedule."""
+    if lr_dev is not None and not (lr_dev.is_cuda and lr_dev.dtype == torch.float64 and lr_dev.numel() == 1):
+        raise RuntimeError("nerf_amd.adam_step: lr_dev = one float64 on the HIP device")
     n = len(params)
     for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError("nerf_amd.adam_step: tensors must be contiguous fp32 on the HIP device")
     numel = (C.c_int64 * n)(*[p.numel() for p in params])
     check(lib.nerf_amd_adam_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), numel, n, _ptr(step),
-                                 float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), _stream()), "nerf_amd_adam_step")
+                                 float(lr), _ptr(lr_dev), float(beta1), float(beta2), float(eps), float(grad_scale), _stream()), "nerf_amd_adam_step")
 
 
 # ------------------------------------------------------------------------------------------------ Ref-NeRF training / density gradients

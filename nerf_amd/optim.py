@@ -4,8 +4,9 @@ nerf_base.DecayLrScheduler rewrites ``param_groups[i]['lr']`` every iteration --
 ``'optimizer'`` entry written by either implementation loads into the other).
 
 torch's own foreach implementation is ~10 launches per step over the 32 parameter tensors; here the step counter lives on the device,
-so a training step captured in a hipGraph replays correctly (the learning rate is a launch argument: re-capture, or keep it constant,
-when it changes under a captured graph).
+so a training step captured in a hipGraph replays correctly; with ``lr_on_device=True`` the learning rate is read from a device scalar
+as well (``set_lr`` / the next eager ``step()`` refresh it from ``param_groups[i]['lr']``), so a replayed graph follows
+DecayLrScheduler; otherwise it is a launch argument.
 """
 from typing import Iterable, Optional
 
@@ -16,13 +17,23 @@ from . import ops
 
 class Adam(torch.optim.Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 amsgrad: bool = False, grad_scale: float = 1.0):
+                 amsgrad: bool = False, grad_scale: float = 1.0, lr_on_device: bool = False):
         if weight_decay != 0.0 or amsgrad:
             raise NotImplementedError("nerf_amd.optim.Adam: weight_decay / amsgrad are not built (the reference uses neither)")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, maximize=False, foreach=None, capturable=False,
                         differentiable=False, fused=None)
         super().__init__(params, defaults)
         self.grad_scale = float(grad_scale)
+        self.lr_on_device = bool(lr_on_device)
+
+    def sync_lr(self):
+        """Copy every group's host-side 'lr' into its device scalar (lr_on_device): call it before replaying a captured step whenever a
+        scheduler has rewritten param_groups[i]['lr'] (one tiny async fill per group, only when the value changed)."""
+        for group in self.param_groups:
+            dev_lr = group.get("_lr_dev")
+            if dev_lr is not None and group.get("_lr_host") != group["lr"]:
+                dev_lr.fill_(float(group["lr"]))
+                group["_lr_host"] = group["lr"]
 
     def _group_state(self, group):
         params = [p for p in group["params"] if p.grad is not None]
@@ -57,8 +68,16 @@ class Adam(torch.optim.Optimizer):
             params, step = gs
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
             b1, b2 = group["betas"]
+            lr_dev = None
+            if self.lr_on_device:
+                if group.get("_lr_dev") is None:
+                    group["_lr_dev"] = torch.full((1,), float(group["lr"]), dtype=torch.float64, device=params[0].device)
+                    group["_lr_host"] = group["lr"]
+                elif not torch.cuda.is_current_stream_capturing():
+                    self.sync_lr()
+                lr_dev = group["_lr_dev"]
             ops.adam_step([p.data for p in params], grads, [self.state[p]["exp_avg"] for p in params],
-                          [self.state[p]["exp_avg_sq"] for p in params], step, group["lr"], b1, b2, group["eps"], self.grad_scale)
+                          [self.state[p]["exp_avg_sq"] for p in params], step, group["lr"], b1, b2, group["eps"], self.grad_scale, lr_dev=lr_dev)
             # the kernel wrote the parameters through raw pointers: bump their version counters, which the packed-weight caches
             # (nerf_amd/_packed.py) and autograd's saved-tensor checks are keyed on
             torch._C._autograd._unsafe_set_version_counter(tuple(params), tuple(p._version + 1 for p in params))
@@ -69,7 +88,8 @@ class Adam(torch.optim.Optimizer):
         counter between all tensors; written out as-is, torch's foreach step would increment that shared tensor once per parameter)."""
         sd = super().state_dict()
         for g in sd["param_groups"]:
-            g.pop("_step_dev", None)
+            for k in ("_step_dev", "_lr_dev", "_lr_host"):
+                g.pop(k, None)
         sd["state"] = {k: dict(v) for k, v in sd["state"].items()}
         for st in sd["state"].values():
             if "step" in st:
@@ -79,4 +99,5 @@ class Adam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         for g in self.param_groups:
-            g.pop("_step_dev", None)
+            for k in ("_step_dev", "_lr_dev", "_lr_host"):
+                g.pop(k, None)

@@ -1,0 +1,104 @@
+"""The reference's training iteration (train.py:151-218, MipNeRF branch of ``run()``) as ONE device-resident step.
+
+The reference draws the pixel indices, the depth jitter and the inverse-CDF uniforms on the CPU generator and copies them to the device
+every iteration (utils.py:76,89,115), reads the camera pose on the host and rewrites the optimizer's learning rate from Python.  At its
+batch size (512-1024 rays) the iteration is launch- and copy-bound, not compute-bound.  Here the training image's pixel table, the camera
+pose, the random-number seed, the Adam step count and the learning rate all live in DEVICE memory and every random number is drawn in
+kernels (Philox4x32-10), so the iteration never synchronises with the host -- and can therefore be captured once in a hipGraph and
+replayed: 0.9 ms instead of 1.7 ms per 512-ray step on one MI355X (bench.py ``train_step.rays_512_hipgraph``).
+
+    step = TrainStep(prop_net, mip_net, optimizer, image_hw=(800, 800), focal=f, near=2., far=6., ray_num=512)
+    step.capture()                                   # optional: hipGraph replay from now on
+    for img, pose in loader:                         # img (3,H,W), pose (3,4): device tensors (nerf_amd.dataset keeps the scene in HBM)
+        lr_sch.update_opt_lr(cnt, optimizer)         # DecayLrScheduler as in train.py:218 -- picked up through the device-side lr
+        loss, img_loss = step(img, pose)             # device scalars; read them (``.item()``) only when logging
+
+Semantics are those of train.py:164-199 with ``prop_normal`` off: proposal forward -> softplus -> get_weights -> maxBlurFilter ->
+inverseSample(sort) -> MipNeRF forward -> render -> getBounds -> ProposalLoss + MSE -> backward -> Adam.  Random streams: the in-kernel
+sampler of ``validSampler(rng="philox")`` and ``ops.philox_uniforms`` for inverseSample's ``u``, both keyed by one device-resident
+seed that ``nerf_amd_advance_seed`` replaces at the end of every step.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .addtional import ProposalLoss, ProposalNetwork, getBounds
+from .mip_methods import maxBlurFilter
+from .nerf_base import NeRF
+from .optim import Adam
+from .utils import _focal_xy, inverseSample, randomFromOneImage
+
+
+class TrainStep:
+    def __init__(self, prop_net, mip_net, optimizer: Adam, image_hw: Tuple[int, int], focal, near: float, far: float, ray_num: int = 512,
+                 coarse_pnum: int = 64, fine_pnum: int = 128, crop_xy=(1.0, 1.0), seed: Optional[int] = None, white_bkg: bool = False):
+        if not isinstance(optimizer, Adam) or not optimizer.lr_on_device:
+            raise ValueError("nerf_amd.training.TrainStep needs nerf_amd.optim.Adam(..., lr_on_device=True): the step must not read host state")
+        self.prop_net, self.mip_net, self.opt = prop_net, mip_net, optimizer
+        self.near, self.far, self.ray_num, self.coarse_pnum, self.fine_pnum = float(near), float(far), int(ray_num), int(coarse_pnum), int(fine_pnum)
+        self.fx, self.fy = _focal_xy(focal)
+        self.white_bkg = bool(white_bkg)
+        dev = next(mip_net.parameters()).device
+        H, W = image_hw
+        self.image = torch.zeros((3, H, W), dtype=torch.float32, device=dev)             # static inputs of the (captured) step
+        self.pose = torch.zeros((3, 4), dtype=torch.float32, device=dev)
+        self.crop_xy = tuple(crop_xy)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                            # torch.manual_seed governs the whole run
+        self.seed = torch.full((1,), seed, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.img_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.prop_loss_fn = ProposalLoss()
+        self.graph = None
+
+    # ---------------------------------------------------------------------------------------------------------------- the iteration
+    def _body(self):
+        pixels, coords = randomFromOneImage(self.image, self.crop_xy)                     # pure indexing on the device (cached table)
+        pts, z_c, rgb_tgt, rays = ops.sample_training_rays_dev(pixels, coords, self.pose, self.fx, self.fy, self.near, self.far, self.ray_num,
+                                                               self.coarse_pnum, self.seed)            # train.py:160-162
+        dirs = rays[:, 3:]
+        density = F.softplus(self.prop_net.forward(pts))                                                # train.py:165-169
+        prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z_c, dirs), 0.01)                   # :170-171
+        u = ops.philox_uniforms((self.ray_num, self.fine_pnum + 1), seed_dev=self.seed)
+        z_f, below = inverseSample(prop_w, z_c, self.fine_pnum + 1, sort=True, u=u)                     # :174
+        z_f = z_f[..., :-1].contiguous()                                                                # :188
+        rgbo = self.mip_net.forward(NeRF.length2pts(rays, z_f))                                         # :189-190
+        rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, white_bkg=self.white_bkg)                   # :191
+        bounds = getBounds(prop_w, below)                                                               # :192
+        self.opt.zero_grad(set_to_none=True)
+        img_loss = torch.mean((rendered - rgb_tgt) ** 2)                                                # :194 (nn.MSELoss)
+        loss = self.prop_loss_fn(bounds, weights.detach()) + img_loss                                   # :196-197
+        loss.backward()
+        self.opt.step()
+        ops.advance_seed(self.seed)
+        self.loss.copy_(loss.detach())
+        self.img_loss.copy_(img_loss.detach())
+
+    # ---------------------------------------------------------------------------------------------------------------- driving it
+    def set_image(self, img: torch.Tensor, pose: torch.Tensor) -> None:
+        """img (3,H,W) / (1,3,H,W), pose (3,4) / (1,3,4) -- device tensors; asynchronous device-to-device copies into the step's inputs"""
+        self.image.copy_(img.reshape(self.image.shape), non_blocking=True)
+        self.pose.copy_(pose.reshape(-1)[:12].reshape(3, 4), non_blocking=True)
+
+    def capture(self, warmup: int = 2) -> None:
+        """Run `warmup` eager iterations on the current image (lazy kernel attributes, optimizer state, allocator pools), then record
+        the iteration into a hipGraph.  The warm-up iterations are real training steps."""
+        self.prop_net.train(); self.mip_net.train()
+        for _ in range(max(1, warmup)):
+            self._body()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()                                                                  # (recorded, not executed)
+
+    def __call__(self, img: Optional[torch.Tensor] = None, pose: Optional[torch.Tensor] = None):
+        if img is not None:
+            self.set_image(img, pose)
+        if self.graph is not None:
+            self.opt.sync_lr()                                                            # a scheduler may have rewritten param_groups' lr
+            self.graph.replay()
+        else:
+            self._body()
+        return self.loss, self.img_loss

@@ -338,3 +338,64 @@ def test_refnerf_training_step_captured_in_a_hipgraph():
         torch.normal = real_normal
     for a, b in zip(list(net_g.parameters()) + list(prop_g.parameters()), list(net_e.parameters()) + list(prop_e.parameters())):
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_device_resident_train_step_eager_and_replayed():
+    """nerf_amd.training.TrainStep = the iteration of train.py:151-218 with pose, pixel table, seed, Adam step count and learning rate in
+    device memory.  (i) Replaying the captured hipGraph reproduces the eager iterations from the same state -- through a change of image /
+    pose AND a change of the learning rate between iterations, which a graph with baked launch arguments would miss; (ii) every iteration
+    draws new random numbers (the device seed advances, the losses differ); (iii) it learns (the loss on a fixed image falls)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import nerf_oracle as O                                      # (test infrastructure: poses / focal only)
+    import nerf_amd
+    from nerf_amd.optim import Adam
+    from nerf_amd.training import TrainStep
+    nerf_amd.set_precision("fp32")
+    gen = torch.Generator().manual_seed(3)
+    imgs = [torch.rand(3, 40, 40, generator=gen).cuda() for _ in range(2)]
+    poses = [O.pose_spherical(a, -30.0, 4.0)[:3].contiguous().cuda() for a in (20.0, 140.0)]
+    focal = O.fov2focal(0.6911112070083618, (40, 40))
+    lrs = [1e-3, 1e-3, 1e-3, 4e-4, 4e-4, 2e-4]                              # "scheduler": rewritten on the host between iterations
+
+    def run(graphed):
+        prop, mip = _nets()
+        prop.train(); mip.train()
+        opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=lrs[0], lr_on_device=True)
+        step = TrainStep(prop, mip, opt, (40, 40), focal, NEAR, FAR, ray_num=96, coarse_pnum=32, fine_pnum=64, seed=1234)
+        step.set_image(imgs[0], poses[0])
+        losses, seeds = [], []
+        if graphed:
+            step.capture(warmup=2)                                           # iterations 0, 1 eager, then recorded
+            losses += [None, None]
+        for it in range(2 if graphed else 0, len(lrs)):
+            for gr in opt.param_groups:
+                gr["lr"] = lrs[it]
+            loss, _ = step(imgs[it % 2], poses[it % 2]) if it >= 3 else step()
+            losses.append(float(loss.item()))
+            seeds.append(int(step.seed.item()))
+        return prop, mip, losses, seeds
+
+    prop_e, mip_e, loss_e, seed_e = run(False)
+    prop_g, mip_g, loss_g, seed_g = run(True)
+    for a, b in zip(list(mip_g.parameters()) + list(prop_g.parameters()), list(mip_e.parameters()) + list(prop_e.parameters())):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert seed_e[-1] == seed_g[-1] and len(set(seed_e)) == len(seed_e)       # the seed advanced every iteration, identically on both paths
+    for a, b in zip(loss_e[2:], loss_g[2:]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+    assert len(set(round(v, 9) for v in loss_e)) == len(loss_e)              # new rays / uniforms every iteration
+    # (iii) a longer eager run on one image: the training loss falls
+    prop, mip = _nets()
+    prop.train(); mip.train()
+    opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-3, lr_on_device=True)
+    step = TrainStep(prop, mip, opt, (40, 40), focal, NEAR, FAR, ray_num=256, coarse_pnum=32, fine_pnum=64, seed=7)
+    step.set_image(imgs[0] * 0.0 + 0.6, poses[0])                            # a constant-colour image: learnable in a few dozen iterations
+    step.capture(warmup=2)
+    first = sum(float(step()[1].item()) for _ in range(5)) / 5
+    for _ in range(120):
+        step()
+    last = sum(float(step()[1].item()) for _ in range(5)) / 5
+    assert last < 0.5 * first, (first, last)
