@@ -13,8 +13,10 @@ replayed: 0.9 ms instead of 1.7 ms per 512-ray step on one MI355X (bench.py ``tr
         lr_sch.update_opt_lr(cnt, optimizer)         # DecayLrScheduler as in train.py:218 -- picked up through the device-side lr
         loss, img_loss = step(img, pose)             # device scalars; read them (``.item()``) only when logging
 
-Semantics are those of train.py:164-199 with ``prop_normal`` off: proposal forward -> softplus -> get_weights -> maxBlurFilter ->
-inverseSample(sort) -> MipNeRF forward -> render -> getBounds -> ProposalLoss + MSE -> backward -> Adam.  Random streams: the in-kernel
+Semantics are those of train.py:164-199: proposal forward -> softplus -> get_weights -> maxBlurFilter -> inverseSample(sort) ->
+MipNeRF forward -> render -> getBounds -> ProposalLoss + MSE -> backward -> Adam; with a RefNeRF as the fine network the
+``is_ref_model`` branch (train.py:176-187: coarse/fine merge, density-gradient normals, normal and back-face losses, and with
+``prop_normal`` the proposal network's normals, train.py:165-168).  Random streams: the in-kernel
 sampler of ``validSampler(rng="philox")`` and ``ops.philox_uniforms`` for inverseSample's ``u``, both keyed by one device-resident
 seed that ``nerf_amd_advance_seed`` replaces at the end of every step.
 """
@@ -33,13 +35,17 @@ from .utils import _focal_xy, inverseSample, randomFromOneImage
 
 class TrainStep:
     def __init__(self, prop_net, mip_net, optimizer: Adam, image_hw: Tuple[int, int], focal, near: float, far: float, ray_num: int = 512,
-                 coarse_pnum: int = 64, fine_pnum: int = 128, crop_xy=(1.0, 1.0), seed: Optional[int] = None, white_bkg: bool = False):
+                 coarse_pnum: int = 64, fine_pnum: int = 128, crop_xy=(1.0, 1.0), seed: Optional[int] = None, white_bkg: bool = False,
+                 prop_normal: bool = False):
         if not isinstance(optimizer, Adam) or not optimizer.lr_on_device:
             raise ValueError("nerf_amd.training.TrainStep needs nerf_amd.optim.Adam(..., lr_on_device=True): the step must not read host state")
         self.prop_net, self.mip_net, self.opt = prop_net, mip_net, optimizer
         self.near, self.far, self.ray_num, self.coarse_pnum, self.fine_pnum = float(near), float(far), int(ray_num), int(coarse_pnum), int(fine_pnum)
         self.fx, self.fy = _focal_xy(focal)
         self.white_bkg = bool(white_bkg)
+        from .ref_model import RefNeRF
+        self.is_ref = isinstance(mip_net, RefNeRF)
+        self.prop_normal = bool(prop_normal) and self.is_ref                              # (train.py: prop_normal only acts with a Ref-NeRF)
         dev = next(mip_net.parameters()).device
         H, W = image_hw
         self.image = torch.zeros((3, H, W), dtype=torch.float32, device=dev)             # static inputs of the (captured) step
@@ -59,17 +65,38 @@ class TrainStep:
         pts, z_c, rgb_tgt, rays = ops.sample_training_rays_dev(pixels, coords, self.pose, self.fx, self.fy, self.near, self.far, self.ray_num,
                                                                self.coarse_pnum, self.seed)            # train.py:160-162
         dirs = rays[:, 3:]
-        density = F.softplus(self.prop_net.forward(pts))                                                # train.py:165-169
+        if self.prop_normal:
+            pts.requires_grad_(True)                                                                    # train.py:165
+        density = self.prop_net.forward(pts)
+        if self.prop_normal:
+            from .ref_model import RefNeRF
+            coarse_grad = -RefNeRF.get_grad(density, pts)                                               # :167-168
+        density = F.softplus(density)                                                                   # :169
         prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z_c, dirs), 0.01)                   # :170-171
         u = ops.philox_uniforms((self.ray_num, self.fine_pnum + 1), seed_dev=self.seed)
         z_f, below = inverseSample(prop_w, z_c, self.fine_pnum + 1, sort=True, u=u)                     # :174
-        z_f = z_f[..., :-1].contiguous()                                                                # :188
-        rgbo = self.mip_net.forward(NeRF.length2pts(rays, z_f))                                         # :189-190
-        rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, white_bkg=self.white_bkg)                   # :191
+        extra = 0.0
+        if self.is_ref:                                                                                 # :175-187
+            from .ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
+            samples, z_f, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, z_f, below)
+            pos, fine_dir = samples.split((3, 3), dim=-1)
+            pos, fine_dir = pos.contiguous().requires_grad_(True), fine_dir.contiguous()
+            rgbo, pred_normal = self.mip_net.forward(pos, fine_dir)
+            density_grad = -RefNeRF.get_grad(rgbo[..., -1], pos)
+            rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
+            rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, density_act=self.mip_net.density_act, white_bkg=self.white_bkg)
+            extra = 4e-4 * WeightedNormalLoss()(weights, density_grad, pred_normal) + 0.1 * BackFaceLoss()(weights, pred_normal, fine_dir)
+            if self.prop_normal:
+                picked = RefNeRF.coarse_grad_select(density_grad, sort_ids, self.coarse_pnum)
+                extra = extra + 4e-5 * WeightedNormalLoss()(prop_w, picked.detach(), coarse_grad)       # 4e-4 * 0.1 (:198)
+        else:
+            z_f = z_f[..., :-1].contiguous()                                                            # :188
+            rgbo = self.mip_net.forward(NeRF.length2pts(rays, z_f))                                     # :189-190
+            rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, white_bkg=self.white_bkg)               # :191
         bounds = getBounds(prop_w, below)                                                               # :192
         self.opt.zero_grad(set_to_none=True)
         img_loss = torch.mean((rendered - rgb_tgt) ** 2)                                                # :194 (nn.MSELoss)
-        loss = self.prop_loss_fn(bounds, weights.detach()) + img_loss                                   # :196-197
+        loss = self.prop_loss_fn(bounds, weights.detach()) + img_loss + extra                           # :196-198
         loss.backward()
         self.opt.step()
         ops.advance_seed(self.seed)

@@ -399,3 +399,62 @@ def test_device_resident_train_step_eager_and_replayed():
         step()
     last = sum(float(step()[1].item()) for _ in range(5)) / 5
     assert last < 0.5 * first, (first, last)
+
+
+@pytest.mark.gpu
+def test_device_resident_train_step_refnerf_branch():
+    """TrainStep with a RefNeRF fine network and prop_normal (train.py:165-168,176-187): hipGraph replays == eager iterations from the same
+    state (the bottle-neck noise pinned to one tensor per shape so that both paths see the same draw), and the step trains (loss falls)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import weights as W
+    from oracle import nerf_oracle as O
+    import nerf_amd
+    from nerf_amd.optim import Adam
+    from nerf_amd.ref_model import RefNeRF
+    from nerf_amd.training import TrainStep
+    nerf_amd.set_precision("fp32")
+    gen = torch.Generator().manual_seed(5)
+    img = (torch.rand(3, 40, 40, generator=gen) * 0.2 + 0.4).cuda()
+    pose = O.pose_spherical(20.0, -30.0, 4.0)[:3].contiguous().cuda()
+    focal = O.fov2focal(0.6911112070083618, (40, 40))
+    real_normal, noise = torch.normal, {}
+
+    def fixed_normal(mean, std, size, **kw):
+        if tuple(size) not in noise:
+            noise[tuple(size)] = (torch.randn(tuple(size), generator=torch.Generator().manual_seed(8)) * std).cuda()
+        return noise[tuple(size)]
+
+    def run(graphed, iters):
+        prop, _ = _nets()
+        net = RefNeRF(10, 4)
+        net.load_state_dict(W.ref_state("small"))
+        prop, net = prop.train(), net.cuda().train()
+        opt = Adam(list(net.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+        step = TrainStep(prop, net, opt, (40, 40), focal, NEAR, FAR, ray_num=64, coarse_pnum=32, fine_pnum=32, seed=99, prop_normal=True)
+        assert step.is_ref and step.prop_normal
+        step.set_image(img, pose)
+        if graphed:
+            step.capture(warmup=2)
+        losses = [float(step()[1].item()) for _ in range(iters - (2 if graphed else 0))]
+        return prop, net, losses, int(step.seed.item())
+
+    torch.normal = fixed_normal
+    try:
+        prop_e, net_e, loss_e, seed_e = run(False, 6)
+        prop_g, net_g, loss_g, seed_g = run(True, 6)
+    finally:
+        torch.normal = real_normal
+    assert seed_e == seed_g
+    for a, b in zip(list(net_g.parameters()) + list(prop_g.parameters()), list(net_e.parameters()) + list(prop_e.parameters())):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    for a, b in zip(loss_e[2:], loss_g):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
+    torch.normal = fixed_normal
+    try:
+        _, _, long_losses, _ = run(True, 150)
+    finally:
+        torch.normal = real_normal
+    assert sum(long_losses[-10:]) < 0.6 * sum(long_losses[:10]), (long_losses[:10], long_losses[-10:])
