@@ -36,7 +36,9 @@ from .utils import _focal_xy, inverseSample, randomFromOneImage
 class TrainStep:
     def __init__(self, prop_net, mip_net, optimizer: Adam, image_hw: Tuple[int, int], focal, near: float, far: float, ray_num: int = 512,
                  coarse_pnum: int = 64, fine_pnum: int = 128, crop_xy=(1.0, 1.0), seed: Optional[int] = None, white_bkg: bool = False,
-                 prop_normal: bool = False):
+                 prop_normal: bool = False, grad_hook=None):
+        """``grad_hook``: called between ``loss.backward()`` and ``optimizer.step()`` -- the place of ddp_train.py's gradient all-reduce
+        (``lambda: parallel.allreduce_gradients([mip_net, prop_net])``).  An iteration with a hook runs eagerly (``capture`` refuses)."""
         if not isinstance(optimizer, Adam) or not optimizer.lr_on_device:
             raise ValueError("nerf_amd.training.TrainStep needs nerf_amd.optim.Adam(..., lr_on_device=True): the step must not read host state")
         self.prop_net, self.mip_net, self.opt = prop_net, mip_net, optimizer
@@ -57,6 +59,7 @@ class TrainStep:
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.img_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.prop_loss_fn = ProposalLoss()
+        self.grad_hook = grad_hook
         self.graph = None
 
     # ---------------------------------------------------------------------------------------------------------------- the iteration
@@ -98,6 +101,8 @@ class TrainStep:
         img_loss = torch.mean((rendered - rgb_tgt) ** 2)                                                # :194 (nn.MSELoss)
         loss = self.prop_loss_fn(bounds, weights.detach()) + img_loss + extra                           # :196-198
         loss.backward()
+        if self.grad_hook is not None:
+            self.grad_hook()
         self.opt.step()
         ops.advance_seed(self.seed)
         self.loss.copy_(loss.detach())
@@ -112,6 +117,8 @@ class TrainStep:
     def capture(self, warmup: int = 2) -> None:
         """Run `warmup` eager iterations on the current image (lazy kernel attributes, optimizer state, allocator pools), then record
         the iteration into a hipGraph.  The warm-up iterations are real training steps."""
+        if self.grad_hook is not None:
+            raise RuntimeError("nerf_amd.training.TrainStep: an iteration with a grad_hook (collective) is not captured; run it eagerly")
         self.prop_net.train(); self.mip_net.train()
         for _ in range(max(1, warmup)):
             self._body()

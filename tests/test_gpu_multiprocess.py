@@ -392,6 +392,13 @@ def test_device_resident_train_step_eager_and_replayed():
     prop.train(); mip.train()
     opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-3, lr_on_device=True)
     step = TrainStep(prop, mip, opt, (40, 40), focal, NEAR, FAR, ray_num=256, coarse_pnum=32, fine_pnum=64, seed=7)
+    calls = []
+    hooked = TrainStep(prop, mip, opt, (40, 40), focal, NEAR, FAR, ray_num=32, coarse_pnum=32, fine_pnum=32, seed=1, grad_hook=lambda: calls.append(1))
+    hooked.set_image(imgs[0], poses[0])
+    hooked(); hooked()
+    assert len(calls) == 2                                                   # the gradient hook (ddp_train.py's all-reduce slot) runs once per iteration
+    with pytest.raises(RuntimeError):
+        hooked.capture()
     step.set_image(imgs[0] * 0.0 + 0.6, poses[0])                            # a constant-colour image: learnable in a few dozen iterations
     step.capture(warmup=2)
     first = sum(float(step()[1].item()) for _ in range(5)) / 5
