@@ -554,7 +554,7 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     if (N == 0) return NERF_AMD_OK;
     if (!packed_prop || !packed_mip || !z_base || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
     if ((u_strat == nullptr) != (u_inv == nullptr)) return fail(NERF_AMD_EINVAL, "u_strat and u_inv are both given or both NULL (in-kernel uniforms)");
-    if (!u_strat && (!camera || n_fine > 255)) return fail(NERF_AMD_EINVAL, "in-kernel uniforms need the descriptor (rng_seed, rng_ray_offset) and n_fine <= 255");
+    if (!u_strat && !camera) return fail(NERF_AMD_EINVAL, "in-kernel uniforms need the descriptor (rng_seed, rng_ray_offset)");
     if (!rays && !camera) return fail(NERF_AMD_EINVAL, "need rays or camera");
     const uint64_t seed = camera ? camera->rng_seed : 0;
     const int64_t ray0 = camera ? camera->rng_ray_offset : 0;
@@ -623,8 +623,12 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
     if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
     if (N == 0) return NERF_AMD_OK;
-    if (!packed_prop || !packed_ref || !z_base || !u_strat || !u_inv || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (!packed_prop || !packed_ref || !z_base || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if ((u_strat == nullptr) != (u_inv == nullptr)) return fail(NERF_AMD_EINVAL, "u_strat and u_inv are both given or both NULL (in-kernel uniforms)");
+    if (!u_strat && !camera) return fail(NERF_AMD_EINVAL, "in-kernel uniforms need the descriptor (rng_seed, rng_ray_offset)");
     if (!rays && !camera) return fail(NERF_AMD_EINVAL, "need rays or camera");
+    const uint64_t seed = camera ? camera->rng_seed : 0;
+    const int64_t ray0 = camera ? camera->rng_ray_offset : 0;
     if ((normal_img != nullptr) != (cam_dir != nullptr)) return fail(NERF_AMD_EINVAL, "normal_img and cam_dir go together");
     if (camera && camera->contract) return fail(NERF_AMD_EINVAL, "scene contraction is wired for the MipNeRF path only");
     constexpr int C = 64;                                   // procedures.py:22 RENDER_COARSE_PNUM
@@ -650,9 +654,10 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     nerf_amd_samples sc{};                                  // rows 2-4
     sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
     sc.z_jitter = jitter; sc.z_stride = C;
+    sc.rng_seed = seed; sc.rng_ray_offset = ray0;          // (read only when u_strat == NULL)
     if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7 (procedures.py:68-70), also returning the stratified depths the proposal pass used
-    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, 0, 0, z_fine,
+    if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, seed, ray0, z_fine,
                             nullptr, nullptr, z_coarse, st)) return hip_status(e, "resample");
     // row 8, Ref-NeRF branch (procedures.py:71-74): fine and coarse depths merged, the last one dropped
     if (int e = sk_merge_sorted(z_fine, z_coarse, N, n_fine + 1, C, z_all, st)) return hip_status(e, "depth merge");

@@ -468,11 +468,22 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
 
 def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                     want_depth=True, cam_dir: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                    camera: Optional[Samples] = None, ray_offset: int = 0, n_rays: Optional[int] = None, flags: int = 0):
+                    camera: Optional[Samples] = None, ray_offset: int = 0, n_rays: Optional[int] = None, flags: int = 0,
+                    seed: Optional[int] = None, rng_ray_offset: int = 0):
     """The tile body of render_image for a Ref-NeRF fine network (procedures.py:64-85, is_ref_model branch) in six launches.
-    `cam_dir` (3,) = render_pose[:, -2] asks for the normal image (procedures.py:79-81)."""
-    dev = u_strat.device
-    N = u_strat.shape[0] if n_rays is None else n_rays
+    `cam_dir` (3,) = render_pose[:, -2] asks for the normal image (procedures.py:79-81).  u_strat = u_inv = None with `seed`: in-kernel
+    uniforms as in render_rays."""
+    in_kernel_rng = u_strat is None
+    if in_kernel_rng:
+        if u_inv is not None or seed is None:
+            raise ValueError("nerf_amd: u_strat and u_inv are both tensors, or both None with a `seed`")
+        dev = rays.device if rays is not None else z_base.device
+        if camera is None:
+            camera = Samples()
+        camera.rng_seed, camera.rng_ray_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_ray_offset)
+    else:
+        dev = u_strat.device
+    N = n_rays if n_rays is not None else (rays.shape[0] if in_kernel_rng else u_strat.shape[0])
     need = lib.nerf_amd_render_ref_workspace_bytes(N, n_fine)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -81,11 +81,11 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         pr, pc = patch_num
         rays = rays.view(H, W, 6)[: pr * sz].reshape(pr, sz, pc, sz, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
     seed = None
-    if rng == "philox" and sample_num <= 255 and not is_ref_model:
+    if rng == "philox":
         u_strat = u_inv = None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())                         # one draw from the CPU generator: torch.manual_seed governs it
     else:
-        u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, "device" if rng == "philox" else rng)
+        u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
     z_base = torch.linspace(near, far, RENDER_COARSE_PNUM, device="cpu").to(dev)   # procedures.py:52 (CPU linspace bits)
     normal_px = None
     ipe_radius = None
@@ -105,7 +105,8 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         # ascending sets).
         rgb, depth, normal_px, _ = ops.render_rays_ref(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
                                                        sample_num, near, far, white_bkg, want_depth=bool(render_depth),
-                                                       cam_dir=render_pose[:, -2].contiguous() if render_normal else None, flags=network.kernel_flags)
+                                                       cam_dir=render_pose[:, -2].contiguous() if render_normal else None, flags=network.kernel_flags,
+                                                       seed=seed)
 
     def to_image(t, ch):
         if sz is None:

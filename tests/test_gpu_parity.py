@@ -1545,6 +1545,26 @@ def test_philox_render_equals_render_with_the_same_uniforms_as_tensors(A):
     assert torch.equal(za[0], zb[0]) and torch.equal(za[1], zb[1])
 
 
+def test_philox_render_refnerf_and_many_fine_samples(A):
+    """In-kernel uniforms on the Ref-NeRF render entry (nerf_amd_render_rays_ref with NULL uniform tensors) and beyond 256 inverse-CDF
+    draws per ray (blocks 64.. of the counter layout): both equal the tensor-fed render of oracle.philox_uniforms' values bit for bit."""
+    prop, mip = build_nets(A, "small")
+    net = build_ref(A, "small")
+    rays, _, _ = _rays_and_u(260, 64, 23)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    seed, off = 0x1234ABCD5678, 1000
+    u1, u2 = O.philox_uniforms(seed, 260, off, 64, 65)
+    a = A.ops.render_rays_ref(prop.packed(A.ops.F32), net.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, None, None, 64, NEAR, FAR, True,
+                              seed=seed, rng_ray_offset=off)
+    b = A.ops.render_rays_ref(prop.packed(A.ops.F32), net.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 64, NEAR, FAR, True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    u1, u2 = O.philox_uniforms(seed, 260, off, 64, 401)                      # n_fine = 400: u_inv blocks 0..2 of every ray
+    a = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, None, None, 400, NEAR, FAR, True,
+                          seed=seed, rng_ray_offset=off)
+    b = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 400, NEAR, FAR, True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_philox_uniforms_are_uniform():
     """Statistical sanity of the in-kernel stream (through its oracle twin, bit-equal to the kernels by the test above): one-sample
     Kolmogorov-Smirnov against U[0,1) on 1.2e6 draws of each stream, lag-1 / cross-stream correlations, and the 24-bit lattice."""
