@@ -46,6 +46,31 @@ DEVINL float sin_quadrant(float a, int quad) {
     return (n & 2) ? -v : v;
 }
 
+// sin(a) and cos(a) from ONE range reduction: bit-identical to sin_quadrant(a, 0) / sin_quadrant(a, 1)
+DEVINL void sincos_quadrant(float a, float& sn, float& cs) {
+    const float k = __builtin_rintf(a * 0.6366197466850281f);
+    float r = __builtin_fmaf(-k, 1.57079637050628662109375f, a);
+    r = __builtin_fmaf(-k, -4.371138828673793e-08f, r);
+    r = __builtin_fmaf(-k, -1.7151245100058819e-15f, r);
+    const int n = (int)k;
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, 1.5896910177e-10f, -2.5050759689e-08f);
+    ps = __builtin_fmaf(z, ps, 2.7557314297e-06f);
+    ps = __builtin_fmaf(z, ps, -1.9841270114e-04f);
+    ps = __builtin_fmaf(z, ps, 8.3333337680e-03f);
+    ps = __builtin_fmaf(z, ps, -1.6666667163e-01f);
+    const float s = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, -1.1359647598e-11f, 2.0875723372e-09f);
+    pc = __builtin_fmaf(z, pc, -2.7557314297e-07f);
+    pc = __builtin_fmaf(z, pc, 2.4801587642e-05f);
+    pc = __builtin_fmaf(z, pc, -1.3888889225e-03f);
+    pc = __builtin_fmaf(z, pc, 4.1666667908e-02f);
+    const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    const float vs = (n & 1) ? c : s, vc = (n & 1) ? s : c;
+    sn = (n & 2) ? -vs : vs;
+    cs = ((n + 1) & 2) ? -vc : vc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Counter-based uniforms (Philox4x32-10, Salmon et al. 2011 -- the generator behind torch's device RNG, restated from the paper's
 // constants).  When a caller passes no uniform tensors, the kernels draw them as a PURE FUNCTION of (seed, ray, sample).  One Philox
