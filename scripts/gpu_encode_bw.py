@@ -42,3 +42,19 @@ for name, fn, nbytes in (
         ("composite (composite_kernel)", lambda: ops.composite(rgbo, z[:, :S].contiguous(), rays[:, 3:].contiguous(), True, True, ops.ACT_RELU, (2.0, 6.0)), M * 24 + N * 40)):
     t = timed(fn)
     print("%-36s %8.3f ms   %6.2f GB   %6.2f TB/s   (%.2f of 8 TB/s)" % (name, t * 1e3, nbytes / 1e9, nbytes / t / 1e12, nbytes / t / 8e12))
+
+# the other stand-alone rows at the same scale (API-parity entry points; the render path uses the fused forms)
+w64 = torch.rand(N, 64, device=dev, generator=g)
+z64 = torch.sort(2.0 + 4.0 * torch.rand(N, 64, device=dev, generator=g), dim=-1)[0].contiguous()
+sig = torch.randn(N, S, device=dev, generator=g)
+zS = z[:, :S].contiguous()
+u129 = torch.rand(N, 129, device=dev, generator=g)
+below = torch.randint(0, 62, (N, 128), device=dev, generator=g)
+for name, fn, nbytes in (
+        ("length2pts", lambda: ops.length2pts(rays, zS), M * (4 + 24) + N * 24),
+        ("sigma_to_weights", lambda: ops.sigma_to_weights(sig, zS, rays[:, 3:].contiguous(), ops.ACT_RELU), M * 12 + N * 12),
+        ("max_blur", lambda: ops.max_blur(w64, 0.01), N * 64 * 8),
+        ("inverse_sample (64 bins -> 129, sorted)", lambda: ops.inverse_sample(w64, z64, u129, True, want_below=True), N * (64 * 8 + 129 * 4 + 129 * 12)),
+        ("get_bounds", lambda: ops.get_bounds(w64[:, :63].contiguous(), below), N * (63 * 4 + 128 * 8 + 128 * 4))):
+    t = timed(fn)
+    print("%-40s %8.3f ms   %6.2f GB   %6.2f TB/s" % (name, t * 1e3, nbytes / 1e9, nbytes / t / 1e12))
