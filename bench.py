@@ -197,6 +197,15 @@ def train_rate(precision):
     best = out["rays_16384"]["rays_per_s"]
     out["roofline"] = {"bound": "mfma", "kernel": "whole training step, 16384 rays (3 x 162.4 MFLOP/ray)", "achieved": best * 3 * FLOP_PER_RAY / 1e12,
                        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": best * 3 * FLOP_PER_RAY / peak, "traffic": None}
+    # the step is HBM-bound by its dumps: measured traffic of one step from the committed PMC passes, and the
+    # bandwidth it implies at this run's step time, next to the algorithmic floor (2 KiB per sample and hidden layer)
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    step_bytes = json.load(open(tfile)).get("train_step_16384_%s" % precision) if os.path.exists(tfile) else None
+    floor_bytes = 16384 * (N_FINE * 8 + C_COARSE * 4) * 2048.0
+    out["roofline"]["traffic"] = step_bytes
+    out["roofline"]["hbm"] = {"algorithmic_bytes": floor_bytes, "measured_bytes": step_bytes, "peak_tbps": 8.0,
+                              "achieved_tbps": (step_bytes * best / 16384 / 1e12) if step_bytes else None,
+                              "algorithmic_tbps": floor_bytes * best / 16384 / 1e12}
     out["iteration_512"] = iteration_rate(precision)
     dt = mod.run_ref(512, 64, 128, precision, iters=10, warm=3, quiet=True)
     out["refnerf_rays_512"] = {"rays_per_s": 512 / dt, "ms_per_iter": dt * 1e3, "note": "Ref-NeRF step with prop_normal (train.py:176-187)"}

@@ -34,6 +34,22 @@ for k, (calls, ms) in sorted(avg.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     w = sum(val["WRITE_SIZE"][k]) / max(1, len(val["WRITE_SIZE"][k]))
     gb = (2 * f + w) * 1024 / 1e9
     lines.append("| %s | %g | %.3f | %.4g | %.4g | %.3f | %.2f |" % (k, calls / steps, ms, f, w, gb, gb / ms))
+# whole-step traffic (every dispatch of the profiled run, torch's own kernels included) / steps in the run -> profiles/pmc_traffic.json
+import json
+tot = {c: 0.0 for c in val}
+steps_pmc = 0
+for c in val:
+    rows = [r for r in csv.DictReader(open(os.path.join(d, "pmc_%s_%s.csv" % (cfg, c)))) if r["Counter_Name"] == c]
+    tot[c] = sum(float(r["Counter_Value"]) for r in rows)
+    if c == "FETCH_SIZE":
+        steps_pmc = len(set(r["Dispatch_Id"] for r in rows if "mip_bwd_kernel" in r["Kernel_Name"] or "ref_heads_delta_kernel" in r["Kernel_Name"]))
+step_bytes = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / max(1, steps_pmc)
+lines += ["", "Whole step (all dispatches of the run / %d steps): %.2f GB of HBM traffic." % (steps_pmc, step_bytes / 1e9)]
+tfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
+tj["train_step_%s" % cfg] = step_bytes
+tj["_source_train_step"] = "scripts/gpu_train_profile.sh PMC=1 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_train_rate.py), all dispatches of a step"
+json.dump(tj, open(tfile, "w"), indent=1)
 out = "\n".join(lines) + "\n"
 open(os.path.join(d, "train_pmc_summary.md"), "w").write(out)
 print(out)
