@@ -68,7 +68,10 @@ lines += ["* %s: %.3f GB" % (k, v / 1e9) for k, v in traffic.items()]
 lines += ["", "Algorithmic bytes per launch (DESIGN.md section 2): mip_kernel 0.35 GB in + 1.31 GB out = 1.66 GB; proposal 0.18 + 0.16 = 0.34 GB; "
           "resample 0.49 GB in the default Philox mode (0.99 GB with resident uniforms); composite 1.98 GB."]
 open(os.path.join(DST, prefix + "_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
-json.dump({"mip_bf16": traffic.get("mip_kernel"),
+tfile = os.path.join(DST, "pmc_traffic.json")
+tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
+tj.update({"mip_bf16": traffic.get("mip_kernel"),
            "_source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command; bytes per "
-                      "launch of the dominant kernel)" % prefix}, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+                      "launch of the dominant kernel)" % prefix})
+json.dump(tj, open(tfile, "w"), indent=1)
 print("\n".join(lines))
