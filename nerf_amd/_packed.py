@@ -24,14 +24,51 @@ class PackedWeightsMixin:
     def _linear_layers(self) -> List[torch.nn.Linear]:
         raise NotImplementedError
 
-    def _pack_now(self, precision: int) -> torch.Tensor:
+    # ---- narrower networks (--prop_net_width / --nerf_net_width < 256) ---------------------------------------------------------------
+    # The kernels are compiled for 256-wide hidden layers.  A network with hidden_unit < 256 is evaluated EXACTLY by them with its
+    # tensors zero-padded to the compiled shapes: the padded units have zero weights and zero bias, so they output relu(0) = 0 and feed
+    # zeros forward, and an fp32 (or bf16 x bf16 -> fp32) accumulation is unchanged by added zero products; the same holds for the
+    # backward (the padded rows / columns of every gradient are the discarded part).  Hidden features are always the LAST column segment
+    # of a layer's input (cat(encoding, hidden)), so padding is at the end of each dimension.  It runs at the 256-wide speed: this is
+    # the compatibility path of the width flags, not a narrow kernel.
+    def _kernel_weight_shapes(self):
+        """(out, in) of every tensor in _linear_layers() order as the kernels expect them; None = the module's own shapes"""
+        return None
+
+    def kernel_params(self):
+        """-> (weights, biases) in the kernels' shapes (the parameters themselves when nothing is padded)"""
         layers = self._linear_layers()
-        return ops.pack_weights(self._net_id, precision, [l.weight for l in layers], [l.bias for l in layers])
+        shapes = self._kernel_weight_shapes()
+        ws, bs = [l.weight for l in layers], [l.bias for l in layers]
+        if shapes is None or all(tuple(w.shape) == tuple(s) for w, s in zip(ws, shapes)):
+            return ws, bs
+        pw, pb = [], []
+        with torch.no_grad():
+            for w, b, s in zip(ws, bs, shapes):
+                if tuple(w.shape) == tuple(s):
+                    pw.append(w); pb.append(b)
+                    continue
+                W = torch.zeros(tuple(s), dtype=w.dtype, device=w.device)
+                W[: w.shape[0], : w.shape[1]] = w
+                B = torch.zeros((s[0],), dtype=b.dtype, device=b.device)
+                B[: b.shape[0]] = b
+                pw.append(W); pb.append(B)
+        return pw, pb
+
+    def unpad_grads(self, gW, gb):
+        """gradients in the kernels' shapes -> the parameters' shapes"""
+        layers = self._linear_layers()
+        return ([g[: l.weight.shape[0], : l.weight.shape[1]] if tuple(g.shape) != tuple(l.weight.shape) else g for g, l in zip(gW, layers)],
+                [g[: l.bias.shape[0]] if tuple(g.shape) != tuple(l.bias.shape) else g for g, l in zip(gb, layers)])
+
+    def _pack_now(self, precision: int) -> torch.Tensor:
+        ws, bs = self.kernel_params()
+        return ops.pack_weights(self._net_id, precision, ws, bs)
 
     def packed_backward(self, precision: int) -> torch.Tensor:
         """The transposed weights for the dgrad chain (nerf_amd_pack_weights_backward); packed when asked for -- the backward runs once
         per training step, after which the weights change anyway."""
-        return ops.pack_weights_backward(self._net_id, precision, [l.weight for l in self._linear_layers()])
+        return ops.pack_weights_backward(self._net_id, precision, self.kernel_params()[0])
 
     def _packed_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())

@@ -68,8 +68,11 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         return [self.layers[0], self.layers[2], self.layers[4], self.layers[6], self.layers[8]]
 
     def _check_config(self):
-        if not (self.position_flevel == 10 and self.hidden_unit == 256 and self.cat_origin):
-            raise NotImplementedError("nerf_amd: the HIP proposal kernel is instantiated for ProposalNetwork(10, 256, cat_origin=True)")
+        if not (self.position_flevel == 10 and 1 <= self.hidden_unit <= 256 and self.cat_origin):
+            raise NotImplementedError("nerf_amd: the HIP proposal kernel is instantiated for ProposalNetwork(10, hidden_unit <= 256, cat_origin=True)")
+
+    def _kernel_weight_shapes(self):
+        return [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]
 
     def loadFromFile(self, load_path: str, use_amp=False, other_stuff=None):
         """addtional.py:73-86."""
@@ -116,6 +119,7 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
                     gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1))
                     return (gx.view(p.shape), *[None] * len(wb))
                 gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5], packed_bwd=held["bwd_blob"])
+                gW, gb = self.unpad_grads(gW, gb)
                 return (None, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts)

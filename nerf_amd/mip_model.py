@@ -37,8 +37,11 @@ class MipNeRF(PackedWeightsMixin, NeRF):
                 self.rgb_layer[0], self.rgb_layer[2]]
 
     def _check_config(self):
-        if not (self.position_flevel == 10 and self.direction_flevel == 4 and self.hidden_unit == 256 and self.cat_origin):
-            raise NotImplementedError("nerf_amd: the HIP fine-MLP kernel is instantiated for MipNeRF(10, 4, 256, cat_origin=True)")
+        if not (self.position_flevel == 10 and self.direction_flevel == 4 and 1 <= self.hidden_unit <= 256 and self.cat_origin):
+            raise NotImplementedError("nerf_amd: the HIP fine-MLP kernel is instantiated for MipNeRF(10, 4, hidden_unit <= 256, cat_origin=True)")
+
+    def _kernel_weight_shapes(self):
+        return [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (256, 256), (1, 256), (128, 283), (3, 128)]
 
     def forward(self, pts: torch.Tensor) -> torch.Tensor:
         """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60)."""
@@ -64,8 +67,10 @@ class MipNeRF(PackedWeightsMixin, NeRF):
             def bwd(g, p, *wb):
                 if "dump" not in held:
                     raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
+                kw, kb = self.kernel_params()
                 gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), p.reshape(-1, 6), held.pop("dump"), prec,
-                                                   wb[:n], wb[n:], packed_bwd=self.packed_backward(prec))
+                                                   kw, kb, packed_bwd=ops.pack_weights_backward(ops.NET_MIP, prec, kw))
+                gW, gb = self.unpad_grads(gW, gb)
                 return (None, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.mip_forward(self.packed(prec), prec, pts)

@@ -83,8 +83,9 @@ def test_mip_module_param_count_and_order():
     assert [tuple(l.weight.shape) for l in p._linear_layers()] == [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]
     with pytest.raises(NotImplementedError):
         MipNeRF(8, 4, 256)._check_config()
+    ProposalNetwork(10)._check_config()                # class default width 128 (addtional.py:61): zero-padded to the 256-wide kernels
     with pytest.raises(NotImplementedError):
-        ProposalNetwork(10)._check_config()            # class default width 128 (addtional.py:61) has no kernel instance yet
+        ProposalNetwork(10, 320)._check_config()
 
 
 def test_host_scalars_and_patching(golden):
@@ -204,3 +205,39 @@ def test_coarse_grad_select_without_mask_gather():
     sel = torch.gather(sel, -1, sort_inds)
     assert torch.equal(got, fine[sel].reshape(n, c, -1))
     assert torch.equal(got, O.coarse_grad_select(fine, sort_inds, c))
+
+
+@pytest.mark.parametrize("width", [64, 128, 200])
+def test_narrower_networks_are_zero_padded_to_the_kernel_shapes(width):
+    """--prop_net_width / --nerf_net_width < 256: the host side hands the 256-wide kernels the zero-padded tensors, which define the same
+    function (checked here with the CPU oracle on the padded state), and un-pads gradients back to the parameters' shapes."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import nerf_oracle as O
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    torch.manual_seed(width)
+    prop, mip = ProposalNetwork(10, width), MipNeRF(10, 4, width)
+    with torch.no_grad():
+        for m in list(prop.modules()) + list(mip.modules()):
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0); m.bias.normal_(0.0, 0.05)
+    prop._check_config(); mip._check_config()
+    pts = torch.cat((torch.rand(40, 7, 3) * 2 - 1, torch.randn(40, 7, 3)), -1)
+    for net, fwd, x in ((prop, O.proposal_forward, pts[..., :3]), (mip, O.mip_forward, pts)):
+        ws, bs = net.kernel_params()
+        assert [tuple(w.shape) for w in ws] == [tuple(s) for s in net._kernel_weight_shapes()]
+        layers = net._linear_layers()
+        names = [k[:-7] for k in net.state_dict().keys() if k.endswith(".weight")]
+        by_layer = {id(l): n for n, l in ((n, dict(net.named_modules())[n]) for n in names)}
+        padded = {}
+        for l, w, b in zip(layers, ws, bs):
+            padded[by_layer[id(l)] + ".weight"], padded[by_layer[id(l)] + ".bias"] = w.detach(), b.detach()
+            assert torch.equal(w[: l.weight.shape[0], : l.weight.shape[1]], l.weight) and int((w != 0).sum()) == int((l.weight != 0).sum())
+        with torch.no_grad():
+            a, b_ = fwd(dict(net.state_dict()), x), fwd(padded, x)
+        assert (a - b_).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
+        gW, gb = net.unpad_grads([torch.ones_like(w) for w in ws], [torch.ones_like(b) for b in bs])
+        assert [tuple(g.shape) for g in gW] == [tuple(l.weight.shape) for l in layers] and [tuple(g.shape) for g in gb] == [tuple(l.bias.shape) for l in layers]
+    with pytest.raises(NotImplementedError):
+        ProposalNetwork(10, 512)._check_config()

@@ -1545,6 +1545,64 @@ def test_philox_render_equals_render_with_the_same_uniforms_as_tensors(A):
     assert torch.equal(za[0], zb[0]) and torch.equal(za[1], zb[1])
 
 
+@pytest.mark.parametrize("width", [128, 200])
+def test_narrower_networks_through_zero_padding(A, width):
+    """--prop_net_width / --nerf_net_width below 256 (procedures.py:176-177): the 256-wide kernels evaluate the zero-padded network, which
+    is the same function.  Forward, end-to-end render and every parameter gradient of a training step against the CPU oracle / torch
+    autograd on networks of that width (also a width that is not a multiple of 16)."""
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.utils import inverseSample
+    torch.manual_seed(100 + width)
+    prop, mip = ProposalNetwork(10, width), MipNeRF(10, 4, width)
+    with torch.no_grad():                                                     # O(1) activations so that every layer matters
+        for m in list(prop.modules()) + list(mip.modules()):
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0); m.bias.normal_(0.0, 0.05)
+    psd = {k: v.detach().clone() for k, v in prop.state_dict().items()}
+    msd = {k: v.detach().clone() for k, v in mip.state_dict().items()}
+    prop, mip = prop.cuda(), mip.cuda()
+    A.pkg.set_precision("fp32")
+    rays, u1, u2 = _rays_and_u(200, 64, 61)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    d64 = lambda sd: {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        want_rgb, want_w, ex = O.render_rays(psd, msd, rays, u1, u2, NEAR, FAR, 64, white_bkg=True)
+        x_rgb, x_w, x_ex = O.render_rays(d64(psd), d64(msd), rays.double(), u1.double(), u2.double(), NEAR, FAR, 64, white_bkg=True)
+    floor = max(max_abs(want_rgb, x_rgb), max_abs(want_w, x_w), max_abs(ex, x_ex))   # fp32 noise of the reference itself
+    tol_img = max(1e-4, 1.5 * floor)
+    prop.eval(); mip.eval()
+    rgb, depth, w, _ = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 64,
+                                         NEAR, FAR, True, want_depth=True, want_weights=True)
+    assert max_abs(rgb.cpu(), want_rgb) <= tol_img and max_abs(w.cpu(), want_w) <= tol_img and max_abs(depth.cpu(), ex) <= tol_img, (tol_img, floor)
+    assert tol_img <= 5e-4
+    # a training step (train.py:164-199): HIP gradients vs torch.autograd of the oracle on the same fine depths
+    prop.train(); mip.train()
+    n = 48
+    r, zc, tgt = dev(rays[:n]), (z_base[None, :] + dev(u1[:n]) * (4.0 / 64)).contiguous(), torch.rand(n, 3).cuda()
+    pts = (r[:, None, :3] + r[:, None, 3:] * zc[:, :, None]).contiguous()
+    pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(prop.forward(pts)), zc, r[:, 3:]), 0.01)
+    fl, below = inverseSample(pw, zc, 65, sort=True, u=u2[:n])
+    fl = fl[..., :-1].contiguous()
+    rend, wts, _ = NeRF.render(mip.forward(NeRF.length2pts(r, fl)), fl, r[:, 3:])
+    (ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)).backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in psd.items()}
+    m64 = {k: v.double().requires_grad_(True) for k, v in msd.items()}
+    r64, z64, fl64 = r.cpu().double(), zc.cpu().double(), fl.detach().cpu().double()
+    pw64 = O.max_blur(O.sigma_to_weights(F.softplus(O.proposal_forward(p64, r64[:, None, :3] + r64[:, None, 3:] * z64[:, :, None])), z64, r64[:, 3:]), 0.01)
+    rend64, wts64, _ = O.composite(O.mip_forward(m64, O.length2pts(r64, fl64)), fl64, r64[:, 3:])
+    (torch.mean((rend64 - tgt.cpu().double()) ** 2) + O.proposal_loss(O.get_bounds(pw64, below.cpu()), wts64.detach())).backward()
+    for net, ref in ((prop, p64), (mip, m64)):
+        for name, prm in net.named_parameters():
+            want = ref[name].grad
+            assert prm.grad is not None and tuple(prm.grad.shape) == tuple(want.shape), name
+            top = want.abs().max().item()
+            # (fp32 kernels against the fp64 value: first-layer tensors carry cancellation noise of a few 1e-3, test_train_step_gradients)
+            assert (prm.grad.cpu().double() - want).abs().max().item() <= 1e-2 * max(top, 1e-12), (name, top)
+
+
 def test_philox_render_refnerf_and_many_fine_samples(A):
     """In-kernel uniforms on the Ref-NeRF render entry (nerf_amd_render_rays_ref with NULL uniform tensors) and beyond 256 inverse-CDF
     draws per ray (blocks 64.. of the counter layout): both equal the tensor-fed render of oracle.philox_uniforms' values bit for bit."""
