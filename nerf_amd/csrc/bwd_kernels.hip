@@ -381,7 +381,9 @@ __global__ void pe_grad_kernel(const float* __restrict__ d_enc, int ld, const fl
         float acc = d[c];
         for (int f = 0; f < L; ++f) {
             const float fr = (float)(1 << f), a = xv * fr;
-            acc += fr * (sin_quadrant(a, 1) * d[3 + 6 * f + c] - sin_quadrant(a, 0) * d[3 + 6 * f + 3 + c]);
+            float sn, cs;
+            sincos_quadrant(a, sn, cs);
+            acc += fr * (cs * d[3 + 6 * f + c] - sn * d[3 + 6 * f + 3 + c]);
         }
         out[i] = scale ? acc * scale[m * scale_stride] : acc;
     }

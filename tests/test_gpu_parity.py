@@ -707,7 +707,8 @@ def test_error_reporting(A):
         A.ops.mip_forward_composite(build_nets(A, "small")[1].packed(A.ops.F32), A.ops.F32, torch.rand(4, 6).cuda(),
                                     torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
     with pytest.raises(NotImplementedError):
-        A.addtional.ProposalNetwork(10).cuda().forward(torch.rand(2, 3, 3).cuda())          # width 128: no kernel instance
+        A.addtional.ProposalNetwork(10, 512).cuda().forward(torch.rand(2, 3, 3).cuda())     # wider than the compiled 256: no kernel instance
+    assert A.addtional.ProposalNetwork(10).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # class default 128: zero-padded
 
 
 def test_render_only_cli(A, tmp_path):
