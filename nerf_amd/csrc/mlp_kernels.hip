@@ -298,7 +298,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
 
 #ifdef MLP_PHASEPROBE
     // diagnostic build: shader cycles of wave 0 of workgroup 0 per tile phase (fetch + encode | layer 0 | layers 1-3 | head + store)
-    uint64_t ph[4] = {0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+    uint64_t ph[5] = {0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
 #define PHASE_MARK(i) { const uint64_t now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_t; ph_t = now_; }
 #else
 #define PHASE_MARK(i)
@@ -310,6 +310,10 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         for (int t = 0; t < NT; ++t) {
             m[t] = tile * TS + (wave * NT + t) * 32 + j;
             const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, false);
+#ifdef MLP_PHASEPROBE
+            asm volatile("" ::"v"(sm.x), "v"(sm.y), "v"(sm.z));       // the position is complete here (loads returned)
+            PHASE_MARK(4)
+#endif
             encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
             if constexpr (TRAIN) {                           // the first-layer weight gradient's operand: slot 4, K groups 0..3
 #pragma unroll
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     ws.drain();
 #ifdef MLP_PHASEPROBE
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 4; ++i) reinterpret_cast<uint64_t*>(density)[i] = ph[i];
+        for (int i = 0; i < 5; ++i) reinterpret_cast<uint64_t*>(density)[i] = ph[i];
 #endif
 #undef PHASE_MARK
 }
