@@ -524,7 +524,7 @@ template <int YKIND> DEVINL int y_slot_feature(int kg, int h, int e) {
 }
 
 // KGX / KGY: K groups of X / Y;  WO: waves along the X (row) dimension, 4 / WO along Y
-template <int KGX, int KGY, int WO, int YKIND>
+template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false>
 __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t n_sub) {
     constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : ((YKIND == Y_PE10 || YKIND == Y_IDE) ? 2 : 1);
     constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
@@ -592,19 +592,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     };
     auto cvt8 = [](const f32x16& v, int g) -> bf16x8 { return PBF16::from_acc<false>(v, 8 * g); };
 
-    bf16x8 xs[NXK], ys[NYK], xn[NXK], yn[NYK];
-    if (s_begin < s_end) { load_x(s_begin, xs); load_y(s_begin, ys); }
-    for (int64_t s = s_begin; s < s_end; ++s) {
-#if WGRAD_LOCKSTEP
-        // Waves that share K groups (same wo / same wi) start every subtile together, so that the second request of a K group is served
-        // by L1 / L2 while the first is still in flight: FETCH_SIZE falls from 1.47x to 1.00x of the algorithmic bytes (PMC).  The kernel's
-        // time does not change (it is bound by bytes in flight, not bandwidth) -- the barrier is there to not waste 7.5 GB of HBM reads a step.
-        if constexpr (WO > 1 || WI > 1) __builtin_amdgcn_s_barrier();
-#endif
-        {   // next subtile in flight while this one is multiplied (the last iteration re-reads its own subtile: unconditional loads)
-            const int64_t sn = (s + 1 < s_end) ? s + 1 : s;
-            load_x(sn, xn); load_y(sn, yn);
-        }
+    // one subtile: transpose the X and Y K groups on the matrix cores, multiply the transposed blocks
+    auto multiply = [&](const bf16x8 (&xs)[NXK], const bf16x8 (&ys)[NYK]) {
         // X^T blocks of this wave: lane = row feature, 2 x 8 registers = the subtile's 32 samples
         bf16x8 xf[OBW][2];
 #pragma unroll
@@ -635,11 +624,73 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
 #pragma unroll
             for (int a = 0; a < OBW; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][1], yf1, acc[a][b], 0, 0, 0);
         }
+    };
+    if constexpr (XCHG) {
+        // Exchange form (the 2 x 2 tiling of the 256 x 256 product).  In the plain form every wave requests all 16 K groups it multiplies,
+        // i.e. the workgroup requests every K group twice and keeps 32 KiB of UNIQUE bytes in flight per CU with one subtile of prefetch --
+        // the kernel's time is that number times the loaded HBM latency, and a second prefetch buffer does not fit the register file.
+        // Here a wave loads only its QUARTER of a subtile (4 of its 8 X K groups, 4 of its 8 Y K groups: 8 KiB, 32 registers), two
+        // subtiles ahead, parks it in LDS when it has landed, and after the workgroup barrier reads its partners' quarters back: the same
+        // 64 operand registers per subtile, but 64 KiB of unique bytes in flight per CU and no duplicate request at all.
+        static_assert(KGX == 16 && KGY == 16 && WO == 2 && YKIND == Y_DMAP, "exchange form: the 2 x 2 tiling of the 256 x 256 product");
+        constexpr uint32_t STAGE = 32 * 1024;                              // X K groups 0..15 | Y K groups 0..15 of one subtile
+        auto load_quarter = [&](int64_t s, bf16x8 (&q)[8]) {               // X K groups 8 wo + 4 wi + k, Y K groups 8 wi + 4 wo + k
+            const char* yb = J.y.base + (size_t)s * J.y.sub_stride + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, 8 * wo + 4 * wi + k));
+                q[4 + k] = *reinterpret_cast<const bf16x8*>(yb + (size_t)(8 * wi + 4 * wo + k) * 1024);
+            }
+        };
+        auto clamp_s = [&](int64_t s) { return s < s_end ? s : s_end - 1; };
+        bf16x8 q0[8], q1[8], q2[8], xs[NXK], ys[NYK];
+        int buf = 0;
+        if (s_begin < s_end) { load_quarter(s_begin, q0); load_quarter(clamp_s(s_begin + 1), q1); }
+        for (int64_t s = s_begin; s < s_end; ++s) {
+            load_quarter(clamp_s(s + 2), q2);                               // (unconditional: past the end the last subtile is read again)
+            const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                   // park my quarter of subtile s (it landed: issued two iterations ago)
+                *reinterpret_cast<bf16x8*>(smem + st + (8 * wo + 4 * wi + k) * 1024) = q0[k];
+                *reinterpret_cast<bf16x8*>(smem + st + (16 + 8 * wi + 4 * wo + k) * 1024) = q0[4 + k];
+            }
+            __syncthreads();                                                // everybody's quarters of s are in LDS (and buffer buf^1 is free again)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                   // my own quarter from registers, the partners' from LDS.  Register
+                xs[k] = q0[k];                                              // arrays must be indexed statically: local blocks 0, 1 = the own K
+                xs[4 + k] = *reinterpret_cast<const bf16x8*>(smem + st + (8 * wo + 4 * (1 - wi) + k) * 1024);   // groups, 2, 3 = the partner's;
+                ys[k] = q0[4 + k];                                          // the permutation is undone in the partial's addresses (xmap / ymap)
+                ys[4 + k] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 8 * wi + 4 * (1 - wo) + k) * 1024);
+            }
+            multiply(xs, ys);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { q0[k] = q1[k]; q1[k] = q2[k]; }
+            buf ^= 1;
+        }
+    } else {
+    bf16x8 xs[NXK], ys[NYK], xn[NXK], yn[NYK];
+    if (s_begin < s_end) { load_x(s_begin, xs); load_y(s_begin, ys); }
+    for (int64_t s = s_begin; s < s_end; ++s) {
+#if WGRAD_LOCKSTEP
+        // Waves that share K groups (same wo / same wi) start every subtile together, so that the second request of a K group is served
+        // by L1 / L2 while the first is still in flight: FETCH_SIZE falls from 1.47x to 1.00x of the algorithmic bytes (PMC).  The kernel's
+        // time does not change (it is bound by bytes in flight, not bandwidth) -- the barrier is there to not waste HBM reads.
+        if constexpr (WO > 1 || WI > 1) __builtin_amdgcn_s_barrier();
+#endif
+        {   // next subtile in flight while this one is multiplied (the last iteration re-reads its own subtile: unconditional loads)
+            const int64_t sn = (s + 1 < s_end) ? s + 1 : s;
+            load_x(sn, xn); load_y(sn, yn);
+        }
+        multiply(xs, ys);
 #pragma unroll
         for (int k = 0; k < NXK; ++k) xs[k] = xn[k];
 #pragma unroll
         for (int k = 0; k < NYK; ++k) ys[k] = yn[k];
     }
+    }
+    // local block index -> block of the wave's rectangle (exchange form: own blocks first, then the partner's)
+    auto xmap = [&](int a) { return XCHG ? ((a < 2) ? 2 * wi + a : 2 * (1 - wi) + a - 2) : a; };
+    auto ymap = [&](int b) { return XCHG ? ((b < 2) ? 2 * wo + b : 2 * (1 - wo) + b - 2) : b; };
     // partial of this workgroup, row-major (32 NOB) x (32 NIB): register r of lane (j, h) = row 32 ob + (r&3) + 8 (r>>2) + 4 h, column 32 ib + j
     float* out = J.partial + (size_t)blockIdx.x * (32 * NOB) * (32 * NIB);
 #pragma unroll
@@ -648,14 +699,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
         for (int b = 0; b < IBW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * (ob0 + a) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                out[(size_t)row * (32 * NIB) + 32 * (ib0 + b) + j] = acc[a][b][r];
+                const int row = 32 * (ob0 + xmap(a)) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)row * (32 * NIB) + 32 * (ib0 + ymap(b)) + j] = acc[a][b][r];
             }
     if (J.bias_partial != nullptr && wi == 0) {
 #pragma unroll
         for (int a = 0; a < OBW; ++a) {
             const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-            if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + a) + j] = v;
+            if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + xmap(a)) + j] = v;
         }
     }
 }
@@ -883,9 +934,12 @@ int launch_mip_bwd(const void* packed, const float* g, const float* rgbo, int64_
     return (int)hipGetLastError();
 }
 
-template <int KGX, int KGY, int WO, int YKIND>
+#ifndef WGRAD_EXCHANGE
+#define WGRAD_EXCHANGE 1            /* the 256 x 256 shape loads quarters and exchanges them through LDS (0 = every wave loads all it multiplies) */
+#endif
+template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false>
 int launch_wgrad(int precision, const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
+    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND, XCHG>), dim3(n_wg, n_jobs), dim3(256), XCHG ? 65536 : 0, st, jobs, n_sub);
     else hipLaunchKernelGGL((wgrad_kernel_f32<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
     return (int)hipGetLastError();
 }
@@ -931,7 +985,7 @@ int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, i
         J.partial = prods[i].partial; J.bias_partial = prods[i].bias_partial;
     }
     switch (shape) {
-        case 0: return launch_wgrad<16, 16, 2, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
+        case 0: return launch_wgrad<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
         case 1: return launch_wgrad<16, 4, 4, Y_PE10>(precision, jobs, n, n_wg, n_sub, st);      // 4 x 1 waves of 2 x 2 blocks
         case 2: return launch_wgrad<9, 16, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // NOB 5 x NIB 8: 1 x 4 waves of 5 x 2 blocks
         case 3: return launch_wgrad<1, 8, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);       // NOB 1 x NIB 4
