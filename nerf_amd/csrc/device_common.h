@@ -152,6 +152,10 @@ constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x14
 template <int CTRL, int ROW_MASK>
 DEVINL int dpp_move(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false); }
 template <int CTRL, int ROW_MASK>
+DEVINL float dpp_move(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
 DEVINL double dpp_move(double identity, double v) {
     const int2 o = __builtin_bit_cast(int2, identity), x = __builtin_bit_cast(int2, v);
     int2 r;
@@ -185,10 +189,10 @@ DEVINL double wave_last(double v) {             // lane 63's value, as a wave-un
     r.y = __builtin_amdgcn_readlane(x.y, 63);
     return __builtin_bit_cast(double, r);
 }
+// sum over the wave, returned to every lane: the DPP scan's last lane (register-file lane moves instead of six ds_bpermute round trips)
 DEVINL float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    const float t = wave_incl_scan(v, 0.0f, [](float a, float b) { return a + b; });
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
 }
 DEVINL double wave_sum_d(double v) {
 #pragma unroll
