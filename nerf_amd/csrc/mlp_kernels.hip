@@ -696,21 +696,17 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
         BReg a[NT][16], b[NT][16];
         int lay = 0, lay_pend = 0;                                  // training dump slots of the layer being computed / of the pending pair
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
-        auto OA = [&](int fb, int t, const f32x16& acc, int half) {   // (the pending pair of the previous layer, or layer `lay` itself when it writes a)
-            a[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
-            if constexpr (TRAIN) dump_breg<P>(dump, lay_pend, sub0 + t, 2 * fb + half, lane, a[t][2 * fb + half]);
+        // (`lay` = the layer whose block pairs are being computed, `lay_pend` = the layer that owns the deferred pair, see proposal_kernel)
+        auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
+            buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
         };
-        auto OB = [&](int fb, int t, const f32x16& acc, int half) {
-            b[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
-            if constexpr (TRAIN) dump_breg<P>(dump, lay, sub0 + t, 2 * fb + half, lane, b[t][2 * fb + half]);
-        };
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay, fb, t, acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay, fb, t, acc, half); };
+        auto OA_pend = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay_pend, fb, t, acc, half); };
+        auto OB_pend = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay_pend, fb, t, acc, half); };
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
-        auto copy_back = [&]() {                                    // K groups 12..15 arrive through the deferred epilogue
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < 12; ++k) a[t][k] = b[t][k];
-        };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         Deferred<P, 6, 2> d;                                        // see mip_kernel
         {
             BReg enc[NT][4];
@@ -731,25 +727,33 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
             d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                  // spa_block1.0 (lay = lay_pend = 0)
                 [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
         }
-        static_assert(L::START[1] % (2 * FPC) == L::START[2] % (2 * FPC) && L::START[5] % (2 * FPC) == L::START[6] % (2 * FPC), "chunk parity");
+        static_assert(L::START[1] % (2 * FPC) == L::START[3] % (2 * FPC) && L::START[5] % (2 * FPC) == L::START[7] % (2 * FPC) &&
+                      L::BIAS_OFF[3] == L::BIAS_OFF[1] + 512 && L::BIAS_OFF[7] == L::BIAS_OFF[5] + 512, "chunk parity / bias spacing of the shared a -> b instance");
+        // The layers ping-pong between the two register buffers (a -> b -> a -> b; the skip layer b -> a; a -> b -> a -> b), so nothing is
+        // copied between layers; the two a -> b layers of a block share one code instance through the loop (same chunk parity, asserted).
 #pragma unroll 1
-        for (int l = 1; l <= 3; ++l) {                                                        // spa_block1.{2,4,6}
-            lay_pend = lay; lay = l;
-            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + (l - 1) * 256) * 4, IN_A, OB, prev_of(d, OA));
-            copy_back();
+        for (int r = 0; r < 2; ++r) {                                                         // spa_block1.{2,4,6}
+            lay_pend = lay; lay = 1 + 2 * r;
+            d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + 2 * r * 256) * 4, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                lay_pend = lay; lay = 2;
+                d = dense<P, 16, 8, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB_pend));
+            }
         }
         lay_pend = lay; lay = 4;
-        d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                      // spa_block2.0 (skip)
-            [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 4 ? kg - 4 : 0]; },
-            OB, prev_of(d, OA));
-        copy_back();
+        d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,                      // spa_block2.0 (skip): cat(enc, b) -> a
+            [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(stash(t) + kg * P::BREG_LDS); return b[t][kg >= 4 ? kg - 4 : 0]; },
+            OA, prev_of(d, OB_pend));
 #pragma unroll 1
-        for (int l = 5; l <= 7; ++l) {                                                        // spa_block2.{2,4,6}
-            lay_pend = lay; lay = l;
-            d = dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + (l - 5) * 256) * 4, IN_A, OB, prev_of(d, OA));
-            copy_back();
+        for (int r = 0; r < 2; ++r) {                                                         // spa_block2.{2,4,6}
+            lay_pend = lay; lay = 5 + 2 * r;
+            d = dense<P, 16, 8, L::START[5]>(ws, bias0 + (L::BIAS_OFF[5] + 2 * r * 256) * 4, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                lay_pend = lay; lay = 6;
+                d = dense<P, 16, 8, L::START[6]>(ws, bias0 + L::BIAS_OFF[6] * 4, IN_B, OA, prev_of(d, OB_pend));
+            }
         }
-        lay_pend = lay;
+        lay_pend = lay;                                                                       // (the spatial features are in b)
         // heads: bottle_neck (4 blocks, no activation) + [normal | roughness || diffuse | density || tint]
         BReg bn[NT][8];
         f32x16 hd[NT];
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                 if constexpr (TRAIN) dump_breg<P>(dump, 8, sub0 + t, 2 * (fb < 4 ? fb : 0) + half, lane, bn[t][2 * (fb < 4 ? fb : 0) + half]);
             } else if (half == 0) hd[t] = acc;
         };
-        dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4, IN_A, OHD, prev_of(d, OA)).flush(OHD);
+        dense<P, 16, 5, L::START[8]>(ws, bias0 + L::BIAS_OFF[8] * 4, IN_B, OHD, prev_of(d, OB_pend)).flush(OHD);
         // half 0 holds rows 0-3 (normal, roughness) in hd[0..3] and rows 8-10 (tint) in hd[4..6]; half 1 rows 4-7 (diffuse, density) in hd[0..3]
         float keep[NT][4];
         BReg ide[NT][3];
@@ -808,28 +812,34 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
         d = dense<P, 11, 8, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,                      // dir_block1.0
             [&](int kg, int t) -> BReg { if (kg < 8) return bn[t][kg < 8 ? kg : 0]; return ide[t][kg >= 8 ? kg - 8 : 0]; },
             OA, NoPrev{});
-        static_assert(L::START[10] % (2 * FPC) == L::START[11] % (2 * FPC) && L::START[14] % (2 * FPC) == L::START[15] % (2 * FPC), "chunk parity");
+        static_assert(L::START[10] % (2 * FPC) == L::START[12] % (2 * FPC) && L::START[14] % (2 * FPC) == L::START[16] % (2 * FPC) &&
+                      L::BIAS_OFF[12] == L::BIAS_OFF[10] + 512 && L::BIAS_OFF[16] == L::BIAS_OFF[14] + 512, "chunk parity / bias spacing of the shared a -> b instance");
 #pragma unroll 1
-        for (int l = 10; l <= 12; ++l) {                                                      // dir_block1.{2,4,6}
-            lay_pend = lay; lay = l;
-            d = dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + (l - 10) * 256) * 4, IN_A, OB, prev_of(d, OA));
-            copy_back();
+        for (int r = 0; r < 2; ++r) {                                                         // dir_block1.{2,4,6}
+            lay_pend = lay; lay = 10 + 2 * r;
+            d = dense<P, 16, 8, L::START[10]>(ws, bias0 + (L::BIAS_OFF[10] + 2 * r * 256) * 4, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                lay_pend = lay; lay = 11;
+                d = dense<P, 16, 8, L::START[11]>(ws, bias0 + L::BIAS_OFF[11] * 4, IN_B, OA, prev_of(d, OB_pend));
+            }
         }
         lay_pend = lay; lay = 13;
-        d = dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                    // dir_block2.0 (skip)
-            [&](int kg, int t) -> BReg { if (kg < 11) return P::unstash(stash(t) + kg * P::BREG_LDS); return a[t][kg >= 11 ? kg - 11 : 0]; },
-            OB, prev_of(d, OA));
-        copy_back();
+        d = dense<P, 27, 8, L::START[13]>(ws, bias0 + L::BIAS_OFF[13] * 4,                    // dir_block2.0 (skip): cat(all_inputs, b) -> a
+            [&](int kg, int t) -> BReg { if (kg < 11) return P::unstash(stash(t) + kg * P::BREG_LDS); return b[t][kg >= 11 ? kg - 11 : 0]; },
+            OA, prev_of(d, OB_pend));
 #pragma unroll 1
-        for (int l = 14; l <= 16; ++l) {                                                      // dir_block2.{2,4,6}
-            lay_pend = lay; lay = l;
-            d = dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + (l - 14) * 256) * 4, IN_A, OB, prev_of(d, OA));
-            copy_back();
+        for (int r = 0; r < 2; ++r) {                                                         // dir_block2.{2,4,6}
+            lay_pend = lay; lay = 14 + 2 * r;
+            d = dense<P, 16, 8, L::START[14]>(ws, bias0 + (L::BIAS_OFF[14] + 2 * r * 256) * 4, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                lay_pend = lay; lay = 15;
+                d = dense<P, 16, 8, L::START[15]>(ws, bias0 + L::BIAS_OFF[15] * 4, IN_B, OA, prev_of(d, OB_pend));
+            }
         }
         lay_pend = lay;
         float sr[NT], sg[NT], sb[NT];
         auto OSPEC = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { sr[t] = acc[0]; sg[t] = acc[1]; sb[t] = acc[2]; } };
-        dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4, IN_A, OSPEC, prev_of(d, OA)).flush(OSPEC);     // spec_rgb_head.0
+        dense<P, 16, 1, L::START[17]>(ws, bias0 + L::BIAS_OFF[17] * 4, IN_B, OSPEC, prev_of(d, OB_pend)).flush(OSPEC);     // spec_rgb_head.0
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             // half 1's keep[] = (diffuse, density); fetch it into half 0, which holds spec and tint (ref_model.py:98-105)
