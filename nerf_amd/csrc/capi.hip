@@ -45,6 +45,7 @@ int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
 int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
 int sk_dirs_norm(const float*, int64_t, float*, hipStream_t);
+int sk_dirs_norm_scratch(const float*, int64_t, float*, void*, hipStream_t);
 int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, const float*, float, float, float, float, int64_t, int, uint64_t, const uint64_t*,
                      float*, float*, float*, float*, hipStream_t);
 int sk_philox_uniforms(float*, int64_t, int, uint64_t, const uint64_t*, hipStream_t);
@@ -580,7 +581,9 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     const bool ipe = camera && camera->ipe;
     if (ipe) {                                              // row 12 inside the fine pass: the direction norm of this ray batch
         if (!(camera->ipe_radius > 0.0f)) return fail(NERF_AMD_EINVAL, "integrated PE needs a positive ipe_radius");
-        if (int e = sk_dirs_norm(rays, N, dir_norm, st)) return hip_status(e, "direction norm");
+        // (the density buffer is scratch until the proposal pass below writes it: room for the 256 fp64 workgroup partials when N >= 8)
+        if (int e = (N >= 8) ? sk_dirs_norm_scratch(rays, N, dir_norm, density, st) : sk_dirs_norm(rays, N, dir_norm, st))
+            return hip_status(e, "direction norm");
     }
     const float jitter = (far - near) / (float)n_fine;      // procedures.py:59
 
