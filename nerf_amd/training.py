@@ -114,6 +114,14 @@ class TrainStep:
         self.image.copy_(img.reshape(self.image.shape), non_blocking=True)
         self.pose.copy_(pose.reshape(-1)[:12].reshape(3, 4), non_blocking=True)
 
+    def set_crop(self, crop_xy) -> None:
+        """train.py:155 switches from the centre crop to the full image after `center_crop_iter` iterations: the pixel table changes
+        shape, so a captured graph is dropped (call capture() again; the eager path needs nothing)."""
+        crop_xy = tuple(crop_xy)
+        if crop_xy != self.crop_xy:
+            self.crop_xy = crop_xy
+            self.graph = None
+
     def capture(self, warmup: int = 2) -> None:
         """Run `warmup` eager iterations on the current image (lazy kernel attributes, optimizer state, allocator pools), then record
         the iteration into a hipGraph.  The warm-up iterations are real training steps."""
