@@ -406,6 +406,11 @@ def test_device_resident_train_step_eager_and_replayed():
         step()
     last = sum(float(step()[1].item()) for _ in range(5)) / 5
     assert last < 0.5 * first, (first, last)
+    step.set_crop((0.5, 0.5))                                                 # the centre-crop phase of train.py:155: another pixel table
+    assert step.graph is None                                                 # -> the captured graph is dropped, the eager path just works
+    assert torch.isfinite(step()[0]).item()
+    step.capture(warmup=1)
+    assert torch.isfinite(step()[0]).item()
 
 
 @pytest.mark.gpu
