@@ -1624,6 +1624,23 @@ def test_philox_render_refnerf_and_many_fine_samples(A):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_philox_uniform_tensor_and_device_seed(A):
+    """nerf_amd_philox_uniforms == the oracle's restatement of the inverse-CDF stream, bit for bit, with the key given as an argument or
+    read from device memory; nerf_amd_advance_seed replaces the device key by a different one, deterministically."""
+    seed = 0x0F1E2D3C4B5A6978
+    want = O.philox_uniforms(seed, 37, 0, 64, 250)[1]
+    got = A.ops.philox_uniforms((37, 250), seed=seed, device=torch.device("cuda", 0))
+    assert torch.equal(got.cpu(), want)
+    sd = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64).cuda()
+    assert torch.equal(A.ops.philox_uniforms((37, 250), seed_dev=sd).cpu(), want)
+    A.ops.advance_seed(sd)
+    s1 = int(sd.item())
+    assert s1 != seed and not torch.equal(A.ops.philox_uniforms((37, 250), seed_dev=sd).cpu(), want)
+    sd2 = torch.tensor([seed], dtype=torch.int64).cuda()
+    A.ops.advance_seed(sd2)
+    assert int(sd2.item()) == s1
+
+
 def test_philox_uniforms_are_uniform():
     """Statistical sanity of the in-kernel stream (through its oracle twin, bit-equal to the kernels by the test above): one-sample
     Kolmogorov-Smirnov against U[0,1) on 1.2e6 draws of each stream, lag-1 / cross-stream correlations, and the 24-bit lattice."""
