@@ -62,6 +62,13 @@ for k in ("mip_kernel", "proposal_kernel", "resample_kernel", "composite_kernel"
     lines.append("| %s | %.3f | %.4g | %.1f %% | %.2f | %.1f %% | %.1f %% | %.4g | %.4g | %.3g |" % (
         k, stats.get(k, float("nan")), m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), 100 * busy, clk, 100 * m.get("SQ_WAIT_ANY", 0) / wc,
         100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, fetch, write, m.get("SQ_LDS_BANK_CONFLICT", 0.0)))
+lines += ["", "Instruction mix per MFMA (pass 4 `SQ_INSTS_*` / pass 1 `SQ_VALU_MFMA_BUSY_CYCLES` / 32; SQ_INSTS_VALU includes the MFMAs):", ""]
+for k in ("mip_kernel", "proposal_kernel"):
+    if k in mean and mean[k].get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        m = mean[k]
+        n_mfma = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 32.0
+        lines.append("* %s: %.3g MFMA per launch; VALU (non-MFMA) %.2f, SALU %.2f, LDS %.2f per MFMA" % (
+            k, n_mfma, (m.get("SQ_INSTS_VALU", 0.0) - n_mfma) / n_mfma, m.get("SQ_INSTS_SALU", 0.0) / n_mfma, m.get("SQ_INSTS_LDS", 0.0) / n_mfma))
 lines += ["", "HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (FETCH_SIZE doubled: gfx950 reports half of a wide coalesced "
           "read stream, MI355X_MICROARCH.md section HBM):", ""]
 lines += ["* %s: %.3f GB" % (k, v / 1e9) for k, v in traffic.items()]
