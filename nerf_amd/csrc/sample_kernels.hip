@@ -525,7 +525,7 @@ struct ResampleArgs {
 };
 
 #ifndef RS_BLOCKS_PER_CU
-#define RS_BLOCKS_PER_CU 4
+#define RS_BLOCKS_PER_CU 5      /* measured: 3 -> 1.54 ms, 4 -> 1.29 ms, 5 -> 1.20 ms per 640 000 rays (96 VGPRs, 13 spilled; LDS fits 5 at the render shapes) */
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RS_BLOCKS_PER_CU, RS_BLOCKS_PER_CU))) void resample_kernel(ResampleArgs a) {
     const int C = a.C, K = a.K;
