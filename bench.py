@@ -60,8 +60,13 @@ def parse():
     p.add_argument("--rng", default="philox", choices=["philox", "resident"],
                    help="philox = every uniform drawn inside the kernels (no uniform tensor exists: what the drop-in render_image does by "
                         "default); resident = pre-drawn (N,64) + (N,129) uniform tensors resident in HBM before the timed region (round 1)")
-    p.add_argument("--mode", default="render", choices=["render", "train-ddp"],
-                   help="render = the headline; train-ddp = per-rank training steps with the flat gradient all_reduce timed separately")
+    p.add_argument("--mode", default="render", choices=["render", "render-strong", "train-ddp"],
+                   help="render = the headline (weak scaling: one image per rank and step); render-strong = ONE image per step split over the "
+                        "ranks by rays + a final all_gather (strong scaling); train-ddp = per-rank training steps with the flat gradient "
+                        "all_reduce timed separately")
+    p.add_argument("--ipe", action="store_true", help="train-ddp: integrated PE in the fine pass (BASELINE configs[2])")
+    p.add_argument("--contract", action="store_true", help="train-ddp: Mip-NeRF 360 scene contraction, unbounded near/far (BASELINE configs[4])")
+    p.add_argument("--hipgraph", action="store_true", help="train-ddp: replay the step (collective included) from a hipGraph")
     p.add_argument("--train-rays", type=int, default=16384, help="rays per rank and step in --mode train-ddp")
     p.add_argument("--launch-check", action="store_true",
                    help="control-flow check of the N-rank launch path only (rendezvous, world size, barrier, max-over-ranks): no GPU work")
@@ -255,11 +260,14 @@ def iteration_rate(precision, n_rays=512, iters=200):
 
 def train_ddp(a, dist, world, rank, dev, backend):
     """--mode train-ddp: what ddp_train.py's inner loop does per iteration (ddp_train.py:66-68,98: forward, backward, gradient
-    all-reduce, optimizer step), one rank per GPU, `--train-rays` rays per rank (weak scaling).  The ONE flat all_reduce of both
-    networks' gradients (nerf_amd/parallel.py) is bracketed by its own events and reported separately from the compute."""
+    all-reduce, optimizer step), one rank per GPU, `--train-rays` rays per rank (weak scaling).  The gradients of BOTH networks live in
+    one persistent flat buffer the weight-gradient kernels write into (nerf_amd.parallel.FlatGradients); the ONE all_reduce over it is
+    bracketed by its own events and reported separately.  --ipe / --contract: BASELINE configs[2] / configs[4] (integrated PE in the
+    fine pass / scene contraction with unbounded depths); --hipgraph: the step incl. the RCCL collective replayed from a hipGraph."""
+    import math
     import torch.nn.functional as F
     import nerf_amd
-    from nerf_amd import parallel
+    from nerf_amd import ops, parallel
     from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
     from nerf_amd.mip_methods import maxBlurFilter
     from nerf_amd.mip_model import MipNeRF
@@ -267,53 +275,77 @@ def train_ddp(a, dist, world, rank, dev, backend):
     from nerf_amd.utils import inverseSample
     nerf_amd.set_precision(a.precision)
     n_rays, c_n, f_n = a.train_rays, C_COARSE, N_FINE
+    near, far = (0.2, 30.0) if a.contract else (NEAR, FAR)
     torch.manual_seed(0)                                              # same initial weights on every rank ...
     prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
     if dist is not None:
         parallel.broadcast_parameters([mip, prop], src=0)             # ... and made sure of (ddp_train.py:98 DDP does this at wrap time)
     from nerf_amd.optim import Adam                                   # torch.optim.Adam's update as one HIP launch
-    opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4)
+    opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-4, lr_on_device=a.hipgraph)
+    flat = parallel.FlatGradients([mip, prop], opt)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)          # every rank draws its own rays
-    o = torch.tensor([0.0, 0.0, 4.0], device=dev).expand(n_rays, 3)
+    o = torch.tensor([0.0, 0.0, 0.5 if a.contract else 4.0], device=dev).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3, device=dev, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0], device=dev), dim=-1)
     rays = torch.cat((o, d), -1).contiguous()
     tgt = torch.rand(n_rays, 3, device=dev, generator=g)
-    res = (FAR - NEAR) / c_n
-    base = torch.linspace(NEAR, FAR - res, c_n).to(dev)
+    res = (far - near) / c_n
+    base = torch.linspace(near, far - res, c_n).to(dev)
+    radius = 2.0 / math.sqrt(12.0) / 1111.0 if a.ipe else None        # pixel footprint of an 800x800 Lego camera (focal 1111)
+    dir_norm = ops.dirs_norm(rays) if a.ipe else None
+    seed_dev = torch.full((1,), 1234 + rank, dtype=torch.int64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    n_grad = sum(p.numel() for p in list(mip.parameters()) + list(prop.parameters()))
+    n_grad = flat.flat.numel()
+    ploss = ProposalLoss()
 
     def step(timed_idx=None):
-        z_c = base + torch.rand((n_rays, c_n), device=dev, generator=g) * res
+        u_c = ops.philox_uniforms((n_rays, c_n), seed_dev=seed_dev)   # (device-resident seed: nothing in the step reads host state)
+        z_c = base + u_c * res
         pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
-        dens = F.softplus(prop.forward(pts))
+        dens = F.softplus(prop.forward(pts, contract=a.contract))
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
-        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device=dev, generator=g))
-        z_f = z_f[..., :-1].contiguous()
-        rgbo = mip.forward(NeRF.length2pts(rays, z_f))
+        ops.advance_seed(seed_dev)
+        z_all, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=ops.philox_uniforms((n_rays, f_n + 1), seed_dev=seed_dev))
+        z_f = z_all[..., :-1].contiguous()
+        if a.ipe:
+            rgbo = mip.forward_rays(rays, z_all, f_n, ipe_radius=radius, ipe_dir_norm=dir_norm, contract=a.contract)
+        elif a.contract:
+            rgbo = mip.forward_rays(rays, z_f, f_n, contract=True)
+        else:
+            rgbo = mip.forward(NeRF.length2pts(rays, z_f))
         rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
-        loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
-        opt.zero_grad()
+        loss = ploss(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+        flat.begin_step()                                             # (the gradient kernels overwrite the flat buffer: no zeroing pass)
         loss.backward()
-        if dist is not None:
-            if timed_idx is not None:
-                ev[timed_idx][0].record()
-            parallel.allreduce_gradients([mip, prop])
-            if timed_idx is not None:
-                ev[timed_idx][1].record()
+        if timed_idx is not None:
+            ev[timed_idx][0].record()
+        flat.all_reduce()                                             # ONE collective (no-op without a process group)
+        if timed_idx is not None:
+            ev[timed_idx][1].record()
         opt.step()
+        ops.advance_seed(seed_dev)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    graph = None
+    for _ in range(max(a.warmup, 2 if a.hipgraph else 0)):
         step()
+    if a.hipgraph:
+        if dist is not None and backend != "nccl":
+            sys.exit("bench.py: --hipgraph needs the RCCL backend (a gloo collective cannot be captured)")
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dist is not None else {})):
+            step()
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(i)
+        if graph is not None:
+            graph.replay()
+        else:
+            step(i)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -321,19 +353,84 @@ def train_ddp(a, dist, world, rank, dev, backend):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        ar_us = (sum(s.elapsed_time(e) for s, e in ev) / a.steps * 1e3) if dist is not None else 0.0
+        ar_us = (sum(s.elapsed_time(e) for s, e in ev) / a.steps * 1e3) if (dist is not None and graph is None) else None
         flop_per_ray = 3 * FLOP_PER_RAY                                  # forward + dgrad + wgrad
+        variant = ("Mip-NeRF + integrated PE (BASELINE configs[2])" if a.ipe else "NeRF / Mip-NeRF point PE") + (", scene contraction, near/far 0.2/30 (configs[4])" if a.contract else "")
         rec = {"metric": "training rays/s (64+128 samples, fwd + bwd + gradient all_reduce + Adam)", "value": world * a.steps * n_rays / dt,
                "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
                "data": "synthetic",
-               "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, MipNeRF(10,4,256) + ProposalNetwork(10,256)" % n_rays,
+               "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, MipNeRF(10,4,256) + ProposalNetwork(10,256); %s%s"
+                                      % (n_rays, variant, "; step replayed from a hipGraph (collective inside)" if graph is not None else ""),
                           "rays_per_step_per_gpu": n_rays, "parallelism": "ray-sharded replicas (dp%d), one flat gradient all_reduce per step" % world},
                "allreduce": {"elements": n_grad, "bytes": 4 * n_grad, "us_per_step": ar_us, "backend": backend if dist is not None else None,
-                             "note": "torch.cat of the gradients + ONE all_reduce(SUM) + divide + copy back (nerf_amd/parallel.py), HIP events on the compute stream"},
+                             "note": "ONE all_reduce(AVG) on the persistent flat gradient buffer the weight-gradient kernels write into "
+                                     "(nerf_amd/parallel.py FlatGradients; no cat / copy-back); HIP events on the compute stream"},
                "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flops)", "achieved": world * a.steps * n_rays * flop_per_ray / dt / 1e12 / world,
                             "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s", "frac": a.steps * n_rays * flop_per_ray / dt / PEAK_BF16_DENSE, "traffic": None}}
         print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def render_strong(a, dist, world, rank, dev, backend):
+    """--mode render-strong: ONE 800x800 image per step, its 640 000 rays split into `world` contiguous shards (no collective on
+    the data path), every uniform drawn in-kernel as a function of the GLOBAL ray index -- so the image does not depend on N -- and one
+    all_gather of rgb + depth (16 B/ray) at the end of the step.  value = image rays / max-over-ranks time; "scaling": "strong"."""
+    import weights as Wt
+    from nerf_amd import ops, parallel
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.utils import fov2Focal, pose_spherical
+    prec = ops.BF16 if a.precision == "bf16" else ops.F32
+    prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
+    prop.load_state_dict(Wt.proposal_state("small")); mip.load_state_dict(Wt.mip_state("small"))
+    prop, mip = prop.to(dev).eval(), mip.to(dev).eval()
+    pk_prop, pk_mip = prop.packed(prec), mip.packed(prec)
+    n = H * W
+    focal = fov2Focal(0.6911112070083618, (H, W))
+    fx, fy = float(focal[1]), float(focal[0])
+    start, end = parallel.shard_range(n, rank, world, align=256)
+    cnt = end - start
+    z_base = torch.linspace(NEAR, FAR, C_COARSE).to(dev)
+    poses = [pose_spherical(float(th), -30.0, 4.0)[:3] for th in torch.linspace(-180, 180, 41)[:-1]]
+    ws = None
+
+    def step(i):
+        nonlocal ws
+        rays = ops.generate_rays(poses[i % len(poses)], H, W, fx, fy, dev, start, cnt)
+        rgb, depth, _, ws = ops.render_rays(pk_prop, pk_mip, prec, rays, z_base, None, None, N_FINE, NEAR, FAR, True, want_depth=True, workspace=ws,
+                                            seed=0x5EED0000 + i, rng_ray_offset=start)
+        out = torch.cat((rgb, depth[:, None]), -1)
+        return parallel.gather_shards(out, n, 256) if dist is not None else out
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        img = step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert img.shape == (n, 4) and bool(torch.isfinite(img).all())
+    if rank == 0:
+        print(json.dumps({"metric": "rays/s (64+128 samples), 800x800, one image split over the ranks", "value": a.steps * n / dt, "unit": "rays/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[1] image (800x800, 64+128 samples, rows 1-10) rendered ONCE per step by all ranks together: "
+                                                 "contiguous 256-aligned ray shards, in-kernel Philox uniforms keyed by the global ray index, one all_gather of "
+                                                 "rgb + depth (16 B/ray) per image", "rays_per_step": n, "parallelism": "ray-sharded (dp%d), strong scaling" % world},
+                          "gather": {"bytes_per_image": 16 * n, "backend": backend if dist is not None else None},
+                          "whole_path_tflops": a.steps * n * FLOP_PER_RAY / dt / 1e12}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -366,6 +463,8 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     if a.mode == "train-ddp":
         return train_ddp(a, dist, world, rank, dev, backend)
+    if a.mode == "render-strong":
+        return render_strong(a, dist, world, rank, dev, backend)
 
     import weights as Wt
     from nerf_amd import ops

@@ -61,6 +61,23 @@ class PackedWeightsMixin:
         return ([g[: l.weight.shape[0], : l.weight.shape[1]] if tuple(g.shape) != tuple(l.weight.shape) else g for g, l in zip(gW, layers)],
                 [g[: l.bias.shape[0]] if tuple(g.shape) != tuple(l.bias.shape) else g for g, l in zip(gb, layers)])
 
+    # ---- persistent gradient sinks ---------------------------------------------------------------------------------------------------
+    # nerf_amd.parallel.FlatGradients keeps ONE flat fp32 buffer over the parameters of both networks and makes every `p.grad` a view of
+    # it.  A module it is attached to has its weight-gradient kernels write straight into those views (the finalize kernels overwrite
+    # every element) and reports "no gradient" to autograd: no per-tensor accumulate launches, no torch.cat before the all-reduce, and the
+    # optimizer walks the same buffer.  Modules wrapped in DistributedDataParallel are NOT attached: there autograd must see the gradients
+    # (DDP's hooks hang off the AccumulateGrad nodes).
+    def grad_sinks(self):
+        """-> (weight views, bias views, overwrite?) or None (not attached / zero-padded narrow network: the ordinary autograd path)"""
+        owner = self.__dict__.get("_grad_owner")
+        if owner is None:
+            return None
+        layers = self._linear_layers()
+        shapes = self._kernel_weight_shapes()
+        if shapes is not None and any(tuple(l.weight.shape) != tuple(sh) for l, sh in zip(layers, shapes)):
+            return None
+        return owner.sinks_for(self, layers)
+
     def _pack_now(self, precision: int) -> torch.Tensor:
         ws, bs = self.kernel_params()
         return ops.pack_weights(self._net_id, precision, ws, bs)

@@ -44,6 +44,7 @@ class LossPSNR(nn.Module):
 
 class ProposalNetwork(PackedWeightsMixin, nn.Module):
     _net_id = ops.NET_PROPOSAL
+    _supports_grad_sinks = True          # the weight-gradient kernels can write into parallel.FlatGradients views
 
     @staticmethod
     def init_weight(m):
@@ -87,17 +88,18 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         if other_stuff is not None:
             return [save[k] for k in other_stuff]
 
-    def forward(self, pts: torch.Tensor, encoded_pt: torch.Tensor = None) -> torch.Tensor:
+    def forward(self, pts: torch.Tensor, encoded_pt: torch.Tensor = None, contract: bool = False) -> torch.Tensor:
         """pts (N,C,3) -> density (N,C), no activation (addtional.py:88-96).  ``encoded_pt`` (a pre-computed
-        encoding) is accepted for signature parity and ignored: the kernel encodes in-register."""
+        encoding) is accepted for signature parity and ignored: the kernel encodes in-register.  ``contract`` (not in the reference;
+        BASELINE configs[4]): Mip-NeRF 360 scene contraction of the positions before the encoding."""
         self._check_config()
         prec = ops.current_precision()
         layers = self._linear_layers()
         params = [l.weight for l in layers] + [l.bias for l in layers]
         if ab.needs_grad(pts, *params):
-            expr = lambda p, *wb: ab.proposal_expr(p, wb[:5], wb[5:])
+            expr = lambda p, *wb: ab.proposal_expr(ab.contract_expr(p) if contract else p, wb[:5], wb[5:])
             if pts.numel() == 0:
-                hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p)
+                hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p, contract=contract)
                 return ab.HipOp.apply(hip, expr, 0, pts, *params)
             # the training forward dumps the hidden activations; the backward is hand-written kernels on them:
             #   parameter gradients: fused dgrad chain + MFMA weight gradients (mlp_backward.py);
@@ -107,7 +109,7 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
             held = {}
 
             def hip(p, *wb):
-                out, held["dump"] = ops.proposal_forward_train(self.packed(prec), prec, p)
+                out, held["dump"] = ops.proposal_forward_train(self.packed(prec), prec, p, contract=contract)
                 return out
 
             def bwd(g, p, *wb):
@@ -116,13 +118,23 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
                 if "bwd_blob" not in held:
                     held["bwd_blob"] = self.packed_backward(prec)
                 if ab._VJP.inputs_only:
+                    if contract:
+                        raise NotImplementedError("nerf_amd: density-gradient normals of contracted positions are not built")
                     gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1))
                     return (gx.view(p.shape), *[None] * len(wb))
-                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, wb[:5], packed_bwd=held["bwd_blob"])
+                sinks = self.grad_sinks()                                # persistent flat gradient buffer (parallel.FlatGradients)?
+                direct = sinks is not None and sinks[2]
+                kw = wb[:5]
+                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, kw, packed_bwd=held["bwd_blob"],
+                                                        out=(sinks[0], sinks[1]) if direct else None)
+                if sinks is not None:
+                    if not direct:                                       # a second backward in the same step accumulates
+                        torch._foreach_add_(list(sinks[0]) + list(sinks[1]), list(gW) + list(gb))
+                    return (None, *[None] * len(wb))
                 gW, gb = self.unpad_grads(gW, gb)
                 return (None, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
-        return ops.proposal_forward(self.packed(prec), prec, pts)
+        return ops.proposal_forward(self.packed(prec), prec, pts, contract=contract)
 
     @staticmethod
     def get_weights(density: torch.Tensor, zvals: torch.Tensor, ray_dirs: torch.Tensor = None) -> torch.Tensor:

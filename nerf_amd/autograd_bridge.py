@@ -160,6 +160,14 @@ def _lin_relu(x, w, b):
     return F.relu(_lin(x, w, b))
 
 
+def contract_expr(pts):
+    """Mip-NeRF 360 scene contraction (eq. 10) of the position columns of (..., 3) / (..., 6) samples -- the kernels' `contract` flag."""
+    x = pts[..., :3]
+    n = x.norm(dim=-1, keepdim=True).clamp(min=1.0)                   # inside the unit ball: factor (2 - 1) / 1 = 1
+    xc = x * ((2.0 - 1.0 / n) / n)
+    return torch.cat((xc, pts[..., 3:]), dim=-1) if pts.shape[-1] > 3 else xc
+
+
 def proposal_expr(pts, w, b):
     """ProposalNetwork.forward as torch ops (addtional.py:88-96); w, b = lists in state_dict order."""
     h = torch.cat((pts, _pe(pts, 10)), dim=-1)

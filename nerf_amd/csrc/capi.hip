@@ -341,13 +341,14 @@ int nerf_amd_proposal_forward_train(const void* packed, int precision, const ner
     if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
     if (src->M && !density) return fail(NERF_AMD_EINVAL, "NULL output");
+    if (int c = check_samples(src, false)) return c;
     return hip_status(mlp_launch_proposal_train(packed, precision, *src, density, dump, S(stream)), "nerf_amd_proposal_forward_train");
 }
 int nerf_amd_mip_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* dump, void* stream) {
     if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
     if (src->M && !rgbo) return fail(NERF_AMD_EINVAL, "NULL output");
-    if (src->ipe) return fail(NERF_AMD_EUNSUPPORTED, "integrated PE has no training forward");
+    if (int c = check_samples(src, true)) return c;         // (every sample mode, integrated PE and scene contraction included)
     return hip_status(mlp_launch_mip_train(packed, precision, *src, rgbo, dump, S(stream)), "nerf_amd_mip_forward_train");
 }
 int nerf_amd_train_dump_to_rows(const void* dump, int net, int precision, int64_t M, int layer, int n_features, void* out, void* stream) {

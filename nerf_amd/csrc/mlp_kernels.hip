@@ -896,7 +896,12 @@ using PB16 = PBF16W;
 
 }  // namespace
 
-// host-visible launchers (capi.hip)
+// host-visible launchers (capi.hip).  The file is compiled three times (Makefile: -DMLP_TU=1 proposal, 2 MipNeRF, 3 Ref-NeRF; undefined
+// = everything) so that the three kernel families build in parallel -- one instance of the fine kernel alone takes a minute of hipcc.
+#ifndef MLP_TU
+#define MLP_TU 0
+#endif
+#if MLP_TU == 0 || MLP_TU == 1
 int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
 #ifdef MLP_PROP_NARROW                                   // A/B knob: the 8-wave x 32-sample tile for the (inference) proposal kernel only
     if (precision == NERF_AMD_BF16) return launch<PBF16, PropLayout>(proposal_kernel<PBF16, false>, packed, s, density, st, NO_DUMP);
@@ -904,6 +909,8 @@ int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_sample
     if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16, false>, packed, s, density, st, NO_DUMP);
     return launch<PF32, PropLayout>(proposal_kernel<PF32, false>, packed, s, density, st, NO_DUMP);
 }
+#endif
+#if MLP_TU == 0 || MLP_TU == 2
 int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
     if (s.ipe) {                                            // integrated positional encoding (validated by the C-ABI: mode 1, z, dir norm)
@@ -920,7 +927,9 @@ int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_s
     if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
     return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
 }
+#endif
 // training forwards: the same kernels, also dumping the hidden activations (ActDump) for the backward
+#if MLP_TU == 0 || MLP_TU == 1
 size_t mlp_train_layer_stride(int precision, int64_t M) {
     const int64_t ts = (precision == NERF_AMD_BF16) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;
     const int64_t n_sub = ((M + ts - 1) / ts) * (ts / 32);
@@ -928,22 +937,36 @@ size_t mlp_train_layer_stride(int precision, int64_t M) {
 }
 // the ReLU bit masks sit behind the `slots` activation slots of a dump: 1 KiB per slot and subtile
 size_t mlp_train_mask_stride(int precision, int64_t M) { return mlp_train_layer_stride(precision, M) / (16 * (precision == NERF_AMD_BF16 ? 1024 : 2048)) * 1024; }
+#else
+size_t mlp_train_layer_stride(int precision, int64_t M);
+size_t mlp_train_mask_stride(int precision, int64_t M);
+#endif
 static ActDump make_dump(void* dump, int precision, int64_t M, int slots) {
     const unsigned long long ls = mlp_train_layer_stride(precision, M);
     return ActDump{reinterpret_cast<char*>(dump), ls, reinterpret_cast<char*>(dump) + (size_t)slots * ls, (unsigned long long)mlp_train_mask_stride(precision, M)};
 }
+#if MLP_TU == 0 || MLP_TU == 1
 int mlp_launch_proposal_train(const void* packed, int precision, const nerf_amd_samples& s, float* density, void* dump, hipStream_t st) {
     const ActDump d = make_dump(dump, precision, s.M, PROP_DUMP_SLOTS);
     if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout, true>(proposal_kernel<PB16, true>, packed, s, density, st, d);
     return launch<PF32, PropLayout, true>(proposal_kernel<PF32, true>, packed, s, density, st, d);
 }
+#endif
+#if MLP_TU == 0 || MLP_TU == 2
 int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, void* dump, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
     const ActDump d = make_dump(dump, precision, s.M, MIP_DUMP_SLOTS);
+    if (s.ipe) {                                            // integrated PE on the training path (BASELINE configs[2]): the dumped encoding slot
+        // holds the IPE features in the PE10 slot map, so the dgrad chain and the weight-gradient kernels run unchanged
+        if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout, true>(mip_kernel<PB16, true, true>, packed, s, rgbo, st, off, d);
+        return launch<PF32, MipLayout, true>(mip_kernel<PF32, true, true>, packed, s, rgbo, st, off, d);
+    }
     if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout, true>(mip_kernel<PB16, true>, packed, s, rgbo, st, off, d);
     return launch<PF32, MipLayout, true>(mip_kernel<PF32, true>, packed, s, rgbo, st, off, d);
 }
 
+#endif
+#if MLP_TU == 0 || MLP_TU == 3
 template <class P, bool TRAIN>
 static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise, ActDump dump, float* aux,
                       int flags, hipStream_t st) {
@@ -967,3 +990,4 @@ int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_sampl
     if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
     return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
 }
+#endif

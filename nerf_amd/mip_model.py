@@ -13,6 +13,7 @@ from .nerf_helper import makeMLP
 
 class MipNeRF(PackedWeightsMixin, NeRF):
     _net_id = ops.NET_MIP
+    _supports_grad_sinks = True          # the weight-gradient kernels can write into parallel.FlatGradients views
 
     def __init__(self, position_flevel, direction_flevel, hidden_unit=256, cat_origin=True) -> None:
         super().__init__(position_flevel, cat_origin)
@@ -43,41 +44,77 @@ class MipNeRF(PackedWeightsMixin, NeRF):
     def _kernel_weight_shapes(self):
         return [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (256, 256), (1, 256), (128, 283), (3, 128)]
 
-    def forward(self, pts: torch.Tensor) -> torch.Tensor:
-        """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60)."""
+    def _params(self):
+        layers = self._linear_layers()
+        return [l.weight for l in layers] + [l.bias for l in layers]
+
+    def _train_op(self, prec, run_forward, spec, *tensors):
+        """Training forward (activation dump) + the hand-written backward on it (mlp_backward.py) as one autograd node.  `run_forward()`
+        -> (rgbo, dump); `spec` = the torch expression the backward is tested against (never evaluated here: a shape the kernels
+        cannot differentiate raises instead of falling back to library GEMMs)."""
+        from . import mlp_backward
+        held = {}
+        n_in = len(tensors)
+
+        def hip(*args):
+            out, held["dump"] = run_forward()
+            held["out"] = out
+            return out
+
+        def bwd(g, *args):
+            if "dump" not in held:
+                raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
+            kw, kb = self.kernel_params()
+            sinks = self.grad_sinks()                                    # persistent flat gradient buffer (parallel.FlatGradients)?
+            direct = sinks is not None and sinks[2]
+            gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), None, held.pop("dump"), prec,
+                                               kw, kb, packed_bwd=ops.pack_weights_backward(ops.NET_MIP, prec, kw),
+                                               out=(sinks[0], sinks[1]) if direct else None)
+            if sinks is not None:
+                if not direct:                                           # a second backward in the same step accumulates
+                    torch._foreach_add_(list(sinks[0]) + list(sinks[1]), list(gW) + list(gb))
+                return (*[None] * (n_in + len(gW) + len(gb)),)
+            gW, gb = self.unpad_grads(gW, gb)
+            return (*[None] * n_in, *gW, *gb)
+        return ab.HipOp.apply(hip, ab.with_hip_backward(spec, bwd), 0, *tensors, *self._params())
+
+    def forward(self, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
+        """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60).
+        `contract` (not in the reference; BASELINE configs[4]): Mip-NeRF 360 scene contraction of the positions before the encoding."""
         self._check_config()
         prec = ops.current_precision()
-        layers = self._linear_layers()
-        params = [l.weight for l in layers] + [l.bias for l in layers]
+        params = self._params()
         if ab.needs_grad(pts, *params):
-            n = len(layers)
-            expr = lambda p, *wb: ab.mip_expr(p, wb[:n], wb[n:])
+            n = len(params) // 2
+            expr = lambda p, *wb: ab.mip_expr(ab.contract_expr(p) if contract else p, wb[:n], wb[n:])
             if pts.requires_grad or pts.numel() == 0:                      # (gradients w.r.t. positions: torch VJP of the expression)
-                hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p)
+                hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p, contract=contract)
                 return ab.HipOp.apply(hip, expr, 0, pts, *params)
             # parameter gradients: the training forward dumps the hidden activations, the backward is hand-written kernels on them (mlp_backward.py)
-            from . import mlp_backward
-            held = {}
+            return self._train_op(prec, lambda: ops.mip_forward_train(self.packed(prec), prec, pts.detach(), contract=contract), expr, pts)
+        return ops.mip_forward(self.packed(prec), prec, pts, contract=contract)
 
-            def hip(p, *wb):
-                out, held["dump"] = ops.mip_forward_train(self.packed(prec), prec, p)
-                held["out"] = out
-                return out
-
-            def bwd(g, p, *wb):
-                if "dump" not in held:
-                    raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
-                kw, kb = self.kernel_params()
-                gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), p.reshape(-1, 6), held.pop("dump"), prec,
-                                                   kw, kb, packed_bwd=ops.pack_weights_backward(ops.NET_MIP, prec, kw))
-                gW, gb = self.unpad_grads(gW, gb)
-                return (None, *gW, *gb)
-            return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
-        return ops.mip_forward(self.packed(prec), prec, pts)
-
-    def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int) -> torch.Tensor:
-        """Same as ``forward(NeRF.length2pts(rays, z[:, :n_samples]))`` without materialising the points."""
+    def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int, ipe_radius=None, ipe_dir_norm: torch.Tensor = None,
+                     contract: bool = False) -> torch.Tensor:
+        """Same as ``forward(NeRF.length2pts(rays, z[:, :n_samples]))`` without materialising the points -- and the entry of the two
+        sample-fetch modes the reference has no caller for:
+          * `ipe_radius` (BASELINE configs[2]): integrated PE (mip_methods.py:15-58) of the `n_samples` conical frusta between consecutive
+            depths (z has >= n_samples + 1 columns); `ipe_dir_norm` = ops.dirs_norm(rays) (default: computed here);
+          * `contract` (configs[4]): scene contraction of the sample positions (of the frustum means with IPE).
+        Differentiable w.r.t. the parameters (training forward + HIP backward); rays and depths carry no gradient, like the reference's
+        detached fine depths (utils.py:35-36)."""
         self._check_config()
         prec = ops.current_precision()
-        s = ops.samples_rays(rays, n_samples, z=z)
-        return ops.mip_forward_samples(self.packed(prec), prec, s, (rays.shape[0], n_samples), rays.device)
+        if rays.requires_grad or z.requires_grad:
+            raise NotImplementedError("nerf_amd: MipNeRF.forward_rays differentiates the parameters only (rays / depths must not require grad)")
+        rays, z = ops._dev(rays, "rays"), ops._dev(z, "z")
+        if ipe_radius is not None and ipe_dir_norm is None:
+            ipe_dir_norm = ops.dirs_norm(rays)
+        s = ops.samples_rays(rays, n_samples, z=z, contract=contract, ipe_radius=ipe_radius, ipe_dir_norm=ipe_dir_norm)
+        shape = (rays.shape[0], n_samples)
+        if ab.needs_grad(*self._params()) and rays.shape[0] > 0:
+            def spec(*a):
+                raise NotImplementedError("nerf_amd: MipNeRF.forward_rays has a HIP backward only")
+            keep = (rays, z, ipe_dir_norm)                               # the descriptor holds raw pointers: keep the tensors alive
+            return self._train_op(prec, lambda: (ops.mip_forward_train_samples(self.packed(prec), prec, s, shape, rays.device), keep)[0], spec)
+        return ops.mip_forward_samples(self.packed(prec), prec, s, shape, rays.device)

@@ -19,21 +19,22 @@ from . import ops
 
 
 def proposal_backward(g_density: torch.Tensor, pts: torch.Tensor, dump: torch.Tensor, precision: int, weights: Sequence[torch.Tensor],
-                      packed_bwd: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-    """g_density (M,), pts (M,3) [unused: the encoding operand is in the dump], weights = layers.{0,2,4,6,8}.weight -> ([dW]*5, [db]*5)"""
+                      packed_bwd: Optional[torch.Tensor] = None, out=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """g_density (M,), pts (M,3) [unused: the encoding operand is in the dump], weights = layers.{0,2,4,6,8}.weight -> ([dW]*5, [db]*5);
+    `out` = (weight sinks, bias sinks) to write instead of fresh tensors"""
     M = g_density.numel()
     if packed_bwd is None:
         packed_bwd = ops.pack_weights_backward(ops.NET_PROPOSAL, precision, weights)
     delta = ops.proposal_backward_chain(packed_bwd, precision, g_density, dump)
-    return ops.proposal_weight_grads(precision, M, dump, delta)
+    return ops.proposal_weight_grads(precision, M, dump, delta, out=out)
 
 
 def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, dump: torch.Tensor, precision: int,
                  weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-                 packed_bwd: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-    """g_rgbo, rgbo (M,4); weights/biases in MipNeRF._linear_layers() order -> ([dW]*11, [db]*11)"""
+                 packed_bwd: Optional[torch.Tensor] = None, out=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """g_rgbo, rgbo (M,4); weights/biases in MipNeRF._linear_layers() order -> ([dW]*11, [db]*11); `out` as in proposal_backward"""
     M = g_rgbo.numel() // 4
     if packed_bwd is None:
         packed_bwd = ops.pack_weights_backward(ops.NET_MIP, precision, weights)
     delta = ops.mip_backward_chain(packed_bwd, precision, g_rgbo, rgbo, dump)
-    return ops.mip_weight_grads(precision, M, dump, delta, weights, biases)
+    return ops.mip_weight_grads(precision, M, dump, delta, weights, biases, out=out)

@@ -556,25 +556,34 @@ def get_bounds_backward(below: torch.Tensor, d_bounds: torch.Tensor, n_coarse: i
 NET_PROPOSAL, NET_MIP = 0, 1
 
 
-def _train_forward(net: int, packed: torch.Tensor, precision: int, pts: torch.Tensor, width: int, out_shape):
-    pts = _dev(pts, "pts")
-    M = pts.numel() // width
-    out = torch.empty(out_shape, dtype=torch.float32, device=pts.device)
-    dump = torch.empty((lib.nerf_amd_train_dump_bytes(net, precision, M),), dtype=torch.uint8, device=pts.device)
-    if M:
-        s = _samples_pts(pts, width)
+def _train_forward_samples(net: int, packed: torch.Tensor, precision: int, s: Samples, out_shape, device):
+    out = torch.empty(out_shape, dtype=torch.float32, device=device)
+    dump = torch.empty((lib.nerf_amd_train_dump_bytes(net, precision, s.M),), dtype=torch.uint8, device=device)
+    if s.M:
         fn = lib.nerf_amd_proposal_forward_train if net == NET_PROPOSAL else lib.nerf_amd_mip_forward_train
         check(fn(_ptr(packed), precision, C.byref(s), _ptr(out), _ptr(dump), _stream()), "nerf_amd_*_forward_train")
     return out, dump
 
 
-def proposal_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor):
+def proposal_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, contract: bool = False):
     """Same result as proposal_forward plus the activation dump the backward needs."""
-    return _train_forward(NET_PROPOSAL, packed, precision, pts, 3, pts.shape[:-1])
+    pts = _dev(pts, "pts")
+    return _train_forward_samples(NET_PROPOSAL, packed, precision, _samples_pts(pts, 3, contract), pts.shape[:-1], pts.device)
 
 
-def mip_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor):
-    return _train_forward(NET_MIP, packed, precision, pts, 6, pts.shape[:-1] + (4,))
+def mip_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, contract: bool = False):
+    pts = _dev(pts, "pts")
+    return _train_forward_samples(NET_MIP, packed, precision, _samples_pts(pts, 6, contract), pts.shape[:-1] + (4,), pts.device)
+
+
+def mip_forward_train_samples(packed: torch.Tensor, precision: int, s: Samples, shape, device):
+    """Training forward on a samples descriptor (rays + depths: positions formed in the kernel; integrated PE and scene contraction are
+    flags of the descriptor, samples_rays) -> (rgbo (*shape, 4), dump)."""
+    return _train_forward_samples(NET_MIP, packed, precision, s, tuple(shape) + (4,), device)
+
+
+def proposal_forward_train_samples(packed: torch.Tensor, precision: int, s: Samples, shape, device):
+    return _train_forward_samples(NET_PROPOSAL, packed, precision, s, tuple(shape), device)
 
 
 def train_dump_rows(dump: torch.Tensor, net: int, precision: int, M: int, layer: int, n_features: int) -> torch.Tensor:
@@ -666,24 +675,44 @@ def _grad_buffers(shapes, device):
     return out
 
 
-def proposal_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Tensor):
-    """-> ([dW of layers.{0,2,4,6,8}], [db ...]) in the reference's (out, in) layout."""
+def _check_sinks(sinks, shapes, what):
+    for t, sh in zip(sinks, shapes):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(sh)):
+            raise RuntimeError("nerf_amd: %s gradient sink must be a contiguous fp32 device tensor of shape %s" % (what, tuple(sh)))
+
+
+PROP_W_SHAPES = [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]
+
+
+def proposal_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Tensor, out=None):
+    """-> ([dW of layers.{0,2,4,6,8}], [db ...]) in the reference's (out, in) layout.  `out` = (weight sinks, bias sinks): existing
+    tensors (e.g. views of one persistent flat gradient buffer, nerf_amd.parallel.FlatGradients) the kernels write instead of fresh ones."""
     dev = dump.device
-    gw = _grad_buffers([(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)], dev)
-    gb = _grad_buffers([(256,), (256,), (256,), (256,), (1,)], dev)
+    if out is not None:
+        gw, gb = list(out[0]), list(out[1])
+        _check_sinks(gw, PROP_W_SHAPES, "proposal weight"); _check_sinks(gb, [(s[0],) for s in PROP_W_SHAPES], "proposal bias")
+    else:
+        gw = _grad_buffers(PROP_W_SHAPES, dev)
+        gb = _grad_buffers([(s[0],) for s in PROP_W_SHAPES], dev)
     ws = torch.empty(lib.nerf_amd_weight_grads_workspace_bytes(NET_PROPOSAL, precision, M), dtype=torch.uint8, device=dev)
     check(lib.nerf_amd_proposal_weight_grads(precision, M, _ptr(dump), _ptr(delta), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()),
           "nerf_amd_proposal_weight_grads")
     return gw, gb
 
 
-def mip_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]):
-    """-> ([dW], [db]) in MipNeRF._linear_layers() order; `weights` / `biases` are needed to un-fold bottle_neck.0 / rgb_layer.0."""
+def mip_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+                     out=None):
+    """-> ([dW], [db]) in MipNeRF._linear_layers() order; `weights` / `biases` are needed to un-fold bottle_neck.0 / rgb_layer.0.
+    `out` = (weight sinks, bias sinks) as in proposal_weight_grads."""
     dev = dump.device
     w = [_dev(t.detach(), "weight") for t in weights]
     b = [_dev(t.detach(), "bias") for t in biases]
-    gw = _grad_buffers([tuple(t.shape) for t in w], dev)
-    gb = _grad_buffers([tuple(t.shape) for t in b], dev)
+    if out is not None:
+        gw, gb = list(out[0]), list(out[1])
+        _check_sinks(gw, [t.shape for t in w], "MipNeRF weight"); _check_sinks(gb, [t.shape for t in b], "MipNeRF bias")
+    else:
+        gw = _grad_buffers([tuple(t.shape) for t in w], dev)
+        gb = _grad_buffers([tuple(t.shape) for t in b], dev)
     ws = torch.empty(lib.nerf_amd_weight_grads_workspace_bytes(NET_MIP, precision, M), dtype=torch.uint8, device=dev)
     check(lib.nerf_amd_mip_weight_grads(precision, M, _ptr(dump), _ptr(delta), _ptr_array(w), _ptr_array(b), _ptr_array(gw), _ptr_array(gb),
                                         _ptr(ws), _stream()), "nerf_amd_mip_weight_grads")

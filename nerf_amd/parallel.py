@@ -63,6 +63,99 @@ def allreduce_gradients(modules: Sequence[torch.nn.Module], group=None, average:
     return off
 
 
+class FlatGradients:
+    """ONE persistent flat fp32 gradient buffer over the parameters of `modules` (fine AND proposal network: 744 069 elements = 2.98 MB);
+    every ``p.grad`` is a view of it for the lifetime of the object.
+
+    * the weight-gradient kernels of attached nerf_amd modules write straight into the views (``PackedWeightsMixin.grad_sinks``): the
+      backward has no per-tensor accumulate launches and nothing is ever concatenated or copied back;
+    * ``all_reduce()`` is ONE collective on the buffer (ddp_train.py:98 reduces per bucket through DDP's hooks; the reference leaves the
+      proposal network un-reduced, ddp_train.py:97-99 -- both are reduced here, deviation noted in DESIGN.md).  RCCL: ReduceOp.AVG, one
+      launch; gloo (CPU tests / two ranks on one GPU): SUM + one scale.  The call uses no host state, so a training step that contains
+      it is captured into a hipGraph like any other (``nerf_amd.training.TrainStep(flat_grads=...)``);
+    * ``nerf_amd.optim.Adam`` (or any optimizer) reads the same views.
+
+    ``begin_step()`` opens a new accumulation window (the first backward of a module in a window OVERWRITES its gradients -- no zeroing
+    pass --, further ones add); it runs automatically after every ``optimizer.step()`` of an optimizer passed as `optimizer`.  Gradients
+    arriving through ordinary autograd (a RefNeRF, a zero-padded narrow network, any other module in `modules`) accumulate into the
+    views as usual; those ranges are zeroed by ``begin_step()``."""
+
+    def __init__(self, modules: Sequence[torch.nn.Module], optimizer: Optional[torch.optim.Optimizer] = None, group=None):
+        self.modules = list(modules)
+        self.group = group
+        self.params: List[torch.nn.Parameter] = [p for m in self.modules for p in m.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradients: no trainable parameters")
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError("FlatGradients: parameters must be fp32 on one device")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, off = {}, 0
+        for p in self.params:
+            n = p.numel()
+            self.views[p] = self.flat[off: off + n].view_as(p)
+            off += n
+        self._fresh, self._autograd_views = {}, []
+        for m in self.modules:
+            direct = getattr(m, "_supports_grad_sinks", False)
+            if direct:
+                m.__dict__["_grad_owner"] = self
+                direct = m.grad_sinks() is not None                      # (None: a zero-padded narrow network -> ordinary autograd path)
+                if not direct:
+                    m.__dict__.pop("_grad_owner", None)
+            if direct:
+                self._fresh[m] = True
+            else:                                                        # gradients arrive through autograd's accumulate: zeroed per window
+                self._autograd_views += [self.views[p] for p in m.parameters() if p.requires_grad]
+        self.bind()
+        self.begin_step()
+        if optimizer is not None:
+            optimizer.register_step_post_hook(lambda *_: self.begin_step())
+
+    def bind(self) -> None:
+        """(re-)point every p.grad at its view -- e.g. after a zero_grad(set_to_none=True)"""
+        for p in self.params:
+            if p.grad is not self.views[p]:
+                p.grad = self.views[p]
+
+    def begin_step(self) -> None:
+        for m in self._fresh:
+            self._fresh[m] = True
+        if self._autograd_views:
+            torch._foreach_zero_(self._autograd_views)
+
+    def sinks_for(self, module, layers):
+        """(weight views, bias views, overwrite?) of an attached module -- called by its backward"""
+        first = self._fresh.get(module, False)
+        self._fresh[module] = False
+        for l in layers:
+            if l.weight.grad is not self.views[l.weight]:
+                l.weight.grad = self.views[l.weight]
+            if l.bias.grad is not self.views[l.bias]:
+                l.bias.grad = self.views[l.bias]
+        return [self.views[l.weight] for l in layers], [self.views[l.bias] for l in layers], first
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+
+    def detach(self) -> None:
+        for m in self.modules:
+            m.__dict__.pop("_grad_owner", None)
+
+    def all_reduce(self, average: bool = True) -> int:
+        """One collective over every gradient; returns the element count.  No-op outside a process group."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return self.flat.numel()
+        world = dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if average else dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if average and world > 1:
+                self.flat.mul_(1.0 / world)
+        return self.flat.numel()
+
+
 def broadcast_parameters(modules: Sequence[torch.nn.Module], src: int = 0, group=None) -> None:
     """Make every rank start from rank `src`'s weights (one flat broadcast)."""
     params = [p for m in modules for p in m.parameters()]

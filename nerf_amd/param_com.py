@@ -16,6 +16,12 @@ def _flat(model: torch.nn.Module) -> torch.Tensor:
     return torch.cat([p.data.reshape(-1) for p in model.parameters()])
 
 
+def _host_staged(flat: torch.Tensor, group) -> bool:
+    """RCCL (backend "nccl": what ddp_train.py / model_average.py initialise) moves device buffers directly.  gloo -- the CPU tests and
+    the two-ranks-on-one-GPU tests -- has no device send / recv / reduce, so there a device buffer is staged through the host."""
+    return flat.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _unflat(model: torch.nn.Module, flat: torch.Tensor) -> None:
     off = 0
     for p in model.parameters():
@@ -34,6 +40,8 @@ def _invalidate(model: torch.nn.Module) -> None:
 def param_send(model, dist_ranks: list, group=None):
     """Send the parameters to specific ranks (param_com.py:13-17)."""
     flat = _flat(model)
+    if _host_staged(flat, group):
+        flat = flat.cpu()
     for rank in dist_ranks:
         dist.send(tensor=flat, dst=rank, group=group)
 
@@ -41,7 +49,12 @@ def param_send(model, dist_ranks: list, group=None):
 def param_recv(model, source_rank, group=None):
     """Receive the parameters from one rank (param_com.py:19-22)."""
     flat = _flat(model)
-    dist.recv(tensor=flat, src=source_rank, group=group)
+    if _host_staged(flat, group):
+        host = flat.cpu()
+        dist.recv(tensor=host, src=source_rank, group=group)
+        flat.copy_(host)
+    else:
+        dist.recv(tensor=flat, src=source_rank, group=group)
     _unflat(model, flat)
 
 
@@ -51,8 +64,13 @@ def param_recv_avg(model, tmp, weights: list, source_ranks: list, self_rank: int
     acc = _flat(model)
     acc *= weights[self_rank]
     buf = _flat(tmp)
+    host = buf.cpu() if _host_staged(buf, group) else None
     for src in source_ranks:
-        dist.recv(tensor=buf, src=src, group=group)
+        if host is not None:
+            dist.recv(tensor=host, src=src, group=group)
+            buf.copy_(host)
+        else:
+            dist.recv(tensor=buf, src=src, group=group)
         acc += weights[src] * buf
     _unflat(tmp, buf)
     _unflat(model, acc)
@@ -63,7 +81,12 @@ def param_reduce(model, weights: list, self_rank: int, dst_rank: int = 0, group=
     weight; `dst_rank` additionally holds the sum."""
     flat = _flat(model)
     flat *= weights[self_rank]
-    dist.reduce(tensor=flat, dst=dst_rank, group=group)
+    if _host_staged(flat, group):
+        host = flat.cpu()
+        dist.reduce(tensor=host, dst=dst_rank, group=group)
+        flat.copy_(host)
+    else:
+        dist.reduce(tensor=flat, dst=dst_rank, group=group)
     _unflat(model, flat)
 
 

@@ -36,9 +36,17 @@ from .utils import _focal_xy, inverseSample, randomFromOneImage
 class TrainStep:
     def __init__(self, prop_net, mip_net, optimizer: Adam, image_hw: Tuple[int, int], focal, near: float, far: float, ray_num: int = 512,
                  coarse_pnum: int = 64, fine_pnum: int = 128, crop_xy=(1.0, 1.0), seed: Optional[int] = None, white_bkg: bool = False,
-                 prop_normal: bool = False, grad_hook=None):
+                 prop_normal: bool = False, grad_hook=None, ipe_radius: Optional[float] = None, contract: bool = False, flat_grads=None):
         """``grad_hook``: called between ``loss.backward()`` and ``optimizer.step()`` -- the place of ddp_train.py's gradient all-reduce
-        (``lambda: parallel.allreduce_gradients([mip_net, prop_net])``).  An iteration with a hook runs eagerly (``capture`` refuses)."""
+        (``lambda: parallel.allreduce_gradients([mip_net, prop_net])``).  An iteration with a hook runs eagerly (``capture`` refuses).
+        ``ipe_radius`` (BASELINE configs[2]): the fine network encodes the conical frusta between consecutive fine depths with the
+        integrated PE (mip_methods.py:15-58) instead of the point PE; ``contract`` (configs[4]): Mip-NeRF 360 scene contraction of every
+        sample position (proposal and fine).  Neither has a caller in the reference -- the wiring is the build's own (oracle.render_rays
+        states it), parity unpinned.
+        ``flat_grads`` (``nerf_amd.parallel.FlatGradients([mip_net, prop_net], optimizer)``): data-parallel training the native way --
+        the weight-gradient kernels write into ONE persistent flat buffer, and between backward and the optimizer step ONE all_reduce
+        (RCCL) averages it over the ranks.  Unlike a ``grad_hook`` this is part of the captured iteration: ``capture()`` records the
+        collective into the hipGraph (backend nccl), so the replayed iteration keeps its launch-free pace on N GPUs."""
         if not isinstance(optimizer, Adam) or not optimizer.lr_on_device:
             raise ValueError("nerf_amd.training.TrainStep needs nerf_amd.optim.Adam(..., lr_on_device=True): the step must not read host state")
         self.prop_net, self.mip_net, self.opt = prop_net, mip_net, optimizer
@@ -47,6 +55,9 @@ class TrainStep:
         self.white_bkg = bool(white_bkg)
         from .ref_model import RefNeRF
         self.is_ref = isinstance(mip_net, RefNeRF)
+        self.ipe_radius, self.contract = (None if ipe_radius is None else float(ipe_radius)), bool(contract)
+        if self.is_ref and (self.ipe_radius is not None or self.contract):
+            raise NotImplementedError("nerf_amd.training.TrainStep: integrated PE / scene contraction are wired for the MipNeRF branch")
         self.prop_normal = bool(prop_normal) and self.is_ref                              # (train.py: prop_normal only acts with a Ref-NeRF)
         dev = next(mip_net.parameters()).device
         H, W = image_hw
@@ -60,6 +71,7 @@ class TrainStep:
         self.img_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.prop_loss_fn = ProposalLoss()
         self.grad_hook = grad_hook
+        self.flat_grads = flat_grads
         self.graph = None
 
     # ---------------------------------------------------------------------------------------------------------------- the iteration
@@ -70,7 +82,7 @@ class TrainStep:
         dirs = rays[:, 3:]
         if self.prop_normal:
             pts.requires_grad_(True)                                                                    # train.py:165
-        density = self.prop_net.forward(pts)
+        density = self.prop_net.forward(pts, contract=True) if self.contract else self.prop_net.forward(pts)
         if self.prop_normal:
             from .ref_model import RefNeRF
             coarse_grad = -RefNeRF.get_grad(density, pts)                                               # :167-168
@@ -87,20 +99,32 @@ class TrainStep:
             rgbo, pred_normal = self.mip_net.forward(pos, fine_dir)
             density_grad = -RefNeRF.get_grad(rgbo[..., -1], pos)
             rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
-            rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, density_act=self.mip_net.density_act, white_bkg=self.white_bkg)
+            # train.py:182 passes mip_net.density_act POSITIONALLY, i.e. into `mul_norm`: the depths are not scaled by |d| and the
+            # density activation stays the default ReLU (a no-op after the softplus) -- reproduced, like the oracle's ref_train_step
+            rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, self.mip_net.density_act, white_bkg=self.white_bkg)
             extra = 4e-4 * WeightedNormalLoss()(weights, density_grad, pred_normal) + 0.1 * BackFaceLoss()(weights, pred_normal, fine_dir)
             if self.prop_normal:
                 picked = RefNeRF.coarse_grad_select(density_grad, sort_ids, self.coarse_pnum)
                 extra = extra + 4e-5 * WeightedNormalLoss()(prop_w, picked.detach(), coarse_grad)       # 4e-4 * 0.1 (:198)
         else:
-            z_f = z_f[..., :-1].contiguous()                                                            # :188
-            rgbo = self.mip_net.forward(NeRF.length2pts(rays, z_f))                                     # :189-190
+            if self.ipe_radius is not None:                      # the fine_pnum frusta between the fine_pnum + 1 sorted depths
+                rgbo = self.mip_net.forward_rays(rays, z_f, self.fine_pnum, ipe_radius=self.ipe_radius, contract=self.contract)
+                z_f = z_f[..., :-1].contiguous()
+            else:
+                z_f = z_f[..., :-1].contiguous()                                                        # :188
+                rgbo = (self.mip_net.forward_rays(rays, z_f, self.fine_pnum, contract=True) if self.contract
+                        else self.mip_net.forward(NeRF.length2pts(rays, z_f)))                          # :189-190
             rendered, weights, _ = NeRF.render(rgbo, z_f, dirs, white_bkg=self.white_bkg)               # :191
         bounds = getBounds(prop_w, below)                                                               # :192
-        self.opt.zero_grad(set_to_none=True)
+        if self.flat_grads is not None:
+            self.flat_grads.bind(); self.flat_grads.begin_step()                                        # (the kernels overwrite: no zeroing pass)
+        else:
+            self.opt.zero_grad(set_to_none=True)
         img_loss = torch.mean((rendered - rgb_tgt) ** 2)                                                # :194 (nn.MSELoss)
         loss = self.prop_loss_fn(bounds, weights.detach()) + img_loss + extra                           # :196-198
         loss.backward()
+        if self.flat_grads is not None:
+            self.flat_grads.all_reduce()                                                                # ddp_train.py:98, as one collective
         if self.grad_hook is not None:
             self.grad_hook()
         self.opt.step()
@@ -132,7 +156,12 @@ class TrainStep:
             self._body()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        kw = {}
+        if self.flat_grads is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            if torch.distributed.get_backend(self.flat_grads.group) != "nccl":
+                raise RuntimeError("nerf_amd.training.TrainStep: only an RCCL (backend 'nccl') all-reduce can be captured into the hipGraph")
+            kw["capture_error_mode"] = "thread_local"                                     # (the process group's watchdog thread polls events meanwhile)
+        with torch.cuda.graph(self.graph, **kw):
             self._body()                                                                  # (recorded, not executed)
 
     def __call__(self, img: Optional[torch.Tensor] = None, pose: Optional[torch.Tensor] = None):

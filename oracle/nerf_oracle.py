@@ -447,10 +447,11 @@ def cone_parameters(z: Tensor, r: float):
     return mu_t, var_t, var_r
 
 
-def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float, dir_norm: Optional[Tensor] = None):
+def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float, dir_norm: Optional[Tensor] = None, contracted: bool = False):
     """mip_methods.py:15-58.  z (N, S+1) -> (N, S, 6L) feature, mu (N,S,3), mu_t (N,S).
     Quirk kept: ``.norm()`` at :31 is over the whole (N,3) direction tensor; ``dir_norm`` (a test hook) substitutes the norm of a
-    larger batch these rays were cut from."""
+    larger batch these rays were cut from.  ``contracted`` (not in the reference; the build's own definition of BASELINE configs[2] +
+    configs[4] together): the frustum MEAN goes through contract() before the lift, the diagonal covariance stays in metric space."""
     mid = (z[:, 1:] + z[:, :-1]) / 2
     hw2 = ((z[:, 1:] - z[:, :-1]) / 2) ** 2
     t1 = 3 * mid ** 2 + hw2
@@ -459,12 +460,14 @@ def ipe_feature(z: Tensor, rays: Tensor, L: int, r: float, dir_norm: Optional[Te
     var_r = (r ** 2) * (0.25 * mid ** 2 + 5 / 12 * hw2 - 4 * hw2 ** 2 / (15 * t1))
     o, d = rays[:, :3], rays[:, 3:]
     mu = o[:, None, :] + mu_t[:, :, None] * d[:, None, :]
+    if contracted:
+        mu = contract(mu)
     dd = d * d
-    perp = torch.ones(3, device=z.device)[None, :] - dd / (d.norm() if dir_norm is None else dir_norm)
+    perp = torch.ones(3, device=z.device, dtype=z.dtype)[None, :] - dd / (d.norm() if dir_norm is None else dir_norm)
     diag = var_t[:, :, None] * dd[:, None, :] + var_r[:, :, None] * perp[:, None, :]
     N, S, _ = mu.shape
-    f2 = torch.tensor([2.0 ** i for i in range(L)], device=z.device)
-    f4 = torch.tensor([4.0 ** i for i in range(L)], device=z.device)
+    f2 = torch.tensor([2.0 ** i for i in range(L)], device=z.device, dtype=z.dtype)
+    f4 = torch.tensor([4.0 ** i for i in range(L)], device=z.device, dtype=z.dtype)
     mu_r = (f2[None, None, :, None] * mu[:, :, None, :])                 # (N,S,L,3)
     var = (f4[None, None, :, None] * diag[:, :, None, :])
     att = torch.exp(-0.5 * var)
@@ -507,9 +510,9 @@ def render_rays(prop_sd, mip_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, n
     pts_f = length2pts(rays, z_f)
     enc = None
     if ipe_radius is not None:
-        enc, mu, _ = ipe_feature(z_all, rays, 10, ipe_radius, ipe_dir_norm)
+        enc, mu, _ = ipe_feature(z_all, rays, 10, ipe_radius, ipe_dir_norm, contracted=contracted)   # (mu already contracted)
         pts_f = torch.cat((mu, pts_f[..., 3:]), dim=-1)
-    if contracted:
+    elif contracted:
         pts_f = torch.cat((contract(pts_f[..., :3]), pts_f[..., 3:]), dim=-1)
     rgbo = mip_forward(mip_sd, pts_f, emulate_bf16=emulate_bf16, encoded_x=enc)
     rgb, w, extras = composite(rgbo, z_f, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far))

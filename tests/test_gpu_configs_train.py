@@ -1,0 +1,297 @@
+"""BASELINE configs[2] (Mip-NeRF with integrated PE, DDP training) and configs[4] (Mip-NeRF-360 scene contraction, 1237x822, batches of
+2^14 rays) as the TRAINING configurations they are: the integrated PE and the contraction are flags of the kernels' sample fetch, on the
+training forward (activation dump) exactly like on the render path, and the hand-written backward runs on the dump unchanged.
+
+Parity is UNPINNED for both by construction: the reference holds `ipe_feature` (pinned by goldens G12 / G18) but never calls it from a
+loop, and has no contraction at all.  The definitions are the build's own, stated by the oracle (oracle.render_rays(ipe_radius=...,
+contracted=...), oracle.ipe_feature(contracted=...), oracle.contract); the tests compare the HIP path with them -- parameter gradients
+against the SAME step evaluated in fp64 by torch.autograd on the oracle's expressions, with the fp32 oracle's own distance from fp64 as
+the yardstick (as for golden G14) -- and through size-independent properties at the configurations' full sizes.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import weights as W
+from conftest import max_abs
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import nerf_amd
+    from nerf_amd import addtional, mip_methods, mip_model, nerf_base, ops, optim, procedures, training, utils
+
+    class NS:
+        pass
+    ns = NS()
+    ns.pkg, ns.ops, ns.addtional, ns.mip_methods, ns.mip_model, ns.nerf_base, ns.utils = nerf_amd, ops, addtional, mip_methods, mip_model, nerf_base, utils
+    ns.optim, ns.training, ns.procedures = optim, training, procedures
+    return ns
+
+
+def build_nets(A, tag, train=True):
+    prop, mip = A.addtional.ProposalNetwork(10, 256), A.mip_model.MipNeRF(10, 4, 256)
+    prop.load_state_dict(W.proposal_state(tag))
+    mip.load_state_dict(W.mip_state(tag))
+    prop, mip = prop.cuda(), mip.cuda()
+    return (prop.train(), mip.train()) if train else (prop.eval(), mip.eval())
+
+
+def _rays(n, seed, spread=0.25, origin=(0.0, 0.0, 4.0)):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor(origin).expand(n, 3)
+    d = torch.randn(n, 3, generator=g) * spread + torch.tensor([0.0, 0.0, -1.0])
+    d = d * (0.7 + 0.6 * torch.rand(n, 1, generator=g))                          # un-normalised directions, like the reference's rays
+    return torch.cat((o, d), -1).contiguous(), g
+
+
+def _oracle_step(dtype, tag, rays, z_c, z_all, below, tgt, ipe_radius, contracted, dir_norm):
+    """train.py:164-199 (non-ref) on the oracle's expressions in `dtype`, the fine depths and bin indices given (they carry no gradient,
+    utils.py:35-36) -> (loss, {name: gradient})."""
+    cast = lambda sd: {k: v.to(dtype).requires_grad_(True) for k, v in sd.items()}
+    p, m = cast(W.proposal_state(tag)), cast(W.mip_state(tag))
+    r, zc, za = rays.to(dtype), z_c.to(dtype), z_all.to(dtype)
+    pts = r[:, None, :3] + r[:, None, 3:] * zc[:, :, None]
+    dens = F.softplus(O.proposal_forward(p, O.contract(pts) if contracted else pts))
+    pw = O.max_blur(O.sigma_to_weights(dens, zc, r[:, 3:]), 0.01)
+    zf = za[:, :-1]
+    pts_f = O.length2pts(r, zf)
+    enc = None
+    if ipe_radius is not None:
+        enc, mu, _ = O.ipe_feature(za, r, 10, ipe_radius, None if dir_norm is None else dir_norm.to(dtype), contracted=contracted)
+        pts_f = torch.cat((mu, pts_f[..., 3:]), -1)
+    elif contracted:
+        pts_f = torch.cat((O.contract(pts_f[..., :3]), pts_f[..., 3:]), -1)
+    rgbo = O.mip_forward(m, pts_f, encoded_x=enc)
+    rend, wts, _ = O.composite(rgbo, zf, r[:, 3:])
+    img = torch.mean((rend - tgt.to(dtype)) ** 2)
+    ploss = O.proposal_loss(O.get_bounds(pw, below), wts.detach())
+    (img + ploss).backward()
+    grads = {"mip." + k: v.grad for k, v in m.items()}
+    grads.update({"prop." + k: v.grad for k, v in p.items()})
+    return img.item(), ploss.item(), rend.detach(), grads
+
+
+PINNED = ("mip.lin_block1.0.weight", "mip.lin_block1.2.weight", "mip.lin_block2.0.weight", "mip.lin_block2.4.bias", "mip.bottle_neck.0.weight",
+          "mip.opacity_head.0.weight", "mip.rgb_layer.0.weight", "mip.rgb_layer.2.weight", "prop.layers.0.weight", "prop.layers.4.weight",
+          "prop.layers.8.weight", "prop.layers.8.bias")
+
+
+@pytest.mark.parametrize("tag", ["small", "he"])
+@pytest.mark.parametrize("variant", ["ipe", "contract", "ipe+contract"])
+def test_train_step_gradients_with_ipe_and_contraction(A, variant, tag):
+    """One training step (train.py:164-199) with the integrated PE / the scene contraction in the sample fetch, fp32 kernels: losses,
+    rendered colours and every pinned parameter gradient against the fp64 evaluation of the oracle's definition."""
+    ipe, contracted = "ipe" in variant, "contract" in variant
+    prop, mip = build_nets(A, tag)
+    A.pkg.set_precision("fp32")
+    n, c_n, f_n = 96, 32, 64
+    near, far = (0.2, 12.0) if contracted else (2.0, 6.0)                         # contraction: samples on both sides of the unit sphere
+    rays, g = _rays(n, 31, origin=(0.0, 0.0, 1.5) if contracted else (0.0, 0.0, 4.0))
+    tgt = torch.rand(n, 3, generator=g)
+    res = (far - near) / c_n
+    z_c = torch.linspace(near, far - res, c_n) + torch.rand(n, c_n, generator=g) * res
+    u_inv = torch.rand(n, f_n + 1, generator=g)
+    radius = 2.0 / math.sqrt(12.0) / 1111.0 if ipe else None
+    R, Zc = rays.cuda(), z_c.cuda()
+    pts = (R[:, None, :3] + R[:, None, 3:] * Zc[:, :, None]).contiguous()
+    dens = F.softplus(prop.forward(pts, contract=contracted))
+    pw = A.mip_methods.maxBlurFilter(A.addtional.ProposalNetwork.get_weights(dens, Zc, R[:, 3:]), 0.01)
+    z_all, below = A.utils.inverseSample(pw, Zc, f_n + 1, sort=True, u=u_inv)
+    dn = A.ops.dirs_norm(R) if ipe else None
+    rgbo = mip.forward_rays(R, z_all, f_n, ipe_radius=radius, ipe_dir_norm=dn, contract=contracted)
+    z_f = z_all[..., :-1].contiguous()
+    rend, wts, _ = A.nerf_base.NeRF.render(rgbo, z_f, R[:, 3:])
+    img = torch.mean((rend - tgt.cuda()) ** 2)
+    ploss = A.addtional.ProposalLoss()(A.addtional.getBounds(pw, below), wts.detach())
+    (img + ploss).backward()
+    have = {"mip." + k: v.grad for k, v in mip.named_parameters()}
+    have.update({"prop." + k: v.grad for k, v in prop.named_parameters()})
+    args = (tag, rays, z_c, z_all.detach().cpu(), below.cpu(), tgt, radius, contracted, None if dn is None else dn.cpu()[0])
+    img64, pl64, rend64, exact = _oracle_step(torch.float64, *args)
+    _, _, _, ref32 = _oracle_step(torch.float32, *args)
+    assert max_abs(rend.detach().cpu().double(), rend64) <= (1e-5 if tag == "small" else 2e-4)
+    assert abs(img.item() - img64) <= 1e-5 * max(1.0, img64) and abs(ploss.item() - pl64) <= 2e-4 * max(1.0, abs(pl64))
+    report = {}
+    for k in PINNED:
+        top = exact[k].abs().max().item()
+        hip_err = (have[k].detach().cpu().double() - exact[k]).abs().max().item() / top
+        ref_err = (ref32[k].double() - exact[k]).abs().max().item() / top
+        report[k] = "hip %.1e oracle-fp32 %.1e" % (hip_err, ref_err)
+        assert hip_err <= max(2.0 * ref_err, 2e-5), (k, hip_err, ref_err)
+    print("\n%s/%s gradients, max error relative to the fp64 value: %s" % (variant, tag, report))
+    # the flags really changed the step: the plain step on the same depths has other gradients
+    mip.zero_grad(); prop.zero_grad()
+    rgbo0 = mip.forward_rays(R, z_all, f_n)
+    rend0, _, _ = A.nerf_base.NeRF.render(rgbo0, z_f, R[:, 3:])
+    torch.mean((rend0 - tgt.cuda()) ** 2).backward()
+    k0 = "mip.rgb_layer.2.weight"
+    if tag == "he":
+        assert (mip.rgb_layer[2].weight.grad.cpu().double() - exact[k0]).abs().max().item() > 1e-3 * exact[k0].abs().max().item()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_rays_equals_forward_on_materialised_points(A, prec):
+    """Without flags `forward_rays` under autograd is `forward(length2pts(...))`: same output, same parameter gradients, bit for bit (the
+    same training kernel, the positions formed in its sample fetch instead of read from memory)."""
+    prop, mip = build_nets(A, "he")
+    A.pkg.set_precision(prec)
+    rays, g = _rays(300, 5)
+    z = torch.sort(torch.rand(300, 129, generator=g) * 4 + 2, dim=-1)[0]
+    R, Z = rays.cuda(), z.cuda()
+    gout = torch.randn(300, 128, 4, generator=g).cuda()
+    a = mip.forward_rays(R, Z, 128)
+    (a * gout).sum().backward()
+    ga = [p.grad.clone() for p in mip.parameters()]
+    mip.zero_grad()
+    b = mip.forward(A.nerf_base.NeRF.length2pts(R, Z[:, :128].contiguous()))
+    (b * gout).sum().backward()
+    assert torch.equal(a.detach(), b.detach())
+    for x, p in zip(ga, mip.parameters()):
+        assert torch.equal(x, p.grad)
+    A.pkg.set_precision("fp32")
+
+
+def _train_some(A, step, iters):
+    losses = []
+    for _ in range(iters):
+        loss, img_loss = step()
+        losses.append(float(img_loss))
+    return losses
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_config2_ipe_training_iteration_800(A, prec):
+    """configs[2]'s iteration: TrainStep(ipe_radius=pixel radius) on an 800x800 image -- device-resident sampler, proposal pass, IPE fine
+    pass, losses, HIP backward, Adam --, eager and replayed from a hipGraph: the replay IS the eager iteration, and the image loss falls."""
+    A.pkg.set_precision(prec)
+    H = Wd = 800
+    focal = O.fov2focal(0.6911112070083618, (H, Wd))
+    radius = 2.0 / math.sqrt(12.0) / float(focal[1])
+    pose = O.pose_spherical(30.0, -30.0, 4.0)[:3].contiguous().cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    img = (torch.rand(3, 8, 8, device="cuda", generator=gen)[:, :, None, :, None].expand(3, 8, 100, 8, 100).reshape(3, H, Wd)).contiguous()
+
+    def make():
+        torch.manual_seed(0)
+        prop, mip = build_nets(A, "small")
+        opt = A.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+        st = A.training.TrainStep(prop, mip, opt, (H, Wd), focal, 2.0, 6.0, ray_num=1024, seed=77, white_bkg=True, ipe_radius=radius)
+        st.set_image(img, pose)
+        return st, mip
+    eager, mip_e = make()
+    le = _train_some(A, eager, 12)
+    graph, mip_g = make()
+    graph.capture(warmup=2)
+    lg = _train_some(A, graph, 10)
+    torch.cuda.synchronize()
+    assert all(math.isfinite(v) for v in le + lg)
+    assert le[2:] == lg or max(abs(a - b) for a, b in zip(le[2:], lg)) <= 1e-6 * max(le)     # same seeds, same kernels
+    for pe_, pg_ in zip(mip_e.parameters(), mip_g.parameters()):
+        assert torch.equal(pe_, pg_)
+    assert sum(le[-3:]) < sum(le[:3])
+    # and it is not the point-encoded iteration
+    torch.manual_seed(0)
+    prop, mip = build_nets(A, "small")
+    opt = A.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+    st = A.training.TrainStep(prop, mip, opt, (H, Wd), focal, 2.0, 6.0, ray_num=1024, seed=77, white_bkg=True)
+    st.set_image(img, pose)
+    lp = _train_some(A, st, 3)
+    assert lp[0] != le[0]
+    A.pkg.set_precision("fp32")
+
+
+def test_config4_contracted_training_batch_2pow14(A):
+    """configs[4]'s batch: 2^14 rays of a 1237x822 image, unbounded near/far with scene contraction, bf16 kernels.  (i) the iteration
+    runs and learns; (ii) size-independent property of the batch: the gradient of the 2^14-ray step equals the combination of its two
+    2^13-ray halves (the image loss is a mean, the proposal loss a sum), which ties the full-size launch to sizes the oracle-checked
+    tests cover."""
+    A.pkg.set_precision("bf16")
+    H, Wd, near, far = 822, 1237, 0.2, 30.0
+    focal = (900.0, 880.0)
+    pose = O.pose_spherical(25.0, -20.0, 1.5)[:3].contiguous().cuda()
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    img = torch.rand(3, 6, 1, 7, 1, device="cuda", generator=gen).expand(3, 6, 137, 7, 177).reshape(3, 822, 1239)[:, :, :Wd].contiguous()   # colour blocks
+    torch.manual_seed(0)
+    prop, mip = build_nets(A, "small")
+    opt = A.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+    st = A.training.TrainStep(prop, mip, opt, (H, Wd), focal, near, far, ray_num=1 << 14, seed=5, white_bkg=False, contract=True)
+    st.set_image(img, pose)
+    losses = _train_some(A, st, 14)
+    assert all(math.isfinite(v) for v in losses) and sum(losses[-3:]) < sum(losses[:3]), losses
+    # (ii) additivity over the batch, on explicit rays
+    N, c_n, f_n = 1 << 14, 64, 128
+    g = torch.Generator(device="cuda").manual_seed(9)
+    o = torch.tensor([0.0, 0.0, 0.5], device="cuda").expand(N, 3)
+    d = F.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+    rays = torch.cat((o, d), -1).contiguous()
+    tgt = torch.rand(N, 3, device="cuda", generator=g)
+    res = (far - near) / c_n
+    z_c = torch.linspace(near, far - res, c_n).cuda() + torch.rand(N, c_n, device="cuda", generator=g) * res
+    u = torch.rand(N, f_n + 1, device="cuda", generator=g)
+
+    def grads(sl, img_scale):
+        mip.zero_grad(); prop.zero_grad()
+        R, Zc = rays[sl].contiguous(), z_c[sl].contiguous()
+        pts = (R[:, None, :3] + R[:, None, 3:] * Zc[:, :, None]).contiguous()
+        dens = F.softplus(prop.forward(pts, contract=True))
+        pw = A.mip_methods.maxBlurFilter(A.addtional.ProposalNetwork.get_weights(dens, Zc, R[:, 3:]), 0.01)
+        z_all, below = A.utils.inverseSample(pw, Zc, f_n + 1, sort=True, u=u[sl].contiguous())
+        z_f = z_all[..., :-1].contiguous()
+        rgbo = mip.forward_rays(R, z_f, f_n, contract=True)
+        rend, wts, _ = A.nerf_base.NeRF.render(rgbo, z_f, R[:, 3:])
+        loss = A.addtional.ProposalLoss()(A.addtional.getBounds(pw, below), wts.detach()) + img_scale * torch.mean((rend - tgt[sl]) ** 2)
+        loss.backward()
+        return [p.grad.double().clone() for p in list(mip.parameters()) + list(prop.parameters())]
+    full = grads(slice(0, N), 1.0)
+    h1, h2 = grads(slice(0, N // 2), 0.5), grads(slice(N // 2, N), 0.5)
+    for f_, a_, b_ in zip(full, h1, h2):
+        want = a_ + b_
+        assert (f_ - want).abs().max().item() <= 2e-2 * max(want.abs().max().item(), 1e-12)      # bf16 operands, fp32 partial sums in another order
+    A.pkg.set_precision("fp32")
+
+
+def test_config4_full_size_contracted_render_properties(A):
+    """configs[4] at its size: a 1237 x 822 image (no reference tile size divides 1237: rendered un-tiled), unbounded near/far, scene
+    contraction, 64+128 samples, bf16.  Scale-free properties (finite, accumulation <= 1, white-background identity, sharding
+    invariance under in-kernel Philox uniforms) + an fp32 oracle spot check on random rays of the same launch."""
+    prop, mip = build_nets(A, "he", train=False)
+    H, Wd, near, far = 822, 1237, 0.2, 30.0
+    pose = O.pose_spherical(25.0, -20.0, 1.5)[:3]
+    fx, fy = 880.0, 900.0
+    n = H * Wd
+    rays = A.ops.generate_rays(pose, H, Wd, fx, fy, "cuda", 0, n)
+    z_base = torch.linspace(near, far, 64).cuda()
+    for P in (A.ops.BF16, A.ops.F32):
+        pk_p, pk_m = prop.packed(P), mip.packed(P)
+        m = n if P == A.ops.BF16 else 150_000
+        R = rays[:m].contiguous()
+        rgb_w, depth, w, ws = A.ops.render_rays(pk_p, pk_m, P, R, z_base, None, None, 128, near, far, True, want_depth=True, want_weights=True,
+                                                contract=True, seed=1234)
+        rgb_b, _, _, ws = A.ops.render_rays(pk_p, pk_m, P, R, z_base, None, None, 128, near, far, False, workspace=ws, contract=True, seed=1234)
+        rgb_plain, _, _, ws = A.ops.render_rays(pk_p, pk_m, P, R, z_base, None, None, 128, near, far, True, workspace=ws, seed=1234)
+        acc = w.sum(-1)
+        assert bool(torch.isfinite(rgb_w).all()) and bool(torch.isfinite(depth).all())
+        assert float(acc.max()) <= 1.0 + 1e-4 and float(w.min()) >= 0.0
+        assert max_abs(rgb_w - rgb_b, (1.0 - acc)[:, None].expand(-1, 3)) <= 2e-6
+        assert float((rgb_w - rgb_plain).abs().max()) > 1e-3                              # the contraction is really on
+        # a shard of the image renders to the same values (uniforms are a function of the global ray index)
+        lo, hi = m // 3 + 17, m // 3 + 17 + 50_000
+        rgb_s, _, _, _ = A.ops.render_rays(pk_p, pk_m, P, R[lo:hi].contiguous(), z_base, None, None, 128, near, far, True, contract=True, seed=1234,
+                                           rng_ray_offset=lo)
+        assert torch.equal(rgb_s, rgb_w[lo:hi])
+        if P == A.ops.F32:
+            pick = torch.randperm(m, generator=torch.Generator().manual_seed(3))[:160]
+            u1, u2 = O.philox_uniforms(1234, m, 0, 64, 129)
+            with torch.no_grad():
+                want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("he"), W.mip_state("he"), R[pick].cpu(), u1[pick], u2[pick], near, far, 128,
+                                                             white_bkg=True, contracted=True)
+            assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 2e-4 and max_abs(w[pick].cpu(), want_w) <= 2e-4
+            assert max_abs(depth[pick].cpu(), want_depth) <= 2e-3

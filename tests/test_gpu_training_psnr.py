@@ -28,6 +28,8 @@ LR = 1.5e-4 * RAYS / 512            # the reference's rule: args.lr * sample_ray
 
 
 N_VIEWS = 8                          # 7 training views + 1 held-out; scripts/gpu_psnr_long.py raises it for the long runs
+N_HELD = 1                           # held-out views (the last N_HELD of the scene); a checkpoint's figure is the mean of their PSNRs
+HELD_CHUNK = 4096                    # rays per held-out render call (bounds the oracle's activation memory at 200x200 views)
 SCHED = None                         # optional it -> learning rate (the long runs use nerf_base.DecayLrScheduler's rule, train.py:133,200)
 
 
@@ -67,7 +69,7 @@ def run_oracle(views, seed):
     res = (FAR - NEAR) / C_N
     hist, held = [], []
     for it in range(ITERS):
-        rays_all, rgb_all = views[it % (len(views) - 1)]
+        rays_all, rgb_all = views[it % (len(views) - N_HELD)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,))
         rays, tgt = rays_all[idx], rgb_all[idx]
         z_c = torch.linspace(NEAR, FAR - res, C_N) + torch.rand((RAYS, C_N)) * res
@@ -88,13 +90,16 @@ def run_oracle(views, seed):
         opt.step()
         hist.append(loss_img.item())
         if it + 1 in CHECKPOINTS:
-            with torch.no_grad():                                        # held-out view, fixed uniforms
-                rays_h, tgt_h = views[-1]
+            with torch.no_grad():                                        # held-out views, fixed uniforms
                 g = torch.Generator().manual_seed(99)
-                u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g), torch.rand(rays_h.shape[0], F_N + 1, generator=g)
-                rgb, _, _ = O.render_rays({k: v.detach() for k, v in prop.items()}, {k: v.detach() for k, v in mip.items()}, rays_h, u1, u2,
-                                          NEAR, FAR, F_N, white_bkg=True)
-                held.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+                psd, msd = {k: v.detach() for k, v in prop.items()}, {k: v.detach() for k, v in mip.items()}
+                vals = []
+                for rays_h, tgt_h in views[len(views) - N_HELD:]:
+                    u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g), torch.rand(rays_h.shape[0], F_N + 1, generator=g)
+                    rgb = torch.cat([O.render_rays(psd, msd, rays_h[a:a + HELD_CHUNK], u1[a:a + HELD_CHUNK], u2[a:a + HELD_CHUNK], NEAR, FAR, F_N,
+                                                   white_bkg=True)[0] for a in range(0, rays_h.shape[0], HELD_CHUNK)])
+                    vals.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+                held.append(sum(vals) / len(vals))
     return hist, held
 
 
@@ -117,7 +122,7 @@ def run_hip(views, seed, precision):
     hist, held = [], []
     gviews = [(r.cuda(), c.cuda()) for r, c in views]
     for it in range(ITERS):
-        rays_all, rgb_all = gviews[it % (len(views) - 1)]
+        rays_all, rgb_all = gviews[it % (len(views) - N_HELD)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,)).cuda()
         rays, tgt = rays_all[idx].contiguous(), rgb_all[idx]
         z_c = (torch.linspace(NEAR, FAR - res, C_N) + torch.rand((RAYS, C_N)) * res).cuda()
@@ -139,12 +144,14 @@ def run_hip(views, seed, precision):
         hist.append(loss_img.item())
         if it + 1 in CHECKPOINTS:
             with torch.no_grad():
-                rays_h, tgt_h = gviews[-1]
                 g = torch.Generator().manual_seed(99)
-                u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g).cuda(), torch.rand(rays_h.shape[0], F_N + 1, generator=g).cuda()
                 P = ops.current_precision()
-                rgb, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P), P, rays_h, torch.linspace(NEAR, FAR, 64).cuda(), u1, u2, F_N, NEAR, FAR, True)
-                held.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+                vals = []
+                for rays_h, tgt_h in gviews[len(views) - N_HELD:]:
+                    u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g).cuda(), torch.rand(rays_h.shape[0], F_N + 1, generator=g).cuda()
+                    rgb, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P), P, rays_h, torch.linspace(NEAR, FAR, 64).cuda(), u1, u2, F_N, NEAR, FAR, True)
+                    vals.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+                held.append(sum(vals) / len(vals))
     nerf_amd.set_precision("fp32")
     return hist, held
 
