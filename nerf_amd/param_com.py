@@ -81,10 +81,13 @@ def param_reduce(model, weights: list, self_rank: int, dst_rank: int = 0, group=
     weight; `dst_rank` additionally holds the sum."""
     flat = _flat(model)
     flat *= weights[self_rank]
-    if _host_staged(flat, group):
-        host = flat.cpu()
-        dist.reduce(tensor=host, dst=dst_rank, group=group)
-        flat.copy_(host)
+    if dist.get_backend(group) == "gloo":
+        # gloo uses a non-root rank's buffer as scratch (its contents after the call are unspecified); RCCL leaves it alone, which is what
+        # the reference's callers see -- so reduce a copy and take the result on the destination only
+        buf = flat.cpu() if flat.is_cuda else flat.clone()
+        dist.reduce(tensor=buf, dst=dst_rank, group=group)
+        if dist.get_rank(group) == dst_rank:
+            flat.copy_(buf)
     else:
         dist.reduce(tensor=flat, dst=dst_rank, group=group)
     _unflat(model, flat)
