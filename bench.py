@@ -67,6 +67,8 @@ def parse():
     p.add_argument("--ipe", action="store_true", help="train-ddp: integrated PE in the fine pass (BASELINE configs[2])")
     p.add_argument("--contract", action="store_true", help="train-ddp: Mip-NeRF 360 scene contraction, unbounded near/far (BASELINE configs[4])")
     p.add_argument("--hipgraph", action="store_true", help="train-ddp: replay the step (collective included) from a hipGraph")
+    p.add_argument("--train-dumps", default="bf16", choices=["bf16", "fp8"],
+                   help="storage of the training dumps in bf16 mode: bf16, or e4m3 with per-sample-and-K-group scales (nerf_amd.set_train_dumps)")
     p.add_argument("--train-rays", type=int, default=16384, help="rays per rank and step in --mode train-ddp")
     p.add_argument("--launch-check", action="store_true",
                    help="control-flow check of the N-rank launch path only (rendezvous, world size, barrier, max-over-ranks): no GPU work")
@@ -274,6 +276,7 @@ def train_ddp(a, dist, world, rank, dev, backend):
     from nerf_amd.nerf_base import NeRF
     from nerf_amd.utils import inverseSample
     nerf_amd.set_precision(a.precision)
+    nerf_amd.set_train_dumps(a.train_dumps)
     n_rays, c_n, f_n = a.train_rays, C_COARSE, N_FINE
     near, far = (0.2, 30.0) if a.contract else (NEAR, FAR)
     torch.manual_seed(0)                                              # same initial weights on every rank ...
@@ -361,7 +364,8 @@ def train_ddp(a, dist, world, rank, dev, backend):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
                "data": "synthetic",
                "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, MipNeRF(10,4,256) + ProposalNetwork(10,256); %s%s"
-                                      % (n_rays, variant, "; step replayed from a hipGraph (collective inside)" if graph is not None else ""),
+                                      % (n_rays, variant, ("; step replayed from a hipGraph (collective inside)" if graph is not None else "") +
+                                         ("; training dumps in scaled e4m3" if a.train_dumps == "fp8" else "")),
                           "rays_per_step_per_gpu": n_rays, "parallelism": "ray-sharded replicas (dp%d), one flat gradient all_reduce per step" % world},
                "allreduce": {"elements": n_grad, "bytes": 4 * n_grad, "us_per_step": ar_us, "backend": backend if dist is not None else None,
                              "note": "ONE all_reduce(AVG) on the persistent flat gradient buffer the weight-gradient kernels write into "

@@ -34,6 +34,11 @@ extern "C" {
 /* arithmetic of the MLP matrix products */
 #define NERF_AMD_F32   0   /* v_mfma_f32_32x32x2_f32: exact fp32 products + fp32 accumulate (parity mode, <=1e-4) */
 #define NERF_AMD_BF16  1   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (throughput mode)          */
+/* NERF_AMD_BF16 arithmetic with the TRAINING DUMPS of the 256-wide hidden layers (activations written by nerf_amd_*_forward_train, deltas
+ * written by nerf_amd_*_backward_chain, both read by nerf_amd_*_weight_grads) stored as OCP e4m3 with one power-of-two scale per sample and
+ * 16-feature K group: 288 B instead of 512 B per sample and layer in each of the four passes over a dump.  Accepted by exactly those entry
+ * points and nerf_amd_train_dump_bytes / nerf_amd_weight_grads_workspace_bytes (pack with NERF_AMD_BF16); encodings and head deltas stay bf16. */
+#define NERF_AMD_BF16_F8 2
 
 /* which network a packed weight blob belongs to */
 #define NERF_AMD_NET_PROPOSAL 0    /* ProposalNetwork(10, 256)        addtional.py:53-96  */

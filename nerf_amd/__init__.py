@@ -6,6 +6,6 @@ Compute lives in hand-written HIP kernels (``nerf_amd/csrc`` -> ``libnerf_amd.so
 interface.  Importing it without the built library raises: there is no CPU or torch fallback.
 """
 from . import _lib                                   # noqa: F401  (fails loudly when the .so is missing)
-from .ops import set_precision, current_precision    # noqa: F401
+from .ops import set_precision, current_precision, set_train_dumps    # noqa: F401
 
-__all__ = ["set_precision", "current_precision"]
+__all__ = ["set_precision", "current_precision", "set_train_dumps"]

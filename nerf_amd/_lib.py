@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so")   # env override: diagnostic builds only
 
 F32, BF16 = 0, 1
+BF16_F8 = 2            # NERF_AMD_BF16_F8: bf16 arithmetic, training dumps of the hidden layers in scaled e4m3 (training entry points only)
+EXPECTED_VERSION = 112  # nerf_amd_version() of the library these signatures were written against
 NET_PROPOSAL, NET_MIP, NET_REF = 0, 1, 2
 ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS = 0, 1, 2
 
@@ -115,6 +117,9 @@ def _load():
         fn = getattr(lib, name)                 # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    got = lib.nerf_amd_version()
+    if got != EXPECTED_VERSION and not os.environ.get("NERF_AMD_LIB"):      # a stale git-ignored .so would be called with shifted arguments
+        raise ImportError("nerf_amd: %s is ABI version %d, this package expects %d -- rebuild it (`make -C nerf_amd/csrc`)" % (LIB_PATH, got, EXPECTED_VERSION))
     return lib
 
 

@@ -107,9 +107,12 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
             #   position + the encoding's derivative (nerf_amd_density_grad).  The positions get a gradient only there.
             from . import mlp_backward
             held = {}
+            # fp8 dumps (ops.set_train_dumps) unless the positions ask for a gradient: the density-gradient chain re-reads the bf16 activations
+            tprec = prec if pts.requires_grad else ops.train_precision(prec)
+            want_pos = bool(pts.requires_grad)
 
             def hip(p, *wb):
-                out, held["dump"] = ops.proposal_forward_train(self.packed(prec), prec, p, contract=contract)
+                out, held["dump"] = ops.proposal_forward_train(self.packed(prec), tprec, p, contract=contract)
                 return out
 
             def bwd(g, p, *wb):
@@ -122,17 +125,22 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
                         raise NotImplementedError("nerf_amd: density-gradient normals of contracted positions are not built")
                     gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1))
                     return (gx.view(p.shape), *[None] * len(wb))
+                gx = None
+                if ab.POSITION_GRADS and want_pos:                       # d loss / d pts as well (autograd_bridge.POSITION_GRADS)
+                    if contract:
+                        raise NotImplementedError("nerf_amd: position gradients of contracted positions are not built")
+                    gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1)).view(p.shape)
                 sinks = self.grad_sinks()                                # persistent flat gradient buffer (parallel.FlatGradients)?
                 direct = sinks is not None and sinks[2]
                 kw = wb[:5]
-                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), prec, kw, packed_bwd=held["bwd_blob"],
+                gW, gb = mlp_backward.proposal_backward(g.reshape(-1), p.reshape(-1, 3), held.pop("dump"), tprec, kw, packed_bwd=held["bwd_blob"],
                                                         out=(sinks[0], sinks[1]) if direct else None)
                 if sinks is not None:
                     if not direct:                                       # a second backward in the same step accumulates
                         torch._foreach_add_(list(sinks[0]) + list(sinks[1]), list(gW) + list(gb))
-                    return (None, *[None] * len(wb))
+                    return (gx, *[None] * len(wb))
                 gW, gb = self.unpad_grads(gW, gb)
-                return (None, *gW, *gb)
+                return (gx, *gW, *gb)
             return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts, contract=contract)
 

@@ -35,6 +35,14 @@ class _VJP:
     bf16 = False          # the op ran in BF16 precision: the re-evaluated Linear layers use bf16 operands with fp32 accumulation too
 
 
+# Gradients w.r.t. sample POSITIONS.  The reference's training loss never uses them (the fine depths are detached, utils.py:35-36; the
+# position leaves of train.py:165,179 exist for RefNeRF.get_grad only), so by default the HIP backward of ProposalNetwork / RefNeRF forms
+# a position gradient ONLY inside get_grad (inputs_only_grad) and `loss.backward()` leaves `pts.grad` untouched -- a dgrad chain and an
+# encoding adjoint per network saved per step.  Set POSITION_GRADS = True to have ProposalNetwork's loss backward also return
+# d loss / d pts (pose / sample refinement); RefNeRF's full position gradient is not built (it raises when asked for).
+POSITION_GRADS = False
+
+
 class inputs_only_grad:
     """with inputs_only_grad(): torch.autograd.grad(y, positions, ...) -- HipOp backward passes inside differentiate the non-parameter
     inputs only (the density-gradient normals of ref_model.py:119-125 need no parameter gradient)."""

@@ -26,6 +26,8 @@
 //   4. adam_kernel: Adam (torch.optim.Adam semantics, train.py:117-118) over all parameters of both networks in one launch.
 //
 // Reference semantics: what torch.autograd computes for addtional.py:88-96 and mip_model.py:41-60 (train.py:164-218).
+#include <type_traits>
+
 #include "mlp_core.h"
 
 namespace {
@@ -92,6 +94,8 @@ constexpr uint32_t BWD_LDS_ZERO = MLP_RING_BYTES;                    // 1 KiB of
 constexpr uint32_t BWD_LDS_MASK = MLP_RING_BYTES + 1024;
 template <class P> constexpr uint32_t bwd_pair_bytes() { return 4 * P::NT * P::BREG_LDS; }          // (2 blocks x 2 halves x NT tiles) mask groups
 template <class P> constexpr uint32_t bwd_lds_total() { return BWD_LDS_MASK + P::NW * 2 * bwd_pair_bytes<P>(); }
+template <class P> constexpr uint32_t bwd_lds_scale() { return bwd_lds_total<P>(); }                             // F8 chains: scale-exponent records
+template <class P> constexpr uint32_t bwd_lds_total_f8() { return bwd_lds_total<P>() + P::NW * 2 * P::NT * 1024; }
 
 // How many weight-ring pieces a wave is guaranteed to have issued AFTER the mask DMA of a feature-block pair of an NKG-step layer by
 // the time the next pair starts: one chunk boundary per FPC fragments, LPW pieces per boundary.  VMEM loads return in order, so
@@ -102,7 +106,7 @@ template <int N> DEVINL void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n
 // Output functor of a layer of the fused chains (NKG_CUR K steps): convert, apply the ReLU adjoint from the forward's BIT masks of
 // `layer` (1 KiB per subtile and layer, LDS-DMA'd when the layer starts into the buffer of the layer's parity -- consecutive chain
 // layers have alternating slot parity, so the previous layer's pending pair still reads its own buffer), keep in registers, dump.
-template <class P, int NKG_CUR, int NKG_PREV>
+template <class P, int NKG_CUR, int NKG_PREV, bool F8 = false>
 struct MaskedOut {
     typename P::BReg (&buf)[P::NT][16];
     Dump act, dlt;
@@ -110,6 +114,7 @@ struct MaskedOut {
     int64_t sub0;
     int lane;
     uint32_t mask_lds;          // this wave's two layer buffers of NT KiB each (wave-uniform byte offset)
+    uint32_t scale_lds = 0;     // F8: this wave's two x NT scale-exponent records (flushed by f8_flush_layer)
 
     DEVINL void begin_group(int G) const {
         if (G == 0) {
@@ -128,9 +133,24 @@ struct MaskedOut {
         const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + mask_lds + ((layer & 1) * P::NT + t) * 1024 + lane * 16 + (kg >> 2) * 4);
         const typename P::BReg v = relu_mask_bits(d, w, kg);
         buf[t][kg] = v;
-        P::store_global(dlt.base + (size_t)layer * dlt.layer_stride + ((size_t)(sub0 + t) * 16 + kg) * (size_t)P::BREG_LDS, lane, v);
+        if constexpr (F8) {                                   // delta dump in scaled e4m3 (the chain itself keeps bf16 in registers)
+            const uint32_t E = f8_group_exponent<true>(v);
+            f8_store_group(dlt.base + (size_t)layer * dlt.layer_stride + (size_t)(sub0 + t) * F8_SUB_BYTES, kg, lane, f8_encode_group(v, E), E,
+                           scale_lds + ((layer & 1) * P::NT + t) * 1024);
+        } else {
+            P::store_global(dlt.base + (size_t)layer * dlt.layer_stride + ((size_t)(sub0 + t) * 16 + kg) * (size_t)P::BREG_LDS, lane, v);
+        }
     }
 };
+// F8: delta slot `layer` of this wave's subtiles is complete (its last feature-block pair has been converted): write its scale exponents
+template <class P>
+DEVINL void f8_flush_layer(const Dump& dlt, uint32_t scale_lds, int layer, int64_t sub0, int lane) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < P::NT; ++t)
+        f8_flush_scales(dlt.base + (size_t)layer * dlt.layer_stride + (size_t)(sub0 + t) * F8_SUB_BYTES, lane, scale_lds + ((layer & 1) * P::NT + t) * 1024);
+    asm volatile("" ::: "memory");
+}
 
 template <class P>
 DEVINL void bwd_prologue(WeightStream<P, MLP_NSLOT, false>& ws, const void* packed, int n_frags) {
@@ -142,7 +162,7 @@ DEVINL void bwd_prologue(WeightStream<P, MLP_NSLOT, false>& ws, const void* pack
 // ================================================================================================
 // ProposalNetwork dgrad chain: g_density (M) -> delta dump (slots 3..0, head in slot 4)
 // ================================================================================================
-template <class P>
+template <class P, bool F8 = false>
 __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __restrict__ packed, const float* __restrict__ g_density, int64_t M,
                                                               Dump act, Dump dlt) {
     using L = PropBwdLayout;
@@ -155,6 +175,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
     const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * NT * 1024);
+    const uint32_t scale_lds = bwd_lds_scale<P>() + wave * 2 * NT * 1024;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
@@ -170,23 +191,26 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
         BReg a[NT][16], b[NT][16];
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
-        const MaskedOut<P, 1, 16> O3{a, act, dlt, 3, sub0, lane, mask_lds};
+        const MaskedOut<P, 1, 16, F8> O3{a, act, dlt, 3, sub0, lane, mask_lds, scale_lds};
         Deferred<P, 6, 2> d = dense<P, 1, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int, int t) -> BReg { return head[t]; }, O3, NoPrev{});
         // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (same chunk parity)
         static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk parity");
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const MaskedOut<P, 16, 1> OB{b, act, dlt, 2 - 2 * r, sub0, lane, mask_lds};        // (follows the 1-step head layer in round 0)
-            const MaskedOut<P, 16, 16> OA_pend{a, act, dlt, 3 - 2 * r, sub0, lane, mask_lds};
+            const MaskedOut<P, 16, 1, F8> OB{b, act, dlt, 2 - 2 * r, sub0, lane, mask_lds, scale_lds};        // (follows the 1-step head layer in round 0)
+            const MaskedOut<P, 16, 16, F8> OA_pend{a, act, dlt, 3 - 2 * r, sub0, lane, mask_lds, scale_lds};
             d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 3 - 2 * r, sub0, lane);      // (its last pair was converted during this layer)
             if (r == 0) {
-                const MaskedOut<P, 16, 16> OA{a, act, dlt, 1, sub0, lane, mask_lds};
+                const MaskedOut<P, 16, 16, F8> OA{a, act, dlt, 1, sub0, lane, mask_lds, scale_lds};
                 d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+                if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 2, sub0, lane);
             }
         }
-        const MaskedOut<P, 16, 16> O0{b, act, dlt, 0, sub0, lane, mask_lds};
+        const MaskedOut<P, 16, 16, F8> O0{b, act, dlt, 0, sub0, lane, mask_lds, scale_lds};
         vm_wait<mask_wait_count<P>(16)>();                   // the last pair's masks
         d.flush(O0);
+        if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 0, sub0, lane);
     }
     ws.drain();
 }
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
 // ================================================================================================
 // MipNeRF dgrad chain: g_rgbo (M,4), rgbo (M,4) -> delta dump (slots 7..0, head in slot 8)
 // ================================================================================================
-template <class P>
+template <class P, bool F8 = false>
 __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restrict__ packed, const float* __restrict__ g_rgbo,
                                                              const float* __restrict__ rgbo, int64_t M, Dump act, Dump dlt) {
     using L = MipBwdLayout;
@@ -208,6 +232,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
     const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * NT * 1024);
+    const uint32_t scale_lds = bwd_lds_scale<P>() + wave * 2 * NT * 1024;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
@@ -232,26 +257,30 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         // dc = W_rgb2^T dpre, masked by c (activation slot 7) -> b[.][0..7]
-        const MaskedOut<P, 2, 16> OC{b, act, dlt, 7, sub0, lane, mask_lds};
+        const MaskedOut<P, 2, 16, F8> OC{b, act, dlt, 7, sub0, lane, mask_lds, scale_lds};
         const Deferred<P, 2, 2> dcp = dense<P, 2, 4, L::START[0]>(ws, BWD_LDS_ZERO,
             [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OC, NoPrev{});
         // d6 = [W_fold^T | W_sigma^T] [dc | head], masked by g6 (slot 6) -> a
-        const MaskedOut<P, 9, 2> O6{a, act, dlt, 6, sub0, lane, mask_lds};
+        const MaskedOut<P, 9, 2, F8> O6{a, act, dlt, 6, sub0, lane, mask_lds, scale_lds};
         Deferred<P, 6, 2> d = dense<P, 9, 8, L::START[1]>(ws, BWD_LDS_ZERO,
             [&](int kg, int t) -> BReg { if (kg < 8) return b[t][kg < 8 ? kg : 0]; return head[t]; }, O6, prev_of(dcp, OC));
+        if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 7, sub0, lane);                  // (slot 7's last pair was converted during the d6 layer)
         // d5 .. d0: six 256 x 256 layers ping-ponging between the register buffers (a -> b -> a ...), two code instances
         static_assert(L::START[2] % (2 * FPC) == L::START[4] % (2 * FPC) && L::START[2] % (2 * FPC) == L::START[6] % (2 * FPC) &&
                       L::START[3] % (2 * FPC) == L::START[5] % (2 * FPC) && L::START[3] % (2 * FPC) == L::START[7] % (2 * FPC), "uniform layer loop");
 #pragma unroll 1
         for (int r = 0; r < 3; ++r) {
-            const MaskedOut<P, 16, 9> OB{b, act, dlt, 5 - 2 * r, sub0, lane, mask_lds};       // (follows the 9-step layer in round 0)
-            const MaskedOut<P, 16, 16> OA_pend{a, act, dlt, 6 - 2 * r, sub0, lane, mask_lds}, OA{a, act, dlt, 4 - 2 * r, sub0, lane, mask_lds};
+            const MaskedOut<P, 16, 9, F8> OB{b, act, dlt, 5 - 2 * r, sub0, lane, mask_lds, scale_lds};       // (follows the 9-step layer in round 0)
+            const MaskedOut<P, 16, 16, F8> OA_pend{a, act, dlt, 6 - 2 * r, sub0, lane, mask_lds, scale_lds}, OA{a, act, dlt, 4 - 2 * r, sub0, lane, mask_lds, scale_lds};
             d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 6 - 2 * r, sub0, lane);
             d = dense<P, 16, 8, L::START[3]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 5 - 2 * r, sub0, lane);
         }
-        const MaskedOut<P, 16, 16> O0{a, act, dlt, 0, sub0, lane, mask_lds};
+        const MaskedOut<P, 16, 16, F8> O0{a, act, dlt, 0, sub0, lane, mask_lds, scale_lds};
         vm_wait<mask_wait_count<P>(16)>();                   // the last pair's masks
         d.flush(O0);
+        if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 0, sub0, lane);
     }
     ws.drain();
 }
@@ -514,6 +543,9 @@ enum { Y_DMAP = 0, Y_PE10 = 1, Y_PE4 = 2, Y_IDE = 3 };
 #ifndef WGRAD_LOCKSTEP
 #define WGRAD_LOCKSTEP 1
 #endif
+#ifndef WGRAD_EXCHANGE_TRANSPOSED
+#define WGRAD_EXCHANGE_TRANSPOSED 1     /* exchange form: park the transposed blocks (0 = park the raw K groups, every block transposed twice) */
+#endif
 
 // slot (kg, h, e) of a Y operand -> feature (column of the reference weight matrix), or -1
 template <int YKIND> DEVINL int y_slot_feature(int kg, int h, int e) {
@@ -523,9 +555,38 @@ template <int YKIND> DEVINL int y_slot_feature(int kg, int h, int e) {
     return dmap_feature(kg, h, e);
 }
 
+// fp8 operands (NERF_AMD_BF16_F8 dumps, mlp_layout.h): K groups kg0 .. kg0 + NK - 1 (kg0 even, NK even) of one subtile as they come from
+// memory -- NK / 2 blocks of two K groups + the lane's scale exponents -- and their decoding into bf16 B register groups
+template <int NK>
+struct F8Raw {
+    f32x4 blk[NK / 2];
+    uint32_t ex[(NK + 3) / 4];
+    // `sub` = the subtile's slot base + lane * 16; exponent bytes of K groups (kg0 & ~3) .. are loaded as whole dwords
+    DEVINL void load(const char* sub, int kg0) {
+#pragma unroll
+        for (int b = 0; b < NK / 2; ++b) blk[b] = *reinterpret_cast<const f32x4*>(sub + (size_t)((kg0 >> 1) + b) * 1024);
+#pragma unroll
+        for (int d = 0; d < (NK + 3) / 4; ++d) ex[d] = *reinterpret_cast<const uint32_t*>(sub + F8_SCALE_OFF + (kg0 & ~3) + 4 * d);
+    }
+    DEVINL void decode(int kg0, bf16x8* out) const {
+        const int sh = kg0 & 3;                              // (non-zero only for NK = 2: the pair sits in the upper half of its dword)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const u32x4 w = __builtin_bit_cast(u32x4, blk[k >> 1]);
+            const uint32_t lo = (k & 1) ? w[2] : w[0], hi = (k & 1) ? w[3] : w[1];
+            const uint32_t E = (NK >= 4) ? ((ex[k >> 2] >> (8 * (k & 3))) & 0xffu) : ((ex[0] >> (8 * (k + sh))) & 0xffu);
+            out[k] = f8_decode_group(lo, hi, E);
+        }
+    }
+};
+
 // KGX / KGY: K groups of X / Y;  WO: waves along the X (row) dimension, 4 / WO along Y
-template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false>
+// XF8 / YF8: the X operand's first source (x0: a delta slot) / the Y operand (a hidden-activation slot) is an fp8 slot; x1 (the head K
+// group) and the encoding operands are always bf16
+template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false, bool XF8 = false, bool YF8 = false>
 __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t n_sub) {
+    static_assert(!YF8 || YKIND == Y_DMAP, "only hidden-activation slots are fp8");
+    static_assert(!XCHG || XF8 == YF8, "exchange form: both operands in the same format");
     constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : ((YKIND == Y_PE10 || YKIND == Y_IDE) ? 2 : 1);
     constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
     static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
@@ -590,6 +651,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
             else if (k < KGY) ys[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)k * 1024);
         }
     };
+    // fp8 operands of the plain (non-exchange) form: NXF / NYF K groups of the wave come from an fp8 slot (an odd KGX keeps its last K
+    // group -- the bf16 head group of x1 -- apart)
+    constexpr int NXF = XF8 ? ((KGX % 2 == 0) ? NXK : KGX - 1) : 0, NYF = YF8 ? NYK : 0;
+    static_assert(!XF8 || NXF >= 2, "an fp8 X operand needs at least one K-group pair");
+    static_assert(!YF8 || KGY % 2 == 0, "fp8 Y operands come in K-group pairs");
+    struct RawX { F8Raw<(NXF > 0 ? NXF : 2)> f; bf16x8 tail; };
+    auto load_x_raw = [&](int64_t s, RawX& r) {
+        r.f.load(J.x0.base + (size_t)s * J.x0.sub_stride + lane * 16, (KGX % 2 == 0) ? 2 * ob0 : 0);
+        if constexpr (KGX % 2 != 0) r.tail = *reinterpret_cast<const bf16x8*>(J.x1.base + (size_t)s * J.x1.sub_stride + lane * 16);
+    };
+    auto decode_x = [&](const RawX& r, bf16x8 (&xs)[NXK]) {
+        r.f.decode((KGX % 2 == 0) ? 2 * ob0 : 0, xs);
+        if constexpr (KGX % 2 != 0) xs[KGX - 1] = r.tail;
+    };
+    using RawY = F8Raw<(NYF > 0 ? NYF : 2)>;
+    auto load_y_raw = [&](int64_t s, RawY& r) { r.load(J.y.base + (size_t)s * J.y.sub_stride + lane * 16, 2 * ib0); };
     auto cvt8 = [](const f32x16& v, int g) -> bf16x8 { return PBF16::from_acc<false>(v, 8 * g); };
 
     // one subtile: transpose the X and Y K groups on the matrix cores, multiply the transposed blocks
@@ -634,38 +711,141 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
         // 64 operand registers per subtile, but 64 KiB of unique bytes in flight per CU and no duplicate request at all.
         static_assert(KGX == 16 && KGY == 16 && WO == 2 && YKIND == Y_DMAP, "exchange form: the 2 x 2 tiling of the 256 x 256 product");
         constexpr uint32_t STAGE = 32 * 1024;                              // X K groups 0..15 | Y K groups 0..15 of one subtile
-        auto load_quarter = [&](int64_t s, bf16x8 (&q)[8]) {               // X K groups 8 wo + 4 wi + k, Y K groups 8 wi + 4 wo + k
-            const char* yb = J.y.base + (size_t)s * J.y.sub_stride + lane * 16;
+        // a quarter in flight: bf16 = 8 B register groups; fp8 = 2 + 2 blocks of two K groups and one dword of scale exponents per operand
+        // (18 registers instead of 32), decoded to bf16 when it is parked -- LDS and everything downstream see bf16 either way
+        struct QuarterBf16 { bf16x8 v[8]; };
+        struct QuarterF8 { F8Raw<4> x, y; };
+        using Quarter = typename std::conditional<XF8, QuarterF8, QuarterBf16>::type;
+        auto load_quarter = [&](int64_t s, Quarter& q) {                   // X K groups 8 wo + 4 wi + k, Y K groups 8 wi + 4 wo + k
+            if constexpr (XF8) {
+                q.x.load(J.x0.base + (size_t)s * J.x0.sub_stride + lane * 16, 8 * wo + 4 * wi);
+                q.y.load(J.y.base + (size_t)s * J.y.sub_stride + lane * 16, 8 * wi + 4 * wo);
+            } else {
+                const char* yb = J.y.base + (size_t)s * J.y.sub_stride + lane * 16;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                q[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, 8 * wo + 4 * wi + k));
-                q[4 + k] = *reinterpret_cast<const bf16x8*>(yb + (size_t)(8 * wi + 4 * wo + k) * 1024);
+                for (int k = 0; k < 4; ++k) {
+                    q.v[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, 8 * wo + 4 * wi + k));
+                    q.v[4 + k] = *reinterpret_cast<const bf16x8*>(yb + (size_t)(8 * wi + 4 * wo + k) * 1024);
+                }
             }
         };
         auto clamp_s = [&](int64_t s) { return s < s_end ? s : s_end - 1; };
-        bf16x8 q0[8], q1[8], q2[8], xs[NXK], ys[NYK];
+        Quarter q0, q1;
         int buf = 0;
         if (s_begin < s_end) { load_quarter(s_begin, q0); load_quarter(clamp_s(s_begin + 1), q1); }
+#if WGRAD_EXCHANGE_TRANSPOSED
+        // What is exchanged are the TRANSPOSED blocks: a wave transposes (and converts, and row-sums for the bias) only the two X and two Y
+        // feature blocks of its own quarter, parks them, and reads its partners' two + two transposed blocks after the barrier -- every block
+        // is transposed once per workgroup instead of twice: 8 transposing MFMAs + 32 products per wave and subtile instead of 16 + 32, half
+        // the conversions, and the bias sums spread over all four waves.  LDS traffic is unchanged (a transposed block pair is as big as the
+        // two K groups it came from).  Stage layout: X block gx, half hf at (2 gx + hf) KiB; Y blocks behind them at +16 KiB.
+        // A quarter's registers are refilled (two subtiles ahead) as soon as it has been transposed: two stages, no copies.
+        auto body = [&](int64_t s, Quarter& cur) {
+            bf16x8 own[8];
+            if constexpr (XF8) { cur.x.decode(0, own); cur.y.decode(0, own + 4); }     // (kg0 = 0: the group's own dword, no byte shift)
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) own[k] = cur.v[k];
+            }
+            const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
+            bf16x8 xf[4][2], yf[4][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {                                   // own X blocks 4 wo + 2 wi + a, own Y blocks 4 wi + 2 wo + a
+                f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[2 * a], idx[0], zero16, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[2 * a + 1], idx[1], t, 0, 0, 0);
+                f32x16 u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[4 + 2 * a], idx[0], zero16, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[4 + 2 * a + 1], idx[1], u, 0, 0, 0);
+                xf[a][0] = cvt8(t, 0); xf[a][1] = cvt8(t, 1);
+                yf[a][0] = cvt8(u, 0); yf[a][1] = cvt8(u, 1);
+                if (J.bias_partial != nullptr) {
+                    const float r0 = (t[0] + t[1]) + (t[2] + t[3]), r1 = (t[4] + t[5]) + (t[6] + t[7]), r2 = (t[8] + t[9]) + (t[10] + t[11]),
+                                r3 = (t[12] + t[13]) + (t[14] + t[15]);
+                    bsum[a] += (r0 + r1) + (r2 + r3);
+                }
+                if (a == 1) load_quarter(clamp_s(s + 2), cur);             // `cur` is consumed: refill the same registers, two subtiles ahead
+                                                                            // (unconditional: past the end the last subtile is read again)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    *reinterpret_cast<bf16x8*>(smem + st + (2 * (4 * wo + 2 * wi + a) + hf) * 1024) = xf[a][hf];
+                    *reinterpret_cast<bf16x8*>(smem + st + (16 + 2 * (4 * wi + 2 * wo + a) + hf) * 1024) = yf[a][hf];
+                }
+            }
+            __syncthreads();                                                // everybody's blocks of s are in LDS (and buffer buf^1 is free again)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)                                     // local blocks 0, 1 = own, 2, 3 = the partner's (xmap / ymap undo it)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    xf[2 + a][hf] = *reinterpret_cast<const bf16x8*>(smem + st + (2 * (4 * wo + 2 * (1 - wi) + a) + hf) * 1024);
+                    yf[2 + a][hf] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 2 * (4 * wi + 2 * (1 - wo) + a) + hf) * 1024);
+                }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][0], yf[b][0], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][1], yf[b][1], acc[a][b], 0, 0, 0);
+            }
+            buf ^= 1;
+        };
+        for (int64_t s = s_begin; s < s_end;) {
+            body(s, q0); if (++s >= s_end) break;
+            body(s, q1); ++s;
+        }
+#else
+        Quarter q2;
+        bf16x8 own[8], xs[NXK], ys[NYK];
         for (int64_t s = s_begin; s < s_end; ++s) {
             load_quarter(clamp_s(s + 2), q2);                               // (unconditional: past the end the last subtile is read again)
             const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
+            if constexpr (XF8) { q0.x.decode(0, own); q0.y.decode(0, own + 4); }       // (kg0 = 0: the group's own dword, no byte shift)
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) own[k] = q0.v[k];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                                   // park my quarter of subtile s (it landed: issued two iterations ago)
-                *reinterpret_cast<bf16x8*>(smem + st + (8 * wo + 4 * wi + k) * 1024) = q0[k];
-                *reinterpret_cast<bf16x8*>(smem + st + (16 + 8 * wi + 4 * wo + k) * 1024) = q0[4 + k];
+                *reinterpret_cast<bf16x8*>(smem + st + (8 * wo + 4 * wi + k) * 1024) = own[k];
+                *reinterpret_cast<bf16x8*>(smem + st + (16 + 8 * wi + 4 * wo + k) * 1024) = own[4 + k];
             }
             __syncthreads();                                                // everybody's quarters of s are in LDS (and buffer buf^1 is free again)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                                   // my own quarter from registers, the partners' from LDS.  Register
-                xs[k] = q0[k];                                              // arrays must be indexed statically: local blocks 0, 1 = the own K
+                xs[k] = own[k];                                             // arrays must be indexed statically: local blocks 0, 1 = the own K
                 xs[4 + k] = *reinterpret_cast<const bf16x8*>(smem + st + (8 * wo + 4 * (1 - wi) + k) * 1024);   // groups, 2, 3 = the partner's;
-                ys[k] = q0[4 + k];                                          // the permutation is undone in the partial's addresses (xmap / ymap)
+                ys[k] = own[4 + k];                                         // the permutation is undone in the partial's addresses (xmap / ymap)
                 ys[4 + k] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 8 * wi + 4 * (1 - wo) + k) * 1024);
             }
             multiply(xs, ys);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { q0[k] = q1[k]; q1[k] = q2[k]; }
+            q0 = q1; q1 = q2;
             buf ^= 1;
+        }
+#endif
+    } else if constexpr (XF8 || YF8) {
+        // plain form with fp8 operands: the next subtile travels as raw blocks (fewer registers in flight) and is decoded after the multiply
+        bf16x8 xs[NXK], ys[NYK], yn[NYK], xn[NXK];
+        RawX xr; RawY yr;
+        auto fetch = [&](int64_t s) {
+            if constexpr (XF8) load_x_raw(s, xr); else load_x(s, xn);
+            if constexpr (YF8) load_y_raw(s, yr); else load_y(s, yn);
+        };
+        auto land = [&]() {
+            if constexpr (XF8) decode_x(xr, xs); else {
+#pragma unroll
+                for (int k = 0; k < NXK; ++k) xs[k] = xn[k];
+            }
+            if constexpr (YF8) yr.decode(2 * ib0, ys); else {
+#pragma unroll
+                for (int k = 0; k < NYK; ++k) ys[k] = yn[k];
+            }
+        };
+        if (s_begin < s_end) { fetch(s_begin); land(); }
+        for (int64_t s = s_begin; s < s_end; ++s) {
+#if WGRAD_LOCKSTEP
+            if constexpr (WO > 1 || WI > 1) __builtin_amdgcn_s_barrier();
+#endif
+            fetch((s + 1 < s_end) ? s + 1 : s);
+            multiply(xs, ys);
+            land();
         }
     } else {
     bf16x8 xs[NXK], ys[NYK], xn[NXK], yn[NYK];
@@ -702,7 +882,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
                 const int row = 32 * (ob0 + xmap(a)) + (r & 3) + 8 * (r >> 2) + 4 * h;
                 out[(size_t)row * (32 * NIB) + 32 * (ib0 + ymap(b)) + j] = acc[a][b][r];
             }
-    if (J.bias_partial != nullptr && wi == 0) {
+    if (XCHG && WGRAD_EXCHANGE_TRANSPOSED) {                // every wave summed the rows of its own two transposed X blocks
+        if (J.bias_partial != nullptr) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+                if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + xmap(a)) + j] = v;
+            }
+        }
+    } else if (J.bias_partial != nullptr && wi == 0) {
 #pragma unroll
         for (int a = 0; a < OBW; ++a) {
             const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
@@ -913,24 +1101,24 @@ int bwd_grid(int64_t n_tiles) {
     return (int)(n_tiles < n_cu ? n_tiles : n_cu);
 }
 
-template <class P>
+template <class P, bool F8 = false>
 int launch_prop_bwd(const void* packed, const float* g, int64_t M, Dump act, Dump dlt, hipStream_t st) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
-    const size_t lds = bwd_lds_total<P>();
-    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(prop_bwd_kernel<P>), lds)) return e;
-    hipLaunchKernelGGL(prop_bwd_kernel<P>, dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, packed, g, M, act, dlt);
+    const size_t lds = F8 ? bwd_lds_total_f8<P>() : bwd_lds_total<P>();
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(prop_bwd_kernel<P, F8>), lds)) return e;
+    hipLaunchKernelGGL((prop_bwd_kernel<P, F8>), dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, packed, g, M, act, dlt);
     return (int)hipGetLastError();
 }
-template <class P>
+template <class P, bool F8 = false>
 int launch_mip_bwd(const void* packed, const float* g, const float* rgbo, int64_t M, Dump act, Dump dlt, hipStream_t st) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
-    const size_t lds = bwd_lds_total<P>();
-    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(mip_bwd_kernel<P>), lds)) return e;
-    hipLaunchKernelGGL(mip_bwd_kernel<P>, dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, packed, g, rgbo, M, act, dlt);
+    const size_t lds = F8 ? bwd_lds_total_f8<P>() : bwd_lds_total<P>();
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(mip_bwd_kernel<P, F8>), lds)) return e;
+    hipLaunchKernelGGL((mip_bwd_kernel<P, F8>), dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, packed, g, rgbo, M, act, dlt);
     return (int)hipGetLastError();
 }
 
@@ -941,6 +1129,12 @@ template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false>
 int launch_wgrad(int precision, const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
     if (precision == NERF_AMD_BF16) hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND, XCHG>), dim3(n_wg, n_jobs), dim3(256), XCHG ? 65536 : 0, st, jobs, n_sub);
     else hipLaunchKernelGGL((wgrad_kernel_f32<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
+    return (int)hipGetLastError();
+}
+// fp8 dump operands (NERF_AMD_BF16_F8): XF8 / YF8 say which operand comes from an fp8 slot
+template <int KGX, int KGY, int WO, int YKIND, bool XCHG, bool XF8, bool YF8>
+int launch_wgrad_f8(const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
+    hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND, XCHG, XF8, YF8>), dim3(n_wg, n_jobs), dim3(256), XCHG ? 65536 : 0, st, jobs, n_sub);
     return (int)hipGetLastError();
 }
 
@@ -955,6 +1149,7 @@ int bwd_launch_prop_chain(const void* packed_bwd, int precision, const float* g_
     const unsigned long long ls = mlp_train_layer_stride(precision, M), ms = mlp_train_mask_stride(precision, M);
     const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls, reinterpret_cast<const char*>(act_dump) + (size_t)PROP_DUMP_SLOTS * ls, ms},
                dlt{reinterpret_cast<char*>(delta_dump), ls, nullptr, 0ull};
+    if (precision == NERF_AMD_BF16_F8) return launch_prop_bwd<PB16, true>(packed_bwd, g_density, M, act, dlt, st);   // (the chain reads only the mask bits of `act`)
     if (precision == NERF_AMD_BF16) return launch_prop_bwd<PB16>(packed_bwd, g_density, M, act, dlt, st);
     return launch_prop_bwd<PF32>(packed_bwd, g_density, M, act, dlt, st);
 }
@@ -963,6 +1158,7 @@ int bwd_launch_mip_chain(const void* packed_bwd, int precision, const float* g_r
     const unsigned long long ls = mlp_train_layer_stride(precision, M), ms = mlp_train_mask_stride(precision, M);
     const Dump act{const_cast<char*>(reinterpret_cast<const char*>(act_dump)), ls, reinterpret_cast<const char*>(act_dump) + (size_t)MIP_DUMP_SLOTS * ls, ms},
                dlt{reinterpret_cast<char*>(delta_dump), ls, nullptr, 0ull};
+    if (precision == NERF_AMD_BF16_F8) return launch_mip_bwd<PB16, true>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
     if (precision == NERF_AMD_BF16) return launch_mip_bwd<PB16>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
     return launch_mip_bwd<PF32>(packed_bwd, g_rgbo, rgbo, M, act, dlt, st);
 }
@@ -972,17 +1168,32 @@ namespace {
 struct Product { const char* x0; int kgx0; const char* x1; const char* y; float* partial; float* bias_partial; };
 
 // shape codes: 0 = 256 x 256 (D map), 1 = 256 x PE10, 2 = (128 + head) x 256, 3 = head x 128, 4 = 128 x PE4, 5 = head x 256
-int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, int64_t n_sub, hipStream_t st) {
+// f8 (NERF_AMD_BF16_F8 dumps of the proposal / MipNeRF networks): the hidden delta / activation slots among the operands are fp8 slots
+// (subtiles F8_SUB_BYTES apart); which operand of a shape is one follows from what the shape multiplies (see the callers)
+int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, int64_t n_sub, hipStream_t st, bool f8 = false) {
     if (n < 1 || n > WG_MAX_JOBS) return (int)hipErrorInvalidValue;
     const size_t breg = precision == NERF_AMD_BF16 ? 1024 : 2048;
+    const bool xf8 = f8 && shape != 3 && shape != 5, yf8 = f8 && (shape == 0 || shape == 2 || shape == 3 || shape == 5);
     WgradJobs jobs = {};
     for (int i = 0; i < n; ++i) {
         WgradJob& J = jobs.j[i];
-        J.x0 = FragMat{prods[i].x0, 16 * breg};
+        J.x0 = FragMat{prods[i].x0, xf8 ? (size_t)F8_SUB_BYTES : 16 * breg};
         J.kgx0 = prods[i].kgx0;
         J.x1 = FragMat{prods[i].x1, 16 * breg};
-        J.y = FragMat{prods[i].y, 16 * breg};
+        J.y = FragMat{prods[i].y, yf8 ? (size_t)F8_SUB_BYTES : 16 * breg};
         J.partial = prods[i].partial; J.bias_partial = prods[i].bias_partial;
+    }
+    if (f8) {
+        if (precision != NERF_AMD_BF16) return (int)hipErrorInvalidValue;
+        switch (shape) {
+            case 0: return launch_wgrad_f8<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0, true, true>(jobs, n, n_wg, n_sub, st);
+            case 1: return launch_wgrad_f8<16, 4, 4, Y_PE10, false, true, false>(jobs, n, n_wg, n_sub, st);
+            case 2: return launch_wgrad_f8<9, 16, 1, Y_DMAP, false, true, true>(jobs, n, n_wg, n_sub, st);
+            case 3: return launch_wgrad_f8<1, 8, 1, Y_DMAP, false, false, true>(jobs, n, n_wg, n_sub, st);
+            case 4: return launch_wgrad_f8<8, 2, 4, Y_PE4, false, true, false>(jobs, n, n_wg, n_sub, st);
+            case 5: return launch_wgrad_f8<1, 16, 1, Y_DMAP, false, false, true>(jobs, n, n_wg, n_sub, st);
+        }
+        return (int)hipErrorInvalidValue;
     }
     switch (shape) {
         case 0: return launch_wgrad<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
@@ -1019,7 +1230,7 @@ struct Carver {
 }  // namespace
 
 int64_t bwd_n_sub(int precision, int64_t M) {
-    const int64_t ts = (precision == NERF_AMD_BF16) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;
+    const int64_t ts = (precision != NERF_AMD_F32) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;
     return ((M + ts - 1) / ts) * (ts / 32);
 }
 
@@ -1044,6 +1255,8 @@ size_t bwd_wgrad_workspace_bytes(int net, int precision, int64_t M) {
 // ProposalNetwork: d_w / d_b = gradients of layers.{0,2,4,6,8} (addtional.py:67-71), written in the reference's (out, in) layout
 int bwd_prop_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, float* const* d_w, float* const* d_b,
                           void* workspace, hipStream_t st) {
+    const bool f8 = precision == NERF_AMD_BF16_F8;          // hidden slots of both dumps in scaled e4m3 (arithmetic: bf16)
+    if (f8) precision = NERF_AMD_BF16;
     const int64_t n_sub = bwd_n_sub(precision, M);
     if (n_sub == 0) return 0;
     const size_t breg = precision == NERF_AMD_BF16 ? 1024 : 2048, ls = mlp_train_layer_stride(precision, M);
@@ -1060,11 +1273,11 @@ int bwd_prop_weight_grads(int precision, int64_t M, const void* act_dump, const 
     // layers.{2,4,6}: delta_L^T y_{L-1}
     Product p0[3];
     for (int i = 0; i < 3; ++i) p0[i] = Product{D(i + 1), 16, nullptr, A(i), pw[i], pb[i]};
-    if (int e = run_wgrad(0, precision, p0, 3, w0, n_sub, st)) return e;
+    if (int e = run_wgrad(0, precision, p0, 3, w0, n_sub, st, f8)) return e;
     const Product p1{D(0), 16, nullptr, A(4), pe, pe_b};                   // layers.0: delta_0^T [x | PE10(x)]
-    if (int e = run_wgrad(1, precision, &p1, 1, w1, n_sub, st)) return e;
+    if (int e = run_wgrad(1, precision, &p1, 1, w1, n_sub, st, f8)) return e;
     const Product p5{D(4), 1, nullptr, A(3), ph, ph_b};                    // layers.8: g^T y_3 (slot feature 0 of the head K group)
-    if (int e = run_wgrad(5, precision, &p5, 1, w1, n_sub, st)) return e;
+    if (int e = run_wgrad(5, precision, &p5, 1, w1, n_sub, st, f8)) return e;
     FinalizeJob f[5];
     for (int i = 0; i < 3; ++i) f[i] = FinalizeJob{pw[i], 256, 256, d_w[i + 1], 256, 0, 0, 256, 256, pb[i], d_b[i + 1], 256, 0, 256, w0};
     f[3] = FinalizeJob{pe, 256, 64, d_w[0], 63, 0, 0, 256, 63, pe_b, d_b[0], 256, 0, 256, w1};
@@ -1075,6 +1288,8 @@ int bwd_prop_weight_grads(int precision, int64_t M, const void* act_dump, const 
 // MipNeRF: tensors in _linear_layers() order (0..3 lin_block1, 4..6 lin_block2, 7 bottle_neck.0, 8 opacity_head.0, 9, 10 rgb_layer.{0,2})
 int bwd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* w, const float* const* b,
                          float* const* d_w, float* const* d_b, void* workspace, hipStream_t st) {
+    const bool f8 = precision == NERF_AMD_BF16_F8;          // hidden slots of both dumps in scaled e4m3 (arithmetic: bf16)
+    if (f8) precision = NERF_AMD_BF16;
     const int64_t n_sub = bwd_n_sub(precision, M);
     if (n_sub == 0) return 0;
     const size_t breg = precision == NERF_AMD_BF16 ? 1024 : 2048, ls = mlp_train_layer_stride(precision, M);
@@ -1096,17 +1311,17 @@ int bwd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const v
     const int Ls[6] = {1, 2, 3, 4, 5, 6};
     Product p0[6];
     for (int i = 0; i < 6; ++i) p0[i] = Product{D(Ls[i]), 16, nullptr, A(Ls[i] - 1), pw[i], pb[i]};
-    if (int e = run_wgrad(0, precision, p0, 6, w0, n_sub, st)) return e;
+    if (int e = run_wgrad(0, precision, p0, 6, w0, n_sub, st, f8)) return e;
     // lin_block1.0 and the encoding columns of lin_block2.0: delta^T [x | PE10(x)]
     const Product p1[2] = {Product{D(0), 16, nullptr, A(8), pe0, pe0_b}, Product{D(4), 16, nullptr, A(8), pe4, nullptr}};
-    if (int e = run_wgrad(1, precision, p1, 2, w1, n_sub, st)) return e;
+    if (int e = run_wgrad(1, precision, p1, 2, w1, n_sub, st, f8)) return e;
     // heads: [dc | dpre dsigma]^T g6 -> G (rows 0..127), rows 128..130 unused, row 131 = opacity_head.0
     const Product p2{D(7), 8, D(8), A(6), pg, pg_b};
-    if (int e = run_wgrad(2, precision, &p2, 1, w2, n_sub, st)) return e;
+    if (int e = run_wgrad(2, precision, &p2, 1, w2, n_sub, st, f8)) return e;
     const Product p3{D(8), 1, nullptr, A(7), phc, nullptr};                // rgb_layer.2: dpre^T c
-    if (int e = run_wgrad(3, precision, &p3, 1, w3, n_sub, st)) return e;
+    if (int e = run_wgrad(3, precision, &p3, 1, w3, n_sub, st, f8)) return e;
     const Product p4{D(7), 8, nullptr, A(8, 4), pcd, nullptr};             // rgb_layer.0's direction columns: dc^T [d | PE4(d)]
-    if (int e = run_wgrad(4, precision, &p4, 1, w3, n_sub, st)) return e;
+    if (int e = run_wgrad(4, precision, &p4, 1, w3, n_sub, st, f8)) return e;
     FinalizeJob f[13];
     int n = 0;
     for (int i = 0; i < 6; ++i) {

@@ -109,7 +109,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 111; }
+int nerf_amd_version(void) { return 112; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -331,22 +331,25 @@ int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N,
 static int train_layers(int net) {
     return net == NERF_AMD_NET_PROPOSAL ? PROP_DUMP_SLOTS : (net == NERF_AMD_NET_MIP ? MIP_DUMP_SLOTS : (net == NERF_AMD_NET_REF ? REF_DUMP_SLOTS : 0));
 }
+static bool bad_train_prec(int p, int net = NERF_AMD_NET_MIP) {           // the fp8-dump mode exists for the proposal and MipNeRF networks
+    return p != NERF_AMD_F32 && p != NERF_AMD_BF16 && !(p == NERF_AMD_BF16_F8 && net != NERF_AMD_NET_REF);
+}
 size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M) {
-    if (M < 0 || !train_layers(net) || (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16)) return 0;
+    if (M < 0 || !train_layers(net) || bad_train_prec(precision, net)) return 0;
     // activation slots + (proposal / MipNeRF) one ReLU bit per activation: 1 KiB per slot and 32-sample subtile
     const size_t bits = net == NERF_AMD_NET_REF ? 0 : (size_t)train_layers(net) * mlp_train_mask_stride(precision, M);
     return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M) + bits;
 }
 int nerf_amd_proposal_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* dump, void* stream) {
     if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
-    if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
+    if (bad_train_prec(precision)) return fail(NERF_AMD_EINVAL, "bad precision");
     if (src->M && !density) return fail(NERF_AMD_EINVAL, "NULL output");
     if (int c = check_samples(src, false)) return c;
     return hip_status(mlp_launch_proposal_train(packed, precision, *src, density, dump, S(stream)), "nerf_amd_proposal_forward_train");
 }
 int nerf_amd_mip_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* dump, void* stream) {
     if (!packed || !src || !dump) return fail(NERF_AMD_EINVAL, "NULL argument");
-    if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "bad precision");
+    if (bad_train_prec(precision)) return fail(NERF_AMD_EINVAL, "bad precision");
     if (src->M && !rgbo) return fail(NERF_AMD_EINVAL, "NULL output");
     if (int c = check_samples(src, true)) return c;         // (every sample mode, integrated PE and scene contraction included)
     return hip_status(mlp_launch_mip_train(packed, precision, *src, rgbo, dump, S(stream)), "nerf_amd_mip_forward_train");
@@ -424,25 +427,25 @@ int nerf_amd_pack_weights_backward(int net, int precision, const float* const* w
 }
 int nerf_amd_proposal_backward_chain(const void* packed_bwd, int precision, const float* g_density, int64_t M, const void* act_dump,
                                      void* delta_dump, void* stream) {
-    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (bad_train_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
     if (M == 0) return NERF_AMD_OK;
     if (!packed_bwd || !g_density || !act_dump || !delta_dump) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(bwd_launch_prop_chain(packed_bwd, precision, g_density, M, act_dump, delta_dump, S(stream)), "nerf_amd_proposal_backward_chain");
 }
 int nerf_amd_mip_backward_chain(const void* packed_bwd, int precision, const float* g_rgbo, const float* rgbo, int64_t M, const void* act_dump,
                                 void* delta_dump, void* stream) {
-    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (bad_train_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
     if (M == 0) return NERF_AMD_OK;
     if (!packed_bwd || !g_rgbo || !rgbo || !act_dump || !delta_dump) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(bwd_launch_mip_chain(packed_bwd, precision, g_rgbo, rgbo, M, act_dump, delta_dump, S(stream)), "nerf_amd_mip_backward_chain");
 }
 size_t nerf_amd_weight_grads_workspace_bytes(int net, int precision, int64_t M) {
-    if (bad_prec(precision) || M < 0) return 0;
-    return bwd_wgrad_workspace_bytes(net, precision, M);
+    if (bad_train_prec(precision, net) || M < 0) return 0;
+    return bwd_wgrad_workspace_bytes(net, precision == NERF_AMD_BF16_F8 ? NERF_AMD_BF16 : precision, M);
 }
 int nerf_amd_proposal_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, float* const* d_weights,
                                    float* const* d_biases, void* workspace, void* stream) {
-    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (bad_train_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
     if (!d_weights || !d_biases) return fail(NERF_AMD_EINVAL, "NULL argument");
     for (int i = 0; i < 5; ++i)
         if (!d_weights[i] || !d_biases[i]) return fail(NERF_AMD_EINVAL, "NULL gradient tensor");
@@ -452,7 +455,7 @@ int nerf_amd_proposal_weight_grads(int precision, int64_t M, const void* act_dum
 }
 int nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const void* delta_dump, const float* const* weights,
                               const float* const* biases, float* const* d_weights, float* const* d_biases, void* workspace, void* stream) {
-    if (bad_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
+    if (bad_train_prec(precision) || M < 0) return fail(NERF_AMD_EINVAL, "bad precision or size");
     if (!weights || !biases || !d_weights || !d_biases) return fail(NERF_AMD_EINVAL, "NULL argument");
     for (int i = 0; i < 11; ++i)
         if (!weights[i] || !biases[i] || !d_weights[i] || !d_biases[i]) return fail(NERF_AMD_EINVAL, "NULL tensor");

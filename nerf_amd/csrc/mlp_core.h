@@ -156,6 +156,64 @@ struct PF32 {
 };
 
 // ------------------------------------------------------------------------------------------------
+// fp8 training dumps (mlp_layout.h F8_SUB_BYTES): scaled e4m3 <-> bf16 B register groups.
+// gfx950's scaled conversions divide by / multiply with a float scale (only powers of two are used: exact); an out-of-range value
+// encodes as NaN (no saturation), so the scale is taken from the group's largest magnitude: 2^(e_max - 7) maps it into [128, 256) <= 448.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+
+// biased scale exponent E of one B register group; SIGNED = false for post-ReLU activations (no sign bits to clear)
+template <bool SIGNED>
+DEVINL uint32_t f8_group_exponent(const bf16x8& v) {
+    const u32x4 d = __builtin_bit_cast(u32x4, v);
+    uint32_t a = d[0], b = d[1], c = d[2], e = d[3];
+    if (SIGNED) { a &= 0x7fff7fffu; b &= 0x7fff7fffu; c &= 0x7fff7fffu; e &= 0x7fff7fffu; }
+    const u16x2 m01 = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));      // bf16 magnitudes order like uint16
+    const u16x2 m23 = __builtin_elementwise_max(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, e));
+    const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(m01, m23));
+    const uint32_t top = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
+    const uint32_t ex = top >> 7;                                     // the bf16 exponent field of the largest magnitude
+    return ex > 8u ? ex - 7u : 1u;
+}
+DEVINL u32x2 f8_encode_group(const bf16x8& v, uint32_t E) {
+    const float scale = __builtin_bit_cast(float, E << 23);
+    const u32x4 d = __builtin_bit_cast(u32x4, v);
+    s16x2 lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, (uint32_t)d[0]), scale, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, (uint32_t)d[1]), scale, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, (uint32_t)d[2]), scale, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, (uint32_t)d[3]), scale, true);
+    u32x2 r = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+    return r;
+}
+DEVINL bf16x8 f8_decode_group(uint32_t lo, uint32_t hi, uint32_t E) {
+    const float scale = __builtin_bit_cast(float, E << 23);
+    const bf16x2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, scale, false), p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, scale, true);
+    const bf16x2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, scale, false), p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, scale, true);
+    bf16x8 r = {p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+    return r;
+}
+// write one K group of a subtile's fp8 slot: 8 bytes of data to global memory (non-temporal like the bf16 dumps), the scale exponent
+// into the wave's LDS record `scale_rec` (lane-major, 16 bytes per lane), which f8_flush_scales writes out once the slot's 16 groups are in
+DEVINL void f8_store_group(char* sub_base, int kg, int lane, const u32x2& v, uint32_t E, uint32_t scale_rec) {
+    u32x2* dst = reinterpret_cast<u32x2*>(sub_base + (kg >> 1) * 1024 + lane * 16 + (kg & 1) * 8);
+#if MLP_DUMP_NT
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+    *reinterpret_cast<unsigned char*>(smem + scale_rec + lane * 16 + kg) = (unsigned char)E;
+}
+DEVINL void f8_flush_scales(char* sub_base, int lane, uint32_t scale_rec) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + scale_rec + lane * 16);
+    *reinterpret_cast<f32x4*>(sub_base + F8_SCALE_OFF + lane * 16) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight stream: L2 -> LDS ring, consumed in lock step by all wavefronts of the workgroup
 // ------------------------------------------------------------------------------------------------
 // SAFE: wait for everything (vmcnt(0)) at every barrier instead of a counted wait.  It was the first form of the training kernels,

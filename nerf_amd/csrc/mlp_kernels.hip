@@ -232,6 +232,20 @@ DEVINL void dump_breg(const ActDump& d, int layer, int64_t subtile, int kg, int 
 // (ds_or_b32: no registers held across the layer) and written out once per layer and subtile.
 template <class P> constexpr uint32_t lds_maskacc() { return lds_total<P>(); }
 template <class P> constexpr uint32_t lds_total_train() { return lds_total<P>() + P::NW * 2 * P::NT * 1024; }
+// fp8 dumps: per wave two (layer parity) x NT records of scale exponents behind the mask records
+template <class P> constexpr uint32_t lds_scaleacc() { return lds_total_train<P>(); }
+template <class P> constexpr uint32_t lds_total_train_f8() { return lds_total_train<P>() + P::NW * 2 * P::NT * 1024; }
+// one hidden-layer K group of the training dump: bf16 fragment block, or (F8) scaled e4m3 + its exponent into the wave's LDS record
+template <class P, bool F8>
+DEVINL void dump_hidden(const ActDump& d, uint32_t sacc_wave, int layer, int64_t subtile, int t, int kg, int lane, const typename P::BReg& r) {
+    if constexpr (F8) {
+        const uint32_t E = f8_group_exponent<false>(r);
+        f8_store_group(d.base + (size_t)layer * d.layer_stride + (size_t)subtile * F8_SUB_BYTES, kg, lane, f8_encode_group(r, E), E,
+                       sacc_wave + ((layer & 1) * P::NT + t) * 1024);
+    } else {
+        dump_breg<P>(d, layer, subtile, kg, lane, r);
+    }
+}
 DEVINL uint32_t breg_bits(const bf16x8& v) {
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
@@ -257,8 +271,8 @@ DEVINL void mask_or(uint32_t acc_wave, int layer, int t, int kg, int lane, const
     __hip_atomic_fetch_or(w, breg_bits(v) << (4 * (kg & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // the layer's records are complete (its last feature-block pair has been converted): write them out and clear the LDS copy
-template <class P>
-DEVINL void mask_flush(const ActDump& d, uint32_t acc_wave, int layer, int64_t sub0, int lane) {
+template <class P, bool F8 = false>
+DEVINL void mask_flush(const ActDump& d, uint32_t acc_wave, int layer, int64_t sub0, int lane, uint32_t sacc_wave = 0) {
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int t = 0; t < P::NT; ++t) {
@@ -266,6 +280,8 @@ DEVINL void mask_flush(const ActDump& d, uint32_t acc_wave, int layer, int64_t s
         const f32x4 v = *rec;
         *reinterpret_cast<f32x4*>(d.mask_base + (size_t)layer * d.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16) = v;
         *rec = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (F8)                                    // the slot's scale exponents (every byte is rewritten by the next layer of this parity)
+            f8_flush_scales(d.base + (size_t)layer * d.layer_stride + (size_t)(sub0 + t) * F8_SUB_BYTES, lane, sacc_wave + ((layer & 1) * P::NT + t) * 1024);
     }
     asm volatile("" ::: "memory");
 }
@@ -278,7 +294,7 @@ DEVINL void mask_acc_init(uint32_t acc_wave, int lane) {
 // ================================================================================================
 // ProposalNetwork
 // ================================================================================================
-template <class P, bool TRAIN>
+template <class P, bool TRAIN, bool F8 = false>
 __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                               float* __restrict__ density, ActDump dump) {
     using L = PropLayout;
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = MLP_RING_BYTES;
     const uint32_t macc = lds_maskacc<P>() + wave * 2 * NT * 1024;      // TRAIN: this wave's ReLU bit-mask records
+    const uint32_t sacc = lds_scaleacc<P>() + wave * 2 * NT * 1024;     // F8: this wave's scale-exponent records
     if constexpr (TRAIN) mask_acc_init<P>(macc, lane);
 
 #ifdef MLP_PHASEPROBE
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
-                dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+                dump_hidden<P, F8>(dump, sacc, layer, sub0 + t, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
                 mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
             }
         };
@@ -351,11 +368,11 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         for (int r = 0; r < 2; ++r) {
             lay_pend = lay; lay = 1 + 2 * r;
             d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + r * 512) * 4, IN_A, OB, prev_of(d, OA_pend));
-            if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);        // (its last pair was converted during this layer)
+            if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, lay_pend, sub0, lane, sacc);        // (its last pair was converted during this layer)
             if (r == 0) {
                 lay_pend = lay; lay = 2;
                 d = dense<P, 16, 8, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB_pend));
-                if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);
+                if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, lay_pend, sub0, lane, sacc);
             }
         }
         lay_pend = lay;
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         float dens[NT];
         auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
         dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB_pend)).flush(OH);
-        if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);
+        if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, lay_pend, sub0, lane, sacc);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
@@ -391,7 +408,7 @@ struct FusedComposite {
     float near, far;
 };
 
-template <class P, bool TRAIN, bool IPE = false>
+template <class P, bool TRAIN, bool IPE = false, bool F8 = false>
 __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                          float* __restrict__ rgbo, FusedComposite fc, ActDump dump) {
     using L = MipLayout;
@@ -411,6 +428,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     const uint32_t bias0 = LDS_BIAS;
     const uint32_t macc = lds_maskacc<P>() + wave * 2 * NT * 1024;      // TRAIN: this wave's ReLU bit-mask records
+    const uint32_t sacc = lds_scaleacc<P>() + wave * 2 * NT * 1024;     // F8: this wave's scale-exponent records
     if constexpr (TRAIN) mask_acc_init<P>(macc, lane);
     // per 32-sample column tile ("subtile" sub = wave*NT + t) LDS slots
     const uint32_t enc_lds0 = LDS_STASH + wave * NT * 4 * P::BREG_LDS + lane * 16;
@@ -426,7 +444,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
-                dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+                dump_hidden<P, F8>(dump, sacc, layer, sub0 + t, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
                 mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
             }
         };
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         for (int r = 0; r < 3; ++r) {
             lay_pend = lay; lay = 1 + 2 * r;
             d = dense<P, 16, 8, L::START[1]>(ws, bias0 + (1 + 2 * r) * 256 * 4, IN_A, OB, prev_of(d, OA_pend));
-            if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);        // (its last pair was converted during this layer)
+            if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, lay_pend, sub0, lane, sacc);        // (its last pair was converted during this layer)
             lay_pend = lay; lay = 2 + 2 * r;
             if (r == 1) {
                 d = dense<P, 20, 8, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4,
@@ -500,14 +518,14 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             } else {
                 d = dense<P, 16, 8, L::START[2]>(ws, bias0 + (2 + 2 * r) * 256 * 4, IN_B, OA, prev_of(d, OB_pend));
             }
-            if constexpr (TRAIN) mask_flush<P>(dump, macc, lay_pend, sub0, lane);
+            if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, lay_pend, sub0, lane, sacc);
         }
         lay_pend = lay;
         // opacity_head.0 : 256 -> 1 (raw sigma)
         float sigma[NT];
         auto OSIG = [&](int, int t, const f32x16& acc, int half) { if (half == 0) sigma[t] = acc[0]; };
         const auto dsig = dense<P, 16, 1, L::START[7]>(ws, bias0 + L::BIAS_OFF[7] * 4, IN_A, OSIG, prev_of(d, OA_pend));
-        if constexpr (TRAIN) mask_flush<P>(dump, macc, 6, sub0, lane);
+        if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, 6, sub0, lane, sacc);
         // direction: d/|d| and PE4 (mip_model.py:43-46,51)
         BReg denc[NT][2];
 #pragma unroll
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         auto OC = [&](int fb, int t, const f32x16& acc, int half) {
             c[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {                                                                       // slot 7: rgb_layer.0 output
-                dump_breg<P>(dump, 7, sub0 + t, 2 * fb + half, lane, c[t][2 * fb + half]);
+                dump_hidden<P, F8>(dump, sacc, 7, sub0 + t, t, 2 * fb + half, lane, c[t][2 * fb + half]);
                 mask_or<P>(macc, 7, t, 2 * fb + half, lane, c[t][2 * fb + half]);
             }
         };
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         auto ORGB = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { r[t] = acc[0]; g[t] = acc[1]; bl[t] = acc[2]; } };
         dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
             [&](int kg, int t) -> BReg { return c[t][kg]; }, ORGB, prev_of(dc, OC)).flush(ORGB);
-        if constexpr (TRAIN) mask_flush<P>(dump, macc, 7, sub0, lane);
+        if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, 7, sub0, lane, sacc);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
         f32x4 o;
@@ -874,12 +892,12 @@ int grid_for(int64_t n_tiles) {
 // Dynamic LDS above 64 KiB is an opt-in per KERNEL FUNCTION and device (host_common.h)
 int allow_dynamic_lds(const void* fn, size_t lds) { return nerf_host::allow_dynamic_lds(fn, lds); }
 
-template <class P, class Lay, bool TRAIN = false, class K, class... Extra>
+template <class P, class Lay, bool TRAIN = false, bool F8 = false, class K, class... Extra>
 int launch(K kernel, const void* packed, const nerf_amd_samples& s, float* out, hipStream_t st, Extra... extra) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
-    const size_t lds = TRAIN ? lds_total_train<P>() : lds_total<P>();
+    const size_t lds = F8 ? lds_total_train_f8<P>() : (TRAIN ? lds_total_train<P>() : lds_total<P>());
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
     hipLaunchKernelGGL(kernel, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, out, extra...);
     return (int)hipGetLastError();
@@ -931,12 +949,12 @@ int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_s
 // training forwards: the same kernels, also dumping the hidden activations (ActDump) for the backward
 #if MLP_TU == 0 || MLP_TU == 1
 size_t mlp_train_layer_stride(int precision, int64_t M) {
-    const int64_t ts = (precision == NERF_AMD_BF16) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;
+    const int64_t ts = (precision != NERF_AMD_F32) ? (int64_t)PB16::NW * PB16::NT * 32 : (int64_t)PF32::NW * PF32::NT * 32;   // (BF16_F8 slots keep the bf16 footprint)
     const int64_t n_sub = ((M + ts - 1) / ts) * (ts / 32);
-    return (size_t)n_sub * 16 * (precision == NERF_AMD_BF16 ? 1024 : 2048);
+    return (size_t)n_sub * 16 * (precision != NERF_AMD_F32 ? 1024 : 2048);
 }
 // the ReLU bit masks sit behind the `slots` activation slots of a dump: 1 KiB per slot and subtile
-size_t mlp_train_mask_stride(int precision, int64_t M) { return mlp_train_layer_stride(precision, M) / (16 * (precision == NERF_AMD_BF16 ? 1024 : 2048)) * 1024; }
+size_t mlp_train_mask_stride(int precision, int64_t M) { return mlp_train_layer_stride(precision, M) / (16 * (precision != NERF_AMD_F32 ? 1024 : 2048)) * 1024; }
 #else
 size_t mlp_train_layer_stride(int precision, int64_t M);
 size_t mlp_train_mask_stride(int precision, int64_t M);
@@ -947,6 +965,10 @@ static ActDump make_dump(void* dump, int precision, int64_t M, int slots) {
 }
 #if MLP_TU == 0 || MLP_TU == 1
 int mlp_launch_proposal_train(const void* packed, int precision, const nerf_amd_samples& s, float* density, void* dump, hipStream_t st) {
+    if (precision == NERF_AMD_BF16_F8) {                    // bf16 arithmetic, hidden slots of the dump in scaled e4m3 (mlp_layout.h)
+        const ActDump d8 = make_dump(dump, NERF_AMD_BF16, s.M, PROP_DUMP_SLOTS);
+        return launch<PB16, PropLayout, true, true>(proposal_kernel<PB16, true, true>, packed, s, density, st, d8);
+    }
     const ActDump d = make_dump(dump, precision, s.M, PROP_DUMP_SLOTS);
     if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout, true>(proposal_kernel<PB16, true>, packed, s, density, st, d);
     return launch<PF32, PropLayout, true>(proposal_kernel<PF32, true>, packed, s, density, st, d);
@@ -955,6 +977,11 @@ int mlp_launch_proposal_train(const void* packed, int precision, const nerf_amd_
 #if MLP_TU == 0 || MLP_TU == 2
 int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, void* dump, hipStream_t st) {
     const FusedComposite off{nullptr, nullptr, nullptr, 0, 0.0f, 1.0f};
+    if (precision == NERF_AMD_BF16_F8) {                    // bf16 arithmetic, hidden slots of the dump in scaled e4m3 (mlp_layout.h)
+        const ActDump d8 = make_dump(dump, NERF_AMD_BF16, s.M, MIP_DUMP_SLOTS);
+        if (s.ipe) return launch<PB16, MipLayout, true, true>(mip_kernel<PB16, true, true, true>, packed, s, rgbo, st, off, d8);
+        return launch<PB16, MipLayout, true, true>(mip_kernel<PB16, true, false, true>, packed, s, rgbo, st, off, d8);
+    }
     const ActDump d = make_dump(dump, precision, s.M, MIP_DUMP_SLOTS);
     if (s.ipe) {                                            // integrated PE on the training path (BASELINE configs[2]): the dumped encoding slot
         // holds the IPE features in the PE10 slot map, so the dgrad chain and the weight-gradient kernels run unchanged

@@ -128,6 +128,11 @@ struct RefBwdLayout {
 // Delta dump of the backward chain: slot L = delta of the layer whose activations sit in activation slot L; the head K group goes to
 // K group 0 of slot 4 (proposal) / slot 8 (MipNeRF).
 constexpr int PROP_DUMP_SLOTS = 5, MIP_DUMP_SLOTS = 9, REF_DUMP_SLOTS = 17;
+// fp8 dumps (NERF_AMD_BF16_F8): a HIDDEN slot (proposal 0..3, MipNeRF 0..7; activations and deltas alike) holds per 32-sample subtile
+//   8 data blocks of 1 KiB -- block fb, lane l: [K group 2 fb: 8 x e4m3 | K group 2 fb + 1: 8 x e4m3] -- followed by 1 KiB of scale
+//   exponents -- lane l, byte kg = E (biased like an fp32 exponent): element value = e4m3 * 2^(E - 127).
+// The slot keeps its `layer_stride` footprint (subtiles 9 KiB apart inside it); the encoding / head slot (proposal 4, MipNeRF 8) stays bf16.
+constexpr int F8_SUB_BYTES = 9216, F8_SCALE_OFF = 8192;
 
 // RefNeRF(10, 4, bottle_neck 128, hidden 256, output 256)  (ref_model.py:16-66), eval mode, use_srgb = False.
 //   spatial: S0 63->256, S1-3, S4 319->256 (skip), S5-7;  H: [bottle_neck 128 rows | 11 head rows];

@@ -49,15 +49,16 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         return [l.weight for l in layers] + [l.bias for l in layers]
 
     def _train_op(self, prec, run_forward, spec, *tensors):
-        """Training forward (activation dump) + the hand-written backward on it (mlp_backward.py) as one autograd node.  `run_forward()`
-        -> (rgbo, dump); `spec` = the torch expression the backward is tested against (never evaluated here: a shape the kernels
+        """Training forward (activation dump) + the hand-written backward on it (mlp_backward.py) as one autograd node.
+        `run_forward(training precision code)` -> (rgbo, dump); `spec` = the torch expression the backward is tested against (never evaluated here: a shape the kernels
         cannot differentiate raises instead of falling back to library GEMMs)."""
         from . import mlp_backward
         held = {}
         n_in = len(tensors)
+        tprec = ops.train_precision(prec)                                # (bf16 arithmetic with fp8 dumps: ops.set_train_dumps)
 
         def hip(*args):
-            out, held["dump"] = run_forward()
+            out, held["dump"] = run_forward(tprec)
             held["out"] = out
             return out
 
@@ -67,7 +68,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
             kw, kb = self.kernel_params()
             sinks = self.grad_sinks()                                    # persistent flat gradient buffer (parallel.FlatGradients)?
             direct = sinks is not None and sinks[2]
-            gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), None, held.pop("dump"), prec,
+            gW, gb = mlp_backward.mip_backward(g.reshape(-1, 4), held.pop("out").reshape(-1, 4), None, held.pop("dump"), tprec,
                                                kw, kb, packed_bwd=ops.pack_weights_backward(ops.NET_MIP, prec, kw),
                                                out=(sinks[0], sinks[1]) if direct else None)
             if sinks is not None:
@@ -91,7 +92,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
                 hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p, contract=contract)
                 return ab.HipOp.apply(hip, expr, 0, pts, *params)
             # parameter gradients: the training forward dumps the hidden activations, the backward is hand-written kernels on them (mlp_backward.py)
-            return self._train_op(prec, lambda: ops.mip_forward_train(self.packed(prec), prec, pts.detach(), contract=contract), expr, pts)
+            return self._train_op(prec, lambda tp: ops.mip_forward_train(self.packed(prec), tp, pts.detach(), contract=contract), expr, pts)
         return ops.mip_forward(self.packed(prec), prec, pts, contract=contract)
 
     def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int, ipe_radius=None, ipe_dir_norm: torch.Tensor = None,
@@ -116,5 +117,5 @@ class MipNeRF(PackedWeightsMixin, NeRF):
             def spec(*a):
                 raise NotImplementedError("nerf_amd: MipNeRF.forward_rays has a HIP backward only")
             keep = (rays, z, ipe_dir_norm)                               # the descriptor holds raw pointers: keep the tensors alive
-            return self._train_op(prec, lambda: (ops.mip_forward_train_samples(self.packed(prec), prec, s, shape, rays.device), keep)[0], spec)
+            return self._train_op(prec, lambda tp: (ops.mip_forward_train_samples(self.packed(prec), tp, s, shape, rays.device), keep)[0], spec)
         return ops.mip_forward_samples(self.packed(prec), prec, s, shape, rays.device)

@@ -24,7 +24,7 @@ def proposal_backward(g_density: torch.Tensor, pts: torch.Tensor, dump: torch.Te
     `out` = (weight sinks, bias sinks) to write instead of fresh tensors"""
     M = g_density.numel()
     if packed_bwd is None:
-        packed_bwd = ops.pack_weights_backward(ops.NET_PROPOSAL, precision, weights)
+        packed_bwd = ops.pack_weights_backward(ops.NET_PROPOSAL, ops.BF16 if precision == ops.BF16_F8 else precision, weights)
     delta = ops.proposal_backward_chain(packed_bwd, precision, g_density, dump)
     return ops.proposal_weight_grads(precision, M, dump, delta, out=out)
 
@@ -35,6 +35,6 @@ def mip_backward(g_rgbo: torch.Tensor, rgbo: torch.Tensor, pts: torch.Tensor, du
     """g_rgbo, rgbo (M,4); weights/biases in MipNeRF._linear_layers() order -> ([dW]*11, [db]*11); `out` as in proposal_backward"""
     M = g_rgbo.numel() // 4
     if packed_bwd is None:
-        packed_bwd = ops.pack_weights_backward(ops.NET_MIP, precision, weights)
+        packed_bwd = ops.pack_weights_backward(ops.NET_MIP, ops.BF16 if precision == ops.BF16_F8 else precision, weights)
     delta = ops.mip_backward_chain(packed_bwd, precision, g_rgbo, rgbo, dump)
     return ops.mip_weight_grads(precision, M, dump, delta, weights, biases, out=out)

@@ -7,7 +7,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import lib, check, Samples, F32, BF16, NET_PROPOSAL, NET_MIP, NET_REF, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
+from ._lib import lib, check, Samples, F32, BF16, BF16_F8, NET_PROPOSAL, NET_MIP, NET_REF, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
 
 _PRECISION_OVERRIDE = None          # None -> follow torch autocast (on: bf16, off: fp32)
 
@@ -19,6 +19,25 @@ def set_precision(p: Optional[str]):
     if p not in (None, "fp32", "bf16"):
         raise ValueError("precision must be None, 'fp32' or 'bf16'")
     _PRECISION_OVERRIDE = p
+
+
+_TRAIN_DUMPS = __import__("os").environ.get("NERF_AMD_TRAIN_DUMPS", "bf16")      # (env: profiling scripts; the API is set_train_dumps)
+
+
+def set_train_dumps(fmt: str):
+    """Storage format of the training dumps (hidden activations written by the training forwards, deltas written by the dgrad chains,
+    both read by the weight-gradient kernels) in 'bf16' precision mode: 'bf16' (default) or 'fp8' = OCP e4m3 with one power-of-two scale
+    per sample and 16-feature group (NERF_AMD_BF16_F8): 288 instead of 512 bytes per sample and layer in each pass.  The arithmetic --
+    forward, dgrad chain, MFMA weight gradients -- stays bf16 x bf16 -> fp32; only the weight gradients' operands are rounded."""
+    global _TRAIN_DUMPS
+    if fmt not in ("bf16", "fp8"):
+        raise ValueError("train dumps: 'bf16' or 'fp8'")
+    _TRAIN_DUMPS = fmt
+
+
+def train_precision(precision: int) -> int:
+    """precision code for the training entry points (forward_train / backward_chain / weight_grads) given the arithmetic precision"""
+    return BF16_F8 if (precision == BF16 and _TRAIN_DUMPS == "fp8") else precision
 
 
 def current_precision() -> int:

@@ -47,9 +47,11 @@ class Adam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             if step is None:
-                prev = st.get("step")
-                val = float(prev) if prev is not None else 0.0          # (a loaded torch.optim.Adam state keeps 'step' on the CPU)
-                step = torch.full((1,), val, dtype=torch.float32, device=dev)
+                # one device counter per group, seeded from the LARGEST per-parameter step of a loaded state (torch.optim.Adam keeps one per
+                # parameter; they agree whenever all parameters stepped together, which is the only regime the one-launch kernel supports:
+                # a parameter that first receives a gradient later inherits the group's count)
+                prevs = [float(self.state[q]["step"]) for q in group["params"] if "step" in self.state[q]]
+                step = torch.full((1,), max(prevs) if prevs else 0.0, dtype=torch.float32, device=dev)
                 group["_step_dev"] = step
         for p in params:
             self.state[p]["step"] = step                                 # one shared device counter (same value for every tensor)

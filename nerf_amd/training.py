@@ -36,7 +36,8 @@ from .utils import _focal_xy, inverseSample, randomFromOneImage
 class TrainStep:
     def __init__(self, prop_net, mip_net, optimizer: Adam, image_hw: Tuple[int, int], focal, near: float, far: float, ray_num: int = 512,
                  coarse_pnum: int = 64, fine_pnum: int = 128, crop_xy=(1.0, 1.0), seed: Optional[int] = None, white_bkg: bool = False,
-                 prop_normal: bool = False, grad_hook=None, ipe_radius: Optional[float] = None, contract: bool = False, flat_grads=None):
+                 prop_normal: bool = False, grad_hook=None, ipe_radius: Optional[float] = None, contract: bool = False, flat_grads=None,
+                 grad_clip: float = -0.01):
         """``grad_hook``: called between ``loss.backward()`` and ``optimizer.step()`` -- the place of ddp_train.py's gradient all-reduce
         (``lambda: parallel.allreduce_gradients([mip_net, prop_net])``).  An iteration with a hook runs eagerly (``capture`` refuses).
         ``ipe_radius`` (BASELINE configs[2]): the fine network encodes the conical frusta between consecutive fine depths with the
@@ -46,7 +47,9 @@ class TrainStep:
         ``flat_grads`` (``nerf_amd.parallel.FlatGradients([mip_net, prop_net], optimizer)``): data-parallel training the native way --
         the weight-gradient kernels write into ONE persistent flat buffer, and between backward and the optimizer step ONE all_reduce
         (RCCL) averages it over the ranks.  Unlike a ``grad_hook`` this is part of the captured iteration: ``capture()`` records the
-        collective into the hipGraph (backend nccl), so the replayed iteration keeps its launch-free pace on N GPUs."""
+        collective into the hipGraph (backend nccl), so the replayed iteration keeps its launch-free pace on N GPUs.
+        ``grad_clip`` (train.py:119-121,217 `--grad_clip`, negative = off like the reference's default): global-norm clipping between
+        backward and the optimizer step, evaluated on the device (no host read: capturable)."""
         if not isinstance(optimizer, Adam) or not optimizer.lr_on_device:
             raise ValueError("nerf_amd.training.TrainStep needs nerf_amd.optim.Adam(..., lr_on_device=True): the step must not read host state")
         self.prop_net, self.mip_net, self.opt = prop_net, mip_net, optimizer
@@ -72,6 +75,7 @@ class TrainStep:
         self.prop_loss_fn = ProposalLoss()
         self.grad_hook = grad_hook
         self.flat_grads = flat_grads
+        self.grad_clip = float(grad_clip)
         self.graph = None
 
     # ---------------------------------------------------------------------------------------------------------------- the iteration
@@ -127,6 +131,12 @@ class TrainStep:
             self.flat_grads.all_reduce()                                                                # ddp_train.py:98, as one collective
         if self.grad_hook is not None:
             self.grad_hook()
+        if self.grad_clip > 0.0:                                                                        # train.py:217 grad_clip_func
+            if self.flat_grads is not None:                                                             # one norm + one scale over the flat buffer
+                flat = self.flat_grads.flat
+                flat.mul_(torch.clamp(self.grad_clip / (torch.linalg.vector_norm(flat) + 1e-6), max=1.0))
+            else:
+                torch.nn.utils.clip_grad_norm_(list(self.mip_net.parameters()) + list(self.prop_net.parameters()), self.grad_clip)
         self.opt.step()
         ops.advance_seed(self.seed)
         self.loss.copy_(loss.detach())

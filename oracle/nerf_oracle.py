@@ -594,7 +594,7 @@ def ide_tables(deg_view: int):
 def ide_encode(xyz: Tensor, kappa_inv: Tensor, deg_view: int = 4) -> Tensor:
     """integrated_dir_enc_fn (ref_func.py:76-108): (..., 3), (..., 1) -> (..., 2T) = [real | imag]."""
     ml, mat = ide_tables(deg_view)
-    ml, mat = ml.to(xyz.device), mat.to(xyz.device)
+    ml, mat = ml.to(xyz.device), mat.to(xyz.device, xyz.dtype)          # (fp64 anchor runs: the reference's fp32 table, widened)
     x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
     vmz = torch.cat([z ** i for i in range(mat.shape[0])], dim=-1)
     vmxy = torch.cat([(x + 1j * y) ** m for m in ml[0, :]], dim=-1)

@@ -1,0 +1,7 @@
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_parity.py -x -q -k "training or train_step or narrower" 2>&1 | tail -5
+python -m pytest tests/test_gpu_fp8_dumps.py tests/test_gpu_configs_train.py -x -q 2>&1 | tail -5
+bash scripts/gpu_train_profile.sh 2>&1 | tail -9
+mv gpurun_out/trainprof/BASE_16384_bf16_kernel_stats.csv gpurun_out/trainprof/bf16dumps_xt_kernel_stats.csv
+NERF_AMD_TRAIN_DUMPS=fp8 bash scripts/gpu_train_profile.sh 2>&1 | tail -9
+mv gpurun_out/trainprof/BASE_16384_bf16_kernel_stats.csv gpurun_out/trainprof/fp8dumps_xt_kernel_stats.csv

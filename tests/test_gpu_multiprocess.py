@@ -470,3 +470,72 @@ def test_device_resident_train_step_refnerf_branch():
     finally:
         torch.normal = real_normal
     assert sum(long_losses[-10:]) < 0.6 * sum(long_losses[:10]), (long_losses[:10], long_losses[-10:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("branch", ["mip", "ref"])
+def test_train_step_losses_equal_the_oracles_step_on_the_same_draws(branch):
+    """TrainStep's iteration against the oracle's restatement of train.py:164-199 on IDENTICAL rays, coarse depths, uniforms (and bottle-neck
+    noise): the in-kernel draws are functions of the device seed, so the test re-derives them with the same entry points and hands them to
+    the oracle.  The Ref-NeRF branch includes the reference's positional quirk (train.py:182: `mip_net.density_act` lands in `mul_norm`, so
+    the depths are NOT scaled by |d|) -- with un-normalised ray directions a scaled composite gives another loss, so this pins it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.nn.functional as F
+    import weights as W
+    from oracle import nerf_oracle as O
+    import nerf_amd
+    from nerf_amd import ops
+    from nerf_amd.optim import Adam
+    from nerf_amd.ref_model import RefNeRF
+    from nerf_amd.training import TrainStep
+    from nerf_amd.utils import randomFromOneImage
+    nerf_amd.set_precision("fp32")
+    N, C_N, F_N, SEED = 48, 16, 32, 2468
+    gen = torch.Generator().manual_seed(5)
+    img = torch.rand(3, 40, 40, generator=gen).cuda()
+    pose = O.pose_spherical(20.0, -30.0, 4.0)[:3].contiguous().cuda()
+    focal = O.fov2focal(0.6911112070083618, (40, 40))          # |d| != 1 for these rays: the mul_norm quirk is visible
+    prop, mip = _nets()
+    prop.train()
+    if branch == "ref":
+        net = RefNeRF(10, 4)
+        net.load_state_dict(W.ref_state("small"))
+        net = net.cuda().train()
+    else:
+        net = mip.train()
+    opt = Adam(list(net.parameters()) + list(prop.parameters()), lr=0.0, lr_on_device=True)
+    step = TrainStep(prop, net, opt, (40, 40), focal, NEAR, FAR, ray_num=N, coarse_pnum=C_N, fine_pnum=F_N, seed=SEED, prop_normal=(branch == "ref"))
+    step.set_image(img, pose)
+    # the step's own draws, re-derived from the same device seed through the same entry points
+    seed = torch.full((1,), SEED, dtype=torch.int64, device="cuda")
+    pixels, coords = randomFromOneImage(img, (1.0, 1.0))
+    fx, fy = float(focal[1]), float(focal[0])
+    _, z_c, tgt, rays = ops.sample_training_rays_dev(pixels, coords, pose, fx, fy, NEAR, FAR, N, C_N, seed)
+    u = ops.philox_uniforms((N, F_N + 1), seed_dev=seed)
+    noise = (torch.randn(N, F_N + C_N, 128, generator=torch.Generator().manual_seed(8)) * 0.1).cuda()
+    real_normal = torch.normal
+    torch.normal = lambda *a, **k: noise
+    try:
+        loss, img_loss = step()
+    finally:
+        torch.normal = real_normal
+    rays_c, zc_c, tgt_c, u_c = rays.cpu(), z_c.cpu(), tgt.cpu(), u.cpu()
+    if branch == "ref":
+        out = O.ref_train_step(W.proposal_state("small"), W.ref_state("small"), rays_c, zc_c, u_c, noise.cpu(), tgt_c, F_N)
+        want_loss, want_img = float(out["loss"]), float(out["img_loss"])
+        scaled, _, _ = O.composite(torch.cat((out["rgbo_raw"][..., :3], F.softplus(out["rgbo_raw"][..., 3:] + 0.5)), -1), out["z_merged"], rays_c[:, 3:], mul_norm=True)
+        assert abs(float(torch.mean((scaled - tgt_c) ** 2)) - want_img) > 1e-4 * want_img         # (the quirk matters on these rays)
+    else:
+        P, M = W.proposal_state("small"), W.mip_state("small")
+        pts = rays_c[:, None, :3] + rays_c[:, None, 3:] * zc_c[:, :, None]
+        pw = O.max_blur(O.sigma_to_weights(F.softplus(O.proposal_forward(P, pts)), zc_c, rays_c[:, 3:]), 0.01)
+        z_f, below = O.inverse_sample(pw, zc_c, u_c, sort=True)
+        z_f = z_f[..., :-1]
+        rend, wts, _ = O.composite(O.mip_forward(M, O.length2pts(rays_c, z_f)), z_f, rays_c[:, 3:])
+        want_img = float(torch.mean((rend - tgt_c) ** 2))
+        want_loss = want_img + float(O.proposal_loss(O.get_bounds(pw, below), wts))
+    assert abs(float(img_loss) - want_img) <= 2e-5 * max(1.0, want_img), (float(img_loss), want_img)
+    assert abs(float(loss) - want_loss) <= 2e-4 * max(1.0, abs(want_loss)), (float(loss), want_loss)

@@ -360,13 +360,24 @@ def test_render_rays_fp32_parity(A, tag, n, n_fine):
     assert torch.equal(z_c.cpu(), stages["z_coarse"])
     assert max_abs(w_prop.cpu(), stages["w_prop"]) <= 1e-5
     assert max_abs(z_f[:, :-1].cpu(), stages["z_fine"]) <= 2e-5
-    # `below` (index work): equal to the reference's except where the GPU's own w_prop (expf / MLP bits) moved a CDF edge across u
+    # `below` is index work.  (i) On IDENTICAL inputs -- the oracle's sampler fed the GPU's own blurred weights and coarse depths -- the
+    # sorted indices and the sort are equal, bit for bit, for every sample count.
+    _, below_same = O.inverse_sample(w_prop.cpu(), z_c.cpu(), u2, sort=True)
+    assert torch.equal(below.cpu(), below_same)
+    # (ii) Against the oracle's own chain the GPU's w_prop differs in its last bits (expf / MLP), which can move a CDF edge across a
+    # uniform: every mismatch must be EXPLAINED by that (off by one bin, u between the two versions of the edge), and they are rare.
+    cdf_want, cdf_got = O.pdf_cdf(stages["w_prop"][:, 1:-1]), O.pdf_cdf(w_prop.cpu()[:, 1:-1])
     if n_fine >= 63:                                          # (ascending bins: the sorted samples are in the order of their uniforms)
-        n_bad = _assert_below_explained(below, stages["below"], torch.sort(u2, dim=-1)[0], O.pdf_cdf(stages["w_prop"][:, 1:-1]),
-                                        O.pdf_cdf(w_prop.cpu()[:, 1:-1]), "resample")
-        assert n_bad <= 0.002 * below.numel()
-    else:
-        assert _below_mismatch(below.cpu(), stages["below"]) <= 0.01
+        n_bad = _assert_below_explained(below, stages["below"], torch.sort(u2, dim=-1)[0], cdf_want, cdf_got, "resample")
+    else:                                                     # (out-of-order coarse depths: compare in the order of the uniforms, before the sort)
+        mids = lambda z: 0.5 * (z[..., 1:] + z[..., :-1])
+        _, b_got, _ = A.ops.sample_pdf(mids(z_c), w_prop[:, 1:-1].contiguous(), dev(u2))
+        _, b_want, _ = O.sample_pdf(mids(stages["z_coarse"]), stages["w_prop"][:, 1:-1], u2)
+        n_bad = _assert_below_explained(b_got, b_want, u2, cdf_want, cdf_got, "sample_pdf")
+    assert n_bad <= 0.002 * below.numel()
+
+
+BF16_RENDER_DB, BF16_DEPTH_TOL = 90.0, 1e-4             # measured on MI355X (round 3): 102.4 dB, max |rgb err| 2.5e-5, max |depth err| 2.1e-5
 
 
 def test_render_rays_bf16_close(A):
@@ -379,8 +390,11 @@ def test_render_rays_bf16_close(A):
     rgb, depth, _, _ = A.ops.render_rays(prop.packed(A.ops.BF16), mip.packed(A.ops.BF16), A.ops.BF16, dev(rays), z_base, dev(u1), dev(u2),
                                          128, NEAR, FAR, True)
     mse = torch.mean((rgb.cpu() - want_rgb) ** 2).item()
-    assert -10 * math.log10(max(mse, 1e-12)) >= 40.0                     # bf16 vs fp32 image: > 40 dB
-    assert max_abs(depth.cpu(), want_depth) <= 5e-2
+    print("\nbf16 render vs fp32 oracle: %.1f dB, max |rgb err| %.2e, max |depth err| %.2e" % (-10 * math.log10(max(mse, 1e-12)), max_abs(rgb.cpu(), want_rgb),
+                                                                                                 max_abs(depth.cpu(), want_depth)))
+    # gates a few times above the measured error of this configuration (reference-style weights), not at "roughly an image"
+    assert -10 * math.log10(max(mse, 1e-12)) >= BF16_RENDER_DB
+    assert max_abs(depth.cpu(), want_depth) <= BF16_DEPTH_TOL
 
 
 @pytest.mark.parametrize("tag,size,sn", [("small_50", 50, 128), ("he_50", 50, 128), ("small_100", 100, 64), ("small_200", 200, 64)])
@@ -442,7 +456,12 @@ def test_full_size_properties(A, prec):
         assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4 and max_abs(depth[pick].cpu(), want_depth) <= 1e-4
         assert max_abs(w[pick].cpu(), want_w) <= 1e-4
     else:
-        assert torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item() <= 1e-3
+        mse16 = torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item()
+        print("\nfull-size bf16 spot check ('he' weights): MSE %.2e = %.1f dB" % (mse16, -10 * math.log10(max(mse16, 1e-12))))
+        assert mse16 <= BF16_HE_SPOT_MSE
+
+
+BF16_HE_SPOT_MSE = 1.5e-4                                 # measured on MI355X (round 3): 4.3e-5 (43.6 dB) on the O(1)-activation 'he' weights
 
 
 # ------------------------------------------------------------------------------------------------ row 13: Ref-NeRF
@@ -955,6 +974,12 @@ def test_get_grad_of_proposal_density_then_parameter_backward(A):
         assert max_abs(a_.cpu(), b_.cpu()) <= 1e-4 * max(1.0, b_.abs().max().item())
 
 
+# HIP fp32 gradient vs the fp64 value, relative to the tensor's largest entry (set from the measured values the test prints; a ReLU whose
+# pre-activation is within rounding of zero can fall on the other side in the kernel, which moves isolated entries by ~1e-3)
+G17_FP64_GATE = {k: 3e-4 for k in ("g_rho_tau", "g_rho_tau_bias", "g_spa2_6", "g_nct", "g_spec", "g_prop_head", "g_bottle", "g_dir0", "g_spa0", "g_prop_l0")}
+# measured on MI355X (round 3): reference fp32 <= 6.5e-5, HIP fp32 <= 7.8e-5 (g_bottle) of each tensor's largest entry
+
+
 def test_refnerf_train_step_vs_reference_golden(A, golden):
     """G17: the Ref-NeRF branch of the training step with prop_normal (train.py:164-199) written against the nerf_amd surface --
     train-mode forward with the recorded bottle-neck noise, RefNeRF.get_grad of the density w.r.t. the positions, normal /
@@ -1019,11 +1044,34 @@ def test_refnerf_train_step_vs_reference_golden(A, golden):
     # parameter gradients RELATIVE to each tensor's own size (they range from 1e-8 to 1e-3 with these weights, so an absolute gate
     # would check nothing).  rho_tau_head and the last spa_block2 layer are where the gradient THROUGH THE WEIGHTS lands (normal /
     # back-face losses on the un-detached weights, train.py:183-184): they fail if render's weights output is not differentiable.
-    for key, got, rel in (("g_rho_tau", net.rho_tau_head.weight.grad, 5e-3), ("g_rho_tau_bias", net.rho_tau_head.bias.grad, 5e-3),
-                          ("g_spa2_6", net.spa_block2[6].weight.grad[:8], 5e-3), ("g_nct", net.norm_col_tint_head.weight.grad, 5e-3),
-                          ("g_spec", net.spec_rgb_head[0].weight.grad, 5e-3), ("g_prop_head", prop.layers[8].weight.grad, 5e-3),
-                          ("g_bottle", net.bottle_neck.weight.grad[:8], 2e-2), ("g_dir0", net.dir_block1[0].weight.grad[:8], 2e-2),
-                          ("g_spa0", net.spa_block1[0].weight.grad[:8], 5e-2), ("g_prop_l0", prop.layers[0].weight.grad[:8], 5e-2)):
+    # ... and anchored: the same step in fp64 (oracle.ref_train_step + torch.autograd on the CPU) is the exact value; the REFERENCE's fp32
+    # gradients (the golden) sit within ~6e-5 of it on these tensors, and the HIP gradients' distance from it is printed and gated below
+    d64 = lambda sd: {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    p64, r64 = d64(W.proposal_state("small")), d64(W.ref_state("small"))
+    o64 = O.ref_train_step(p64, r64, g["rays"].double(), g["z_coarse"].double(), g["u_inv"].double(), g["noise"].double(), g["rgb_tgt"].double(),
+                           g["u_inv"].shape[-1] - 1)
+    o64["loss"].backward()
+    assert torch.equal(o64["sort_ids"], g["sort_ids"]) and torch.equal(o64["below_merged"], g["below_merged"])
+    exact = {"g_rho_tau": r64["rho_tau_head.weight"].grad, "g_rho_tau_bias": r64["rho_tau_head.bias"].grad, "g_spa2_6": r64["spa_block2.6.weight"].grad[:8],
+             "g_nct": r64["norm_col_tint_head.weight"].grad, "g_spec": r64["spec_rgb_head.0.weight"].grad, "g_prop_head": p64["layers.8.weight"].grad,
+             "g_bottle": r64["bottle_neck.weight"].grad[:8], "g_dir0": r64["dir_block1.0.weight"].grad[:8], "g_spa0": r64["spa_block1.0.weight"].grad[:8],
+             "g_prop_l0": p64["layers.0.weight"].grad[:8]}
+    have = {"g_rho_tau": net.rho_tau_head.weight.grad, "g_rho_tau_bias": net.rho_tau_head.bias.grad, "g_spa2_6": net.spa_block2[6].weight.grad[:8],
+            "g_nct": net.norm_col_tint_head.weight.grad, "g_spec": net.spec_rgb_head[0].weight.grad, "g_prop_head": prop.layers[8].weight.grad,
+            "g_bottle": net.bottle_neck.weight.grad[:8], "g_dir0": net.dir_block1[0].weight.grad[:8], "g_spa0": net.spa_block1[0].weight.grad[:8],
+            "g_prop_l0": prop.layers[0].weight.grad[:8]}
+    rep = {}
+    for k in exact:
+        top = exact[k].abs().max().item()
+        rep[k] = ((g[k].double() - exact[k]).abs().max().item() / top, (have[k].detach().cpu().double() - exact[k]).abs().max().item() / top)
+    print("\nG17 gradients, max error relative to the fp64 value (reference fp32 | HIP fp32):", {k: "%.1e | %.1e" % v for k, v in rep.items()})
+    for k, (ref_e, hip_e) in rep.items():
+        assert hip_e <= max(2.0 * ref_e, G17_FP64_GATE[k]), (k, ref_e, hip_e)
+    for key, got, rel in (("g_rho_tau", net.rho_tau_head.weight.grad, 5e-4), ("g_rho_tau_bias", net.rho_tau_head.bias.grad, 5e-4),
+                          ("g_spa2_6", net.spa_block2[6].weight.grad[:8], 5e-4), ("g_nct", net.norm_col_tint_head.weight.grad, 5e-4),
+                          ("g_spec", net.spec_rgb_head[0].weight.grad, 5e-4), ("g_prop_head", prop.layers[8].weight.grad, 5e-4),
+                          ("g_bottle", net.bottle_neck.weight.grad[:8], 5e-4), ("g_dir0", net.dir_block1[0].weight.grad[:8], 5e-4),
+                          ("g_spa0", net.spa_block1[0].weight.grad[:8], 5e-4), ("g_prop_l0", prop.layers[0].weight.grad[:8], 5e-4)):
         err, size = max_abs(got.cpu(), g[key]), g[key].abs().max().item()
         assert err <= rel * size, "%s: |err| %.3e vs max|g| %.3e (rel %.2e > %.0e)" % (key, err, size, err / size, rel)
 
