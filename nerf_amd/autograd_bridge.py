@@ -35,6 +35,25 @@ class _VJP:
     bf16 = False          # the op ran in BF16 precision: the re-evaluated Linear layers use bf16 operands with fp32 accumulation too
 
 
+# The torch VJP of an op's specification expression (re-evaluated on the device with library GEMMs) is NOT a product path: every shape the
+# reference's training loops produce has a hand-written HIP backward.  An op that reaches the VJP -- a compositing row longer than
+# ops.BWD_MAX_SAMPLES, MipNeRF positions that require a gradient, an empty batch -- raises unless this switch is on (tests that
+# differentiate the specification itself, and callers who knowingly want the slow generic path, set it).
+TORCH_VJP_FALLBACK = False
+
+
+class allow_torch_vjp:
+    """with allow_torch_vjp(): ... -- HipOp backward passes inside may fall back to the torch VJP of the specification expression"""
+
+    def __enter__(self):
+        global TORCH_VJP_FALLBACK
+        self.prev, TORCH_VJP_FALLBACK = TORCH_VJP_FALLBACK, True
+
+    def __exit__(self, *exc):
+        global TORCH_VJP_FALLBACK
+        TORCH_VJP_FALLBACK = self.prev
+
+
 # Gradients w.r.t. sample POSITIONS.  The reference's training loss never uses them (the fine depths are detached, utils.py:35-36; the
 # position leaves of train.py:165,179 exist for RefNeRF.get_grad only), so by default the HIP backward of ProposalNetwork / RefNeRF forms
 # a position gradient ONLY inside get_grad (inputs_only_grad) and `loss.backward()` leaves `pts.grad` untouched -- a dgrad chain and an
@@ -311,6 +330,11 @@ class HipOp(torch.autograd.Function):
                 grads = hip_bwd(grad, *full)
             if grads is not None:                                   # None = "not supported for these sizes": fall through to the VJP
                 return (None, None, None, *grads)
+        if not TORCH_VJP_FALLBACK:
+            raise NotImplementedError(
+                "nerf_amd: no HIP backward for this call (%s); the torch re-evaluation of the specification is off by default -- "
+                "`with nerf_amd.autograd_bridge.allow_torch_vjp():` enables it" %
+                ("the op's HIP backward declined these sizes" if hip_bwd is not None else "the op differentiates inputs only the generic VJP covers"))
         # only the inputs autograd actually asks for become leaves: e.g. the sample positions of MipNeRF carry no gradient, which
         # spares the VJP the first layer's dgrad and the whole sin/cos backward
         cache = getattr(ctx, "vjp_cache", None)

@@ -899,6 +899,121 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 256 x 256 product on EIGHT waves (two per SIMD): dW (8 x 8 blocks of 32 x 32) = delta^T . y.
+// The four-wave forms above run one wave per SIMD (256 accumulator registers each), and a subtile is a dependent chain -- loads land ->
+// transposing MFMAs -> conversions -> LDS exchange -> barrier -> products -- that nothing overlaps: measured 53 % of the MFMA issue
+// slots, and neither 44 % fewer bytes (fp8 dumps) nor 17 % fewer MFMAs (transposed exchange) moved its time by more than 3 %.  Here every
+// wave owns a 2 x 4 block rectangle (128 accumulator registers), so TWO waves share a SIMD and the hardware interleaves one wave's
+// conversions / LDS traffic / barrier wait with the other's MFMAs.  Per subtile and wave: load ONE X and ONE Y feature block (two K groups
+// each; fp8: one 16-byte block + a scale dword), transpose them on the matrix cores (4 MFMAs), convert, row-sum the X block for the
+// bias, park both in LDS; after the workgroup barrier read the other X block of the row pair and the other three Y blocks of the column
+// quad (8 ds_read_b128) and issue the 16 products.  Every block is loaded and transposed exactly once per workgroup.
+//   wave w = (wo = w >> 1, wi = w & 1): rows = X blocks 2 wo, 2 wo + 1; columns = Y blocks 4 wi .. 4 wi + 3;
+//   it loads / transposes X block w (= 2 wo + wi) and Y block 4 wi + wo.
+// ------------------------------------------------------------------------------------------------
+template <bool F8>
+__global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n_sub) {
+    constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr uint32_t STAGE = 32 * 1024;                                  // X blocks 0..7 (2 KiB each: two halves) | Y blocks 0..7
+    const WgradJob& J = jobs.j[blockIdx.y];
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wo = wave >> 1, wi = wave & 1;
+    const int xb = wave, yb = 4 * wi + wo;                                 // the blocks this wave loads and transposes
+    bf16x8 idx[2];                                                         // constant 0/1 selection operands of the transposing MFMAs
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) idx[p][e] = (__bf16)((dmap_feature(p, h, e) == j) ? 1.0f : 0.0f);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = zero16;
+    float bsum = 0.0f;
+    const int64_t per = (n_sub + gridDim.x - 1) / gridDim.x;
+    const int64_t s_begin = blockIdx.x * per, s_end = (s_begin + per < n_sub) ? s_begin + per : n_sub;
+    auto cvt8 = [](const f32x16& v, int g) -> bf16x8 { return PBF16::from_acc<false>(v, 8 * g); };
+    struct StageBf16 { bf16x8 x[2], y[2]; };
+    struct StageF8 { F8Raw<2> x, y; };
+    using Stage = typename std::conditional<F8, StageF8, StageBf16>::type;
+    auto fetch = [&](int64_t s, Stage& q) {
+        const char* xs = J.x0.base + (size_t)s * J.x0.sub_stride + lane * 16;
+        const char* ys = J.y.base + (size_t)s * J.y.sub_stride + lane * 16;
+        if constexpr (F8) { q.x.load(xs, 2 * xb); q.y.load(ys, 2 * yb); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                q.x[k] = *reinterpret_cast<const bf16x8*>(xs + (size_t)(2 * xb + k) * 1024);
+                q.y[k] = *reinterpret_cast<const bf16x8*>(ys + (size_t)(2 * yb + k) * 1024);
+            }
+        }
+    };
+    auto clamp_s = [&](int64_t s) { return s < s_end ? s : s_end - 1; };
+    Stage q0, q1;
+    int buf = 0;
+    if (s_begin < s_end) { fetch(s_begin, q0); fetch(clamp_s(s_begin + 1), q1); }
+    auto body = [&](int64_t s, Stage& cur) {
+        bf16x8 ox[2], oy[2];
+        if constexpr (F8) { cur.x.decode(2 * xb, ox); cur.y.decode(2 * yb, oy); }
+        else { ox[0] = cur.x[0]; ox[1] = cur.x[1]; oy[0] = cur.y[0]; oy[1] = cur.y[1]; }
+        f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ox[0], idx[0], zero16, 0, 0, 0);
+        f32x16 u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oy[0], idx[0], zero16, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ox[1], idx[1], t, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oy[1], idx[1], u, 0, 0, 0);
+        fetch(clamp_s(s + 2), cur);                                        // `cur` is consumed: refill it two subtiles ahead (past the end: re-read the last)
+        bf16x8 xf[2][2], yf[4][2];                                         // local X block 0 = own, 1 = the pair's other; local Y block 0 = own, 1..3 = the others
+        xf[0][0] = cvt8(t, 0); xf[0][1] = cvt8(t, 1);
+        yf[0][0] = cvt8(u, 0); yf[0][1] = cvt8(u, 1);
+        if (J.bias_partial != nullptr) {
+            const float r0 = (t[0] + t[1]) + (t[2] + t[3]), r1 = (t[4] + t[5]) + (t[6] + t[7]), r2 = (t[8] + t[9]) + (t[10] + t[11]),
+                        r3 = (t[12] + t[13]) + (t[14] + t[15]);
+            bsum += (r0 + r1) + (r2 + r3);
+        }
+        const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            *reinterpret_cast<bf16x8*>(smem + st + (2 * xb + hf) * 1024) = xf[0][hf];
+            *reinterpret_cast<bf16x8*>(smem + st + (16 + 2 * yb + hf) * 1024) = yf[0][hf];
+        }
+        __syncthreads();                                                   // all sixteen transposed blocks of s are in LDS (and stage buf^1 is free again)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            xf[1][hf] = *reinterpret_cast<const bf16x8*>(smem + st + (2 * (xb ^ 1) + hf) * 1024);
+#pragma unroll
+            for (int b = 1; b < 4; ++b)
+                yf[b][hf] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 2 * (4 * wi + ((wo + b) & 3)) + hf) * 1024);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][hf], yf[b][hf], acc[a][b], 0, 0, 0);
+        buf ^= 1;
+    };
+    for (int64_t s = s_begin; s < s_end;) {
+        body(s, q0); if (++s >= s_end) break;
+        body(s, q1); ++s;
+    }
+    // partial of this workgroup, row-major 256 x 256: local X block a -> block xb ^ a; local Y block b -> block 4 wi + ((wo + b) & 3)
+    float* out = J.partial + (size_t)blockIdx.x * 256 * 256;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (xb ^ a) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)row * 256 + 32 * (4 * wi + ((wo + b) & 3)) + j] = acc[a][b][r];
+            }
+    if (J.bias_partial != nullptr) {
+        const float v = bsum + __shfl_xor(bsum, 32, 64);
+        if (h == 0) J.bias_partial[(size_t)blockIdx.x * 256 + 32 * xb + j] = v;
+    }
+}
+
 // fp32 twin (parity mode): v_mfma_f32_32x32x2_f32 contracts two samples per instruction, and with K = 2 the operands ARE single
 // elements -- lane (feature i, k) reads dump element (sample 2 r + k, feature i) straight from the fragment-ordered dump (4-byte gathers
 // served by L2); no transposition at all.  Exact fp32 products and sums.
@@ -1122,6 +1237,15 @@ int launch_mip_bwd(const void* packed, const float* g, const float* rgbo, int64_
     return (int)hipGetLastError();
 }
 
+#ifndef WGRAD_EIGHT_WAVES
+#define WGRAD_EIGHT_WAVES 1         /* the 256 x 256 shape on eight waves (two per SIMD), wgrad256_kernel; 0 = the four-wave exchange form */
+#endif
+template <bool F8>
+int launch_wgrad256(const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(wgrad256_kernel<F8>), 65536)) return e;
+    hipLaunchKernelGGL((wgrad256_kernel<F8>), dim3(n_wg, n_jobs), dim3(512), 65536, st, jobs, n_sub);
+    return (int)hipGetLastError();
+}
 #ifndef WGRAD_EXCHANGE
 #define WGRAD_EXCHANGE 1            /* the 256 x 256 shape loads quarters and exchanges them through LDS (0 = every wave loads all it multiplies) */
 #endif
@@ -1186,7 +1310,8 @@ int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, i
     if (f8) {
         if (precision != NERF_AMD_BF16) return (int)hipErrorInvalidValue;
         switch (shape) {
-            case 0: return launch_wgrad_f8<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0, true, true>(jobs, n, n_wg, n_sub, st);
+            case 0: if (WGRAD_EIGHT_WAVES) return launch_wgrad256<true>(jobs, n, n_wg, n_sub, st);
+                    return launch_wgrad_f8<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0, true, true>(jobs, n, n_wg, n_sub, st);
             case 1: return launch_wgrad_f8<16, 4, 4, Y_PE10, false, true, false>(jobs, n, n_wg, n_sub, st);
             case 2: return launch_wgrad_f8<9, 16, 1, Y_DMAP, false, true, true>(jobs, n, n_wg, n_sub, st);
             case 3: return launch_wgrad_f8<1, 8, 1, Y_DMAP, false, false, true>(jobs, n, n_wg, n_sub, st);
@@ -1196,7 +1321,8 @@ int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, i
         return (int)hipErrorInvalidValue;
     }
     switch (shape) {
-        case 0: return launch_wgrad<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
+        case 0: if (WGRAD_EIGHT_WAVES && precision == NERF_AMD_BF16) return launch_wgrad256<false>(jobs, n, n_wg, n_sub, st);      // 4 x 2 waves of 2 x 4 blocks
+                return launch_wgrad<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
         case 1: return launch_wgrad<16, 4, 4, Y_PE10>(precision, jobs, n, n_wg, n_sub, st);      // 4 x 1 waves of 2 x 2 blocks
         case 2: return launch_wgrad<9, 16, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // NOB 5 x NIB 8: 1 x 4 waves of 5 x 2 blocks
         case 3: return launch_wgrad<1, 8, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);       // NOB 1 x NIB 4

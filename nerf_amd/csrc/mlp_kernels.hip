@@ -222,6 +222,9 @@ struct ActDump {
 };
 template <class P>
 DEVINL void dump_breg(const ActDump& d, int layer, int64_t subtile, int kg, int lane, const typename P::BReg& r) {
+#ifdef ABL_NODUMPST                                          // timing ablation: the training forward without its activation stores
+    if constexpr (sizeof(typename P::BReg) == 16) { asm volatile("" ::"v"(r)); return; }
+#endif
     P::store_global(d.base + (size_t)layer * d.layer_stride + ((size_t)subtile * 16 + kg) * (size_t)P::BREG_LDS, lane, r);
 }
 
@@ -267,6 +270,9 @@ DEVINL uint32_t breg_bits(const f32x8& v) {
 }
 template <class P>
 DEVINL void mask_or(uint32_t acc_wave, int layer, int t, int kg, int lane, const typename P::BReg& v) {
+#ifdef ABL_NOMASK                                            // timing ablation: no ReLU bit masks (the backward then reads garbage)
+    return;
+#endif
     unsigned* w = reinterpret_cast<unsigned*>(smem + acc_wave + ((layer & 1) * P::NT + t) * 1024 + lane * 16 + (kg >> 2) * 4);
     __hip_atomic_fetch_or(w, breg_bits(v) << (4 * (kg & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -1748,3 +1748,32 @@ def test_he_weights_conditioning(A):
         assert ref_exact >= 5e-5                                 # the reference's own fp32 noise floor on this set
         assert hip_ref <= max(1e-4, 1.5 * ref_exact)              # HIP differs from the fp32 reference by no more than that floor
         assert hip_exact <= 2.0 * ref_exact
+
+
+def test_no_silent_torch_vjp_fallback(A):
+    """"No library GEMM anywhere" is a property, not a coincidence of the tested shapes: an op whose HIP backward does not cover the call
+    (a compositing row longer than BWD_MAX_SAMPLES; MipNeRF positions that require a gradient) RAISES in backward instead of silently
+    re-evaluating its torch specification; `allow_torch_vjp()` opts into that generic path, which then agrees with autograd."""
+    from nerf_amd import autograd_bridge as ab
+    A.pkg.set_precision("fp32")
+    gen = torch.Generator().manual_seed(3)
+    N, S = 9, A.ops.BWD_MAX_SAMPLES + 44
+    rgbo = torch.cat((torch.rand(N, S, 3, generator=gen), torch.randn(N, S, 1, generator=gen)), -1).cuda().requires_grad_(True)
+    z = torch.sort(torch.rand(N, S, generator=gen) * 4 + 2, dim=-1)[0].cuda()
+    dirs = torch.randn(N, 3, generator=gen).cuda()
+    rgb, w, _ = A.nerf_base.NeRF.render(rgbo, z, dirs)
+    with pytest.raises(NotImplementedError):
+        rgb.sum().backward()
+    rgb, w, _ = A.nerf_base.NeRF.render(rgbo, z, dirs)
+    with ab.allow_torch_vjp():
+        rgb.sum().backward()
+    ref = rgbo.detach().clone().requires_grad_(True)
+    want, _ = ab.weights_expr(ref[..., 3], z * dirs.norm(dim=-1, keepdim=True), A.ops.ACT_RELU), None
+    (want[:, :, None] * ref[..., :3]).sum().backward()
+    assert max_abs(rgbo.grad.cpu(), ref.grad.cpu()) <= 2e-5 * max(1.0, ref.grad.abs().max().item())
+    _, mip = build_nets(A, "small")
+    mip.train()
+    pts = torch.randn(5, 7, 6, generator=gen).cuda().requires_grad_(True)
+    out = mip.forward(pts)
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
