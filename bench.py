@@ -241,7 +241,9 @@ def iteration_rate(precision, n_rays=512, iters=200):
     for mode in ("eager", "hipgraph"):
         prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
         opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
-        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11)
+        from nerf_amd.parallel import FlatGradients               # gradients in one persistent flat buffer (the data-parallel layout; no-op collective here)
+        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11,
+                         flat_grads=FlatGradients([mip, prop], opt))
         step.set_image(img, pose)
         if mode == "hipgraph":
             step.capture(warmup=3)

@@ -976,7 +976,10 @@ int mlp_launch_proposal_train(const void* packed, int precision, const nerf_amd_
         return launch<PB16, PropLayout, true, true>(proposal_kernel<PB16, true, true>, packed, s, density, st, d8);
     }
     const ActDump d = make_dump(dump, precision, s.M, PROP_DUMP_SLOTS);
-    if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout, true>(proposal_kernel<PB16, true>, packed, s, density, st, d);
+    // bf16 training forward of the proposal network: the 8-wave x 32-sample tile (two waves per SIMD hide the dump's stores and mask
+    // arithmetic, and the 64-sample tile spills ~90 registers here) -- 0.83 -> 0.73 ms at 16 384 rays in a same-box A/B; the dump layout
+    // does not depend on the tile policy (32-sample subtiles either way).  The MipNeRF forward and both dgrad chains measured no gain.
+    if (precision == NERF_AMD_BF16) return launch<PBF16, PropLayout, true>(proposal_kernel<PBF16, true>, packed, s, density, st, d);
     return launch<PF32, PropLayout, true>(proposal_kernel<PF32, true>, packed, s, density, st, d);
 }
 #endif

@@ -19,13 +19,19 @@ from nerf_amd.utils import inverseSample
 NEAR, FAR = 2.0, 6.0
 
 
-def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False, torch_adam=False):
+def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False, torch_adam=False, flat=True):
+    """flat: gradients in ONE persistent flat buffer the weight-gradient kernels write into (nerf_amd.parallel.FlatGradients: what
+    TrainStep / bench.py --mode train-ddp use); False = ordinary autograd accumulation into per-tensor gradients (what train.py does)."""
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, mip = ProposalNetwork(10, 256).cuda().train(), MipNeRF(10, 4, 256).cuda().train()
     from nerf_amd.optim import Adam                        # one-launch Adam (nerf_amd_adam_step); torch_adam=True: torch.optim.Adam
     params = list(mip.parameters()) + list(prop.parameters())
     opt = torch.optim.Adam(params, lr=1e-4, capturable=graph) if torch_adam else Adam(params, lr=1e-4)
+    fg = None
+    if flat:
+        from nerf_amd.parallel import FlatGradients
+        fg = FlatGradients([mip, prop], opt)
     o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
     d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
     rays = torch.cat((o, d), -1).cuda().contiguous()
@@ -43,7 +49,10 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False,
         rgbo = mip.forward(NeRF.length2pts(rays, z_f))
         rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
         loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
-        opt.zero_grad()
+        if fg is not None:
+            fg.begin_step()
+        else:
+            opt.zero_grad()
         loss.backward()
         opt.step()
 
@@ -53,7 +62,8 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False,
     if graph:
         # whole step (forward, backward, Adam, re-pack) as ONE hipGraph: the 512-ray step is launch-bound (~200 launches)
         g = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
+        if fg is None:
+            opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(g):
             step()
         step_eager, step = step, g.replay
