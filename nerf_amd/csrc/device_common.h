@@ -174,6 +174,15 @@ DEVINL T wave_incl_scan(T v, T identity, OP&& op) {
     return v;
 }
 DEVINL double wave_incl_scan_mul(double v) { return wave_incl_scan(v, 1.0, [](double a, double b) { return a * b; }); }
+// the same without the last step: two independent 32-lane scans (lanes 0..31 | 32..63) -- the full scan's value before row_bcast:31
+DEVINL double seg32_incl_scan_mul(double v) {
+    v = v * dpp_move<DPP_ROW_SHR + 1, 0xF>(1.0, v);
+    v = v * dpp_move<DPP_ROW_SHR + 2, 0xF>(1.0, v);
+    v = v * dpp_move<DPP_ROW_SHR + 4, 0xF>(1.0, v);
+    v = v * dpp_move<DPP_ROW_SHR + 8, 0xF>(1.0, v);
+    v = v * dpp_move<DPP_ROW_BCAST15, 0xA>(1.0, v);
+    return v;
+}
 DEVINL double wave_incl_scan_add(double v) { return wave_incl_scan(v, 0.0, [](double a, double b) { return a + b; }); }
 DEVINL int wave_incl_scan_add(int v) { return wave_incl_scan(v, 0, [](int a, int b) { return a + b; }); }
 DEVINL int wave_max_i(int v) {                  // maximum over the wave, as a wave-uniform scalar

@@ -200,8 +200,8 @@ DEVINL IpeSample fetch_sample_ipe(const nerf_amd_samples& s, int64_t m) {
 constexpr uint32_t LDS_BIAS = MLP_RING_BYTES;
 constexpr uint32_t LDS_STASH = MLP_RING_BYTES + 9216;                 // bias table: <= 2240 floats
 template <class P> constexpr uint32_t lds_dir() { return LDS_STASH + P::NW * P::NT * 4 * P::BREG_LDS; }
-template <class P> constexpr uint32_t lds_tile() { return lds_dir<P>() + P::NW * P::NT * 1024; }            // (tile samples) x float4 + 8 tickets
-template <class P> constexpr uint32_t lds_total() { return lds_tile<P>() + P::NW * P::NT * 32 * 24 + 64; }
+template <class P> constexpr uint32_t lds_tile() { return lds_dir<P>() + P::NW * P::NT * 1024; }            // fused compositing: (tile samples) x 2 float4, segment totals, tickets
+template <class P> constexpr uint32_t lds_total() { return lds_tile<P>() + P::NW * P::NT * 32 * 32 + P::NW * P::NT * 8 + 64; }   // records, segment totals, tickets
 
 DEVINL void load_biases(const void* packed, size_t stream_bytes, int n_bias, uint32_t lds_off = MLP_RING_BYTES) {
     const float* b = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + stream_bytes);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #ifdef MLP_CLOCKPROBE
     const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 24)[threadIdx.x] = 0u;   // ray tickets
+    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 32 + P::NW * P::NT * 8)[threadIdx.x] = 0u;   // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
     WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
@@ -562,70 +562,104 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         dense<P, 8, 1, L::START[9]>(ws, bias0 + L::BIAS_OFF[9] * 4,
             [&](int kg, int t) -> BReg { return c[t][kg]; }, ORGB, prev_of(dc, OC)).flush(ORGB);
         if constexpr (TRAIN) mask_flush<P, F8>(dump, macc, 7, sub0, lane, sacc);
+        f32x4 o[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-        f32x4 o;
-        o[0] = 1.0f / (1.0f + expf(-r[t]));
-        o[1] = 1.0f / (1.0f + expf(-g[t]));
-        o[2] = 1.0f / (1.0f + expf(-bl[t]));
-        o[3] = sigma[t];
-        if (fc.rgb == nullptr) {
-            if (h == 0 && m[t] < s.M) *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o;
-        } else {
-            // ---- fused compositing epilogue (S in {32, 64, 128} divides the tile: a ray = S/32 consecutive subtiles) ----
-            // Every subtile parks (rgb, sigma, z|d|, delta) of its 32 samples in LDS and takes an LDS ticket; the LAST subtile of
-            // the ray to arrive composites it: sigma -> alpha, wave prefix product of the transmittance (fp64, like torch's CPU
-            // cumprod), weighted sums.  Nobody waits for anybody, and nothing here touches global memory except the outputs.
-            const int S = s.S;
-            const int spr = S >> 5;                                        // subtiles per ray
-            const int sub = wave * NT + t;
-            const int ray_in_tile = sub / spr;
-            const int64_t n = (tile * TS) / S + ray_in_tile;
-            char* tb = smem + lds_tile<P>();
-            f32x4* t_rgbo = reinterpret_cast<f32x4*>(tb);                               // [TS] rgb + sigma
-            f32x2* t_zd = reinterpret_cast<f32x2*>(tb + TS * 16);                       // [TS] z|d|, delta
-            unsigned* tickets = reinterpret_cast<unsigned*>(tb + TS * 24);
-            {
-                const float keep3 = (*reinterpret_cast<const f32x4*>(smem + dir_lds(t)))[3];   // half 0: z|d|, half 1: delta (tile start)
-                const float dl = __shfl(keep3, j + 32, 64);
-                if (h == 0) {
-                    t_rgbo[sub * 32 + j] = o;
-                    f32x2 zd = {keep3, dl};
-                    t_zd[sub * 32 + j] = zd;
-                }
+            o[t][0] = 1.0f / (1.0f + expf(-r[t]));
+            o[t][1] = 1.0f / (1.0f + expf(-g[t]));
+            o[t][2] = 1.0f / (1.0f + expf(-bl[t]));
+            o[t][3] = sigma[t];
+            if (fc.rgb == nullptr) {
+                if (h == 0 && m[t] < s.M) *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o[t];
             }
-            // LDS executes one wavefront's DS instructions in order, so the ticket is ordered behind the record writes without
-            // a fence (a workgroup-scope fence would also wait vmcnt(0) and drain the weight DMA queue); the asm statements only
-            // stop the compiler from moving LDS accesses across the ticket.
+        }
+        if (fc.rgb != nullptr) {
+            // ---- fused compositing epilogue (nerf_base.py:91-113; S in {32, 64, 128}: a ray = S / 32 consecutive 32-sample SEGMENTS of the tile) ----
+            // Every wave does the expensive part for ITS OWN segments: sigma -> alpha and the exclusive prefix product of the transmittance
+            // INSIDE each segment (fp64, one 32-segmented DPP scan for both column tiles), parks per sample (colour, alpha, z|d|, that
+            // product) and per segment its total in LDS, and takes an LDS ticket per segment.  The wave whose ticket completes a ray only
+            // COMBINES: segment products chained exactly as the 64-lane scan of the two-launch composite kernel chains them (its last DPP
+            // step multiplies lanes 32..63 by lane 31's prefix -- here: by the first segment's total), weights, weighted sums.  The
+            // (N,S,4) network output never reaches HBM, nobody waits for anybody, and the serial work of the last arriver is a fraction of
+            // compositing the whole ray alone (round 2's form).  Bit-compatible with nerf_amd_mip_forward + nerf_amd_composite.
+            const int S = s.S;
+            const int spr = S >> 5;                                        // segments per ray
+            char* tb = smem + lds_tile<P>();
+            f32x4* t_ca = reinterpret_cast<f32x4*>(tb);                                  // [TS] r, g, b, alpha
+            u32x4* t_pz = reinterpret_cast<u32x4*>(tb + TS * 16);                        // [TS] exclusive product inside the segment (double bits), z|d|, -
+            double* t_seg = reinterpret_cast<double*>(tb + TS * 32);                     // [TS / 32] product over the segment
+            unsigned* tickets = reinterpret_cast<unsigned*>(tb + TS * 32 + (TS / 32) * 8);
+            {
+                // segment-lane layout: lane L <-> column tile L >> 5 (NT = 2; lanes 32..63 idle for NT = 1), sample L & 31
+                const int tt = (NT > 1) ? h : 0;
+                const bool live = (NT > 1) || h == 0;
+                const float k0 = (*reinterpret_cast<const f32x4*>(smem + dir_lds(0)))[3];              // half 0: z|d|, half 1: delta (tile start)
+                const float k1 = (NT > 1) ? (*reinterpret_cast<const f32x4*>(smem + dir_lds(NT - 1)))[3] : 0.0f;
+                float cr, cg, cb, sg, zn, dl;
+                if (NT > 1) {
+                    // (the lane moves run on ALL lanes, then the select: a shuffle under a lane condition reads inactive source lanes as 0)
+                    const float s0 = __shfl(o[NT - 1][0], j, 64), s1 = __shfl(o[NT - 1][1], j, 64), s2 = __shfl(o[NT - 1][2], j, 64),
+                                s3 = __shfl(o[NT - 1][3], j, 64), sz = __shfl(k1, j, 64), d0 = __shfl(k0, j + 32, 64);
+                    cr = h ? s0 : o[0][0]; cg = h ? s1 : o[0][1]; cb = h ? s2 : o[0][2]; sg = h ? s3 : o[0][3];
+                    zn = h ? sz : k0;
+                    dl = h ? k1 : d0;
+                } else {
+                    cr = o[0][0]; cg = o[0][1]; cb = o[0][2]; sg = o[0][3]; zn = k0; dl = __shfl(k0, j + 32, 64);
+                }
+                const float mm = expf(-fmaxf(sg, 0.0f) * dl);
+                const float al = live ? 1.0f - mm : 0.0f;
+                const double p = live ? (double)(mm + 1e-10f) : 1.0;
+                const double incl = seg32_incl_scan_mul(p);
+                double excl = wave_shift_up1(incl, 1.0);
+                if (lane == 32) excl = 1.0;                                  // (the second segment starts over)
+                const int sub = wave * NT + tt;
+                if (live) {
+                    const int ts = sub * 32 + j;
+                    t_ca[ts] = f32x4{cr, cg, cb, al};
+                    const u32x2 eb = __builtin_bit_cast(u32x2, excl);
+                    t_pz[ts] = u32x4{eb[0], eb[1], __builtin_bit_cast(uint32_t, zn), 0u};
+                }
+                if (j == 31 && live) t_seg[sub] = incl;                      // lanes 31 and 63 hold their segment's total
+            }
+            // LDS executes one wavefront's DS instructions in order, so the tickets are ordered behind the record writes without a fence
+            // (a workgroup-scope fence would also wait vmcnt(0) and drain the weight DMA queue); the asm statements only stop the compiler
+            // from moving LDS accesses across the tickets.
             asm volatile("" ::: "memory");
-            unsigned old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(&tickets[ray_in_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = __builtin_amdgcn_readfirstlane(old);
-            asm volatile("" ::: "memory");
-            if (((old + 1) % (unsigned)spr) == 0 && n * S < s.M) {         // last arriver of this ray (tickets only ever grow)
-                const f32x4* px = t_rgbo + ray_in_tile * S;
-                const f32x2* pz = t_zd + ray_in_tile * S;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int sub = wave * NT + t;
+                const int ray_in_tile = sub / spr;
+                const int64_t n = (tile * TS) / S + ray_in_tile;
+                unsigned old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(&tickets[ray_in_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old = __builtin_amdgcn_readfirstlane(old);
+                asm volatile("" ::: "memory");
+                if (((old + 1) % (unsigned)spr) != 0 || n * S >= s.M) continue;      // not the last segment of this ray (tickets only ever grow)
+                const int seg0 = ray_in_tile * spr;
                 float ar = 0.0f, ag = 0.0f, abl = 0.0f, aw = 0.0f, ad = 0.0f;
                 float* wout = fc.weights ? fc.weights + n * S : nullptr;
                 double carry = 1.0;
-                for (int base = 0; base < S; base += 64) {
+                for (int base = 0; base < S; base += 64) {                   // 64 samples = two segments per pass, like the composite kernel's chunks
                     const int q = base + lane;
+                    const int sg0 = seg0 + (base >> 5);
+                    const bool two = base + 32 < S;
+                    const double T0 = t_seg[sg0], T1 = two ? t_seg[sg0 + (two ? 1 : 0)] : 1.0;
                     float w = 0.0f;
-                    double p = 1.0;
-                    f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                    f32x2 zd = {0.0f, 0.0f};
+                    f32x4 ca = {0.0f, 0.0f, 0.0f, 0.0f};
+                    float zn = 0.0f;
                     if (q < S) {
-                        c4 = px[q]; zd = pz[q];
-                        const float mm = expf(-fmaxf(c4[3], 0.0f) * zd[1]);
-                        w = 1.0f - mm;
-                        p = (double)(mm + 1e-10f);
+                        const int ts = seg0 * 32 + q;
+                        ca = t_ca[ts];
+                        const u32x4 pz = t_pz[ts];
+                        const u32x2 eb = {pz[0], pz[1]};
+                        double excl = __builtin_bit_cast(double, eb);
+                        if (h) excl = excl * T0;                             // what row_bcast:31 does in the 64-lane scan
+                        zn = __builtin_bit_cast(float, (uint32_t)pz[2]);
+                        w = ca[3] * (float)(carry * excl);
                     }
-                    const double incl = wave_incl_scan_mul(p);
-                    const double excl = wave_shift_up1(incl, 1.0);
-                    w *= (float)(carry * excl);
-                    carry *= wave_last(incl);
+                    carry *= (T1 * T0);
                     if (q < S) {
-                        ar += w * c4[0]; ag += w * c4[1]; abl += w * c4[2]; aw += w; ad += w * zd[0];
+                        ar += w * ca[0]; ag += w * ca[1]; abl += w * ca[2]; aw += w; ad += w * zn;
                         if (wout) wout[q] = w;
                     }
                 }
@@ -636,7 +670,6 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                     if (fc.depth) fc.depth[n] = (ad - fc.near) / (fc.far - fc.near);
                 }
             }
-        }
         }
     }
     ws.drain();
