@@ -49,10 +49,49 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         self.apply(self.init_weight)
 
     def _check_config(self):
-        ok = (self.position_flevel == 10 and self.sh_max_level == 4 and self.bottle_neck_dim == 128 and self.hidden_unit == 256
-              and self.output_dim == 256 and self.cat_origin)
+        # hidden widths below 256 (`--nerf_net_width`, train.py:80) run on the same kernels through exact zero-padding, like MipNeRF
+        # (_packed.py); the reference itself needs hidden_unit == output_dim (dir_block2.6 takes hidden_unit inputs from an output_dim-wide layer)
+        # `--ide_level` 1..3 (procedures.py:211, train.py:80) run on the level-4 kernel as well: the (m, l) terms of level d are the first
+        # T_d = 2, 5, 10 of level 4's 19 (ref_func.py:56-58 orders them by l), so the directional layers' weights are embedded into the
+        # level-4 column layout [bottle-neck 128 | real 19 | imag 19 | n.d] with zeros on the terms the module does not have.  Level 5
+        # (36 terms) does not fit the kernel's three IDE K groups.
+        ok = (self.position_flevel == 10 and 1 <= self.sh_max_level <= 4 and self.bottle_neck_dim == 128 and 1 <= self.hidden_unit <= 256
+              and self.output_dim == self.hidden_unit and self.cat_origin)
         if not ok:
-            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, 4, 128, 256, 256) (use_srgb on or off)")
+            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, ide_level 1..4, 128, hidden_unit = output_dim <= 256) "
+                                      "(use_srgb on or off)")
+
+    def _dir_cols(self):
+        """column of the level-4 directional input vector (167 wide) that each of the module's 128 + 2 T + 1 directional inputs occupies"""
+        T = self.dir_enc_dim // 2
+        return list(range(128)) + [128 + t for t in range(T)] + [128 + 19 + t for t in range(T)] + [166]
+
+    def _embed_dir(self, w: torch.Tensor) -> torch.Tensor:
+        """dir_block{1,2}.0 weight (rows, 128 + 2 T + 1 [+ hidden]) -> (rows, 167 [+ hidden]) in the kernel's column layout"""
+        if self.sh_max_level == 4:
+            return w
+        n_in = 129 + self.dir_enc_dim
+        out = torch.zeros((w.shape[0], 167 + w.shape[1] - n_in), dtype=w.dtype, device=w.device)
+        out[:, self._dir_cols()] = w[:, :n_in]
+        out[:, 167:] = w[:, n_in:]
+        return out
+
+    def _extract_dir(self, g: torch.Tensor) -> torch.Tensor:
+        if self.sh_max_level == 4:
+            return g
+        return torch.cat((g[:, self._dir_cols()], g[:, 167:]), dim=1)
+
+    # kernel shapes of the 20 packed tensors (spatial 0..7, bottle_neck 8, heads 9, directional 10..17, spec head 18; the IDE table is not padded)
+    _KERNEL_SHAPES = ([(256, 63)] + [(256, 256)] * 3 + [(256, 319)] + [(256, 256)] * 3 + [(128, 256), (11, 256), (256, 167)] + [(256, 256)] * 3 +
+                      [(256, 423)] + [(256, 256)] * 3 + [(3, 256)])
+
+    @staticmethod
+    def _pad_to(t, shape):
+        if tuple(t.shape) == tuple(shape):
+            return t
+        out = torch.zeros(tuple(shape), dtype=t.dtype, device=t.device)
+        out[tuple(slice(0, n) for n in t.shape)] = t
+        return out
 
     @property
     def kernel_flags(self) -> int:
@@ -72,9 +111,15 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         if hw.device not in tables:
             tables[hw.device] = ide_table(4).to(hw.device).contiguous()
         table = tables[hw.device]
-        ws = [l.weight for l in lin] + [hw] + [l.weight for l in tail] + [table]
-        bs = [l.bias for l in lin] + [hb] + [l.bias for l in tail] + [hb]
-        return ws, bs
+        ws = [l.weight for l in lin] + [hw] + [l.weight for l in tail]
+        bs = [l.bias for l in lin] + [hb] + [l.bias for l in tail]
+        if self.sh_max_level != 4:
+            ws[10], ws[14] = self._embed_dir(ws[10].detach()), self._embed_dir(ws[14].detach())       # dir_block1.0, dir_block2.0
+        if self.hidden_unit != 256:                          # zero-padded to the compiled 256-wide shapes: the same function (hidden features are
+            with torch.no_grad():                            # always the LAST column segment of a layer's input, so the padding goes at the end)
+                ws = [self._pad_to(w.detach(), sh) for w, sh in zip(ws, self._KERNEL_SHAPES)]
+                bs = [self._pad_to(b.detach(), (sh[0],)) for b, sh in zip(bs, self._KERNEL_SHAPES)]
+        return ws + [table], bs + [hb]
 
     def _pack_now(self, precision: int) -> torch.Tensor:
         ws, bs = self._pack_tensors()
@@ -117,7 +162,12 @@ class RefNeRF(PackedWeightsMixin, NeRF):
                     return (gx.view(p.shape), None, *[None] * len(wb))
                 gw, gb = ops.ref_backward(held["bwd_blob"], prec, held.pop("dump"), held.pop("aux"), held["pts"][:, 3:], g2, self._ide_table(p.device), self.kernel_flags)
                 by_name = self._grads_by_name(gw, gb)
-                return (None, None, *[by_name[n] for n in names])
+                if self.sh_max_level != 4:
+                    for k_ in ("dir_block1.0.weight", "dir_block2.0.weight"):
+                        by_name[k_] = self._extract_dir(by_name[k_])
+                shapes = {n: p_.shape for n, p_ in named}                 # (narrow networks: the padded rows / columns are the discarded part)
+                return (None, None, *[by_name[n][tuple(slice(0, k) for k in shapes[n])] if tuple(by_name[n].shape) != tuple(shapes[n]) else by_name[n]
+                                      for n in names])
             expr = lambda p, dd, *wb: ab.ref_expr(p, dd, noise, dict(zip(names, wb)), self.integrated_dir_enc, self.use_srgb)
             out = ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pos, d, *params)
             return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
