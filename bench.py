@@ -598,6 +598,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                          "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": traffic,
+                         "traffic_source": ("not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, committed as "
+                                            "profiles/pmc_traffic.json (PMC collection needs the profiler around the process)") if traffic is not None else None,
                          # MFMA work actually issued (512 MAC per 32x16 fragment and sample; padded K, bottle_neck folded away)
                          "executed_tflops": executed_flops / (fine_ms * 1e-3) / 1e12, "executed_frac": executed_flops / (fine_ms * 1e-3) / peak},
             "whole_path_tflops": world * a.steps * n_rays * flop_per_ray / dt / 1e12,

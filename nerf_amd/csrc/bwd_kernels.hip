@@ -170,7 +170,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
     WeightStream<P, MLP_NSLOT, false> ws;
     bwd_prologue<P>(ws, packed, L::CHAIN_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
     WeightStream<P, MLP_NSLOT, false> ws;
     bwd_prologue<P>(ws, packed, L::N_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(P::NW * 64) void dgrad_layer_kernel(const void* __r
     WeightStream<P, MLP_NSLOT, false> ws;
     bwd_prologue<P>(ws, packed_layer, n_frags);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const WgradJob& J = jobs.j[blockIdx.y];
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     const int wo = (WO == 1) ? 0 : wave / WI, wi = (WI == 1) ? 0 : wave % WI;
     const int ob0 = wo * OBW, ib0 = wi * IBW;
 
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_f32(WgradJobs jobs, int64_t 
     constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const WgradJob& J = jobs.j[blockIdx.y];
     const int lane = lane_id(), hk = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     const int wo = wave / WI, wi = wave % WI;
     const int ob0 = wo * OBW, ib0 = wi * IBW;
     // byte offset of (feature, sample 0) inside a subtile's fp32 fragment block [kg][e>>2][lane = sample + 32 h][e&3]; -1 = no such feature

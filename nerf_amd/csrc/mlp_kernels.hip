@@ -310,7 +310,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
     WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
     WeightStream<P, MLP_NSLOT_REF> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
     constexpr int NT = P::NT;
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;

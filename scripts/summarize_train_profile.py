@@ -26,7 +26,7 @@ for c in val:
         if r["Counter_Name"] == c:
             val[c][short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
 lines = ["| kernel | launches / step | avg ms | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM GB / launch | TB/s |", "|---|---|---|---|---|---|---|"]
-steps = avg.get("mip_bwd_kernel<PBF16W>", avg.get("mip_bwd_kernel<PF32>", (1, 0)))[0]
+steps = next((v[0] for k, v in avg.items() if k.startswith("mip_bwd_kernel")), 1)
 for k, (calls, ms) in sorted(avg.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     if k not in val["FETCH_SIZE"] or ms < 0.05 or k.startswith("at::"):
         continue
