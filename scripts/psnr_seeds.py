@@ -50,7 +50,17 @@ def main():
     for mode in a.modes.split(","):
         for seed in [int(s) for s in a.seeds.split(",")]:
             t0 = time.time()
-            hist, held = T.run_oracle(views, seed) if mode == "cpu" else T.run_hip(views, seed, mode)
+            if mode == "cpu":
+                hist, held = T.run_oracle(views, seed)
+            elif mode == "bf16-fp8dumps":                                # bf16 arithmetic, training dumps in scaled e4m3 (nerf_amd.set_train_dumps)
+                import nerf_amd
+                nerf_amd.set_train_dumps("fp8")
+                try:
+                    hist, held = T.run_hip(views, seed, "bf16")
+                finally:
+                    nerf_amd.set_train_dumps("bf16")
+            else:
+                hist, held = T.run_hip(views, seed, mode)
             tail = T.psnr(sum(hist[-200:]) / len(hist[-200:]))
             final = sum(held) / len(held)
             res.setdefault(mode, []).append((final, tail))
