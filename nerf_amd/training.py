@@ -44,7 +44,8 @@ class TrainStep:
         integrated PE (mip_methods.py:15-58) instead of the point PE; ``contract`` (configs[4]): Mip-NeRF 360 scene contraction of every
         sample position (proposal and fine).  Neither has a caller in the reference -- the wiring is the build's own (oracle.render_rays
         states it), parity unpinned.
-        ``flat_grads`` (``nerf_amd.parallel.FlatGradients([mip_net, prop_net], optimizer)``): data-parallel training the native way --
+        ``flat_grads`` (default: built here; ``False`` = ordinary per-tensor autograd gradients; or pass
+        ``nerf_amd.parallel.FlatGradients([mip_net, prop_net], optimizer, group=...)``): data-parallel training the native way --
         the weight-gradient kernels write into ONE persistent flat buffer, and between backward and the optimizer step ONE all_reduce
         (RCCL) averages it over the ranks.  Unlike a ``grad_hook`` this is part of the captured iteration: ``capture()`` records the
         collective into the hipGraph (backend nccl), so the replayed iteration keeps its launch-free pace on N GPUs.
@@ -74,7 +75,13 @@ class TrainStep:
         self.img_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.prop_loss_fn = ProposalLoss()
         self.grad_hook = grad_hook
-        self.flat_grads = flat_grads
+        # an explicitly passed FlatGradients is a request for data-parallel averaging; the default one only holds the gradients (ranks of a
+        # model-averaging run, model_average.py, train independently: no implicit collective)
+        self._reduce = flat_grads is not None and flat_grads is not False
+        if flat_grads is None:
+            from .parallel import FlatGradients
+            flat_grads = FlatGradients([mip_net, prop_net], optimizer)
+        self.flat_grads = flat_grads if flat_grads is not False else None
         self.grad_clip = float(grad_clip)
         self.graph = None
 
@@ -127,7 +134,7 @@ class TrainStep:
         img_loss = torch.mean((rendered - rgb_tgt) ** 2)                                                # :194 (nn.MSELoss)
         loss = self.prop_loss_fn(bounds, weights.detach()) + img_loss + extra                           # :196-198
         loss.backward()
-        if self.flat_grads is not None:
+        if self._reduce:
             self.flat_grads.all_reduce()                                                                # ddp_train.py:98, as one collective
         if self.grad_hook is not None:
             self.grad_hook()
@@ -167,7 +174,7 @@ class TrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         kw = {}
-        if self.flat_grads is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+        if self._reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
             if torch.distributed.get_backend(self.flat_grads.group) != "nccl":
                 raise RuntimeError("nerf_amd.training.TrainStep: only an RCCL (backend 'nccl') all-reduce can be captured into the hipGraph")
             kw["capture_error_mode"] = "thread_local"                                     # (the process group's watchdog thread polls events meanwhile)

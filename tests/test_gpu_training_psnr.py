@@ -12,6 +12,7 @@ Note on conditioning: early NeRF training is chaotic at aggressive learning rate
 already produces an isolated loss spike within 25 iterations, and the bf16 run tips into the well-known empty-density
 collapse).  The test therefore uses the reference's own learning-rate rule, under which both paths follow the same trajectory.
 """
+import os
 import math
 
 import pytest
@@ -61,14 +62,30 @@ def psnr(mse):
     return -10.0 * math.log10(max(mse, 1e-12))
 
 
-def run_oracle(views, seed):
+def run_oracle(views, seed, resume=None):
+    """`resume`: a path; the whole state (weights, Adam moments, the generator, the histories) is saved there every 250 iterations and a
+    run restarted with the same path continues bit-identically (the hours-long CPU runs of scripts/psnr_seeds.py)."""
     torch.manual_seed(seed)
     prop = {k: v.clone().requires_grad_(True) for k, v in W.proposal_state("small").items()}
     mip = {k: v.clone().requires_grad_(True) for k, v in W.mip_state("small").items()}
     opt = torch.optim.Adam(list(mip.values()) + list(prop.values()), lr=LR)
     res = (FAR - NEAR) / C_N
-    hist, held = [], []
-    for it in range(ITERS):
+    hist, held, start = [], [], 0
+    if resume is not None and os.path.exists(resume):
+        st = torch.load(resume, weights_only=False)
+        with torch.no_grad():
+            for k, v in st["prop"].items():
+                prop[k].copy_(v)
+            for k, v in st["mip"].items():
+                mip[k].copy_(v)
+        opt.load_state_dict(st["opt"])
+        torch.set_rng_state(st["rng"])
+        hist, held, start = st["hist"], st["held"], st["it"]
+    for it in range(start, ITERS):
+        if resume is not None and it > start and it % 250 == 0:
+            torch.save({"prop": {k: v.detach() for k, v in prop.items()}, "mip": {k: v.detach() for k, v in mip.items()}, "opt": opt.state_dict(),
+                        "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": it}, resume + ".tmp")
+            os.replace(resume + ".tmp", resume)
         rays_all, rgb_all = views[it % (len(views) - N_HELD)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,))
         rays, tgt = rays_all[idx], rgb_all[idx]

@@ -205,3 +205,72 @@ def test_local_shuffle_sampler_partitions():
     assert list(LocalShuffleSampler(data, 2, rank=0, shuffle=False)) == data
     with pytest.raises(ValueError):
         LocalShuffleSampler(data, 2, rank=2)
+
+
+# ------------------------------------------------------------------------------------------------ the flat gradient buffer (parallel.FlatGradients)
+def _flat_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_amd import parallel
+        from nerf_amd.addtional import ProposalNetwork
+        torch.manual_seed(5)
+        plain = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))      # gradients through ordinary autograd
+        prop = ProposalNetwork(10, 256)                                                                # a module the kernels write into directly
+        opt = torch.optim.SGD(list(plain.parameters()) + list(prop.parameters()), lr=0.5)
+        flat = parallel.FlatGradients([plain, prop], opt)
+        res = {"n": flat.flat.numel(), "views": all(p.grad is flat.views[p] for p in flat.params)}
+        x = torch.full((4, 6), float(rank + 1))
+        plain(x).sum().backward()
+        plain(x).sum().backward()                                          # same window: autograd accumulates into the views
+        local = [p.grad.clone() for p in plain.parameters()]
+        # what a backward of the attached module does: ask for its sinks (first call of a window: overwrite) and write them
+        ws, bs, first = prop.grad_sinks()
+        _, _, again = prop.grad_sinks()
+        res["first"], res["again"] = first, again
+        for t in ws + bs:
+            t.fill_(float(rank + 1))
+        flat.all_reduce()
+        res["plain"] = [torch.stack((p.grad.flatten()[0], l.flatten()[0])).tolist() for p, l in zip(plain.parameters(), local)]
+        res["prop"] = [float(p.grad.flatten()[-1]) for p in prop.parameters()]
+        before = [p.detach().clone() for p in plain.parameters()]
+        g_red = [p.grad.clone() for p in plain.parameters()]
+        opt.step()                                                         # reads the views; its post-hook opens the next window
+        res["stepped"] = all(torch.allclose(p.detach(), b - 0.5 * g) for p, b, g in zip(plain.parameters(), before, g_red))
+        res["zeroed"] = all(float(p.grad.abs().max()) == 0.0 for p in plain.parameters())
+        res["kept"] = float(next(prop.parameters()).grad.flatten()[0])     # direct sinks are overwritten by the next backward, not zeroed
+        res["reopened"] = prop.grad_sinks()[2]
+        opt.zero_grad(set_to_none=True)
+        flat.bind()
+        res["rebound"] = all(p.grad is flat.views[p] for p in flat.params)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_flat_gradients_world_2_gloo():
+    """parallel.FlatGradients on two gloo ranks: every p.grad is a view of one buffer, ONE all-reduce averages both networks
+    (ddp_train.py:98 reduces the fine network per bucket), the accumulation window opens after optimizer.step()."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        o = out[r]
+        assert o["n"] == 6 * 8 + 8 + 8 * 3 + 3 + 214017 and o["views"] and o["rebound"]
+        assert o["first"] is True and o["again"] is False and o["reopened"] is True
+        assert all(abs(v - 1.5) < 1e-6 for v in o["prop"]) and abs(o["kept"] - 1.5) < 1e-6
+        assert o["zeroed"] and o["stepped"]
+    # the autograd-path gradients: mean of the two ranks' local (twice-accumulated) values, identical on both ranks
+    for k in range(4):
+        mean = 0.5 * (out[0]["plain"][k][1] + out[1]["plain"][k][1])
+        assert abs(out[0]["plain"][k][0] - mean) < 1e-5 * max(1.0, abs(mean)) and out[0]["plain"][k][0] == out[1]["plain"][k][0]
