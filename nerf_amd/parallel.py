@@ -76,7 +76,8 @@ class FlatGradients:
     * ``nerf_amd.optim.Adam`` (or any optimizer) reads the same views.
 
     ``begin_step()`` opens a new accumulation window (the first backward of a module in a window OVERWRITES its gradients -- no zeroing
-    pass --, further ones add); it runs automatically after every ``optimizer.step()`` of an optimizer passed as `optimizer`.  Gradients
+    pass --, further ones add); it runs automatically after every ``optimizer.step()`` of an optimizer passed as `optimizer`, and a
+    ``zero_grad(set_to_none=True)`` opens one too (the next backward finds ``p.grad is None``, re-binds the views and overwrites).  Gradients
     arriving through ordinary autograd (a RefNeRF, a zero-padded narrow network, any other module in `modules`) accumulate into the
     views as usual; those ranges are zeroed by ``begin_step()``."""
 
@@ -129,10 +130,10 @@ class FlatGradients:
         first = self._fresh.get(module, False)
         self._fresh[module] = False
         for l in layers:
-            if l.weight.grad is not self.views[l.weight]:
-                l.weight.grad = self.views[l.weight]
-            if l.bias.grad is not self.views[l.bias]:
-                l.bias.grad = self.views[l.bias]
+            for p in (l.weight, l.bias):
+                if p.grad is not self.views[p]:                          # zero_grad(set_to_none=True) (or a foreign tensor) since the last
+                    p.grad = self.views[p]                               # backward: torch's meaning is "start over", so this backward
+                    first = True                                         # overwrites
         return [self.views[l.weight] for l in layers], [self.views[l.bias] for l in layers], first
 
     def zero_(self) -> None:

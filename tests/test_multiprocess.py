@@ -242,6 +242,8 @@ def _flat_worker(rank, world, port, q):
         res["kept"] = float(next(prop.parameters()).grad.flatten()[0])     # direct sinks are overwritten by the next backward, not zeroed
         res["reopened"] = prop.grad_sinks()[2]
         opt.zero_grad(set_to_none=True)
+        res["after_none"] = prop.grad_sinks()[2]                           # torch's "start over": the next backward overwrites ...
+        res["after_none_again"] = prop.grad_sinks()[2]                     # ... and the one after it accumulates
         flat.bind()
         res["rebound"] = all(p.grad is flat.views[p] for p in flat.params)
         q.put((rank, res))
@@ -268,6 +270,7 @@ def test_flat_gradients_world_2_gloo():
         o = out[r]
         assert o["n"] == 6 * 8 + 8 + 8 * 3 + 3 + 214017 and o["views"] and o["rebound"]
         assert o["first"] is True and o["again"] is False and o["reopened"] is True
+        assert o["after_none"] is True and o["after_none_again"] is False
         assert all(abs(v - 1.5) < 1e-6 for v in o["prop"]) and abs(o["kept"] - 1.5) < 1e-6
         assert o["zeroed"] and o["stepped"]
     # the autograd-path gradients: mean of the two ranks' local (twice-accumulated) values, identical on both ranks
