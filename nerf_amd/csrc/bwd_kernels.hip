@@ -56,10 +56,22 @@ DEVINL void glds_piece(const char* gptr, uint32_t lds_dst) {
 
 // delta *= [y > 0] on one B register group.  y is a post-ReLU activation: non-negative, +0 exactly where the unit was off.
 DEVINL bf16x8 relu_mask(const bf16x8& d, const bf16x8& y) {
-    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
-    const u16x8 one = {1, 1, 1, 1, 1, 1, 1, 1};
-    const u16x8 on = __builtin_elementwise_min(__builtin_bit_cast(u16x8, y), one);      // 0 / 1 per element (packed min)
-    return __builtin_bit_cast(bf16x8, (u16x8)(__builtin_bit_cast(u16x8, d) * on));        // packed 16-bit multiply
+    // two packed 16-bit ops per dword: on = min(y, 1) (0 / 1 per element), d * on.  Written as asm: from the vector-builtin form
+    // (__builtin_elementwise_min + a 16-bit multiply) hipcc recognises "y != 0 ? d : 0" and scalarises it into one compare, one select
+    // and half a v_perm per ELEMENT -- 3x the instructions and the registers to match (the fused Ref-NeRF chains spilled 170-700
+    // registers with it, none without).
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const u32x4 dv = __builtin_bit_cast(u32x4, d), yv = __builtin_bit_cast(u32x4, y);
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t on, out;
+        const uint32_t yi = yv[i], di = dv[i];
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(yi), "v"(0x00010001u));
+        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(out) : "v"(di), "v"(on));
+        r[i] = out;
+    }
+    return __builtin_bit_cast(bf16x8, r);
 }
 DEVINL f32x8 relu_mask(const f32x8& d, const f32x8& y) {
     f32x8 r;
@@ -188,16 +200,18 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
             for (int e = 0; e < 8; ++e) P::set(head[t], e, e == 0 ? g : 0.0f);          // slot feature 0 = lane half 0, element 0
             P::store_global(dlt.base + 4 * dlt.layer_stride + ((size_t)(sub0 + t) * 16) * (size_t)P::BREG_LDS, lane, head[t]);
         }
-        BReg a[NT][16], b[NT][16];
+        BReg a[NT][16], b[NT][16], zero_kg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) P::set(zero_kg, e, 0.0f);
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
-        const MaskedOut<P, 1, 16, F8> O3{a, act, dlt, 3, sub0, lane, mask_lds, scale_lds};
-        Deferred<P, 6, 2> d = dense<P, 1, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int, int t) -> BReg { return head[t]; }, O3, NoPrev{});
+        const MaskedOut<P, 2, 16, F8> O3{a, act, dlt, 3, sub0, lane, mask_lds, scale_lds};
+        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, O3, NoPrev{});
         // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (same chunk parity)
         static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk parity");
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const MaskedOut<P, 16, 1, F8> OB{b, act, dlt, 2 - 2 * r, sub0, lane, mask_lds, scale_lds};        // (follows the 1-step head layer in round 0)
+            const MaskedOut<P, 16, 2, F8> OB{b, act, dlt, 2 - 2 * r, sub0, lane, mask_lds, scale_lds};        // (follows the 2-step head layer in round 0)
             const MaskedOut<P, 16, 16, F8> OA_pend{a, act, dlt, 3 - 2 * r, sub0, lane, mask_lds, scale_lds};
             d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 3 - 2 * r, sub0, lane);      // (its last pair was converted during this layer)
@@ -383,6 +397,242 @@ __global__ __launch_bounds__(P::NW * 64) void dgrad_layer_kernel(const void* __r
             auto d = dense<P, NKG, NFB, 0>(ws, BWD_LDS_ZERO, IN, O, NoPrev{});
             d.flush(O);
         }
+    }
+    ws.drain();
+}
+
+// ================================================================================================
+// Fused chains of Ref-NeRF's backward and the density-gradient chains (RefNeRF.get_grad, train.py:165-168,178): delta stays in
+// registers from layer to layer exactly as in the MipNeRF chain above; what differs is where the ReLU adjoint comes from -- these
+// training forwards' consumers have no bit masks to read (the Ref-NeRF forward dumps none), so a layer's mask is the dumped
+// ACTIVATION itself, DMA'd into LDS one feature-block pair ahead (512 B per sample and layer instead of 32 B; still 1 KiB per sample
+// and layer with the delta store, against 1.5 KiB for the single-layer launches these replace).  The skip layers' side outputs
+// (gradient w.r.t. the directional input vector / the encoded position, fp32 rows in the reference's column order) are ordinary
+// layers of the chain with a row-writing output functor.
+// ================================================================================================
+template <class P, int NKG_CUR, int NKG_PREV, bool STORE>
+struct ActMaskedOut {
+    typename P::BReg (&buf)[P::NT][16];
+    const char* act; char* dlt;                             // K group 0 of subtile 0 of the activation slot / of the delta slot
+    int64_t sub0; int lane; uint32_t mask_lds;
+    static constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
+    // group G's activations go to pair buffer G & 1.  Its reader is the deferred epilogue, which runs during group G + 1 (after that
+    // group's wait below) or, for the last group, during the first group of the NEXT layer -- whose begin_group(0) therefore waits
+    // with the previous layer's K-step count (NKG_PREV = 0: nothing known about what was issued since -> wait for everything).
+    DEVINL void begin_group(int G) const {
+        if (G == 0) vm_wait<mask_wait_count<P>(NKG_PREV)>(); else vm_wait<mask_wait_count<P>(NKG_CUR)>();
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int t = 0; t < P::NT; ++t) {
+                    const int kg = 2 * (2 * G + blk) + half;
+                    const char* src = act + (size_t)(sub0 + t) * SUB + (size_t)kg * P::BREG_LDS + lane * 16;
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(mask_lds + (G & 1) * bwd_pair_bytes<P>() + ((blk * 2 + half) * P::NT + t) * P::BREG_LDS);
+#pragma unroll
+                    for (int p = 0; p < P::BREG_LDS / 1024; ++p) glds_piece(src + p * 1024, dst + p * 1024);
+                }
+    }
+    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
+        const typename P::BReg d = to_breg_half<P, false>(acc, half);
+        const uint32_t at = mask_lds + ((fb >> 1) & 1) * bwd_pair_bytes<P>() + (((fb & 1) * 2 + half) * P::NT + t) * P::BREG_LDS + lane * 16;
+        const typename P::BReg v = relu_mask(d, P::unstash(at));
+        buf[t][2 * fb + half] = v;
+        if constexpr (STORE) P::store_global(dlt + (size_t)(sub0 + t) * SUB + (size_t)(2 * fb + half) * P::BREG_LDS, lane, v);
+        else pin(v);
+    }
+    // !STORE: an empty asm that "uses" the slice where the store would have been.  Without any such anchor hipcc's scheduler moves the
+    // conversions of a whole chain around freely and the nine-layer density chain spills 1 300 registers (110 with the anchor).
+    static DEVINL void pin(const bf16x8& r) { asm volatile("" ::"v"(r)); }
+    template <class T> static DEVINL void pin(const T& r) { asm volatile("" ::"v"(r.lo), "v"(r.hi)); }
+};
+
+// The chains' bodies are written as short loops over layer pairs like mip_bwd_kernel, not as ten layers of straight-line code: with
+// one basic block per tile hipcc's scheduler and register allocator lose track of the pressure (170-1000 spilled registers per kernel
+// against 0-50 in this form); layers that share a loop body must start at the same chunk phase (all layers here are multiples of
+// 16 fragments, so they do).
+
+// Nine-layer chains with two skip-layer side outputs -- one body for
+//   !DEN  Ref-NeRF's directional network (parameter gradients): spec-head delta (K group 9 of delta slot 8, ref_spec_delta_kernel) ->
+//         delta slots 16..9 and rows (M, 192) = dir_block2.0[:, :167]^T D4 + dir_block1.0^T D0, the gradient w.r.t. the 167-wide input vector;
+//    DEN  Ref-NeRF's spatial network, d density / d (encoded position) (RefNeRF.get_grad): the density row -> activation slots 7..0,
+//         nothing stored but rows (M, 64) = spa_block2.0[:, :63]^T S4 + spa_block1.0^T S0.
+template <class P, bool DEN>
+__global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ act,
+                                                                char* __restrict__ dlt, unsigned long long layer_stride, float* __restrict__ rows) {
+    using L = RefBwdLayout;
+    using BReg = typename P::BReg;
+    constexpr int L0 = DEN ? 18 : 0, S0 = DEN ? L::DEN_START : L::DIR_START;      // first layer of the chain in the layer table, its stream start
+    constexpr int TOP = DEN ? 7 : 16;                                              // activation / delta slot of the chain's first hidden layer
+    constexpr int NFB_ROWS = DEN ? 2 : 6, LD = DEN ? 64 : 192;
+    constexpr bool STORE = !DEN;
+    WeightStream<P, MLP_NSLOT, false> ws;
+    bwd_prologue<P>(ws, stream, DEN ? L::DEN_FRAGS : L::DIR_FRAGS);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+    auto A = [&](int slot) { return act + (size_t)slot * layer_stride; };
+    auto D = [&](int slot) { return STORE ? dlt + (size_t)slot * layer_stride : nullptr; };
+    constexpr int W16 = mask_wait_count<P>(16);
+    static_assert(L::START[L0 + 1] % (2 * P::FPC) == L::START[L0 + 3] % (2 * P::FPC) && L::START[L0 + 2] % (2 * P::FPC) == L::START[L0 + 4] % (2 * P::FPC) &&
+                  L::START[L0 + 6] % (2 * P::FPC) == L::START[L0 + 8] % (2 * P::FPC) && S0 % (2 * P::FPC) == 0, "chunk phase of the shared loop bodies");
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        BReg head[NT], zero_kg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) P::set(zero_kg, e, 0.0f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (DEN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) P::set(head[t], e, (e == 0 && h == 0) ? 1.0f : 0.0f);          // the density row: slot feature 0
+            } else {
+                head[t] = P::load_global(dlt + 8 * (size_t)layer_stride + (size_t)(sub0 + t) * SUB + 9 * (size_t)P::BREG_LDS, lane);
+            }
+        }
+        BReg a[NT][16], b[NT][16];
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        const ActMaskedOut<P, 2, 0, STORE> OT{a, A(TOP), D(TOP), sub0, lane, mask_lds};
+        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[L0] - S0>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OT, NoPrev{});
+        // TOP-1 .. TOP-4 (the fourth is the skip layer through its hidden columns): a -> b -> a -> b -> a
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const ActMaskedOut<P, 16, 2, STORE> OB{b, A(TOP - 1 - 2 * r), D(TOP - 1 - 2 * r), sub0, lane, mask_lds};      // (follows the 2-step head layer in round 0)
+            const ActMaskedOut<P, 16, 16, STORE> OA_pend{a, A(TOP - 2 * r), D(TOP - 2 * r), sub0, lane, mask_lds}, OA{a, A(TOP - 2 - 2 * r), D(TOP - 2 - 2 * r), sub0, lane, mask_lds};
+            d = dense<P, 16, 8, L::START[L0 + 1] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[L0 + 2] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+        }
+        // the skip layer's side output from b (= TOP-3, complete); a's last pair (TOP-4) stays pending across it -- the row layer issues no
+        // mask DMA, so the pair's activations stay where they are in LDS
+        {
+            const RowsOut R1{rows, LD, 0, sub0 * 32, j, h, M};
+            const auto r1 = dense<P, 16, NFB_ROWS, L::START[L0 + 5] - S0>(ws, BWD_LDS_ZERO, IN_B, R1, NoPrev{});
+            r1.flush(R1);
+        }
+        // TOP-5, TOP-6, TOP-7: a -> b -> a -> b
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const ActMaskedOut<P, 16, 16, STORE> OB{b, A(TOP - 5 - 2 * r), D(TOP - 5 - 2 * r), sub0, lane, mask_lds};
+            const ActMaskedOut<P, 16, 16, STORE> OA_pend{a, A(TOP - 4 - 2 * r), D(TOP - 4 - 2 * r), sub0, lane, mask_lds};
+            d = dense<P, 16, 8, L::START[L0 + 6] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                const ActMaskedOut<P, 16, 16, STORE> OA{a, A(TOP - 6), D(TOP - 6), sub0, lane, mask_lds};
+                d = dense<P, 16, 8, L::START[L0 + 7] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            }
+        }
+        vm_wait<W16>();                                      // (the row layer has no mask wait of its own)
+        const ActMaskedOut<P, 16, 16, STORE> OL{b, A(TOP - 7), D(TOP - 7), sub0, lane, mask_lds};
+        const RowsOut R2{rows, LD, 1, sub0 * 32, j, h, M};
+        const auto r2 = dense<P, 16, NFB_ROWS, L::START[L0 + 9] - S0>(ws, BWD_LDS_ZERO, IN_B, R2, prev_of(d, OL));
+        r2.flush(R2);
+    }
+    ws.drain();
+}
+
+// Ref-NeRF, spatial network (parameter gradients): [bottle-neck delta | head deltas] (K groups 0..8 of delta slot 8,
+// ref_heads_delta_kernel) -> delta slots 7..0
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ act,
+                                                                 char* __restrict__ dlt, unsigned long long layer_stride) {
+    using L = RefBwdLayout;
+    using BReg = typename P::BReg;
+    constexpr int S0 = L::SPA_START;
+    WeightStream<P, MLP_NSLOT, false> ws;
+    bwd_prologue<P>(ws, stream, L::SPA_FRAGS);
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+    auto A = [&](int slot) { return act + (size_t)slot * layer_stride; };
+    auto D = [&](int slot) { return dlt + (size_t)slot * layer_stride; };
+    static_assert(L::START[11] % (2 * P::FPC) == L::START[13] % (2 * P::FPC) && L::START[11] % (2 * P::FPC) == L::START[15] % (2 * P::FPC) &&
+                  L::START[11] % (2 * P::FPC) == L::START[17] % (2 * P::FPC) && L::START[12] % (2 * P::FPC) == L::START[14] % (2 * P::FPC) &&
+                  L::START[12] % (2 * P::FPC) == L::START[16] % (2 * P::FPC) && S0 % (2 * P::FPC) == 0, "chunk phase of the shared loop bodies");
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        BReg x[NT][9], zero_kg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) P::set(zero_kg, e, 0.0f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) x[t][k] = P::load_global(D(8) + (size_t)(sub0 + t) * SUB + (size_t)k * P::BREG_LDS, lane);
+        BReg a[NT][16], b[NT][16];
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        const ActMaskedOut<P, 10, 0, true> O7{a, A(7), D(7), sub0, lane, mask_lds};
+        Deferred<P, 6, 2> d = dense<P, 10, 8, L::START[10] - S0>(ws, BWD_LDS_ZERO,
+            [&](int kg, int t) -> BReg { if (kg < 9) return x[t][kg < 9 ? kg : 0]; return zero_kg; }, O7, NoPrev{});
+        // S6 .. S0: a -> b -> a ... -> b; round 3 runs the first layer of the body only
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const ActMaskedOut<P, 16, 10, true> OB{b, A(6 - 2 * r), D(6 - 2 * r), sub0, lane, mask_lds};              // (follows the 10-step layer in round 0)
+            const ActMaskedOut<P, 16, 16, true> OA_pend{a, A(7 - 2 * r), D(7 - 2 * r), sub0, lane, mask_lds};
+            d = dense<P, 16, 8, L::START[11] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            if (r < 3) {
+                const ActMaskedOut<P, 16, 16, true> OA{a, A(5 - 2 * r), D(5 - 2 * r), sub0, lane, mask_lds};
+                d = dense<P, 16, 8, L::START[12] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            }
+        }
+        const ActMaskedOut<P, 16, 16, true> O0{b, A(0), D(0), sub0, lane, mask_lds};
+        vm_wait<mask_wait_count<P>(16)>();
+        d.flush(O0);
+    }
+    ws.drain();
+}
+
+// the proposal network's d density / d (encoded position) (train.py:165-168, `prop_normal`): the head row -> activation slots 3..0,
+// nothing stored but d_enc (M, 64) = layers.0^T d0
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ act,
+                                                                        unsigned long long layer_stride, float* __restrict__ d_enc) {
+    using L = PropBwdLayout;
+    using BReg = typename P::BReg;
+    WeightStream<P, MLP_NSLOT, false> ws;
+    bwd_prologue<P>(ws, stream, L::N_FRAGS);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
+    auto A = [&](int slot) { return act + (size_t)slot * layer_stride; };
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t sub0 = tile * (TS / 32) + wave * NT;
+        BReg one_kg, zero_kg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { P::set(one_kg, e, (e == 0 && h == 0) ? 1.0f : 0.0f); P::set(zero_kg, e, 0.0f); }
+        BReg a[NT][16], b[NT][16];
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        const ActMaskedOut<P, 2, 0, false> O3{a, A(3), nullptr, sub0, lane, mask_lds};
+        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int kg, int) -> BReg { return kg == 0 ? one_kg : zero_kg; }, O3, NoPrev{});
+        // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (as in prop_bwd_kernel)
+        static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk phase");
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const ActMaskedOut<P, 16, 2, false> OB{b, A(2 - 2 * r), nullptr, sub0, lane, mask_lds};
+            const ActMaskedOut<P, 16, 16, false> OA_pend{a, A(3 - 2 * r), nullptr, sub0, lane, mask_lds};
+            d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            if (r == 0) {
+                const ActMaskedOut<P, 16, 16, false> OA{a, A(1), nullptr, sub0, lane, mask_lds};
+                d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            }
+        }
+        vm_wait<mask_wait_count<P>(16)>();
+        const ActMaskedOut<P, 16, 16, false> O0{b, A(0), nullptr, sub0, lane, mask_lds};
+        const RowsOut R{d_enc, 64, 0, sub0 * 32, j, h, M};
+        const auto r = dense<P, 16, 2, L::ENC_START>(ws, BWD_LDS_ZERO, IN_B, R, prev_of(d, O0));
+        r.flush(R);
     }
     ws.drain();
 }
@@ -1216,6 +1466,67 @@ int bwd_grid(int64_t n_tiles) {
     return (int)(n_tiles < n_cu ? n_tiles : n_cu);
 }
 
+// The file is compiled as two translation units (Makefile: -DBWD_TU=1 / 2; 0 = everything in one): 2 holds the fused chains of
+// Ref-NeRF's backward and of the density gradient -- whose straight-line ten-layer bodies do not go through hipcc's
+// -amdgpu-mfma-vgpr-form pass -- behind bwd_launch_chain, 1 everything else.
+#ifndef BWD_TU
+#define BWD_TU 0
+#endif
+// REF_FUSED_CHAINS=0: the single-layer launches the fused chains replaced, for A/B runs
+#ifndef REF_FUSED_CHAINS
+#define REF_FUSED_CHAINS 1
+#endif
+#if BWD_TU != 1
+template <class P>
+int launch_chain_t(int which, const char* stream, int64_t M, const char* act, char* dlt, size_t ls, float* rows, hipStream_t st) {
+    constexpr int TS = P::NW * P::NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = bwd_lds_total<P>();
+    const dim3 grid(bwd_grid(n_tiles)), block(P::NW * 64);
+#ifdef CHAIN_PROBE
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(CHAIN_PROBE), lds)) return e;
+    return 0;
+#else
+    switch (which) {
+        case 0:
+            if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_chain9_kernel<P, false>), lds)) return e;
+            hipLaunchKernelGGL((ref_chain9_kernel<P, false>), grid, block, lds, st, stream, M, act, dlt, (unsigned long long)ls, rows);
+            break;
+        case 1:
+            if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_spa_bwd_kernel<P>), lds)) return e;
+            hipLaunchKernelGGL((ref_spa_bwd_kernel<P>), grid, block, lds, st, stream, M, act, dlt, (unsigned long long)ls);
+            break;
+        case 2:
+            if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_chain9_kernel<P, true>), lds)) return e;
+            hipLaunchKernelGGL((ref_chain9_kernel<P, true>), grid, block, lds, st, stream, M, act, (char*)nullptr, (unsigned long long)ls, rows);
+            break;
+        default:
+            if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(prop_density_chain_kernel<P>), lds)) return e;
+            hipLaunchKernelGGL((prop_density_chain_kernel<P>), grid, block, lds, st, stream, M, act, (unsigned long long)ls, rows);
+    }
+    return (int)hipGetLastError();
+#endif
+}
+// which: 0 Ref-NeRF directional, 1 Ref-NeRF spatial, 2 Ref-NeRF density gradient, 3 proposal density gradient; `start_frag`: where the
+// chain's stream begins in the blob
+}  // namespace
+size_t mlp_train_layer_stride(int precision, int64_t M);
+int bwd_launch_chain(int which, int precision, const void* blob, int start_frag, int64_t M, const void* act, void* dlt, float* rows, hipStream_t st) {
+    const size_t fb = precision == NERF_AMD_BF16 ? 1024 : 2048;
+    const char* stream = reinterpret_cast<const char*>(blob) + (size_t)start_frag * fb;
+    const size_t ls = mlp_train_layer_stride(precision, M);
+    if (precision == NERF_AMD_BF16) return launch_chain_t<PB16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, rows, st);
+    return launch_chain_t<PF32>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, rows, st);
+}
+#endif  // BWD_TU != 1
+#if BWD_TU != 2
+#if BWD_TU == 1
+}  // namespace
+int bwd_launch_chain(int which, int precision, const void* blob, int start_frag, int64_t M, const void* act, void* dlt, float* rows, hipStream_t st);
+#endif
+namespace {
+
 template <class P, bool F8 = false>
 int launch_prop_bwd(const void* packed, const float* g, int64_t M, Dump act, Dump dlt, hipStream_t st) {
     constexpr int TS = P::NW * P::NT * 32;
@@ -1510,25 +1821,31 @@ int rows_layer(const ChainCtx& c, const void* blob, int start, const char* x, fl
     return launch_layer<16, NFB, false>(c.precision, blob, start, io, c.M, st);
 }
 int blocks_1d(int64_t work) { int64_t b = (work + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
 }  // namespace
 
 // d density / d position, times scale[m] (RefNeRF.get_grad, ref_model.py:119-125; train.py:165-168,178) for the proposal network
 // (net 0: activation slots 0..3) and Ref-NeRF's spatial network (net 2: slots 0..7): a dgrad-only chain from the density row down to
 // the encoded position, then the encoding's derivative.  workspace: two delta buffers of one slot each + d_enc rows (M, 64) fp32.
 size_t bwd_density_grad_workspace_bytes(int precision, int64_t M) {
-    return 2 * align256(mlp_train_layer_stride(precision, M)) + align256((size_t)M * 64 * 4) + 256;
+    return (REF_FUSED_CHAINS ? 0 : 2 * align256(mlp_train_layer_stride(precision, M))) + align256((size_t)M * 64 * 4) + 256;
 }
 int bwd_density_grad(int net, const void* blob, int precision, int64_t M, const void* act, const float* x, int x_stride, const float* scale, int scale_stride,
                      float* out, void* workspace, hipStream_t st) {
     if (M == 0) return 0;
     const ChainCtx c(precision, M);
     Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
+#if REF_FUSED_CHAINS
+    float* denc = ws.take((size_t)M * 64);
+    if (net == NERF_AMD_NET_PROPOSAL) { if (int e = bwd_launch_chain(3, precision, blob, 0, M, act, nullptr, denc, st)) return e; }
+    else if (int e = bwd_launch_chain(2, precision, blob, RefBwdLayout::DEN_START, M, act, nullptr, denc, st)) return e;
+#else
     char* d[2] = {reinterpret_cast<char*>(ws.take(c.ls / 4)), reinterpret_cast<char*>(ws.take(c.ls / 4))};
     float* denc = ws.take((size_t)M * 64);
     int cur = 0;
     if (net == NERF_AMD_NET_PROPOSAL) {
         using L = PropBwdLayout;
-        if (int e = hidden_layer<1>(c, blob, L::START[0], nullptr, 1, nullptr, 1, c.at(act, 3), d[cur], st)) return e;        // delta_3 from the head row
+        if (int e = hidden_layer<2>(c, blob, L::START[0], nullptr, 2, nullptr, 1, c.at(act, 3), d[cur], st)) return e;        // delta_3 from the head row
         for (int l = 1; l <= 3; ++l) {                                                                                       // delta_2, delta_1, delta_0
             if (int e = hidden_layer<16>(c, blob, L::START[l], d[cur], 16, nullptr, 0, c.at(act, 3 - l), d[cur ^ 1], st)) return e;
             cur ^= 1;
@@ -1536,20 +1853,21 @@ int bwd_density_grad(int net, const void* blob, int precision, int64_t M, const 
         if (int e = rows_layer<2>(c, blob, L::ENC_START, d[cur], denc, 64, 0, st)) return e;
     } else {
         using L = RefBwdLayout;
-        if (int e = hidden_layer<1>(c, blob, L::START[20], nullptr, 1, nullptr, 1, c.at(act, 7), d[cur], st)) return e;       // delta_S7 from the density row
+        if (int e = hidden_layer<2>(c, blob, L::START[18], nullptr, 2, nullptr, 1, c.at(act, 7), d[cur], st)) return e;       // delta_S7 from the density row
         for (int l = 0; l < 3; ++l) {                                                                                        // S6, S5, S4
-            if (int e = hidden_layer<16>(c, blob, L::START[11 + l], d[cur], 16, nullptr, 0, c.at(act, 6 - l), d[cur ^ 1], st)) return e;
+            if (int e = hidden_layer<16>(c, blob, L::START[19 + l], d[cur], 16, nullptr, 0, c.at(act, 6 - l), d[cur ^ 1], st)) return e;
             cur ^= 1;
         }
-        if (int e = rows_layer<2>(c, blob, L::START[15], d[cur], denc, 64, 0, st)) return e;                                  // skip layer: its encoding columns
-        if (int e = hidden_layer<16>(c, blob, L::START[14], d[cur], 16, nullptr, 0, c.at(act, 3), d[cur ^ 1], st)) return e;  // ... and its hidden columns -> S3
+        if (int e = rows_layer<2>(c, blob, L::START[23], d[cur], denc, 64, 0, st)) return e;                                  // skip layer: its encoding columns
+        if (int e = hidden_layer<16>(c, blob, L::START[22], d[cur], 16, nullptr, 0, c.at(act, 3), d[cur ^ 1], st)) return e;  // ... and its hidden columns -> S3
         cur ^= 1;
         for (int l = 0; l < 3; ++l) {                                                                                        // S2, S1, S0
-            if (int e = hidden_layer<16>(c, blob, L::START[16 + l], d[cur], 16, nullptr, 0, c.at(act, 2 - l), d[cur ^ 1], st)) return e;
+            if (int e = hidden_layer<16>(c, blob, L::START[24 + l], d[cur], 16, nullptr, 0, c.at(act, 2 - l), d[cur ^ 1], st)) return e;
             cur ^= 1;
         }
-        if (int e = rows_layer<2>(c, blob, L::START[19], d[cur], denc, 64, 1, st)) return e;
+        if (int e = rows_layer<2>(c, blob, L::START[27], d[cur], denc, 64, 1, st)) return e;
     }
+#endif
     hipLaunchKernelGGL(pe_grad_kernel, dim3(blocks_1d(M * 3)), dim3(256), 0, st, denc, 64, x, x_stride, scale, scale_stride, M, 10, out);
     return (int)hipGetLastError();
 }
@@ -1588,7 +1906,10 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
     // stage 1: spec head delta, then the directional network backwards
     if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
     else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
-    if (int e = hidden_layer<1>(c, blob, L::START[0], D(8, 9), 1, nullptr, 0, A(16), D(16), st)) return e;                    // D7
+#if REF_FUSED_CHAINS
+    if (int e = bwd_launch_chain(0, precision, blob, L::DIR_START, M, act, dlt, dallin, st)) return e;                            // D7 .. D0 + the input-vector columns
+#else
+    if (int e = hidden_layer<2>(c, blob, L::START[0], D(8, 9), 2, nullptr, 0, A(16), D(16), st)) return e;                    // D7
     if (int e = hidden_layer<16>(c, blob, L::START[1], D(16), 16, nullptr, 0, A(15), D(15), st)) return e;                    // D6
     if (int e = hidden_layer<16>(c, blob, L::START[2], D(15), 16, nullptr, 0, A(14), D(14), st)) return e;                    // D5
     if (int e = hidden_layer<16>(c, blob, L::START[3], D(14), 16, nullptr, 0, A(13), D(13), st)) return e;                    // D4
@@ -1598,20 +1919,25 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
     if (int e = hidden_layer<16>(c, blob, L::START[7], D(11), 16, nullptr, 0, A(10), D(10), st)) return e;                    // D1
     if (int e = hidden_layer<16>(c, blob, L::START[8], D(10), 16, nullptr, 0, A(9), D(9), st)) return e;                      // D0
     if (int e = rows_layer<6>(c, blob, L::START[9], D(9), dallin, 192, 1, st)) return e;
+#endif
     // stage 2: IDE / reflection / normal / head activations backwards -> delta of the heads and of the bottle-neck
     if (elem == 2) hipLaunchKernelGGL(ref_heads_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M,
                                       D(8), (unsigned long long)c.sub, srgb);
     else hipLaunchKernelGGL(ref_heads_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, D(8),
                             (unsigned long long)c.sub, srgb);
     // stage 3: the spatial network backwards
-    if (int e = hidden_layer<9>(c, blob, L::START[10], D(8), 9, nullptr, 0, A(7), D(7), st)) return e;                        // S7 from [bottle-neck | heads]
+#if REF_FUSED_CHAINS
+    if (int e = bwd_launch_chain(1, precision, blob, L::SPA_START, M, act, dlt, nullptr, st)) return e;                           // S7 .. S0
+#else
+    if (int e = hidden_layer<10>(c, blob, L::START[10], D(8), 10, nullptr, 0, A(7), D(7), st)) return e;                      // S7 from [bottle-neck | heads | 0]
     if (int e = hidden_layer<16>(c, blob, L::START[11], D(7), 16, nullptr, 0, A(6), D(6), st)) return e;
     if (int e = hidden_layer<16>(c, blob, L::START[12], D(6), 16, nullptr, 0, A(5), D(5), st)) return e;
     if (int e = hidden_layer<16>(c, blob, L::START[13], D(5), 16, nullptr, 0, A(4), D(4), st)) return e;
     if (int e = hidden_layer<16>(c, blob, L::START[14], D(4), 16, nullptr, 0, A(3), D(3), st)) return e;                      // skip layer's hidden columns -> S3
-    if (int e = hidden_layer<16>(c, blob, L::START[16], D(3), 16, nullptr, 0, A(2), D(2), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[17], D(2), 16, nullptr, 0, A(1), D(1), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[18], D(1), 16, nullptr, 0, A(0), D(0), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[15], D(3), 16, nullptr, 0, A(2), D(2), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[16], D(2), 16, nullptr, 0, A(1), D(1), st)) return e;
+    if (int e = hidden_layer<16>(c, blob, L::START[17], D(1), 16, nullptr, 0, A(0), D(0), st)) return e;
+#endif
     // weight gradients
     const int w7 = wgrad_workgroups(n_sub, 7, true), w2 = wgrad_workgroups(n_sub, 2, false), w1h = wgrad_workgroups(n_sub, 1, true),
               w1 = wgrad_workgroups(n_sub, 1, false);
@@ -1679,3 +2005,4 @@ int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, flo
     }
     return (int)hipGetLastError();
 }
+#endif  // BWD_TU != 2

@@ -85,12 +85,12 @@ struct MipLayout {
 // ------------------------------------------------------------------------------------------------
 struct PropBwdLayout {
     static constexpr int N_LAYERS = 4;
-    static constexpr int NKG[4] = {1, 16, 16, 16};
-    static constexpr int NFB[4] = {8, 8, 8, 8};
-    static constexpr int START[4] = {0, 8, 136, 264};
-    static constexpr int CHAIN_FRAGS = 392;              // what the fused chain streams cyclically
-    static constexpr int ENC_START = 392;                // + layers.0^T (rows = the 63 input columns, 2 blocks): the gradient w.r.t. the
-    static constexpr int N_FRAGS = 424;                  //   encoded position, used by the density-gradient chain (RefNeRF.get_grad)
+    static constexpr int NKG[4] = {2, 16, 16, 16};       // (head: its second K group is zero padding -- every cyclic stream holds an EVEN
+    static constexpr int NFB[4] = {8, 8, 8, 8};          //  number of chunks, so that the barrier pattern of WeightStream is the same in every tile)
+    static constexpr int START[4] = {0, 16, 144, 272};
+    static constexpr int CHAIN_FRAGS = 400;              // what the fused parameter chain streams cyclically
+    static constexpr int ENC_START = 400;                // + layers.0^T (rows = the 63 input columns, 2 blocks): the gradient w.r.t. the
+    static constexpr int N_FRAGS = 432;                  //   encoded position; the density-gradient chain (RefNeRF.get_grad) streams all 432
     LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec); }
 };
@@ -104,19 +104,27 @@ struct MipBwdLayout {
     LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + FOLD_SCRATCH; }
 };
-// Ref-NeRF backward: every layer is its own launch (bwd_kernels.hip dgrad_layer_kernel), so the blob is a table of independent
-// transposed layers, each starting on a chunk boundary.  (rows x K groups; "e" = a side output in the reference's column order)
-//    0 R    spec_rgb_head^T     256 x 1      1-3 D7,D6,D5  dir_block2.{6,4,2}^T        4 D4h  dir_block2.0[:, 167:]^T   256 x 16
-//    5 D4a  dir_block2.0[:, :167]^T  167 x 16 (e)           6-8 D3,D2,D1  dir_block1.{6,4,2}^T   9 D0a  dir_block1.0^T  167 x 16 (e)
-//   10 H    [bottle_neck ; heads]^T  256 x 9               11-13 S7,S6,S5 spa_block2.{6,4,2}^T  14 S4h  spa_block2.0[:, 63:]^T
-//   15 S4e  spa_block2.0[:, :63]^T    63 x 16 (e)          16-18 S3,S2,S1 spa_block1.{6,4,2}^T  19 S0e  spa_block1.0^T   63 x 16 (e)
-//   20 Hd   density row of the heads^T  256 x 1  (the density-gradient chain of RefNeRF.get_grad)
+// Ref-NeRF backward: three fused chains (bwd_kernels.hip), each a contiguous cyclic stream of transposed layers in consumption order
+// (rows x K groups; "e" = a side output in the reference's column order, written as fp32 rows):
+//   DIR  (directional network, from the spec head down to the 167-wide input vector)
+//      0 R   spec_rgb_head^T 256 x 2 (second K group: zero pad)   1-3 D7,D6,D5 dir_block2.{6,4,2}^T   4 D4h dir_block2.0[:, 167:]^T
+//      5 D4a dir_block2.0[:, :167]^T 167 x 16 (e)                  6-8 D3,D2,D1 dir_block1.{6,4,2}^T   9 D0a dir_block1.0^T 167 x 16 (e)
+//   SPA  (spatial network, parameter gradients: from [bottle-neck | heads] down to the first hidden layer)
+//     10 H   [bottle_neck ; heads]^T 256 x 10 (K group 9: zero pad)   11-13 S7,S6,S5 spa_block2.{6,4,2}^T   14 S4h spa_block2.0[:, 63:]^T
+//     15-17 S3,S2,S1 spa_block1.{6,4,2}^T
+//   DEN  (spatial network, d density / d encoded position: RefNeRF.get_grad)
+//     18 Hd  density row of the heads^T 256 x 2 (zero pad)   19-21 = 11-13   22 = 14   23 S4e spa_block2.0[:, :63]^T 63 x 16 (e)
+//     24-26 = 15-17   27 S0e spa_block1.0^T 63 x 16 (e)
+// Layers 19-22 and 24-26 are second copies of 11-17 (7 x 128 KiB in bf16): a chain's stream has to be contiguous.
 struct RefBwdLayout {
-    static constexpr int N_LAYERS = 21;
-    static constexpr int NKG[21] = {1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 9, 16, 16, 16, 16, 16, 16, 16, 16, 16, 1};
-    static constexpr int NFB[21] = {8, 8, 8, 8, 8, 6, 8, 8, 8, 6, 8, 8, 8, 8, 8, 2, 8, 8, 8, 2, 8};
-    static constexpr int START[21] = {0, 8, 136, 264, 392, 520, 616, 744, 872, 1000, 1096, 1168, 1296, 1424, 1552, 1680, 1712, 1840, 1968, 2096, 2128};
-    static constexpr int N_FRAGS = 2136;
+    static constexpr int N_LAYERS = 28;
+    static constexpr int NKG[28] = {2, 16, 16, 16, 16, 16, 16, 16, 16, 16,   10, 16, 16, 16, 16, 16, 16, 16,   2, 16, 16, 16, 16, 16, 16, 16, 16, 16};
+    static constexpr int NFB[28] = {8, 8, 8, 8, 8, 6, 8, 8, 8, 6,   8, 8, 8, 8, 8, 8, 8, 8,   8, 8, 8, 8, 8, 2, 8, 8, 8, 2};
+    static constexpr int START[28] = {0, 16, 144, 272, 400, 528, 624, 752, 880, 1008,
+                                      1104, 1184, 1312, 1440, 1568, 1696, 1824, 1952,
+                                      2080, 2096, 2224, 2352, 2480, 2608, 2640, 2768, 2896, 3024};
+    static constexpr int DIR_START = 0, DIR_FRAGS = 1104, SPA_START = 1104, SPA_FRAGS = 976, DEN_START = 2080, DEN_FRAGS = 976;
+    static constexpr int N_FRAGS = 3056;
     LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec); }
 };

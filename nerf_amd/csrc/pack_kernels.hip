@@ -199,7 +199,7 @@ PackLayer make_trans_layer(const float* w, int stride, int col0, int rows, int k
 int pack_proposal_bwd(int precision, const float* const* w, void* packed, hipStream_t st) {
     using Lay = PropBwdLayout;
     PackBatch B = {};
-    B.L[0] = make_trans_layer(w[4], 256, 0, 256, 1, Lay::NKG[0], Lay::NFB[0], Lay::START[0]);       // d3 = layers.8^T g
+    B.L[0] = make_trans_layer(w[4], 256, 0, 256, 1, Lay::NKG[0], Lay::NFB[0], Lay::START[0]);       // d3 = layers.8^T g (+ one zero K group)
     for (int l = 1; l < 4; ++l) B.L[l] = make_trans_layer(w[4 - l], 256, 0, 256, 256, Lay::NKG[l], Lay::NFB[l], Lay::START[l]);
     B.L[4] = make_trans_layer(w[0], 63, 0, 63, 256, 16, 2, Lay::ENC_START);                        // d enc = layers.0^T delta_0 (density-gradient chain)
     return launch_pack(B, 5, precision, reinterpret_cast<char*>(packed), nullptr, st);
@@ -232,20 +232,30 @@ int pack_ref_bwd(int precision, const float* const* w, void* packed, hipStream_t
     using Lay = RefBwdLayout;
     PackBatch B = {};
     auto full = [&](int l, const float* m) { B.L[l] = make_trans_layer(m, 256, 0, 256, 256, 16, 8, Lay::START[l]); };
-    B.L[0] = make_trans_layer(w[18], 256, 0, 256, 3, 1, 8, Lay::START[0]);                          // spec head (slot features 0..2)
+    // DIR chain
+    B.L[0] = make_trans_layer(w[18], 256, 0, 256, 3, Lay::NKG[0], 8, Lay::START[0]);                // spec head (slot features 0..2; K group 1: zero)
     full(1, w[17]); full(2, w[16]); full(3, w[15]);
     B.L[4] = make_trans_layer(w[14], 423, 167, 256, 256, 16, 8, Lay::START[4]);                     // dir_block2.0: hidden columns
     B.L[5] = make_trans_layer(w[14], 423, 0, 167, 256, 16, 6, Lay::START[5]);                       //               input-vector columns
     full(6, w[13]); full(7, w[12]); full(8, w[11]);
     B.L[9] = make_trans_layer(w[10], 167, 0, 167, 256, 16, 6, Lay::START[9]);                       // dir_block1.0
-    PackLayer& H = B.L[10] = make_trans_layer(w[8], 256, 0, 256, 128, 9, 8, Lay::START[10]);        // [bottle_neck (K 0..127) | heads (K group 8)]
+    // SPA chain
+    PackLayer& H = B.L[10] = make_trans_layer(w[8], 256, 0, 256, 128, Lay::NKG[10], 8, Lay::START[10]);   // [bottle_neck (K 0..127) | heads (K group 8) | zero]
     H.seg_nkg[0] = 8;
     H.seg_w[1] = w[9]; H.seg_stride[1] = 256; H.seg_nkg[1] = 1; H.seg_first[1] = 0; H.seg_width[1] = 11;
+    H.seg_w[2] = w[9]; H.seg_stride[2] = 256; H.seg_nkg[2] = 1; H.seg_first[2] = 0; H.seg_width[2] = 0;    // (a K group of width 0: all padding)
     full(11, w[7]); full(12, w[6]); full(13, w[5]);
     B.L[14] = make_trans_layer(w[4], 319, 63, 256, 256, 16, 8, Lay::START[14]);                     // spa_block2.0: hidden columns
-    B.L[15] = make_trans_layer(w[4], 319, 0, 63, 256, 16, 2, Lay::START[15]);                       //               encoding columns
-    full(16, w[3]); full(17, w[2]); full(18, w[1]);
-    B.L[19] = make_trans_layer(w[0], 63, 0, 63, 256, 16, 2, Lay::START[19]);                        // spa_block1.0
-    B.L[20] = make_trans_layer(w[9] + 7 * 256, 256, 0, 256, 1, 1, 8, Lay::START[20]);               // the density row of the heads alone
-    return launch_pack(B, 21, precision, reinterpret_cast<char*>(packed), nullptr, st);
+    full(15, w[3]); full(16, w[2]); full(17, w[1]);
+    if (int e = launch_pack(B, 18, precision, reinterpret_cast<char*>(packed), nullptr, st)) return e;
+    // DEN chain (second copies of the spatial layers + the encoding columns)
+    PackBatch C = {};
+    auto fullc = [&](int l, const float* m) { C.L[l - 18] = make_trans_layer(m, 256, 0, 256, 256, 16, 8, Lay::START[l]); };
+    C.L[0] = make_trans_layer(w[9] + 7 * 256, 256, 0, 256, 1, Lay::NKG[18], 8, Lay::START[18]);     // the density row of the heads alone
+    fullc(19, w[7]); fullc(20, w[6]); fullc(21, w[5]);
+    C.L[4] = make_trans_layer(w[4], 319, 63, 256, 256, 16, 8, Lay::START[22]);
+    C.L[5] = make_trans_layer(w[4], 319, 0, 63, 256, 16, 2, Lay::START[23]);                        // spa_block2.0: encoding columns
+    fullc(24, w[3]); fullc(25, w[2]); fullc(26, w[1]);
+    C.L[9] = make_trans_layer(w[0], 63, 0, 63, 256, 16, 2, Lay::START[27]);                         // spa_block1.0
+    return launch_pack(C, 10, precision, reinterpret_cast<char*>(packed), nullptr, st);
 }
