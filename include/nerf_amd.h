@@ -246,6 +246,20 @@ int nerf_amd_composite(const float* rgbo, const float* z, int z_stride, const fl
  * is sorted first, so the result always equals the sort.  K + C <= 2048. */
 int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N, int K, int C, float* z_out, void* stream);
 
+/* NeRF.coarseFineMerge as the TRAINING loop calls it (nerf_base.py:59-73 with f_inds; train.py:176): z_out as above, plus
+ * order (N, K+C) int64 = the stable argsort of cat(z_fine, z_coarse) (fine index i before coarse index K + j among equal depths --
+ * what torch.sort's device radix sort returns; the reference hands order[..., :-1] to RefNeRF.coarse_grad_select), and, when
+ * f_inds (N,K) int64 is given, all_inds (N, K+C) int64 = gather(cat(f_inds, arange(C)), order) (the bin indices getBounds reads).
+ * f_inds / all_inds may be NULL.  K + C <= 1024. */
+int nerf_amd_merge_depths_order(const float* z_fine, const float* z_coarse, const int64_t* f_inds, int64_t N, int K, int C, float* z_out,
+                                int64_t* order, int64_t* all_inds, void* stream);
+
+/* RefNeRF.coarse_grad_select (ref_model.py:108-117): grads (N,T,D) fp32, sort_inds (N,T) int64 -> out (N,c_pnum,D): the rows of the
+ * first c_pnum positions p (ascending) with sort_inds[n,p] >= T - c_pnum -- the reference's boolean mask
+ * gather(cat(zeros(T-c), ones(c)), sort_inds) without its data-dependent output size; rows with fewer flagged positions continue with
+ * the unflagged ones in order. */
+int nerf_amd_coarse_grad_select(const float* grads, const int64_t* sort_inds, int64_t N, int T, int D, int c_pnum, float* out, void* stream);
+
 /* getBounds (addtional.py:14-18): w_prop (N,C), below (N,K) int64 -> bounds (N,K-1). */
 int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream);
 

@@ -18,6 +18,8 @@ int mlp_launch_mip_train(const void*, int, const nerf_amd_samples&, float*, void
 int sk_frag_to_rows(const void*, int, int64_t, int, int64_t, void*, hipStream_t);
 int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
 int sk_merge_sorted(const float*, const float*, int64_t, int, int, float*, hipStream_t);
+int sk_merge_sorted_order(const float*, const float*, const int64_t*, int64_t, int, int, float*, int64_t*, int64_t*, hipStream_t);
+int sk_coarse_grad_select(const float*, const int64_t*, int64_t, int, int, int, float*, hipStream_t);
 int sk_encode_rows(const float*, int, int64_t, int, int, int, void*, hipStream_t);
 int sk_frag_rows_mask_blocks();
 int sk_frag_rows_mask(const void*, int, int64_t, int, int64_t, void*, void*, float*, hipStream_t);
@@ -109,7 +111,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 112; }
+int nerf_amd_version(void) { return 113; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -325,6 +327,20 @@ int nerf_amd_merge_depths(const float* z_fine, const float* z_coarse, int64_t N,
     if (N < 0 || K < 1 || C < 1 || K + C > 2048) return fail(NERF_AMD_EINVAL, "bad size (K + C <= 2048: four rays of depths and their sort scratch per workgroup live in 64 KiB of LDS)");
     if (N && (!z_fine || !z_coarse || !z_out)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_merge_sorted(z_fine, z_coarse, N, K, C, z_out, S(stream)), "nerf_amd_merge_depths");
+}
+
+int nerf_amd_merge_depths_order(const float* z_fine, const float* z_coarse, const int64_t* f_inds, int64_t N, int K, int C, float* z_out, int64_t* order,
+                                int64_t* all_inds, void* stream) {
+    if (N < 0 || K < 1 || C < 1 || K + C > 1024) return fail(NERF_AMD_EINVAL, "bad size (K + C <= 1024: four rays of depths, indices and their sort scratch per workgroup live in 64 KiB of LDS)");
+    if (N && (!z_fine || !z_coarse || !z_out || !order)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    if (N && all_inds && !f_inds) return fail(NERF_AMD_EINVAL, "all_inds needs f_inds");
+    return hip_status(sk_merge_sorted_order(z_fine, z_coarse, f_inds, N, K, C, z_out, order, all_inds, S(stream)), "nerf_amd_merge_depths_order");
+}
+
+int nerf_amd_coarse_grad_select(const float* grads, const int64_t* sort_inds, int64_t N, int T, int D, int c_pnum, float* out, void* stream) {
+    if (N < 0 || T < 1 || D < 1 || c_pnum < 0 || c_pnum > T) return fail(NERF_AMD_EINVAL, "bad size");
+    if (N && c_pnum && (!grads || !sort_inds || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_coarse_grad_select(grads, sort_inds, N, T, D, c_pnum, out, S(stream)), "nerf_amd_coarse_grad_select");
 }
 
 // ---- training forward: the MLP kernels also dump their hidden activations ----

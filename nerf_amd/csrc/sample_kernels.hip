@@ -1181,6 +1181,92 @@ __global__ __launch_bounds__(256) void merge_sorted_kernel(const float* __restri
     }
 }
 
+// The same merge with its sort order, for the training path (train.py:176: coarseFineMerge(..., below_idxs) -> all_inds for getBounds,
+// sort_inds for RefNeRF.coarse_grad_select).  order (N, K + C) = the STABLE argsort of cat(a, b) -- fine index i before coarse index
+// K + j among equal depths, which is what the device radix sort behind torch.sort produces --, all_inds = gather(cat(f_inds, 0..C-1), order).
+DEVINL void wave_sort_idx_if_needed(float* v, int* idx, float* tmp, int* itmp, int n, int lane) {
+    int bad = 0;
+    for (int i = lane; i + 1 < n; i += 64) bad |= (v[i] > v[i + 1]) ? 1 : 0;
+    if (!__any(bad)) return;
+    for (int i = lane; i < n; i += 64) {
+        const float x = v[i];
+        int r = 0;
+        for (int k = 0; k < n; ++k) { const float y = v[k]; r += (y < x || (y == x && k < i)) ? 1 : 0; }
+        tmp[r] = x; itmp[r] = idx[i];
+    }
+    lds_wave_sync();
+    for (int i = lane; i < n; i += 64) { v[i] = tmp[i]; idx[i] = itmp[i]; }
+    lds_wave_sync();
+}
+__global__ __launch_bounds__(256) void merge_sorted_order_kernel(const float* __restrict__ a, const float* __restrict__ b, const int64_t* __restrict__ f_inds,
+                                                                 int64_t N, int K, int C, float* __restrict__ out, int64_t* __restrict__ order,
+                                                                 int64_t* __restrict__ all_inds) {
+    float* la = reinterpret_cast<float*>(smem) + wave_in_block() * 4 * (K + C);
+    float* lb = la + K;
+    float* tmp = lb + C;
+    int* ia = reinterpret_cast<int*>(tmp + K + C);
+    int* ib = ia + K;
+    int* itmp = ib + C;
+    const int lane = lane_id();
+    const int T = K + C - 1;
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        lds_wave_sync();
+        for (int i = lane; i < K; i += 64) { la[i] = a[n * K + i]; ia[i] = i; }
+        for (int j = lane; j < C; j += 64) { lb[j] = b[n * C + j]; ib[j] = K + j; }
+        lds_wave_sync();
+        wave_sort_idx_if_needed(la, ia, tmp, itmp, K, lane);
+        wave_sort_idx_if_needed(lb, ib, tmp, itmp, C, lane);
+        float* o = out + n * T;
+        int64_t* ord = order + n * (K + C);
+        int64_t* ai = all_inds ? all_inds + n * (K + C) : nullptr;
+        for (int i = lane; i < K; i += 64) {
+            const float v = la[i];
+            int lo = 0, hi = C;                                 // #(b < v)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (lb[mid] < v) lo = mid + 1; else hi = mid; }
+            const int p = i + lo, src = ia[i];
+            if (p < T) o[p] = v;
+            ord[p] = src;
+            if (ai) ai[p] = f_inds[n * K + src];
+        }
+        for (int j = lane; j < C; j += 64) {
+            const float v = lb[j];
+            int lo = 0, hi = K;                                 // #(a <= v)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (la[mid] <= v) lo = mid + 1; else hi = mid; }
+            const int p = j + lo, src = ib[j];
+            if (p < T) o[p] = v;
+            ord[p] = src;
+            if (ai) ai[p] = src - K;
+        }
+    }
+}
+
+// RefNeRF.coarse_grad_select (ref_model.py:108-117): out[n, k] = grads[n, p_k], p_k the k-th position (ascending) whose sort index is
+// flagged (>= T - c_pnum: the reference's mask cat(zeros(T - c), ones(c)) gathered by the sort order); should a row hold fewer than c_pnum
+// flagged positions, the unflagged ones follow in order -- exactly what the reference's boolean mask does when the row counts agree and
+// what a stable descending sort of the flags does otherwise.  One wavefront per ray, ranks by ballot.
+__global__ __launch_bounds__(256) void coarse_grad_select_kernel(const float* __restrict__ grads, const int64_t* __restrict__ sort_inds, int64_t N, int T, int D,
+                                                                 int c_pnum, float* __restrict__ out) {
+    const int lane = lane_id();
+    const int64_t thr = (int64_t)T - c_pnum;
+    for (int64_t n = blockIdx.x * (int64_t)WAVES_PER_BLOCK + wave_in_block(); n < N; n += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t* si = sort_inds + n * T;
+        const float* g = grads + n * (int64_t)T * D;
+        float* o = out + n * (int64_t)c_pnum * D;
+        int base = 0;
+        for (int want = 1; want >= 0; --want) {                // flagged positions first, then the others
+            for (int p0 = 0; p0 < T && base < c_pnum; p0 += 64) {
+                const int p = p0 + lane;
+                const bool hit = p < T && ((si[p] >= thr) == (want == 1));
+                const unsigned long long m = __ballot(hit);
+                const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (hit && k < c_pnum)
+                    for (int d = 0; d < D; ++d) o[(int64_t)k * D + d] = g[(int64_t)p * D + d];
+                base += __popcll(m);
+            }
+        }
+    }
+}
+
 int blocks_for(int64_t work, int per_block) {
     int64_t b = (work + per_block - 1) / per_block;
     const int64_t cap = 256 * 8;
@@ -1386,6 +1472,18 @@ int sk_merge_sorted(const float* a, const float* b, int64_t N, int K, int C, flo
     if (N == 0) return 0;
     const size_t lds = WAVES_PER_BLOCK * (size_t)(K + C) * 2 * 4;
     hipLaunchKernelGGL(merge_sorted_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a, b, N, K, C, out);
+    return (int)hipGetLastError();
+}
+int sk_merge_sorted_order(const float* a, const float* b, const int64_t* f_inds, int64_t N, int K, int C, float* out, int64_t* order, int64_t* all_inds,
+                          hipStream_t st) {
+    if (N == 0) return 0;
+    const size_t lds = WAVES_PER_BLOCK * (size_t)(K + C) * 4 * 4;
+    hipLaunchKernelGGL(merge_sorted_order_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), lds, st, a, b, f_inds, N, K, C, out, order, all_inds);
+    return (int)hipGetLastError();
+}
+int sk_coarse_grad_select(const float* grads, const int64_t* sort_inds, int64_t N, int T, int D, int c_pnum, float* out, hipStream_t st) {
+    if (N == 0 || c_pnum == 0 || D == 0) return 0;
+    hipLaunchKernelGGL(coarse_grad_select_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, grads, sort_inds, N, T, D, c_pnum, out);
     return (int)hipGetLastError();
 }
 int sk_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize, int elem_bytes, void* out, hipStream_t st) {

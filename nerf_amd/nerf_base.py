@@ -65,9 +65,18 @@ class NeRF(nn.Module):
 
     @staticmethod
     def coarseFineMerge(rays: torch.Tensor, c_zvals: torch.Tensor, f_zvals: torch.Tensor, f_inds: Optional[torch.Tensor] = None):
-        """cat(fine, coarse) -> sort -> drop last -> points (nerf_base.py:59-73).  The sort/gather are
-        device torch ops (Ref-NeRF path); the points come from the HIP kernel."""
-        z, order = torch.sort(torch.cat((f_zvals, c_zvals), dim=-1), dim=-1)
+        """cat(fine, coarse) -> sort -> drop last -> points (nerf_base.py:59-73).  On the device the sort, the index bookkeeping
+        (arange / cat / gather) and the points are two HIP launches (nerf_amd_merge_depths_order: a stable merge of the two ascending
+        depth sets, out-of-order rays sorted first; nerf_amd_length2pts).  CPU tensors -- host-side unit tests only -- take the torch
+        expression of the same definition."""
+        require_no_grad(rays, c_zvals, f_zvals)
+        if rays.is_cuda:
+            z, order, all_inds = ops.merge_depths_order(f_zvals, c_zvals, f_inds)
+            samples = ops.length2pts(rays, z)
+            if f_inds is not None:
+                return samples, z, all_inds, order[..., :-1]
+            return samples, z,
+        z, order = torch.sort(torch.cat((f_zvals, c_zvals), dim=-1), dim=-1, stable=True)
         if f_inds is not None:
             c_inds = torch.arange(c_zvals.shape[-1], device=z.device).unsqueeze(0).expand(c_zvals.shape[0], -1)
             all_inds = torch.gather(torch.cat((f_inds, c_inds), dim=-1), -1, order)

@@ -50,11 +50,11 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+def _dev(t: torch.Tensor, name: str, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError("nerf_amd: '%s' must live on the HIP device (got %s); there is no CPU path" % (name, t.device))
-    if t.dtype != torch.float32:
-        t = t.float()
+    if t.dtype != dtype:
+        t = t.to(dtype)
     return t.contiguous()
 
 
@@ -399,6 +399,33 @@ def composite(rgbo: torch.Tensor, z: torch.Tensor, dirs: torch.Tensor, mul_norm:
                                  float(near), float(far), _ptr(normal), _ptr(cam_dir), _ptr(rgb), _ptr(w), _ptr(depth), _ptr(nimg),
                                  _stream()), "nerf_amd_composite")
     return rgb, w, depth, nimg
+
+
+def merge_depths_order(z_fine: torch.Tensor, z_coarse: torch.Tensor, f_inds: Optional[torch.Tensor] = None):
+    """NeRF.coarseFineMerge's sort with its order (nerf_base.py:59-73, train.py:176) -> (z (N, K+C-1), order (N, K+C) int64,
+    all_inds (N, K+C) int64 or None): one merge kernel instead of torch.sort + arange + cat + gather."""
+    z_fine, z_coarse = _dev(z_fine, "z_fine"), _dev(z_coarse, "z_coarse")
+    N, K = z_fine.shape
+    Cn = z_coarse.shape[-1]
+    dev = z_fine.device
+    out = torch.empty((N, K + Cn - 1), dtype=torch.float32, device=dev)
+    order = torch.empty((N, K + Cn), dtype=torch.int64, device=dev)
+    all_inds = None
+    if f_inds is not None:
+        f_inds = _dev(f_inds, "f_inds", torch.int64)
+        all_inds = torch.empty((N, K + Cn), dtype=torch.int64, device=dev)
+    check(lib.nerf_amd_merge_depths_order(_ptr(z_fine), _ptr(z_coarse), _ptr(f_inds) if f_inds is not None else None, N, K, Cn, _ptr(out), _ptr(order),
+                                          _ptr(all_inds) if all_inds is not None else None, _stream()), "nerf_amd_merge_depths_order")
+    return out, order, all_inds
+
+
+def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum: int) -> torch.Tensor:
+    """RefNeRF.coarse_grad_select (ref_model.py:108-117) on the device: (N,T,D), (N,T) int64 -> (N,c_pnum,D)"""
+    fine_grads, sort_inds = _dev(fine_grads, "fine_grads"), _dev(sort_inds, "sort_inds", torch.int64)
+    N, T, D = fine_grads.shape
+    out = torch.empty((N, int(c_pnum), D), dtype=torch.float32, device=fine_grads.device)
+    check(lib.nerf_amd_coarse_grad_select(_ptr(fine_grads), _ptr(sort_inds), N, T, D, int(c_pnum), _ptr(out), _stream()), "nerf_amd_coarse_grad_select")
+    return out
 
 
 def merge_depths(z_fine: torch.Tensor, z_coarse: torch.Tensor) -> torch.Tensor:

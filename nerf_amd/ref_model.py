@@ -201,6 +201,8 @@ class RefNeRF(PackedWeightsMixin, NeRF):
     @staticmethod
     def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum: int) -> torch.Tensor:
         """Pick the gradients that belong to the coarse samples after the coarse/fine merge sort (ref_model.py:108-117)."""
+        if fine_grads.is_cuda and not fine_grads.requires_grad:      # one launch (nerf_amd_coarse_grad_select): ranks by ballot, no sort
+            return ops.coarse_grad_select(fine_grads, sort_inds, c_pnum)
         n, total, _ = fine_grads.shape
         sel = torch.cat((torch.zeros((n, total - c_pnum), dtype=torch.bool, device=fine_grads.device),
                          torch.ones((n, c_pnum), dtype=torch.bool, device=fine_grads.device)), dim=-1)

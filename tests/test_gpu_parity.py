@@ -1179,6 +1179,71 @@ def test_merge_depths_equals_sort_of_concatenation(K, C):
     assert torch.equal(ops.merge_depths(a2, b2), want2)
 
 
+@pytest.mark.parametrize("K,C", [(129, 64), (65, 64), (7, 3), (1, 1), (300, 200)])
+def test_coarse_fine_merge_with_order_equals_the_stable_sort(K, C):
+    """coarseFineMerge as the training loop calls it (nerf_base.py:59-73 with f_inds, train.py:176): sorted depths, the sort order and
+    the gathered bin indices from ONE merge kernel equal torch.sort(stable=True) + arange / cat / gather exactly -- ties and
+    out-of-order inputs included (integer work: torch.equal)."""
+    from nerf_amd import ops
+    from nerf_amd.nerf_base import NeRF
+    g = torch.Generator().manual_seed(K * 1000 + C + 1)
+    N = 515
+    a = torch.sort(torch.rand(N, K, generator=g) * 4 + 2, dim=-1)[0]
+    b = torch.sort(torch.rand(N, C, generator=g) * 4 + 2, dim=-1)[0]
+    if K > 2 and C > 2:
+        b[:, 1] = a[:, 2]
+        a[::2, 1] = a[::2, 2]
+        b[::3, C - 1] = b[::3, C - 2]
+        a, b = torch.sort(a, dim=-1)[0], torch.sort(b, dim=-1)[0]
+    if C > 3:                                              # some rays out of order (the rank-sort path keeps the indices with the values)
+        b[::4, 1], b[::4, 2] = b[::4, 2].clone(), b[::4, 1].clone()
+        b[1::7] = b[1::7].flip(-1)
+    if K > 3:
+        a[2::5, 0], a[2::5, K - 1] = a[2::5, K - 1].clone(), a[2::5, 0].clone()
+    f_inds = torch.randint(0, C, (N, K), generator=g)
+    a, b, f_inds = a.cuda(), b.cuda(), f_inds.cuda()
+    wz, wo = torch.sort(torch.cat((a, b), dim=-1), dim=-1, stable=True)
+    wi = torch.gather(torch.cat((f_inds, torch.arange(C, device="cuda").expand(N, -1)), dim=-1), -1, wo)
+    z, order, all_inds = ops.merge_depths_order(a, b, f_inds)
+    assert torch.equal(z, wz[:, :-1]) and torch.equal(order, wo) and torch.equal(all_inds, wi)
+    z2, order2, none = ops.merge_depths_order(a, b)
+    assert none is None and torch.equal(z2, z) and torch.equal(order2, order)
+    rays = torch.cat((torch.zeros(N, 3), torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)), -1).cuda()
+    samples, zz, ai, so = NeRF.coarseFineMerge(rays, b, a, f_inds)
+    assert torch.equal(zz, wz[:, :-1]) and torch.equal(ai, wi) and torch.equal(so, wo[:, :-1])
+    assert torch.equal(samples, ops.length2pts(rays, wz[:, :-1].contiguous()))
+    assert len(NeRF.coarseFineMerge(rays, b, a)) == 2
+
+
+def test_coarse_grad_select_kernel_equals_the_references_mask():
+    """RefNeRF.coarse_grad_select (ref_model.py:108-117) on the device, against the oracle's boolean-mask form on real merge orders, and
+    the rows a boolean mask cannot express (fewer flagged positions than c_pnum: the stable-sort definition)."""
+    from nerf_amd import ops
+    from nerf_amd.ref_model import RefNeRF
+    g = torch.Generator().manual_seed(12)
+    N, K, C = 301, 129, 64
+    a = torch.sort(torch.rand(N, K, generator=g) * 4 + 2, dim=-1)[0]
+    b = torch.sort(torch.rand(N, C, generator=g) * 4 + 2, dim=-1)[0]
+    b[:, -1] = 6.5                                          # the last coarse depth is the largest, as in the training loop: it is the one dropped
+    T = K + C - 1
+    order = torch.sort(torch.cat((a, b), dim=-1), dim=-1, stable=True)[1][:, :-1]
+    grads = torch.randn(N, T, 3, generator=g)
+    want = O.coarse_grad_select(grads, order, C)
+    got = RefNeRF.coarse_grad_select(grads.cuda(), order.cuda(), C)
+    assert got.shape == (N, C, 3) and torch.equal(got.cpu(), want)
+    # fewer flagged positions than asked for: the flagged ones first, then the rest in order
+    si = torch.arange(T).expand(4, -1).clone()
+    si[1] = si[1].flip(-1)
+    si[2, :] = 0
+    si[3, ::2] = T
+    sel = (si >= T - C).to(torch.int8)
+    pos = torch.sort(sel, dim=-1, descending=True, stable=True)[1][:, :C]
+    g4 = torch.randn(4, T, 5, generator=g)
+    want4 = torch.gather(g4, 1, pos[:, :, None].expand(-1, -1, 5))
+    assert torch.equal(ops.coarse_grad_select(g4.cuda(), si.cuda(), C).cpu(), want4)
+    assert ops.coarse_grad_select(g4.cuda()[:0], si.cuda()[:0], C).shape == (0, C, 5)
+
+
 @pytest.mark.parametrize("L,normalize", [(10, False), (4, True)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_encode_rows_matches_positional_encoding(L, normalize, prec):
