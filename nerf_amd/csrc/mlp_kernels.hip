@@ -250,15 +250,18 @@ DEVINL void dump_hidden(const ActDump& d, uint32_t sacc_wave, int layer, int64_t
     }
 }
 DEVINL uint32_t breg_bits(const bf16x8& v) {
+    // per dword: min(element, 1) on both 16-bit halves (a post-ReLU bf16 is +0 or a positive pattern), shifted into place.  The min is
+    // written as asm: from __builtin_elementwise_min on a 2 x u16 vector hipcc builds two 16-bit compares, two selects and a v_perm per
+    // dword (3 100 VALU instructions per tile in the fine training forward, against 1 088 MFMAs) instead of one v_pk_min_u16.
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
     const u32x4 d = __builtin_bit_cast(u32x4, v);
-    const u16x2 one = {1, 1};
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t x = d[i];           // (a scalar copy: __builtin_bit_cast applied to a vector-element expression reads the wrong bytes)
-        m |= __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), one)) << i;
+        const uint32_t x = d[i];
+        uint32_t on;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(x), "v"(0x00010001u));
+        m |= on << i;
     }
     return m;
 }
