@@ -1162,6 +1162,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
 //   wave w = (wo = w >> 1, wi = w & 1): rows = X blocks 2 wo, 2 wo + 1; columns = Y blocks 4 wi .. 4 wi + 3;
 //   it loads / transposes X block w (= 2 wo + wi) and Y block 4 wi + wo.
 // ------------------------------------------------------------------------------------------------
+// -DWGRAD256_PIPELINED=1: the subtile loop software-pipelined (transposition of s + 1 inside the LDS-read latency of s).  Parity-clean,
+// spill-free (230 registers) and measured on one box at EXACTLY the un-pipelined time, with bf16 and with fp8 dumps alike (1.387 / 1.352 ms
+// against 1.364 / 1.369 ms, profiles/r03_wgrad_pipelined_ab.log): the subtile's time is neither its bytes nor the length of one wave's
+// dependent chain -- the workgroup barrier phase-locks all eight waves, so the LDS phase (96-128 KiB per subtile through a 128 B/clk port)
+// and the MFMA phase (2 x 640 cycles per SIMD) of a subtile do not overlap ACROSS waves whatever one wave does inside its own stream.
+#ifndef WGRAD256_PIPELINED
+#define WGRAD256_PIPELINED 0
+#endif
 template <bool F8>
 __global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n_sub) {
     constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1203,7 +1211,67 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n
     auto clamp_s = [&](int64_t s) { return s < s_end ? s : s_end - 1; };
     Stage q0, q1;
     int buf = 0;
-    if (s_begin < s_end) { fetch(s_begin, q0); fetch(clamp_s(s_begin + 1), q1); }
+    if (s_begin < s_end) { fetch(s_begin, q0); if (!WGRAD256_PIPELINED) fetch(clamp_s(s_begin + 1), q1); }
+#if WGRAD256_PIPELINED
+    // Software pipeline over subtiles: the transposition of subtile s + 1 (4 MFMAs, 16 conversions, the bias row sum, 4 ds_write_b128
+    // into the other stage) runs between the barrier of subtile s and its 16 products, i.e. inside the latency of the 12 ds_read_b128 that
+    // fetch s's transposed blocks.  The un-pipelined body ran transposition -> barrier -> LDS reads -> products as one dependent chain in
+    // ALL eight waves at once (the barrier puts both waves of a SIMD in the same phase, so they never filled each other's gaps):
+    // 3 070 cycles per subtile against 1 280 of MFMA work per SIMD.  One barrier per subtile still orders everything: a wave reaches
+    // barrier(s) only after its products of s - 1 (the last reads of stage buf ^ 1) and its writes of s.
+    auto transpose = [&](int64_t s, Stage& cur, int into, bool live) {    // subtile s (held in `cur`) -> stage `into`; refills `cur` with s + 1
+        bf16x8 ox[2], oy[2];
+        if constexpr (F8) { cur.x.decode(2 * xb, ox); cur.y.decode(2 * yb, oy); }
+        else { ox[0] = cur.x[0]; ox[1] = cur.x[1]; oy[0] = cur.y[0]; oy[1] = cur.y[1]; }
+        f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ox[0], idx[0], zero16, 0, 0, 0);
+        f32x16 u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oy[0], idx[0], zero16, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ox[1], idx[1], t, 0, 0, 0);
+        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oy[1], idx[1], u, 0, 0, 0);
+        fetch(clamp_s(s + 1), cur);                                        // ONE staging set (a second costs 16 registers the kernel does not have at two waves per SIMD)
+        if (J.bias_partial != nullptr) {
+            const float r0 = (t[0] + t[1]) + (t[2] + t[3]), r1 = (t[4] + t[5]) + (t[6] + t[7]), r2 = (t[8] + t[9]) + (t[10] + t[11]),
+                        r3 = (t[12] + t[13]) + (t[14] + t[15]);
+            bsum += live ? (r0 + r1) + (r2 + r3) : 0.0f;
+        }
+        const uint32_t st = (uint32_t)into * STAGE + lane * 16;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            *reinterpret_cast<bf16x8*>(smem + st + (2 * xb + hf) * 1024) = cvt8(t, hf);
+            *reinterpret_cast<bf16x8*>(smem + st + (16 + 2 * yb + hf) * 1024) = cvt8(u, hf);
+        }
+    };
+    auto body = [&](int64_t s, Stage& next) {                              // `next` holds subtile s + 1 (requested one iteration ago)
+        __syncthreads();                                                   // stage buf: all sixteen transposed blocks of s; stage buf ^ 1: free
+        const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
+        // local X block a = block xb ^ a; local Y block b = block 4 wi + ((wo + b) & 3).  The two sample halves (hf) are read separately:
+        // half 0 before the transposition (its latency hides there), half 1 after it, when the transposition's accumulators are dead --
+        // all twelve reads up front cost 48 registers next to them and spilled 146
+        bf16x8 xf[2], yf[4], xg[2], yg[4];
+        auto read_half = [&](int hf, bf16x8 (&x)[2], bf16x8 (&y)[4]) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) x[a] = *reinterpret_cast<const bf16x8*>(smem + st + (2 * (xb ^ a) + hf) * 1024);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) y[b] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 2 * (4 * wi + ((wo + b) & 3)) + hf) * 1024);
+        };
+        read_half(0, xf, yf);
+        __builtin_amdgcn_sched_barrier(0);
+        transpose(s + 1, next, buf ^ 1, s + 1 < s_end);                    // (past the end: a harmless repeat of the last subtile into the free stage)
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(1, xg, yg);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xg[a], yg[b], acc[a][b], 0, 0, 0);
+        buf ^= 1;
+    };
+    if (s_begin < s_end) transpose(s_begin, q0, 0, true);
+#pragma unroll 1
+    for (int64_t s = s_begin; s < s_end; ++s) body(s, q0);
+#else
     auto body = [&](int64_t s, Stage& cur) {
         bf16x8 ox[2], oy[2];
         if constexpr (F8) { cur.x.decode(2 * xb, ox); cur.y.decode(2 * yb, oy); }
@@ -1247,6 +1315,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n
         body(s, q0); if (++s >= s_end) break;
         body(s, q1); ++s;
     }
+#endif
     // partial of this workgroup, row-major 256 x 256: local X block a -> block xb ^ a; local Y block b -> block 4 wi + ((wo + b) & 3)
     float* out = J.partial + (size_t)blockIdx.x * 256 * 256;
 #pragma unroll
