@@ -39,3 +39,19 @@ if "cpu" in st:
             d = st[mode][k][0] - st["cpu"][k][0]
             se = math.sqrt(st[mode][k][2] ** 2 + st["cpu"][k][2] ** 2)
             print("gap %s - cpu, %s: %+.2f +- %.2f dB (%.1f sigma)" % (mode, name, d, se, abs(d) / se if se else 0.0))
+# paired comparison on the seeds two modes share (identical initial weights, batches and uniforms per seed): mean of the per-seed differences
+# +- its standard error -- tighter than the independent-sample gap whenever the seed explains part of a run's PSNR
+print()
+modes = [m for m in ("cpu", "fp32", "bf16", "bf16-fp8dumps") if m in res]
+for i, a in enumerate(modes):
+    for b in modes[i + 1:]:
+        common = sorted(set(res[a]) & set(res[b]))
+        if len(common) < 2:
+            continue
+        for k, name in ((0, "held-out"), (1, "train")):
+            m, sd, sem, n = stats([res[b][s][k] - res[a][s][k] for s in common])
+            xs, ys = [res[a][s][k] for s in common], [res[b][s][k] for s in common]
+            mx, my = sum(xs) / n, sum(ys) / n
+            den = math.sqrt(sum((x - mx) ** 2 for x in xs) * sum((y - my) ** 2 for y in ys))
+            corr = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / den if den else 0.0
+            print("paired %s - %s, %s: %+.2f +- %.2f dB over %d common seeds (sd of the differences %.2f, correlation %.2f)" % (b, a, name, m, sem, n, sd, corr))
