@@ -553,6 +553,38 @@ def test_refnerf_ragged_sizes(A, M):
     assert max_abs(got.cpu(), want) <= 2e-5 * max(1.0, want.abs().max().item()) and max_abs(gn.cpu(), wn) <= 2e-5
 
 
+@pytest.mark.parametrize("M", [1, 33, 300, 1000])
+def test_refnerf_backward_ragged_sizes(A, M):
+    """The fused backward chains work on 256-sample tiles of 32-sample subtiles: sample counts that end inside a subtile / a tile.  Every
+    parameter gradient and RefNeRF.get_grad (the density-gradient chain) of the fp32 kernels against fp64 autograd of the oracle's forward
+    (ref_model.py:68-125) on the same points."""
+    from nerf_amd.ref_model import RefNeRF
+    net = build_ref(A, "small")                          # (eval mode: no bottle-neck noise; the training forward runs because gradients are asked for)
+    gen = torch.Generator().manual_seed(500 + M)
+    pts = torch.cat(((torch.rand(M, 1, 3, generator=gen) - 0.5) * 6, torch.nn.functional.normalize(torch.randn(M, 1, 3, generator=gen), dim=-1)), -1)
+    g_rgbo, g_nrm = torch.randn(M, 1, 4, generator=gen), torch.randn(M, 1, 3, generator=gen)
+    A.pkg.set_precision("fp32")
+    pos = dev(pts[..., :3]).contiguous().requires_grad_(True)
+    rgbo, nrm = net.forward(pos, dev(pts[..., 3:]).contiguous())
+    dgrad = RefNeRF.get_grad(rgbo[..., -1], pos)
+    ((rgbo * dev(g_rgbo)).sum() + (nrm * dev(g_nrm)).sum()).backward()
+    sd = {k: v.double().requires_grad_(True) for k, v in W.ref_state("small").items()}
+    p64 = pts[..., :3].double().requires_grad_(True)
+    want, wn = O.ref_forward(sd, torch.cat((p64, pts[..., 3:].double()), -1))
+    dg64, = torch.autograd.grad(want[..., -1].sum(), p64, retain_graph=True)
+    dg64 = dg64 / torch.clamp(dg64.norm(dim=-1, keepdim=True), min=1e-5)
+    ((want * g_rgbo.double()).sum() + (wn * g_nrm.double()).sum()).backward()
+    assert max_abs(rgbo.detach().cpu().double(), want.detach()) <= 2e-5 * max(1.0, want.abs().max().item())
+    assert max_abs(dgrad.cpu().double(), dg64) <= 2e-3
+    worst = {}
+    for name, p in net.named_parameters():
+        ex = sd[name].grad
+        top = max(ex.abs().max().item(), 1e-12)
+        worst[name] = (p.grad.detach().cpu().double() - ex).abs().max().item() / top
+        assert worst[name] <= 2e-3, (M, name, worst[name], top)
+    print("\nRef-NeRF backward, M = %d: worst parameter-gradient error relative to the fp64 value %.1e" % (M, max(worst.values())))
+
+
 def test_render_image_refnerf_vs_reference(A, golden):
     """Drop-in surface with a RefNeRF: the reference's own image (coarse+fine merge, softplus(sigma+.5), normal map)."""
     g = golden("g13_refnerf")
