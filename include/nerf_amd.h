@@ -260,6 +260,17 @@ int nerf_amd_merge_depths_order(const float* z_fine, const float* z_coarse, cons
  * the unflagged ones in order. */
 int nerf_amd_coarse_grad_select(const float* grads, const int64_t* sort_inds, int64_t N, int T, int D, int c_pnum, float* out, void* stream);
 
+/* Ref-NeRF's normal losses (ref_model.py:127-143) as one streaming pass + a fixed-order two-stage sum (deterministic):
+ *   mode 0  WeightedNormalLoss(size_average=False): out[0] = scale * sum_i w_i (1 - <a_i, b_i>)      (a = d_norm, b = p_norm; scale 1, or 1/M for size_average)
+ *   mode 1  BackFaceLoss:                            out[0] = scale * sum_i w_i relu(<a_i, b_i>)      (a = normal, b = ray_d; scale = 1 / M: torch.mean)
+ * w (M), a, b (M,3) fp32 contiguous; workspace: NERF_AMD_DOT_LOSS_WORKSPACE_FLOATS floats.
+ * Backward: g = d loss / d out (ONE float in device memory, so the call needs no synchronisation) -> d_w (M), d_a, d_b (M,3); any of the
+ * three may be NULL. */
+#define NERF_AMD_DOT_LOSS_WORKSPACE_FLOATS 512
+int nerf_amd_weighted_dot_loss(const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* out, float* workspace, void* stream);
+int nerf_amd_weighted_dot_loss_backward(const float* g, const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* d_w,
+                                        float* d_a, float* d_b, void* stream);
+
 /* getBounds (addtional.py:14-18): w_prop (N,C), below (N,K) int64 -> bounds (N,K-1). */
 int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream);
 

@@ -20,6 +20,8 @@ int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
 int sk_merge_sorted(const float*, const float*, int64_t, int, int, float*, hipStream_t);
 int sk_merge_sorted_order(const float*, const float*, const int64_t*, int64_t, int, int, float*, int64_t*, int64_t*, hipStream_t);
 int sk_coarse_grad_select(const float*, const int64_t*, int64_t, int, int, int, float*, hipStream_t);
+int sk_weighted_dot_loss(const float*, const float*, const float*, int64_t, int, float, float*, float*, hipStream_t);
+int sk_weighted_dot_loss_backward(const float*, const float*, const float*, const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_encode_rows(const float*, int, int64_t, int, int, int, void*, hipStream_t);
 int sk_frag_rows_mask_blocks();
 int sk_frag_rows_mask(const void*, int, int64_t, int, int64_t, void*, void*, float*, hipStream_t);
@@ -111,7 +113,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 113; }
+int nerf_amd_version(void) { return 114; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -341,6 +343,19 @@ int nerf_amd_coarse_grad_select(const float* grads, const int64_t* sort_inds, in
     if (N < 0 || T < 1 || D < 1 || c_pnum < 0 || c_pnum > T) return fail(NERF_AMD_EINVAL, "bad size");
     if (N && c_pnum && (!grads || !sort_inds || !out)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_coarse_grad_select(grads, sort_inds, N, T, D, c_pnum, out, S(stream)), "nerf_amd_coarse_grad_select");
+}
+
+int nerf_amd_weighted_dot_loss(const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* out, float* workspace, void* stream) {
+    if (M < 0 || (mode != 0 && mode != 1)) return fail(NERF_AMD_EINVAL, "bad size / mode");
+    if (!out || !workspace || (M && (!w || !a || !b))) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_weighted_dot_loss(w, a, b, M, mode, scale, out, workspace, S(stream)), "nerf_amd_weighted_dot_loss");
+}
+
+int nerf_amd_weighted_dot_loss_backward(const float* g, const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* d_w,
+                                        float* d_a, float* d_b, void* stream) {
+    if (M < 0 || (mode != 0 && mode != 1)) return fail(NERF_AMD_EINVAL, "bad size / mode");
+    if (M && (!g || !w || !a || !b)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_weighted_dot_loss_backward(g, w, a, b, M, mode, scale, d_w, d_a, d_b, S(stream)), "nerf_amd_weighted_dot_loss_backward");
 }
 
 // ---- training forward: the MLP kernels also dump their hidden activations ----

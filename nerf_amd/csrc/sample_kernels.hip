@@ -1267,6 +1267,47 @@ __global__ __launch_bounds__(256) void coarse_grad_select_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------- Ref-NeRF's normal losses (ref_model.py:127-143)
+// WeightedNormalLoss: sum w (1 - <d_norm, p_norm>)  (mode 0);  BackFaceLoss: mean w relu(<normal, ray_d>)  (mode 1; the mean's 1 / M is `scale`).
+// One streaming pass + a fixed-order two-stage sum (block partials, then one block) -- deterministic -- instead of the reference's
+// five element-wise torch launches per loss; the backward is one pass too (a product rule per element).
+constexpr int LOSS_BLOCKS = 256;
+DEVINL float dot_loss_term(float x, int mode) { return mode == 0 ? 1.0f - x : (x > 0.0f ? x : 0.0f); }
+__global__ __launch_bounds__(256) void weighted_dot_loss_kernel(const float* __restrict__ w, const float* __restrict__ a, const float* __restrict__ b, int64_t M,
+                                                                int mode, float* __restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const float x = (a[3 * i] * b[3 * i] + a[3 * i + 1] * b[3 * i + 1]) + a[3 * i + 2] * b[3 * i + 2];
+        acc += (double)(w[i] * dot_loss_term(x, mode));
+    }
+    acc = wave_sum_d(acc);
+    double* red = reinterpret_cast<double*>(smem);
+    if (lane_id() == 0) red[wave_in_block()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<double*>(partial)[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void weighted_dot_loss_final_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += reinterpret_cast<const double*>(partial)[i];
+    acc = wave_sum_d(acc);
+    double* red = reinterpret_cast<double*>(smem);
+    if (lane_id() == 0) red[wave_in_block()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((((red[0] + red[1]) + red[2]) + red[3]) * (double)scale);
+}
+__global__ void weighted_dot_loss_backward_kernel(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ a, const float* __restrict__ b,
+                                                  int64_t M, int mode, float scale, float* __restrict__ d_w, float* __restrict__ d_a, float* __restrict__ d_b) {
+    const float gs = g[0] * scale;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+        const float ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2], bx = b[3 * i], by = b[3 * i + 1], bz = b[3 * i + 2];
+        const float x = (ax * bx + ay * by) + az * bz;
+        if (d_w) d_w[i] = gs * dot_loss_term(x, mode);
+        const float k = gs * w[i] * (mode == 0 ? -1.0f : (x > 0.0f ? 1.0f : 0.0f));      // d term / d x, times the weight
+        if (d_a) { d_a[3 * i] = k * bx; d_a[3 * i + 1] = k * by; d_a[3 * i + 2] = k * bz; }
+        if (d_b) { d_b[3 * i] = k * ax; d_b[3 * i + 1] = k * ay; d_b[3 * i + 2] = k * az; }
+    }
+}
+
 int blocks_for(int64_t work, int per_block) {
     int64_t b = (work + per_block - 1) / per_block;
     const int64_t cap = 256 * 8;
@@ -1484,6 +1525,19 @@ int sk_merge_sorted_order(const float* a, const float* b, const int64_t* f_inds,
 int sk_coarse_grad_select(const float* grads, const int64_t* sort_inds, int64_t N, int T, int D, int c_pnum, float* out, hipStream_t st) {
     if (N == 0 || c_pnum == 0 || D == 0) return 0;
     hipLaunchKernelGGL(coarse_grad_select_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, grads, sort_inds, N, T, D, c_pnum, out);
+    return (int)hipGetLastError();
+}
+int sk_weighted_dot_loss(const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* out, float* workspace, hipStream_t st) {
+    int64_t nb = (M + 255) / 256;
+    const int blocks = (int)(nb > LOSS_BLOCKS ? LOSS_BLOCKS : (nb < 1 ? 1 : nb));
+    hipLaunchKernelGGL(weighted_dot_loss_kernel, dim3(blocks), dim3(256), 64, st, w, a, b, M, mode, workspace);
+    hipLaunchKernelGGL(weighted_dot_loss_final_kernel, dim3(1), dim3(256), 64, st, workspace, blocks, scale, out);
+    return (int)hipGetLastError();
+}
+int sk_weighted_dot_loss_backward(const float* g, const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* d_w, float* d_a,
+                                  float* d_b, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(weighted_dot_loss_backward_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, st, g, w, a, b, M, mode, scale, d_w, d_a, d_b);
     return (int)hipGetLastError();
 }
 int sk_encode_rows(const float* x, int x_stride, int64_t M, int L, int normalize, int elem_bytes, void* out, hipStream_t st) {

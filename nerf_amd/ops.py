@@ -428,6 +428,33 @@ def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum
     return out
 
 
+DOT_LOSS_WORKSPACE_FLOATS = 512
+
+
+def weighted_dot_loss(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mode: int, scale: float) -> torch.Tensor:
+    """scale * sum w f(<a, b>) (f = 1 - x: WeightedNormalLoss, mode 0; relu: BackFaceLoss, mode 1; ref_model.py:127-143) -> 0-dim tensor"""
+    w, a, b = _dev(w, "weight"), _dev(a, "a"), _dev(b, "b")
+    M = w.numel()
+    if a.numel() != 3 * M or b.numel() != 3 * M:
+        raise ValueError("nerf_amd: weighted_dot_loss needs weight (...,) and two (..., 3) tensors of the same leading shape")
+    out = torch.empty((1,), dtype=torch.float32, device=w.device)
+    ws = torch.empty((DOT_LOSS_WORKSPACE_FLOATS,), dtype=torch.float32, device=w.device)
+    check(lib.nerf_amd_weighted_dot_loss(_ptr(w), _ptr(a), _ptr(b), M, int(mode), float(scale), _ptr(out), _ptr(ws), _stream()), "nerf_amd_weighted_dot_loss")
+    return out.reshape(())
+
+
+def weighted_dot_loss_backward(g: torch.Tensor, w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mode: int, scale: float, need=(True, True, True)):
+    """gradients of weighted_dot_loss w.r.t. (w, a, b) for the upstream gradient g (a 0-dim device tensor); `need` picks which are produced"""
+    g, w, a, b = _dev(g, "g").reshape(1), _dev(w, "weight"), _dev(a, "a"), _dev(b, "b")
+    M = w.numel()
+    d_w = torch.empty_like(w) if need[0] else None
+    d_a = torch.empty_like(a) if need[1] else None
+    d_b = torch.empty_like(b) if need[2] else None
+    check(lib.nerf_amd_weighted_dot_loss_backward(_ptr(g), _ptr(w), _ptr(a), _ptr(b), M, int(mode), float(scale), _ptr(d_w), _ptr(d_a), _ptr(d_b), _stream()),
+          "nerf_amd_weighted_dot_loss_backward")
+    return d_w, d_a, d_b
+
+
 def merge_depths(z_fine: torch.Tensor, z_coarse: torch.Tensor) -> torch.Tensor:
     """sort(cat(z_fine, z_coarse))[..., :-1] (the render path of coarseFineMerge): a merge when both sets are ascending, which they
     normally are; rays with an out-of-order input are sorted first."""

@@ -224,6 +224,23 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         return grad / torch.maximum(torch.full_like(grad_norm, 1e-5), grad_norm)
 
 
+def _dot_loss(weight: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mode: int, scale: float, expr) -> torch.Tensor:
+    """scale * sum w f(<a, b>) on the device: one streaming kernel + a fixed-order sum forward, one kernel backward
+    (nerf_amd_weighted_dot_loss[_backward]) instead of five element-wise launches each way; `expr` = the reference's torch expression, the
+    specification (and what CPU tensors -- host-side unit tests -- evaluate)."""
+    if not weight.is_cuda:
+        return expr(weight, a, b)
+    if not ab.needs_grad(weight, a, b):
+        return ops.weighted_dot_loss(weight, a, b, mode, scale)
+    need = (weight.requires_grad, a.requires_grad, b.requires_grad)
+
+    def bwd(g, w_, a_, b_):
+        d_w, d_a, d_b = ops.weighted_dot_loss_backward(g, w_, a_, b_, mode, scale, need)
+        return (d_w.view(w_.shape) if d_w is not None else None, d_a.view(a_.shape) if d_a is not None else None,
+                d_b.view(b_.shape) if d_b is not None else None)
+    return ab.HipOp.apply(lambda w_, a_, b_: ops.weighted_dot_loss(w_, a_, b_, mode, scale), ab.with_hip_backward(expr, bwd), 0, weight, a, b)
+
+
 class WeightedNormalLoss(nn.Module):
     def __init__(self, size_average=False):
         super().__init__()
@@ -231,11 +248,13 @@ class WeightedNormalLoss(nn.Module):
 
     def forward(self, weight: torch.Tensor, d_norm: torch.Tensor, p_norm: torch.Tensor) -> torch.Tensor:
         """sum / mean of w (1 - <n_density, n_pred>)  (ref_model.py:127-135)."""
-        diff = 1. - torch.sum(d_norm * p_norm, dim=-1)
-        return torch.mean(weight * diff) if self.size_average else torch.sum(weight * diff)
+        def expr(w, d, p):
+            diff = 1. - torch.sum(d * p, dim=-1)
+            return torch.mean(w * diff) if self.size_average else torch.sum(w * diff)
+        return _dot_loss(weight, d_norm, p_norm, 0, 1.0 / max(weight.numel(), 1) if self.size_average else 1.0, expr)
 
 
 class BackFaceLoss(nn.Module):
     def forward(self, weight: torch.Tensor, normal: torch.Tensor, ray_d: torch.Tensor) -> torch.Tensor:
         """mean of w relu(<n, d>)  (ref_model.py:137-143)."""
-        return torch.mean(weight * F.relu(torch.sum(normal * ray_d, dim=-1)))
+        return _dot_loss(weight, normal, ray_d, 1, 1.0 / max(weight.numel(), 1), lambda w, n, d: torch.mean(w * F.relu(torch.sum(n * d, dim=-1))))

@@ -1276,6 +1276,37 @@ def test_coarse_grad_select_kernel_equals_the_references_mask():
     assert ops.coarse_grad_select(g4.cuda()[:0], si.cuda()[:0], C).shape == (0, C, 5)
 
 
+def test_refnerf_normal_losses_kernels_equal_the_torch_expressions():
+    """WeightedNormalLoss / BackFaceLoss (ref_model.py:127-143) on the device (nerf_amd_weighted_dot_loss[_backward]): value and the three
+    gradients against the reference's torch expressions evaluated in fp64 (the kernels sum in double, fixed order)."""
+    from nerf_amd.ref_model import BackFaceLoss, WeightedNormalLoss
+    g = torch.Generator().manual_seed(3)
+    for shape in ((1, 1), (37, 5), (512, 192)):
+        w = torch.rand(*shape, generator=g)
+        a = torch.nn.functional.normalize(torch.randn(*shape, 3, generator=g), dim=-1)
+        both = torch.randn(*shape, 6, generator=g)                     # (b is a strided view, like fine_dir in train.py:177)
+        for mod, expr in ((WeightedNormalLoss(), lambda w_, a_, b_: torch.sum(w_ * (1.0 - torch.sum(a_ * b_, dim=-1)))),
+                          (WeightedNormalLoss(size_average=True), lambda w_, a_, b_: torch.mean(w_ * (1.0 - torch.sum(a_ * b_, dim=-1)))),
+                          (BackFaceLoss(), lambda w_, a_, b_: torch.mean(w_ * F.relu(torch.sum(a_ * b_, dim=-1))))):
+            W64, A64, B64 = (t.double().requires_grad_(True) for t in (w, a, both[..., 3:]))
+            want = expr(W64, A64, B64)
+            (want * 1.7).backward()
+            Wd, Ad = w.cuda().requires_grad_(True), a.cuda().requires_grad_(True)
+            Bd = both.cuda().requires_grad_(True)
+            got = mod(Wd, Ad, Bd[..., 3:])
+            (got * 1.7).backward()
+            assert got.shape == () and abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+            for have, ex in ((Wd.grad, W64.grad), (Ad.grad, A64.grad), (Bd.grad[..., 3:], B64.grad)):
+                assert max_abs(have.cpu().double(), ex) <= 2e-6 * max(1e-6, ex.abs().max().item())
+            assert float(Bd.grad[..., :3].abs().max()) == 0.0
+            with torch.no_grad():                                       # no graph: the plain kernel
+                assert abs(mod(Wd, Ad, Bd[..., 3:]).item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+            # only the inputs that ask get a gradient (train.py:187: the coarse normals carry none)
+            Wd2 = w.cuda().requires_grad_(True)
+            mod(Wd2, a.cuda(), both.cuda()[..., 3:]).backward()
+            assert max_abs(Wd2.grad.cpu().double() * 1.7, W64.grad) <= 4e-6 * max(1e-6, W64.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("L,normalize", [(10, False), (4, True)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_encode_rows_matches_positional_encoding(L, normalize, prec):
