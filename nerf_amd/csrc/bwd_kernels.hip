@@ -1553,7 +1553,8 @@ int launch_chain_t(int which, const char* stream, int64_t M, const char* act, ch
     if (n_tiles == 0) return 0;
     const size_t lds = bwd_lds_total<P>();
     const dim3 grid(bwd_grid(n_tiles)), block(P::NW * 64);
-#ifdef CHAIN_PROBE
+#ifdef CHAIN_PROBE                                             // developer switch: compile ONE chain instance (-DCHAIN_PROBE="(kernel<...>)" with
+                                                              // -Rpass-analysis=kernel-resource-usage: seconds instead of minutes per register-pressure experiment)
     if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(CHAIN_PROBE), lds)) return e;
     return 0;
 #else
