@@ -448,6 +448,15 @@ DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 
 #pragma unroll
         for (int t = 0; t < P::NT; ++t) acc1[t] = P::template mma_pos<POS>(a1, b[t], acc1[t]);
         emit_step<NKG, KG>(prev);
+#ifdef MLP_SCHED_GROUPS                                           // A/B experiment: ask the scheduler for an explicit MFMA / LDS / VALU / SALU interleave per K step
+#pragma unroll
+        for (int q = 0; q < 2 * P::NT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MLP_SCHED_GROUPS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+        }
+#endif
         if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
             nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
             nb[1] = load_bias(next_bias + 128);
