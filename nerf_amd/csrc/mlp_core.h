@@ -224,6 +224,14 @@ DEVINL void f8_flush_scales(char* sub_base, int lane, uint32_t scale_rec) {
 #define MLP_TRAIN_SAFE_STREAM 0
 #endif
 
+// -DMLP_LEAN_RING=1 (A/B experiment, round 3): M0 declared clobbered instead of saved / restored around every LDS-DMA piece and the slot
+// counters wrapped with one AND -- 169 of the 1 111 non-MFMA instructions of a 256 x 256 layer's loop gone (4.34 -> 3.68 per MFMA).
+// Parity-clean; same box, alternated three times: fine kernel 53.60 / 53.70 / 53.95 ms against 53.57 / 53.80 / 54.12 ms -- nothing
+// (profiles/r03_lean_ring_ab.log), although an isolated wave pays 8 cycles for every instruction beyond three per MFMA
+// (scripts/mfma_probe.hip).  The chip is at its power limit on this kernel: time follows energy, and SALU instructions carry none.
+#ifndef MLP_LEAN_RING
+#define MLP_LEAN_RING 0
+#endif
 template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false>
 struct WeightStream {
     static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk
@@ -252,7 +260,11 @@ struct WeightStream {
         // does not pad inside inline asm), so it was dropped.)
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-#if !defined(ABL_NOGLDS)
+#if !defined(ABL_NOGLDS) && MLP_LEAN_RING
+            // M0 is declared clobbered instead of saved and restored around every piece (2 of the 5 instructions of a piece): with one wave
+            // per SIMD every instruction beyond ~3 per MFMA costs 8 issue cycles (scripts/mfma_probe.hip)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g + i * 1024), "s"(dst + i * 1024) : "memory", "m0");
+#elif !defined(ABL_NOGLDS)
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
@@ -263,7 +275,8 @@ struct WeightStream {
 #endif
         }
         load_idx = (load_idx + 1 == n_chunks) ? 0u : load_idx + 1;
-        load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
+        if constexpr (MLP_LEAN_RING && (NSLOT & (NSLOT - 1)) == 0) load_slot = (load_slot + 1) & (NSLOT - 1);      // (one SALU instead of add / compare / select)
+        else load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
     }
     // Synchronisation protocol (all code is branch-free; the only conditional instruction is the s_barrier itself):
     //   * chunk boundary i = the moment a wave's register prefetch enters chunk i.  At EVERY boundary a wave waits
@@ -315,7 +328,8 @@ struct WeightStream {
         const typename P::AReg a = q[F % P::DEPTH];
         constexpr int G = F + P::DEPTH;
         if (G % P::FPC == 0) {
-            cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
+            if constexpr (MLP_LEAN_RING && (NSLOT & (NSLOT - 1)) == 0) cur_slot = (cur_slot + 1) & (NSLOT - 1);
+            else cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
             cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
             boundary<(G / P::FPC) & 1>();
         }
