@@ -185,6 +185,25 @@ def gemm_reference(dev):
     return out
 
 
+def mfma_stream_reference(dev, achieved_tflops, executed_tflops):
+    """What a stream of nothing but v_mfma_f32_32x32x16_bf16 (constant operands, one wave per SIMD, every CU) sustains on THIS box under
+    its power limit, measured after the timed region: the attainable ceiling next to the datasheet's 2.5 PFLOP/s."""
+    from nerf_amd import ops
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    ops.mfma_stream(2000, n_cu, dev)
+    torch.cuda.synchronize()
+    iters = 60000                                            # ~60 ms: long enough for the power governor to settle
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    ops.mfma_stream(iters, n_cu, dev)
+    e.record()
+    torch.cuda.synchronize()
+    tf = n_cu * 4 * iters * 64 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
+    return {"tflops": tf, "frac_of_datasheet_peak": tf * 1e12 / PEAK_BF16_DENSE, "kernel_frac_of_this": achieved_tflops / tf,
+            "kernel_executed_frac_of_this": executed_tflops / tf,
+            "note": "MFMA-only stream (nerf_amd_mfma_stream) on this box after the timed region: the power-limited ceiling of the matrix cores"}
+
+
 def train_rate(precision):
     """Second figure of SURVEY 8d: rays/s of a whole training step (train.py:164-199 body + Adam: HIP training forward with activation
     dump, fused dgrad chain, MFMA weight gradients, one-launch Adam -- no library GEMM anywhere) on synthetic rays, measured after the
@@ -606,6 +625,7 @@ def main():
         }
         if world == 1 and not a.no_gemm_ref and prec == ops.BF16:
             rec["roofline"]["gemm_ref"] = gemm_reference(dev)
+            rec["roofline"]["mfma_stream_ref"] = mfma_stream_reference(dev, rec["roofline"]["achieved"], rec["roofline"]["executed_tflops"])
         if world == 1 and not a.no_train_rate and not is_ref:
             rec["train_step"] = train_rate(a.precision)
         if world == 1 and not a.no_cpu_baseline:

@@ -266,6 +266,11 @@ int nerf_amd_coarse_grad_select(const float* grads, const int64_t* sort_inds, in
  * w (M), a, b (M,3) fp32 contiguous; workspace: NERF_AMD_DOT_LOSS_WORKSPACE_FLOATS floats.
  * Backward: g = d loss / d out (ONE float in device memory, so the call needs no synchronisation) -> d_w (M), d_a, d_b (M,3); any of the
  * three may be NULL. */
+/* Measurement aid, no reference counterpart (the roofline's denominator checked on the box): `workgroups` workgroups of four
+ * waves (one per SIMD; 160 KiB of LDS each, so one workgroup per CU) issue iters * 64 v_mfma_f32_32x32x16_bf16 per wave on constant
+ * operands and nothing else; timed by the caller, 32 768 flop per MFMA and wave.  sink: 256 floats (never written in practice). */
+int nerf_amd_mfma_stream(int iters, int workgroups, float* sink, void* stream);
+
 #define NERF_AMD_DOT_LOSS_WORKSPACE_FLOATS 512
 int nerf_amd_weighted_dot_loss(const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* out, float* workspace, void* stream);
 int nerf_amd_weighted_dot_loss_backward(const float* g, const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* d_w,

@@ -259,3 +259,36 @@ int pack_ref_bwd(int precision, const float* const* w, void* packed, hipStream_t
     C.L[9] = make_trans_layer(w[0], 63, 0, 63, 256, 16, 2, Lay::START[27]);                         // spa_block1.0
     return launch_pack(C, 10, precision, reinterpret_cast<char*>(packed), nullptr, st);
 }
+
+// ------------------------------------------------------------------------------------------------ measurement aid (bench.py roofline.mfma_stream_ref)
+// A stream of nothing but v_mfma_f32_32x32x16_bf16 on four independent accumulators and constant operands, one wave per SIMD (160 KiB of
+// LDS per workgroup keeps everything else off the CU): what the matrix cores of THIS box sustain under its power limit -- the measured
+// ceiling next to the datasheet peak (scripts/mfma_probe.hip is the stand-alone, more detailed form).  64 MFMAs per iteration and wave.
+namespace {
+typedef __attribute__((ext_vector_type(16))) float pk_f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t pk_u32x4;
+__global__ __launch_bounds__(256) void mfma_stream_kernel(int iters, float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    pk_f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
+    pk_u32x4 a = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}, b = a;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b));
+        }
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += (acc0[i] + acc1[i]) + (acc2[i] + acc3[i]);
+    if (r == 123.456f) sink[threadIdx.x] = r;
+}
+}  // namespace
+int pack_mfma_stream(int iters, int workgroups, float* sink, hipStream_t st) {
+    const size_t lds = 160 * 1024;
+    if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+    hipLaunchKernelGGL(mfma_stream_kernel, dim3(workgroups), dim3(256), lds, st, iters, sink);
+    return (int)hipGetLastError();
+}

@@ -428,6 +428,12 @@ def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum
     return out
 
 
+def mfma_stream(iters: int, workgroups: int, device) -> None:
+    """launch the MFMA-only stream (bench.py's measured ceiling): iters * 64 MFMAs of 32 768 flop per wave, 4 waves per workgroup"""
+    sink = torch.zeros((256,), dtype=torch.float32, device=device)
+    check(lib.nerf_amd_mfma_stream(int(iters), int(workgroups), _ptr(sink), _stream()), "nerf_amd_mfma_stream")
+
+
 DOT_LOSS_WORKSPACE_FLOATS = 512
 
 
