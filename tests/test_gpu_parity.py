@@ -1276,6 +1276,26 @@ def test_coarse_grad_select_kernel_equals_the_references_mask():
     assert ops.coarse_grad_select(g4.cuda()[:0], si.cuda()[:0], C).shape == (0, C, 5)
 
 
+def test_mfma_stream_measurement_aid_runs():
+    """nerf_amd_mfma_stream (bench.py roofline.mfma_stream_ref): launches, completes, and sustains a rate in the range of a matrix-core
+    stream (sanity bounds only: the number is a measurement, not a contract)."""
+    from nerf_amd import ops
+    dev = torch.device("cuda")
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    ops.mfma_stream(200, n_cu, dev)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    ops.mfma_stream(5000, n_cu, dev)
+    e.record()
+    torch.cuda.synchronize()
+    tf = n_cu * 4 * 5000 * 64 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
+    print("\nMFMA-only stream: %.0f TFLOP/s on %d CUs" % (tf, n_cu))
+    assert 500.0 < tf < 2600.0
+    with pytest.raises(RuntimeError):
+        ops.mfma_stream(10, 0, dev)
+
+
 def test_refnerf_normal_losses_kernels_equal_the_torch_expressions():
     """WeightedNormalLoss / BackFaceLoss (ref_model.py:127-143) on the device (nerf_amd_weighted_dot_loss[_backward]): value and the three
     gradients against the reference's torch expressions evaluated in fp64 (the kernels sum in double, fixed order)."""
