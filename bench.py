@@ -6,8 +6,9 @@ ray generation -> stratified sampling -> proposal MLP -> sigma->weights -> max-b
 sampling (sorted) -> fine MLP -> alpha compositing (rgb, depth, weights written), i.e. SURVEY.md section 8a
 rows 1-10 -- BASELINE configs[1] ("Original NeRF, Lego 800x800, 64+128 samples, bf16, 1xMI355X").
 Synthetic inputs (no dataset on the box): orbit pose pose_spherical(theta,-30,4), Lego's camera_angle_x,
-near/far 2/6, white background, closed-form deterministic network weights, uniforms pre-generated and
-RESIDENT IN HBM before the timed region.
+near/far 2/6, white background, closed-form deterministic network weights; every uniform (stratified jitter, inverse-CDF
+draws) is drawn INSIDE the kernels with Philox4x32-10 (the default, what the drop-in render_image does), or -- `--rng resident` --
+pre-generated and resident in HBM before the timed region.
 
 N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL); every rank renders its own image
 per step (weak scaling, rays are independent: no data-path collective); value = total rays / max-over-ranks time.
@@ -18,11 +19,18 @@ WORLD_SIZE == N, and with the nccl backend that the box has N devices -- it neve
 --mode train-ddp: one step = every rank's 16 384-ray training step (train.py:164-199 body) + ONE flat all_reduce of the
 744 069 gradient elements of both networks (ddp_train.py:98) + Adam; the collective is timed separately (bytes, us).
 
+An N > 1 line is self-contained: besides the max-over-ranks `value` it carries every rank's own ms_per_step (min / max / list), what an
+MFMA-only stream sustains on EVERY rank's GPU while all of them run it at once (`roofline.mfma_stream_ref`: eight GPUs share a chassis
+power budget, so the clocks differ from a one-GPU box), and -- measured by rank 0 after the timed region while the other ranks wait at a
+host-side (gloo) barrier -- `cpu_baseline`, `train_step` and `roofline.gemm_ref` exactly as in the N = 1 line.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import datetime
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -70,6 +78,7 @@ def parse():
     p.add_argument("--train-dumps", default="bf16", choices=["bf16", "fp8"],
                    help="storage of the training dumps in bf16 mode: bf16, or e4m3 with per-sample-and-K-group scales (nerf_amd.set_train_dumps)")
     p.add_argument("--train-rays", type=int, default=16384, help="rays per rank and step in --mode train-ddp")
+    p.add_argument("--dump-image", default=None, help="render-strong: rank 0 saves the last timed image (N,4) to this path (N-independence tests)")
     p.add_argument("--launch-check", action="store_true",
                    help="control-flow check of the N-rank launch path only (rendezvous, world size, barrier, max-over-ranks): no GPU work")
     return p.parse_args()
@@ -116,6 +125,94 @@ def launch_check(a, world, rank):
         print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(t.item())}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+class Comm:
+    """The bench's view of the process group: the data-path backend (nccl = RCCL; gloo only to smoke-test the N > 1 control flow on a
+    one-GPU box) for the timed region's barriers, and a host-side gloo group for everything after it -- per-rank statistics, and the
+    barrier the other ranks wait at while rank 0 measures the CPU baseline (a wait on the host: their GPUs stay idle instead of spinning
+    in a collective kernel)."""
+
+    def __init__(self, dist, world, rank, backend, dev):
+        self.dist, self.world, self.rank, self.backend, self.dev = dist, world, rank, backend, dev
+        self.ctl = None
+        if dist is not None and backend != "gloo":
+            self.ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=60))
+
+    def sync(self):
+        """the contract's bracket of the timed region: barrier over the data-path backend + device synchronisation"""
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(group=self.ctl)
+
+    def max_over_ranks(self, dt: float) -> float:
+        if self.dist is None:
+            return dt
+        t = torch.tensor([dt], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        """-> [rank 0's obj, rank 1's obj, ...] on every rank"""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.ctl)
+        return out
+
+    def finish(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+def rank_spread(comm, local_dt, steps):
+    ms = comm.gather(local_dt / steps * 1e3)
+    return {"min": min(ms), "max": max(ms), "all": ms,
+            "note": "every rank's own wall time per step between the barriers of the timed region; `ms_per_step` / `value` use the max"}
+
+
+def cpu_baseline_train(n_rays: int = 512, steps: int = 3):
+    """The reference's training step on the host cores (the oracle's restatement of train.py:164-199 under torch autograd + torch.optim.Adam,
+    fp32), `steps` steps of `n_rays` rays at 64 + 128 samples after one warm-up step."""
+    import torch.nn.functional as F
+    import weights as Wt
+    from oracle import nerf_oracle as O
+    torch.manual_seed(0)
+    prop = {k: v.clone().requires_grad_(True) for k, v in Wt.proposal_state("small").items()}
+    mip = {k: v.clone().requires_grad_(True) for k, v in Wt.mip_state("small").items()}
+    opt = torch.optim.Adam(list(mip.values()) + list(prop.values()), lr=1e-4)
+    d = F.normalize(torch.randn(n_rays, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1)
+    rays = torch.cat((torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3), d), -1)
+    tgt = torch.rand(n_rays, 3)
+    res = (FAR - NEAR) / C_COARSE
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+
+    def one():
+        z_c = torch.linspace(NEAR, FAR - res, C_COARSE) + torch.rand((n_rays, C_COARSE)) * res
+        pts = rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]
+        pw = O.max_blur(O.sigma_to_weights(F.softplus(O.proposal_forward(prop, pts)), z_c, rays[:, 3:]), 0.01)
+        z_f, below = O.inverse_sample(pw, z_c, torch.rand((n_rays, N_FINE + 1)), sort=True)
+        z_f = z_f[..., :-1]
+        rend, wts, _ = O.composite(O.mip_forward(mip, O.length2pts(rays, z_f)), z_f, rays[:, 3:], white_bkg=True)
+        loss = O.proposal_loss(O.get_bounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": steps * n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "%d training steps of %d rays (64+128 samples; oracle forward, torch autograd backward, torch.optim.Adam), torch CPU fp32, %d threads on a %d-CPU host, %.1f s"
+                      % (steps, n_rays, cores, os.cpu_count() or 1, dt)}
 
 
 def cpu_baseline(n_rays: int):
@@ -185,46 +282,136 @@ def gemm_reference(dev):
     return out
 
 
-def mfma_stream_reference(dev, achieved_tflops, executed_tflops):
-    """What a stream of nothing but v_mfma_f32_32x32x16_bf16 (constant operands, one wave per SIMD, every CU) sustains on THIS box under
-    its power limit, measured after the timed region: the attainable ceiling next to the datasheet's 2.5 PFLOP/s."""
+MFMA_STREAM_MODES = (("constant_operands", 0), ("random_operands", 1), ("weights_x_relu_activations", 2), ("weights_x_relu_activations_a_from_lds", 3))
+
+
+def mfma_stream_measure(dev):
+    """What streams of nothing but v_mfma_f32_32x32x16_bf16 (one wave per SIMD, every CU) sustain on THIS GPU under its power limit, measured
+    after the timed region: with constant operands (the datapath does not toggle: an optimistic ceiling), with
+    operands that change on every MFMA (pseudo-random bf16: pessimistic), with network-like data (random weights x post-ReLU-like
+    activations, half zeros) and with that data arriving through the weight ring's ds_read_b128 cadence.  TFLOP/s per mode."""
     from nerf_amd import ops
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    ops.mfma_stream(2000, n_cu, dev)
-    torch.cuda.synchronize()
-    iters = 60000                                            # ~60 ms: long enough for the power governor to settle
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    ops.mfma_stream(iters, n_cu, dev)
-    e.record()
-    torch.cuda.synchronize()
-    tf = n_cu * 4 * iters * 64 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
+    out = {}
+    for name, mode in MFMA_STREAM_MODES:
+        ops.mfma_stream(2000, n_cu, dev, mode)
+        torch.cuda.synchronize()
+        iters = 40000                                        # ~40 ms: long enough for the power governor to settle
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        ops.mfma_stream(iters, n_cu, dev, mode)
+        e.record()
+        torch.cuda.synchronize()
+        out[name] = n_cu * 4 * iters * 64 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
+    return out
+
+
+def mfma_stream_reference(comm, dev, achieved_tflops, executed_tflops):
+    """roofline.mfma_stream_ref: every rank measures its own GPU AT THE SAME TIME (the GPUs of a node share a chassis power budget), rank 0
+    reports its own figures in the keys of the one-GPU line and every rank's in `per_rank`."""
+    comm.barrier()
+    mine = mfma_stream_measure(dev)
+    per_rank = comm.gather(mine)
+    if comm.rank != 0:
+        return None
+    tf, tf_data = mine["constant_operands"], mine["weights_x_relu_activations"]
     return {"tflops": tf, "frac_of_datasheet_peak": tf * 1e12 / PEAK_BF16_DENSE, "kernel_frac_of_this": achieved_tflops / tf,
             "kernel_executed_frac_of_this": executed_tflops / tf,
-            "note": "MFMA-only stream (nerf_amd_mfma_stream) on this box after the timed region: the power-limited ceiling of the matrix cores"}
+            "data_realistic_tflops": tf_data, "data_realistic_frac_of_datasheet_peak": tf_data * 1e12 / PEAK_BF16_DENSE,
+            "kernel_frac_of_data_realistic": achieved_tflops / tf_data, "kernel_executed_frac_of_data_realistic": executed_tflops / tf_data,
+            "streams_tflops": mine, "per_rank": per_rank,
+            "note": "MFMA-only streams (nerf_amd_mfma_stream, modes 0-3) on this box after the timed region, all ranks at once: `tflops` = constant "
+                    "operands (optimistic: nothing toggles), `data_realistic_tflops` = pseudo-random weights x post-ReLU-like activations "
+                    "(the ceiling a kernel multiplying real data can be held against); 64 MFMAs per iteration and wave, 40 ms per stream"}
+
+
+def _spread(xs):
+    xs = sorted(xs)
+    return {"min": xs[0], "median": statistics.median(xs), "max": xs[-1], "n": len(xs)}
+
+
+def timed_steps(step, iters, warm):
+    """Run `step` warm + iters times without a host synchronisation in between and time it three ways:
+      wall  total host time / iters between two device synchronisations (what a training loop sees);
+      gpu   per-iteration time between HIP events recorded on the compute stream at the iteration boundaries (min / median / max:
+            an outlier iteration -- an allocation, a clock dip -- is visible instead of averaged in);
+      alloc what torch's caching allocator did meanwhile (hipMalloc'ed segments, retries), and the library's persistent buffers.
+    wall - gpu median = host-side cost the device does not hide; gpu max - min = jitter."""
+    from nerf_amd import ops
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats()
+    ar0 = dict(ops.ARENA_STATS)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(iters):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    st1 = torch.cuda.memory_stats()
+    gpu = [evs[i].elapsed_time(evs[i + 1]) for i in range(iters)]
+    alloc = {"hipMalloc_segments": st1.get("segment.all.allocated", 0) - st0.get("segment.all.allocated", 0),
+             "block_allocations": st1.get("allocation.all.allocated", 0) - st0.get("allocation.all.allocated", 0),
+             "alloc_retries": st1.get("num_alloc_retries", 0) - st0.get("num_alloc_retries", 0),
+             "reserved_gb": st1.get("reserved_bytes.all.current", 0) / 1e9,
+             "persistent_buffer_uses": ops.ARENA_STATS["persistent"] - ar0["persistent"], "fresh_buffer_uses": ops.ARENA_STATS["fresh"] - ar0["fresh"]}
+    return wall, gpu, alloc
+
+
+def kernel_sum_ms(step):
+    """Sum of the device kernels' own durations over ONE iteration (torch.profiler's kernel records, i.e. roctracer inside the process --
+    no rocprof around it): what the step costs with every launch gap removed.  None when the profiler is unavailable on the box."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        step()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            step()
+            torch.cuda.synchronize()
+        tot, n = 0.0, 0
+        for ev in prof.events():
+            if str(getattr(ev, "device_type", "")).endswith("CUDA") and getattr(ev, "device_time_total", 0) > 0:
+                tot += ev.device_time_total
+                n += 1
+        return {"ms": tot / 1e3, "kernels": n} if n else None
+    except Exception as ex:                                   # noqa: BLE001  (a measurement aid must not take the bench line down)
+        return {"ms": None, "error": repr(ex)[:200]}
 
 
 def train_rate(precision):
     """Second figure of SURVEY 8d: rays/s of a whole training step (train.py:164-199 body + Adam: HIP training forward with activation
     dump, fused dgrad chain, MFMA weight gradients, one-launch Adam -- no library GEMM anywhere) on synthetic rays, measured after the
     timed region; never part of `value`.  Its roofline: 3 x the forward's algorithmic flops (forward + dgrad + wgrad) against the dense
-    bf16 MFMA peak; the step is HBM-bound by design (activation dump written once, read twice: DESIGN.md section 5)."""
+    bf16 MFMA peak.  Every figure is the MEDIAN of >= 30 iterations with its min / max, host wall clock beside the device time, and the
+    allocator's activity -- round 3's line was one mean of ten iterations and hid a 4 ms gap between the driver's box and the kernels' sum."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpu_train_rate", os.path.join(ROOT, "scripts", "gpu_train_rate.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    out = {"unit": "rays/s (fwd + bwd + Adam step, 64+128 samples)", "precision": precision}
+    out = {"unit": "rays/s (fwd + bwd + Adam step, 64+128 samples)", "precision": precision,
+           "timing": "median of the per-iteration HIP-event times of a free-running loop (no host synchronisation inside); wall = host clock over the same loop"}
     peak = PEAK_BF16_DENSE if precision == "bf16" else PEAK_F32_MFMA
-    for n in (512, 4096, 16384):
-        dt = mod.run(n, 64, 128, precision, iters=10, warm=3, quiet=True)
-        out["rays_%d" % n] = {"rays_per_s": n / dt, "ms_per_iter": dt * 1e3}
-    dt = mod.run(512, 64, 128, precision, iters=30, warm=5, quiet=True, graph=True)
-    out["rays_512_hipgraph"] = {"rays_per_s": 512 / dt, "ms_per_iter": dt * 1e3}
+
+    def entry(n, step, iters, warm, profile_kernels=False):
+        wall, gpu, alloc = timed_steps(step, iters, warm)
+        sp = _spread(gpu)
+        e = {"rays_per_s": n / (sp["median"] * 1e-3), "ms_per_iter": sp["median"], "ms_min": sp["min"], "ms_max": sp["max"], "iters": iters,
+             "wall_ms_per_iter": wall * 1e3, "allocator": alloc}
+        if profile_kernels:
+            e["kernel_sum"] = kernel_sum_ms(step)
+        return e
+
+    for n, iters in ((512, 60), (4096, 40), (16384, 30)):
+        out["rays_%d" % n] = entry(n, mod.make_step(n, 64, 128, precision), iters, 5, profile_kernels=(n == 16384))
+    out["rays_512_hipgraph"] = entry(512, mod.make_step(512, 64, 128, precision, graph=True), 100, 5)
     best = out["rays_16384"]["rays_per_s"]
     out["roofline"] = {"bound": "mfma", "kernel": "whole training step, 16384 rays (3 x 162.4 MFLOP/ray)", "achieved": best * 3 * FLOP_PER_RAY / 1e12,
                        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": best * 3 * FLOP_PER_RAY / peak, "traffic": None}
-    # the step is HBM-bound by its dumps (DESIGN.md section 3.6): measured traffic of one step from the committed PMC passes, and the
-    # bandwidth it implies at this run's step time, next to the algorithmic floor (2 KiB per sample and hidden layer)
+    # measured traffic of one step from the committed PMC passes, and the bandwidth it implies at this run's step time, next to the
+    # algorithmic floor of the dump design (2 KiB per sample and hidden layer; DESIGN.md section 3.6)
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     step_bytes = json.load(open(tfile)).get("train_step_16384_%s" % precision) if os.path.exists(tfile) else None
     floor_bytes = 16384 * (N_FINE * 8 + C_COARSE * 4) * 2048.0
@@ -233,8 +420,13 @@ def train_rate(precision):
                               "achieved_tbps": (step_bytes * best / 16384 / 1e12) if step_bytes else None,
                               "algorithmic_tbps": floor_bytes * best / 16384 / 1e12}
     out["iteration_512"] = iteration_rate(precision)
-    dt = mod.run_ref(512, 64, 128, precision, iters=10, warm=3, quiet=True)
-    out["refnerf_rays_512"] = {"rays_per_s": 512 / dt, "ms_per_iter": dt * 1e3, "note": "Ref-NeRF step with prop_normal (train.py:176-187)"}
+    # Ref-NeRF (BASELINE configs[3]) with prop_normal: the reference's batch and the paper's 2^14-ray batch, 64 + (128 + 64 merged) samples
+    ref_flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
+    for n, iters in ((512, 40), (16384, 10)):
+        e = entry(n, mod.make_ref_step(n, 64, 128, precision), iters, 3)
+        e["roofline_frac"] = e["rays_per_s"] * 3 * ref_flop_per_ray / peak
+        e["note"] = "Ref-NeRF step with prop_normal (train.py:176-187); roofline_frac = 3 x %.1f MFLOP/ray (forward + dgrad + wgrad; the two density-gradient chains not counted) / MFMA peak" % (ref_flop_per_ray / 1e6)
+        out["refnerf_rays_%d" % n] = e
     import nerf_amd
     nerf_amd.set_precision(precision)
     return out
@@ -281,7 +473,7 @@ def iteration_rate(precision, n_rays=512, iters=200):
     return out
 
 
-def train_ddp(a, dist, world, rank, dev, backend):
+def train_ddp(a, comm):
     """--mode train-ddp: what ddp_train.py's inner loop does per iteration (ddp_train.py:66-68,98: forward, backward, gradient
     all-reduce, optimizer step), one rank per GPU, `--train-rays` rays per rank (weak scaling).  The gradients of BOTH networks live in
     one persistent flat buffer the weight-gradient kernels write into (nerf_amd.parallel.FlatGradients); the ONE all_reduce over it is
@@ -292,6 +484,7 @@ def train_ddp(a, dist, world, rank, dev, backend):
     import nerf_amd
     from nerf_amd import ops, parallel
     from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    dist, world, rank, dev, backend = comm.dist, comm.world, comm.rank, comm.dev, comm.backend
     from nerf_amd.mip_methods import maxBlurFilter
     from nerf_amd.mip_model import MipNeRF
     from nerf_amd.nerf_base import NeRF
@@ -348,11 +541,6 @@ def train_ddp(a, dist, world, rank, dev, backend):
         opt.step()
         ops.advance_seed(seed_dev)
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     graph = None
     for _ in range(max(a.warmup, 2 if a.hipgraph else 0)):
         step()
@@ -363,43 +551,53 @@ def train_ddp(a, dist, world, rank, dev, backend):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dist is not None else {})):
             step()
-    sync()
+    comm.sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         if graph is not None:
             graph.replay()
         else:
             step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    comm.sync()
+    local_dt = time.perf_counter() - t0
+    dt = comm.max_over_ranks(local_dt)
+    spread = rank_spread(comm, local_dt, a.steps)
+    ar_ms = [s_.elapsed_time(e_) for s_, e_ in ev] if graph is None else None
+    ar_ranks = comm.gather((sum(ar_ms) / a.steps * 1e3) if ar_ms else None)
+    flop_per_ray = 3 * FLOP_PER_RAY                                      # forward + dgrad + wgrad
+    achieved = a.steps * n_rays * flop_per_ray / dt / 1e12               # per GPU
+    rec = None
     if rank == 0:
-        ar_us = (sum(s.elapsed_time(e) for s, e in ev) / a.steps * 1e3) if (dist is not None and graph is None) else None
-        flop_per_ray = 3 * FLOP_PER_RAY                                  # forward + dgrad + wgrad
         variant = ("Mip-NeRF + integrated PE (BASELINE configs[2])" if a.ipe else "NeRF / Mip-NeRF point PE") + (", scene contraction, near/far 0.2/30 (configs[4])" if a.contract else "")
         rec = {"metric": "training rays/s (64+128 samples, fwd + bwd + gradient all_reduce + Adam)", "value": world * a.steps * n_rays / dt,
                "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+               "ms_per_step_ranks": spread,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
                "data": "synthetic",
                "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, MipNeRF(10,4,256) + ProposalNetwork(10,256); %s%s"
                                       % (n_rays, variant, ("; step replayed from a hipGraph (collective inside)" if graph is not None else "") +
                                          ("; training dumps in scaled e4m3" if a.train_dumps == "fp8" else "")),
                           "rays_per_step_per_gpu": n_rays, "parallelism": "ray-sharded replicas (dp%d), one flat gradient all_reduce per step" % world},
-               "allreduce": {"elements": n_grad, "bytes": 4 * n_grad, "us_per_step": ar_us, "backend": backend if dist is not None else None,
+               "allreduce": {"elements": n_grad, "bytes": 4 * n_grad,
+                             "us_per_step": ar_ranks[0] if dist is not None else None, "us_per_step_ranks": ar_ranks if dist is not None else None,
+                             "backend": backend if dist is not None else None,
                              "note": "ONE all_reduce(AVG) on the persistent flat gradient buffer the weight-gradient kernels write into "
-                                     "(nerf_amd/parallel.py FlatGradients; no cat / copy-back); HIP events on the compute stream"},
-               "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flops)", "achieved": world * a.steps * n_rays * flop_per_ray / dt / 1e12 / world,
-                            "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s", "frac": a.steps * n_rays * flop_per_ray / dt / PEAK_BF16_DENSE, "traffic": None}}
+                                     "(nerf_amd/parallel.py FlatGradients; no cat / copy-back); HIP events on the compute stream around the call: it includes "
+                                     "the wait for the slowest rank's backward (null when the step is replayed from a hipGraph or runs without a process group)"},
+               "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward flops)", "achieved": achieved,
+                            "peak": PEAK_BF16_DENSE / 1e12, "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": None}}
+    if a.precision == "bf16" and not a.no_gemm_ref:
+        ref = mfma_stream_reference(comm, dev, achieved, achieved)
+        if rank == 0:
+            rec["roofline"]["mfma_stream_ref"] = ref
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline_train()
         print(json.dumps(rec), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.finish()
 
 
-def render_strong(a, dist, world, rank, dev, backend):
+def render_strong(a, comm):
     """--mode render-strong: ONE 800x800 image per step, its 640 000 rays split into `world` contiguous shards (no collective on
     the data path), every uniform drawn in-kernel as a function of the GLOBAL ray index -- so the image does not depend on N -- and one
     all_gather of rgb + depth (16 B/ray) at the end of the step.  value = image rays / max-over-ranks time; "scaling": "strong"."""
@@ -408,6 +606,7 @@ def render_strong(a, dist, world, rank, dev, backend):
     from nerf_amd.addtional import ProposalNetwork
     from nerf_amd.mip_model import MipNeRF
     from nerf_amd.utils import fov2Focal, pose_spherical
+    dist, world, rank, dev, backend = comm.dist, comm.world, comm.rank, comm.dev, comm.backend
     prec = ops.BF16 if a.precision == "bf16" else ops.F32
     prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
     prop.load_state_dict(Wt.proposal_state("small")); mip.load_state_dict(Wt.mip_state("small"))
@@ -430,35 +629,42 @@ def render_strong(a, dist, world, rank, dev, backend):
         out = torch.cat((rgb, depth[:, None]), -1)
         return parallel.gather_shards(out, n, 256) if dist is not None else out
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i)
-    sync()
+    comm.sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         img = step(a.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    comm.sync()
+    local_dt = time.perf_counter() - t0
+    dt = comm.max_over_ranks(local_dt)
+    spread = rank_spread(comm, local_dt, a.steps)
     assert img.shape == (n, 4) and bool(torch.isfinite(img).all())
+    if a.dump_image and rank == 0:                          # the LAST timed image (every rank holds the same one): N-independence checks
+        torch.save(img.cpu(), a.dump_image)
+    achieved = a.steps * n * FLOP_PER_RAY / dt / 1e12 / world          # per GPU
+    rec = None
     if rank == 0:
-        print(json.dumps({"metric": "rays/s (64+128 samples), 800x800, one image split over the ranks", "value": a.steps * n / dt, "unit": "rays/s", "n_gpus": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-                          "vs_baseline": None, "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic",
-                          "config": {"workload": "BASELINE configs[1] image (800x800, 64+128 samples, rows 1-10) rendered ONCE per step by all ranks together: "
-                                                 "contiguous 256-aligned ray shards, in-kernel Philox uniforms keyed by the global ray index, one all_gather of "
-                                                 "rgb + depth (16 B/ray) per image", "rays_per_step": n, "parallelism": "ray-sharded (dp%d), strong scaling" % world},
-                          "gather": {"bytes_per_image": 16 * n, "backend": backend if dist is not None else None},
-                          "whole_path_tflops": a.steps * n * FLOP_PER_RAY / dt / 1e12}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        rec = {"metric": "rays/s (64+128 samples), 800x800, one image split over the ranks", "value": a.steps * n / dt, "unit": "rays/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_ranks": spread, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1] image (800x800, 64+128 samples, rows 1-10) rendered ONCE per step by all ranks together: "
+                                      "contiguous 256-aligned ray shards, in-kernel Philox uniforms keyed by the global ray index, one all_gather of "
+                                      "rgb + depth (16 B/ray) per image", "rays_per_step": n, "parallelism": "ray-sharded (dp%d), strong scaling" % world},
+               "gather": {"bytes_per_image": 16 * n, "backend": backend if dist is not None else None},
+               "roofline": {"bound": "mfma", "kernel": "whole render path (proposal + fine MLP flops of this rank's shard) over the step's wall time, gather included",
+                            "achieved": achieved, "peak": (PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA) / 1e12, "unit": "TFLOP/s",
+                            "frac": achieved * 1e12 / (PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA), "traffic": None},
+               "whole_path_tflops": a.steps * n * FLOP_PER_RAY / dt / 1e12}
+    if prec == ops.BF16 and not a.no_gemm_ref:
+        ref = mfma_stream_reference(comm, dev, achieved, achieved)
+        if rank == 0:
+            rec["roofline"]["mfma_stream_ref"] = ref
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
+        print(json.dumps(rec), flush=True)
+    comm.finish()
 
 
 def main():
@@ -478,18 +684,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local % n_dev)
+        long_wait = datetime.timedelta(minutes=60)              # (rank 0 measures the CPU baseline / training rates while the others wait)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % n_dev))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % n_dev), timeout=long_wait)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=long_wait)
         assert dist.get_world_size() == a.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    comm = Comm(dist, world, rank, backend, dev)
     if a.mode == "train-ddp":
-        return train_ddp(a, dist, world, rank, dev, backend)
+        return train_ddp(a, comm)
     if a.mode == "render-strong":
-        return render_strong(a, dist, world, rank, dev, backend)
+        return render_strong(a, comm)
 
     import weights as Wt
     from nerf_amd import ops
@@ -566,46 +774,41 @@ def main():
             ev[timed_idx][1].record()
         return rgb, depth, w
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(a.warmup):
         step(i)
-    sync()
+    comm.sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         out = step(a.warmup + i, i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    comm.sync()
+    local_dt = time.perf_counter() - t0
+    dt = comm.max_over_ranks(local_dt)
+    spread = rank_spread(comm, local_dt, a.steps)
     assert os.environ.get("NERF_AMD_LIB") or bool(torch.isfinite(out[0]).all())     # (ablation builds compute garbage)
 
+    fine_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+    fine_ms_ranks = comm.gather(fine_ms)
+    fine_flops = n_rays * N_FINE * 2 * MAC_FINE
+    kernel_name = "mip_kernel (fine MLP, 527872 MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)" + (" + fused compositing epilogue" if a.fused else "")
+    flop_per_ray = FLOP_PER_RAY
+    if is_ref:
+        fine_flops = n_rays * (N_FINE + C_COARSE) * 2 * 1_071_616
+        kernel_name = "ref_kernel (Ref-NeRF spatial + directional MLP, 1071616 MAC/sample, 192 merged samples/ray)"
+        flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
+    peak = PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA
+    executed_flops = n_rays * ((N_FINE + C_COARSE) * 2 * 2128 * 512 if is_ref else N_FINE * 2 * 928 * 512)   # mlp_layout.h N_FRAGS
+    achieved = fine_flops / (fine_ms * 1e-3)
+    rec = None
     if rank == 0:
-        fine_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
-        fine_flops = n_rays * N_FINE * 2 * MAC_FINE
-        kernel_name = "mip_kernel (fine MLP, 527872 MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)" + (" + fused compositing epilogue" if a.fused else "")
-        flop_per_ray = FLOP_PER_RAY
-        if is_ref:
-            fine_flops = n_rays * (N_FINE + C_COARSE) * 2 * 1_071_616
-            kernel_name = "ref_kernel (Ref-NeRF spatial + directional MLP, 1071616 MAC/sample, 192 merged samples/ray)"
-            flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command (profiles/*pmc*), FETCH_SIZE
         # doubled per the gfx950 note of MI355X_MICROARCH.md; null when no profile for this configuration is committed
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("%s_%s" % (a.model, a.precision))
-        peak = PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA
-        executed_flops = n_rays * ((N_FINE + C_COARSE) * 2 * 2128 * 512 if is_ref else N_FINE * 2 * 928 * 512)   # mlp_layout.h N_FRAGS
-        achieved = fine_flops / (fine_ms * 1e-3)
         rec = {
             "metric": "rays/s (64+128 samples), 800x800" if not is_ref else "rays/s (64+192 samples, Ref-NeRF), 800x800", "value": world * a.steps * n_rays / dt, "unit": "rays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_ranks": spread,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if prec == ops.BF16 else "f32", "data": "synthetic" if a.weights == "small" else "synthetic (DIAGNOSTIC weights=%s)" % a.weights,
             "config": {"workload": ("BASELINE configs[1]: NeRF render 800x800 (640000 rays/step/GPU), 64 proposal + 128 fine samples, "
@@ -616,24 +819,26 @@ def main():
                        if prec == ops.BF16 else "fp32 MFMA", "parallelism": "ray-sharded replicas (dp%d)" % world},
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "ms_per_launch": fine_ms, "flop_per_launch": fine_flops, "traffic": traffic,
+                         "ms_per_launch": fine_ms, "ms_per_launch_ranks": fine_ms_ranks, "flop_per_launch": fine_flops, "traffic": traffic,
                          "traffic_source": ("not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, committed as "
                                             "profiles/pmc_traffic.json (PMC collection needs the profiler around the process)") if traffic is not None else None,
                          # MFMA work actually issued (512 MAC per 32x16 fragment and sample; padded K, bottle_neck folded away)
                          "executed_tflops": executed_flops / (fine_ms * 1e-3) / 1e12, "executed_frac": executed_flops / (fine_ms * 1e-3) / peak},
             "whole_path_tflops": world * a.steps * n_rays * flop_per_ray / dt / 1e12,
         }
-        if world == 1 and not a.no_gemm_ref and prec == ops.BF16:
+    if prec == ops.BF16 and not a.no_gemm_ref:
+        ref = mfma_stream_reference(comm, dev, achieved / 1e12, executed_flops / (fine_ms * 1e-3) / 1e12)       # every rank, at the same time
+        if rank == 0:
+            rec["roofline"]["mfma_stream_ref"] = ref
+    if rank == 0:                                            # (the other ranks wait at the host-side barrier of comm.finish())
+        if not a.no_gemm_ref and prec == ops.BF16:
             rec["roofline"]["gemm_ref"] = gemm_reference(dev)
-            rec["roofline"]["mfma_stream_ref"] = mfma_stream_reference(dev, rec["roofline"]["achieved"], rec["roofline"]["executed_tflops"])
-        if world == 1 and not a.no_train_rate and not is_ref:
+        if not a.no_train_rate and not is_ref:
             rec["train_step"] = train_rate(a.precision)
-        if world == 1 and not a.no_cpu_baseline:
+        if not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
         print(json.dumps(rec), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.finish()
 
 
 if __name__ == "__main__":

@@ -266,15 +266,18 @@ int nerf_amd_coarse_grad_select(const float* grads, const int64_t* sort_inds, in
  * w (M), a, b (M,3) fp32 contiguous; workspace: NERF_AMD_DOT_LOSS_WORKSPACE_FLOATS floats.
  * Backward: g = d loss / d out (ONE float in device memory, so the call needs no synchronisation) -> d_w (M), d_a, d_b (M,3); any of the
  * three may be NULL. */
-/* Measurement aid, no reference counterpart (SURVEY.md 8d: the roofline's denominator checked on the box): `workgroups` workgroups of four
- * waves (one per SIMD; 160 KiB of LDS each, so one workgroup per CU) issue iters * 64 v_mfma_f32_32x32x16_bf16 per wave on constant
- * operands and nothing else; timed by the caller, 32 768 flop per MFMA and wave.  sink: 256 floats (never written in practice). */
-int nerf_amd_mfma_stream(int iters, int workgroups, float* sink, void* stream);
-
 #define NERF_AMD_DOT_LOSS_WORKSPACE_FLOATS 512
 int nerf_amd_weighted_dot_loss(const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* out, float* workspace, void* stream);
 int nerf_amd_weighted_dot_loss_backward(const float* g, const float* w, const float* a, const float* b, int64_t M, int mode, float scale, float* d_w,
                                         float* d_a, float* d_b, void* stream);
+
+/* Measurement aid, no reference counterpart (SURVEY.md 8d: the roofline's denominator checked on the box): `workgroups` workgroups of four
+ * waves (one per SIMD; 160 KiB of LDS each, so one workgroup per CU) issue iters * 64 v_mfma_f32_32x32x16_bf16 per wave and nothing else;
+ * timed by the caller, 32 768 flop per MFMA and wave.  mode 0: constant operands (optimistic: the datapath does not toggle); 1: a rotating
+ * pool of pseudo-random bf16 A / B register groups (pessimistic); 2: random weights-like A, post-ReLU-like B (half zeros); 3: mode 2 with
+ * every A operand read from LDS four fragments ahead and feeding two MFMAs (the weight ring's cadence).  sink: 256 floats (never written
+ * in practice). */
+int nerf_amd_mfma_stream(int iters, int workgroups, int mode, float* sink, void* stream);
 
 /* getBounds (addtional.py:14-18): w_prop (N,C), below (N,K) int64 -> bounds (N,K-1). */
 int nerf_amd_get_bounds(const float* w_prop, const int64_t* below, int64_t N, int C, int K, float* bounds, void* stream);

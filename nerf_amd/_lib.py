@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so
 
 F32, BF16 = 0, 1
 BF16_F8 = 2            # NERF_AMD_BF16_F8: bf16 arithmetic, training dumps of the hidden layers in scaled e4m3 (training entry points only)
-EXPECTED_VERSION = 115  # nerf_amd_version() of the library these signatures were written against
+EXPECTED_VERSION = 116  # nerf_amd_version() of the library these signatures were written against
 NET_PROPOSAL, NET_MIP, NET_REF = 0, 1, 2
 ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS = 0, 1, 2
 
@@ -74,7 +74,7 @@ SIGNATURES = {
     "nerf_amd_merge_depths": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_merge_depths_order": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void, c_void, c_void]),
     "nerf_amd_coarse_grad_select": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, C.c_int, c_void, c_void]),
-    "nerf_amd_mfma_stream": (C.c_int, [C.c_int, C.c_int, c_void, c_void]),
+    "nerf_amd_mfma_stream": (C.c_int, [C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_weighted_dot_loss": (C.c_int, [c_void, c_void, c_void, i64, C.c_int, C.c_float, c_void, c_void, c_void]),
     "nerf_amd_weighted_dot_loss_backward": (C.c_int, [c_void, c_void, c_void, c_void, i64, C.c_int, C.c_float, c_void, c_void, c_void, c_void]),
     "nerf_amd_get_bounds": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, c_void, c_void]),

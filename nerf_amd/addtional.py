@@ -13,8 +13,7 @@ from .nerf_helper import makeMLP
 def getBounds(weights: torch.Tensor, inds: torch.Tensor):
     """Proposal weight mass covering each fine interval (addtional.py:14-18, index quirk included)."""
     if ab.needs_grad(weights):
-        expr = ab.with_hip_backward(lambda w, i: ab.bounds_expr(w, i), lambda g, w, i: (ops.get_bounds_backward(i, g, w.shape[-1]), None))
-        return ab.HipOp.apply(lambda w, i: ops.get_bounds(w, i), expr, 0, weights, inds)
+        return ab.HipOp.apply(lambda w, i: ops.get_bounds(w, i), lambda g, w, i: (ops.get_bounds_backward(i, g, w.shape[-1]), None), 1, weights, inds)
     return ops.get_bounds(weights, inds)
 
 
@@ -97,10 +96,8 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         layers = self._linear_layers()
         params = [l.weight for l in layers] + [l.bias for l in layers]
         if ab.needs_grad(pts, *params):
-            expr = lambda p, *wb: ab.proposal_expr(ab.contract_expr(p) if contract else p, wb[:5], wb[5:])
-            if pts.numel() == 0:
-                hip = lambda p, *wb: ops.proposal_forward(self.packed(prec), prec, p, contract=contract)
-                return ab.HipOp.apply(hip, expr, 0, pts, *params)
+            if pts.numel() == 0:                                         # an empty batch: nothing to launch, zero gradients for every parameter
+                return ops.proposal_forward(self.packed(prec), prec, pts.detach(), contract=contract) + sum(q.sum() for q in params) * 0.0
             # the training forward dumps the hidden activations; the backward is hand-written kernels on them:
             #   parameter gradients: fused dgrad chain + MFMA weight gradients (mlp_backward.py);
             #   RefNeRF.get_grad (train.py:165-168 with prop_normal: d density / d position): a dgrad-only chain down to the encoded
@@ -141,7 +138,7 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
                     return (gx, *[None] * len(wb))
                 gW, gb = self.unpad_grads(gW, gb)
                 return (gx, *gW, *gb)
-            return ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pts, *params)
+            return ab.HipOp.apply(hip, bwd, 1, pts, *params)
         return ops.proposal_forward(self.packed(prec), prec, pts, contract=contract)
 
     @staticmethod
@@ -151,7 +148,8 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         if ab.needs_grad(density, zvals):
             if ray_dirs is not None:
                 zvals = zvals * ray_dirs.norm(dim=-1, keepdim=True)
-            expr = ab.with_hip_backward(lambda s, z: ab.weights_expr(s, z, ops.ACT_RELU), lambda g, s, z: (
-                (ops.sigma_to_weights_backward(s, z, None, ops.ACT_RELU, g), None) if s.shape[-1] <= ops.BWD_MAX_SAMPLES else None))
-            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, ops.ACT_RELU), expr, 0, density, zvals)
+            if density.shape[-1] > ops.BWD_MAX_SAMPLES:
+                ab.unsupported("a differentiable sigma -> weights row of %d samples (the backward kernel keeps a ray in registers: <= %d)" % (density.shape[-1], ops.BWD_MAX_SAMPLES))
+            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, ops.ACT_RELU),
+                                  lambda g, s, z: (ops.sigma_to_weights_backward(s, z, None, ops.ACT_RELU, g), None), 1, density, zvals)
         return ops.sigma_to_weights(density, zvals, ray_dirs, ops.ACT_RELU)

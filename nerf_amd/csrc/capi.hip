@@ -20,7 +20,7 @@ int sk_relu_mask(void*, const void*, int, int64_t, hipStream_t);
 int sk_merge_sorted(const float*, const float*, int64_t, int, int, float*, hipStream_t);
 int sk_merge_sorted_order(const float*, const float*, const int64_t*, int64_t, int, int, float*, int64_t*, int64_t*, hipStream_t);
 int sk_coarse_grad_select(const float*, const int64_t*, int64_t, int, int, int, float*, hipStream_t);
-int pack_mfma_stream(int, int, float*, hipStream_t);
+int pack_mfma_stream(int, int, int, float*, hipStream_t);
 int sk_weighted_dot_loss(const float*, const float*, const float*, int64_t, int, float, float*, float*, hipStream_t);
 int sk_weighted_dot_loss_backward(const float*, const float*, const float*, const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_encode_rows(const float*, int, int64_t, int, int, int, void*, hipStream_t);
@@ -114,7 +114,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 115; }
+int nerf_amd_version(void) { return 116; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -359,9 +359,9 @@ int nerf_amd_weighted_dot_loss_backward(const float* g, const float* w, const fl
     return hip_status(sk_weighted_dot_loss_backward(g, w, a, b, M, mode, scale, d_w, d_a, d_b, S(stream)), "nerf_amd_weighted_dot_loss_backward");
 }
 
-int nerf_amd_mfma_stream(int iters, int workgroups, float* sink, void* stream) {
-    if (iters < 0 || workgroups < 1 || !sink) return fail(NERF_AMD_EINVAL, "bad argument");
-    return hip_status(pack_mfma_stream(iters, workgroups, sink, S(stream)), "nerf_amd_mfma_stream");
+int nerf_amd_mfma_stream(int iters, int workgroups, int mode, float* sink, void* stream) {
+    if (iters < 0 || workgroups < 1 || mode < 0 || mode > 3 || !sink) return fail(NERF_AMD_EINVAL, "bad argument");
+    return hip_status(pack_mfma_stream(iters, workgroups, mode, sink, S(stream)), "nerf_amd_mfma_stream");
 }
 
 // ---- training forward: the MLP kernels also dump their hidden activations ----

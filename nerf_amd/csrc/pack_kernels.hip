@@ -261,23 +261,98 @@ int pack_ref_bwd(int precision, const float* const* w, void* packed, hipStream_t
 }
 
 // ------------------------------------------------------------------------------------------------ measurement aid (bench.py roofline.mfma_stream_ref)
-// A stream of nothing but v_mfma_f32_32x32x16_bf16 on four independent accumulators and constant operands, one wave per SIMD (160 KiB of
-// LDS per workgroup keeps everything else off the CU): what the matrix cores of THIS box sustain under its power limit -- the measured
-// ceiling next to the datasheet peak (scripts/mfma_probe.hip is the stand-alone, more detailed form).  64 MFMAs per iteration and wave.
+// Streams of nothing but v_mfma_f32_32x32x16_bf16 on four independent accumulators, one wave per SIMD (160 KiB of LDS per workgroup keeps
+// everything else off the CU): what the matrix cores of THIS box sustain under its power limit -- the measured ceiling next to the
+// datasheet peak (scripts/mfma_probe.hip is the stand-alone, more detailed form).  64 MFMAs per iteration and wave.
+//   mode 0  constant operands (round 3's probe): the datapath barely toggles -- an OPTIMISTIC ceiling (a zero-weight run
+//           of the fine kernel is 19 % faster than a real one at identical cycles)
+//   mode 1  operands that toggle: a rotating pool of 8 A and 8 B register groups of pseudo-random bf16 (random sign, mantissa and a few
+//           exponents: weights-like A, signed B) -- every MFMA sees other operands than its predecessor: the PESSIMISTIC ceiling
+//   mode 2  data like the networks': A as in mode 1, B post-ReLU-like (half the elements zero, the rest positive)
+//   mode 3  mode 2 + the weight ring's LDS cadence: every second MFMA's A operand arrives through a ds_read_b128 issued four fragments
+//           ahead from 128 KiB of random fragments in LDS (each A fragment feeds two MFMAs, like the 64-sample tile of the MLP kernels)
 namespace {
 typedef __attribute__((ext_vector_type(16))) float pk_f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t pk_u32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 pk_bf16x8;
+__device__ __forceinline__ uint32_t stream_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// two bf16 per dword: sign and mantissa random, exponent 2^-3 .. 2^0; relu_like: half the elements +0, the others positive
+__device__ __forceinline__ uint32_t stream_bf16_pair(uint32_t key, bool relu_like) {
+    const uint32_t r = stream_hash(key);
+    uint32_t lo = (r & 0x807fu) | ((124u + ((r >> 8) & 3u)) << 7), hi = ((r >> 16) & 0x807fu) | ((124u + ((r >> 24) & 3u)) << 7);
+    if (relu_like) {
+        lo = (r & 0x8000u) ? 0u : (lo & 0x7fffu);
+        hi = (r & 0x80000000u) ? 0u : (hi & 0x7fffu);
+    }
+    return lo | (hi << 16);
+}
+template <int MODE>
 __global__ __launch_bounds__(256) void mfma_stream_kernel(int iters, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char stream_lds[];
     const int lane = threadIdx.x & 63;
     pk_f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
-    pk_u32x4 a = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}, b = a;
-    for (int it = 0; it < iters; ++it) {
+    if constexpr (MODE == 0) {
+        pk_u32x4 a = {0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}, b = a;
+        for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b));
+            for (int k = 0; k < 16; ++k) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b));
+            }
+        }
+    } else {
+        pk_u32x4 a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[i][e] = stream_bf16_pair((uint32_t)(threadIdx.x * 64 + i * 4 + e) * 2654435761u + blockIdx.x, false);
+                b[i][e] = stream_bf16_pair((uint32_t)(threadIdx.x * 64 + 32 + i * 4 + e) * 2246822519u + blockIdx.x, MODE >= 2);
+            }
+        if constexpr (MODE == 3) {
+            // 128 fragments of 1 KiB (lane-linear 16-byte slots, conflict-free like the weight ring) of weights-like random data
+            for (int i = threadIdx.x; i < 128 * 64; i += 256) {
+                pk_u32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = stream_bf16_pair((uint32_t)(i * 4 + e) * 40503u + 977u * blockIdx.x, false);
+                *reinterpret_cast<pk_u32x4*>(stream_lds + (size_t)i * 16) = v;
+            }
+            __syncthreads();
+            const uint32_t base = lane * 16;
+            pk_u32x4 q[4];
+            uint32_t f = (threadIdx.x >> 6) * 8;                      // (the four waves read different fragments)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const pk_u32x4*>(stream_lds + base + ((f + i) & 127u) * 1024);
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {                         // 32 fragments, two MFMAs (two column tiles) each
+                    const pk_u32x4 af = q[k & 3];
+                    q[k & 3] = *reinterpret_cast<const pk_u32x4*>(stream_lds + base + ((f + k + 4) & 127u) * 1024);
+                    if (k & 1) {
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(af), "v"(b[(k >> 1) & 7]));
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc3) : "v"(af), "v"(b[((k >> 1) + 3) & 7]));
+                    } else {
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(af), "v"(b[(k >> 1) & 7]));
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(af), "v"(b[((k >> 1) + 3) & 7]));
+                    }
+                }
+                f = (f + 32) & 127u;
+            }
+        } else {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a[k & 7]), "v"(b[(k + 1) & 7]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a[(k + 2) & 7]), "v"(b[(k + 5) & 7]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a[(k + 4) & 7]), "v"(b[(k + 3) & 7]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a[(k + 6) & 7]), "v"(b[(k + 7) & 7]));
+                }
+            }
         }
     }
     float r = 0.0f;
@@ -285,10 +360,19 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(int iters, float* __re
     for (int i = 0; i < 16; ++i) r += (acc0[i] + acc1[i]) + (acc2[i] + acc3[i]);
     if (r == 123.456f) sink[threadIdx.x] = r;
 }
-}  // namespace
-int pack_mfma_stream(int iters, int workgroups, float* sink, hipStream_t st) {
+template <int MODE>
+int launch_mfma_stream(int iters, int workgroups, float* sink, hipStream_t st) {
     const size_t lds = 160 * 1024;
-    if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
-    hipLaunchKernelGGL(mfma_stream_kernel, dim3(workgroups), dim3(256), lds, st, iters, sink);
+    if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_stream_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+    hipLaunchKernelGGL(mfma_stream_kernel<MODE>, dim3(workgroups), dim3(256), lds, st, iters, sink);
     return (int)hipGetLastError();
+}
+}  // namespace
+int pack_mfma_stream(int iters, int workgroups, int mode, float* sink, hipStream_t st) {
+    switch (mode) {
+        case 0: return launch_mfma_stream<0>(iters, workgroups, sink, st);
+        case 1: return launch_mfma_stream<1>(iters, workgroups, sink, st);
+        case 2: return launch_mfma_stream<2>(iters, workgroups, sink, st);
+        default: return launch_mfma_stream<3>(iters, workgroups, sink, st);
+    }
 }

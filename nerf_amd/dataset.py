@@ -38,15 +38,15 @@ class AdaptiveResize(torch.nn.Module):
         super().__init__()
         self.ratio = ratio
 
-    def forward(self, image: Image.Image) -> Image.Image:
+    def forward(self, input: Image.Image) -> Image.Image:
         if self.ratio == 1.0:
-            return image
-        w, h = image.size
-        return image.resize((int(w * self.ratio), int(h * self.ratio)), resample=Image.BILINEAR)
+            return input
+        w, h = input.size
+        return input.resize((int(w * self.ratio), int(h * self.ratio)), resample=Image.BILINEAR)
 
 
 class CustomDataSet(torch.utils.data.Dataset):
-    def __init__(self, root_dir, transform: Optional[Callable] = None, scene_scale=1.0, is_train=True, use_alpha=False, white_bkg=False,
+    def __init__(self, root_dir, transform: Optional[Callable], scene_scale=1.0, is_train=True, use_alpha=False, white_bkg=False,
                  use_div=False):
         self.is_train = is_train
         self.root_dir = root_dir

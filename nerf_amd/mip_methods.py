@@ -9,8 +9,7 @@ from ._packed import require_no_grad
 def maxBlurFilter(weights: torch.Tensor, alpha: float):
     """2-tap max then 2-tap blur plus ``alpha`` (mip_methods.py:61-66) -- HIP kernel."""
     if ab.needs_grad(weights):
-        expr = ab.with_hip_backward(lambda w: ab.max_blur_expr(w, alpha), lambda g, w: (ops.max_blur_backward(w, g),))
-        return ab.HipOp.apply(lambda w: ops.max_blur(w, alpha), expr, 0, weights)
+        return ab.HipOp.apply(lambda w: ops.max_blur(w, alpha), lambda g, w: (ops.max_blur_backward(w, g),), 1, weights)
     return ops.max_blur(weights, alpha)
 
 

@@ -48,10 +48,9 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         layers = self._linear_layers()
         return [l.weight for l in layers] + [l.bias for l in layers]
 
-    def _train_op(self, prec, run_forward, spec, *tensors):
+    def _train_op(self, prec, run_forward, *tensors):
         """Training forward (activation dump) + the hand-written backward on it (mlp_backward.py) as one autograd node.
-        `run_forward(training precision code)` -> (rgbo, dump); `spec` = the torch expression the backward is tested against (never evaluated here: a shape the kernels
-        cannot differentiate raises instead of falling back to library GEMMs)."""
+        `run_forward(training precision code)` -> (rgbo, dump)."""
         from . import mlp_backward
         held = {}
         n_in = len(tensors)
@@ -59,7 +58,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
 
         def hip(*args):
             out, held["dump"] = run_forward(tprec)
-            held["out"] = out
+            held["out"] = out.detach()                                   # (an alias without grad_fn: `out` itself would close a cycle out -> grad_fn -> held)
             return out
 
         def bwd(g, *args):
@@ -77,7 +76,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
                 return (*[None] * (n_in + len(gW) + len(gb)),)
             gW, gb = self.unpad_grads(gW, gb)
             return (*[None] * n_in, *gW, *gb)
-        return ab.HipOp.apply(hip, ab.with_hip_backward(spec, bwd), 0, *tensors, *self._params())
+        return ab.HipOp.apply(hip, bwd, 1, *tensors, *self._params())
 
     def forward(self, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
         """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60).
@@ -86,13 +85,12 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         prec = ops.current_precision()
         params = self._params()
         if ab.needs_grad(pts, *params):
-            n = len(params) // 2
-            expr = lambda p, *wb: ab.mip_expr(ab.contract_expr(p) if contract else p, wb[:n], wb[n:])
-            if pts.requires_grad or pts.numel() == 0:                      # (gradients w.r.t. positions: torch VJP of the expression)
-                hip = lambda p, *wb: ops.mip_forward(self.packed(prec), prec, p, contract=contract)
-                return ab.HipOp.apply(hip, expr, 0, pts, *params)
+            if pts.requires_grad:                                          # the reference's loss never differentiates the fine positions (utils.py:35-36)
+                ab.unsupported("MipNeRF.forward with sample positions that require a gradient")
+            if pts.numel() == 0:                                           # an empty batch: nothing to launch, zero gradients for every parameter
+                return ops.mip_forward(self.packed(prec), prec, pts, contract=contract) + sum(q.sum() for q in params) * 0.0
             # parameter gradients: the training forward dumps the hidden activations, the backward is hand-written kernels on them (mlp_backward.py)
-            return self._train_op(prec, lambda tp: ops.mip_forward_train(self.packed(prec), tp, pts.detach(), contract=contract), expr, pts)
+            return self._train_op(prec, lambda tp: ops.mip_forward_train(self.packed(prec), tp, pts.detach(), contract=contract), pts)
         return ops.mip_forward(self.packed(prec), prec, pts, contract=contract)
 
     def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int, ipe_radius=None, ipe_dir_norm: torch.Tensor = None,
@@ -114,8 +112,6 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         s = ops.samples_rays(rays, n_samples, z=z, contract=contract, ipe_radius=ipe_radius, ipe_dir_norm=ipe_dir_norm)
         shape = (rays.shape[0], n_samples)
         if ab.needs_grad(*self._params()) and rays.shape[0] > 0:
-            def spec(*a):
-                raise NotImplementedError("nerf_amd: MipNeRF.forward_rays has a HIP backward only")
             keep = (rays, z, ipe_dir_norm)                               # the descriptor holds raw pointers: keep the tensors alive
-            return self._train_op(prec, lambda tp: (ops.mip_forward_train_samples(self.packed(prec), tp, s, shape, rays.device), keep)[0], spec)
+            return self._train_op(prec, lambda tp: (ops.mip_forward_train_samples(self.packed(prec), tp, s, shape, rays.device), keep)[0])
         return ops.mip_forward_samples(self.packed(prec), prec, s, shape, rays.device)

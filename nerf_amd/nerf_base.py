@@ -93,9 +93,10 @@ class NeRF(nn.Module):
         if pre is not None:
             opacity = pre(opacity)
         if ab.needs_grad(opacity, depth):
-            expr = ab.with_hip_backward(lambda s, z: ab.weights_expr(s, z, code), lambda g, s, z: (
-                (ops.sigma_to_weights_backward(s, z, None, code, g), None) if s.shape[-1] <= ops.BWD_MAX_SAMPLES else None))
-            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, code), expr, 0, opacity, depth)
+            if opacity.shape[-1] > ops.BWD_MAX_SAMPLES:
+                ab.unsupported("a differentiable sigma -> weights row of %d samples (the backward kernel keeps a ray in registers: <= %d)" % (opacity.shape[-1], ops.BWD_MAX_SAMPLES))
+            return ab.HipOp.apply(lambda s, z: ops.sigma_to_weights(s, z, None, code), lambda g, s, z: (ops.sigma_to_weights_backward(s, z, None, code, g), None),
+                                  1, opacity, depth)
         return ops.sigma_to_weights(opacity, depth, None, code)
 
     @staticmethod
@@ -114,16 +115,10 @@ class NeRF(nn.Module):
                 rgb_, w_, _, _ = ops.composite(r, z, dd, mul_norm == True, bool(white_bkg), code, None)
                 return rgb_, w_
 
-            def expr(r, z, dd):
-                zz = z * dd.norm(dim=-1, keepdim=True) if mul_norm == True else z
-                w_ = ab.weights_expr(r[..., 3], zz, code)
-                c = torch.sum(w_[:, :, None] * r[..., :3], dim=-2)
-                return (c + (1.0 - torch.sum(w_, -1)[..., None]) if white_bkg else c), w_
-            expr.n_diff = 2
-            ab.with_hip_backward(expr, lambda g, r, z, dd: (
-                (ops.composite_backward(r, z, dd, mul_norm == True, bool(white_bkg), code, None, g[0], g[1], None), None, None)
-                if r.shape[1] <= ops.BWD_MAX_SAMPLES else None))
-            rgb, w = ab.HipOp.apply(hip, expr, 1, rgbo, depth, ray_dirs)
+            if rgbo.shape[1] > ops.BWD_MAX_SAMPLES:
+                ab.unsupported("differentiable compositing of %d samples per ray (the backward kernel keeps a ray in registers: <= %d)" % (rgbo.shape[1], ops.BWD_MAX_SAMPLES))
+            rgb, w = ab.HipOp.apply(hip, lambda g, r, z, dd: (ops.composite_backward(r, z, dd, mul_norm == True, bool(white_bkg), code, None, g[0], g[1], None),
+                                                              None, None), 2, rgbo, depth, ray_dirs)
             extras = dict()
             if render_depth is not None or normal_info is not None:
                 with torch.no_grad():

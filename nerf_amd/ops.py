@@ -62,6 +62,87 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# ------------------------------------------------------------------------------------------------ persistent training buffers
+# A 16 384-ray training step needs ~23 GB of dump / delta / workspace buffers.  They are OWNED here -- one grow-only buffer per
+# (device, stream, purpose), sized by the largest step seen -- instead of being torch.empty()-allocated and freed every step (round 3:
+# the driver's training-step line was 4 ms slower than the kernels' sum; bench.py's train_step now reports both).  Two kinds:
+#   * scratch(tag, ...): contents die inside the call chain that asked for them (the delta dump between the dgrad chain and the
+#     weight-gradient kernels, the products' partial sums): always the persistent buffer;
+#   * leased(tag, ...): alive from a training forward to its backward (the activation dump).  The persistent buffer is handed out while
+#     no earlier lease on it is alive (the returned view carries the lease; it ends when the view is freed, i.e. when the backward has
+#     consumed the dump or the graph is dropped); a second forward before that gets a fresh allocation, so nothing is ever overwritten.
+# While a hipGraph is being captured both fall back to torch.empty: the graph's private pool then owns the memory it replays into.
+_PERSISTENT = __import__("os").environ.get("NERF_AMD_PERSISTENT_BUFFERS", "1") != "0"
+_ARENA = {}
+_ARENA_BUSY = set()
+ARENA_STATS = {"persistent": 0, "fresh": 0, "grown": 0}
+
+
+def set_persistent_buffers(on: bool) -> None:
+    """Turn the persistent training buffers on / off (off: every call allocates through torch's caching allocator, as in round 3)."""
+    global _PERSISTENT
+    _PERSISTENT = bool(on)
+    if not on:
+        release_buffers()
+
+
+def release_buffers() -> None:
+    """Give the persistent training buffers back to torch's allocator (they are re-created on demand)."""
+    _ARENA.clear()
+    _ARENA_BUSY.clear()
+
+
+def _arena_key(tag, device):
+    return (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream, tag)
+
+
+def _arena_buffer(key, nbytes: int, device) -> torch.Tensor:
+    buf = _ARENA.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ARENA.pop(key, None)
+        buf = None                                             # (free the smaller one before allocating its replacement)
+        buf = _ARENA[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ARENA_STATS["grown"] += 1
+    return buf
+
+
+def scratch(tag, nbytes: int, device) -> torch.Tensor:
+    nbytes = int(nbytes)
+    device = torch.device(device)
+    if nbytes == 0 or not _PERSISTENT or torch.cuda.is_current_stream_capturing():
+        ARENA_STATS["fresh"] += 1
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    ARENA_STATS["persistent"] += 1
+    return _arena_buffer(_arena_key(tag, device), nbytes, device)[:nbytes]
+
+
+class _Lease:
+    __slots__ = ("key",)
+
+    def __init__(self, key):
+        self.key = key
+        _ARENA_BUSY.add(key)
+
+    def __del__(self):
+        _ARENA_BUSY.discard(self.key)
+
+
+def leased(tag, nbytes: int, device) -> torch.Tensor:
+    nbytes = int(nbytes)
+    device = torch.device(device)
+    if nbytes == 0 or not _PERSISTENT or torch.cuda.is_current_stream_capturing():
+        ARENA_STATS["fresh"] += 1
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = _arena_key(tag, device)
+    if key in _ARENA_BUSY:                                     # an earlier forward's dump is still waiting for its backward
+        ARENA_STATS["fresh"] += 1
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    view = _arena_buffer(key, nbytes, device)[:nbytes]
+    view._nerf_amd_lease = _Lease(key)                         # the lease lives exactly as long as this view object
+    ARENA_STATS["persistent"] += 1
+    return view
+
+
 # ------------------------------------------------------------------------------------------------ weights
 def pack_weights(net: int, precision: int, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
     ws = [_dev(w.detach(), "weight") for w in weights]
@@ -428,10 +509,11 @@ def coarse_grad_select(fine_grads: torch.Tensor, sort_inds: torch.Tensor, c_pnum
     return out
 
 
-def mfma_stream(iters: int, workgroups: int, device) -> None:
-    """launch the MFMA-only stream (bench.py's measured ceiling): iters * 64 MFMAs of 32 768 flop per wave, 4 waves per workgroup"""
+def mfma_stream(iters: int, workgroups: int, device, mode: int = 0) -> None:
+    """launch the MFMA-only stream (bench.py's measured ceiling): iters * 64 MFMAs of 32 768 flop per wave, 4 waves per workgroup.
+    mode 0 constant operands, 1 random operands, 2 random weights x post-ReLU-like activations, 3 = 2 with the A operands read from LDS"""
     sink = torch.zeros((256,), dtype=torch.float32, device=device)
-    check(lib.nerf_amd_mfma_stream(int(iters), int(workgroups), _ptr(sink), _stream()), "nerf_amd_mfma_stream")
+    check(lib.nerf_amd_mfma_stream(int(iters), int(workgroups), int(mode), _ptr(sink), _stream()), "nerf_amd_mfma_stream")
 
 
 DOT_LOSS_WORKSPACE_FLOATS = 512
@@ -637,7 +719,7 @@ NET_PROPOSAL, NET_MIP = 0, 1
 
 def _train_forward_samples(net: int, packed: torch.Tensor, precision: int, s: Samples, out_shape, device):
     out = torch.empty(out_shape, dtype=torch.float32, device=device)
-    dump = torch.empty((lib.nerf_amd_train_dump_bytes(net, precision, s.M),), dtype=torch.uint8, device=device)
+    dump = leased(("dump", net), lib.nerf_amd_train_dump_bytes(net, precision, s.M), device)
     if s.M:
         fn = lib.nerf_amd_proposal_forward_train if net == NET_PROPOSAL else lib.nerf_amd_mip_forward_train
         check(fn(_ptr(packed), precision, C.byref(s), _ptr(out), _ptr(dump), _stream()), "nerf_amd_*_forward_train")
@@ -729,7 +811,7 @@ def pack_weights_backward(net: int, precision: int, weights: Sequence[torch.Tens
 def proposal_backward_chain(packed_bwd: torch.Tensor, precision: int, g_density: torch.Tensor, dump: torch.Tensor) -> torch.Tensor:
     """dgrad chain of the proposal network: g_density (M,) + the training forward's activation dump -> delta dump."""
     g = _dev(g_density.reshape(-1), "g_density")
-    delta = torch.empty_like(dump)
+    delta = leased(("delta", NET_PROPOSAL), dump.numel(), dump.device)      # (held by the returned tensor until the products consumed it)
     check(lib.nerf_amd_proposal_backward_chain(_ptr(packed_bwd), precision, _ptr(g), g.numel(), _ptr(dump), _ptr(delta), _stream()),
           "nerf_amd_proposal_backward_chain")
     return delta
@@ -737,7 +819,7 @@ def proposal_backward_chain(packed_bwd: torch.Tensor, precision: int, g_density:
 
 def mip_backward_chain(packed_bwd: torch.Tensor, precision: int, g_rgbo: torch.Tensor, rgbo: torch.Tensor, dump: torch.Tensor) -> torch.Tensor:
     g, o = _dev(g_rgbo.reshape(-1, 4), "g_rgbo"), _dev(rgbo.reshape(-1, 4), "rgbo")
-    delta = torch.empty_like(dump)
+    delta = leased(("delta", NET_MIP), dump.numel(), dump.device)
     check(lib.nerf_amd_mip_backward_chain(_ptr(packed_bwd), precision, _ptr(g), _ptr(o), g.shape[0], _ptr(dump), _ptr(delta), _stream()),
           "nerf_amd_mip_backward_chain")
     return delta
@@ -773,7 +855,7 @@ def proposal_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: tor
     else:
         gw = _grad_buffers(PROP_W_SHAPES, dev)
         gb = _grad_buffers([(s[0],) for s in PROP_W_SHAPES], dev)
-    ws = torch.empty(lib.nerf_amd_weight_grads_workspace_bytes(NET_PROPOSAL, precision, M), dtype=torch.uint8, device=dev)
+    ws = scratch(("wgrad", NET_PROPOSAL), lib.nerf_amd_weight_grads_workspace_bytes(NET_PROPOSAL, precision, M), dev)
     check(lib.nerf_amd_proposal_weight_grads(precision, M, _ptr(dump), _ptr(delta), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()),
           "nerf_amd_proposal_weight_grads")
     return gw, gb
@@ -792,7 +874,7 @@ def mip_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Te
     else:
         gw = _grad_buffers([tuple(t.shape) for t in w], dev)
         gb = _grad_buffers([tuple(t.shape) for t in b], dev)
-    ws = torch.empty(lib.nerf_amd_weight_grads_workspace_bytes(NET_MIP, precision, M), dtype=torch.uint8, device=dev)
+    ws = scratch(("wgrad", NET_MIP), lib.nerf_amd_weight_grads_workspace_bytes(NET_MIP, precision, M), dev)
     check(lib.nerf_amd_mip_weight_grads(precision, M, _ptr(dump), _ptr(delta), _ptr_array(w), _ptr_array(b), _ptr_array(gw), _ptr_array(gb),
                                         _ptr(ws), _stream()), "nerf_amd_mip_weight_grads")
     return gw, gb
@@ -821,7 +903,7 @@ def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, n
     pts = _dev(pts, "pts")
     rgbo, normal = _ref_out(pts.shape[:-1], pts.device, True)
     s = _samples_pts(pts, 6)
-    dump = torch.empty((lib.nerf_amd_train_dump_bytes(NET_REF, precision, s.M),), dtype=torch.uint8, device=pts.device)
+    dump = leased(("dump", NET_REF), lib.nerf_amd_train_dump_bytes(NET_REF, precision, s.M), pts.device)
     aux = torch.empty((s.M, 16), dtype=torch.float32, device=pts.device)
     if s.M:
         noise = _dev(noise, "noise") if noise is not None else None
@@ -838,7 +920,7 @@ def density_grad(net: int, packed_bwd: torch.Tensor, precision: int, dump: torch
     out = torch.empty((M, 3), dtype=torch.float32, device=x.device)
     if M == 0:
         return out
-    ws = torch.empty(lib.nerf_amd_density_grad_workspace_bytes(net, precision, M), dtype=torch.uint8, device=x.device)
+    ws = scratch(("density_grad", net), lib.nerf_amd_density_grad_workspace_bytes(net, precision, M), x.device)
     sc_stride = 0
     if scale is not None:
         if scale.dtype != torch.float32 or not scale.is_cuda or scale.dim() != 1:
@@ -862,7 +944,7 @@ def ref_backward(packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, a
     dev = g_out.device
     gw = _grad_buffers(REF_GRAD_SHAPES, dev)
     gb = _grad_buffers([(s[0],) for s in REF_GRAD_SHAPES], dev)
-    ws = torch.empty(lib.nerf_amd_ref_backward_workspace_bytes(precision, M), dtype=torch.uint8, device=dev)
+    ws = scratch(("ref_backward",), lib.nerf_amd_ref_backward_workspace_bytes(precision, M), dev)
     check(lib.nerf_amd_ref_backward(_ptr(packed_bwd), precision, int(flags), M, _ptr(dump), _ptr(aux), _ptr(dirs), dirs.shape[1], _ptr(g_out), g_out.shape[1],
                                     _ptr(_dev(ide_table, "ide_table")), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()), "nerf_amd_ref_backward")
     return gw, gb

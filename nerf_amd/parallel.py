@@ -76,10 +76,19 @@ class FlatGradients:
     * ``nerf_amd.optim.Adam`` (or any optimizer) reads the same views.
 
     ``begin_step()`` opens a new accumulation window (the first backward of a module in a window OVERWRITES its gradients -- no zeroing
-    pass --, further ones add); it runs automatically after every ``optimizer.step()`` of an optimizer passed as `optimizer`, and a
-    ``zero_grad(set_to_none=True)`` opens one too (the next backward finds ``p.grad is None``, re-binds the views and overwrites).  Gradients
+    pass --, further ones add); it runs automatically after every ``optimizer.step()`` of an optimizer passed as `optimizer`.  Gradients
     arriving through ordinary autograd (a RefNeRF, a zero-padded narrow network, any other module in `modules`) accumulate into the
-    views as usual; those ranges are zeroed by ``begin_step()``."""
+    views as usual; those ranges are zeroed by ``begin_step()``.
+
+    The reference loop calls ``opt.zero_grad()`` every iteration (train.py:200), which sets ``p.grad = None``:
+      * an attached module's next backward re-binds its views and overwrites them (``sinks_for``);
+      * a module on the autograd path then receives FRESH gradient tensors outside the buffer.  ``all_reduce()`` and the optimizer
+        pre-step hook therefore close the window with ``finalize_window()``: every ``p.grad`` that is not its view is copied into the view
+        and re-bound, a parameter left without a gradient has its range zeroed -- the buffer always holds this window's gradients when the
+        collective, the clip or the optimizer read it;
+      * an attached module that received NO backward in the window (a loss without the proposal term, a fine-network-only phase) has its
+        ranges zeroed by ``finalize_window()`` instead of keeping the previous window's values (torch would skip such a parameter; Adam
+        with a zero gradient only decays its moments)."""
 
     def __init__(self, modules: Sequence[torch.nn.Module], optimizer: Optional[torch.optim.Optimizer] = None, group=None):
         self.modules = list(modules)
@@ -96,22 +105,35 @@ class FlatGradients:
             n = p.numel()
             self.views[p] = self.flat[off: off + n].view_as(p)
             off += n
-        self._fresh, self._autograd_views = {}, []
+        self._fresh, self._autograd_views, self._autograd_params, self._direct_views = {}, [], [], {}
         for m in self.modules:
             direct = getattr(m, "_supports_grad_sinks", False)
             if direct:
+                prev = m.__dict__.get("_grad_owner")
+                if prev is not None and prev is not self:
+                    prev.detach()                                        # one owner per module: the older buffer would silently go stale
                 m.__dict__["_grad_owner"] = self
-                direct = m.grad_sinks() is not None                      # (None: a zero-padded narrow network -> ordinary autograd path)
+                direct = m.grad_sinks() is not None                      # (None: a zero-padded narrow network / a frozen parameter -> ordinary autograd path)
                 if not direct:
                     m.__dict__.pop("_grad_owner", None)
             if direct:
                 self._fresh[m] = True
+                self._direct_views[m] = [self.views[p] for p in m.parameters() if p.requires_grad]
             else:                                                        # gradients arrive through autograd's accumulate: zeroed per window
+                self._autograd_params += [p for p in m.parameters() if p.requires_grad]
                 self._autograd_views += [self.views[p] for p in m.parameters() if p.requires_grad]
         self.bind()
         self.begin_step()
+        self._hooks = []
         if optimizer is not None:
-            optimizer.register_step_post_hook(lambda *_: self.begin_step())
+            self._hooks.append(optimizer.register_step_pre_hook(lambda *_: self.finalize_window()))
+            self._hooks.append(optimizer.register_step_post_hook(lambda *_: self.begin_step()))
+
+    def covers(self, modules) -> bool:
+        """True when this buffer is the live gradient owner of exactly these modules"""
+        mods = list(modules)
+        return len(mods) == len(self.modules) and all(a is b for a, b in zip(sorted(mods, key=id), sorted(self.modules, key=id))) and \
+            all(m.__dict__.get("_grad_owner", self) is self for m in mods)
 
     def bind(self) -> None:
         """(re-)point every p.grad at its view -- e.g. after a zero_grad(set_to_none=True)"""
@@ -120,13 +142,37 @@ class FlatGradients:
                 p.grad = self.views[p]
 
     def begin_step(self) -> None:
+        """open a new accumulation window: views re-bound, autograd-path ranges zeroed, attached modules overwrite on their first backward"""
+        self.bind()
         for m in self._fresh:
             self._fresh[m] = True
         if self._autograd_views:
             torch._foreach_zero_(self._autograd_views)
 
+    def finalize_window(self) -> None:
+        """make the flat buffer hold THIS window's gradients before anything reads it (collective, clip, optimizer): see the class docstring"""
+        stale = [v for m, fresh in self._fresh.items() if fresh for v in self._direct_views[m]]      # attached, but no backward this window
+        for p in self._autograd_params:
+            v = self.views[p]
+            if p.grad is None:                                           # zero_grad(set_to_none=True) and no gradient since
+                stale.append(v)
+                p.grad = v
+            elif p.grad is not v:                                        # autograd allocated a fresh tensor outside the buffer
+                v.copy_(p.grad)
+                p.grad = v
+        if stale:
+            torch._foreach_zero_(stale)
+        for m in self._direct_views:                                     # (an un-written module's p.grad may be None as well)
+            if self._fresh[m]:
+                for p in m.parameters():
+                    if p.requires_grad and p.grad is not self.views[p]:
+                        p.grad = self.views[p]
+
     def sinks_for(self, module, layers):
-        """(weight views, bias views, overwrite?) of an attached module -- called by its backward"""
+        """(weight views, bias views, overwrite?) of an attached module -- called by its backward; None when a layer's parameter is not in
+        the buffer (frozen): the module then takes the ordinary autograd path"""
+        if any(l.weight not in self.views or l.bias not in self.views for l in layers):
+            return None
         first = self._fresh.get(module, False)
         self._fresh[module] = False
         for l in layers:
@@ -140,11 +186,17 @@ class FlatGradients:
         self.flat.zero_()
 
     def detach(self) -> None:
+        """stop owning the modules' gradients (their kernels return gradients to autograd again) and drop the optimizer hooks"""
         for m in self.modules:
-            m.__dict__.pop("_grad_owner", None)
+            if m.__dict__.get("_grad_owner") is self:
+                m.__dict__.pop("_grad_owner", None)
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks = []
 
     def all_reduce(self, average: bool = True) -> int:
-        """One collective over every gradient; returns the element count.  No-op outside a process group."""
+        """One collective over every gradient; returns the element count.  No-op (after closing the window) outside a process group."""
+        self.finalize_window()
         if not (dist.is_available() and dist.is_initialized()):
             return self.flat.numel()
         world = dist.get_world_size(self.group)

@@ -168,8 +168,7 @@ class RefNeRF(PackedWeightsMixin, NeRF):
                 shapes = {n: p_.shape for n, p_ in named}                 # (narrow networks: the padded rows / columns are the discarded part)
                 return (None, None, *[by_name[n][tuple(slice(0, k) for k in shapes[n])] if tuple(by_name[n].shape) != tuple(shapes[n]) else by_name[n]
                                       for n in names])
-            expr = lambda p, dd, *wb: ab.ref_expr(p, dd, noise, dict(zip(names, wb)), self.integrated_dir_enc, self.use_srgb)
-            out = ab.HipOp.apply(hip, ab.with_hip_backward(expr, bwd), 0, pos, d, *params)
+            out = ab.HipOp.apply(hip, bwd, 1, pos, d, *params)
             return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
         return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise, flags=self.kernel_flags)
 
@@ -216,8 +215,7 @@ class RefNeRF(PackedWeightsMixin, NeRF):
     def get_grad(func_val: torch.Tensor, inputs: torch.Tensor) -> torch.Tensor:
         """Normalised d(func)/d(inputs) (ref_model.py:119-125): first-order only, like the reference (no create_graph).  Works for
         every differentiable op of this package -- e.g. the proposal density w.r.t. its sample positions (train.py:165-168,
-        `prop_normal`), whose position gradient comes from the device-side VJP of autograd_bridge.py.  RefNeRF's own training
-        forward is not built (see forward)."""
+        `prop_normal`), whose position gradient is the dgrad-only density chain (nerf_amd_density_grad), like RefNeRF's own."""
         with ab.inputs_only_grad():                              # no parameter gradient is needed for d(func)/d(inputs)
             grad, = torch.autograd.grad(func_val, inputs, torch.ones_like(func_val), retain_graph=True)
         grad_norm = grad.norm(dim=-1, keepdim=True)
@@ -238,7 +236,7 @@ def _dot_loss(weight: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mode: int,
         d_w, d_a, d_b = ops.weighted_dot_loss_backward(g, w_, a_, b_, mode, scale, need)
         return (d_w.view(w_.shape) if d_w is not None else None, d_a.view(a_.shape) if d_a is not None else None,
                 d_b.view(b_.shape) if d_b is not None else None)
-    return ab.HipOp.apply(lambda w_, a_, b_: ops.weighted_dot_loss(w_, a_, b_, mode, scale), ab.with_hip_backward(expr, bwd), 0, weight, a, b)
+    return ab.HipOp.apply(lambda w_, a_, b_: ops.weighted_dot_loss(w_, a_, b_, mode, scale), bwd, 1, weight, a, b)
 
 
 class WeightedNormalLoss(nn.Module):

@@ -80,7 +80,11 @@ class TrainStep:
         self._reduce = flat_grads is not None and flat_grads is not False
         if flat_grads is None:
             from .parallel import FlatGradients
-            flat_grads = FlatGradients([mip_net, prop_net], optimizer)
+            owner = mip_net.__dict__.get("_grad_owner")                                   # a second TrainStep over the same networks (centre crop /
+            if owner is not None and prop_net.__dict__.get("_grad_owner") is owner and owner.covers([mip_net, prop_net]):
+                flat_grads = owner                                                        # full image) shares the buffer the kernels write into
+            else:
+                flat_grads = FlatGradients([mip_net, prop_net], optimizer)
         self.flat_grads = flat_grads if flat_grads is not False else None
         self.grad_clip = float(grad_clip)
         self.graph = None
@@ -140,6 +144,7 @@ class TrainStep:
             self.grad_hook()
         if self.grad_clip > 0.0:                                                                        # train.py:217 grad_clip_func
             if self.flat_grads is not None:                                                             # one norm + one scale over the flat buffer
+                self.flat_grads.finalize_window()
                 flat = self.flat_grads.flat
                 flat.mul_(torch.clamp(self.grad_clip / (torch.linalg.vector_norm(flat) + 1e-6), max=1.0))
             else:

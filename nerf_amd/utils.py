@@ -117,11 +117,24 @@ def fov2Focal(fov, img_size):
     return (f, f)
 
 
+def trans_t(t):
+    """translation along the camera's z axis (utils.py:136-140)"""
+    return torch.Tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, t], [0, 0, 0, 1]]).float()
+
+
+def rot_phi(phi):
+    """rotation about x by `phi` radians (utils.py:142-146)"""
+    c, s_ = np.cos(phi), np.sin(phi)
+    return torch.Tensor([[1, 0, 0, 0], [0, c, -s_, 0], [0, s_, c, 0], [0, 0, 0, 1]]).float()
+
+
+def rot_theta(th):
+    """rotation about y by `th` radians (utils.py:148-152)"""
+    c, s_ = np.cos(th), np.sin(th)
+    return torch.Tensor([[c, 0, -s_, 0], [0, 1, 0, 0], [s_, 0, c, 0], [0, 0, 0, 1]]).float()
+
+
 def pose_spherical(theta, phi, radius):
-    """Orbit camera-to-world matrix (utils.py:136-159)."""
-    ph, th = phi / 180. * np.pi, theta / 180. * np.pi
-    t = torch.Tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]]).float()
-    rp = torch.Tensor([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]]).float()
-    rt = torch.Tensor([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]]).float()
+    """Orbit camera-to-world matrix (utils.py:154-159): pitch, then yaw, then the COLMAP axis flip."""
     flip = torch.Tensor(np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]))
-    return flip @ (rt @ (rp @ t))
+    return flip @ (rot_theta(theta / 180. * np.pi) @ (rot_phi(phi / 180. * np.pi) @ trans_t(radius)))

@@ -10,7 +10,9 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "tests"))
 import nerf_amd
 import weights as W
-from nerf_amd import ops, autograd_bridge as ab
+from nerf_amd import ops
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
+import torch_spec as ab                                 # the ops' torch specifications (test infrastructure)
 from nerf_amd.addtional import ProposalNetwork
 from nerf_amd.mip_model import MipNeRF
 

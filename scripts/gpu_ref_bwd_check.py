@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic of the hand-written Ref-NeRF training kernels against torch.autograd of the reference expression (autograd_bridge.ref_expr)
+"""Diagnostic of the hand-written Ref-NeRF training kernels against torch.autograd of the reference expression (tests/torch_spec.py ref_expr)
 on the device: training forward == inference forward, density gradients (RefNeRF.get_grad) of both networks, every parameter gradient."""
 import sys
 
@@ -10,7 +10,9 @@ ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("o
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import nerf_amd
 import weights as W
-from nerf_amd import ops, autograd_bridge as ab
+from nerf_amd import ops
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
+import torch_spec as ab                                 # the ops' torch specifications (test infrastructure)
 from nerf_amd.addtional import ProposalNetwork
 from nerf_amd.ref_model import RefNeRF
 

@@ -19,8 +19,9 @@ from nerf_amd.utils import inverseSample
 NEAR, FAR = 2.0, 6.0
 
 
-def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False, torch_adam=False, flat=True):
-    """flat: gradients in ONE persistent flat buffer the weight-gradient kernels write into (nerf_amd.parallel.FlatGradients: what
+def make_step(n_rays, c_n, f_n, precision, graph=False, torch_adam=False, flat=True, graph_warm=3):
+    """-> a callable running ONE training step (graph=True: replaying it from a hipGraph captured here after `graph_warm` eager steps).
+    flat: gradients in ONE persistent flat buffer the weight-gradient kernels write into (nerf_amd.parallel.FlatGradients: what
     TrainStep / bench.py --mode train-ddp use); False = ordinary autograd accumulation into per-tensor gradients (what train.py does)."""
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
@@ -38,17 +39,18 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False,
     tgt = torch.rand(n_rays, 3).cuda()
     res = (FAR - NEAR) / c_n
     base = torch.linspace(NEAR, FAR - res, c_n).cuda()
+    ploss = ProposalLoss()
 
     def step():
         z_c = base + torch.rand((n_rays, c_n), device="cuda") * res
         pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
         dens = F.softplus(prop.forward(pts))
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
-        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda") if graph else None)
+        z_f, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda"))
         z_f = z_f[..., :-1].contiguous()
         rgbo = mip.forward(NeRF.length2pts(rays, z_f))
         rend, wts, _ = NeRF.render(rgbo, z_f, rays[:, 3:], white_bkg=True)
-        loss = ProposalLoss()(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
+        loss = ploss(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2)
         if fg is not None:
             fg.begin_step()
         else:
@@ -56,18 +58,27 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False,
         loss.backward()
         opt.step()
 
+    if not graph:
+        return step
+    for _ in range(graph_warm):
+        step()
+    torch.cuda.synchronize()
+    # whole step (forward, backward, Adam, re-pack) as ONE hipGraph: the 512-ray step is launch-bound (~200 launches)
+    g = torch.cuda.CUDAGraph()
+    if fg is None:
+        opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        step()
+    torch.cuda.synchronize()
+    keep = (step, prop, mip, opt, fg)                       # (the graph replays into these objects' memory)
+    return lambda: (g.replay(), keep)[0]
+
+
+def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False, torch_adam=False, flat=True):
+    step = make_step(n_rays, c_n, f_n, precision, graph=graph, torch_adam=torch_adam, flat=flat, graph_warm=warm)
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    if graph:
-        # whole step (forward, backward, Adam, re-pack) as ONE hipGraph: the 512-ray step is launch-bound (~200 launches)
-        g = torch.cuda.CUDAGraph()
-        if fg is None:
-            opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            step()
-        step_eager, step = step, g.replay
-        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
@@ -78,9 +89,9 @@ def run(n_rays, c_n, f_n, precision, iters=20, warm=5, quiet=False, graph=False,
     return dt
 
 
-def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False, graph=False):
+def make_ref_step(n_rays, c_n, f_n, precision, graph=False, graph_warm=3):
     """The Ref-NeRF branch of the step with prop_normal (train.py:164-199): train-mode forward, density-gradient normals from
-    RefNeRF.get_grad on both networks, normal / back-face / coarse-normal losses, backward, Adam."""
+    RefNeRF.get_grad on both networks, normal / back-face / coarse-normal losses, backward, Adam -> a callable running one step."""
     from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
@@ -101,7 +112,7 @@ def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False, graph=Fa
         coarse_grad = -RefNeRF.get_grad(dens, pts)
         dens = F.softplus(dens)
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
-        fl, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda") if graph else None)
+        fl, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda"))
         samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, fl, below)
         pos, dd = samples.split((3, 3), dim=-1)
         pos = pos.contiguous().requires_grad_(True)
@@ -117,16 +128,25 @@ def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False, graph=Fa
         loss.backward()
         opt.step()
 
+    if not graph:
+        return step
+    for _ in range(graph_warm):
+        step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        step()
+    torch.cuda.synchronize()
+    keep = (step, prop, net, opt)
+    return lambda: (g.replay(), keep)[0]
+
+
+def run_ref(n_rays, c_n, f_n, precision, iters=10, warm=3, quiet=False, graph=False):
+    step = make_ref_step(n_rays, c_n, f_n, precision, graph=graph, graph_warm=warm)
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    if graph:
-        g = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            step()
-        step = g.replay
-        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()

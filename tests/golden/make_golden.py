@@ -59,8 +59,24 @@ def npz(name, **arrs):
     print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
 
 
+def write_signatures():
+    """G20: inspect.signature of every public function / class / method of the reference modules the entry scripts import
+    (train.py:12-22,77,82; ddp_train.py:17-27; model_average.py:16-29) -- the call-surface contract of SURVEY.md section 8b as data."""
+    import importlib
+    import json
+    import sigtools
+    rec = {}
+    for m in sigtools.MODULES:
+        rec[m] = sigtools.module_signatures(importlib.import_module("nerf." + m), m)
+    with open(os.path.join(HERE, "g20_signatures.json"), "w") as f:
+        json.dump(rec, f, indent=0, sort_keys=True)
+    print("wrote g20_signatures.json (%d names)" % sum(len(v) for v in rec.values()))
+
+
 def main():
     install_shims()
+    if "--signatures-only" in sys.argv:
+        return write_signatures()
     from nerf import nerf_helper, nerf_base, mip_methods, mip_model, addtional, utils, procedures
     import weights as W
 
@@ -391,6 +407,8 @@ def main():
         o19[tag + "_g_spa2_6"] = net.spa_block2[6].weight.grad[:8, :]
         o19[tag + "_g_spa0"] = net.spa_block1[0].weight.grad[:8, :]
     npz("g19_refnerf_srgb", **o19)
+
+    write_signatures()
 
 
 if __name__ == "__main__":

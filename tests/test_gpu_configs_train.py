@@ -304,3 +304,51 @@ def test_config4_full_size_contracted_render_properties(A):
                 want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), R[pick].cpu(), u1[pick], u2[pick], near, far, 128,
                                                              white_bkg=True, contracted=True)
             assert max_abs(rgb_s2.cpu(), want_rgb) <= 1e-4 and max_abs(w_s2.cpu(), want_w) <= 1e-4 and max_abs(depth_s2.cpu(), want_depth) <= 1e-3
+
+
+def test_config3_full_size_refnerf_render_properties(A):
+    """configs[3] at its size: Ref-NeRF, 800 x 800 = 640 000 rays, 64 proposal + 192 merged samples (procedures.py:64-85, is_ref_model branch:
+    proposal -> resample -> coarseFineMerge -> RefNeRF -> softplus(sigma + 0.5) -> composite), through nerf_amd_render_rays_ref in bf16 (the
+    whole image) and fp32 (100 000 rays).  Scale-free properties -- finite, accumulation <= 1 (read off the white-background identity:
+    rgb_white - rgb_black = 1 - sum w on all three channels), the normal image bounded, shard == full image under in-kernel Philox -- and
+    an fp32 oracle spot check <= 1e-4 on random rays of the same launch (round 3 had this scale only for configs[1] / [2] / [4])."""
+    from nerf_amd.ref_model import RefNeRF
+    prop, _ = build_nets(A, "small", train=False)
+    net = RefNeRF(10, 4)
+    net.load_state_dict(W.ref_state("small"))
+    net = net.cuda().eval()
+    Hh, near, far, n_fine = 800, 2.0, 6.0, 128
+    pose = O.pose_spherical(30.0, -30.0, 4.0)[:3]
+    focal = O.fov2focal(0.6911112070083618, (Hh, Hh))
+    fx, fy = float(focal[1]), float(focal[0])
+    n = Hh * Hh
+    rays = A.ops.generate_rays(pose, Hh, Hh, fx, fy, "cuda", 0, n)
+    z_base = torch.linspace(near, far, 64).cuda()
+    cam_dir = pose[:, -2].contiguous().cuda()
+    for P in (A.ops.BF16, A.ops.F32):
+        pk_p, pk_r = prop.packed(P), net.packed(P)
+        m = n if P == A.ops.BF16 else 100_000
+        R = rays[:m].contiguous()
+        rgb_w, depth, nimg, ws = A.ops.render_rays_ref(pk_p, pk_r, P, R, z_base, None, None, n_fine, near, far, True, want_depth=True, cam_dir=cam_dir,
+                                                       seed=4321)
+        rgb_b, _, _, ws = A.ops.render_rays_ref(pk_p, pk_r, P, R, z_base, None, None, n_fine, near, far, False, workspace=ws, seed=4321)
+        assert rgb_w.shape == (m, 3) and bool(torch.isfinite(rgb_w).all()) and bool(torch.isfinite(depth).all()) and bool(torch.isfinite(nimg).all())
+        bg = rgb_w - rgb_b                                                          # = 1 - accumulation, the same on every channel
+        assert float((bg - bg[:, :1]).abs().max()) <= 4e-6
+        assert float(bg.min()) >= -1e-4 and float(bg.max()) <= 1.0 + 1e-4          # 0 <= sum w <= 1
+        assert float(rgb_b.min()) >= -1e-6 and float(rgb_b.max()) <= 2.0 + 1e-4    # specular * tint + diffuse: two sigmoids at most
+        assert float(nimg.min()) >= -1e-4 and float(nimg.max()) <= 1.0 + 1e-4       # (sum w <n, cam> + 1) / 2 with unit normals
+        # a shard of the image renders to the same values (every uniform is a function of the global ray index)
+        lo, hi = m // 3 + 29, m // 3 + 29 + 40_000
+        rgb_s, depth_s, _, _ = A.ops.render_rays_ref(pk_p, pk_r, P, R[lo:hi].contiguous(), z_base, None, None, n_fine, near, far, True, want_depth=True,
+                                                     seed=4321, rng_ray_offset=lo)
+        assert torch.equal(rgb_s, rgb_w[lo:hi]) and torch.equal(depth_s, depth[lo:hi])
+        if P == A.ops.F32:
+            pick = torch.randperm(m, generator=torch.Generator().manual_seed(5))[:160]
+            u1, u2 = O.philox_uniforms(4321, m, 0, 64, n_fine + 1)
+            with torch.no_grad():
+                want_rgb, _, extras = O.render_rays_ref(W.proposal_state("small"), W.ref_state("small"), R[pick].cpu(), u1[pick], u2[pick], near, far, n_fine,
+                                                        white_bkg=True, cam_z=pose[:, -2])
+            assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4
+            assert max_abs(depth[pick].cpu(), extras["depth_img"]) <= 1e-3
+            assert max_abs(nimg[pick].cpu(), extras["normal_img"]) <= 1e-4

@@ -541,3 +541,77 @@ def test_train_step_losses_equal_the_oracles_step_on_the_same_draws(branch):
         want_loss = want_img + float(O.proposal_loss(O.get_bounds(pw, below), wts))
     assert abs(float(img_loss) - want_img) <= 2e-5 * max(1.0, want_img), (float(img_loss), want_img)
     assert abs(float(loss) - want_loss) <= 2e-4 * max(1.0, abs(want_loss)), (float(loss), want_loss)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's real N > 1 path on the box
+def _bench_line(tmp_path, tag, *args, gpus=1):
+    """Run bench.py as the driver does (stand-alone for N = 1; for N = 2 it re-executes itself under torch.distributed.run) with the gloo
+    control-flow backend -- two ranks on the box's one GPU, which RCCL refuses -- and return the parsed JSON line."""
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--cpu-rays", "2500"] + list(args)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0, (tag, r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (tag, r.stdout[-2000:])                       # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def _key_tree(d, prefix=""):
+    """every key path of a record (lists are leaves); the per-rank entries are compared by presence, not by length"""
+    out = set()
+    for k, v in d.items():
+        out.add(prefix + k)
+        if isinstance(v, dict):
+            out |= _key_tree(v, prefix + k + ".")
+    return out
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "config", "roofline", "cpu_baseline")
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("mode", ["render", "render-strong", "train-ddp"])
+def test_bench_n_gt_1_path_runs_on_the_box_and_its_line_is_self_contained(mode, tmp_path):
+    """What the driver's scaling run executes -- `bench.py --gpus N` with WORLD_SIZE > 1: process group, per-rank device, barriers around
+    the timed region, max-over-ranks, the JSON line -- runs here with two ranks on the one GPU for all three modes (the only thing a
+    one-GPU box cannot provide is RCCL across two devices).  The two-rank line must carry every key of the one-rank line (cpu_baseline,
+    roofline incl. the per-rank MFMA-stream ceilings, train_step for the headline mode) plus the per-rank step times; render-strong must
+    produce the SAME image bit for bit whatever N is (every uniform is a function of the global ray index)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    extra = {"render": [], "render-strong": ["--mode", "render-strong"], "train-ddp": ["--mode", "train-ddp", "--train-rays", "2048"]}[mode]
+    img = {}
+    if mode == "render-strong":
+        img = {1: str(tmp_path / "img1.pt"), 2: str(tmp_path / "img2.pt")}
+    one = _bench_line(tmp_path, mode + "/1", *extra, *(["--dump-image", img[1]] if img else []), gpus=1)
+    two = _bench_line(tmp_path, mode + "/2", *extra, *(["--dump-image", img[2]] if img else []), gpus=2)
+    for rec, n in ((one, 1), (two, 2)):
+        for k in CONTRACT_KEYS:
+            assert k in rec, (mode, n, k)
+        assert rec["n_gpus"] == n and rec["steps"] == 2 and rec["warmup"] == 1 and rec["value"] > 0
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"])
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"]) and rec["cpu_baseline"]["value"] > 0
+        sp = rec["ms_per_step_ranks"]
+        assert len(sp["all"]) == n and sp["min"] <= sp["max"] <= rec["ms_per_step"] * 1.0001
+        ref = rec["roofline"]["mfma_stream_ref"]
+        assert len(ref["per_rank"]) == n and all(r["constant_operands"] > 0 and r["weights_x_relu_activations"] > 0 for r in ref["per_rank"])
+    missing = _key_tree(one) - _key_tree(two)
+    assert not missing, (mode, sorted(missing))                          # the two-rank line has every key of the one-rank line
+    assert two["scaling"] == ("strong" if mode == "render-strong" else "weak")
+    if mode == "render":
+        assert "train_step" in two and two["train_step"]["rays_16384"]["ms_per_iter"] > 0 and two["train_step"]["rays_16384"]["ms_min"] <= two["train_step"]["rays_16384"]["ms_max"]
+        assert len(two["roofline"]["ms_per_launch_ranks"]) == 2
+        # weak scaling on ONE device: two ranks time-share it, so the whole-job rate stays within the one-rank rate's neighbourhood
+        assert 0.5 * one["value"] < two["value"] < 1.3 * one["value"], (one["value"], two["value"])
+    if mode == "train-ddp":
+        assert two["allreduce"]["backend"] == "gloo" and two["allreduce"]["us_per_step"] > 0 and len(two["allreduce"]["us_per_step_ranks"]) == 2
+        assert two["allreduce"]["elements"] == 530052 + 214017
+    if mode == "render-strong":
+        a, b = torch.load(img[1]), torch.load(img[2])
+        assert a.shape == (800 * 800, 4) and torch.equal(a, b)              # N = 2 == N = 1, bit for bit

@@ -239,7 +239,22 @@ def _flat_worker(rank, world, port, q):
         opt.step()                                                         # reads the views; its post-hook opens the next window
         res["stepped"] = all(torch.allclose(p.detach(), b - 0.5 * g) for p, b, g in zip(plain.parameters(), before, g_red))
         res["zeroed"] = all(float(p.grad.abs().max()) == 0.0 for p in plain.parameters())
-        res["kept"] = float(next(prop.parameters()).grad.flatten()[0])     # direct sinks are overwritten by the next backward, not zeroed
+        # window 2, the reference loop's way (train.py:200 opt.zero_grad(): p.grad = None): autograd hands the plain module FRESH gradient
+        # tensors outside the buffer, and the attached module gets no backward at all.  all_reduce() must still reduce this window's
+        # gradients (it used to reduce the stale buffer) and zero the un-written module's ranges instead of re-applying them.
+        opt.zero_grad(set_to_none=True)
+        plain(x).sum().backward()
+        res["fresh_outside"] = all(p.grad is not flat.views[p] for p in plain.parameters())
+        local2 = [p.grad.clone() for p in plain.parameters()]
+        flat.all_reduce()
+        res["picked_up"] = all(p.grad is flat.views[p] for p in flat.params)
+        res["plain2"] = [torch.stack((p.grad.flatten()[0], l.flatten()[0])).tolist() for p, l in zip(plain.parameters(), local2)]
+        res["unwritten_zeroed"] = all(float(flat.views[p].abs().max()) == 0.0 for p in prop.parameters())
+        # a parameter that gets no gradient at all in a window (zero_grad, then nothing): its range is zeroed by the optimizer's pre-step hook
+        opt.zero_grad(set_to_none=True)
+        flat.flat.fill_(7.0)
+        opt.step()
+        res["all_zeroed_before_step"] = float(flat.flat.abs().max()) == 0.0
         res["reopened"] = prop.grad_sinks()[2]
         opt.zero_grad(set_to_none=True)
         res["after_none"] = prop.grad_sinks()[2]                           # torch's "start over": the next backward overwrites ...
@@ -271,9 +286,11 @@ def test_flat_gradients_world_2_gloo():
         assert o["n"] == 6 * 8 + 8 + 8 * 3 + 3 + 214017 and o["views"] and o["rebound"]
         assert o["first"] is True and o["again"] is False and o["reopened"] is True
         assert o["after_none"] is True and o["after_none_again"] is False
-        assert all(abs(v - 1.5) < 1e-6 for v in o["prop"]) and abs(o["kept"] - 1.5) < 1e-6
+        assert all(abs(v - 1.5) < 1e-6 for v in o["prop"])
         assert o["zeroed"] and o["stepped"]
+        assert o["fresh_outside"] and o["picked_up"] and o["unwritten_zeroed"] and o["all_zeroed_before_step"]
     # the autograd-path gradients: mean of the two ranks' local (twice-accumulated) values, identical on both ranks
-    for k in range(4):
-        mean = 0.5 * (out[0]["plain"][k][1] + out[1]["plain"][k][1])
-        assert abs(out[0]["plain"][k][0] - mean) < 1e-5 * max(1.0, abs(mean)) and out[0]["plain"][k][0] == out[1]["plain"][k][0]
+    for key in ("plain", "plain2"):
+        for k in range(4):
+            mean = 0.5 * (out[0][key][k][1] + out[1][key][k][1])
+            assert abs(out[0][key][k][0] - mean) < 1e-5 * max(1.0, abs(mean)) and out[0][key][k][0] == out[1][key][k][0]
