@@ -44,6 +44,13 @@ extern "C" {
 #define NERF_AMD_NET_PROPOSAL 0    /* ProposalNetwork(10, 256)        addtional.py:53-96  */
 #define NERF_AMD_NET_MIP      1    /* MipNeRF(10, 4, 256)             mip_model.py:14-60  */
 #define NERF_AMD_NET_REF      2    /* RefNeRF(10, 4, 128, 256, 256)   ref_model.py:16-66  */
+/* ProposalNetwork(10, 128) -- the reference's class default (addtional.py:61) and `--prop_net_width 128` (procedures.py:176): its own packed
+ * layout (five tensors in their 128-wide shapes) and a narrow-tile kernel at a quarter of the 256-wide MACs.  Forward / render only: a blob
+ * packed for this network is passed as `packed_prop` together with NERF_AMD_PROP_W128 OR-ed into the call's `precision` argument
+ * (nerf_amd_proposal_forward, nerf_amd_render_rays, nerf_amd_render_rays_ref).  Training a narrow network runs the 256-wide kernels on
+ * zero-padded tensors (exactly the same function). */
+#define NERF_AMD_NET_PROPOSAL_128 3
+#define NERF_AMD_PROP_W128 0x100   /* layout flag in `precision`: packed_prop is a NERF_AMD_NET_PROPOSAL_128 blob */
 
 /* density activation applied inside sigma->alpha (nerf_base.py:82 `density_act`) */
 #define NERF_AMD_ACT_RELU     0

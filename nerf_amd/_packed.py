@@ -35,10 +35,11 @@ class PackedWeightsMixin:
         """(out, in) of every tensor in _linear_layers() order as the kernels expect them; None = the module's own shapes"""
         return None
 
-    def kernel_params(self):
-        """-> (weights, biases) in the kernels' shapes (the parameters themselves when nothing is padded)"""
+    def kernel_params(self, shapes=None):
+        """-> (weights, biases) in the kernels' shapes (the parameters themselves when nothing is padded); `shapes` overrides
+        _kernel_weight_shapes() (the narrow-tile layout of a network)"""
         layers = self._linear_layers()
-        shapes = self._kernel_weight_shapes()
+        shapes = self._kernel_weight_shapes() if shapes is None else shapes
         ws, bs = [l.weight for l in layers], [l.bias for l in layers]
         if shapes is None or all(tuple(w.shape) == tuple(s) for w, s in zip(ws, shapes)):
             return ws, bs
@@ -78,7 +79,15 @@ class PackedWeightsMixin:
             return None
         return owner.sinks_for(self, layers)
 
-    def _pack_now(self, precision: int) -> torch.Tensor:
+    # ---- narrow-tile layouts -------------------------------------------------------------------------------------------------------
+    # A module may have a second packed layout evaluated by a narrower kernel (ProposalNetwork with hidden_unit <= 128: NET_PROPOSAL_128,
+    # a quarter of the 256-wide MACs).  It is a FORWARD layout: `packed(precision)` hands it to the eval / render entry points (the blob
+    # carries its layout flag, which ops.* OR into the call's precision argument); `packed(precision, wide=True)` is the 256-wide blob the
+    # training forward and the backward kernels take.
+    def _narrow_layout(self) -> bool:
+        return False
+
+    def _pack_now(self, precision: int, narrow: bool = False) -> torch.Tensor:
         ws, bs = self.kernel_params()
         return ops.pack_weights(self._net_id, precision, ws, bs)
 
@@ -97,16 +106,17 @@ class PackedWeightsMixin:
         self.invalidate_packed()
         return super().train(mode)
 
-    def packed(self, precision: int) -> torch.Tensor:
+    def packed(self, precision: int, wide: bool = False) -> torch.Tensor:
+        narrow = (not wide) and self._narrow_layout()
         cache = self.__dict__.setdefault("_packed_cache", {})
         if self.training:
             cache.clear()
-            return self._pack_now(precision)
+            return self._pack_now(precision, narrow)
         key = self._packed_key()
-        hit = cache.get(precision)
+        hit = cache.get((precision, narrow))
         if hit is None or hit[0] != key:
-            blob = self._pack_now(precision)
-            cache[precision] = (key, blob)
+            blob = self._pack_now(precision, narrow)
+            cache[(precision, narrow)] = (key, blob)
             return blob
         return hit[1]
 

@@ -74,6 +74,21 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
     def _kernel_weight_shapes(self):
         return [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]
 
+    # hidden_unit <= 128 (the class default, addtional.py:61; `--prop_net_width 128`): the narrow-tile kernel on its own packed layout
+    # (include/nerf_amd.h NERF_AMD_NET_PROPOSAL_128) for every forward-only call; widths below 128 are zero-padded to it (exact).
+    _NARROW_SHAPES = [(128, 63), (128, 128), (128, 128), (128, 128), (1, 128)]
+
+    def _narrow_layout(self) -> bool:
+        return self.hidden_unit <= 128
+
+    def _pack_now(self, precision: int, narrow: bool = False) -> torch.Tensor:
+        if not narrow:
+            return super()._pack_now(precision)
+        ws, bs = self.kernel_params(self._NARROW_SHAPES)
+        blob = ops.pack_weights(ops.NET_PROPOSAL_128, precision, ws, bs)
+        blob._nerf_amd_layout = ops.PROP_W128                      # ops.* OR this into the precision argument of the calls that take the blob
+        return blob
+
     def loadFromFile(self, load_path: str, use_amp=False, other_stuff=None):
         """addtional.py:73-86."""
         save = torch.load(load_path, map_location="cpu")
@@ -109,7 +124,7 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
             want_pos = bool(pts.requires_grad)
 
             def hip(p, *wb):
-                out, held["dump"] = ops.proposal_forward_train(self.packed(prec), tprec, p, contract=contract)
+                out, held["dump"] = ops.proposal_forward_train(self.packed(prec, wide=True), tprec, p, contract=contract)
                 return out
 
             def bwd(g, p, *wb):

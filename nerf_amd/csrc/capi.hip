@@ -8,6 +8,7 @@
 
 // launchers defined in the kernel translation units
 int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
+int mlp_launch_proposal128(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
 int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, const float*, int, hipStream_t);
@@ -46,6 +47,7 @@ int bwd_mip_weight_grads(int, int64_t, const void*, const void*, const float* co
 int bwd_launch_adam(float* const*, const float* const*, float* const*, float* const*, const long long*, int, float*, double, const double*, double,
                     double, double, float, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
+int pack_proposal128(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
 int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
@@ -114,7 +116,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 116; }
+int nerf_amd_version(void) { return 117; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -132,30 +134,38 @@ size_t nerf_amd_packed_bytes(int net, int precision) {
     if (net == NERF_AMD_NET_PROPOSAL) return PropLayout::packed_bytes(precision);
     if (net == NERF_AMD_NET_MIP) return MipLayout::packed_bytes(precision);
     if (net == NERF_AMD_NET_REF) return RefLayout::packed_bytes(precision);
+    if (net == NERF_AMD_NET_PROPOSAL_128) return PropLayout128::packed_bytes(precision);
     return 0;
+}
+// the proposal pass of an entry point: `flags` = the layout bits of its precision argument
+static int launch_proposal_any(int flags, const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
+    return (flags & NERF_AMD_PROP_W128) ? mlp_launch_proposal128(packed, precision, s, density, st) : mlp_launch_proposal(packed, precision, s, density, st);
 }
 
 int nerf_amd_pack_weights(int net, int precision, const float* const* weights, const float* const* biases, int n_tensors,
                           void* packed, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (!weights || !biases || !packed) return fail(NERF_AMD_EINVAL, "NULL argument");
-    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
+    const int want = (net == NERF_AMD_NET_PROPOSAL || net == NERF_AMD_NET_PROPOSAL_128) ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
     if (want < 0) return fail(NERF_AMD_EINVAL, "unknown network");
     if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
     for (int i = 0; i < want; ++i)
         if (!weights[i] || !biases[i]) return fail(NERF_AMD_EINVAL, "NULL weight or bias tensor");
     const int e = net == NERF_AMD_NET_PROPOSAL ? pack_proposal(precision, weights, biases, packed, S(stream))
+                  : net == NERF_AMD_NET_PROPOSAL_128 ? pack_proposal128(precision, weights, biases, packed, S(stream))
                   : (net == NERF_AMD_NET_MIP ? pack_mip(precision, weights, biases, packed, S(stream))
                                              : pack_ref(precision, weights, biases, packed, S(stream)));
     return hip_status(e, "nerf_amd_pack_weights");
 }
 
 int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    const int lflags = precision & ~0xff;
+    precision &= 0xff;
+    if (bad_prec(precision) || (lflags & ~NERF_AMD_PROP_W128)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (int c = check_samples(src, false)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !density) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_proposal(packed, precision, *src, density, S(stream)), "nerf_amd_proposal_forward");
+    return hip_status(launch_proposal_any(lflags, packed, precision, *src, density, S(stream)), "nerf_amd_proposal_forward");
 }
 
 int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* stream) {
@@ -453,7 +463,7 @@ size_t nerf_amd_packed_backward_bytes(int net, int precision) {
 int nerf_amd_pack_weights_backward(int net, int precision, const float* const* weights, int n_tensors, void* packed_bwd, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (!weights || !packed_bwd) return fail(NERF_AMD_EINVAL, "NULL argument");
-    const int want = net == NERF_AMD_NET_PROPOSAL ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
+    const int want = (net == NERF_AMD_NET_PROPOSAL || net == NERF_AMD_NET_PROPOSAL_128) ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
     if (want < 0) return fail(NERF_AMD_EINVAL, "unknown network");
     if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
     for (int i = 0; i < want; ++i)
@@ -591,7 +601,9 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
                          const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
                          const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, float* rgb,
                          float* depth, float* weights, void* workspace, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    const int lflags = precision & ~0xff;
+    precision &= 0xff;
+    if (bad_prec(precision) || (lflags & ~NERF_AMD_PROP_W128)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
     if (N == 0) return NERF_AMD_OK;
     if (!packed_prop || !packed_mip || !z_base || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
@@ -633,7 +645,7 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     sc.z_jitter = jitter; sc.z_stride = C;
     sc.contract = camera ? camera->contract : 0;           // (the descriptor may accompany explicit rays just to carry this flag)
     sc.rng_seed = seed; sc.rng_ray_offset = ray0;          // (read only when u_strat == NULL)
-    if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
+    if (int e = launch_proposal_any(lflags, packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7: weights -> max-blur(0.01) -> inverse sampling of n_fine+1 sorted depths (procedures.py:68-70)
     if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, seed, ray0, z_fine,
                             nullptr, nullptr, nullptr, st)) return hip_status(e, "resample");
@@ -664,7 +676,9 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
                              const nerf_amd_samples* camera, int64_t ray_offset, const float* z_base, const float* u_strat,
                              const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, const float* cam_dir,
                              float* rgb, float* depth, float* normal_img, void* workspace, void* stream) {
-    if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
+    const int lflags = precision & ~0xff;
+    precision &= 0xff;
+    if (bad_prec(precision) || (lflags & ~NERF_AMD_PROP_W128) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
     if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
     if (N == 0) return NERF_AMD_OK;
     if (!packed_prop || !packed_ref || !z_base || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
@@ -699,7 +713,7 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
     sc.z_jitter = jitter; sc.z_stride = C;
     sc.rng_seed = seed; sc.rng_ray_offset = ray0;          // (read only when u_strat == NULL)
-    if (int e = mlp_launch_proposal(packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
+    if (int e = launch_proposal_any(lflags, packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7 (procedures.py:68-70), also returning the stratified depths the proposal pass used
     if (int e = sk_resample(density, nullptr, z_base, u_strat, jitter, rays + 3, 6, u_inv, N, C, n_fine + 1, 0, 0.01f, seed, ray0, z_fine,
                             nullptr, nullptr, z_coarse, st)) return hip_status(e, "resample");

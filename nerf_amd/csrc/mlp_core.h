@@ -94,6 +94,18 @@ struct PBF16W : PBF16 {
     static constexpr int NT = 2;
 };
 
+// bf16, narrow networks (hidden width 128: PropLayout128): 4 wavefronts x 96 samples.  Half the K groups per layer leave room for THREE
+// column tiles per wave (2 x 3 x 8 activation register groups = 192 VGPRs, 96 accumulators: 480 registers with everything else,
+// spill-free), so every A fragment read from LDS feeds three MFMAs and a chunk of the weight ring lasts 24 MFMAs instead of 16.
+// (Four column tiles crash hipcc's AGPR-copy rewrite pass under -amdgpu-mfma-vgpr-form and spill 57 registers without it.)
+#ifndef MLP_NARROW_NT
+#define MLP_NARROW_NT 3
+#endif
+struct PBF16N : PBF16 {
+    static constexpr int NW = 4;
+    static constexpr int NT = MLP_NARROW_NT;
+};
+
 struct PF32 {
     using BReg = f32x8;                        // 8 VGPRs per 16-feature K group
     static constexpr int PREC = NERF_AMD_F32;
@@ -365,6 +377,17 @@ struct WeightStream {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 };
+
+// fetch and drop N fragments of the stream (padding that keeps a cyclic stream at an even number of chunks): the ring protocol
+// (boundaries, barriers, refills) advances exactly as if they had been multiplied
+template <class P, int F0, int N, class WS, int I = 0>
+DEVINL void skip_frags(WS& ws) {
+    if constexpr (I < N) {
+        const typename P::AReg a = ws.template next<F0 + I>();
+        WS::dummy_sink(a);
+        skip_frags<P, F0, N, WS, I + 1>(ws);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // One dense layer for this wavefront's NT x 32 samples:  out[fb] = act(W[fb] . in + bias[fb]).

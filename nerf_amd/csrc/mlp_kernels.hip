@@ -404,6 +404,60 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
 }
 
 // ================================================================================================
+// ProposalNetwork, hidden width 128 (PropLayout128; the reference's class default, addtional.py:61, and --prop_net_width 128)
+// ================================================================================================
+// Inference only (the training path of a narrow network runs the 256-wide kernels on zero-padded tensors: exact, nerf_amd/_packed.py).
+// Same machinery as proposal_kernel at half the K groups and feature blocks per hidden layer; NT column tiles per wave (bf16: 4).
+constexpr uint32_t lds_total_narrow() { return MLP_RING_BYTES + 9216; }
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void proposal128_kernel(const void* __restrict__ packed, nerf_amd_samples s, float* __restrict__ density) {
+    using L = PropLayout128;
+    using BReg = typename P::BReg;
+    constexpr int HK = L::HK, HFB = L::HFB;
+    load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
+    WeightStream<P, MLP_NSLOT> ws;
+    ws.init(packed, L::N_FRAGS / P::FPC);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    const int64_t n_tiles = (s.M + TS - 1) / TS;
+    const uint32_t bias0 = MLP_RING_BYTES;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int64_t m[NT];
+        BReg a[NT][HK], b[NT][HK];
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        Deferred<P, HFB - 2, 2> d;
+        {
+            BReg enc[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                m[t] = tile * TS + (wave * NT + t) * 32 + j;
+                const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, false);
+                encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+            }
+            d = dense<P, 4, HFB, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4, [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
+        }
+        // layers.2/4/6 ping-pong between the two register buffers (a -> b -> a -> b); d = a layer's last feature-block pair, converted
+        // during the first K steps of the next layer (which reads those features -- K groups HK-4 .. HK-1 -- in its second half only)
+        d = dense<P, HK, HFB, L::START[1]>(ws, bias0 + L::BIAS_OFF[1] * 4, IN_A, OB, prev_of(d, OA));
+        d = dense<P, HK, HFB, L::START[2]>(ws, bias0 + L::BIAS_OFF[2] * 4, IN_B, OA, prev_of(d, OB));
+        d = dense<P, HK, HFB, L::START[3]>(ws, bias0 + L::BIAS_OFF[3] * 4, IN_A, OB, prev_of(d, OA));
+        float dens[NT];
+        auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
+        dense<P, HK, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB)).flush(OH);
+        skip_frags<P, L::USED_FRAGS, L::N_FRAGS - L::USED_FRAGS>(ws);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
+    }
+    ws.drain();
+}
+
+// ================================================================================================
 // MipNeRF
 // ================================================================================================
 // Optional fused compositing epilogue (nerf_base.py:91-113): when `rgb` is set, the (rgb, sigma) of a tile are parked in
@@ -986,6 +1040,23 @@ int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_s
     const FusedComposite fc{rgb, depth, weights, white_bkg, near, far};
     if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
     return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
+}
+#endif
+#if MLP_TU == 0 || MLP_TU == 1
+template <class P>
+static int launch_proposal128(const void* packed, const nerf_amd_samples& s, float* density, hipStream_t st) {
+    constexpr int TS = P::NW * P::NT * 32;
+    const int64_t n_tiles = (s.M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = lds_total_narrow();
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(proposal128_kernel<P>), lds)) return e;
+    hipLaunchKernelGGL(proposal128_kernel<P>, dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, density);
+    return (int)hipGetLastError();
+}
+// packed = nerf_amd_pack_weights(NERF_AMD_NET_PROPOSAL_128, ...)
+int mlp_launch_proposal128(const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
+    if (precision == NERF_AMD_BF16) return launch_proposal128<PBF16N>(packed, s, density, st);
+    return launch_proposal128<PF32>(packed, s, density, st);
 }
 #endif
 // training forwards: the same kernels, also dumping the hidden activations (ActDump) for the backward

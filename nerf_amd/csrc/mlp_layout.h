@@ -57,6 +57,23 @@ struct PropLayout {
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4; }
 };
 
+// ProposalNetwork(10, hidden <= 128) -- the reference's CLASS DEFAULT is 128 (addtional.py:61) and `--prop_net_width` selects it
+// (procedures.py:176): half the K groups and half the feature blocks per hidden layer (a quarter of the MACs), evaluated by a tile policy
+// with FOUR 32-sample column tiles per wave (every A fragment read from LDS feeds four MFMAs).  The stream is padded by one chunk's worth
+// of fragments (120 -> 128) that the kernel fetches and drops: every cyclic stream holds an even number of chunks (see PropBwdLayout).
+struct PropLayout128 {
+    static constexpr int N_LAYERS = 5;
+    static constexpr int HK = 8, HFB = 4;                // hidden K groups / feature blocks
+    static constexpr int NKG[5] = {4, 8, 8, 8, 8};
+    static constexpr int NFB[5] = {4, 4, 4, 4, 1};
+    static constexpr int START[5] = {0, 16, 48, 80, 112};
+    static constexpr int BIAS_OFF[5] = {0, 128, 256, 384, 512};
+    static constexpr int USED_FRAGS = 120, N_FRAGS = 128;
+    static constexpr int N_BIAS = 544;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4; }
+};
+
 // MipNeRF.  The bottle_neck layer has no activation (mip_model.py:31,58), so it is folded into rgb_layer.0 at pack time:
 //   relu(W8a.(Wb g + bb) + W8b.r + b8) = relu((W8a Wb) g + W8b r + (W8a bb + b8))     -- exact algebra, 12 % fewer MFMAs.
 struct MipLayout {

@@ -125,6 +125,24 @@ int pack_proposal(int precision, const float* const* w, const float* const* b, v
     return launch_pack(B, 5, precision, stream, bias, st);
 }
 
+// ProposalNetwork(10, 128): w = layers.{0,2,4,6,8}.weight in their own (128-wide) shapes; the stream's last 8 fragments are padding
+// (never multiplied: the kernel fetches and drops them), zeroed once here so that the blob is deterministic
+int pack_proposal128(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
+    using Lay = PropLayout128;
+    char* stream = reinterpret_cast<char*>(packed);
+    float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    const size_t frag = (precision == NERF_AMD_BF16) ? 1024 : 2048;
+    if (int e = (int)hipMemsetAsync(stream + Lay::USED_FRAGS * frag, 0, (Lay::N_FRAGS - Lay::USED_FRAGS) * frag, st)) return e;
+    const int rows[5] = {128, 128, 128, 128, 1};
+    const int inf[5] = {63, 128, 128, 128, 128};
+    PackBatch B = {};
+    for (int l = 0; l < 5; ++l) {
+        PackLayer& L = B.L[l] = make_layer(w[l], b[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
+    }
+    return launch_pack(B, 5, precision, stream, bias, st);
+}
+
 int pack_mip(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
     using Lay = MipLayout;
     char* stream = reinterpret_cast<char*>(packed);

@@ -7,7 +7,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import lib, check, Samples, F32, BF16, BF16_F8, NET_PROPOSAL, NET_MIP, NET_REF, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
+from ._lib import lib, check, Samples, F32, BF16, BF16_F8, NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, PROP_W128, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
 
 _PRECISION_OVERRIDE = None          # None -> follow torch autocast (on: bf16, off: fp32)
 
@@ -60,6 +60,11 @@ def _dev(t: torch.Tensor, name: str, dtype: torch.dtype = torch.float32) -> torc
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prop_prec(packed_prop: torch.Tensor, precision: int) -> int:
+    """precision argument of a call that takes a proposal blob: + the blob's layout flag (PROP_W128 for a NET_PROPOSAL_128 blob)"""
+    return int(precision) | int(getattr(packed_prop, "_nerf_amd_layout", 0))
 
 
 # ------------------------------------------------------------------------------------------------ persistent training buffers
@@ -204,13 +209,13 @@ def proposal_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, co
     if out.numel() == 0:
         return out
     s = _samples_pts(pts, 3, contract)
-    check(lib.nerf_amd_proposal_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
+    check(lib.nerf_amd_proposal_forward(_ptr(packed), _prop_prec(packed, precision), C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
     return out
 
 
 def proposal_forward_samples(packed, precision, s: Samples, shape, device) -> torch.Tensor:
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(lib.nerf_amd_proposal_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
+    check(lib.nerf_amd_proposal_forward(_ptr(packed), _prop_prec(packed, precision), C.byref(s), _ptr(out), _stream()), "nerf_amd_proposal_forward")
     return out
 
 
@@ -620,7 +625,7 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
     rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
     w = torch.empty((N, n_fine), dtype=torch.float32, device=dev) if want_weights else None
-    check(lib.nerf_amd_render_rays(_ptr(packed_prop), _ptr(packed_mip), precision, _ptr(rays),
+    check(lib.nerf_amd_render_rays(_ptr(packed_prop), _ptr(packed_mip), _prop_prec(packed_prop, precision), _ptr(rays),
                                    C.byref(camera) if camera is not None else None, ray_offset, _ptr(z_base), _ptr(u_strat),
                                    _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(rgb), _ptr(depth),
                                    _ptr(w), _ptr(workspace), _stream()), "nerf_amd_render_rays")
@@ -652,7 +657,7 @@ def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u
     depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
     cam_dir = _dev(cam_dir, "cam_dir") if cam_dir is not None else None
     normal_img = torch.empty((N,), dtype=torch.float32, device=dev) if cam_dir is not None else None
-    check(lib.nerf_amd_render_rays_ref(_ptr(packed_prop), _ptr(packed_ref), precision, int(flags), _ptr(rays),
+    check(lib.nerf_amd_render_rays_ref(_ptr(packed_prop), _ptr(packed_ref), _prop_prec(packed_prop, precision), int(flags), _ptr(rays),
                                        C.byref(camera) if camera is not None else None, ray_offset, _ptr(z_base), _ptr(u_strat),
                                        _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(cam_dir), _ptr(rgb),
                                        _ptr(depth), _ptr(normal_img), _ptr(workspace), _stream()), "nerf_amd_render_rays_ref")

@@ -121,7 +121,7 @@ class RefNeRF(PackedWeightsMixin, NeRF):
                 bs = [self._pad_to(b.detach(), (sh[0],)) for b, sh in zip(bs, self._KERNEL_SHAPES)]
         return ws + [table], bs + [hb]
 
-    def _pack_now(self, precision: int) -> torch.Tensor:
+    def _pack_now(self, precision: int, narrow: bool = False) -> torch.Tensor:
         ws, bs = self._pack_tensors()
         return ops.pack_weights(self._net_id, precision, ws, bs)
 

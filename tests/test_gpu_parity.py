@@ -2033,3 +2033,51 @@ def test_refnerf_other_ide_levels(A, level, width):
             "%s: |err|_2 %.3e of %.3e, max %.3e of %.3e" % (name, diff.norm().item(), wantg.norm().item(), diff.abs().max().item(), top)
     with pytest.raises(NotImplementedError):
         RefNeRF(10, 5).cuda().eval().forward(pts.cuda())
+
+
+@pytest.mark.parametrize("width", [128, 64, 100])
+def test_narrow_proposal_tile_policy(A, width):
+    """ProposalNetwork(10, hidden <= 128) -- the reference's class default (addtional.py:61), `--prop_net_width 128` (procedures.py:176) --
+    is evaluated by its own kernel (NERF_AMD_NET_PROPOSAL_128: half the K groups and feature blocks, three column tiles per wave) on every
+    forward-only path.  It must be THE SAME FUNCTION as the 256-wide kernel on zero-padded tensors -- bit for bit in both precisions: the
+    added K groups only ever add zero products, in the same order -- and equal the oracle; ragged sizes; the fused stratified-sample
+    fetch with in-kernel Philox draws; the whole render path; widths below 128 pad up to it."""
+    from nerf_amd.addtional import ProposalNetwork
+    torch.manual_seed(500 + width)
+    prop = ProposalNetwork(10, width)
+    with torch.no_grad():                                                     # O(1) activations so that every layer matters
+        for m in prop.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0); m.bias.normal_(0.0, 0.05)
+    psd = {k: v.detach().clone() for k, v in prop.state_dict().items()}
+    prop = prop.cuda().eval()
+    gen = torch.Generator().manual_seed(width)
+    for P, tol in ((A.ops.F32, 2e-5), (A.ops.BF16, 2e-2)):
+        narrow, wide = prop.packed(P), prop.packed(P, wide=True)
+        assert getattr(narrow, "_nerf_amd_layout", 0) == A.ops.PROP_W128 and getattr(wide, "_nerf_amd_layout", 0) == 0
+        assert narrow.numel() == A.ops.lib.nerf_amd_packed_bytes(A.ops.NET_PROPOSAL_128, P) < wide.numel()
+        for M in (1, 33, 383, 384, 385, 1000, 50001):
+            pts = (torch.rand(M, 3, generator=gen) * 4.0 - 2.0).cuda()
+            got_n = A.ops.proposal_forward(narrow, P, pts)
+            got_w = A.ops.proposal_forward(wide, P, pts)
+            assert torch.equal(got_n, got_w), (width, P, M, max_abs(got_n.cpu(), got_w.cpu()))
+            if M <= 1000:
+                with torch.no_grad():
+                    want = O.proposal_forward(psd, pts.cpu(), emulate_bf16=(P == A.ops.BF16))
+                scale = max(1.0, want.abs().max().item())
+                assert max_abs(got_n.cpu(), want) <= tol * scale, (width, P, M)
+    # the fused stratified fetch (rows 2-4) with in-kernel uniforms, and the whole render path through nerf_amd_render_rays
+    _, mip = build_nets(A, "small")
+    rays, _, _ = _rays_and_u(777, 64, 91)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    for P in (A.ops.F32, A.ops.BF16):
+        kw = dict(z_base=z_base, z_jitter=(FAR - NEAR) / 128, seed=99)
+        d_n = A.ops.proposal_forward_samples(prop.packed(P), P, A.ops.samples_rays(dev(rays), 64, **kw), (777, 64), "cuda")
+        d_w = A.ops.proposal_forward_samples(prop.packed(P, wide=True), P, A.ops.samples_rays(dev(rays), 64, **kw), (777, 64), "cuda")
+        assert torch.equal(d_n, d_w)
+        a = A.ops.render_rays(prop.packed(P), mip.packed(P), P, dev(rays), z_base, None, None, 128, NEAR, FAR, True, want_depth=True, seed=5)
+        b = A.ops.render_rays(prop.packed(P, wide=True), mip.packed(P), P, dev(rays), z_base, None, None, 128, NEAR, FAR, True, want_depth=True, seed=5)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # a layout flag the entry point does not know is refused
+    with pytest.raises(RuntimeError):
+        A.ops.check(A.ops.lib.nerf_amd_proposal_forward(None, A.ops.F32 | 0x400, None, None, None), "nerf_amd_proposal_forward")
