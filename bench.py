@@ -78,6 +78,11 @@ def parse():
     p.add_argument("--train-dumps", default="bf16", choices=["bf16", "fp8"],
                    help="storage of the training dumps in bf16 mode: bf16, or e4m3 with per-sample-and-K-group scales (nerf_amd.set_train_dumps)")
     p.add_argument("--train-rays", type=int, default=16384, help="rays per rank and step in --mode train-ddp")
+    p.add_argument("--prop-width", type=int, default=256, choices=[256, 128],
+                   help="hidden width of the proposal network: 256 = BASELINE configs[1] (the headline); 128 = the reference's class default "
+                        "(addtional.py:61, --prop_net_width 128) on the narrow-tile kernel -- a different, cheaper workload, labelled as such")
+    p.add_argument("--fine-width", type=int, default=256, choices=[256, 128],
+                   help="hidden width of the fine MipNeRF: 256 = the headline; 128 = --nerf_net_width 128 on the narrow-tile kernel (labelled)")
     p.add_argument("--dump-image", default=None, help="render-strong: rank 0 saves the last timed image (N,4) to this path (N-independence tests)")
     p.add_argument("--launch-check", action="store_true",
                    help="control-flow check of the N-rank launch path only (rendezvous, world size, barrier, max-over-ranks): no GPU work")
@@ -669,6 +674,9 @@ def render_strong(a, comm):
 
 def main():
     a = parse()
+    if os.environ.get("BENCH_DUMP_STACKS_AFTER"):            # debugging aid: every thread's Python stack to stderr after N seconds (and exit)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_DUMP_STACKS_AFTER"]), exit=True)
     launch_or_verify(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -711,10 +719,10 @@ def main():
         from nerf_amd.ref_model import RefNeRF
         prop, mip = ProposalNetwork(10, 256), RefNeRF(10, 4)
     else:
-        prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
+        prop, mip = ProposalNetwork(10, a.prop_width), MipNeRF(10, 4, a.fine_width)
     wtag = "small" if a.weights == "zero" else a.weights
-    prop.load_state_dict(Wt.proposal_state(wtag))
-    mip.load_state_dict(Wt.ref_state(wtag) if is_ref else Wt.mip_state(wtag))
+    prop.load_state_dict(Wt.proposal_state(wtag, hidden=a.prop_width))
+    mip.load_state_dict(Wt.ref_state(wtag) if is_ref else Wt.mip_state(wtag, hidden=a.fine_width))
     if a.weights == "zero":
         for q in list(prop.parameters()) + list(mip.parameters()):
             q.data.zero_()
@@ -733,6 +741,7 @@ def main():
     jitter = (FAR - NEAR) / N_FINE
     poses = [pose_spherical(float(th), -30.0, 4.0)[:3] for th in torch.linspace(-180, 180, 41)[:-1]]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev_p = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]      # the proposal launch
 
     philox = a.rng == "philox"
 
@@ -742,7 +751,11 @@ def main():
         seed = 0x5EED0000 + 1000003 * rank + i                                                       # a fresh stream per image
         us, ui = (None, None) if philox else (u_strat, u_inv)
         sc = ops.samples_rays(rays, C_COARSE, z_base=z_base, u=us, z_jitter=jitter, seed=seed)      # rows 2-4
+        if timed_idx is not None:
+            ev_p[timed_idx][0].record()
         dens = ops.proposal_forward_samples(pk_prop, prec, sc, (n_rays, C_COARSE), dev)
+        if timed_idx is not None:
+            ev_p[timed_idx][1].record()
         z_fine, _, _, z_c = ops.resample(dens, None, z_base, us, jitter, rays, ui, N_FINE + 1, want_zc=is_ref, seed=seed)   # rows 5-7
         if is_ref:                                                                                    # procedures.py:71-74
             z_all = ops.merge_depths(z_fine, z_c)
@@ -788,15 +801,20 @@ def main():
 
     fine_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
     fine_ms_ranks = comm.gather(fine_ms)
-    fine_flops = n_rays * N_FINE * 2 * MAC_FINE
-    kernel_name = "mip_kernel (fine MLP, 527872 MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)" + (" + fused compositing epilogue" if a.fused else "")
+    prop_ms = sum(s.elapsed_time(e) for s, e in ev_p) / a.steps
+    wd = a.prop_width
+    mac_prop = 63 * wd + 3 * wd * wd + wd                          # = MAC_PROP at width 256
+    fw = a.fine_width
+    mac_fine = 63 * fw + 3 * fw * fw + (fw + 63) * fw + fw * fw + 256 * fw + 256 * 256 + 256 + 283 * 128 + 128 * 3      # = MAC_FINE at width 256
+    fine_flops = n_rays * N_FINE * 2 * mac_fine
+    kernel_name = ("mip_kernel (fine MLP, %d MAC/sample; bottle_neck folded into rgb_layer.0 at pack time)" % mac_fine) + (" + fused compositing epilogue" if a.fused else "")
     flop_per_ray = FLOP_PER_RAY
     if is_ref:
         fine_flops = n_rays * (N_FINE + C_COARSE) * 2 * 1_071_616
         kernel_name = "ref_kernel (Ref-NeRF spatial + directional MLP, 1071616 MAC/sample, 192 merged samples/ray)"
         flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
     peak = PEAK_BF16_DENSE if prec == ops.BF16 else PEAK_F32_MFMA
-    executed_flops = n_rays * ((N_FINE + C_COARSE) * 2 * 2128 * 512 if is_ref else N_FINE * 2 * 928 * 512)   # mlp_layout.h N_FRAGS
+    executed_flops = n_rays * ((N_FINE + C_COARSE) * 2 * 2128 * 512 if is_ref else N_FINE * 2 * (928 if fw == 256 else 352) * 512)   # mlp_layout.h N_FRAGS
     achieved = fine_flops / (fine_ms * 1e-3)
     rec = None
     if rank == 0:
@@ -824,8 +842,15 @@ def main():
                                             "profiles/pmc_traffic.json (PMC collection needs the profiler around the process)") if traffic is not None else None,
                          # MFMA work actually issued (512 MAC per 32x16 fragment and sample; padded K, bottle_neck folded away)
                          "executed_tflops": executed_flops / (fine_ms * 1e-3) / 1e12, "executed_frac": executed_flops / (fine_ms * 1e-3) / peak},
+            "roofline_proposal": {"bound": "mfma", "kernel": "proposal_kernel (63->%dx4->1, %d MAC/sample, stratified sample fetch + encoding in the prologue)" % (wd, mac_prop),
+                                  "ms_per_launch": prop_ms, "flop_per_launch": n_rays * C_COARSE * 2 * mac_prop,
+                                  "achieved": n_rays * C_COARSE * 2 * mac_prop / (prop_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                                  "frac": n_rays * C_COARSE * 2 * mac_prop / (prop_ms * 1e-3) / peak},
             "whole_path_tflops": world * a.steps * n_rays * flop_per_ray / dt / 1e12,
         }
+        if wd != 256 or fw != 256:
+            rec["config"]["workload"] += "; PROPOSAL WIDTH %d, FINE WIDTH %d (not the headline configuration)" % (wd, fw)
+            rec["whole_path_tflops"] = world * a.steps * n_rays * 2 * (C_COARSE * mac_prop + N_FINE * mac_fine) / dt / 1e12
     if prec == ops.BF16 and not a.no_gemm_ref:
         ref = mfma_stream_reference(comm, dev, achieved / 1e12, executed_flops / (fine_ms * 1e-3) / 1e12)       # every rank, at the same time
         if rank == 0:

@@ -51,6 +51,11 @@ extern "C" {
  * zero-padded tensors (exactly the same function). */
 #define NERF_AMD_NET_PROPOSAL_128 3
 #define NERF_AMD_PROP_W128 0x100   /* layout flag in `precision`: packed_prop is a NERF_AMD_NET_PROPOSAL_128 blob */
+/* MipNeRF(10, 4, 128) -- `--nerf_net_width 128` (procedures.py:177): the eleven tensors in their own shapes (lin_block1 128 wide, lin_block2.0
+ * (128, 191), lin_block2.4 (256, 128), the heads as at width 256), a narrow-tile kernel at a third of the 256-wide MACs.  Forward / render with
+ * the point PE only: NERF_AMD_FINE_W128 in `precision` of nerf_amd_mip_forward / nerf_amd_render_rays (not with the integrated PE). */
+#define NERF_AMD_NET_MIP_128 4
+#define NERF_AMD_FINE_W128 0x200   /* layout flag in `precision`: the fine-network blob is a NERF_AMD_NET_MIP_128 blob */
 
 /* density activation applied inside sigma->alpha (nerf_base.py:82 `density_act`) */
 #define NERF_AMD_ACT_RELU     0

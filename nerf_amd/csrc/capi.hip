@@ -10,6 +10,7 @@
 int mlp_launch_proposal(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_proposal128(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
+int mlp_launch_mip128(const void*, int, const nerf_amd_samples&, float*, hipStream_t);
 int mlp_launch_mip_composite(const void*, int, const nerf_amd_samples&, float*, float*, float*, int, float, float, hipStream_t);
 int mlp_launch_ref(const void*, int, const nerf_amd_samples&, float*, float*, const float*, int, hipStream_t);
 size_t mlp_train_layer_stride(int, int64_t);
@@ -48,6 +49,7 @@ int bwd_launch_adam(float* const*, const float* const*, float* const*, float* co
                     double, double, float, hipStream_t);
 int pack_proposal(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal128(int, const float* const*, const float* const*, void*, hipStream_t);
+int pack_mip128(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
 int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
@@ -116,7 +118,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 117; }
+int nerf_amd_version(void) { return 118; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -135,7 +137,11 @@ size_t nerf_amd_packed_bytes(int net, int precision) {
     if (net == NERF_AMD_NET_MIP) return MipLayout::packed_bytes(precision);
     if (net == NERF_AMD_NET_REF) return RefLayout::packed_bytes(precision);
     if (net == NERF_AMD_NET_PROPOSAL_128) return PropLayout128::packed_bytes(precision);
+    if (net == NERF_AMD_NET_MIP_128) return MipLayout128::packed_bytes(precision);
     return 0;
+}
+static int launch_mip_any(int flags, const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
+    return (flags & NERF_AMD_FINE_W128) ? mlp_launch_mip128(packed, precision, s, rgbo, st) : mlp_launch_mip(packed, precision, s, rgbo, st);
 }
 // the proposal pass of an entry point: `flags` = the layout bits of its precision argument
 static int launch_proposal_any(int flags, const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
@@ -146,13 +152,15 @@ int nerf_amd_pack_weights(int net, int precision, const float* const* weights, c
                           void* packed, void* stream) {
     if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (!weights || !biases || !packed) return fail(NERF_AMD_EINVAL, "NULL argument");
-    const int want = (net == NERF_AMD_NET_PROPOSAL || net == NERF_AMD_NET_PROPOSAL_128) ? 5 : (net == NERF_AMD_NET_MIP ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
+    const int want = (net == NERF_AMD_NET_PROPOSAL || net == NERF_AMD_NET_PROPOSAL_128) ? 5
+                     : ((net == NERF_AMD_NET_MIP || net == NERF_AMD_NET_MIP_128) ? 11 : (net == NERF_AMD_NET_REF ? 20 : -1));
     if (want < 0) return fail(NERF_AMD_EINVAL, "unknown network");
     if (n_tensors != want) return fail(NERF_AMD_EINVAL, "wrong number of weight tensors for this network");
     for (int i = 0; i < want; ++i)
         if (!weights[i] || !biases[i]) return fail(NERF_AMD_EINVAL, "NULL weight or bias tensor");
     const int e = net == NERF_AMD_NET_PROPOSAL ? pack_proposal(precision, weights, biases, packed, S(stream))
                   : net == NERF_AMD_NET_PROPOSAL_128 ? pack_proposal128(precision, weights, biases, packed, S(stream))
+                  : net == NERF_AMD_NET_MIP_128 ? pack_mip128(precision, weights, biases, packed, S(stream))
                   : (net == NERF_AMD_NET_MIP ? pack_mip(precision, weights, biases, packed, S(stream))
                                              : pack_ref(precision, weights, biases, packed, S(stream)));
     return hip_status(e, "nerf_amd_pack_weights");
@@ -169,11 +177,14 @@ int nerf_amd_proposal_forward(const void* packed, int precision, const nerf_amd_
 }
 
 int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_samples* src, float* rgbo, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    const int lflags = precision & ~0xff;
+    precision &= 0xff;
+    if (bad_prec(precision) || (lflags & ~NERF_AMD_FINE_W128)) return fail(NERF_AMD_EINVAL, "unknown precision");
     if (int c = check_samples(src, true)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_mip(packed, precision, *src, rgbo, S(stream)), "nerf_amd_mip_forward");
+    if ((lflags & NERF_AMD_FINE_W128) && src->ipe) return fail(NERF_AMD_EINVAL, "the 128-wide fine layout has no integrated-PE kernel: pack the network 256-wide");
+    return hip_status(launch_mip_any(lflags, packed, precision, *src, rgbo, S(stream)), "nerf_amd_mip_forward");
 }
 
 int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf_amd_samples* src, int white_bkg, float near,
@@ -603,7 +614,8 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
                          float* depth, float* weights, void* workspace, void* stream) {
     const int lflags = precision & ~0xff;
     precision &= 0xff;
-    if (bad_prec(precision) || (lflags & ~NERF_AMD_PROP_W128)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (bad_prec(precision) || (lflags & ~(NERF_AMD_PROP_W128 | NERF_AMD_FINE_W128))) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if ((lflags & NERF_AMD_FINE_W128) && camera && camera->ipe) return fail(NERF_AMD_EINVAL, "the 128-wide fine layout has no integrated-PE kernel: pack the network 256-wide");
     if (N < 0 || n_fine < 1 || n_fine > 1023) return fail(NERF_AMD_EINVAL, "bad N or n_fine");
     if (N == 0) return NERF_AMD_OK;
     if (!packed_prop || !packed_mip || !z_base || !rgb || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
@@ -655,7 +667,7 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     if (ipe) { sf.ipe = 1; sf.ipe_radius = camera->ipe_radius; sf.ipe_dir_norm = dir_norm; }   // frustum s = [z_fine[s], z_fine[s+1]]
     // rows 9 and 10 as two launches: measured 2-3 % faster than the fused epilogue of nerf_amd_mip_forward_composite on
     // MI355X, and the composite kernel's HBM rate stays individually measurable
-    if (int e = mlp_launch_mip(packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");
+    if (int e = launch_mip_any(lflags, packed_mip, precision, sf, rgbo, st)) return hip_status(e, "fine MLP");
     const int flags = 1 | (white_bkg ? 2 : 0);              // row 10
     if (int e = sk_composite(rgbo, z_fine, n_fine + 1, rays + 3, 6, N, n_fine, flags, NERF_AMD_ACT_RELU, 0.0f, near, far, nullptr,
                              nullptr, rgb, weights, depth, nullptr, st)) return hip_status(e, "composite");

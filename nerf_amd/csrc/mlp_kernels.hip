@@ -77,6 +77,63 @@ DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG])
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Paired tile prologue (round 4).  A wave's lanes are (sample j, half h); half 0 of a B register group holds the sin-type slots of
+// sample j, half 1 the cos-type slots -- so in the plain prologue BOTH halves fetch the same sample, draw the same Philox block and run
+// the same range reductions and angle-doubling chains, and each keeps half of what it computed.  With two column tiles per wave the
+// halves can split the SAMPLES instead: lane (j, h) does the whole scalar prologue for sample j of column tile h only -- both the
+// sin-type group S and the cos-type group C of that one sample come out of the one sincos chain it runs anyway -- and one
+// v_permlane32_swap per packed dword (upper half of S <-> lower half of C) leaves S = tile 0's registers and C = tile 1's registers in
+// B-operand layout.  Same values bit for bit; half the prologue's fetch / Philox / reduction / doubling instructions per tile.
+// -DMLP_PAIRED_PROLOGUE=0 restores the plain prologue (A/B).
+// ------------------------------------------------------------------------------------------------
+#ifndef MLP_PAIRED_PROLOGUE
+#define MLP_PAIRED_PROLOGUE 1
+#endif
+// a = [a.lo | b.lo], b = [a.hi | b.hi]   (lo / hi = lanes 0..31 / 32..63)
+DEVINL void half_swap(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+template <int NKG>
+DEVINL void half_swap_groups(bf16x8 (&S)[NKG], bf16x8 (&C)[NKG]) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+#pragma unroll
+    for (int k = 0; k < NKG; ++k) {
+        u32x4_ a = __builtin_bit_cast(u32x4_, S[k]), b = __builtin_bit_cast(u32x4_, C[k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { uint32_t x = a[i], y = b[i]; half_swap(x, y); a[i] = x; b[i] = y; }
+        S[k] = __builtin_bit_cast(bf16x8, a); C[k] = __builtin_bit_cast(bf16x8, b);
+    }
+}
+// encode<> for BOTH lane halves of one sample: S = what half 0 holds (sin slots, x, y), C = what half 1 holds (cos slots, z, 0)
+template <class P, int L, int NKG>
+DEVINL void encode_pair(float x, float y, float z, typename P::BReg (&S)[NKG], typename P::BReg (&C)[NKG]) {
+    static_assert(P::FAST_PE, "the paired prologue is the bf16 form (octaves by angle doubling)");
+    float sv[3], cv[3];
+    sincos_quadrant(x, sv[0], cv[0]); sincos_quadrant(y, sv[1], cv[1]); sincos_quadrant(z, sv[2], cv[2]);
+#pragma unroll
+    for (int f = 0; f < L; ++f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int q = 3 * f + c;
+            P::set(S[q >> 3], q & 7, sv[c]);
+            P::set(C[q >> 3], q & 7, cv[c]);
+            if (f + 1 < L) {
+                const float s2 = 2.0f * sv[c];
+                const float ns = s2 * cv[c];
+                const float nc = __builtin_fmaf(-s2, sv[c], 1.0f);
+                sv[c] = ns; cv[c] = nc;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 3 * L; q < 8 * NKG; ++q) {
+        P::set(S[q >> 3], q & 7, (q == 3 * L) ? x : ((q == 3 * L + 1) ? y : 0.0f));
+        P::set(C[q >> 3], q & 7, (q == 3 * L) ? z : 0.0f);
+    }
+}
+
 // Integrated positional encoding (mip_methods.py:36-58) into the same B-operand slots: slot (l, c) = sin|cos(2^l mu_c) * exp(-0.5 * 4^l var_c),
 // raw slots = mu (the cat_origin prefix).  bf16 mode: octaves by angle doubling, attenuation by att_{l+1} = att_l^4.
 template <class P, int L, int NKG>
@@ -332,6 +389,25 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg enc[NT][4];
+        if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE) {
+            // paired prologue: lane (j, h) fetches and encodes sample j of column tile h for BOTH halves, then the halves trade
+            m[0] = tile * TS + (wave * NT) * 32 + j;
+            m[1] = m[0] + 32;
+            const int64_t mo = h ? m[1] : m[0];
+            const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, false);
+#ifdef MLP_PHASEPROBE
+            asm volatile("" ::"v"(sm.x), "v"(sm.y), "v"(sm.z));
+            PHASE_MARK(4)
+#endif
+            encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
+            half_swap_groups<4>(enc[0], enc[1]);
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 4, tile * (TS / 32) + wave * NT + t, k, lane, enc[t][k]);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             m[t] = tile * TS + (wave * NT + t) * 32 + j;
@@ -345,6 +421,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 4, tile * (TS / 32) + wave * NT + t, k, lane, enc[t][k]);
             }
+        }
         }
         BReg a[NT][16], b[NT][16];
         // (layer indices for the training dump: `lay` = the layer whose block pairs are being computed, `lay_pend` = the layer
@@ -433,9 +510,17 @@ __global__ __launch_bounds__(P::NW * 64) void proposal128_kernel(const void* __r
         Deferred<P, HFB - 2, 2> d;
         {
             BReg enc[NT][4];
+            constexpr int PAIRED = (MLP_PAIRED_PROLOGUE && NT >= 2 && P::FAST_PE) ? 2 : 0;       // column tiles 0 and 1 through the paired prologue
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                m[t] = tile * TS + (wave * NT + t) * 32 + j;
+            for (int t = 0; t < NT; ++t) m[t] = tile * TS + (wave * NT + t) * 32 + j;
+            if constexpr (PAIRED) {
+                const int64_t mo = h ? m[1] : m[0];
+                const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, false);
+                encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
+                half_swap_groups<4>(enc[0], enc[1]);
+            }
+#pragma unroll
+            for (int t = PAIRED; t < NT; ++t) {
                 const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, false);
                 encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
             }
@@ -471,7 +556,9 @@ struct FusedComposite {
     float near, far;
 };
 
-template <class P, bool TRAIN, bool IPE = false, bool F8 = false>
+// FUSED: the compositing epilogue below (nerf_amd_mip_forward_composite) -- a template flag since round 4, so that the shipped two-launch
+// instantiations carry neither its code nor its branches and can use the paired tile prologue.
+template <class P, bool TRAIN, bool IPE = false, bool F8 = false, bool FUSED = false>
 __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                          float* __restrict__ rgbo, FusedComposite fc, ActDump dump) {
     using L = MipLayout;
@@ -480,7 +567,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #ifdef MLP_CLOCKPROBE
     const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 32 + P::NW * P::NT * 8)[threadIdx.x] = 0u;   // ray tickets
+    if constexpr (FUSED) { if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 32 + P::NW * P::NT * 8)[threadIdx.x] = 0u; }  // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
     WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
@@ -521,6 +608,32 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         Deferred<P, 6, 2> d;
         {
             BReg enc[NT][4];
+            if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE && !IPE && !FUSED) {
+                // paired prologue (see encode_pair): lane (j, h) fetches and encodes sample j of column tile h, the halves then trade
+                m[0] = tile * TS + (wave * NT) * 32 + j;
+                m[1] = m[0] + 32;
+                const int64_t mo = h ? m[1] : m[0];
+                const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, true);
+                encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
+                half_swap_groups<4>(enc[0], enc[1]);
+                // the raw direction of BOTH tiles' samples for both halves: swap(d, copy of d) -> [d.lo | d.lo], [d.hi | d.hi]
+                uint32_t d0[3] = {__builtin_bit_cast(uint32_t, sm.dx), __builtin_bit_cast(uint32_t, sm.dy), __builtin_bit_cast(uint32_t, sm.dz)};
+                uint32_t d1[3] = {d0[0], d0[1], d0[2]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) half_swap(d0[c], d1[c]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) P::stash(enc_lds(t) + k * P::BREG_LDS, enc[t][k]);
+                    if constexpr (TRAIN) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 8, sub0 + t, k, lane, enc[t][k]);
+                    }
+                    const uint32_t* dd = t ? d1 : d0;
+                    const f32x4 dv = {__builtin_bit_cast(float, dd[0]), __builtin_bit_cast(float, dd[1]), __builtin_bit_cast(float, dd[2]), 0.0f};
+                    *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 m[t] = tile * TS + (wave * NT + t) * 32 + j;
@@ -542,7 +655,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                     for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 8, sub0 + t, k, lane, enc[t][k]);
                 }
                 f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
-                if (fc.rgb != nullptr) {
+                if constexpr (FUSED) {
                     // fused compositing needs z|d| and the distance to the next sample at the END of the tile; fetch them now,
                     // while the tile's other global loads are in flight (a load at the tile end would drain the weight DMA queue)
                     const int64_t mm_ = m[t] < s.M ? m[t] : s.M - 1;
@@ -555,6 +668,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
                     dv[3] = h ? dl : zn0;
                 }
                 *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+            }
             }
             // lin_block1.0 : 63 -> 256
             d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
@@ -626,11 +740,11 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             o[t][1] = 1.0f / (1.0f + expf(-g[t]));
             o[t][2] = 1.0f / (1.0f + expf(-bl[t]));
             o[t][3] = sigma[t];
-            if (fc.rgb == nullptr) {
+            if constexpr (!FUSED) {
                 if (h == 0 && m[t] < s.M) *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o[t];
             }
         }
-        if (fc.rgb != nullptr) {
+        if constexpr (FUSED) {
             // ---- fused compositing epilogue (nerf_base.py:91-113; S in {32, 64, 128}: a ray = S / 32 consecutive 32-sample SEGMENTS of the tile) ----
             // Every wave does the expensive part for ITS OWN segments: sigma -> alpha and the exclusive prefix product of the transmittance
             // INSIDE each segment (fp64, one 32-segmented DPP scan for both column tiles), parks per sample (colour, alpha, z|d|, that
@@ -739,6 +853,118 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #endif
 }
 
+
+// ================================================================================================
+// MipNeRF, hidden width 128 (MipLayout128; --nerf_net_width 128).  Inference only, point PE; same structure as mip_kernel with half the
+// K groups / feature blocks in the 128-wide layers (lin_block2.4 widens to 256 for the heads, mip_model.py:28).
+// ================================================================================================
+template <class P>
+__global__ __launch_bounds__(P::NW * 64) void mip128_kernel(const void* __restrict__ packed, nerf_amd_samples s, float* __restrict__ rgbo) {
+    using L = MipLayout128;
+    using BReg = typename P::BReg;
+    load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
+    WeightStream<P, MLP_NSLOT> ws;
+    ws.init(packed, L::N_FRAGS / P::FPC);
+    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NT = P::NT;
+    constexpr int TS = P::NW * NT * 32;
+    const int64_t n_tiles = (s.M + TS - 1) / TS;
+    const uint32_t bias0 = LDS_BIAS;
+    const uint32_t enc_lds0 = LDS_STASH + wave * NT * 4 * P::BREG_LDS + lane * 16;
+    const uint32_t dir_lds0 = lds_dir<P>() + wave * NT * 1024 + lane * 16;
+    auto enc_lds = [&](int t) -> uint32_t { return enc_lds0 + t * 4 * P::BREG_LDS; };
+    auto dir_lds = [&](int t) -> uint32_t { return dir_lds0 + t * 1024; };
+    auto bias = [&](int l) -> uint32_t { return bias0 + L::BIAS_OFF[l] * 4; };
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int64_t m[NT];
+        BReg a[NT][8], b[NT][8], g[NT][16];
+        auto OA = [&](int fb, int t, const f32x16& acc, int half) { a[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OB = [&](int fb, int t, const f32x16& acc, int half) { b[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto OG = [&](int fb, int t, const f32x16& acc, int half) { g[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
+        auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
+        auto IN_G = [&](int kg, int t) -> BReg { return g[t][kg]; };
+        Deferred<P, 2, 2> d;
+        {
+            BReg enc[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) m[t] = tile * TS + (wave * NT + t) * 32 + j;
+            if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE) {
+                const int64_t mo = h ? m[1] : m[0];
+                const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, true);
+                encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
+                half_swap_groups<4>(enc[0], enc[1]);
+                uint32_t d0[3] = {__builtin_bit_cast(uint32_t, sm.dx), __builtin_bit_cast(uint32_t, sm.dy), __builtin_bit_cast(uint32_t, sm.dz)};
+                uint32_t d1[3] = {d0[0], d0[1], d0[2]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) half_swap(d0[c], d1[c]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) P::stash(enc_lds(t) + k * P::BREG_LDS, enc[t][k]);
+                    const uint32_t* dd = t ? d1 : d0;
+                    const f32x4 dv = {__builtin_bit_cast(float, dd[0]), __builtin_bit_cast(float, dd[1]), __builtin_bit_cast(float, dd[2]), 0.0f};
+                    *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, true);
+                    encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) P::stash(enc_lds(t) + k * P::BREG_LDS, enc[t][k]);
+                    const f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
+                    *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+                }
+            }
+            d = dense<P, 4, 4, L::START[0]>(ws, bias(0), [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});     // lin_block1.0
+        }
+        // lin_block1.{2,4,6}: a -> b -> a -> b;  lin_block2.0 (skip: cat(enc 63, h 128)): b -> a;  lin_block2.2: a -> b;  lin_block2.4 (128 -> 256): b -> g.
+        // A layer's last feature-block pair is converted during the first K steps of the next layer (which reads it in its second half only).
+        // (the two a -> b layers share one code instance through the loop -- same chunk parity, asserted; short loops also keep hipcc's
+        //  register allocation from losing track in one giant basic block)
+        static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC) && L::BIAS_OFF[3] == L::BIAS_OFF[1] + 256, "shared a -> b instance");
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            d = dense<P, 8, 4, L::START[1]>(ws, bias0 + (L::BIAS_OFF[1] + r * 256) * 4, IN_A, OB, prev_of(d, OA));
+            if (r == 0) d = dense<P, 8, 4, L::START[2]>(ws, bias(2), IN_B, OA, prev_of(d, OB));
+        }
+        d = dense<P, 12, 4, L::START[4]>(ws, bias(4),
+            [&](int kg, int t) -> BReg { if (kg < 4) return P::unstash(enc_lds(t) + kg * P::BREG_LDS); return b[t][kg >= 4 ? kg - 4 : 0]; }, OA, prev_of(d, OB));
+        d = dense<P, 8, 4, L::START[5]>(ws, bias(5), IN_A, OB, prev_of(d, OA));
+        const auto dg = dense<P, 8, 8, L::START[6]>(ws, bias(6), IN_B, OG, prev_of(d, OB));
+        // opacity_head.0 : 256 -> 1 (raw sigma)
+        float sigma[NT];
+        auto OSIG = [&](int, int t, const f32x16& acc, int half) { if (half == 0) sigma[t] = acc[0]; };
+        const auto dsig = dense<P, 16, 1, L::START[7]>(ws, bias(7), IN_G, OSIG, prev_of(dg, OG));
+        BReg denc[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(smem + dir_lds(t));
+            const float nrm = norm3(dv[0], dv[1], dv[2]);
+            encode<P, 4, 2>(dv[0] / nrm, dv[1] / nrm, dv[2] / nrm, h, denc[t]);
+        }
+        // rgb_layer.0 with bottle_neck.0 folded in: cat(g 256, dir 27) -> 128, ReLU;  rgb_layer.2 : 128 -> 3, sigmoid
+        BReg c[NT][8];
+        auto OC = [&](int fb, int t, const f32x16& acc, int half) { c[t][2 * fb + half] = to_breg_half<P, true>(acc, half); };
+        const auto dc = dense<P, 18, 4, L::START[8]>(ws, bias(8),
+            [&](int kg, int t) -> BReg { if (kg < 16) return g[t][kg < 16 ? kg : 0]; return denc[t][kg >= 16 ? kg - 16 : 0]; }, OC, prev_of(dsig, OSIG));
+        float r[NT], gg[NT], bl[NT];
+        auto ORGB = [&](int, int t, const f32x16& acc, int half) { if (half == 0) { r[t] = acc[0]; gg[t] = acc[1]; bl[t] = acc[2]; } };
+        dense<P, 8, 1, L::START[9]>(ws, bias(9), [&](int kg, int t) -> BReg { return c[t][kg]; }, ORGB, prev_of(dc, OC)).flush(ORGB);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 o;
+            o[0] = 1.0f / (1.0f + expf(-r[t]));
+            o[1] = 1.0f / (1.0f + expf(-gg[t]));
+            o[2] = 1.0f / (1.0f + expf(-bl[t]));
+            o[3] = sigma[t];
+            if (h == 0 && m[t] < s.M) *reinterpret_cast<f32x4*>(rgbo + m[t] * 4) = o;
+        }
+    }
+    ws.drain();
+}
 
 // ================================================================================================
 // RefNeRF (ref_model.py:68-106, eval mode, use_srgb = False)
@@ -1034,12 +1260,17 @@ int mlp_launch_mip(const void* packed, int precision, const nerf_amd_samples& s,
     if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, rgbo, st, off, NO_DUMP);
     return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, rgbo, st, off, NO_DUMP);
 }
+// packed = nerf_amd_pack_weights(NERF_AMD_NET_MIP_128, ...); point PE only (the C-ABI refuses s.ipe with this layout)
+int mlp_launch_mip128(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, hipStream_t st) {
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout128>(mip128_kernel<PB16>, packed, s, rgbo, st);
+    return launch<PF32, MipLayout128>(mip128_kernel<PF32>, packed, s, rgbo, st);
+}
 // fine MLP + compositing in one launch; requires mode 1 (rays + z) and S in {32, 64, 128}
 int mlp_launch_mip_composite(const void* packed, int precision, const nerf_amd_samples& s, float* rgb, float* depth, float* weights,
                              int white_bkg, float near, float far, hipStream_t st) {
     const FusedComposite fc{rgb, depth, weights, white_bkg, near, far};
-    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
-    return launch<PF32, MipLayout>(mip_kernel<PF32, false>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
+    if (precision == NERF_AMD_BF16) return launch<PB16, MipLayout>(mip_kernel<PB16, false, false, false, true>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
+    return launch<PF32, MipLayout>(mip_kernel<PF32, false, false, false, true>, packed, s, (float*)nullptr, st, fc, NO_DUMP);
 }
 #endif
 #if MLP_TU == 0 || MLP_TU == 1

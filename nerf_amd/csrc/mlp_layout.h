@@ -90,6 +90,23 @@ struct MipLayout {
     LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4 + FOLD_SCRATCH; }
 };
 
+// MipNeRF(10, 4, hidden <= 128) (`--nerf_net_width 128`, procedures.py:177): lin_block1 63 -> 128 x 4, lin_block2 (128 + 63) -> 128 -> 128 -> 256
+// (its last layer is 256 wide whatever the hidden width, mip_model.py:28), heads as in MipLayout (bottle_neck folded into rgb_layer.0).
+// 233 216 MAC per sample (the reference's layers, bottle_neck counted) against 527 872 at width 256; executed: 352 fragments against 928.
+struct MipLayout128 {
+    static constexpr int N_LAYERS = 10;
+    //                             l1.0 l1.2 l1.4 l1.6 l2.0 l2.2 l2.4 sigma rgb0' rgb2
+    static constexpr int NKG[10] = {4, 8, 8, 8, 12, 8, 8, 16, 18, 8};
+    static constexpr int NFB[10] = {4, 4, 4, 4, 4, 4, 8, 1, 4, 1};
+    static constexpr int START[10] = {0, 16, 48, 80, 112, 160, 192, 256, 272, 344};
+    static constexpr int BIAS_OFF[10] = {0, 128, 256, 384, 512, 640, 768, 1024, 1056, 1184};
+    static constexpr int N_FRAGS = 352;
+    static constexpr int N_BIAS = 1216;
+    static constexpr size_t FOLD_SCRATCH = (128 * 256 + 128) * 4;
+    LAYOUT_HD static constexpr size_t stream_bytes(int prec) { return (size_t)N_FRAGS * (prec == NERF_AMD_BF16 ? 1024 : 2048); }
+    LAYOUT_HD static constexpr size_t packed_bytes(int prec) { return stream_bytes(prec) + N_BIAS * 4 + FOLD_SCRATCH; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Backward (dgrad) chains: the same stream format, carrying TRANSPOSED weights.  Layer "dL" turns delta_{L+1} (gradient w.r.t. the
 // pre-activation of forward layer L+1, K operand) into delta_L = (W_{L+1}^T delta_{L+1}) * [y_L > 0]: rows = the inputs of W_{L+1}.

@@ -170,6 +170,33 @@ int pack_mip(int precision, const float* const* w, const float* const* b, void* 
     return launch_pack(B, 10, precision, stream, bias, st);
 }
 
+// MipNeRF(10, 4, 128): the 11 tensors in their own shapes (lin_block1 128 wide, lin_block2.0 (128, 191), lin_block2.4 (256, 128), heads as at 256)
+int pack_mip128(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {
+    using Lay = MipLayout128;
+    char* stream = reinterpret_cast<char*>(packed);
+    float* bias = reinterpret_cast<float*>(stream + Lay::stream_bytes(precision));
+    float* wf = bias + Lay::N_BIAS;
+    float* bf = wf + 128 * 256;
+    hipLaunchKernelGGL(fold_bottleneck_kernel, dim3(128), dim3(256), 0, st, w[9], b[9], w[7], b[7], wf, bf);
+    if (int e = (int)hipGetLastError()) return e;
+    const float* lw[10] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[8], wf, w[10]};
+    const float* lb[10] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[8], bf, b[10]};
+    const int rows[10] = {128, 128, 128, 128, 128, 128, 256, 1, 128, 3};
+    const int inf[10] = {63, 128, 128, 128, 191, 128, 128, 256, 256, 128};
+    PackBatch B = {};
+    for (int l = 0; l < 10; ++l) {
+        PackLayer& L = B.L[l] = make_layer(lw[l], lb[l], rows[l], inf[l], Lay::NKG[l], Lay::NFB[l], Lay::START[l], Lay::BIAS_OFF[l]);
+        if (l == 0) set_seg(L, 0, SEG_PE, 4, 0, 10, 63);
+        if (l == 4) { set_seg(L, 0, SEG_PE, 4, 0, 10, 63); set_seg(L, 1, SEG_DMAP, 8, 63, 0, 128); }
+        if (l == 8) {
+            set_seg(L, 0, SEG_DMAP, 16, 0, 0, 256);
+            set_seg(L, 1, SEG_PE, 2, 256, 4, 27);
+            L.seg_w[1] = w[9]; L.seg_stride[1] = 283;
+        }
+    }
+    return launch_pack(B, 10, precision, stream, bias, st);
+}
+
 // tensors: 0-3 spa_block1.{0,2,4,6}; 4-7 spa_block2.{0,2,4,6}; 8 bottle_neck; 9 heads (11,256); 10-13 dir_block1.{0,2,4,6};
 //          14-17 dir_block2.{0,2,4,6}; 18 spec_rgb_head.0; 19 ide_table (9,19) in the weights slot
 int pack_ref(int precision, const float* const* w, const float* const* b, void* packed, hipStream_t st) {

@@ -44,6 +44,21 @@ class MipNeRF(PackedWeightsMixin, NeRF):
     def _kernel_weight_shapes(self):
         return [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (256, 256), (1, 256), (128, 283), (3, 128)]
 
+    # hidden_unit <= 128 (`--nerf_net_width 128`): the narrow-tile kernel on its own packed layout (NERF_AMD_NET_MIP_128) for forward-only
+    # calls with the point PE; widths below 128 are zero-padded to it.  lin_block2.4 / bottle_neck / heads are 256 wide at every hidden width.
+    _NARROW_SHAPES = [(128, 63), (128, 128), (128, 128), (128, 128), (128, 191), (128, 128), (256, 128), (256, 256), (1, 256), (128, 283), (3, 128)]
+
+    def _narrow_layout(self) -> bool:
+        return self.hidden_unit <= 128
+
+    def _pack_now(self, precision: int, narrow: bool = False) -> torch.Tensor:
+        if not narrow:
+            return super()._pack_now(precision)
+        ws, bs = self.kernel_params(self._NARROW_SHAPES)
+        blob = ops.pack_weights(ops.NET_MIP_128, precision, ws, bs)
+        blob._nerf_amd_layout = ops.FINE_W128
+        return blob
+
     def _params(self):
         layers = self._linear_layers()
         return [l.weight for l in layers] + [l.bias for l in layers]
@@ -90,7 +105,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
             if pts.numel() == 0:                                           # an empty batch: nothing to launch, zero gradients for every parameter
                 return ops.mip_forward(self.packed(prec), prec, pts, contract=contract) + sum(q.sum() for q in params) * 0.0
             # parameter gradients: the training forward dumps the hidden activations, the backward is hand-written kernels on them (mlp_backward.py)
-            return self._train_op(prec, lambda tp: ops.mip_forward_train(self.packed(prec), tp, pts.detach(), contract=contract), pts)
+            return self._train_op(prec, lambda tp: ops.mip_forward_train(self.packed(prec, wide=True), tp, pts.detach(), contract=contract), pts)
         return ops.mip_forward(self.packed(prec), prec, pts, contract=contract)
 
     def forward_rays(self, rays: torch.Tensor, z: torch.Tensor, n_samples: int, ipe_radius=None, ipe_dir_norm: torch.Tensor = None,
@@ -113,5 +128,5 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         shape = (rays.shape[0], n_samples)
         if ab.needs_grad(*self._params()) and rays.shape[0] > 0:
             keep = (rays, z, ipe_dir_norm)                               # the descriptor holds raw pointers: keep the tensors alive
-            return self._train_op(prec, lambda tp: (ops.mip_forward_train_samples(self.packed(prec), tp, s, shape, rays.device), keep)[0])
-        return ops.mip_forward_samples(self.packed(prec), prec, s, shape, rays.device)
+            return self._train_op(prec, lambda tp: (ops.mip_forward_train_samples(self.packed(prec, wide=True), tp, s, shape, rays.device), keep)[0])
+        return ops.mip_forward_samples(self.packed(prec, wide=ipe_radius is not None), prec, s, shape, rays.device)

