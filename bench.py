@@ -457,9 +457,9 @@ def iteration_rate(precision, n_rays=512, iters=200):
     for mode in ("eager", "hipgraph"):
         prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
         opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
-        from nerf_amd.parallel import FlatGradients               # gradients in one persistent flat buffer (the data-parallel layout; no-op collective here)
-        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11,
-                         flat_grads=FlatGradients([mip, prop], opt))
+        # (gradients in TrainStep's own flat buffer, WITHOUT the data-parallel all_reduce: in an N > 1 run only rank 0 measures this, and a
+        #  collective that one rank enters alone never returns -- the two-rank GPU test of round 4 found exactly that hang)
+        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11)
         step.set_image(img, pose)
         if mode == "hipgraph":
             step.capture(warmup=3)
@@ -673,6 +673,9 @@ def render_strong(a, comm):
 
 
 def main():
+    # multi-process GPU work on these hosts needs dmabuf IPC (without it RCCL fails with `hipIpcGetMemHandle: invalid argument`); the variable is
+    # read when the HIP runtime initialises, i.e. at the first device call below -- and inherited by the ranks this process may launch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     a = parse()
     if os.environ.get("BENCH_DUMP_STACKS_AFTER"):            # debugging aid: every thread's Python stack to stderr after N seconds (and exit)
         import faulthandler

@@ -1051,8 +1051,31 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
         {
             BReg enc[NT][4];
 #pragma unroll
+            for (int t = 0; t < NT; ++t) m[t] = tile * TS + (wave * NT + t) * 32 + j;
+            if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE) {        // paired prologue (see encode_pair)
+                const int64_t mo = h ? m[1] : m[0];
+                const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, true);
+                encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
+                half_swap_groups<4>(enc[0], enc[1]);
+                uint32_t d0[3] = {__builtin_bit_cast(uint32_t, sm.dx), __builtin_bit_cast(uint32_t, sm.dy), __builtin_bit_cast(uint32_t, sm.dz)};
+                uint32_t d1[3] = {d0[0], d0[1], d0[2]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) half_swap(d0[c], d1[c]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) P::stash(stash(t) + k * P::BREG_LDS, enc[t][k]);
+                    if constexpr (TRAIN) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dump_breg<P>(dump, 8, sub0 + t, 11 + k, lane, enc[t][k]);
+                    }
+                    const uint32_t* dd = t ? d1 : d0;
+                    const f32x4 dv = {__builtin_bit_cast(float, dd[0]), __builtin_bit_cast(float, dd[1]), __builtin_bit_cast(float, dd[2]), 0.0f};
+                    *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+                }
+            } else {
+#pragma unroll
             for (int t = 0; t < NT; ++t) {
-                m[t] = tile * TS + (wave * NT + t) * 32 + j;
                 const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, true);
                 encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
 #pragma unroll
@@ -1063,6 +1086,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                 }
                 f32x4 dv = {sm.dx, sm.dy, sm.dz, 0.0f};
                 *reinterpret_cast<f32x4*>(smem + dir_lds(t)) = dv;
+            }
             }
             d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,                  // spa_block1.0 (lay = lay_pend = 0)
                 [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});

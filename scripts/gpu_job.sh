@@ -6,11 +6,12 @@
 #        profile               rocprofv3 kernel stats + PMC passes of the bench (scripts/gpu_round_profile.sh)
 #        trainprof             rocprofv3 of the 16 384-ray training step (+ PMC=1 traffic passes)
 #        ab                    AB_LIST / AB_REPS / BENCH_ARGS: scripts/gpu_ab.sh             py FILE [args]   run a script
+#        psnr                  PSNR_SEEDS: the converging 20 000-iteration recipe, HIP fp32 + bf16 (scripts/psnr_seeds.py)
 # A job's arguments end at the next job name; everything is logged, nothing aborts the rest.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${TAG:-r04}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-JOBS="tests bench benchall profile trainprof ab py"
+JOBS="tests bench benchall profile trainprof ab py psnr"
 is_job() { for j in $JOBS; do [ "$1" = "$j" ] && return 0; done; return 1; }
 while [ $# -gt 0 ]; do
   job=$1; shift; args=()
@@ -30,5 +31,8 @@ while [ $# -gt 0 ]; do
     trainprof) PMC=${PMC:-1} bash scripts/gpu_train_profile.sh "${args[@]}" > $OUT/train_profile.log 2>&1; tail -3 $OUT/train_profile.log ;;
     ab)       bash scripts/gpu_ab.sh 2>&1 | tee $OUT/ab_${AB_NAME:-run}.log ;;
     py)       python "${args[@]}" 2>&1 | tee -a $OUT/py.log | tail -40 ;;
+    psnr)     # the converging recipe of profiles/r04_psnr (40 x 40 views x 25, 512 rays, 32+64 samples, 20 000 iterations, lr x 3, hold 0.6): HIP fp32 + bf16
+              python scripts/psnr_seeds.py --modes fp32,bf16 --seeds ${PSNR_SEEDS:-1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16} --size 40 --views 25 --held 1 --rays 512 \
+                     --coarse 32 --fine 64 --iters 20000 --lr-mult 3 --hold 0.6 --ckpts 4 > $OUT/psnr_hip.log 2>&1; grep SUMMARY $OUT/psnr_hip.log ;;
   esac
 done
