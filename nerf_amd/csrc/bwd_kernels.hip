@@ -448,6 +448,40 @@ struct ActMaskedOut {
     template <class T> static DEVINL void pin(const T& r) { asm volatile("" ::"v"(r.lo), "v"(r.hi)); }
 };
 
+// Round 4: the Ref-NeRF training forward writes ReLU bit masks too (mlp_kernels.hip ref_kernel: one register per column tile instead of an
+// LDS record), so the fused chains read 32 B per sample and layer like the MipNeRF chain instead of the 512 B of activations above:
+// -13.6 GB (directional), -12.1 GB (spatial), -12.1 GB (density gradient) per 2^14-ray step.  Same protocol as MaskedOut: a layer's
+// 1 KiB record per subtile is LDS-DMA'd when the layer starts into the buffer of the slot's parity (consecutive chain layers alternate),
+// waited for when its second feature-block pair starts (the first reader is pair 0's deferred epilogue).
+template <class P, int NKG_CUR, bool STORE, int parity>          // parity = slot & 1: which of the wave's two LDS buffers
+struct BitMaskedOut {
+    typename P::BReg (&buf)[P::NT][16];
+    const char* mask;            // the slot's bit-mask records: subtile s -> mask + s * 1024
+    char* dlt;                   // K group 0 of subtile 0 of the delta slot (STORE)
+    int64_t sub0; int lane; uint32_t mask_lds;
+    static constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
+    DEVINL void begin_group(int G) const {
+        if (G == 0) {
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t)
+                glds_piece(mask + (size_t)(sub0 + t) * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(mask_lds + (parity * P::NT + t) * 1024));
+        } else if (G == 1) {
+            vm_wait<mask_wait_count<P>(NKG_CUR)>();
+        }
+    }
+    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
+        const int kg = 2 * fb + half;
+        const typename P::BReg d = to_breg_half<P, false>(acc, half);
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(smem + mask_lds + (parity * P::NT + t) * 1024 + lane * 16 + (kg >> 2) * 4);
+        const typename P::BReg v = relu_mask_bits(d, w, kg);
+        buf[t][kg] = v;
+        if constexpr (STORE) P::store_global(dlt + (size_t)(sub0 + t) * SUB + (size_t)kg * P::BREG_LDS, lane, v);
+        else pin(v);
+    }
+    static DEVINL void pin(const bf16x8& r) { asm volatile("" ::"v"(r)); }
+    template <class T> static DEVINL void pin(const T& r) { asm volatile("" ::"v"(r.lo), "v"(r.hi)); }
+};
+
 // The chains' bodies are written as short loops over layer pairs like mip_bwd_kernel, not as ten layers of straight-line code: with
 // one basic block per tile hipcc's scheduler and register allocator lose track of the pressure (170-1000 spilled registers per kernel
 // against 0-50 in this form); layers that share a loop body must start at the same chunk phase (all layers here are multiples of
@@ -459,7 +493,7 @@ struct ActMaskedOut {
 //    DEN  Ref-NeRF's spatial network, d density / d (encoded position) (RefNeRF.get_grad): the density row -> activation slots 7..0,
 //         nothing stored but rows (M, 64) = spa_block2.0[:, :63]^T S4 + spa_block1.0^T S0.
 template <class P, bool DEN>
-__global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ act,
+__global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ masks, unsigned long long mask_stride,
                                                                 char* __restrict__ dlt, unsigned long long layer_stride, float* __restrict__ rows) {
     using L = RefBwdLayout;
     using BReg = typename P::BReg;
@@ -476,7 +510,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
     constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
     const int64_t n_tiles = (M + TS - 1) / TS;
     const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
-    auto A = [&](int slot) { return act + (size_t)slot * layer_stride; };
+    auto A = [&](int slot) { return masks + (size_t)slot * mask_stride; };
     auto D = [&](int slot) { return STORE ? dlt + (size_t)slot * layer_stride : nullptr; };
     constexpr int W16 = mask_wait_count<P>(16);
     static_assert(L::START[L0 + 1] % (2 * P::FPC) == L::START[L0 + 3] % (2 * P::FPC) && L::START[L0 + 2] % (2 * P::FPC) == L::START[L0 + 4] % (2 * P::FPC) &&
@@ -498,13 +532,13 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
         BReg a[NT][16], b[NT][16];
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
-        const ActMaskedOut<P, 2, 0, STORE> OT{a, A(TOP), D(TOP), sub0, lane, mask_lds};
+        const BitMaskedOut<P, 2, STORE, TOP & 1> OT{a, A(TOP), D(TOP), sub0, lane, mask_lds};
         Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[L0] - S0>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OT, NoPrev{});
         // TOP-1 .. TOP-4 (the fourth is the skip layer through its hidden columns): a -> b -> a -> b -> a
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const ActMaskedOut<P, 16, 2, STORE> OB{b, A(TOP - 1 - 2 * r), D(TOP - 1 - 2 * r), sub0, lane, mask_lds};      // (follows the 2-step head layer in round 0)
-            const ActMaskedOut<P, 16, 16, STORE> OA_pend{a, A(TOP - 2 * r), D(TOP - 2 * r), sub0, lane, mask_lds}, OA{a, A(TOP - 2 - 2 * r), D(TOP - 2 - 2 * r), sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, STORE, (TOP - 1) & 1> OB{b, A(TOP - 1 - 2 * r), D(TOP - 1 - 2 * r), sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, STORE, TOP & 1> OA_pend{a, A(TOP - 2 * r), D(TOP - 2 * r), sub0, lane, mask_lds}, OA{a, A(TOP - 2 - 2 * r), D(TOP - 2 - 2 * r), sub0, lane, mask_lds};
             d = dense<P, 16, 8, L::START[L0 + 1] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             d = dense<P, 16, 8, L::START[L0 + 2] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
         }
@@ -518,16 +552,16 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
         // TOP-5, TOP-6, TOP-7: a -> b -> a -> b
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const ActMaskedOut<P, 16, 16, STORE> OB{b, A(TOP - 5 - 2 * r), D(TOP - 5 - 2 * r), sub0, lane, mask_lds};
-            const ActMaskedOut<P, 16, 16, STORE> OA_pend{a, A(TOP - 4 - 2 * r), D(TOP - 4 - 2 * r), sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, STORE, (TOP - 5) & 1> OB{b, A(TOP - 5 - 2 * r), D(TOP - 5 - 2 * r), sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, STORE, (TOP - 4) & 1> OA_pend{a, A(TOP - 4 - 2 * r), D(TOP - 4 - 2 * r), sub0, lane, mask_lds};
             d = dense<P, 16, 8, L::START[L0 + 6] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if (r == 0) {
-                const ActMaskedOut<P, 16, 16, STORE> OA{a, A(TOP - 6), D(TOP - 6), sub0, lane, mask_lds};
+                const BitMaskedOut<P, 16, STORE, (TOP - 6) & 1> OA{a, A(TOP - 6), D(TOP - 6), sub0, lane, mask_lds};
                 d = dense<P, 16, 8, L::START[L0 + 7] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             }
         }
         vm_wait<W16>();                                      // (the row layer has no mask wait of its own)
-        const ActMaskedOut<P, 16, 16, STORE> OL{b, A(TOP - 7), D(TOP - 7), sub0, lane, mask_lds};
+        const BitMaskedOut<P, 16, STORE, (TOP - 7) & 1> OL{b, A(TOP - 7), D(TOP - 7), sub0, lane, mask_lds};
         const RowsOut R2{rows, LD, 1, sub0 * 32, j, h, M};
         const auto r2 = dense<P, 16, NFB_ROWS, L::START[L0 + 9] - S0>(ws, BWD_LDS_ZERO, IN_B, R2, prev_of(d, OL));
         r2.flush(R2);
@@ -538,7 +572,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
 // Ref-NeRF, spatial network (parameter gradients): [bottle-neck delta | head deltas] (K groups 0..8 of delta slot 8,
 // ref_heads_delta_kernel) -> delta slots 7..0
 template <class P>
-__global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ act,
+__global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ masks, unsigned long long mask_stride,
                                                                  char* __restrict__ dlt, unsigned long long layer_stride) {
     using L = RefBwdLayout;
     using BReg = typename P::BReg;
@@ -552,7 +586,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __r
     constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
     const int64_t n_tiles = (M + TS - 1) / TS;
     const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
-    auto A = [&](int slot) { return act + (size_t)slot * layer_stride; };
+    auto A = [&](int slot) { return masks + (size_t)slot * mask_stride; };
     auto D = [&](int slot) { return dlt + (size_t)slot * layer_stride; };
     static_assert(L::START[11] % (2 * P::FPC) == L::START[13] % (2 * P::FPC) && L::START[11] % (2 * P::FPC) == L::START[15] % (2 * P::FPC) &&
                   L::START[11] % (2 * P::FPC) == L::START[17] % (2 * P::FPC) && L::START[12] % (2 * P::FPC) == L::START[14] % (2 * P::FPC) &&
@@ -569,21 +603,21 @@ __global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __r
         BReg a[NT][16], b[NT][16];
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
-        const ActMaskedOut<P, 10, 0, true> O7{a, A(7), D(7), sub0, lane, mask_lds};
+        const BitMaskedOut<P, 10, true, 1> O7{a, A(7), D(7), sub0, lane, mask_lds};
         Deferred<P, 6, 2> d = dense<P, 10, 8, L::START[10] - S0>(ws, BWD_LDS_ZERO,
             [&](int kg, int t) -> BReg { if (kg < 9) return x[t][kg < 9 ? kg : 0]; return zero_kg; }, O7, NoPrev{});
         // S6 .. S0: a -> b -> a ... -> b; round 3 runs the first layer of the body only
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
-            const ActMaskedOut<P, 16, 10, true> OB{b, A(6 - 2 * r), D(6 - 2 * r), sub0, lane, mask_lds};              // (follows the 10-step layer in round 0)
-            const ActMaskedOut<P, 16, 16, true> OA_pend{a, A(7 - 2 * r), D(7 - 2 * r), sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, true, 0> OB{b, A(6 - 2 * r), D(6 - 2 * r), sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, true, 1> OA_pend{a, A(7 - 2 * r), D(7 - 2 * r), sub0, lane, mask_lds};
             d = dense<P, 16, 8, L::START[11] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if (r < 3) {
-                const ActMaskedOut<P, 16, 16, true> OA{a, A(5 - 2 * r), D(5 - 2 * r), sub0, lane, mask_lds};
+                const BitMaskedOut<P, 16, true, 1> OA{a, A(5 - 2 * r), D(5 - 2 * r), sub0, lane, mask_lds};
                 d = dense<P, 16, 8, L::START[12] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             }
         }
-        const ActMaskedOut<P, 16, 16, true> O0{b, A(0), D(0), sub0, lane, mask_lds};
+        const BitMaskedOut<P, 16, true, 0> O0{b, A(0), D(0), sub0, lane, mask_lds};
         vm_wait<mask_wait_count<P>(16)>();
         d.flush(O0);
     }
@@ -593,8 +627,8 @@ __global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __r
 // the proposal network's d density / d (encoded position) (train.py:165-168, `prop_normal`): the head row -> activation slots 3..0,
 // nothing stored but d_enc (M, 64) = layers.0^T d0
 template <class P>
-__global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ act,
-                                                                        unsigned long long layer_stride, float* __restrict__ d_enc) {
+__global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const void* __restrict__ stream, int64_t M, const char* __restrict__ masks,
+                                                                        unsigned long long mask_stride, float* __restrict__ d_enc) {
     using L = PropBwdLayout;
     using BReg = typename P::BReg;
     WeightStream<P, MLP_NSLOT, false> ws;
@@ -605,7 +639,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const vo
     constexpr int TS = P::NW * NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
     const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
-    auto A = [&](int slot) { return act + (size_t)slot * layer_stride; };
+    auto A = [&](int slot) { return masks + (size_t)slot * mask_stride; };
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
         BReg one_kg, zero_kg;
@@ -614,22 +648,22 @@ __global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const vo
         BReg a[NT][16], b[NT][16];
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
-        const ActMaskedOut<P, 2, 0, false> O3{a, A(3), nullptr, sub0, lane, mask_lds};
+        const BitMaskedOut<P, 2, false, 1> O3{a, A(3), nullptr, sub0, lane, mask_lds};
         Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int kg, int) -> BReg { return kg == 0 ? one_kg : zero_kg; }, O3, NoPrev{});
         // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (as in prop_bwd_kernel)
         static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk phase");
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const ActMaskedOut<P, 16, 2, false> OB{b, A(2 - 2 * r), nullptr, sub0, lane, mask_lds};
-            const ActMaskedOut<P, 16, 16, false> OA_pend{a, A(3 - 2 * r), nullptr, sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, false, 0> OB{b, A(2 - 2 * r), nullptr, sub0, lane, mask_lds};
+            const BitMaskedOut<P, 16, false, 1> OA_pend{a, A(3 - 2 * r), nullptr, sub0, lane, mask_lds};
             d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if (r == 0) {
-                const ActMaskedOut<P, 16, 16, false> OA{a, A(1), nullptr, sub0, lane, mask_lds};
+                const BitMaskedOut<P, 16, false, 1> OA{a, A(1), nullptr, sub0, lane, mask_lds};
                 d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             }
         }
         vm_wait<mask_wait_count<P>(16)>();
-        const ActMaskedOut<P, 16, 16, false> O0{b, A(0), nullptr, sub0, lane, mask_lds};
+        const BitMaskedOut<P, 16, false, 0> O0{b, A(0), nullptr, sub0, lane, mask_lds};
         const RowsOut R{d_enc, 64, 0, sub0 * 32, j, h, M};
         const auto r = dense<P, 16, 2, L::ENC_START>(ws, BWD_LDS_ZERO, IN_B, R, prev_of(d, O0));
         r.flush(R);
@@ -1545,9 +1579,40 @@ int bwd_grid(int64_t n_tiles) {
 #ifndef REF_FUSED_CHAINS
 #define REF_FUSED_CHAINS 1
 #endif
-#if BWD_TU != 1
+// TU 3 (round 4): the Ref-NeRF DIRECTIONAL chain alone, compiled WITHOUT -amdgpu-mfma-vgpr-form: with the bit-mask functor hipcc's
+// AGPR-copy rewrite pass segfaults on this one kernel (AMDGPURewriteAGPRCopyMFMA, eliminateSpillsOfReassignedVGPRs); without the flag it
+// compiles with 65 spilled registers (91 in round 3's activation-mask form with the flag).
+#if BWD_TU == 3 || BWD_TU == 0
 template <class P>
-int launch_chain_t(int which, const char* stream, int64_t M, const char* act, char* dlt, size_t ls, float* rows, hipStream_t st) {
+int launch_dir_chain_t(const char* stream, int64_t M, const char* masks, size_t ms, char* dlt, size_t ls, float* rows, hipStream_t st) {
+    constexpr int TS = P::NW * P::NT * 32;
+    const int64_t n_tiles = (M + TS - 1) / TS;
+    if (n_tiles == 0) return 0;
+    const size_t lds = bwd_lds_total<P>();
+    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_chain9_kernel<P, false>), lds)) return e;
+    hipLaunchKernelGGL((ref_chain9_kernel<P, false>), dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, stream, M, masks, (unsigned long long)ms, dlt,
+                       (unsigned long long)ls, rows);
+    return (int)hipGetLastError();
+}
+}  // namespace
+int bwd_launch_dir_chain(int precision, const char* stream, int64_t M, const char* masks, size_t ms, char* dlt, size_t ls, float* rows, hipStream_t st) {
+    if (precision == NERF_AMD_BF16) return launch_dir_chain_t<PB16>(stream, M, masks, ms, dlt, ls, rows, st);
+    return launch_dir_chain_t<PF32>(stream, M, masks, ms, dlt, ls, rows, st);
+}
+#if BWD_TU != 3
+namespace {
+#endif
+#endif
+#if BWD_TU == 2
+}  // namespace
+int bwd_launch_dir_chain(int precision, const char* stream, int64_t M, const char* masks, size_t ms, char* dlt, size_t ls, float* rows, hipStream_t st);
+namespace {
+#endif
+#if BWD_TU != 1 && BWD_TU != 3
+template <class P>
+int launch_chain_t(int which, const char* stream, int64_t M, const char* act, char* dlt, size_t ls, size_t ms, float* rows, hipStream_t st) {
+    // the forward's ReLU bit-mask records sit behind the activation slots of its dump (17 slots for Ref-NeRF, 5 for the proposal network)
+    const char* masks = act + (size_t)(which == 3 ? PROP_DUMP_SLOTS : REF_DUMP_SLOTS) * ls;
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
@@ -1559,21 +1624,19 @@ int launch_chain_t(int which, const char* stream, int64_t M, const char* act, ch
     return 0;
 #else
     switch (which) {
-        case 0:
-            if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_chain9_kernel<P, false>), lds)) return e;
-            hipLaunchKernelGGL((ref_chain9_kernel<P, false>), grid, block, lds, st, stream, M, act, dlt, (unsigned long long)ls, rows);
-            break;
+        case 0:                                                // (its own translation unit: see bwd_launch_dir_chain)
+            return bwd_launch_dir_chain(P::PREC, stream, M, masks, ms, dlt, ls, rows, st);
         case 1:
             if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_spa_bwd_kernel<P>), lds)) return e;
-            hipLaunchKernelGGL((ref_spa_bwd_kernel<P>), grid, block, lds, st, stream, M, act, dlt, (unsigned long long)ls);
+            hipLaunchKernelGGL((ref_spa_bwd_kernel<P>), grid, block, lds, st, stream, M, masks, (unsigned long long)ms, dlt, (unsigned long long)ls);
             break;
         case 2:
             if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(ref_chain9_kernel<P, true>), lds)) return e;
-            hipLaunchKernelGGL((ref_chain9_kernel<P, true>), grid, block, lds, st, stream, M, act, (char*)nullptr, (unsigned long long)ls, rows);
+            hipLaunchKernelGGL((ref_chain9_kernel<P, true>), grid, block, lds, st, stream, M, masks, (unsigned long long)ms, (char*)nullptr, (unsigned long long)ls, rows);
             break;
         default:
             if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(prop_density_chain_kernel<P>), lds)) return e;
-            hipLaunchKernelGGL((prop_density_chain_kernel<P>), grid, block, lds, st, stream, M, act, (unsigned long long)ls, rows);
+            hipLaunchKernelGGL((prop_density_chain_kernel<P>), grid, block, lds, st, stream, M, masks, (unsigned long long)ms, rows);
     }
     return (int)hipGetLastError();
 #endif
@@ -1582,15 +1645,16 @@ int launch_chain_t(int which, const char* stream, int64_t M, const char* act, ch
 // chain's stream begins in the blob
 }  // namespace
 size_t mlp_train_layer_stride(int precision, int64_t M);
+size_t mlp_train_mask_stride(int precision, int64_t M);
 int bwd_launch_chain(int which, int precision, const void* blob, int start_frag, int64_t M, const void* act, void* dlt, float* rows, hipStream_t st) {
     const size_t fb = precision == NERF_AMD_BF16 ? 1024 : 2048;
     const char* stream = reinterpret_cast<const char*>(blob) + (size_t)start_frag * fb;
-    const size_t ls = mlp_train_layer_stride(precision, M);
-    if (precision == NERF_AMD_BF16) return launch_chain_t<PB16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, rows, st);
-    return launch_chain_t<PF32>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, rows, st);
+    const size_t ls = mlp_train_layer_stride(precision, M), ms = mlp_train_mask_stride(precision, M);
+    if (precision == NERF_AMD_BF16) return launch_chain_t<PB16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
+    return launch_chain_t<PF32>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
 }
-#endif  // BWD_TU != 1
-#if BWD_TU != 2
+#endif  // BWD_TU != 1 && != 3
+#if BWD_TU != 2 && BWD_TU != 3
 #if BWD_TU == 1
 }  // namespace
 int bwd_launch_chain(int which, int precision, const void* blob, int start_frag, int64_t M, const void* act, void* dlt, float* rows, hipStream_t st);
@@ -2075,4 +2139,4 @@ int bwd_launch_adam(float* const* p, const float* const* g, float* const* m, flo
     }
     return (int)hipGetLastError();
 }
-#endif  // BWD_TU != 2
+#endif  // BWD_TU != 2 && != 3

@@ -394,8 +394,8 @@ static bool bad_train_prec(int p, int net = NERF_AMD_NET_MIP) {           // the
 }
 size_t nerf_amd_train_dump_bytes(int net, int precision, int64_t M) {
     if (M < 0 || !train_layers(net) || bad_train_prec(precision, net)) return 0;
-    // activation slots + (proposal / MipNeRF) one ReLU bit per activation: 1 KiB per slot and 32-sample subtile
-    const size_t bits = net == NERF_AMD_NET_REF ? 0 : (size_t)train_layers(net) * mlp_train_mask_stride(precision, M);
+    // activation slots + one ReLU bit per activation: 1 KiB per slot and 32-sample subtile (Ref-NeRF too since round 4)
+    const size_t bits = (size_t)train_layers(net) * mlp_train_mask_stride(precision, M);
     return (size_t)train_layers(net) * mlp_train_layer_stride(precision, M) + bits;
 }
 int nerf_amd_proposal_forward_train(const void* packed, int precision, const nerf_amd_samples* src, float* density, void* dump, void* stream) {

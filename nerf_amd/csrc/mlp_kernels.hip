@@ -1037,9 +1037,25 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
         int lay = 0, lay_pend = 0;                                  // training dump slots of the layer being computed / of the pending pair
         const int64_t sub0 = tile * (TS / 32) + wave * NT;
         // (`lay` = the layer whose block pairs are being computed, `lay_pend` = the layer that owns the deferred pair, see proposal_kernel)
+        // TRAIN (round 4): next to the activations, ONE ReLU bit per activation for the dgrad chains (32 B per sample and layer instead of
+        // the 512 B of activations they re-read as masks until round 3: -38 GB of the 156 GB a 2^14-ray step moved).  Same record layout as
+        // the proposal / MipNeRF forwards' (mask_or), but accumulated in ONE REGISTER per column tile instead of an LDS record -- this
+        // kernel's LDS is full (ring 48 + biases 16.75 + stash 88 KiB): the four K groups of a feature-block pair are converted back to back
+        // (pair p = K groups 4p .. 4p+3 = dword p of the lane's 16-byte record), so the dword is complete, stored and cleared at kg & 3 == 3.
+        uint32_t mreg[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mreg[t] = 0u;
         auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
-            buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
-            if constexpr (TRAIN) dump_breg<P>(dump, layer, sub0 + t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+            const int kg = 2 * fb + half;
+            buf[t][kg] = to_breg_half<P, true>(acc, half);
+            if constexpr (TRAIN) {
+                dump_breg<P>(dump, layer, sub0 + t, kg, lane, buf[t][kg]);
+                mreg[t] |= breg_bits(buf[t][kg]) << (4 * (kg & 3));
+                if ((kg & 3) == 3) {
+                    *reinterpret_cast<uint32_t*>(dump.mask_base + (size_t)layer * dump.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16 + (kg >> 2) * 4) = mreg[t];
+                    mreg[t] = 0u;
+                }
+            }
         };
         auto OA = [&](int fb, int t, const f32x16& acc, int half) { put(a, lay, fb, t, acc, half); };
         auto OB = [&](int fb, int t, const f32x16& acc, int half) { put(b, lay, fb, t, acc, half); };
@@ -1384,7 +1400,7 @@ int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s,
 // training forward of Ref-NeRF: activation dump (REF_DUMP_SLOTS slots of mlp_train_layer_stride bytes) + aux (M,16)
 int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
                          void* dump, float* aux, int flags, hipStream_t st) {
-    const ActDump d{reinterpret_cast<char*>(dump), (unsigned long long)mlp_train_layer_stride(precision, s.M), nullptr, 0ull};
+    const ActDump d = make_dump(dump, precision, s.M, REF_DUMP_SLOTS);     // 17 activation slots + (round 4) their ReLU bit-mask records
     if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
     return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
 }
