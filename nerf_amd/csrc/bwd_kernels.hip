@@ -805,7 +805,28 @@ __global__ void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_st
         const int j = (int)(m & 31);
 #pragma unroll
         for (int f = 0; f < 16; ++f) store_slot_feature<ELEM>(sub + 8 * BREG, j, f, f < 11 ? dh[f] : 0.0f);
-        for (int f = 0; f < 128; ++f) store_slot_feature<ELEM>(sub + (f >> 4) * BREG, j, f & 15, da[f]);
+    }
+    // delta of the bottle-neck = d_allin[:, 0:128] -> K groups 0..7 in fragment order.  Round 4: one work item per (subtile, K group, lane)
+    // -- the lane's 8 features of its sample are two aligned float4 reads of the row and ONE 16-byte slot of the fragment block, so a wave
+    // writes 1 KiB contiguously (it was 128 strided scalar reads and 128 two-byte scattered stores per sample inside the loop above:
+    // 1.7 ms per 2^14-ray step).
+    const int64_t n_items = ((M + 31) / 32) * 8 * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), kg = (int)((i >> 6) & 7);
+        const int64_t sb = i >> 9, m = sb * 32 + (lane & 31);
+        if (m >= M) continue;
+        const float* da = d_allin + m * ld + 16 * kg + 4 * (lane >> 5);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(da), hi = *reinterpret_cast<const f32x4*>(da + 8);
+        char* blk = frag + (size_t)sb * sub_stride + (size_t)kg * BREG;
+        if (ELEM == 2) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (__bf16)lo[e]; v[4 + e] = (__bf16)hi[e]; }
+            *reinterpret_cast<bf16x8*>(blk + lane * 16) = v;
+        } else {
+            *reinterpret_cast<f32x4*>(blk + lane * 16) = lo;
+            *reinterpret_cast<f32x4*>(blk + 1024 + lane * 16) = hi;
+        }
     }
 }
 
