@@ -118,18 +118,26 @@ def launch_or_verify(a):
 
 
 def launch_check(a, world, rank):
-    """Everything the N-rank path does around the GPU work, on CPU tensors: process group, barriers, max-over-ranks."""
+    """Everything the N-rank path does around the GPU work, on CPU tensors (the world-size-2 gloo test of tests/test_multiprocess.py):
+    process group, the Comm helper of the real modes -- barriers, max-over-ranks, the per-rank gathers of a self-contained N > 1 line,
+    the wait of the other ranks while rank 0 measures alone -- and the one JSON line from rank 0."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
     assert dist.get_world_size() == a.gpus
-    dist.barrier()
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    comm = Comm(dist, world, rank, "gloo", torch.device("cpu"))
+    comm.dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                            # "the timed region": rank r takes (r + 1) x 10 ms
+    local_dt = time.perf_counter() - t0
+    dt = comm.max_over_ranks(local_dt)
+    spread = rank_spread(comm, local_dt, 1)
+    streams = comm.gather({"rank": rank, "tflops": 1000.0 + rank})
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(t.item())}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+        time.sleep(0.2)                                      # rank 0's extras (cpu_baseline, train_step): the others wait in comm.finish()
+        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(world),
+                          "ms_per_step": dt * 1e3, "ms_per_step_ranks": spread, "per_rank": streams}), flush=True)
+    comm.finish()
 
 
 class Comm:

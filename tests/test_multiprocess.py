@@ -107,6 +107,11 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["max_over_ranks"] == 2.0
+    # the helpers every real mode builds its N > 1 line with: per-rank step times (rank r sleeps (r + 1) x 10 ms), max over the ranks, gathers
+    sp = rec["ms_per_step_ranks"]
+    assert len(sp["all"]) == 2 and sp["all"][1] > sp["all"][0] >= 9.0 and sp["min"] == min(sp["all"]) and sp["max"] == max(sp["all"])
+    assert abs(rec["ms_per_step"] - sp["max"]) < 1e-6
+    assert [r["rank"] for r in rec["per_rank"]] == [0, 1]
 
 
 def test_bench_refuses_fewer_ranks_than_asked():
