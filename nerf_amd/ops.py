@@ -130,7 +130,10 @@ class _Lease:
         _ARENA_BUSY.add(key)
 
     def __del__(self):
-        _ARENA_BUSY.discard(self.key)
+        try:
+            _ARENA_BUSY.discard(self.key)
+        except Exception:                                      # (interpreter shutdown: the module's globals may be gone already)
+            pass
 
 
 def leased(tag, nbytes: int, device) -> torch.Tensor:
