@@ -2114,7 +2114,7 @@ def test_narrow_mip_tile_policy(A, width):
                     want = O.mip_forward(msd, pts.cpu(), emulate_bf16=(P == A.ops.BF16))
                 scale = max(1.0, want.abs().max().item())
                 assert max_abs(got_n.cpu(), want) <= tol * scale, (width, P, M)
-    rays, u1, u2 = _rays_and_u(600, 128, 17)
+    rays, u1, u2 = _rays_and_u(200, 128, 17)
     z_base = torch.linspace(NEAR, FAR, 64).cuda()
     for P in (A.ops.F32, A.ops.BF16):
         a = A.ops.render_rays(prop.packed(P), mip.packed(P), P, dev(rays), z_base, dev(u1), dev(u2), 128, NEAR, FAR, True, want_depth=True, want_weights=True)
@@ -2129,10 +2129,10 @@ def test_narrow_mip_tile_policy(A, width):
     a = A.ops.render_rays(prop.packed(A.ops.F32), mip.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 128, NEAR, FAR, True, want_weights=True)
     assert max_abs(a[0].cpu(), want_rgb) <= tol_img and max_abs(a[2].cpu(), want_w) <= tol_img and tol_img <= 5e-4
     # the narrow layout has no integrated-PE kernel: the C-ABI refuses the combination, the module hands out its 256-wide blob for it
-    z = torch.sort(torch.rand(600, 129, generator=gen) * 4 + 2, dim=-1)[0].cuda()
+    z = torch.sort(torch.rand(200, 129, generator=gen) * 4 + 2, dim=-1)[0].cuda()
     dn = A.ops.dirs_norm(dev(rays))
     with pytest.raises(RuntimeError):
-        A.ops.mip_forward_samples(mip.packed(A.ops.F32), A.ops.F32, A.ops.samples_rays(dev(rays), 128, z=z, ipe_radius=1e-3, ipe_dir_norm=dn), (600, 128), "cuda")
+        A.ops.mip_forward_samples(mip.packed(A.ops.F32), A.ops.F32, A.ops.samples_rays(dev(rays), 128, z=z, ipe_radius=1e-3, ipe_dir_norm=dn), (200, 128), "cuda")
     with torch.no_grad():
         out = mip.forward_rays(dev(rays), z, 128, ipe_radius=1e-3)
-    assert out.shape == (600, 128, 4) and bool(torch.isfinite(out).all())
+    assert out.shape == (200, 128, 4) and bool(torch.isfinite(out).all())
