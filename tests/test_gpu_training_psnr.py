@@ -71,8 +71,12 @@ def run_oracle(views, seed, resume=None):
     opt = torch.optim.Adam(list(mip.values()) + list(prop.values()), lr=LR)
     res = (FAR - NEAR) / C_N
     hist, held, start = [], [], 0
+    recipe = (H, C_N, F_N, RAYS, ITERS, float(LR), N_HELD, len(views), int(seed))
     if resume is not None and os.path.exists(resume):
         st = torch.load(resume, weights_only=False)
+        # a state file of ANOTHER recipe must never be continued (round 4 lost three CPU runs to round 3's files of the same names)
+        if tuple(st.get("recipe", ())) != recipe:
+            raise RuntimeError("run_oracle: %s holds the state of another recipe %s (this run: %s) -- use a fresh --resume-dir" % (resume, st.get("recipe"), recipe))
         with torch.no_grad():
             for k, v in st["prop"].items():
                 prop[k].copy_(v)
@@ -84,7 +88,7 @@ def run_oracle(views, seed, resume=None):
     for it in range(start, ITERS):
         if resume is not None and it > start and it % 250 == 0:
             torch.save({"prop": {k: v.detach() for k, v in prop.items()}, "mip": {k: v.detach() for k, v in mip.items()}, "opt": opt.state_dict(),
-                        "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": it}, resume + ".tmp")
+                        "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": it, "recipe": recipe}, resume + ".tmp")
             os.replace(resume + ".tmp", resume)
         rays_all, rgb_all = views[it % (len(views) - N_HELD)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,))
