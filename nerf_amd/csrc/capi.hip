@@ -700,7 +700,7 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     const uint64_t seed = camera ? camera->rng_seed : 0;
     const int64_t ray0 = camera ? camera->rng_ray_offset : 0;
     if ((normal_img != nullptr) != (cam_dir != nullptr)) return fail(NERF_AMD_EINVAL, "normal_img and cam_dir go together");
-    if (camera && camera->contract) return fail(NERF_AMD_EINVAL, "scene contraction is wired for the MipNeRF path only");
+    const int contract = camera ? camera->contract : 0;    // (round 4: a flag of the sample fetch for this path too; the build's own definition)
     constexpr int C = 64;                                   // procedures.py:22 RENDER_COARSE_PNUM
     const int S_all = n_fine + C;                           // (n_fine + 1) fine + 64 coarse depths, the last one dropped
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
@@ -724,6 +724,7 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     nerf_amd_samples sc{};                                  // rows 2-4
     sc.mode = 1; sc.rays = rays; sc.S = C; sc.M = N * C; sc.z = nullptr; sc.z_base = z_base; sc.u = u_strat;
     sc.z_jitter = jitter; sc.z_stride = C;
+    sc.contract = contract;
     sc.rng_seed = seed; sc.rng_ray_offset = ray0;          // (read only when u_strat == NULL)
     if (int e = launch_proposal_any(lflags, packed_prop, precision, sc, density, st)) return hip_status(e, "proposal MLP");
     // rows 5-7 (procedures.py:68-70), also returning the stratified depths the proposal pass used
@@ -733,6 +734,7 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     if (int e = sk_merge_sorted(z_fine, z_coarse, N, n_fine + 1, C, z_all, st)) return hip_status(e, "depth merge");
     nerf_amd_samples sf{};                                  // row 13
     sf.mode = 1; sf.rays = rays; sf.S = S_all; sf.M = N * S_all; sf.z = z_all; sf.z_stride = S_all;
+    sf.contract = contract;
     if (int e = mlp_launch_ref(packed_ref, precision, sf, rgbo, normal_img ? normals : nullptr, nullptr, ref_flags, st)) return hip_status(e, "Ref-NeRF MLP");
     const int flags = 1 | (white_bkg ? 2 : 0);              // row 10 with sigma -> softplus(sigma + 0.5) (procedures.py:73)
     if (int e = sk_composite(rgbo, z_all, S_all, rays + 3, 6, N, S_all, flags, NERF_AMD_ACT_SOFTPLUS, 0.5f, near, far,

@@ -639,7 +639,7 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
 def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                     want_depth=True, cam_dir: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
                     camera: Optional[Samples] = None, ray_offset: int = 0, n_rays: Optional[int] = None, flags: int = 0,
-                    seed: Optional[int] = None, rng_ray_offset: int = 0):
+                    seed: Optional[int] = None, rng_ray_offset: int = 0, contract: bool = False):
     """The tile body of render_image for a Ref-NeRF fine network (procedures.py:64-85, is_ref_model branch) in six launches.
     `cam_dir` (3,) = render_pose[:, -2] asks for the normal image (procedures.py:79-81).  u_strat = u_inv = None with `seed`: in-kernel
     uniforms as in render_rays."""
@@ -653,6 +653,10 @@ def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u
         camera.rng_seed, camera.rng_ray_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_ray_offset)
     else:
         dev = u_strat.device
+    if contract:                                             # Mip-NeRF 360 scene contraction of every sample position (the build's own definition)
+        if camera is None:
+            camera = Samples()
+        camera.contract = 1
     N = n_rays if n_rays is not None else (rays.shape[0] if in_kernel_rng else u_strat.shape[0])
     need = lib.nerf_amd_render_ref_workspace_bytes(N, n_fine)
     if workspace is None or workspace.numel() < need:

@@ -99,15 +99,13 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
                                            sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,
                                            ipe_radius=ipe_radius, seed=seed)
     else:
-        if contract:
-            raise NotImplementedError("nerf_amd: scene contraction is wired for the MipNeRF render path only")
         # Ref-NeRF branch (procedures.py:71-74): coarse and fine depths are merged and sorted, the last one dropped,
         # sigma -> softplus(sigma + 0.5) before compositing (nerf_amd_render_rays_ref: six launches; the sort is a merge of two
         # ascending sets).
         rgb, depth, normal_px, _ = ops.render_rays_ref(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
                                                        sample_num, near, far, white_bkg, want_depth=bool(render_depth),
                                                        cam_dir=render_pose[:, -2].contiguous() if render_normal else None, flags=network.kernel_flags,
-                                                       seed=seed)
+                                                       seed=seed, contract=contract)
 
     def to_image(t, ch):
         if sz is None:

@@ -719,15 +719,19 @@ def ref_train_step(prop_sd, ref_sd, rays: Tensor, z_coarse: Tensor, u_inv: Tenso
 
 
 def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float, sample_num: int = 128,
-                    white_bkg: bool = False, cam_z: Optional[Tensor] = None, use_srgb: bool = False):
+                    white_bkg: bool = False, cam_z: Optional[Tensor] = None, use_srgb: bool = False, contracted: bool = False):
     """Tile body of render_image for a RefNeRF (procedures.py:64-85, is_ref_model branch): coarse+fine merge, sigma ->
     softplus(sigma + 0.5), composite with relu (a no-op after softplus)."""
     z_c = stratified_render(near, far, sample_num, u_strat)
     pts_c = rays[:, None, :3] + z_c[..., None] * rays[:, None, 3:]
+    if contracted:                                           # (not in the reference: the build's own definition, as in render_rays)
+        pts_c = contract(pts_c)
     density = proposal_forward(prop_sd, pts_c)
     w_prop = max_blur(sigma_to_weights(density, z_c, rays[:, 3:]), 0.01)
     z_f, _ = inverse_sample(w_prop, z_c, u_inv, sort=True)
     samples, z_all = coarse_fine_merge(rays, z_c, z_f)
+    if contracted:
+        samples = torch.cat((contract(samples[..., :3]), samples[..., 3:]), dim=-1)
     rgbo, normal = ref_forward(ref_sd, samples, use_srgb=use_srgb)
     rgbo = torch.cat((rgbo[..., :3], F.softplus(rgbo[..., 3:] + 0.5)), dim=-1)
     rgb, w, extras = composite(rgbo, z_all, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far),

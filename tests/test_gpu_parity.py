@@ -1496,9 +1496,9 @@ def test_render_rays_ref_equals_the_separate_entry_points(A, prec):
         assert torch.equal(rgb3, want_rgb) and torch.equal(depth3, want_depth) and torch.equal(nimg3, want_nimg)
         with pytest.raises(RuntimeError, match="ray range"):
             ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, camera=cam, ray_offset=H * Wd - 10, n_rays=N)
-        cam.contract = 1
-        with pytest.raises(RuntimeError, match="contraction"):
-            ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, camera=cam, ray_offset=lo, n_rays=N)
+        cam.contract = 1                                        # (round 4: accepted -- test_refnerf_render_with_scene_contraction checks the values)
+        rgb_c, _, _, _ = ops.render_rays_ref(prop.packed(P), net.packed(P), P, None, z_base, u1, u2, n_fine, NEAR, FAR, True, camera=cam, ray_offset=lo, n_rays=N)
+        assert bool(rgb_c.isfinite().all())
     assert (rgb.isfinite().all() and 0.0 < rgb.std().item())
     A.pkg.set_precision("fp32")
 
@@ -2136,3 +2136,31 @@ def test_narrow_mip_tile_policy(A, width):
     with torch.no_grad():
         out = mip.forward_rays(dev(rays), z, 128, ipe_radius=1e-3)
     assert out.shape == (200, 128, 4) and bool(torch.isfinite(out).all())
+
+
+def test_refnerf_render_with_scene_contraction(A):
+    """Mip-NeRF 360 scene contraction on the Ref-NeRF render path (round 4: a flag of the sample fetch of nerf_amd_render_rays_ref too; it
+    used to raise).  Not in the reference -- the build's own definition, oracle.render_rays_ref(contracted=True): every sample position,
+    proposal and merged fine, is contracted before its encoding.  fp32 against the oracle on unbounded depths, the flag really changes
+    the image, and the drop-in render_image accepts it for a RefNeRF."""
+    prop, _ = build_nets(A, "small")
+    net = build_ref(A, "small")
+    near, far = 0.2, 30.0
+    rays, u1, u2 = _rays_and_u(300, 64, 41)
+    rays = rays.clone(); rays[:, :3] *= 0.3                                   # cameras inside the unit ball, samples far outside it
+    z_base = torch.linspace(near, far, 64).cuda()
+    cam = torch.tensor([0.0, 0.6, -0.8])
+    with torch.no_grad():
+        want_rgb, _, extras = O.render_rays_ref(W.proposal_state("small"), W.ref_state("small"), rays, u1, u2, near, far, 64, white_bkg=True, cam_z=cam,
+                                                contracted=True)
+    rgb, depth, nimg, _ = A.ops.render_rays_ref(prop.packed(A.ops.F32), net.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 64, near, far, True,
+                                                want_depth=True, cam_dir=cam.cuda(), contract=True)
+    plain, _, _, _ = A.ops.render_rays_ref(prop.packed(A.ops.F32), net.packed(A.ops.F32), A.ops.F32, dev(rays), z_base, dev(u1), dev(u2), 64, near, far, True)
+    assert max_abs(rgb.cpu(), want_rgb) <= 1e-4 and max_abs(nimg.cpu(), extras["normal_img"]) <= 1e-4
+    assert max_abs(depth.cpu(), extras["depth_img"]) <= 1e-3
+    assert float((rgb - plain).abs().max()) > 5e-6                             # (reference-style weights: a small but real effect)
+    A.pkg.set_precision("fp32")
+    pose = A.utils.pose_spherical(20.0, -25.0, 0.4)[:3].cuda()
+    with torch.no_grad():
+        out = A.procedures.render_image(net, prop, pose, 50, 60.0, near, far, 64, white_bkg=True, contract=True)
+    assert out["rgb"].shape == (3, 50, 50) and bool(torch.isfinite(out["rgb"]).all())
