@@ -35,6 +35,21 @@ class PackedWeightsMixin:
         """(out, in) of every tensor in _linear_layers() order as the kernels expect them; None = the module's own shapes"""
         return None
 
+    # ---- other positional-encoding depths / cat_origin=False ---------------------------------------------------------------------------
+    # The kernels evaluate the encoding [x | sin 2^0 x | cos 2^0 x | ... | sin 2^9 x | cos 2^9 x] (nerf_helper.py:38-48 behind the raw
+    # position, mip_model.py:50-52) in registers.  A module built with FEWER octaves, or without the raw position (cat_origin=False), is
+    # the same function as the compiled one with ZERO weights on the encoding columns it does not have -- every encoding value is finite,
+    # so the added products are exact zeros.  Its weight columns are therefore not padded at the end but placed: `_column_segments()` lists,
+    # per tensor, (kernel column, module column, count) runs; gradients come back through the same runs.
+    def _column_segments(self):
+        """per tensor of _linear_layers(): None (columns are padded at the end) or [(kernel column, module column, count), ...]"""
+        return None
+
+    @staticmethod
+    def encoding_segment(levels: int, cat_origin: bool, kernel_col: int = 0, module_col: int = 0):
+        """the run of one [raw 3 | 6 L] encoding block: L octaves are the first 6 L encoding columns of any deeper encoding"""
+        return (kernel_col, module_col, 3 + 6 * levels) if cat_origin else (kernel_col + 3, module_col, 6 * levels)
+
     def kernel_params(self, shapes=None):
         """-> (weights, biases) in the kernels' shapes (the parameters themselves when nothing is padded); `shapes` overrides
         _kernel_weight_shapes() (the narrow-tile layout of a network)"""
@@ -44,13 +59,18 @@ class PackedWeightsMixin:
         if shapes is None or all(tuple(w.shape) == tuple(s) for w, s in zip(ws, shapes)):
             return ws, bs
         pw, pb = [], []
+        segs = self._column_segments() or [None] * len(ws)
         with torch.no_grad():
-            for w, b, s in zip(ws, bs, shapes):
+            for w, b, s, seg in zip(ws, bs, shapes, segs):
                 if tuple(w.shape) == tuple(s):
                     pw.append(w); pb.append(b)
                     continue
                 W = torch.zeros(tuple(s), dtype=w.dtype, device=w.device)
-                W[: w.shape[0], : w.shape[1]] = w
+                if seg is None:
+                    W[: w.shape[0], : w.shape[1]] = w
+                else:
+                    for kc, mc, n in seg:
+                        W[: w.shape[0], kc: kc + n] = w[:, mc: mc + n]
                 B = torch.zeros((s[0],), dtype=b.dtype, device=b.device)
                 B[: b.shape[0]] = b
                 pw.append(W); pb.append(B)
@@ -59,7 +79,15 @@ class PackedWeightsMixin:
     def unpad_grads(self, gW, gb):
         """gradients in the kernels' shapes -> the parameters' shapes"""
         layers = self._linear_layers()
-        return ([g[: l.weight.shape[0], : l.weight.shape[1]] if tuple(g.shape) != tuple(l.weight.shape) else g for g, l in zip(gW, layers)],
+        segs = self._column_segments() or [None] * len(layers)
+
+        def cols(g, l, seg):
+            if tuple(g.shape) == tuple(l.weight.shape):
+                return g
+            if seg is None:
+                return g[: l.weight.shape[0], : l.weight.shape[1]]
+            return torch.cat([g[: l.weight.shape[0], kc: kc + n] for kc, _, n in seg], dim=1)
+        return ([cols(g, l, seg) for g, l, seg in zip(gW, layers, segs)],
                 [g[: l.bias.shape[0]] if tuple(g.shape) != tuple(l.bias.shape) else g for g, l in zip(gb, layers)])
 
     # ---- persistent gradient sinks ---------------------------------------------------------------------------------------------------

@@ -68,8 +68,14 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         return [self.layers[0], self.layers[2], self.layers[4], self.layers[6], self.layers[8]]
 
     def _check_config(self):
-        if not (self.position_flevel == 10 and 1 <= self.hidden_unit <= 256 and self.cat_origin):
-            raise NotImplementedError("nerf_amd: the HIP proposal kernel is instantiated for ProposalNetwork(10, hidden_unit <= 256, cat_origin=True)")
+        # position_flevel < 10 / cat_origin=False: the same kernels with zero weights on the encoding columns the module lacks (_packed.py)
+        if not (1 <= self.position_flevel <= 10 and 1 <= self.hidden_unit <= 256):
+            raise NotImplementedError("nerf_amd: the HIP proposal kernel is instantiated for ProposalNetwork(position_flevel <= 10, hidden_unit <= 256)")
+
+    def _column_segments(self):
+        if self.position_flevel == 10 and self.cat_origin:
+            return None
+        return [[self.encoding_segment(self.position_flevel, self.cat_origin)], None, None, None, None]
 
     def _kernel_weight_shapes(self):
         return [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]

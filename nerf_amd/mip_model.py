@@ -38,8 +38,20 @@ class MipNeRF(PackedWeightsMixin, NeRF):
                 self.rgb_layer[0], self.rgb_layer[2]]
 
     def _check_config(self):
-        if not (self.position_flevel == 10 and self.direction_flevel == 4 and 1 <= self.hidden_unit <= 256 and self.cat_origin):
-            raise NotImplementedError("nerf_amd: the HIP fine-MLP kernel is instantiated for MipNeRF(10, 4, hidden_unit <= 256, cat_origin=True)")
+        # position_flevel < 10 and cat_origin=False run on the same kernels with zero weights on the encoding columns the module lacks
+        # (_packed.py, `_column_segments`); the direction depth is 4 in the reference itself: rgb_layer.0 is built 280 (+3) wide
+        # (mip_model.py:34), so its own forward only runs with direction_flevel == 4.
+        if not (1 <= self.position_flevel <= 10 and self.direction_flevel == 4 and 1 <= self.hidden_unit <= 256):
+            raise NotImplementedError("nerf_amd: the HIP fine-MLP kernel is instantiated for MipNeRF(position_flevel <= 10, 4, hidden_unit <= 256)")
+
+    def _column_segments(self):
+        if self.position_flevel == 10 and self.cat_origin:
+            return None
+        L, cat, W = self.position_flevel, self.cat_origin, self.hidden_unit
+        enc = 6 * L + (3 if cat else 0)
+        seg = self.encoding_segment
+        return [[seg(L, cat)], None, None, None, [seg(L, cat), (63, enc, W)], None, None, None, None,
+                None if cat else [(0, 0, 256), seg(4, False, 256, 256)], None]
 
     def _kernel_weight_shapes(self):
         return [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (256, 256), (1, 256), (128, 283), (3, 128)]

@@ -55,11 +55,31 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         # T_d = 2, 5, 10 of level 4's 19 (ref_func.py:56-58 orders them by l), so the directional layers' weights are embedded into the
         # level-4 column layout [bottle-neck 128 | real 19 | imag 19 | n.d] with zeros on the terms the module does not have.  Level 5
         # (36 terms) does not fit the kernel's three IDE K groups.
-        ok = (self.position_flevel == 10 and 1 <= self.sh_max_level <= 4 and self.bottle_neck_dim == 128 and 1 <= self.hidden_unit <= 256
-              and self.output_dim == self.hidden_unit and self.cat_origin)
+        # position_flevel < 10 / cat_origin=False: zero weights on the position-encoding columns the module lacks (_embed_pos, as in _packed.py)
+        ok = (1 <= self.position_flevel <= 10 and 1 <= self.sh_max_level <= 4 and self.bottle_neck_dim == 128 and 1 <= self.hidden_unit <= 256
+              and self.output_dim == self.hidden_unit)
         if not ok:
-            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(10, ide_level 1..4, 128, hidden_unit = output_dim <= 256) "
-                                      "(use_srgb on or off)")
+            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(position_flevel <= 10, ide_level 1..4, 128, "
+                                      "hidden_unit = output_dim <= 256) (use_srgb on or off)")
+
+    def _pos_segment(self):
+        return self.encoding_segment(self.position_flevel, self.cat_origin)
+
+    def _embed_pos(self, w: torch.Tensor) -> torch.Tensor:
+        """spa_block{1,2}.0 weight (rows, enc [+ hidden]) -> (rows, 63 [+ hidden]): the module's encoding columns placed in the level-10 layout"""
+        if self.position_flevel == 10 and self.cat_origin:
+            return w
+        kc, mc, n = self._pos_segment()
+        out = torch.zeros((w.shape[0], 63 + w.shape[1] - n), dtype=w.dtype, device=w.device)
+        out[:, kc: kc + n] = w[:, :n]
+        out[:, 63:] = w[:, n:]
+        return out
+
+    def _extract_pos(self, g: torch.Tensor) -> torch.Tensor:
+        if self.position_flevel == 10 and self.cat_origin:
+            return g
+        kc, mc, n = self._pos_segment()
+        return torch.cat((g[:, kc: kc + n], g[:, 63:]), dim=1)
 
     def _dir_cols(self):
         """column of the level-4 directional input vector (167 wide) that each of the module's 128 + 2 T + 1 directional inputs occupies"""
@@ -115,6 +135,7 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         bs = [l.bias for l in lin] + [hb] + [l.bias for l in tail]
         if self.sh_max_level != 4:
             ws[10], ws[14] = self._embed_dir(ws[10].detach()), self._embed_dir(ws[14].detach())       # dir_block1.0, dir_block2.0
+        ws[0], ws[4] = self._embed_pos(ws[0].detach()), self._embed_pos(ws[4].detach())               # spa_block1.0, spa_block2.0
         if self.hidden_unit != 256:                          # zero-padded to the compiled 256-wide shapes: the same function (hidden features are
             with torch.no_grad():                            # always the LAST column segment of a layer's input, so the padding goes at the end)
                 ws = [self._pad_to(w.detach(), sh) for w, sh in zip(ws, self._KERNEL_SHAPES)]
@@ -165,6 +186,8 @@ class RefNeRF(PackedWeightsMixin, NeRF):
                 if self.sh_max_level != 4:
                     for k_ in ("dir_block1.0.weight", "dir_block2.0.weight"):
                         by_name[k_] = self._extract_dir(by_name[k_])
+                for k_ in ("spa_block1.0.weight", "spa_block2.0.weight"):
+                    by_name[k_] = self._extract_pos(by_name[k_])
                 shapes = {n: p_.shape for n, p_ in named}                 # (narrow networks: the padded rows / columns are the discarded part)
                 return (None, None, *[by_name[n][tuple(slice(0, k) for k in shapes[n])] if tuple(by_name[n].shape) != tuple(shapes[n]) else by_name[n]
                                       for n in names])

@@ -156,26 +156,28 @@ def _linear(x: Tensor, w: Tensor, b: Tensor, emulate_bf16: bool) -> Tensor:
     return F.linear(x, w, b)
 
 
-def proposal_forward(sd: Dict[str, Tensor], pts: Tensor, L: int = 10, emulate_bf16: bool = False) -> Tensor:
+def proposal_forward(sd: Dict[str, Tensor], pts: Tensor, L: int = 10, emulate_bf16: bool = False, cat_origin: bool = True) -> Tensor:
     """ProposalNetwork.forward: [x, PE_L(x)] -> 4x(Linear+ReLU) -> Linear(.,1).  addtional.py:67-71,88-96.
-    pts (N, C, 3) -> density (N, C) (no activation)."""
-    h = torch.cat((pts, positional_encoding(pts, L)), dim=-1)
+    pts (N, C, 3) -> density (N, C) (no activation).  `cat_origin` = the constructor flag (addtional.py:61,93-94: the raw position in front)."""
+    h = torch.cat((pts, positional_encoding(pts, L)), dim=-1) if cat_origin else positional_encoding(pts, L)
     for i in (0, 2, 4, 6):
         h = F.relu(_linear(h, sd[f"layers.{i}.weight"], sd[f"layers.{i}.bias"], emulate_bf16))
     return _linear(h, sd["layers.8.weight"], sd["layers.8.bias"], emulate_bf16).squeeze(-1)
 
 
 def mip_forward(sd: Dict[str, Tensor], pts: Tensor, Lp: int = 10, Ld: int = 4, emulate_bf16: bool = False,
-                encoded_x: Optional[Tensor] = None) -> Tensor:
+                encoded_x: Optional[Tensor] = None, cat_origin: bool = True) -> Tensor:
     """MipNeRF.forward (mip_model.py:41-60).  pts (N, S, 6) = [position | raw direction] -> (N, S, 4)
     = [sigmoid rgb | raw sigma].  Skip-cat order (enc, h) (:55); head-cat order (bottleneck, dir) (:59).
     ``encoded_x`` (not in the reference's forward): the 6 Lp encoding columns that follow the position, e.g. ipe_feature's output,
-    used instead of positional_encoding(x)."""
+    used instead of positional_encoding(x).  `cat_origin` = the constructor flag (mip_model.py:50-52: raw position / direction in front)."""
     x = pts[..., :3]
     d = pts[..., 3:6]
     d = d / d.norm(dim=-1, keepdim=True)
-    ex = torch.cat((x, positional_encoding(x, Lp) if encoded_x is None else encoded_x), dim=-1)
-    ed = torch.cat((d, positional_encoding(d, Ld)), dim=-1)
+    ex = positional_encoding(x, Lp) if encoded_x is None else encoded_x
+    ed = positional_encoding(d, Ld)
+    if cat_origin:
+        ex, ed = torch.cat((x, ex), dim=-1), torch.cat((d, ed), dim=-1)
     h = ex
     for i in (0, 2, 4, 6):
         h = F.relu(_linear(h, sd[f"lin_block1.{i}.weight"], sd[f"lin_block1.{i}.bias"], emulate_bf16))
@@ -203,18 +205,18 @@ def init_linear_params(shapes: Sequence[Tuple[str, int, int]], seed: int, std: f
     return sd
 
 
-def proposal_shapes(L: int = 10, hidden: int = 256):
-    i = 6 * L + 3
+def proposal_shapes(L: int = 10, hidden: int = 256, cat_origin: bool = True):
+    i = 6 * L + (3 if cat_origin else 0)
     return [("layers.0", hidden, i), ("layers.2", hidden, hidden), ("layers.4", hidden, hidden),
             ("layers.6", hidden, hidden), ("layers.8", 1, hidden)]
 
 
-def mip_shapes(Lp: int = 10, Ld: int = 4, hidden: int = 256):
-    i = 6 * Lp + 3
+def mip_shapes(Lp: int = 10, Ld: int = 4, hidden: int = 256, cat_origin: bool = True):
+    i = 6 * Lp + (3 if cat_origin else 0)
     return [("lin_block1.0", hidden, i), ("lin_block1.2", hidden, hidden), ("lin_block1.4", hidden, hidden),
             ("lin_block1.6", hidden, hidden), ("lin_block2.0", hidden, hidden + i), ("lin_block2.2", hidden, hidden),
             ("lin_block2.4", 256, hidden), ("bottle_neck.0", 256, 256), ("opacity_head.0", 1, 256),
-            ("rgb_layer.0", 128, 256 + 6 * Ld + 3), ("rgb_layer.2", 3, 128)]
+            ("rgb_layer.0", 128, 256 + 6 * Ld + (3 if cat_origin else 0)), ("rgb_layer.2", 3, 128)]
 
 
 # --------------------------------------------------------------------------------------------
@@ -604,8 +606,8 @@ def ide_encode(xyz: Tensor, kappa_inv: Tensor, deg_view: int = 4) -> Tensor:
     return torch.cat([torch.real(ide), torch.imag(ide)], dim=-1)
 
 
-def ref_shapes(Lp: int = 10, deg: int = 4, hidden: int = 256, bottle: int = 128, out_dim: int = 256):
-    i = 6 * Lp + 3
+def ref_shapes(Lp: int = 10, deg: int = 4, hidden: int = 256, bottle: int = 128, out_dim: int = 256, cat_origin: bool = True):
+    i = 6 * Lp + (3 if cat_origin else 0)
     enc = ((1 << deg) - 1 + deg) << 1
     din = 1 + bottle + enc
     s = [("spa_block1.0", hidden, i), ("spa_block1.2", hidden, hidden), ("spa_block1.4", hidden, hidden), ("spa_block1.6", hidden, hidden),
@@ -625,13 +627,13 @@ def linear_to_srgb(linear: Tensor) -> Tensor:
 
 
 def ref_forward(sd: Dict[str, Tensor], pts: Tensor, ray_d: Optional[Tensor] = None, Lp: int = 10, deg: int = 4,
-                emulate_bf16: bool = False, noise: Optional[Tensor] = None, use_srgb: bool = False):
+                emulate_bf16: bool = False, noise: Optional[Tensor] = None, use_srgb: bool = False, cat_origin: bool = True):
     """RefNeRF.forward (ref_model.py:68-106; `use_srgb`: lines 100-102 instead of 104-105).  pts (N,S,6) [or (N,S,3) + ray_d] ->
     ((N,S,4) = [rgb | raw density], normal (N,S,3)).  `noise` = the train-mode perturbation of the bottle-neck vector
     (ref_model.py:84-85: torch.normal(0, perturb_bottle_neck_w, shape)); None = eval mode."""
     lin = lambda name, t: _linear(t, sd[name + ".weight"], sd[name + ".bias"], emulate_bf16)
     x = pts[..., :3]
-    ex = torch.cat((x, positional_encoding(x, Lp)), dim=-1)
+    ex = torch.cat((x, positional_encoding(x, Lp)), dim=-1) if cat_origin else positional_encoding(x, Lp)      # ref_model.py:70-74
     h = ex
     for i in (0, 2, 4, 6):
         h = F.relu(lin(f"spa_block1.{i}", h))

@@ -73,10 +73,46 @@ def write_signatures():
     print("wrote g20_signatures.json (%d names)" % sum(len(v) for v in rec.values()))
 
 
+def write_shallow_encodings():
+    """G21: the reference's three networks built with FEWER encoding octaves and / or cat_origin=False (constructor arguments,
+    mip_model.py:15-18, addtional.py:61, ref_model.py:17-24) -- forward values and (the first 8 rows of) parameter gradients of sum(out * G) from the REAL modules.
+    States: oracle.init_linear_params on the oracle's shape tables (deterministic), so the test can rebuild them."""
+    from nerf import mip_model, addtional, ref_model
+    from oracle import nerf_oracle as O
+    g = torch.Generator().manual_seed(2121)
+    pts = torch.cat((torch.rand(6, 9, 3, generator=g) * 3 - 1.5, torch.randn(6, 9, 3, generator=g)), dim=-1)
+    pts[..., 3:] = pts[..., 3:] / pts[..., 3:].norm(dim=-1, keepdim=True)
+    G4, G1, G3 = torch.randn(6, 9, 4, generator=g), torch.randn(6, 9, generator=g), torch.randn(6, 9, 3, generator=g)
+    out = {"pts": pts, "G4": G4, "G1": G1, "G3": G3}
+    for L, cat, width in ((6, True, 256), (10, False, 256), (4, False, 96)):
+        tag = "L%d_%s_w%d" % (L, "cat" if cat else "nocat", width)
+        seed = 100 * L + width + int(cat)
+        mip = mip_model.MipNeRF(L, 4, hidden_unit=width, cat_origin=cat)
+        mip.load_state_dict(O.init_linear_params(O.mip_shapes(L, 4, width, cat), seed, std=0.08, bias_std=0.05))
+        y = mip.forward(pts)
+        (y * G4).sum().backward()
+        out[tag + "_mip"], out[tag + "_mip_g0"], out[tag + "_mip_gskip"], out[tag + "_mip_grgb"] = (
+            y, mip.lin_block1[0].weight.grad[:8], mip.lin_block2[0].weight.grad[:8], mip.rgb_layer[0].weight.grad[:8])
+        prop = addtional.ProposalNetwork(L, hidden_unit=width, cat_origin=cat)
+        prop.load_state_dict(O.init_linear_params(O.proposal_shapes(L, width, cat), seed + 1, std=0.08, bias_std=0.05))
+        d = prop.forward(pts[..., :3])
+        (d * G1).sum().backward()
+        out[tag + "_prop"], out[tag + "_prop_g0"] = d, prop.layers[0].weight.grad[:8]
+        ref = ref_model.RefNeRF(L, 4, hidden_unit=width, output_dim=width, cat_origin=cat); ref.eval()
+        ref.load_state_dict(O.init_linear_params(O.ref_shapes(L, 4, width, 128, width, cat), seed + 2, std=0.08, bias_std=0.05))
+        rgbo, nrm = ref.forward(pts)
+        ((rgbo * G4).sum() + (nrm * G3).sum()).backward()
+        out[tag + "_ref_rgbo"], out[tag + "_ref_normal"], out[tag + "_ref_g0"], out[tag + "_ref_gskip"] = (
+            rgbo, nrm, ref.spa_block1[0].weight.grad[:8], ref.spa_block2[0].weight.grad[:8])
+    npz("g21_shallow_encodings", **out)
+
+
 def main():
     install_shims()
     if "--signatures-only" in sys.argv:
         return write_signatures()
+    if "--shallow-only" in sys.argv:
+        return write_shallow_encodings()
     from nerf import nerf_helper, nerf_base, mip_methods, mip_model, addtional, utils, procedures
     import weights as W
 
@@ -408,6 +444,7 @@ def main():
         o19[tag + "_g_spa0"] = net.spa_block1[0].weight.grad[:8, :]
     npz("g19_refnerf_srgb", **o19)
 
+    write_shallow_encodings()
     write_signatures()
 
 

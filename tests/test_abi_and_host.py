@@ -82,7 +82,7 @@ def test_mip_module_param_count_and_order():
                                                                    (256, 256), (256, 256), (256, 256), (1, 256), (128, 283), (3, 128)]
     assert [tuple(l.weight.shape) for l in p._linear_layers()] == [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]
     with pytest.raises(NotImplementedError):
-        MipNeRF(8, 4, 256)._check_config()
+        MipNeRF(12, 4, 256)._check_config()          # (fewer than 10 octaves run: zero weights on the missing encoding columns)
     ProposalNetwork(10)._check_config()                # class default width 128 (addtional.py:61): zero-padded to the 256-wide kernels
     with pytest.raises(NotImplementedError):
         ProposalNetwork(10, 320)._check_config()
@@ -241,6 +241,49 @@ def test_narrower_networks_are_zero_padded_to_the_kernel_shapes(width):
         assert [tuple(g.shape) for g in gW] == [tuple(l.weight.shape) for l in layers] and [tuple(g.shape) for g in gb] == [tuple(l.bias.shape) for l in layers]
     with pytest.raises(NotImplementedError):
         ProposalNetwork(10, 512)._check_config()
+
+
+@pytest.mark.parametrize("L,cat,width", [(6, True, 256), (10, False, 256), (4, False, 96), (1, True, 128), (7, False, 200)])
+def test_shallow_encodings_and_cat_origin_are_placed_in_the_kernel_columns(L, cat, width):
+    """position_flevel < 10 / cat_origin=False (constructor arguments, mip_model.py:15-18, addtional.py:61): the host side places the
+    module's encoding columns inside the compiled [x | 10 octaves] layout with zeros elsewhere -- the same function (checked with the CPU
+    oracle: the module's own state at (L, cat_origin) == the kernel-shaped state at (10, True)), in the wide and the narrow-tile shapes,
+    and gradients come back through the same column runs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import nerf_oracle as O
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    torch.manual_seed(L * 1000 + width)
+    prop, mip = ProposalNetwork(L, width, cat_origin=cat), MipNeRF(L, 4, width, cat_origin=cat)
+    with torch.no_grad():
+        for m in list(prop.modules()) + list(mip.modules()):
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(4.0); m.bias.normal_(0.0, 0.05)
+    prop._check_config(); mip._check_config()
+    pts = torch.cat((torch.rand(40, 7, 3) * 2 - 1, torch.randn(40, 7, 3)), -1)
+    for net, fwd, x, kw in ((prop, O.proposal_forward, pts[..., :3], dict(L=L)), (mip, O.mip_forward, pts, dict(Lp=L))):
+        layers = net._linear_layers()
+        names = [k[:-7] for k in net.state_dict().keys() if k.endswith(".weight")]
+        by_layer = {id(l): n for n, l in ((n, dict(net.named_modules())[n]) for n in names)}
+        with torch.no_grad():
+            want = fwd(dict(net.state_dict()), x, cat_origin=cat, **kw)
+        for shapes in [net._kernel_weight_shapes()] + ([net._NARROW_SHAPES] if width <= 128 else []):
+            ws, bs = net.kernel_params(shapes)
+            assert [tuple(w.shape) for w in ws] == [tuple(s) for s in shapes]
+            padded = {}
+            for l, w, b in zip(layers, ws, bs):
+                padded[by_layer[id(l)] + ".weight"], padded[by_layer[id(l)] + ".bias"] = w.detach(), b.detach()
+                assert int((w != 0).sum()) == int((l.weight != 0).sum())
+            with torch.no_grad():
+                got = fwd(padded, x)                                  # the kernels' function: 10 octaves behind the raw position
+            assert (want - got).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+        ws, bs = net.kernel_params()
+        gW, gb = net.unpad_grads([w.detach().clone() for w in ws], [b.detach().clone() for b in bs])
+        assert all(torch.equal(g, l.weight) for g, l in zip(gW, layers)) and all(torch.equal(g, l.bias) for g, l in zip(gb, layers))
+    for bad in (lambda: ProposalNetwork(11, 64), lambda: MipNeRF(11, 4), lambda: MipNeRF(10, 3)):
+        with pytest.raises(NotImplementedError):
+            bad()._check_config()
 
 
 # ------------------------------------------------------------------------------------------------ the call surface as a pinned contract (G20)

@@ -2164,3 +2164,72 @@ def test_refnerf_render_with_scene_contraction(A):
     with torch.no_grad():
         out = A.procedures.render_image(net, prop, pose, 50, 60.0, near, far, 64, white_bkg=True, contract=True)
     assert out["rgb"].shape == (3, 50, 50) and bool(torch.isfinite(out["rgb"]).all())
+
+
+@pytest.mark.parametrize("L,cat,width", [(6, True, 256), (10, False, 256), (4, False, 96)])
+def test_shallow_encodings_and_cat_origin(A, golden, L, cat, width):
+    """Fewer encoding octaves / cat_origin=False (constructor arguments: mip_model.py:15-18, addtional.py:61, ref_model.py:17-24): the
+    compiled kernels evaluate all three networks with the module's encoding columns placed inside the [x | 10 octaves] layout and zeros
+    elsewhere (nerf_amd/_packed.py `_column_segments`, RefNeRF._embed_pos).  Forward values and the golden's gradient rows against the REAL
+    reference (G21), every parameter gradient against fp64 autograd of the oracle, the density-gradient normals of the proposal network,
+    and the bf16 path close to fp32."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.ref_model import RefNeRF
+    from test_oracle_golden import shallow_states
+    g = golden("g21_shallow_encodings")
+    tag = "L%d_%s_w%d" % (L, "cat" if cat else "nocat", width)
+    msd, psd, rsd = shallow_states(L, cat, width)
+    mip, prop = MipNeRF(L, 4, width, cat_origin=cat), ProposalNetwork(L, width, cat_origin=cat)
+    ref = RefNeRF(L, 4, hidden_unit=width, output_dim=width, cat_origin=cat, perturb_bottle_neck_w=0.0)
+    mip.load_state_dict(msd); prop.load_state_dict(psd); ref.load_state_dict(rsd)
+    mip, prop, ref = mip.cuda(), prop.cuda(), ref.cuda()
+    A.pkg.set_precision("fp32")
+    pts = g["pts"].cuda()
+    scale = lambda t: max(1.0, t.abs().max().item())
+    with torch.no_grad():                                                  # eval: the narrow-tile kernels at width 96, the wide ones at 256
+        y, d = mip.eval().forward(pts), prop.eval().forward(pts[..., :3].contiguous())
+        rgbo, nrm = ref.eval().forward(pts)
+    assert max_abs(y.cpu(), g[tag + "_mip"]) <= 1e-5 * scale(g[tag + "_mip"])
+    assert max_abs(d.cpu(), g[tag + "_prop"]) <= 1e-5 * scale(g[tag + "_prop"])
+    assert max_abs(rgbo.cpu(), g[tag + "_ref_rgbo"]) <= 2e-5 * scale(g[tag + "_ref_rgbo"]) and max_abs(nrm.cpu(), g[tag + "_ref_normal"]) <= 2e-5
+    # training forward + HIP backward (the wide kernels on the placed tensors)
+    mip.train(); prop.train(); ref.train()
+    (mip.forward(pts) * g["G4"].cuda()).sum().backward()
+    (prop.forward(pts[..., :3].contiguous()) * g["G1"].cuda()).sum().backward()
+    r2, n2 = ref.forward(pts)
+    ((r2 * g["G4"].cuda()).sum() + (n2 * g["G3"].cuda()).sum()).backward()
+    d64 = lambda sd: {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    m64, p64, r64 = d64(msd), d64(psd), d64(rsd)
+    p_ = g["pts"].double()
+    (O.mip_forward(m64, p_, Lp=L, cat_origin=cat) * g["G4"].double()).sum().backward()
+    (O.proposal_forward(p64, p_[..., :3], L=L, cat_origin=cat) * g["G1"].double()).sum().backward()
+    a64, b64 = O.ref_forward(r64, p_, Lp=L, cat_origin=cat)
+    ((a64 * g["G4"].double()).sum() + (b64 * g["G3"].double()).sum()).backward()
+    for net, want in ((mip, m64), (prop, p64), (ref, r64)):
+        for name, prm in net.named_parameters():
+            wg = want[name].grad
+            assert prm.grad is not None and tuple(prm.grad.shape) == tuple(wg.shape), name
+            diff, top = prm.grad.cpu().double() - wg, max(wg.abs().max().item(), 1e-12)
+            assert diff.norm().item() <= 1e-2 * max(wg.norm().item(), 1e-12) and diff.abs().max().item() <= 5e-2 * top, \
+                "%s %s: |err|_2 %.3e of %.3e, max %.3e of %.3e" % (type(net).__name__, name, diff.norm().item(), wg.norm().item(), diff.abs().max().item(), top)
+    for net, key, name in ((mip, "_mip_g0", "lin_block1.0.weight"), (mip, "_mip_gskip", "lin_block2.0.weight"), (mip, "_mip_grgb", "rgb_layer.0.weight"),
+                           (prop, "_prop_g0", "layers.0.weight"), (ref, "_ref_g0", "spa_block1.0.weight"), (ref, "_ref_gskip", "spa_block2.0.weight")):
+        got, want = dict(net.named_parameters())[name].grad[:8].cpu(), g[tag + key]      # the real reference's own fp32 gradient rows
+        assert (got - want).norm().item() <= 1e-2 * max(want.norm().item(), 1e-12), (key, (got - want).norm().item(), want.norm().item())
+    # density-gradient normals of the proposal network (train.py:165-168): the encoding's derivative incl. the raw-position column
+    x = pts[..., :3].detach().clone().requires_grad_(True)
+    normals = RefNeRF.get_grad(prop.forward(x), x)
+    x64 = p_[..., :3].clone().requires_grad_(True)
+    g64, = torch.autograd.grad(O.proposal_forward({k: v.detach() for k, v in p64.items()}, x64, L=L, cat_origin=cat).sum(), x64)
+    want_n = g64 / torch.maximum(torch.full_like(g64[..., :1], 1e-5), g64.norm(dim=-1, keepdim=True))
+    assert max_abs(normals.cpu(), want_n) <= 1e-3
+    # bf16 (the default precision): same function up to the operand rounding
+    A.pkg.set_precision("bf16")
+    with torch.no_grad():
+        yb, db = mip.eval().forward(pts), prop.eval().forward(pts[..., :3].contiguous())
+    A.pkg.set_precision("fp32")
+    assert max_abs(yb[..., :3].cpu(), g[tag + "_mip"][..., :3]) <= 0.05 and max_abs(db.cpu(), g[tag + "_prop"]) <= 0.05 * scale(g[tag + "_prop"])
+    for bad in (lambda: MipNeRF(11, 4), lambda: ProposalNetwork(12, 64), lambda: RefNeRF(11, 4)):
+        with pytest.raises(NotImplementedError):
+            bad()._check_config()

@@ -298,3 +298,42 @@ def test_contraction_definition():
     assert torch.allclose(c / cn[:, None], x / n[:, None], atol=1e-5)
     edge = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0000001, 0.0]])
     assert torch.allclose(O.contract(edge), edge, atol=1e-6)
+
+
+SHALLOW = ((6, True, 256), (10, False, 256), (4, False, 96))
+
+
+def shallow_states(L, cat, width):
+    """the states tests/golden/make_golden.py:write_shallow_encodings loaded into the reference's modules (deterministic)"""
+    seed = 100 * L + width + int(cat)
+    return (O.init_linear_params(O.mip_shapes(L, 4, width, cat), seed, std=0.08, bias_std=0.05),
+            O.init_linear_params(O.proposal_shapes(L, width, cat), seed + 1, std=0.08, bias_std=0.05),
+            O.init_linear_params(O.ref_shapes(L, 4, width, 128, width, cat), seed + 2, std=0.08, bias_std=0.05))
+
+
+@pytest.mark.parametrize("L,cat,width", SHALLOW)
+def test_g21_shallow_encodings_and_cat_origin(golden, L, cat, width):
+    """Fewer encoding octaves and cat_origin=False (constructor arguments of the three networks, mip_model.py:15-18, addtional.py:61,
+    ref_model.py:17-24): the oracle's `Lp` / `cat_origin` parameters against the REAL modules' forward values and parameter gradients."""
+    g = golden("g21_shallow_encodings")
+    tag = "L%d_%s_w%d" % (L, "cat" if cat else "nocat", width)
+    req = lambda sd: {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    msd, psd, rsd = (req(s) for s in shallow_states(L, cat, width))
+    pts = g["pts"]
+    y = O.mip_forward(msd, pts, Lp=L, cat_origin=cat)
+    (y * g["G4"]).sum().backward()
+    assert max_abs(y, g[tag + "_mip"]) <= 1e-6
+    for key, name in (("_mip_g0", "lin_block1.0.weight"), ("_mip_gskip", "lin_block2.0.weight"), ("_mip_grgb", "rgb_layer.0.weight")):
+        want = g[tag + key]
+        assert tuple(msd[name].grad.shape[1:]) == tuple(want.shape[1:])
+        assert max_abs(msd[name].grad[:8], want) <= 2e-5 * max(1.0, want.abs().max().item()), key
+    d = O.proposal_forward(psd, pts[..., :3], L=L, cat_origin=cat)
+    (d * g["G1"]).sum().backward()
+    assert max_abs(d, g[tag + "_prop"]) <= 1e-6 * max(1.0, g[tag + "_prop"].abs().max().item())
+    assert max_abs(psd["layers.0.weight"].grad[:8], g[tag + "_prop_g0"]) <= 2e-5 * max(1.0, g[tag + "_prop_g0"].abs().max().item())
+    rgbo, nrm = O.ref_forward(rsd, pts, Lp=L, cat_origin=cat)
+    ((rgbo * g["G4"]).sum() + (nrm * g["G3"]).sum()).backward()
+    assert max_abs(rgbo, g[tag + "_ref_rgbo"]) <= 2e-6 * max(1.0, g[tag + "_ref_rgbo"].abs().max().item()) and max_abs(nrm, g[tag + "_ref_normal"]) <= 2e-6
+    for key, name in (("_ref_g0", "spa_block1.0.weight"), ("_ref_gskip", "spa_block2.0.weight")):
+        want = g[tag + key]
+        assert max_abs(rsd[name].grad[:8], want) <= 1e-4 * max(1.0, want.abs().max().item()), key
