@@ -244,7 +244,20 @@ DEVINL void f8_flush_scales(char* sub_base, int lane, uint32_t scale_rec) {
 #ifndef MLP_LEAN_RING
 #define MLP_LEAN_RING 0
 #endif
-template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false>
+// STORES (round 4, -DMLP_STORE_AWARE=0 is the A side): the training forwards interleave their activation-dump stores with the ring's
+// LDS-DMA pieces, and on gfx9-class hardware stores count on vmcnt like loads and retire IN ORDER with them (hipcc itself emits
+// `vmcnt(2)` for load, store, store, use) -- so the counted wait `vmcnt(INFLIGHT)` at a chunk boundary also waits until all but INFLIGHT
+// of the wave's recent dump stores have reached memory: HBM write latency on the kernel's critical path every two chunks (the Ref-NeRF
+// training forward, with its 6-slot ring and `vmcnt(4)`, pays 2.1 ms of its 8.9 for its stores, profiles/r04_refnerf_fwd_nodumpstores_ab.log).
+// A store-aware count: the wait needs the pieces of chunk 2b+1 landed, which were issued NSLOT-3 boundaries ago; every VMEM operation
+// issued after them may stay in flight -- (NSLOT-4) chunks of pieces PLUS the dump stores issued since.  The wave counts its dump stores
+// (`note_store`, wave-uniform, folded by the compiler inside straight-line code) per issue interval -- the running interval and a one-byte
+// history of the NSLOT-4 before it: two SGPRs -- and waits with the largest immediate of a small ladder that does not exceed INFLIGHT + stores since.  Counting FEWER stores than were issued
+// (uncounted mask / aux stores, a 32-byte fp32 group that is two instructions) only makes the wait stricter, never weaker.
+#ifndef MLP_STORE_AWARE
+#define MLP_STORE_AWARE 0
+#endif
+template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false, bool STORES = false>
 struct WeightStream {
     static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk
     const char* src;        // packed stream + this lane's offset inside a chunk
@@ -255,6 +268,16 @@ struct WeightStream {
     uint32_t cur_slot;
     uint32_t wave_lds;      // wave-uniform LDS offset of this wave's pieces inside a slot
     typename P::AReg q[P::DEPTH];   // A fragments f .. f+DEPTH-1 already in registers (f = next fragment to multiply)
+    static constexpr bool COUNT_STORES = STORES && !SAFE && P::NW <= 4 && MLP_STORE_AWARE;
+    static constexpr int NHIST = NSLOT - 4;     // complete issue intervals a wait looks back over (+ the running one)
+    static_assert(!COUNT_STORES || NHIST <= 4, "one byte per interval in a 32-bit history");
+    uint32_t st_cur;                // COUNT_STORES: dump stores this wave issued since its last issue() ...
+    uint32_t st_hist;               // ... and in the intervals before it, one byte each (byte 0 = the latest complete interval)
+    DEVINL void note_store(int n = 1) {
+#ifndef ABL_NODUMPST
+        if constexpr (COUNT_STORES) st_cur += n;
+#endif
+    }
 
     static DEVINL void dummy_sink(const bf16x8& d) { asm volatile("" ::"v"(d)); }
     template <class T> static DEVINL void dummy_sink(const T& d) { asm volatile("" ::"v"(d.lo), "v"(d.hi)); }
@@ -289,6 +312,10 @@ struct WeightStream {
         load_idx = (load_idx + 1 == n_chunks) ? 0u : load_idx + 1;
         if constexpr (MLP_LEAN_RING && (NSLOT & (NSLOT - 1)) == 0) load_slot = (load_slot + 1) & (NSLOT - 1);      // (one SALU instead of add / compare / select)
         else load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
+        if constexpr (COUNT_STORES) {                  // (a count above 255 wraps DOWN: fewer stores counted = a stricter wait)
+            st_hist = (st_hist << 8) | (st_cur & 0xffu);
+            st_cur = 0;
+        }
     }
     // Synchronisation protocol (all code is branch-free; the only conditional instruction is the s_barrier itself):
     //   * chunk boundary i = the moment a wave's register prefetch enters chunk i.  At EVERY boundary a wave waits
@@ -315,6 +342,7 @@ struct WeightStream {
         src = reinterpret_cast<const char*>(packed) + (size_t)wave * LPW * 1024 + lane * 16;
         wave_lds = wave * LPW * 1024;
         n_chunks = nchunks;
+        st_cur = 0; st_hist = 0;
         load_idx = 0; load_slot = 0;
         cur_slot = 0;
         cur = lane * 16;
@@ -362,7 +390,24 @@ struct WeightStream {
             return;
         }
 #ifndef ABL_NOVMWAIT
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        if constexpr (COUNT_STORES) {
+            // needed complete: the pieces issued NSLOT-3 issue() calls ago = the stores of the running interval + NSLOT-4 complete ones
+            uint32_t sum = st_cur;
+#pragma unroll
+            for (int k = 0; k < NHIST; ++k) sum += (st_hist >> (8 * k)) & 0xffu;
+            const uint32_t since = __builtin_amdgcn_readfirstlane(sum);
+            asm volatile("s_cmp_lt_u32 %0, 8\n\ts_cbranch_scc1 .Lw0%=\n\t"
+                         "s_cmp_lt_u32 %0, 16\n\ts_cbranch_scc1 .Lw8%=\n\t"
+                         "s_cmp_lt_u32 %0, 24\n\ts_cbranch_scc1 .Lw16%=\n\t"
+                         "s_waitcnt vmcnt(%4)\n\ts_branch .Lwe%=\n"
+                         ".Lw16%=:\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lwe%=\n"
+                         ".Lw8%=:\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Lwe%=\n"
+                         ".Lw0%=:\n\ts_waitcnt vmcnt(%1)\n"
+                         ".Lwe%=:"
+                         ::"s"(since), "n"(INFLIGHT), "n"(INFLIGHT + 8), "n"(INFLIGHT + 16), "n"(INFLIGHT + 24) : "memory", "scc");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        }
 #endif
         // s_barrier only when this boundary's parity is mine; the branch lives inside the asm so that the compiler
         // sees straight-line code (a C++ `if` here splits every feature block into many basic blocks and spills)

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
+    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN, TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_hidden<P, F8>(dump, sacc, layer, sub0 + t, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+                if constexpr (!F8) ws.note_store();              // (store-aware ring wait, mlp_core.h WeightStream)
                 mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
             }
         };
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #endif
     if constexpr (FUSED) { if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 32 + P::NW * P::NT * 8)[threadIdx.x] = 0u; }  // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN> ws;
+    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN, TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_hidden<P, F8>(dump, sacc, layer, sub0 + t, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
+                if constexpr (!F8) ws.note_store();              // (store-aware ring wait, mlp_core.h WeightStream)
                 mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
             }
         };
@@ -721,6 +723,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             c[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {                                                                       // slot 7: rgb_layer.0 output
                 dump_hidden<P, F8>(dump, sacc, 7, sub0 + t, t, 2 * fb + half, lane, c[t][2 * fb + half]);
+                if constexpr (!F8) ws.note_store();
                 mask_or<P>(macc, 7, t, 2 * fb + half, lane, c[t][2 * fb + half]);
             }
         };
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS, REF_LDS_BIAS);
     const float* ide_mat = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + L::stream_bytes(P::PREC)) + L::N_BIAS;
-    WeightStream<P, MLP_NSLOT_REF> ws;
+    WeightStream<P, MLP_NSLOT_REF, false, TRAIN> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -1050,6 +1053,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
             buf[t][kg] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_breg<P>(dump, layer, sub0 + t, kg, lane, buf[t][kg]);
+                ws.note_store();                                   // (store-aware ring wait, mlp_core.h WeightStream)
                 mreg[t] |= breg_bits(buf[t][kg]) << (4 * (kg & 3));
                 if ((kg & 3) == 3) {
                     *reinterpret_cast<uint32_t*>(dump.mask_base + (size_t)layer * dump.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16 + (kg >> 2) * 4) = mreg[t];
