@@ -1617,6 +1617,9 @@ int launch_dir_chain_t(const char* stream, int64_t M, const char* masks, size_t 
 }
 }  // namespace
 int bwd_launch_dir_chain(int precision, const char* stream, int64_t M, const char* masks, size_t ms, char* dlt, size_t ls, float* rows, hipStream_t st) {
+#ifdef REF_DIR_CHAIN_NARROW                                    // A/B knob: the 8-wave x 32-sample tile for the directional chain -- measured SLOWER
+    if (precision == NERF_AMD_BF16) return launch_dir_chain_t<PBF16>(stream, M, masks, ms, dlt, ls, rows, st);      // (5.87 -> 6.34 ms, profiles/r04_ref_chains_8wave_ab.log)
+#endif
     if (precision == NERF_AMD_BF16) return launch_dir_chain_t<PB16>(stream, M, masks, ms, dlt, ls, rows, st);
     return launch_dir_chain_t<PF32>(stream, M, masks, ms, dlt, ls, rows, st);
 }
@@ -1671,6 +1674,12 @@ int bwd_launch_chain(int which, int precision, const void* blob, int start_frag,
     const size_t fb = precision == NERF_AMD_BF16 ? 1024 : 2048;
     const char* stream = reinterpret_cast<const char*>(blob) + (size_t)start_frag * fb;
     const size_t ls = mlp_train_layer_stride(precision, M), ms = mlp_train_mask_stride(precision, M);
+    // the SPATIAL chain of Ref-NeRF on the 8-wave x 32-sample tile: like the training forwards, its delta stores cost issue slots that a second
+    // wave per SIMD fills -- 3.61 -> 3.31 ms per 2^14-ray step, same box, alternated twice (profiles/r04_ref_chains_8wave_ab.log; the
+    // directional chain, with 65 spilled registers, got slower on it and stays on the wide tile).  -DREF_SPA_CHAIN_WIDE = the A side.
+#ifndef REF_SPA_CHAIN_WIDE
+    if (precision == NERF_AMD_BF16 && which == 1) return launch_chain_t<PBF16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
+#endif
     if (precision == NERF_AMD_BF16) return launch_chain_t<PB16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
     return launch_chain_t<PF32>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
 }

@@ -1405,6 +1405,13 @@ int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s,
 int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
                          void* dump, float* aux, int flags, hipStream_t st) {
     const ActDump d = make_dump(dump, precision, s.M, REF_DUMP_SLOTS);     // 17 activation slots + (round 4) their ReLU bit-mask records
+    // bf16 training forward: the 8-wave x 32-sample tile, like the proposal network's -- its 512 dump stores per wave and tile cost their
+    // ISSUE slots (~80 cycles of the vector-memory path each, during which a lone wave per SIMD issues no MFMA; not a wait: the store-aware
+    // ring wait changed nothing, mlp_core.h), which a second wave per SIMD fills: 9.01 -> 8.38 ms per 2^14-ray step, same box, alternated
+    // twice (profiles/r04_ref_train_fwd_8wave_ab.log); the dump layout does not depend on the tile policy.  -DREF_TRAIN_WIDE = the A side.
+#ifndef REF_TRAIN_WIDE
+    if (precision == NERF_AMD_BF16) return launch_ref<PBF16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
+#endif
     if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
     return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
 }
