@@ -431,6 +431,29 @@ int    nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref,
                                 const float* u_inv, int64_t N, int n_fine, float near, float far, int white_bkg, const float* cam_dir,
                                 float* rgb, float* depth, float* normal_img, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Generic-shape layer product (ABI 119): the path of networks LARGER than the shapes the fused MLP kernels are compiled for -- hidden
+ * widths above 256 (`--nerf_net_width` / `--prop_net_width`, procedures.py:176-177), more than 10 encoding octaves (mip_model.py:15-18,
+ * addtional.py:61).  Such a network is evaluated layer by layer (nerf_helper.py:28-36 makeMLP = nn.Linear + activation) with fp32
+ * row-major activations in HBM, forward and backward, by ONE hand-written MFMA GEMM with explicit element strides:
+ *
+ *     C[i, j] = act( sum_{p < P} A[i*a_si + p*a_sp] * B[p*b_sp + j*b_sj] + bias[j] ) * [mask[i*ldm + j] > 0]        i < M, j < N
+ *
+ *   forward  y = act(x W^T + b): A = x, B(p, j) = W[j, p];   input gradient  dx = (dy W) . [x > 0]: A = dy, B = W, mask = x;
+ *   weight gradient  dW = dy^T x: A(i, p) = dy[p, i], B = x (db: B = a column of ones) -- a long contraction over the samples is split
+ *   over workgroups, partial sums in `workspace` (nerf_amd_gemm_workspace_bytes bytes; may be NULL when that is 0), added in a fixed
+ *   order: deterministic, no atomics.
+ * Of each operand's two strides one must be 1.  C row-major, row stride ldc.  bias (N) or NULL; act 0 none / 1 ReLU / 2 sigmoid; mask or NULL.
+ * precision: NERF_AMD_F32 = v_mfma_f32_32x32x2_f32 on the fp32 operands; NERF_AMD_BF16 = operands rounded to bf16 (RNE), fp32 accumulation.
+ * All matrices fp32 on the device.  Every compiled shape keeps its fused kernel; this is the compatibility path of the shape arguments. */
+size_t nerf_amd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t P);
+int    nerf_amd_gemm(int precision, int64_t M, int64_t N, int64_t P, const float* A, int64_t a_si, int64_t a_sp,
+                     const float* B, int64_t b_sp, int64_t b_sj, float* C, int64_t ldc, const float* bias, int act,
+                     const float* mask, int64_t ldm, void* workspace, void* stream);
+/* out[m, c] = g[m, c] * y[m, c] * (1 - y[m, c]), c < cols: the adjoint of y = sigmoid(.) (rgb_layer.2, mip_model.py:35); row strides in floats */
+int    nerf_amd_sigmoid_backward(const float* g, int64_t g_stride, const float* y, int64_t y_stride, int64_t M, int cols,
+                                 float* out, int64_t out_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

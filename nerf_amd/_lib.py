@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so
 
 F32, BF16 = 0, 1
 BF16_F8 = 2            # NERF_AMD_BF16_F8: bf16 arithmetic, training dumps of the hidden layers in scaled e4m3 (training entry points only)
-EXPECTED_VERSION = 118  # nerf_amd_version() of the library these signatures were written against
+EXPECTED_VERSION = 119  # nerf_amd_version() of the library these signatures were written against
 NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, NET_MIP_128 = 0, 1, 2, 3, 4
 FINE_W128 = 0x200     # layout flag: the fine-network blob is a NET_MIP_128 blob
 PROP_W128 = 0x100     # layout flag OR-ed into `precision`: packed_prop is a NET_PROPOSAL_128 blob
@@ -111,6 +111,9 @@ SIGNATURES = {
     "nerf_amd_render_workspace_bytes": (C.c_size_t, [i64, C.c_int]),
     "nerf_amd_render_rays": (C.c_int, [c_void, c_void, C.c_int, c_void, C.POINTER(Samples), i64, c_void, c_void, c_void, i64,
                                        C.c_int, C.c_float, C.c_float, C.c_int, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
+    "nerf_amd_gemm": (C.c_int, [C.c_int, i64, i64, i64, c_void, i64, i64, c_void, i64, i64, c_void, i64, c_void, C.c_int, c_void, i64, c_void, c_void]),
+    "nerf_amd_sigmoid_backward": (C.c_int, [c_void, i64, c_void, i64, i64, C.c_int, c_void, i64, c_void]),
 }
 
 

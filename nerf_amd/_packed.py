@@ -96,10 +96,14 @@ class PackedWeightsMixin:
     # every element) and reports "no gradient" to autograd: no per-tensor accumulate launches, no torch.cat before the all-reduce, and the
     # optimizer walks the same buffer.  Modules wrapped in DistributedDataParallel are NOT attached: there autograd must see the gradients
     # (DDP's hooks hang off the AccumulateGrad nodes).
+    # ---- shapes LARGER than the compiled ones (hidden width > 256, > 10 octaves): nerf_amd/generic_path.py, layer by layer -----------------
+    def _generic(self) -> bool:
+        return False
+
     def grad_sinks(self):
         """-> (weight views, bias views, overwrite?) or None (not attached / zero-padded narrow network: the ordinary autograd path)"""
         owner = self.__dict__.get("_grad_owner")
-        if owner is None:
+        if owner is None or self._generic():
             return None
         layers = self._linear_layers()
         shapes = self._kernel_weight_shapes()

@@ -69,8 +69,13 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
 
     def _check_config(self):
         # position_flevel < 10 / cat_origin=False: the same kernels with zero weights on the encoding columns the module lacks (_packed.py)
-        if not (1 <= self.position_flevel <= 10 and 1 <= self.hidden_unit <= 256):
-            raise NotImplementedError("nerf_amd: the HIP proposal kernel is instantiated for ProposalNetwork(position_flevel <= 10, hidden_unit <= 256)")
+        # Shapes LARGER than the compiled ones (`--prop_net_width` above 256, more than 10 octaves): layer by layer on the generic MFMA GEMM
+        # (nerf_amd/generic_path.py), forward and backward.
+        if not (self.position_flevel >= 1 and self.hidden_unit >= 1):
+            raise NotImplementedError("nerf_amd: ProposalNetwork needs position_flevel >= 1 and hidden_unit >= 1")
+
+    def _generic(self) -> bool:
+        return self.hidden_unit > 256 or self.position_flevel > 10
 
     def _column_segments(self):
         if self.position_flevel == 10 and self.cat_origin:
@@ -113,6 +118,11 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         encoding) is accepted for signature parity and ignored: the kernel encodes in-register.  ``contract`` (not in the reference;
         BASELINE configs[4]): Mip-NeRF 360 scene contraction of the positions before the encoding."""
         self._check_config()
+        if self._generic():
+            if contract:
+                raise NotImplementedError("nerf_amd: scene contraction is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+            from . import generic_path
+            return generic_path.proposal_forward(self, pts)
         prec = ops.current_precision()
         layers = self._linear_layers()
         params = [l.weight for l in layers] + [l.bias for l in layers]

@@ -58,6 +58,10 @@ int sk_dirs_norm_scratch(const float*, int64_t, float*, void*, hipStream_t);
 int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, const float*, float, float, float, float, int64_t, int, uint64_t, const uint64_t*,
                      float*, float*, float*, float*, hipStream_t);
 int sk_philox_uniforms(float*, int64_t, int, uint64_t, const uint64_t*, hipStream_t);
+size_t gk_gemm_workspace_bytes(int64_t, int64_t, int64_t);
+int gk_gemm(int, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*, int64_t, int64_t, float*, int64_t, const float*, int, const float*, int64_t,
+            void*, hipStream_t);
+int gk_sigmoid_backward(const float*, int64_t, const float*, int64_t, int64_t, int, float*, int64_t, hipStream_t);
 int sk_advance_seed(uint64_t*, hipStream_t);
 int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
@@ -118,7 +122,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 118; }
+int nerf_amd_version(void) { return 119; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -740,6 +744,32 @@ int nerf_amd_render_rays_ref(const void* packed_prop, const void* packed_ref, in
     if (int e = sk_composite(rgbo, z_all, S_all, rays + 3, 6, N, S_all, flags, NERF_AMD_ACT_SOFTPLUS, 0.5f, near, far,
                              normal_img ? normals : nullptr, cam_dir, rgb, nullptr, depth, normal_img, st)) return hip_status(e, "composite");
     return NERF_AMD_OK;
+}
+
+size_t nerf_amd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t P) {
+    if (M <= 0 || N <= 0 || P <= 0) return 0;
+    return gk_gemm_workspace_bytes(M, N, P);
+}
+
+int nerf_amd_gemm(int precision, int64_t M, int64_t N, int64_t P, const float* A, int64_t a_si, int64_t a_sp, const float* B, int64_t b_sp, int64_t b_sj,
+                  float* C, int64_t ldc, const float* bias, int act, const float* mask, int64_t ldm, void* workspace, void* stream) {
+    if (precision != NERF_AMD_F32 && precision != NERF_AMD_BF16) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: precision must be NERF_AMD_F32 or NERF_AMD_BF16");
+    if (M < 0 || N < 0 || P < 0 || N > 65535LL * 128) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: bad size");
+    if (M == 0 || N == 0) return 0;
+    if (!C || (P && (!A || !B))) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: NULL argument");
+    if ((a_si != 1 && a_sp != 1) || (b_sp != 1 && b_sj != 1)) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: one stride of each operand must be 1");
+    if (ldc < N || (mask && ldm < N)) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: row stride smaller than N");
+    if (act < 0 || act > 2) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: act must be 0 (none), 1 (ReLU) or 2 (sigmoid)");
+    if (gk_gemm_workspace_bytes(M, N, P) && !workspace) return fail(NERF_AMD_EINVAL, "nerf_amd_gemm: this shape needs nerf_amd_gemm_workspace_bytes of workspace");
+    return hip_status(gk_gemm(precision == NERF_AMD_BF16, M, N, P, A, a_si, a_sp, B, b_sp, b_sj, C, ldc, bias, act, mask, ldm, workspace, S(stream)), "nerf_amd_gemm");
+}
+
+int nerf_amd_sigmoid_backward(const float* g, int64_t g_stride, const float* y, int64_t y_stride, int64_t M, int cols, float* out, int64_t out_stride,
+                              void* stream) {
+    if (M < 0 || cols < 0) return fail(NERF_AMD_EINVAL, "nerf_amd_sigmoid_backward: bad size");
+    if (M * cols && (!g || !y || !out)) return fail(NERF_AMD_EINVAL, "nerf_amd_sigmoid_backward: NULL argument");
+    if (g_stride < cols || y_stride < cols || out_stride < cols) return fail(NERF_AMD_EINVAL, "nerf_amd_sigmoid_backward: row stride smaller than cols");
+    return hip_status(gk_sigmoid_backward(g, g_stride, y, y_stride, M, cols, out, out_stride, S(stream)), "nerf_amd_sigmoid_backward");
 }
 
 }  // extern "C"

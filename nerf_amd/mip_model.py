@@ -41,8 +41,13 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         # position_flevel < 10 and cat_origin=False run on the same kernels with zero weights on the encoding columns the module lacks
         # (_packed.py, `_column_segments`); the direction depth is 4 in the reference itself: rgb_layer.0 is built 280 (+3) wide
         # (mip_model.py:34), so its own forward only runs with direction_flevel == 4.
-        if not (1 <= self.position_flevel <= 10 and self.direction_flevel == 4 and 1 <= self.hidden_unit <= 256):
-            raise NotImplementedError("nerf_amd: the HIP fine-MLP kernel is instantiated for MipNeRF(position_flevel <= 10, 4, hidden_unit <= 256)")
+        # Shapes LARGER than the compiled ones (`--nerf_net_width` above 256, more than 10 octaves) run layer by layer on the generic MFMA GEMM
+        # (nerf_amd/generic_path.py), forward and backward.
+        if not (self.position_flevel >= 1 and self.direction_flevel == 4 and self.hidden_unit >= 1):
+            raise NotImplementedError("nerf_amd: MipNeRF needs direction_flevel == 4 (the reference's own rgb_layer.0 is built for it, mip_model.py:34)")
+
+    def _generic(self) -> bool:
+        return self.hidden_unit > 256 or self.position_flevel > 10
 
     def _column_segments(self):
         if self.position_flevel == 10 and self.cat_origin:
@@ -109,6 +114,11 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         """pts (N,S,6) = [position | raw direction] -> (N,S,4) = [sigmoid rgb | raw sigma]  (mip_model.py:41-60).
         `contract` (not in the reference; BASELINE configs[4]): Mip-NeRF 360 scene contraction of the positions before the encoding."""
         self._check_config()
+        if self._generic():
+            if contract:
+                raise NotImplementedError("nerf_amd: scene contraction is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+            from . import generic_path
+            return generic_path.mip_forward(self, pts)
         prec = ops.current_precision()
         params = self._params()
         if ab.needs_grad(pts, *params):
@@ -133,6 +143,10 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         prec = ops.current_precision()
         if rays.requires_grad or z.requires_grad:
             raise NotImplementedError("nerf_amd: MipNeRF.forward_rays differentiates the parameters only (rays / depths must not require grad)")
+        if self._generic():
+            if contract or ipe_radius is not None:
+                raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+            return self.forward(NeRF.length2pts(rays, z[:, :n_samples].contiguous()))
         rays, z = ops._dev(rays, "rays"), ops._dev(z, "z")
         if ipe_radius is not None and ipe_dir_norm is None:
             ipe_dir_norm = ops.dirs_norm(rays)

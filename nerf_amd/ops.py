@@ -961,3 +961,59 @@ def ref_backward(packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, a
     check(lib.nerf_amd_ref_backward(_ptr(packed_bwd), precision, int(flags), M, _ptr(dump), _ptr(aux), _ptr(dirs), dirs.shape[1], _ptr(g_out), g_out.shape[1],
                                     _ptr(_dev(ide_table, "ide_table")), _ptr_array(gw), _ptr_array(gb), _ptr(ws), _stream()), "nerf_amd_ref_backward")
     return gw, gb
+
+
+# ------------------------------------------------------------------------------------------------ generic-shape layer product (ABI 119)
+def _view2d(t: torch.Tensor, name: str):
+    """-> (tensor, stride 0, stride 1) of a 2-D fp32 device view whose strides the GEMM can walk (one of them 1, or a 1-wide dimension)"""
+    if not t.is_cuda:
+        raise RuntimeError("nerf_amd: '%s' must live on the HIP device (got %s); there is no CPU path" % (name, t.device))
+    if t.dim() != 2 or t.dtype != torch.float32:
+        raise RuntimeError("nerf_amd: '%s' must be a 2-D float32 tensor" % name)
+    s0, s1 = t.stride()
+    if t.shape[1] == 1:
+        s1 = 1
+    elif t.shape[0] == 1 and s1 != 1:
+        s0 = 1
+    if s0 != 1 and s1 != 1:
+        t = t.contiguous()
+        s0, s1 = t.stride()
+    return t, int(s0), int(s1)
+
+
+def gemm(precision: int, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0,
+         mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i, j] = act(sum_p a[i, p] b[p, j] + bias[j]) * [mask[i, j] > 0]  (nerf_amd_gemm: one hand-written MFMA GEMM with explicit strides;
+    act 0 none / 1 ReLU / 2 sigmoid).  a (M, P), b (P, N): 2-D fp32 device VIEWS (a transposed view is a stride pair, nothing is copied);
+    out / mask: (M, N) views with unit column stride.  The layer products of networks larger than the fused kernels' compiled shapes."""
+    a, a_si, a_sp = _view2d(a, "a")
+    b, b_sp, b_sj = _view2d(b, "b")
+    M, P = a.shape
+    if b.shape[0] != P:
+        raise RuntimeError("nerf_amd.gemm: inner dimensions differ (%s x %s)" % (tuple(a.shape), tuple(b.shape)))
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if tuple(out.shape) != (M, N) or out.dtype != torch.float32 or not out.is_cuda or (N > 1 and out.stride(1) != 1):
+        raise RuntimeError("nerf_amd.gemm: out must be a (%d, %d) float32 device view with unit column stride" % (M, N))
+    ldm = 0
+    if mask is not None:
+        if tuple(mask.shape) != (M, N) or mask.dtype != torch.float32 or (N > 1 and mask.stride(1) != 1):
+            raise RuntimeError("nerf_amd.gemm: mask must be a (%d, %d) float32 view with unit column stride" % (M, N))
+        ldm = max(int(mask.stride(0)), N)
+    if bias is not None:
+        bias = _dev(bias.reshape(-1), "bias")
+    prec = F32 if (precision & 0xff) == F32 else BF16
+    wsb = lib.nerf_amd_gemm_workspace_bytes(M, N, P)
+    ws = scratch(("gemm", 0), wsb, a.device) if wsb else None
+    check(lib.nerf_amd_gemm(prec, M, N, P, _ptr(a), a_si, a_sp, _ptr(b), b_sp, b_sj, _ptr(out), max(int(out.stride(0)), N), _ptr(bias), int(act),
+                            _ptr(mask), ldm, _ptr(ws), _stream()), "nerf_amd_gemm")
+    return out
+
+
+def sigmoid_backward(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """g * y * (1 - y) over (M, cols) fp32 views with unit column stride (the adjoint of y = sigmoid(.))"""
+    M, cols = y.shape
+    out = torch.empty((M, cols), dtype=torch.float32, device=y.device)
+    check(lib.nerf_amd_sigmoid_backward(_ptr(g), int(g.stride(0)), _ptr(y), int(y.stride(0)), M, cols, _ptr(out), cols, _stream()), "nerf_amd_sigmoid_backward")
+    return out

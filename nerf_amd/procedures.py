@@ -42,6 +42,36 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
     return u1.view(-1, RENDER_COARSE_PNUM).to(device), u2.view(-1, sample_num + 1).to(device)
 
 
+def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096):
+    """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
+    maxBlurFilter, inverseSample, NeRF.length2pts, network.forward, NeRF.render -- on chunks of rays: the route of networks the fused
+    render entry (nerf_amd_render_rays) has no packed layout for.  Every call is a HIP kernel of this package; uniforms that were not
+    given are drawn on the device generator per chunk."""
+    from .mip_methods import maxBlurFilter
+    from .utils import inverseSample
+    N = rays.shape[0]
+    rgb = torch.empty((N, 3), dtype=torch.float32, device=rays.device)
+    depth = torch.empty((N,), dtype=torch.float32, device=rays.device) if render_depth else None
+    resolution = (far - near) / sample_num                                           # procedures.py:57
+    for s in range(0, N, chunk):
+        r = rays[s: s + chunk].contiguous()
+        n = r.shape[0]
+        u1 = u_strat[s: s + n] if u_strat is not None else torch.rand((n, RENDER_COARSE_PNUM), device=rays.device)
+        u2 = u_inv[s: s + n] if u_inv is not None else torch.rand((n, sample_num + 1), device=rays.device)
+        z, pts = ops.stratified_points(r, z_base, u1.contiguous(), resolution)      # :65-66
+        density = prop_net.forward(pts)
+        prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z, r[:, 3:]), 0.01)
+        fine, _ = inverseSample(prop_w, z, sample_num + 1, sort=True, u=u2.contiguous())
+        fine = fine[..., :-1].contiguous()
+        rgbo = network.forward(NeRF.length2pts(r, fine))
+        part, _, extras = NeRF.render(rgbo, fine, r[:, 3:], white_bkg=white_bkg, density_act=torch.nn.functional.relu,
+                                      render_depth=(near, far) if render_depth else None)
+        rgb[s: s + n] = part
+        if render_depth:
+            depth[s: s + n] = extras["depth_img"].reshape(-1)
+    return rgb, depth
+
+
 def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
                  near: float, far: float, sample_num: int = 128, white_bkg: bool = False, render_depth=False,
                  render_normal=False, rng: str = "philox", contract: bool = False, ipe=False) -> dict:
@@ -93,7 +123,14 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         if is_ref_model:
             raise NotImplementedError("nerf_amd: the integrated PE is wired for the MipNeRF render path only")
         ipe_radius = (2.0 / (12.0 ** 0.5) / fx) if ipe is True else float(ipe)
-    if not is_ref_model:
+    generic = (not is_ref_model) and (network._generic() or prop_net._generic())
+    if generic:
+        # a network LARGER than the fused kernels' compiled shapes (hidden width > 256, > 10 octaves): the reference's tile body
+        # (procedures.py:62-85) call by call on the mirrored ops -- the networks run layer by layer (nerf_amd/generic_path.py)
+        if contract or ipe:
+            raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+        rgb, depth = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth))
+    elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,
                                            sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,

@@ -44,7 +44,7 @@ def test_struct_layout_matches_header():
 def test_pure_queries_without_gpu():
     from nerf_amd import _lib
     lib = _lib.lib
-    assert lib.nerf_amd_version() == 118
+    assert lib.nerf_amd_version() == 119
     assert lib.nerf_amd_packed_bytes(_lib.NET_PROPOSAL, _lib.BF16) == 432 * 1024 + 1056 * 4
     fold = (128 * 256 + 128) * 4                       # scratch of the bottle_neck -> rgb_layer.0 fold
     assert lib.nerf_amd_packed_bytes(_lib.NET_MIP, _lib.BF16) == 928 * 1024 + 1984 * 4 + fold
@@ -82,10 +82,11 @@ def test_mip_module_param_count_and_order():
                                                                    (256, 256), (256, 256), (256, 256), (1, 256), (128, 283), (3, 128)]
     assert [tuple(l.weight.shape) for l in p._linear_layers()] == [(256, 63), (256, 256), (256, 256), (256, 256), (1, 256)]
     with pytest.raises(NotImplementedError):
-        MipNeRF(12, 4, 256)._check_config()          # (fewer than 10 octaves run: zero weights on the missing encoding columns)
+        MipNeRF(10, 3, 256)._check_config()          # (the reference's own rgb_layer.0 is built for direction_flevel 4, mip_model.py:34)
     ProposalNetwork(10)._check_config()                # class default width 128 (addtional.py:61): zero-padded to the 256-wide kernels
-    with pytest.raises(NotImplementedError):
-        ProposalNetwork(10, 320)._check_config()
+    # shapes LARGER than the compiled ones run layer by layer on the generic MFMA GEMM (nerf_amd/generic_path.py); smaller ones on the fused kernels
+    assert ProposalNetwork(10, 320)._generic() and MipNeRF(12, 4, 256)._generic() and MipNeRF(10, 4, 512)._generic()
+    assert not ProposalNetwork(10, 256)._generic() and not MipNeRF(8, 4, 200)._generic()
 
 
 def test_host_scalars_and_patching(golden):
@@ -239,8 +240,7 @@ def test_narrower_networks_are_zero_padded_to_the_kernel_shapes(width):
         assert (a - b_).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
         gW, gb = net.unpad_grads([torch.ones_like(w) for w in ws], [torch.ones_like(b) for b in bs])
         assert [tuple(g.shape) for g in gW] == [tuple(l.weight.shape) for l in layers] and [tuple(g.shape) for g in gb] == [tuple(l.bias.shape) for l in layers]
-    with pytest.raises(NotImplementedError):
-        ProposalNetwork(10, 512)._check_config()
+    assert ProposalNetwork(10, 512)._generic()       # wider than the compiled shapes: the generic layer-by-layer path, not padding
 
 
 @pytest.mark.parametrize("L,cat,width", [(6, True, 256), (10, False, 256), (4, False, 96), (1, True, 128), (7, False, 200)])
@@ -281,9 +281,9 @@ def test_shallow_encodings_and_cat_origin_are_placed_in_the_kernel_columns(L, ca
         ws, bs = net.kernel_params()
         gW, gb = net.unpad_grads([w.detach().clone() for w in ws], [b.detach().clone() for b in bs])
         assert all(torch.equal(g, l.weight) for g, l in zip(gW, layers)) and all(torch.equal(g, l.bias) for g, l in zip(gb, layers))
-    for bad in (lambda: ProposalNetwork(11, 64), lambda: MipNeRF(11, 4), lambda: MipNeRF(10, 3)):
-        with pytest.raises(NotImplementedError):
-            bad()._check_config()
+    with pytest.raises(NotImplementedError):
+        MipNeRF(10, 3)._check_config()
+    assert ProposalNetwork(11, 64)._generic() and MipNeRF(11, 4)._generic()       # more octaves than compiled: the generic path
 
 
 # ------------------------------------------------------------------------------------------------ the call surface as a pinned contract (G20)

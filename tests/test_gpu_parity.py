@@ -757,8 +757,9 @@ def test_error_reporting(A):
     with pytest.raises(NerfAmdError):
         A.ops.mip_forward_composite(build_nets(A, "small")[1].packed(A.ops.F32), A.ops.F32, torch.rand(4, 6).cuda(),
                                     torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
-    with pytest.raises(NotImplementedError):
-        A.addtional.ProposalNetwork(10, 512).cuda().forward(torch.rand(2, 3, 3).cuda())     # wider than the compiled 256: no kernel instance
+    with pytest.raises(NotImplementedError):                           # scene contraction is a flag of the fused kernels' sample fetch only
+        A.addtional.ProposalNetwork(10, 512).cuda().forward(torch.rand(2, 3, 3).cuda(), contract=True)
+    assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # wider than compiled: generic path
     assert A.addtional.ProposalNetwork(10).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # class default 128: zero-padded
 
 
@@ -2230,6 +2231,126 @@ def test_shallow_encodings_and_cat_origin(A, golden, L, cat, width):
         yb, db = mip.eval().forward(pts), prop.eval().forward(pts[..., :3].contiguous())
     A.pkg.set_precision("fp32")
     assert max_abs(yb[..., :3].cpu(), g[tag + "_mip"][..., :3]) <= 0.05 and max_abs(db.cpu(), g[tag + "_prop"]) <= 0.05 * scale(g[tag + "_prop"])
-    for bad in (lambda: MipNeRF(11, 4), lambda: ProposalNetwork(12, 64), lambda: RefNeRF(11, 4)):
-        with pytest.raises(NotImplementedError):
-            bad()._check_config()
+    with pytest.raises(NotImplementedError):
+        RefNeRF(11, 4)._check_config()
+
+
+# ------------------------------------------------------------------------------------------------ shapes LARGER than the compiled ones
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_generic_gemm_stride_forms(A, prec):
+    """nerf_amd_gemm (nerf_amd/csrc/generic_kernels.hip) in the three stride forms the layer-by-layer path uses -- forward x W^T (+ bias,
+    activation), input gradient dy W with the ReLU mask, weight gradient dy^T x with the contraction over the samples split over
+    workgroups -- at ragged sizes, against fp64 matmul of the same (bf16-rounded in bf16 mode) operands; the split sum is reproducible."""
+    code = A.ops.F32 if prec == "fp32" else A.ops.BF16
+    gen = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    q = (lambda t: t) if prec == "fp32" else (lambda t: t.to(torch.bfloat16).float())
+    for M, N, K in ((300, 77, 131), (129, 513, 64), (1, 1, 5), (2500, 320, 383)):
+        x, w, b, dy = rnd(M, K), rnd(N, K) * 0.1, rnd(N), rnd(M, N)
+        want = q(x).double() @ q(w).double().t() + b.double()
+        tol = lambda ref: 2e-5 * max(1.0, ref.abs().max().item())
+        for act, f in ((0, lambda t: t), (1, torch.relu), (2, torch.sigmoid)):
+            got = A.ops.gemm(code, x.cuda(), w.cuda().t(), bias=b.cuda(), act=act)
+            assert max_abs(got.cpu(), f(want)) <= tol(f(want)), (M, N, K, act)
+        buf = torch.full((M, N + 5), -7.0).cuda()                                   # strided output: a column range of a wider buffer
+        A.ops.gemm(code, x.cuda(), w.cuda().t(), out=buf[:, 3: 3 + N], bias=b.cuda(), act=1)
+        assert max_abs(buf[:, 3: 3 + N].cpu(), torch.relu(want)) <= tol(want) and float(buf[:, :3].min()) == -7.0 and float(buf[:, 3 + N:].max()) == -7.0
+        mask = torch.relu(rnd(M, K))
+        dx = A.ops.gemm(code, dy.cuda(), w.cuda(), mask=mask.cuda())
+        want_dx = (q(dy).double() @ q(w).double()) * (mask > 0)
+        assert max_abs(dx.cpu(), want_dx) <= tol(want_dx), (M, N, K, "dx")
+        dw = A.ops.gemm(code, dy.cuda().t(), x.cuda())
+        want_dw = q(dy).double().t() @ q(x).double()
+        assert max_abs(dw.cpu(), want_dw) <= 2e-5 * max(1.0, want_dw.abs().max().item()) * (4 if M > 1000 else 1), (M, N, K, "dw")
+    # the weight-gradient shape: a contraction over 70 001 samples is split over workgroups; fixed summation order
+    M, N, K = 70001, 96, 130
+    dy, x = rnd(M, N), rnd(M, K)
+    assert A.ops.lib.nerf_amd_gemm_workspace_bytes(N, K, M) > 0
+    a1 = A.ops.gemm(code, dy.cuda().t(), x.cuda())
+    a2 = A.ops.gemm(code, dy.cuda().t(), x.cuda())
+    assert torch.equal(a1, a2)
+    want = q(dy).double().t() @ q(x).double()
+    assert max_abs(a1.cpu(), want) <= 1e-4 * want.abs().max().item()
+    db = A.ops.gemm(code, dy.cuda().t(), torch.ones(M, 1).cuda())
+    assert max_abs(db.cpu().reshape(-1), q(dy).double().sum(0)) <= 1e-4 * q(dy).double().sum(0).abs().max().item()
+    xd = x.cuda()                                                                    # the C-ABI refuses an operand with no unit stride
+    assert A.ops.lib.nerf_amd_gemm(code, 4, 4, 4, xd.data_ptr(), 2, 3, xd.data_ptr(), 1, 4, a1.data_ptr(), 4, None, 0, None, 0, None, None) != 0
+    assert b"stride" in A.ops.lib.nerf_amd_last_error()
+
+
+@pytest.mark.parametrize("L,cat,w_mip,w_prop", [(10, True, 320, 512), (12, True, 128, 64), (11, False, 288, 300)])
+def test_networks_larger_than_the_compiled_shapes(A, L, cat, w_mip, w_prop):
+    """`--nerf_net_width` / `--prop_net_width` above 256 (procedures.py:176-177) and more than 10 position octaves (mip_model.py:15-18,
+    addtional.py:61): the networks run layer by layer on the generic MFMA GEMM (nerf_amd/generic_path.py).  Forward against the oracle,
+    every parameter gradient against fp64 autograd of the oracle, bf16 close to fp32, and no position gradient on offer."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    msd = O.init_linear_params(O.mip_shapes(L, 4, w_mip, cat), 900 + w_mip, std=0.06, bias_std=0.05)
+    psd = O.init_linear_params(O.proposal_shapes(L, w_prop, cat), 901 + w_prop, std=0.06, bias_std=0.05)
+    mip, prop = MipNeRF(L, 4, w_mip, cat_origin=cat), ProposalNetwork(L, w_prop, cat_origin=cat)
+    mip.load_state_dict(msd); prop.load_state_dict(psd)
+    assert mip._generic() and (prop._generic() or (w_prop <= 256 and L <= 10))
+    mip, prop = mip.cuda(), prop.cuda()
+    A.pkg.set_precision("fp32")
+    gen = torch.Generator().manual_seed(L * 100 + w_mip)
+    pts = torch.cat((torch.rand(37, 11, 3, generator=gen) * 3 - 1.5, torch.randn(37, 11, 3, generator=gen)), dim=-1)
+    G4, G1 = torch.randn(37, 11, 4, generator=gen), torch.randn(37, 11, generator=gen)
+    scale = lambda t: max(1.0, t.abs().max().item())
+    with torch.no_grad():
+        want_y, want_d = O.mip_forward(msd, pts, Lp=L, cat_origin=cat), O.proposal_forward(psd, pts[..., :3], L=L, cat_origin=cat)
+        y, d = mip.eval().forward(pts.cuda()), prop.eval().forward(pts[..., :3].contiguous().cuda())
+    # (octaves 10, 11 multiply the position by 1024 / 2048 before sin / cos: the fp32 reference's own rounding of that argument is ~1e-4)
+    tol = 1e-5 if L <= 10 else 5e-4
+    assert y.shape == (37, 11, 4) and max_abs(y.cpu(), want_y) <= tol * scale(want_y), max_abs(y.cpu(), want_y)
+    assert d.shape == (37, 11) and max_abs(d.cpu(), want_d) <= tol * scale(want_d), max_abs(d.cpu(), want_d)
+    mip.train(); prop.train()
+    (mip.forward(pts.cuda()) * G4.cuda()).sum().backward()
+    (prop.forward(pts[..., :3].contiguous().cuda()) * G1.cuda()).sum().backward()
+    d64 = lambda sd: {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    m64, p64 = d64(msd), d64(psd)
+    (O.mip_forward(m64, pts.double(), Lp=L, cat_origin=cat) * G4.double()).sum().backward()
+    (O.proposal_forward(p64, pts[..., :3].double(), L=L, cat_origin=cat) * G1.double()).sum().backward()
+    for net, want in ((mip, m64), (prop, p64)):
+        for name, prm in net.named_parameters():
+            wg = want[name].grad
+            assert prm.grad is not None and tuple(prm.grad.shape) == tuple(wg.shape), name
+            diff, top = prm.grad.cpu().double() - wg, max(wg.abs().max().item(), 1e-12)
+            assert diff.norm().item() <= 1e-2 * max(wg.norm().item(), 1e-12) and diff.abs().max().item() <= 5e-2 * top, \
+                "%s %s: |err|_2 %.3e of %.3e, max %.3e of %.3e" % (type(net).__name__, name, diff.norm().item(), wg.norm().item(), diff.abs().max().item(), top)
+    A.pkg.set_precision("bf16")
+    with torch.no_grad():
+        yb = mip.eval().forward(pts.cuda())
+    A.pkg.set_precision("fp32")
+    assert max_abs(yb[..., :3].cpu(), want_y[..., :3]) <= 0.06
+    with pytest.raises(NotImplementedError):                                          # no position gradient on the generic path: refused at forward time
+        mip.train().forward(pts.cuda().requires_grad_(True))
+    with pytest.raises(NotImplementedError):
+        mip.forward(pts.cuda(), contract=True)
+
+
+def test_render_image_with_a_wide_network(A):
+    """render_image (procedures.py:34-97) with `--nerf_net_width 320`: the fused render entry has no packed layout for it, so the tile body
+    runs call by call on the mirrored ops with the fine network on the generic GEMM path -- same seed, same image as the oracle's
+    restatement of the reference's loop (its tile order and CPU RNG draw order), 1e-4 abs."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    msd = O.init_linear_params(O.mip_shapes(10, 4, 320), 77, std=0.05, bias_std=0.02)
+    psd = W.proposal_state("small")
+    mip, prop = MipNeRF(10, 4, 320), ProposalNetwork(10, 256)
+    mip.load_state_dict(msd); prop.load_state_dict(psd)
+    mip, prop = mip.cuda().eval(), prop.cuda().eval()
+    A.pkg.set_precision("fp32")
+    pose = O.pose_spherical(37.0, -30.0, 4.0)[:3]
+    focal = O.fov2focal(0.6911112070083618, (50, 50))
+    torch.manual_seed(99)
+    with torch.no_grad():
+        want = O.render_image(psd, msd, pose, 50, focal, NEAR, FAR, 32, white_bkg=True, render_depth=True)
+    torch.manual_seed(99)
+    with torch.no_grad():
+        res = A.procedures.render_image(mip, prop, pose.cuda(), 50, focal, NEAR, FAR, 32, white_bkg=True, render_depth=True, rng="reference")
+    assert res["rgb"].shape == (3, 50, 50)
+    assert max_abs(res["rgb"].cpu(), want["rgb"]) <= 1e-4 and max_abs(res["depth_img"][0].cpu(), want["depth_img"][0]) <= 1e-4
+    with torch.no_grad():                                                            # default rng on this route: device-generator uniforms per chunk
+        res2 = A.procedures.render_image(mip, prop, pose.cuda(), 50, focal, NEAR, FAR, 32, white_bkg=True)
+    assert torch.isfinite(res2["rgb"]).all() and float(res2["rgb"].min()) >= 0.0 and float(res2["rgb"].max()) <= 1.0 + 1e-5
+    assert abs(float(res2["rgb"].mean()) - float(want["rgb"].mean())) <= 0.05        # (other uniforms: the same image up to sampling noise)
