@@ -1,0 +1,37 @@
+#!/bin/bash
+# CPU-oracle PSNR seeds of the converging recipe (profiles/r04_psnr) on the GPU BOX's host cores: the build container has 8 cores
+# (50 iterations a minute per 2-thread seed: 20 000 iterations do not fit a round), the box has 256 hardware threads that idle
+# while the GPU works.  NSEED oracle processes run side by side, THREADS each; the iteration count is chosen from a calibration
+# so that the seeds finish inside BUDGET_MIN; when it is not the 20 000 of the committed HIP rows, the HIP fp32 / bf16 seeds of
+# the SAME recipe run on the GPU meanwhile (identical initial weights, batches and uniforms per seed, so the rows pair).
+#   gpurun --timeout T -- 'NSEED=16 BUDGET_MIN=55 bash scripts/gpu_cpu_psnr.sh'      -> gpurun_out/psnr_cpu/
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/psnr_cpu; mkdir -p $OUT; cd $R
+NSEED=${NSEED:-16}; NCPU=$(nproc); THREADS=${THREADS:-$(( NCPU / NSEED ))}; [ $THREADS -lt 1 ] && THREADS=1
+BUDGET_MIN=${BUDGET_MIN:-55}
+RECIPE="--size 40 --views 25 --held 1 --rays 512 --coarse 32 --fine 64 --lr-mult 3 --hold 0.6"
+SEEDS=$(seq -s, 1 $NSEED)
+python -c "import torch" > /dev/null 2>&1                                  # page the image in before anything is timed
+echo "# host: $NCPU hardware threads, $NSEED seeds x $THREADS threads, budget $BUDGET_MIN min" | tee $OUT/calibration.log
+for s in $(seq 1 $NSEED); do
+  OMP_NUM_THREADS=$THREADS python scripts/psnr_seeds.py --modes cpu --seeds $((100 + s)) --threads $THREADS $RECIPE --iters 40 --ckpts 1 2>/dev/null | grep RESULT > $OUT/cal_$s.log &
+done
+wait
+SECS=$(cat $OUT/cal_*.log | sed -n 's/.* \([0-9]*\) s$/\1/p' | sort -n | tail -1); rm -f $OUT/cal_*.log
+[ -z "$SECS" ] || [ "$SECS" -lt 1 ] && SECS=1
+ITERS=$(python -c "
+r = 40.0 / $SECS; b = $BUDGET_MIN * 60.0
+print(20000 if r * b >= 20000 else 10000 if r * b >= 10000 else 6000)")
+[ -n "$FORCE_ITERS" ] && ITERS=$FORCE_ITERS
+echo "# calibration: 40 iterations (+ one held-out render) in $SECS s with all $NSEED processes running -> $ITERS iterations per seed" | tee -a $OUT/calibration.log
+for s in $(seq 1 $NSEED); do
+  OMP_NUM_THREADS=$THREADS PSNR_PROGRESS_EVERY=500 timeout $(( BUDGET_MIN * 60 + 600 )) python scripts/psnr_seeds.py --modes cpu --seeds $s --threads $THREADS \
+      $RECIPE --iters $ITERS --ckpts 4 > $OUT/cpu_${ITERS}_seed$s.log 2>&1 &
+done
+if [ "$ITERS" != 20000 ]; then
+  python scripts/psnr_seeds.py --modes fp32,bf16 --seeds $SEEDS $RECIPE --iters $ITERS --ckpts 4 > $OUT/hip_${ITERS}_seeds1-$NSEED.log 2>&1
+  grep SUMMARY $OUT/hip_${ITERS}_seeds1-$NSEED.log
+fi
+wait
+grep -h "RESULT" $OUT/cpu_${ITERS}_seed*.log
+grep -h PROGRESS $OUT/cpu_${ITERS}_seed*.log | sort -k5n -k3n | tail -$NSEED

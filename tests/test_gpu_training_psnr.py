@@ -31,6 +31,7 @@ LR = 1.5e-4 * RAYS / 512            # the reference's rule: args.lr * sample_ray
 N_VIEWS = 8                          # 7 training views + 1 held-out; scripts/gpu_psnr_long.py raises it for the long runs
 N_HELD = 1                           # held-out views (the last N_HELD of the scene); a checkpoint's figure is the mean of their PSNRs
 HELD_CHUNK = 4096                    # rays per held-out render call (bounds the oracle's activation memory at 200x200 views)
+PROGRESS_EVERY = int(os.environ.get("PSNR_PROGRESS_EVERY", "0"))   # run_oracle: a PROGRESS line every so many iterations (0 = none)
 SCHED = None                         # optional it -> learning rate (the long runs use nerf_base.DecayLrScheduler's rule, train.py:133,200)
 
 
@@ -110,6 +111,8 @@ def run_oracle(views, seed, resume=None):
         loss.backward()
         opt.step()
         hist.append(loss_img.item())
+        if PROGRESS_EVERY and (it + 1) % PROGRESS_EVERY == 0:            # the hours-long CPU runs: a partial run still leaves its trajectory
+            print("PROGRESS seed %d it %d train-psnr(last 200) %.3f" % (seed, it + 1, psnr(sum(hist[-200:]) / len(hist[-200:]))), flush=True)
         if it + 1 in CHECKPOINTS:
             with torch.no_grad():                                        # held-out views, fixed uniforms
                 g = torch.Generator().manual_seed(99)
