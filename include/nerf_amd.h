@@ -454,6 +454,40 @@ int    nerf_amd_gemm(int precision, int64_t M, int64_t N, int64_t P, const float
 int    nerf_amd_sigmoid_backward(const float* g, int64_t g_stride, const float* y, int64_t y_stride, int64_t M, int cols,
                                  float* out, int64_t out_stride, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Generic-shape Ref-NeRF (ABI 120): a RefNeRF the fused kernel is not compiled for -- hidden width above 256, more than 10 position
+ * octaves, `--ide_level 5` (procedures.py:211; 36 spherical-harmonic terms) -- runs layer by layer on nerf_amd_gemm; these are the
+ * element-wise stages between its layer products (ref_model.py:78-105), forward and adjoint.  One row per sample, fp32, explicit row
+ * strides in floats (column ranges of a concatenated buffer are views).  `heads` (M, >= 11) = the raw outputs of
+ * cat(norm_col_tint_head, rho_tau_head):  [normal 0-2 | diffuse 3-5 | tint 6-8 | roughness 9 | density 10].
+ *
+ *   nerf_amd_ref_dir_inputs            ref_model.py:80-92: roughness = softplus(rho - 1), n = -n / (|n| + 1e-7), w_r = d - 2 (d.n) n, the
+ *                                      integrated directional encoding of ref_func.py:76-108 at `ide_level` 1..5 (T = 2^level - 1 + level
+ *                                      terms; `ide_table` = its (2^(level-1) + 1, T) coefficient matrix, ref_func.py:60-74) and n.d
+ *                                      -> out (M, >= 2T+1) = [IDE real T | IDE imag T | n.d], normal (M,3) contiguous
+ *   nerf_amd_ref_dir_inputs_backward   d_out (M, >= 2T+1), g_normal (M, >= 3) -> d_heads columns 0-2 (normal) and 9 (roughness)
+ *   nerf_amd_ref_combine               ref_model.py:98-105: rgb = spec * sigmoid(tint) + sigmoid(diffuse) (NERF_AMD_REF_SRGB: linear_to_srgb(
+ *                                      spec * sigmoid(tint) + sigmoid(diffuse - log 3))), `spec` (M, >= 3) = sigmoid(spec_rgb_head);
+ *                                      rgbo (M,4) contiguous = [rgb | raw density]
+ *   nerf_amd_ref_combine_backward      g_rgbo (M, >= 4) -> d_spec (M, >= 3) w.r.t. spec_rgb_head's PRE-activation, d_heads columns 3-8, 10
+ *   nerf_amd_positional_encoding_backward   d_x (M,3) = (d [x | sin 2^f x | cos 2^f x] / d x)^T d_enc, f < L (nerf_helper.py:38-48 layout behind
+ *                                      the raw position when cat_origin): RefNeRF.get_grad's last step (ref_model.py:119-125)
+ *   nerf_amd_add_rows                  dst[m, c] += src[m, c], c < cols
+ */
+int nerf_amd_ref_dir_inputs(const float* heads, int64_t heads_stride, const float* dirs, int64_t dirs_stride, int64_t M, int ide_level,
+                            const float* ide_table, float* out, int64_t out_stride, float* normal, void* stream);
+int nerf_amd_ref_dir_inputs_backward(const float* heads, int64_t heads_stride, const float* dirs, int64_t dirs_stride, int64_t M, int ide_level,
+                                     const float* ide_table, const float* d_out, int64_t d_out_stride, const float* g_normal,
+                                     int64_t g_normal_stride, float* d_heads, int64_t d_heads_stride, void* stream);
+int nerf_amd_ref_combine(const float* heads, int64_t heads_stride, const float* spec, int64_t spec_stride, int64_t M, int ref_flags,
+                         float* rgbo, void* stream);
+int nerf_amd_ref_combine_backward(const float* g_rgbo, int64_t g_stride, const float* heads, int64_t heads_stride, const float* spec,
+                                  int64_t spec_stride, int64_t M, int ref_flags, float* d_spec, int64_t d_spec_stride, float* d_heads,
+                                  int64_t d_heads_stride, void* stream);
+int nerf_amd_positional_encoding_backward(const float* d_enc, int64_t d_enc_stride, const float* x, int64_t x_stride, int64_t M, int L,
+                                          int cat_origin, float* d_x, void* stream);
+int nerf_amd_add_rows(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int64_t M, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

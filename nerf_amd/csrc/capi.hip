@@ -62,6 +62,13 @@ size_t gk_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int gk_gemm(int, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*, int64_t, int64_t, float*, int64_t, const float*, int, const float*, int64_t,
             void*, hipStream_t);
 int gk_sigmoid_backward(const float*, int64_t, const float*, int64_t, int64_t, int, float*, int64_t, hipStream_t);
+int gr_dir_inputs(const float*, int64_t, const float*, int64_t, int64_t, int, const float*, float*, int64_t, float*, hipStream_t);
+int gr_dir_inputs_backward(const float*, int64_t, const float*, int64_t, int64_t, int, const float*, const float*, int64_t, const float*, int64_t, float*, int64_t,
+                           hipStream_t);
+int gr_combine(const float*, int64_t, const float*, int64_t, int64_t, int, float*, hipStream_t);
+int gr_combine_backward(const float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int, float*, int64_t, float*, int64_t, hipStream_t);
+int gr_pe_backward(const float*, int64_t, const float*, int64_t, int64_t, int, int, float*, hipStream_t);
+int gr_add_rows(float*, int64_t, const float*, int64_t, int64_t, int, hipStream_t);
 int sk_advance_seed(uint64_t*, hipStream_t);
 int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
@@ -122,7 +129,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 119; }
+int nerf_amd_version(void) { return 120; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -770,6 +777,60 @@ int nerf_amd_sigmoid_backward(const float* g, int64_t g_stride, const float* y, 
     if (M * cols && (!g || !y || !out)) return fail(NERF_AMD_EINVAL, "nerf_amd_sigmoid_backward: NULL argument");
     if (g_stride < cols || y_stride < cols || out_stride < cols) return fail(NERF_AMD_EINVAL, "nerf_amd_sigmoid_backward: row stride smaller than cols");
     return hip_status(gk_sigmoid_backward(g, g_stride, y, y_stride, M, cols, out, out_stride, S(stream)), "nerf_amd_sigmoid_backward");
+}
+
+// ---- generic-shape Ref-NeRF: the element-wise stages between its layer products (generic_ref_kernels.hip) ----
+int nerf_amd_ref_dir_inputs(const float* heads, int64_t heads_stride, const float* dirs, int64_t dirs_stride, int64_t M, int ide_level, const float* ide_table,
+                            float* out, int64_t out_stride, float* normal, void* stream) {
+    if (M < 0 || ide_level < 1 || ide_level > 5) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_dir_inputs: bad size / ide_level (1..5)");
+    if (M && (!heads || !dirs || !ide_table || !out || !normal)) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_dir_inputs: NULL argument");
+    const int T = (1 << ide_level) - 1 + ide_level;
+    if (heads_stride < 11 || dirs_stride < 3 || out_stride < 2 * T + 1) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_dir_inputs: row stride too small");
+    return hip_status(gr_dir_inputs(heads, heads_stride, dirs, dirs_stride, M, ide_level, ide_table, out, out_stride, normal, S(stream)), "nerf_amd_ref_dir_inputs");
+}
+
+int nerf_amd_ref_dir_inputs_backward(const float* heads, int64_t heads_stride, const float* dirs, int64_t dirs_stride, int64_t M, int ide_level,
+                                     const float* ide_table, const float* d_out, int64_t d_out_stride, const float* g_normal, int64_t g_normal_stride,
+                                     float* d_heads, int64_t d_heads_stride, void* stream) {
+    if (M < 0 || ide_level < 1 || ide_level > 5) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_dir_inputs_backward: bad size / ide_level (1..5)");
+    if (M && (!heads || !dirs || !ide_table || !d_out || !g_normal || !d_heads)) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_dir_inputs_backward: NULL argument");
+    const int T = (1 << ide_level) - 1 + ide_level;
+    if (heads_stride < 11 || dirs_stride < 3 || d_out_stride < 2 * T + 1 || g_normal_stride < 3 || d_heads_stride < 11)
+        return fail(NERF_AMD_EINVAL, "nerf_amd_ref_dir_inputs_backward: row stride too small");
+    return hip_status(gr_dir_inputs_backward(heads, heads_stride, dirs, dirs_stride, M, ide_level, ide_table, d_out, d_out_stride, g_normal, g_normal_stride, d_heads,
+                                             d_heads_stride, S(stream)), "nerf_amd_ref_dir_inputs_backward");
+}
+
+int nerf_amd_ref_combine(const float* heads, int64_t heads_stride, const float* spec, int64_t spec_stride, int64_t M, int ref_flags, float* rgbo, void* stream) {
+    if (M < 0 || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_combine: bad size / ref_flags");
+    if (M && (!heads || !spec || !rgbo)) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_combine: NULL argument");
+    if (heads_stride < 11 || spec_stride < 3) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_combine: row stride too small");
+    return hip_status(gr_combine(heads, heads_stride, spec, spec_stride, M, (ref_flags & NERF_AMD_REF_SRGB) ? 1 : 0, rgbo, S(stream)), "nerf_amd_ref_combine");
+}
+
+int nerf_amd_ref_combine_backward(const float* g_rgbo, int64_t g_stride, const float* heads, int64_t heads_stride, const float* spec, int64_t spec_stride, int64_t M,
+                                  int ref_flags, float* d_spec, int64_t d_spec_stride, float* d_heads, int64_t d_heads_stride, void* stream) {
+    if (M < 0 || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_combine_backward: bad size / ref_flags");
+    if (M && (!g_rgbo || !heads || !spec || !d_spec || !d_heads)) return fail(NERF_AMD_EINVAL, "nerf_amd_ref_combine_backward: NULL argument");
+    if (g_stride < 4 || heads_stride < 11 || spec_stride < 3 || d_spec_stride < 3 || d_heads_stride < 11)
+        return fail(NERF_AMD_EINVAL, "nerf_amd_ref_combine_backward: row stride too small");
+    return hip_status(gr_combine_backward(g_rgbo, g_stride, heads, heads_stride, spec, spec_stride, M, (ref_flags & NERF_AMD_REF_SRGB) ? 1 : 0, d_spec, d_spec_stride,
+                                          d_heads, d_heads_stride, S(stream)), "nerf_amd_ref_combine_backward");
+}
+
+int nerf_amd_positional_encoding_backward(const float* d_enc, int64_t d_enc_stride, const float* x, int64_t x_stride, int64_t M, int L, int cat_origin, float* d_x,
+                                          void* stream) {
+    if (M < 0 || L < 0) return fail(NERF_AMD_EINVAL, "nerf_amd_positional_encoding_backward: bad size");
+    if (M && (!d_enc || !x || !d_x)) return fail(NERF_AMD_EINVAL, "nerf_amd_positional_encoding_backward: NULL argument");
+    if (d_enc_stride < 6 * L + (cat_origin ? 3 : 0) || x_stride < 3) return fail(NERF_AMD_EINVAL, "nerf_amd_positional_encoding_backward: row stride too small");
+    return hip_status(gr_pe_backward(d_enc, d_enc_stride, x, x_stride, M, L, cat_origin ? 1 : 0, d_x, S(stream)), "nerf_amd_positional_encoding_backward");
+}
+
+int nerf_amd_add_rows(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int64_t M, int cols, void* stream) {
+    if (M < 0 || cols < 0) return fail(NERF_AMD_EINVAL, "nerf_amd_add_rows: bad size");
+    if (M * cols && (!dst || !src)) return fail(NERF_AMD_EINVAL, "nerf_amd_add_rows: NULL argument");
+    if (dst_stride < cols || src_stride < cols) return fail(NERF_AMD_EINVAL, "nerf_amd_add_rows: row stride smaller than cols");
+    return hip_status(gr_add_rows(dst, dst_stride, src, src_stride, M, cols, S(stream)), "nerf_amd_add_rows");
 }
 
 }  // extern "C"

@@ -9,8 +9,10 @@ modules, with no torch arithmetic and no library GEMM.  torch only owns the buff
 
 This is the COMPATIBILITY path of the shape arguments: activations make a round trip through HBM per layer (fp32 rows), so it runs at a
 fraction of the fused kernels' rate -- every shape the fused kernels are compiled for (widths <= 256, <= 10 octaves, either cat_origin)
-keeps them.  Sample positions get no gradient here (the reference's loss never uses it, utils.py:35-36); scene contraction and the
-integrated PE are flags of the fused kernels' sample fetch only.
+keeps them.  Sample positions get a gradient inside RefNeRF.get_grad only (d density / d position: a dgrad-only chain + the encoding's
+adjoint, like on the fused path; the reference's loss never uses another, utils.py:35-36); scene contraction and the integrated PE are
+flags of the fused kernels' sample fetch only.  RefNeRF takes this path as well (`ref_forward`: hidden width > 256, > 10 octaves, or
+`--ide_level 5`, whose 36 spherical-harmonic terms the fused kernel's three IDE K groups do not hold).
 """
 from typing import List, Tuple
 
@@ -80,11 +82,17 @@ def proposal_forward(net, pts: torch.Tensor) -> torch.Tensor:
 
     if not ab.needs_grad(pts, *params):
         return run(pts)
-    if pts.requires_grad:
-        ab.unsupported("a generic-shape ProposalNetwork (hidden width > 256 or > 10 octaves) with sample positions that require a gradient")
     held = {}
 
     def bwd(g, p, *wb):
+        if "acts" not in held:
+            raise RuntimeError("nerf_amd: the activations of this forward were already consumed (backward twice over the same graph)")
+        if ab._VJP.inputs_only:                                  # RefNeRF.get_grad(density, coarse_samples) (train.py:165-168, `prop_normal`)
+            acts = held["acts"]
+            delta = ops.gemm(prec, g.reshape(-1, 1).float().contiguous(), layers[4].weight.detach(), mask=acts[4])
+            d_enc, _ = _dgrad_only(prec, delta, layers[:4], acts[:4], acts[0].shape[1])
+            gx = ops.positional_encoding_backward(d_enc, p.reshape(-1, 3).float().contiguous(), net.position_flevel, net.cat_origin)
+            return (gx.view(p.shape), *[None] * len(wb))
         acts = held.pop("acts")
         ones = torch.ones((acts[0].shape[0], 1), dtype=torch.float32, device=g.device)
         delta = g.reshape(-1, 1).float().contiguous()
@@ -161,3 +169,135 @@ def mip_forward(net, pts: torch.Tensor) -> torch.Tensor:
         gW[:4], gb[:4] = w1, b1
         return (None, *gW, *gb)
     return ab.HipOp.apply(lambda p, *wb: run(p, held), bwd, 1, pts, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------------- RefNeRF
+def _dgrad_only(prec: int, delta: torch.Tensor, layers, inputs, enc_cols: int):
+    """dgrad-only chain (no parameter gradients: RefNeRF.get_grad) through Linear+ReLU `layers` whose first input is cat(encoding
+    [enc_cols], hidden) (enc_cols == its whole width: a plain encoding).  -> (gradient w.r.t. the encoding columns, gradient w.r.t. the
+    pre-activation that produced the hidden columns or None)."""
+    for k in range(len(layers) - 1, 0, -1):
+        delta = ops.gemm(prec, delta, layers[k].weight.detach(), mask=inputs[k])
+    w0 = layers[0].weight.detach()
+    d_enc = ops.gemm(prec, delta, w0[:, :enc_cols])
+    d_hid = ops.gemm(prec, delta, w0[:, enc_cols:], mask=inputs[0][:, enc_cols:]) if w0.shape[1] > enc_cols else None
+    return d_enc, d_hid
+
+
+def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise) -> Tuple[torch.Tensor, torch.Tensor]:
+    """RefNeRF.forward (ref_model.py:68-106) for a module the fused Ref-NeRF kernel is not compiled for (hidden width > 256, > 10 position
+    octaves, ide_level 5): pos, dirs (N,S,3) -> ((N,S,4) = [rgb | raw density], predicted normal (N,S,3)).  Layer products on nerf_amd_gemm,
+    the stages between them (normal / reflection / IDE / colour combination) on the element-wise kernels of generic_ref_kernels.hip; the
+    backward is the same GEMM in its other stride forms + those kernels' adjoints.  `noise` = the train-mode bottle-neck perturbation
+    (ref_model.py:84-85) or None.  Position gradients exist for RefNeRF.get_grad only (d density / d position), like on the fused path."""
+    prec = ops.current_precision()
+    S1 = [net.spa_block1[i] for i in (0, 2, 4, 6)]
+    S2 = [net.spa_block2[i] for i in (0, 2, 4, 6)]
+    D1 = [net.dir_block1[i] for i in (0, 2, 4, 6)]
+    D2 = [net.dir_block2[i] for i in (0, 2, 4, 6)]
+    nct, rt, bn, sph = net.norm_col_tint_head, net.rho_tau_head, net.bottle_neck, net.spec_rgb_head[0]
+    named = list(net.named_parameters())
+    names = [n for n, _ in named]
+    params = [p for _, p in named]
+    shape = pos.shape[:-1]
+    deg, Bd, T = net.sh_max_level, net.bottle_neck_dim, net.dir_enc_dim // 2
+    Din = Bd + 2 * T + 1
+    flags = net.kernel_flags
+    table = net._ide_table(pos.device, deg)
+
+    def run(p, dd, keep=None):
+        x = p.reshape(-1, 3).float().contiguous()
+        dv = dd.reshape(-1, 3).float().contiguous()
+        M, dev = x.shape[0], x.device
+        ex = _encode_positions(x, net.position_flevel, net.cat_origin)
+        E, W = ex.shape[1], net.hidden_unit
+        a = [ex]
+        for l in S1[:3]:
+            a.append(_linear(prec, a[-1], l, RELU))
+        skip = torch.empty((M, E + W), dtype=torch.float32, device=dev)          # cat(encoded_x, x_tmp) (ref_model.py:76)
+        skip[:, :E] = ex
+        _linear(prec, a[-1], S1[3], RELU, out=skip[:, E:])
+        b = [skip]
+        for l in S2:
+            b.append(_linear(prec, b[-1], l, RELU))
+        g = b[-1]                                                               # `intermediate` (M, output_dim)
+        # the three heads hang off g: one product on cat(norm_col_tint_head, rho_tau_head) (11 rows), one for the bottle-neck, written
+        # straight into its columns of the directional input vector [bottle-neck | IDE real | IDE imag | n.d] = the front of cat(all_inputs, r_tmp)
+        w_heads = torch.cat((nct.weight.detach(), rt.weight.detach()), dim=0)
+        b_heads = torch.cat((nct.bias.detach(), rt.bias.detach()), dim=0)
+        heads = ops.gemm(prec, g, w_heads.t(), bias=b_heads)
+        cat2 = torch.empty((M, Din + W), dtype=torch.float32, device=dev)
+        _linear(prec, g, bn, out=cat2[:, :Bd])
+        if noise is not None:
+            ops.add_rows_(cat2[:, :Bd], noise.reshape(-1, Bd).float())
+        normal = ops.ref_dir_inputs(heads, dv, deg, table, cat2[:, Bd:Din])
+        r = [cat2[:, :Din]]
+        for l in D1[:3]:
+            r.append(_linear(prec, r[-1], l, RELU))
+        _linear(prec, r[-1], D1[3], RELU, out=cat2[:, Din:])
+        q = [cat2]
+        for l in D2:
+            q.append(_linear(prec, q[-1], l, RELU))
+        spec = _linear(prec, q[-1], sph, SIGMOID)
+        rgbo = ops.ref_combine(heads, spec, flags)
+        if keep is not None:
+            keep.update(x=x, dv=dv, a=a, b=b, heads=heads, r=r, q=q, spec=spec, E=E, w_heads=w_heads)
+        return torch.cat((rgbo, normal), dim=-1).view(*shape, 7)
+
+    if not ab.needs_grad(pos, dirs, *params):
+        out = run(pos, dirs)
+        return out[..., :4].contiguous(), out[..., 4:].contiguous()
+    held = {}
+
+    def bwd(gr, p, dd, *wb):
+        if "heads" not in held:
+            raise RuntimeError("nerf_amd: the activations of this forward were already consumed (backward twice over the same graph)")
+        g7 = gr.reshape(-1, 7).float().contiguous()
+        M, dev = g7.shape[0], g7.device
+        a, b, E = held["a"], held["b"], held["E"]
+        g = b[-1]
+        if ab._VJP.inputs_only:                                  # RefNeRF.get_grad: d density / d position, a dgrad-only chain
+            delta = ops.gemm(prec, g7[:, 3:4], rt.weight.detach()[1:2, :], mask=g)
+            d_enc, d_hid = _dgrad_only(prec, delta, S2, b[:4], E)
+            d_enc1, _ = _dgrad_only(prec, d_hid, S1, a[:4], E)
+            ops.add_rows_(d_enc, d_enc1)
+            gx = ops.positional_encoding_backward(d_enc, held["x"], net.position_flevel, net.cat_origin)
+            return (gx.view(p.shape), None, *[None] * len(wb))
+        heads, r, q, spec, w_heads = (held.pop(k) for k in ("heads", "r", "q", "spec", "w_heads"))
+        x, dv = held.pop("x"), held.pop("dv")
+        held.pop("a"); held.pop("b")
+        ones = torch.ones((M, 1), dtype=torch.float32, device=dev)
+        G = {}
+        dhb = torch.empty((M, 11 + Bd), dtype=torch.float32, device=dev)        # [d heads 11 | d bottle-neck]: one product back into g
+        d_spec = ops.ref_combine_backward(g7[:, :4], heads, spec, flags, dhb)
+        G["spec_rgb_head.0.weight"], G["spec_rgb_head.0.bias"] = _param_grads(prec, d_spec, q[4], ones)
+        delta = ops.gemm(prec, d_spec, sph.weight.detach(), mask=q[4])
+        # dir_block2 (its first input is cat(all_inputs [Din], r_tmp)): the all_inputs columns get an unmasked gradient, the hidden ones r_tmp's ReLU
+        for k in (3, 2, 1):
+            G["dir_block2.%d.weight" % (2 * k)], G["dir_block2.%d.bias" % (2 * k)] = _param_grads(prec, delta, q[k], ones)
+            delta = ops.gemm(prec, delta, D2[k].weight.detach(), mask=q[k])
+        G["dir_block2.0.weight"], G["dir_block2.0.bias"] = _param_grads(prec, delta, q[0], ones)
+        w20 = D2[0].weight.detach()
+        d_all = ops.gemm(prec, delta, w20[:, :Din])
+        delta = ops.gemm(prec, delta, w20[:, Din:], mask=q[0][:, Din:])
+        for k in (3, 2, 1):
+            G["dir_block1.%d.weight" % (2 * k)], G["dir_block1.%d.bias" % (2 * k)] = _param_grads(prec, delta, r[k], ones)
+            delta = ops.gemm(prec, delta, D1[k].weight.detach(), mask=r[k])
+        G["dir_block1.0.weight"], G["dir_block1.0.bias"] = _param_grads(prec, delta, r[0], ones)
+        ops.add_rows_(d_all, ops.gemm(prec, delta, D1[0].weight.detach()))
+        ops.ref_dir_inputs_backward(heads, dv, deg, table, d_all[:, Bd:], g7[:, 4:7], dhb)
+        dhb[:, 11:] = d_all[:, :Bd]                                              # the bottle-neck has no activation (and the noise no gradient)
+        gh_w, gh_b = _param_grads(prec, dhb[:, :11], g, ones)
+        G["norm_col_tint_head.weight"], G["norm_col_tint_head.bias"] = gh_w[:9], gh_b[:9]
+        G["rho_tau_head.weight"], G["rho_tau_head.bias"] = gh_w[9:11], gh_b[9:11]
+        G["bottle_neck.weight"], G["bottle_neck.bias"] = _param_grads(prec, dhb[:, 11:], g, ones)
+        delta = ops.gemm(prec, dhb, torch.cat((w_heads, bn.weight.detach()), dim=0), mask=g)
+        w2, b2, delta = _chain_back(prec, delta, S2, b[:4], ones, first_cols=E)
+        w1, b1, _ = _chain_back(prec, delta, S1, a[:4], ones, first_cols=-1)
+        for i, k in enumerate((0, 2, 4, 6)):
+            G["spa_block2.%d.weight" % k], G["spa_block2.%d.bias" % k] = w2[i], b2[i]
+            G["spa_block1.%d.weight" % k], G["spa_block1.%d.bias" % k] = w1[i], b1[i]
+        return (None, None, *[G[n].reshape(wb[i].shape) for i, n in enumerate(names)])
+
+    out = ab.HipOp.apply(lambda p, dd, *wb: run(p, dd, held), bwd, 1, pos, dirs, *params)
+    return out[..., :4].clone(), out[..., 4:].clone()                            # (callers write into rgbo[..., -1] in place)

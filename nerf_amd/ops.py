@@ -1017,3 +1017,79 @@ def sigmoid_backward(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     out = torch.empty((M, cols), dtype=torch.float32, device=y.device)
     check(lib.nerf_amd_sigmoid_backward(_ptr(g), int(g.stride(0)), _ptr(y), int(y.stride(0)), M, cols, _ptr(out), cols, _stream()), "nerf_amd_sigmoid_backward")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ generic-shape Ref-NeRF stages (ABI 120)
+def _rows(t: torch.Tensor, name: str, min_cols: int) -> torch.Tensor:
+    """a 2-D fp32 device view with unit column stride (row stride = t.stride(0)); anything else is made contiguous"""
+    if not t.is_cuda:
+        raise RuntimeError("nerf_amd: '%s' must live on the HIP device (got %s); there is no CPU path" % (name, t.device))
+    if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1) or t.stride(0) < t.shape[1]:
+        t = t.reshape(-1, t.shape[-1]).float().contiguous()
+    if t.shape[1] < min_cols:
+        raise RuntimeError("nerf_amd: '%s' needs at least %d columns (got %d)" % (name, min_cols, t.shape[1]))
+    return t
+
+
+def ref_dir_inputs(heads: torch.Tensor, dirs: torch.Tensor, ide_level: int, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """ref_model.py:80-92 per sample: heads (M,11) [normal | diffuse | tint | roughness | density] raw, dirs (M,3) -> writes
+    [IDE real T | IDE imag T | n.d] into the (M, 2T+1) view `out`, returns the predicted normal (M,3)."""
+    heads, dirs, out_v = _rows(heads, "heads", 11), _rows(dirs, "dirs", 3), out
+    M = heads.shape[0]
+    T = (1 << ide_level) - 1 + ide_level
+    if out_v.dim() != 2 or out_v.dtype != torch.float32 or tuple(out_v.shape) != (M, 2 * T + 1) or out_v.stride(1) != 1 or not out_v.is_cuda:
+        raise RuntimeError("nerf_amd.ref_dir_inputs: out must be a (%d, %d) float32 device view with unit column stride" % (M, 2 * T + 1))
+    normal = torch.empty((M, 3), dtype=torch.float32, device=heads.device)
+    check(lib.nerf_amd_ref_dir_inputs(_ptr(heads), int(heads.stride(0)), _ptr(dirs), int(dirs.stride(0)), M, int(ide_level), _ptr(_dev(table, "ide_table")),
+                                      _ptr(out_v), int(out_v.stride(0)), _ptr(normal), _stream()), "nerf_amd_ref_dir_inputs")
+    return normal
+
+
+def ref_dir_inputs_backward(heads: torch.Tensor, dirs: torch.Tensor, ide_level: int, table: torch.Tensor, d_out: torch.Tensor, g_normal: torch.Tensor,
+                            d_heads: torch.Tensor) -> None:
+    """adjoint of ref_dir_inputs: writes columns 0-2 (normal) and 9 (roughness) of the (M, >= 11) view `d_heads`"""
+    heads, dirs, d_out, g_normal = _rows(heads, "heads", 11), _rows(dirs, "dirs", 3), _rows(d_out, "d_out", 3), _rows(g_normal, "g_normal", 3)
+    M = heads.shape[0]
+    check(lib.nerf_amd_ref_dir_inputs_backward(_ptr(heads), int(heads.stride(0)), _ptr(dirs), int(dirs.stride(0)), M, int(ide_level), _ptr(_dev(table, "ide_table")),
+                                               _ptr(d_out), int(d_out.stride(0)), _ptr(g_normal), int(g_normal.stride(0)), _ptr(d_heads), int(d_heads.stride(0)),
+                                               _stream()), "nerf_amd_ref_dir_inputs_backward")
+
+
+def ref_combine(heads: torch.Tensor, spec: torch.Tensor, flags: int) -> torch.Tensor:
+    """ref_model.py:98-105: spec (M,3) = sigmoid(spec_rgb_head) -> rgbo (M,4) = [rgb | raw density]"""
+    heads, spec = _rows(heads, "heads", 11), _rows(spec, "spec", 3)
+    M = heads.shape[0]
+    rgbo = torch.empty((M, 4), dtype=torch.float32, device=heads.device)
+    check(lib.nerf_amd_ref_combine(_ptr(heads), int(heads.stride(0)), _ptr(spec), int(spec.stride(0)), M, int(flags), _ptr(rgbo), _stream()), "nerf_amd_ref_combine")
+    return rgbo
+
+
+def ref_combine_backward(g_rgbo: torch.Tensor, heads: torch.Tensor, spec: torch.Tensor, flags: int, d_heads: torch.Tensor) -> torch.Tensor:
+    """adjoint of ref_combine: -> d_spec (M,3) w.r.t. spec_rgb_head's pre-activation; writes columns 3-8 and 10 of `d_heads`"""
+    g, heads, spec = _rows(g_rgbo, "g_rgbo", 4), _rows(heads, "heads", 11), _rows(spec, "spec", 3)
+    M = heads.shape[0]
+    d_spec = torch.empty((M, 3), dtype=torch.float32, device=heads.device)
+    check(lib.nerf_amd_ref_combine_backward(_ptr(g), int(g.stride(0)), _ptr(heads), int(heads.stride(0)), _ptr(spec), int(spec.stride(0)), M, int(flags),
+                                            _ptr(d_spec), 3, _ptr(d_heads), int(d_heads.stride(0)), _stream()), "nerf_amd_ref_combine_backward")
+    return d_spec
+
+
+def positional_encoding_backward(d_enc: torch.Tensor, x: torch.Tensor, L: int, cat_origin: bool) -> torch.Tensor:
+    """d_x (M,3) from the gradient w.r.t. [x | sin 2^f x | cos 2^f x] rows (nerf_helper.py:38-48 layout, raw position in front when cat_origin)"""
+    d_enc, x = _rows(d_enc, "d_enc", 6 * L + (3 if cat_origin else 0)), _rows(x, "x", 3)
+    M = x.shape[0]
+    out = torch.empty((M, 3), dtype=torch.float32, device=x.device)
+    check(lib.nerf_amd_positional_encoding_backward(_ptr(d_enc), int(d_enc.stride(0)), _ptr(x), int(x.stride(0)), M, int(L), int(bool(cat_origin)), _ptr(out),
+                                                    _stream()), "nerf_amd_positional_encoding_backward")
+    return out
+
+
+def add_rows_(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """dst += src over (M, cols) fp32 device views with unit column stride"""
+    if tuple(dst.shape) != tuple(src.shape) or dst.dim() != 2 or dst.dtype != torch.float32 or src.dtype != torch.float32 or not dst.is_cuda:
+        raise RuntimeError("nerf_amd.add_rows_: (M, cols) float32 device views of one shape")
+    M, cols = dst.shape
+    if cols > 1 and (dst.stride(1) != 1 or src.stride(1) != 1):
+        raise RuntimeError("nerf_amd.add_rows_: unit column stride")
+    check(lib.nerf_amd_add_rows(_ptr(dst), int(dst.stride(0)), _ptr(src), int(src.stride(0)), M, cols, _stream()), "nerf_amd_add_rows")
+    return dst

@@ -42,7 +42,8 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
     return u1.view(-1, RENDER_COARSE_PNUM).to(device), u2.view(-1, sample_num + 1).to(device)
 
 
-def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096):
+def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096,
+                          is_ref_model: bool = False, cam_dir=None):
     """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
     maxBlurFilter, inverseSample, NeRF.length2pts, network.forward, NeRF.render -- on chunks of rays: the route of networks the fused
     render entry (nerf_amd_render_rays) has no packed layout for.  Every call is a HIP kernel of this package; uniforms that were not
@@ -52,6 +53,7 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
     N = rays.shape[0]
     rgb = torch.empty((N, 3), dtype=torch.float32, device=rays.device)
     depth = torch.empty((N,), dtype=torch.float32, device=rays.device) if render_depth else None
+    normal_px = torch.empty((N,), dtype=torch.float32, device=rays.device) if cam_dir is not None else None
     resolution = (far - near) / sample_num                                           # procedures.py:57
     for s in range(0, N, chunk):
         r = rays[s: s + chunk].contiguous()
@@ -62,14 +64,23 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
         density = prop_net.forward(pts)
         prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z, r[:, 3:]), 0.01)
         fine, _ = inverseSample(prop_w, z, sample_num + 1, sort=True, u=u2.contiguous())
-        fine = fine[..., :-1].contiguous()
-        rgbo = network.forward(NeRF.length2pts(r, fine))
+        normal = None
+        if is_ref_model:                                                             # :71-74
+            samples, fine = NeRF.coarseFineMerge(r, z, fine)
+            rgbo, normal = network.forward(samples)
+            rgbo[..., -1] = torch.nn.functional.softplus(rgbo[..., -1] + 0.5)
+        else:
+            fine = fine[..., :-1].contiguous()
+            rgbo = network.forward(NeRF.length2pts(r, fine))
         part, _, extras = NeRF.render(rgbo, fine, r[:, 3:], white_bkg=white_bkg, density_act=torch.nn.functional.relu,
-                                      render_depth=(near, far) if render_depth else None)
+                                      render_depth=(near, far) if render_depth else None,
+                                      normal_info=(normal, cam_dir) if cam_dir is not None else None)
         rgb[s: s + n] = part
         if render_depth:
             depth[s: s + n] = extras["depth_img"].reshape(-1)
-    return rgb, depth
+        if cam_dir is not None:
+            normal_px[s: s + n] = extras["normal_img"].reshape(-1)
+    return rgb, depth, normal_px
 
 
 def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
@@ -123,13 +134,15 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         if is_ref_model:
             raise NotImplementedError("nerf_amd: the integrated PE is wired for the MipNeRF render path only")
         ipe_radius = (2.0 / (12.0 ** 0.5) / fx) if ipe is True else float(ipe)
-    generic = (not is_ref_model) and (network._generic() or prop_net._generic())
+    generic = network._generic() or prop_net._generic()
     if generic:
         # a network LARGER than the fused kernels' compiled shapes (hidden width > 256, > 10 octaves): the reference's tile body
         # (procedures.py:62-85) call by call on the mirrored ops -- the networks run layer by layer (nerf_amd/generic_path.py)
         if contract or ipe:
             raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
-        rgb, depth = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth))
+        rgb, depth, normal_px = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth),
+                                                      is_ref_model=is_ref_model,
+                                                      cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None)
     elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,

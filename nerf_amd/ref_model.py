@@ -56,11 +56,18 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         # level-4 column layout [bottle-neck 128 | real 19 | imag 19 | n.d] with zeros on the terms the module does not have.  Level 5
         # (36 terms) does not fit the kernel's three IDE K groups.
         # position_flevel < 10 / cat_origin=False: zero weights on the position-encoding columns the module lacks (_embed_pos, as in _packed.py)
-        ok = (1 <= self.position_flevel <= 10 and 1 <= self.sh_max_level <= 4 and self.bottle_neck_dim == 128 and 1 <= self.hidden_unit <= 256
-              and self.output_dim == self.hidden_unit)
-        if not ok:
-            raise NotImplementedError("nerf_amd: the HIP Ref-NeRF kernel is instantiated for RefNeRF(position_flevel <= 10, ide_level 1..4, 128, "
-                                      "hidden_unit = output_dim <= 256) (use_srgb on or off)")
+        # Shapes the fused kernel is NOT compiled for -- hidden width above 256, more than 10 position octaves, `--ide_level 5` (36 terms), another
+        # bottle-neck width -- run layer by layer on the generic MFMA GEMM + the element-wise Ref-NeRF stages (nerf_amd/generic_path.py
+        # `ref_forward`, generic_ref_kernels.hip), forward and backward.
+        if not (self.position_flevel >= 1 and 1 <= self.sh_max_level <= 5 and self.bottle_neck_dim >= 1 and self.hidden_unit >= 1):
+            raise NotImplementedError("nerf_amd: RefNeRF needs position_flevel >= 1, ide_level 1..5 (ref_func.py:63: higher levels are numerically "
+                                      "unstable in the reference too) and positive widths")
+        if self.output_dim != self.hidden_unit:
+            raise NotImplementedError("nerf_amd: RefNeRF needs hidden_unit == output_dim (the reference's own dir_block2.6 takes hidden_unit inputs "
+                                      "from an output_dim-wide layer, ref_model.py:56-58)")
+
+    def _generic(self) -> bool:
+        return self.hidden_unit > 256 or self.position_flevel > 10 or self.sh_max_level > 4 or self.bottle_neck_dim != 128
 
     def _pos_segment(self):
         return self.encoding_segment(self.position_flevel, self.cat_origin)
@@ -154,6 +161,9 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         noise = None
         if self.training and self.perturb_bottle_neck_w > 0:                      # ref_model.py:84-85 (drawn here, given to the kernel)
             noise = torch.normal(0, self.perturb_bottle_neck_w, pos.shape[:-1] + (self.bottle_neck_dim,), device=pos.device)
+        if self._generic():
+            from . import generic_path
+            return generic_path.ref_forward(self, pos, d, noise)
         named = list(self.named_parameters())
         params = [p for _, p in named]
         if ab.needs_grad(pos, d, *params):
@@ -195,11 +205,13 @@ class RefNeRF(PackedWeightsMixin, NeRF):
             return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
         return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise, flags=self.kernel_flags)
 
-    def _ide_table(self, device):
+    def _ide_table(self, device, level: int = 4):
+        """the (2^(level-1) + 1, T) coefficient matrix of ref_func.py:60-74 on `device` (constant: float64 host loops, uploaded once)"""
         tables = self.__dict__.setdefault("_ide_table_on", {})
-        if device not in tables:
-            tables[device] = ide_table(4).to(device).contiguous()
-        return tables[device]
+        key = device if level == 4 else (device, level)
+        if key not in tables:
+            tables[key] = ide_table(level).to(device).contiguous()
+        return tables[key]
 
     def packed_backward(self, precision: int) -> torch.Tensor:
         ws, _ = self._pack_tensors()

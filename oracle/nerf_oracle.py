@@ -721,7 +721,8 @@ def ref_train_step(prop_sd, ref_sd, rays: Tensor, z_coarse: Tensor, u_inv: Tenso
 
 
 def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tensor, near: float, far: float, sample_num: int = 128,
-                    white_bkg: bool = False, cam_z: Optional[Tensor] = None, use_srgb: bool = False, contracted: bool = False):
+                    white_bkg: bool = False, cam_z: Optional[Tensor] = None, use_srgb: bool = False, contracted: bool = False,
+                    Lp: int = 10, deg: int = 4):
     """Tile body of render_image for a RefNeRF (procedures.py:64-85, is_ref_model branch): coarse+fine merge, sigma ->
     softplus(sigma + 0.5), composite with relu (a no-op after softplus)."""
     z_c = stratified_render(near, far, sample_num, u_strat)
@@ -734,7 +735,7 @@ def render_rays_ref(prop_sd, ref_sd, rays: Tensor, u_strat: Tensor, u_inv: Tenso
     samples, z_all = coarse_fine_merge(rays, z_c, z_f)
     if contracted:
         samples = torch.cat((contract(samples[..., :3]), samples[..., 3:]), dim=-1)
-    rgbo, normal = ref_forward(ref_sd, samples, use_srgb=use_srgb)
+    rgbo, normal = ref_forward(ref_sd, samples, Lp=Lp, deg=deg, use_srgb=use_srgb)
     rgbo = torch.cat((rgbo[..., :3], F.softplus(rgbo[..., 3:] + 0.5)), dim=-1)
     rgb, w, extras = composite(rgbo, z_all, rays[:, 3:], white_bkg=white_bkg, render_depth=(near, far),
                                normal_info=(normal, cam_z) if cam_z is not None else None)

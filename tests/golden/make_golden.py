@@ -107,12 +107,42 @@ def write_shallow_encodings():
     npz("g21_shallow_encodings", **out)
 
 
+def write_generic_refnerf():
+    """G22: the reference's RefNeRF in shapes the fused HIP kernel is not compiled for -- `--ide_level 5` (procedures.py:211: 36 spherical-harmonic
+    terms), hidden width 320 (`--nerf_net_width`, train.py:80), 11 position octaves with use_srgb -- forward values (rgbo, normal), the first 8 rows of
+    four parameter gradients of sum(rgbo * G4) + sum(normal * G3), and RefNeRF.get_grad of the density w.r.t. the positions (ref_model.py:119-125),
+    from the REAL modules.  States: oracle.init_linear_params on the oracle's shape table (deterministic), so the test can rebuild them."""
+    from nerf import ref_model
+    from oracle import nerf_oracle as O
+    g = torch.Generator().manual_seed(2222)
+    pos = torch.rand(5, 7, 3, generator=g) * 3 - 1.5
+    dirs = torch.randn(5, 7, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True) * (0.6 + 0.8 * torch.rand(5, 7, 1, generator=g))      # (ray directions are not unit vectors, utils.py:78-85)
+    G4, G3 = torch.randn(5, 7, 4, generator=g), torch.randn(5, 7, 3, generator=g)
+    out = {"pos": pos, "dirs": dirs, "G4": G4, "G3": G3}
+    for L, deg, width, srgb in ((10, 5, 256, False), (10, 4, 320, False), (11, 3, 288, True)):
+        tag = "L%d_d%d_w%d" % (L, deg, width)
+        ref = ref_model.RefNeRF(L, deg, hidden_unit=width, output_dim=width, use_srgb=srgb); ref.eval()
+        ref.load_state_dict(O.init_linear_params(O.ref_shapes(L, deg, width, 128, width, True), 3000 + 10 * L + deg + width, std=0.07, bias_std=0.05))
+        p = pos.clone().requires_grad_(True)
+        rgbo, nrm = ref.forward(p, dirs)
+        grad = ref_model.RefNeRF.get_grad(rgbo[..., -1], p)
+        ((rgbo * G4).sum() + (nrm * G3).sum()).backward()
+        out[tag + "_rgbo"], out[tag + "_normal"], out[tag + "_density_grad"] = rgbo, nrm, grad
+        out[tag + "_g_spa0"], out[tag + "_g_dir0"], out[tag + "_g_dirskip"], out[tag + "_g_heads"] = (
+            ref.spa_block1[0].weight.grad[:8], ref.dir_block1[0].weight.grad[:8], ref.dir_block2[0].weight.grad[:8], ref.norm_col_tint_head.weight.grad)
+        out[tag + "_g_rho_tau"], out[tag + "_g_bottle"] = ref.rho_tau_head.weight.grad, ref.bottle_neck.weight.grad[:8]
+    npz("g22_generic_refnerf", **out)
+
+
 def main():
     install_shims()
     if "--signatures-only" in sys.argv:
         return write_signatures()
     if "--shallow-only" in sys.argv:
         return write_shallow_encodings()
+    if "--generic-ref-only" in sys.argv:
+        return write_generic_refnerf()
     from nerf import nerf_helper, nerf_base, mip_methods, mip_model, addtional, utils, procedures
     import weights as W
 
@@ -445,6 +475,7 @@ def main():
     npz("g19_refnerf_srgb", **o19)
 
     write_shallow_encodings()
+    write_generic_refnerf()
     write_signatures()
 
 

@@ -2032,8 +2032,8 @@ def test_refnerf_other_ide_levels(A, level, width):
         diff, top = prm.grad.cpu().double() - wantg, max(wantg.abs().max().item(), 1e-12)
         assert diff.norm().item() <= 3e-2 * max(wantg.norm().item(), 1e-12) and diff.abs().max().item() <= 0.1 * top, \
             "%s: |err|_2 %.3e of %.3e, max %.3e of %.3e" % (name, diff.norm().item(), wantg.norm().item(), diff.abs().max().item(), top)
-    with pytest.raises(NotImplementedError):
-        RefNeRF(10, 5).cuda().eval().forward(pts.cuda())
+    with pytest.raises(ValueError):                                                    # ref_func.py:63 "Only deg_view of at most 5 is numerically stable", like the
+        RefNeRF(10, 6)                                                                 # reference; level 5 itself runs on the generic path (test_refnerf_outside_the_compiled_shapes)
 
 
 @pytest.mark.parametrize("width", [128, 64, 100])
@@ -2231,8 +2231,7 @@ def test_shallow_encodings_and_cat_origin(A, golden, L, cat, width):
         yb, db = mip.eval().forward(pts), prop.eval().forward(pts[..., :3].contiguous())
     A.pkg.set_precision("fp32")
     assert max_abs(yb[..., :3].cpu(), g[tag + "_mip"][..., :3]) <= 0.05 and max_abs(db.cpu(), g[tag + "_prop"]) <= 0.05 * scale(g[tag + "_prop"])
-    with pytest.raises(NotImplementedError):
-        RefNeRF(11, 4)._check_config()
+    assert RefNeRF(11, 4)._generic() and not RefNeRF(L, 4, hidden_unit=width, output_dim=width, cat_origin=cat)._generic()
 
 
 # ------------------------------------------------------------------------------------------------ shapes LARGER than the compiled ones
@@ -2326,6 +2325,118 @@ def test_networks_larger_than_the_compiled_shapes(A, L, cat, w_mip, w_prop):
         mip.train().forward(pts.cuda().requires_grad_(True))
     with pytest.raises(NotImplementedError):
         mip.forward(pts.cuda(), contract=True)
+
+
+@pytest.mark.parametrize("L,deg,width,srgb", [(10, 5, 256, False), (10, 4, 320, False), (11, 3, 288, True)])
+def test_refnerf_outside_the_compiled_shapes(A, golden, L, deg, width, srgb):
+    """`-t --ide_level 5` (procedures.py:211: 36 spherical-harmonic terms), `-t --nerf_net_width 320` (train.py:80), 11 position octaves with
+    use_srgb: a RefNeRF the fused kernel is not compiled for runs layer by layer on the generic MFMA GEMM with the element-wise stages of
+    generic_ref_kernels.hip between the products (nerf_amd/generic_path.py `ref_forward`).  Against the REAL reference (golden G22): forward
+    values, predicted normals, RefNeRF.get_grad of the density, the golden's gradient rows; every parameter gradient against fp64 autograd of the
+    oracle; the train-mode bottle-neck noise; bf16 close to fp32."""
+    from nerf_amd.ref_model import RefNeRF
+    from test_oracle_golden import generic_ref_state
+    g = golden("g22_generic_refnerf")
+    tag = "L%d_d%d_w%d" % (L, deg, width)
+    sd = generic_ref_state(L, deg, width)
+    net = RefNeRF(L, deg, hidden_unit=width, output_dim=width, use_srgb=srgb, perturb_bottle_neck_w=0.0)
+    net.load_state_dict(sd)
+    assert net._generic()
+    net = net.cuda()
+    A.pkg.set_precision("fp32")
+    pos, dirs = g["pos"].cuda(), g["dirs"].cuda()
+    sc = lambda t: max(1.0, t.abs().max().item())
+    tol = 2e-5 if L <= 10 else 5e-4          # (octave 10 multiplies the position by 1024 before sin / cos: fp32 argument rounding)
+    with torch.no_grad():
+        rgbo, nrm = net.eval().forward(pos, dirs)
+        rgbo6, nrm6 = net.forward(torch.cat((pos, dirs), dim=-1))                         # the (N,S,6) form of the call
+    assert rgbo.shape == (5, 7, 4) and nrm.shape == (5, 7, 3) and torch.equal(rgbo, rgbo6) and torch.equal(nrm, nrm6)
+    assert max_abs(rgbo.cpu(), g[tag + "_rgbo"]) <= tol * sc(g[tag + "_rgbo"]), max_abs(rgbo.cpu(), g[tag + "_rgbo"])
+    assert max_abs(nrm.cpu(), g[tag + "_normal"]) <= tol
+    # training: get_grad (d density / d position, first order, ref_model.py:119-125), then the loss backward over the same graph (train.py:179-186)
+    net.train()
+    p = pos.clone().requires_grad_(True)
+    r2, n2 = net.forward(p, dirs)
+    normals = RefNeRF.get_grad(r2[..., -1], p)
+    assert max_abs(normals.cpu(), g[tag + "_density_grad"]) <= 2e-3, max_abs(normals.cpu(), g[tag + "_density_grad"])
+    ((r2 * g["G4"].cuda()).sum() + (n2 * g["G3"].cuda()).sum()).backward()
+    assert p.grad is None                                                              # (positions get a gradient inside get_grad only, like on the fused path)
+    s64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    a64, b64 = O.ref_forward(s64, g["pos"].double(), g["dirs"].double(), Lp=L, deg=deg, use_srgb=srgb)
+    ((a64 * g["G4"].double()).sum() + (b64 * g["G3"].double()).sum()).backward()
+    for name, prm in net.named_parameters():
+        wg = s64[name].grad
+        assert prm.grad is not None and tuple(prm.grad.shape) == tuple(wg.shape), name
+        diff, top = prm.grad.cpu().double() - wg, max(wg.abs().max().item(), 1e-12)
+        assert diff.norm().item() <= 1e-2 * max(wg.norm().item(), 1e-12) and diff.abs().max().item() <= 5e-2 * top, \
+            "%s: |err|_2 %.3e of %.3e, max %.3e of %.3e" % (name, diff.norm().item(), wg.norm().item(), diff.abs().max().item(), top)
+    grads = dict(net.named_parameters())
+    for key, name in (("_g_spa0", "spa_block1.0.weight"), ("_g_dir0", "dir_block1.0.weight"), ("_g_dirskip", "dir_block2.0.weight"),
+                      ("_g_heads", "norm_col_tint_head.weight"), ("_g_rho_tau", "rho_tau_head.weight"), ("_g_bottle", "bottle_neck.weight")):
+        want = g[tag + key]                                                              # the real reference's own fp32 gradient rows
+        got = grads[name].grad[: want.shape[0]].cpu()
+        assert (got - want).norm().item() <= 1e-2 * max(want.norm().item(), 1e-12), (key, (got - want).norm().item(), want.norm().item())
+    # train-mode perturbation of the bottle-neck (ref_model.py:84-85): the torch.normal draw of the forward, reproduced for the oracle
+    noisy = RefNeRF(L, deg, hidden_unit=width, output_dim=width, use_srgb=srgb, perturb_bottle_neck_w=0.1)
+    noisy.load_state_dict(sd)
+    noisy = noisy.cuda().train()
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    with torch.no_grad():
+        rn, _ = noisy.forward(pos, dirs)
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    noise = torch.normal(0, 0.1, (5, 7, 128), device="cuda").cpu()
+    with torch.no_grad():
+        want_n, _ = O.ref_forward(sd, g["pos"], g["dirs"], Lp=L, deg=deg, use_srgb=srgb, noise=noise)
+    assert max_abs(rn.cpu(), want_n) <= 10 * tol * sc(want_n) and max_abs(rn.cpu(), g[tag + "_rgbo"]) > 1e-4
+    A.pkg.set_precision("bf16")
+    with torch.no_grad():
+        rb, nb = net.eval().forward(pos, dirs)
+    A.pkg.set_precision("fp32")
+    assert max_abs(rb[..., :3].cpu(), g[tag + "_rgbo"][..., :3]) <= 0.08 and max_abs(nb.cpu(), g[tag + "_normal"]) <= 0.08
+    # density-gradient normals of a generic-shape proposal network (`--prop_normal --prop_net_width 320`, train.py:165-168)
+    from nerf_amd.addtional import ProposalNetwork
+    psd = O.init_linear_params(O.proposal_shapes(L, 320, True), 71, std=0.06, bias_std=0.05)
+    prop = ProposalNetwork(L, 320)
+    prop.load_state_dict(psd)
+    prop = prop.cuda().train()
+    x = pos.clone().requires_grad_(True)
+    pn = RefNeRF.get_grad(prop.forward(x), x)
+    x64 = g["pos"].double().clone().requires_grad_(True)
+    g64, = torch.autograd.grad(O.proposal_forward({k: v.double() for k, v in psd.items()}, x64, L=L).sum(), x64)
+    want_pn = g64 / torch.maximum(torch.full_like(g64[..., :1], 1e-5), g64.norm(dim=-1, keepdim=True))
+    assert max_abs(pn.cpu(), want_pn) <= 2e-3
+
+
+def test_render_image_with_an_ide_level_5_refnerf(A):
+    """render_image (procedures.py:34-97) with `-t --ide_level 5`: the Ref-NeRF tile body (coarse / fine merge, forward, softplus(sigma + 0.5),
+    compositing with the normal image) call by call on the mirrored ops, the network on the generic path -- same seed, same images as the
+    oracle's restatement of the reference's loop, 1e-4 abs."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.ref_model import RefNeRF
+    rsd = O.init_linear_params(O.ref_shapes(10, 5, 256, 128, 256, True), 78, std=0.05, bias_std=0.02)
+    psd = W.proposal_state("small")
+    ref, prop = RefNeRF(10, 5), ProposalNetwork(10, 256)
+    ref.load_state_dict(rsd); prop.load_state_dict(psd)
+    ref, prop = ref.cuda().eval(), prop.cuda().eval()
+    A.pkg.set_precision("fp32")
+    pose = O.pose_spherical(37.0, -30.0, 4.0)[:3]
+    focal = O.fov2focal(0.6911112070083618, (50, 50))
+    torch.manual_seed(98)                                                                # a 50 x 50 image is ONE tile (procedures.py:20-32): the reference's two draws
+    u1, u2 = torch.rand((50, 50, 64)).view(-1, 64), torch.rand((2500, 33))
+    rays = torch.cat((pose[:, -1].expand(2500, -1), O.ray_dirs_image(pose, 50, 50, focal).reshape(-1, 3)), dim=-1)
+    with torch.no_grad():
+        want_rgb, _, ex = O.render_rays_ref(psd, rsd, rays, u1, u2, NEAR, FAR, 32, white_bkg=True, cam_z=pose[:, -2], deg=5)
+    torch.manual_seed(98)
+    with torch.no_grad():
+        res = A.procedures.render_image(ref, prop, pose.cuda(), 50, focal, NEAR, FAR, 32, white_bkg=True, render_depth=True, render_normal=True, rng="reference")
+    assert list(res.keys()) == ["rgb", "depth_img", "normal_img"] and res["rgb"].shape == (3, 50, 50)
+    img = lambda t, ch: t.view(50, 50, ch).permute(2, 0, 1)
+    assert max_abs(res["rgb"].cpu(), img(want_rgb, 3)) <= 1e-4
+    assert max_abs(res["depth_img"][0].cpu(), img(ex["depth_img"].reshape(-1, 1), 1)[0]) <= 1e-4
+    assert max_abs(res["normal_img"][0].cpu(), img(ex["normal_img"].reshape(-1, 1), 1)[0]) <= 1e-4
+    with torch.no_grad():                                                                # default rng on this route: device-generator uniforms per chunk
+        res2 = A.procedures.render_image(ref, prop, pose.cuda(), 50, focal, NEAR, FAR, 32, white_bkg=True)
+    assert torch.isfinite(res2["rgb"]).all() and abs(float(res2["rgb"].mean()) - float(want_rgb.mean())) <= 0.05
 
 
 def test_render_image_with_a_wide_network(A):

@@ -337,3 +337,35 @@ def test_g21_shallow_encodings_and_cat_origin(golden, L, cat, width):
     for key, name in (("_ref_g0", "spa_block1.0.weight"), ("_ref_gskip", "spa_block2.0.weight")):
         want = g[tag + key]
         assert max_abs(rsd[name].grad[:8], want) <= 1e-4 * max(1.0, want.abs().max().item()), key
+
+
+GENERIC_REF_CASES = ((10, 5, 256, False), (10, 4, 320, False), (11, 3, 288, True))
+
+
+def generic_ref_state(L, deg, width):
+    return O.init_linear_params(O.ref_shapes(L, deg, width, 128, width, True), 3000 + 10 * L + deg + width, std=0.07, bias_std=0.05)
+
+
+@pytest.mark.parametrize("L,deg,width,srgb", GENERIC_REF_CASES)
+def test_g22_refnerf_outside_the_compiled_shapes(golden, L, deg, width, srgb):
+    """`--ide_level 5`, hidden width 320, 11 octaves + use_srgb (the shapes the generic Ref-NeRF path of the product exists for): the oracle's
+    `deg` / width / `Lp` parameters against the REAL RefNeRF's forward values, RefNeRF.get_grad and parameter gradients (golden G22)."""
+    g = golden("g22_generic_refnerf")
+    tag = "L%d_d%d_w%d" % (L, deg, width)
+    sd = {k: v.clone().requires_grad_(True) for k, v in generic_ref_state(L, deg, width).items()}
+    pos = g["pos"].clone().requires_grad_(True)
+    rgbo, nrm = O.ref_forward(sd, pos, g["dirs"], Lp=L, deg=deg, use_srgb=srgb)
+    grad, = torch.autograd.grad(rgbo[..., -1], pos, torch.ones_like(rgbo[..., -1]), retain_graph=True)
+    gn = grad.norm(dim=-1, keepdim=True)
+    grad = grad / torch.maximum(torch.full_like(gn, 1e-5), gn)
+    ((rgbo * g["G4"]).sum() + (nrm * g["G3"]).sum()).backward()
+    sc = lambda t: max(1.0, t.abs().max().item())
+    tol = 2e-6 if L <= 10 else 2e-4          # (octave 10 multiplies the position by 1024 before sin / cos: fp32 argument rounding)
+    assert max_abs(rgbo, g[tag + "_rgbo"]) <= tol * sc(g[tag + "_rgbo"]) and max_abs(nrm, g[tag + "_normal"]) <= tol
+    assert max_abs(grad, g[tag + "_density_grad"]) <= 50 * tol
+    for key, name in (("_g_spa0", "spa_block1.0.weight"), ("_g_dir0", "dir_block1.0.weight"), ("_g_dirskip", "dir_block2.0.weight"),
+                      ("_g_heads", "norm_col_tint_head.weight"), ("_g_rho_tau", "rho_tau_head.weight"), ("_g_bottle", "bottle_neck.weight")):
+        want = g[tag + key]
+        got = sd[name].grad[: want.shape[0]]
+        assert tuple(got.shape) == tuple(want.shape), key
+        assert max_abs(got, want) <= 1e-4 * sc(want), (key, max_abs(got, want), sc(want))
