@@ -34,9 +34,37 @@ struct GemmArgs {
     float* C; int64_t ldc;
     const float* bias; int act;
     const float* mask; int64_t ldm;
-    int64_t p_chunk;                        // contraction elements per blockIdx.z slice (>= P: no split)
+    int64_t p_chunk;                        // contraction elements per slice (>= P: no split)
     int64_t part_stride;                    // split: slice z writes C + z * part_stride (dense ld = ldc), no bias / act / mask
+    int tiles_m, tiles_n, slices;           // the 1-D grid = tiles_m * tiles_n * slices workgroups (tile_of())
 };
+
+// Workgroup -> (output tile, contraction slice), XCD-aware.  The dispatcher places block b on XCD b % 8 and every XCD has its own L2, so
+// with the plain 3-D grid the workgroups that read the SAME operand tile -- the N tiles of one 128-row block of activations (forward /
+// input gradient: 256 KiB of fp32 rows each), all output tiles of one contraction slice (weight gradient) -- sat on different XCDs and each
+// fetched it from HBM again: the forward of a 512-wide layer moved 4x its activations.  Here every XCD gets a CONTIGUOUS range of logical
+// ids (bijective for any grid size: the first nwg % 8 XCDs take one more) and the logical order keeps the sharers adjacent: [slice][M tile]
+// [N tile] when the rows are the long dimension, [slice][N tile][M tile] otherwise.
+struct TileId { int64_t ti, tj, tz; };
+DEVINL TileId tile_of(const GemmArgs& g) {
+    const int64_t nwg = gridDim.x, b = blockIdx.x;
+    const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
+    const int64_t per_slice = (int64_t)g.tiles_m * g.tiles_n;
+    TileId t;
+#ifdef GK_PLAIN_GRID                        // A/B build: the order of the former 3-D grid (M tile fastest, no XCD remap)
+    t.tz = b / per_slice;
+    t.tj = (b - t.tz * per_slice) / g.tiles_m;
+    t.ti = b - t.tz * per_slice - t.tj * g.tiles_m;
+    (void)q; (void)r; (void)xcd;
+#else
+    const int64_t id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    t.tz = id / per_slice;
+    const int64_t rem = id - t.tz * per_slice;
+    if (g.tiles_m >= g.tiles_n) { t.ti = rem / g.tiles_n; t.tj = rem - t.ti * g.tiles_n; }
+    else { t.tj = rem / g.tiles_m; t.ti = rem - t.tj * g.tiles_m; }
+#endif
+    return t;
+}
 
 template <bool BF16> struct Stage;
 template <> struct Stage<true> {
@@ -126,8 +154,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) elem Bs[GBN * LD];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int wi = wave >> 1, wj = wave & 1;                  // this wave's 64 x 64 quadrant
-    const int64_t i0 = (int64_t)blockIdx.x * GBM, j0 = (int64_t)blockIdx.y * GBN;
-    const int64_t p_begin = (int64_t)blockIdx.z * g.p_chunk;
+    const TileId tid = tile_of(g);
+    const int64_t i0 = tid.ti * GBM, j0 = tid.tj * GBN;
+    const int64_t p_begin = tid.tz * g.p_chunk;
     const int64_t p_end = (p_begin + g.p_chunk < g.P) ? p_begin + g.p_chunk : g.P;
     f32x16 acc[2][2];
 #pragma unroll
@@ -186,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     // accumulator register r of lane l: output row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the 32 x 32 block
     const bool split = g.part_stride != 0;
-    float* C = g.C + (split ? (int64_t)blockIdx.z * g.part_stride : 0);
+    float* C = g.C + (split ? tid.tz * g.part_stride : 0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -257,9 +286,9 @@ size_t gk_gemm_workspace_bytes(int64_t M, int64_t N, int64_t P) {
 int gk_gemm(int bf16, int64_t M, int64_t N, int64_t P, const float* A, int64_t a_si, int64_t a_sp, const float* B, int64_t b_sp, int64_t b_sj, float* C,
             int64_t ldc, const float* bias, int act, const float* mask, int64_t ldm, void* workspace, hipStream_t st) {
     if (M == 0 || N == 0) return 0;
-    GemmArgs g{M, N, P, A, a_si, a_sp, B, b_sp, b_sj, C, ldc, bias, act, mask, ldm, P > 0 ? P : 1, 0};
     const int S = split_count(M, N, P);
-    const dim3 grid((unsigned)((M + GBM - 1) / GBM), (unsigned)((N + GBN - 1) / GBN), (unsigned)S);
+    GemmArgs g{M, N, P, A, a_si, a_sp, B, b_sp, b_sj, C, ldc, bias, act, mask, ldm, P > 0 ? P : 1, 0, (int)((M + GBM - 1) / GBM), (int)((N + GBN - 1) / GBN), S};
+    const dim3 grid((unsigned)((int64_t)g.tiles_m * g.tiles_n * S));
     if (S > 1) {
         g.p_chunk = ((P + S - 1) / S + GBK - 1) / GBK * GBK;
         g.C = reinterpret_cast<float*>(workspace);
