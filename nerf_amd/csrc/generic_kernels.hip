@@ -25,7 +25,11 @@
 
 namespace {
 
-constexpr int GBM = 128, GBN = 128, GBK = 32;
+#ifndef GK_GBK
+#define GK_GBK 64
+#endif
+constexpr int GBM = 128, GBN = 128, GBK = GK_GBK;        // contraction elements per LDS stage: 64 (two 32-wide sub-tiles; 32 = the first version, A/B)
+static_assert(GBK == 32 || GBK == 64, "GBK");
 
 struct GemmArgs {
     int64_t M, N, P;
@@ -100,30 +104,35 @@ DEVINL f32x4 load4(const float* __restrict__ p, bool vec_ok, int64_t n_valid) {
     return v;
 }
 
-// One operand tile -- rows = output index (0..127), columns = contraction index (0..31) -- in two steps so that the global loads of the NEXT
+// One operand tile -- rows = output index (0..127), columns = contraction index (0..GBK-1, as 32-wide sub-tiles) -- in two steps so that the global loads of the NEXT
 // tile are in flight while the matrix cores work on the current one: fetch() into 16 registers per thread, stage() into LDS.
 //   contraction index contiguous in memory (s_p == 1):  thread t -> rows (t >> 3) + 32 r, columns 4 (t & 7) .. +3        (r = 0..3)
 //   output index contiguous (s_out == 1):               thread t -> rows 8 (t & 15) .. +7, columns 2 (t >> 4), 2 (t >> 4) + 1
 struct OperandTile {
-    f32x4 v[4];
+    static constexpr int NH = GBK / 32;     // 32-wide sub-tiles of a stage
+    f32x4 v[NH][4];
     bool p_contig;
     DEVINL void fetch(const float* __restrict__ src, int64_t s_out, int64_t s_p, bool vec_ok, int64_t out0, int64_t n_out, int64_t p0, int64_t p_end) {
         const int t = threadIdx.x;
-        if (p_contig) {
-            const int64_t pp = p0 + 4 * (t & 7);
-            const int64_t np = p_end - pp;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t oo = out0 + (t >> 3) + 32 * r;
-                v[r] = load4(src + oo * s_out + pp, vec_ok, oo < n_out ? np : 0);
-            }
-        } else {
-            const int64_t oo = out0 + 8 * (t & 15);
+        for (int s = 0; s < NH; ++s) {
+            const int64_t ps = p0 + 32 * s;
+            if (p_contig) {
+                const int64_t pp = ps + 4 * (t & 7);
+                const int64_t np = p_end - pp;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int64_t pp = p0 + 2 * (t >> 4) + q;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t oo = out0 + (t >> 3) + 32 * r;
+                    v[s][r] = load4(src + oo * s_out + pp, vec_ok, oo < n_out ? np : 0);
+                }
+            } else {
+                const int64_t oo = out0 + 8 * (t & 15);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) v[2 * q + h] = load4(src + (oo + 4 * h) + pp * s_p, vec_ok, pp < p_end ? n_out - (oo + 4 * h) : 0);
+                for (int q = 0; q < 2; ++q) {
+                    const int64_t pp = ps + 2 * (t >> 4) + q;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) v[s][2 * q + h] = load4(src + (oo + 4 * h) + pp * s_p, vec_ok, pp < p_end ? n_out - (oo + 4 * h) : 0);
+                }
             }
         }
     }
@@ -131,15 +140,18 @@ struct OperandTile {
     DEVINL void stage(typename Stage<BF16>::elem* dst) const {
         constexpr int LD = Stage<BF16>::LD;
         const int t = threadIdx.x;
-        if (p_contig) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Stage<BF16>::store4(dst + ((t >> 3) + 32 * r) * LD + 4 * (t & 7), v[r]);
-        } else {
-            const int o = 8 * (t & 15), p = 2 * (t >> 4);
+        for (int s = 0; s < NH; ++s) {
+            if (p_contig) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 4; ++r) Stage<BF16>::store4(dst + ((t >> 3) + 32 * r) * LD + 32 * s + 4 * (t & 7), v[s][r]);
+            } else {
+                const int o = 8 * (t & 15), p = 32 * s + 2 * (t >> 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Stage<BF16>::store2(dst + (o + 4 * h + e) * LD + p, v[h][e], v[2 + h][e]);
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Stage<BF16>::store2(dst + (o + 4 * h + e) * LD + p, v[s][h][e], v[s][2 + h][e]);
+            }
         }
     }
 };

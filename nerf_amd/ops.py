@@ -981,6 +981,9 @@ def _view2d(t: torch.Tensor, name: str):
     return t, int(s0), int(s1)
 
 
+_GEMM_RELAYOUT_B = __import__("os").environ.get("NERF_AMD_GEMM_RELAYOUT_B", "1") != "0"        # (A/B switch of the re-layout below)
+
+
 def gemm(precision: int, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0,
          mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i, j] = act(sum_p a[i, p] b[p, j] + bias[j]) * [mask[i, j] > 0]  (nerf_amd_gemm: one hand-written MFMA GEMM with explicit strides;
@@ -992,6 +995,12 @@ def gemm(precision: int, a: torch.Tensor, b: torch.Tensor, out: Optional[torch.T
     if b.shape[0] != P:
         raise RuntimeError("nerf_amd.gemm: inner dimensions differ (%s x %s)" % (tuple(a.shape), tuple(b.shape)))
     N = b.shape[1]
+    # The kernel stages an operand fastest when its CONTRACTION index is the unit-stride one (16-byte loads, 8-byte LDS stores; the other
+    # order goes through 4-byte LDS stores).  The input-gradient form dx = dy W has b = W row-major, i.e. the slow order -- but W is small
+    # (a layer's weights) while M is the sample count: re-lay it out once per call (a copy of <= 16 MiB, no arithmetic).
+    if _GEMM_RELAYOUT_B and b_sj == 1 and b_sp != 1 and P > 1 and N > 1 and M >= 4096 and P * N <= (1 << 22):
+        b = b.t().contiguous().t()
+        b_sp, b_sj = 1, int(b.stride(1))
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if tuple(out.shape) != (M, N) or out.dtype != torch.float32 or not out.is_cuda or (N > 1 and out.stride(1) != 1):
