@@ -26,9 +26,12 @@
 namespace {
 
 #ifndef GK_GBK
-#define GK_GBK 64
+#define GK_GBK 32
 #endif
-constexpr int GBM = 128, GBN = 128, GBK = GK_GBK;        // contraction elements per LDS stage: 64 (two 32-wide sub-tiles; 32 = the first version, A/B)
+// contraction elements per LDS stage: 32.  -DGK_GBK=64 (two 32-wide sub-tiles per stage, twice the loads in flight) was measured on the box
+// (profiles/r04_generic_gemm_gbk64_relayout_ab.log): bf16 forward / input gradient unchanged (208 vs 210, 113 vs 113 TFLOP/s), weight gradient
+// +3 %, the fp32 parity mode 12-20 % SLOWER (one workgroup less per CU: 66 KiB of LDS) -> not the stage length that bounds this kernel.
+constexpr int GBM = 128, GBN = 128, GBK = GK_GBK;
 static_assert(GBK == 32 || GBK == 64, "GBK");
 
 struct GemmArgs {
@@ -46,7 +49,8 @@ struct GemmArgs {
 // Workgroup -> (output tile, contraction slice), XCD-aware.  The dispatcher places block b on XCD b % 8 and every XCD has its own L2, so
 // with the plain 3-D grid the workgroups that read the SAME operand tile -- the N tiles of one 128-row block of activations (forward /
 // input gradient: 256 KiB of fp32 rows each), all output tiles of one contraction slice (weight gradient) -- sat on different XCDs and each
-// fetched it from HBM again: the forward of a 512-wide layer moved 4x its activations.  Here every XCD gets a CONTIGUOUS range of logical
+// fetched it through its own L2 (same box, alternated, profiles/r04_generic_gemm_xcd_ab.log: forward 182 -> 210 TFLOP/s bf16 at 262 144 x 512
+// x 512, input gradient 100 -> 106, weight gradient 212 -> 220; render_image at width 512 +10 %).  Here every XCD gets a CONTIGUOUS range of logical
 // ids (bijective for any grid size: the first nwg % 8 XCDs take one more) and the logical order keeps the sharers adjacent: [slice][M tile]
 // [N tile] when the rows are the long dimension, [slice][N tile][M tile] otherwise.
 struct TileId { int64_t ti, tj, tz; };
