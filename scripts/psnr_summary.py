@@ -37,6 +37,11 @@ if "cpu" in st:
             continue
         for k, name in ((0, "held-out"), (1, "train")):
             d = st[mode][k][0] - st["cpu"][k][0]
+            if st["cpu"][k][3] < 2:          # ONE CPU run has no error bar of its own: place it inside the other path's run-to-run distribution
+                sd = st[mode][k][1]
+                print("gap %s - cpu, %s: %+.2f dB; the single CPU run sits %.1f sd (sd %.2f dB over %d runs) from the %s mean"
+                      % (mode, name, d, abs(d) / sd if sd else 0.0, sd, st[mode][k][3], mode))
+                continue
             se = math.sqrt(st[mode][k][2] ** 2 + st["cpu"][k][2] ** 2)
             print("gap %s - cpu, %s: %+.2f +- %.2f dB (%.1f sigma)" % (mode, name, d, se, abs(d) / se if se else 0.0))
 # paired comparison on the seeds two modes share (identical initial weights, batches and uniforms per seed): mean of the per-seed differences
