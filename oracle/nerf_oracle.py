@@ -691,19 +691,20 @@ def back_face_loss(weight: Tensor, normal: Tensor, ray_d: Tensor) -> Tensor:
     return torch.mean(weight * F.relu(torch.sum(normal * ray_d, dim=-1)))           # ref_model.py:137-143
 
 
-def ref_train_step(prop_sd, ref_sd, rays: Tensor, z_coarse: Tensor, u_inv: Tensor, noise: Tensor, rgb_tgt: Tensor, n_fine: int):
+def ref_train_step(prop_sd, ref_sd, rays: Tensor, z_coarse: Tensor, u_inv: Tensor, noise: Tensor, rgb_tgt: Tensor, n_fine: int,
+                   Lp: int = 10, deg: int = 4):
     """The Ref-NeRF branch of the training step with prop_normal on (train.py:164-199).  prop_sd / ref_sd hold leaf tensors
     (requires_grad) when parameter gradients are wanted.  Returns a dict of every intermediate the golden G17 pins."""
     C = z_coarse.shape[-1]
     pts = (rays[:, None, :3] + rays[:, None, 3:] * z_coarse[:, :, None]).detach().requires_grad_(True)
-    dens = proposal_forward(prop_sd, pts)
+    dens = proposal_forward(prop_sd, pts, L=Lp)
     coarse_grad = -get_grad(dens, pts)
     pw = max_blur(sigma_to_weights(F.softplus(dens), z_coarse, rays[:, 3:]), 0.01)
     z_fine, below = inverse_sample(pw, z_coarse, u_inv, sort=True)
     samples, z_all, below_all, sort_ids = coarse_fine_merge(rays, z_coarse, z_fine, below)
     pos = samples[..., :3].detach().requires_grad_(True)
     d = samples[..., 3:]
-    rgbo, normal = ref_forward(ref_sd, pos, d, noise=noise)
+    rgbo, normal = ref_forward(ref_sd, pos, d, Lp=Lp, deg=deg, noise=noise)
     density_grad = -get_grad(rgbo[..., -1], pos)
     rgbo_act = torch.cat((rgbo[..., :3], F.softplus(rgbo[..., 3:] + 0.5)), dim=-1)
     # train.py:182 passes mip_net.density_act positionally into `mul_norm`: a truthy object that is not `== True`, so the

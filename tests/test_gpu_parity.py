@@ -2407,6 +2407,78 @@ def test_refnerf_outside_the_compiled_shapes(A, golden, L, deg, width, srgb):
     assert max_abs(pn.cpu(), want_pn) <= 2e-3
 
 
+def test_refnerf_train_step_outside_the_compiled_shapes(A):
+    """The reference's whole Ref-NeRF training iteration (train.py:164-199 with `-t --ide_level 5 --prop_normal --prop_net_width 320`) on the
+    generic path: both networks layer by layer on nerf_amd_gemm, RefNeRF.get_grad twice (proposal density and fine density w.r.t. their
+    positions), the normal / back-face / coarse-normal losses, backward to every parameter -- against the oracle's restatement of the step
+    evaluated in fp64 (its pieces are pinned by G17 at ide_level 4 and by G22 at ide_level 5)."""
+    from nerf_amd.addtional import ProposalLoss, ProposalNetwork, getBounds
+    from nerf_amd.mip_methods import maxBlurFilter
+    from nerf_amd.nerf_base import NeRF
+    from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
+    from nerf_amd.utils import inverseSample
+    A.pkg.set_precision("fp32")
+    N, C, Fn = 24, 16, 32
+    gen = torch.Generator().manual_seed(55)
+    psd = O.init_linear_params(O.proposal_shapes(10, 320, True), 551, std=0.06, bias_std=0.05)
+    rsd = O.init_linear_params(O.ref_shapes(10, 5, 256, 128, 256, True), 552, std=0.06, bias_std=0.05)
+    prop, net = ProposalNetwork(10, 320), RefNeRF(10, 5)
+    prop.load_state_dict(psd); net.load_state_dict(rsd)
+    assert prop._generic() and net._generic()
+    prop, net = prop.cuda().train(), net.cuda().train()
+    dirs = F.normalize(torch.randn(N, 3, generator=gen) * 0.3 + torch.tensor([0.0, 0.0, -1.0]), dim=-1) * (0.8 + 0.4 * torch.rand(N, 1, generator=gen))
+    rays_c = torch.cat((torch.tensor([0.0, 0.0, 4.0]).expand(N, 3) + 0.1 * torch.randn(N, 3, generator=gen), dirs), dim=-1).contiguous()
+    zc_c = (torch.linspace(NEAR, FAR - (FAR - NEAR) / C, C) + torch.rand(N, C, generator=gen) * (FAR - NEAR) / C).contiguous()
+    u_c, tgt_c = torch.rand(N, Fn + 1, generator=gen), torch.rand(N, 3, generator=gen)
+    noise_c = 0.1 * torch.randn(N, C + Fn, 128, generator=gen)
+    rays, zc, tgt, noise = rays_c.cuda(), zc_c.cuda(), tgt_c.cuda(), noise_c.cuda()
+    real_normal = torch.normal
+    torch.normal = lambda *a, **k: noise
+    try:
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * zc[:, :, None]).contiguous().requires_grad_(True)
+        dens = prop.forward(pts)
+        coarse_grad = -RefNeRF.get_grad(dens, pts)
+        pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(dens), zc, rays[:, 3:]), 0.01)
+        fl, below = inverseSample(pw, zc, Fn + 1, sort=True, u=u_c)
+        samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, zc, fl, below)
+        pos, d = samples.split((3, 3), dim=-1)
+        pos = pos.contiguous().requires_grad_(True)
+        rgbo, nrm = net.forward(pos, d.contiguous())
+        dgrad = -RefNeRF.get_grad(rgbo[..., -1], pos)
+        rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
+        rend, wts, _ = NeRF.render(rgbo, fl, rays[:, 3:], net.density_act)        # the reference's positional quirk (train.py:182)
+        nl = WeightedNormalLoss()(wts, dgrad, nrm)
+        bf = BackFaceLoss()(wts, nrm, d)
+        cnl = WeightedNormalLoss()(pw, RefNeRF.coarse_grad_select(dgrad, sort_ids, C).detach(), coarse_grad)
+        img = torch.mean((rend - tgt) ** 2)
+        pl = ProposalLoss()(getBounds(pw, below), wts.detach())
+        loss = pl + img + 4e-4 * (nl + 0.1 * cnl) + 0.1 * bf
+        loss.backward()
+    finally:
+        torch.normal = real_normal
+    d64 = lambda sd: {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    p64, r64 = d64(psd), d64(rsd)
+    o = O.ref_train_step(p64, r64, rays_c.double(), zc_c.double(), u_c.double(), noise_c.double(), tgt_c.double(), Fn, Lp=10, deg=5)
+    o["loss"].backward()
+    assert torch.equal(sort_ids.cpu(), o["sort_ids"]) and torch.equal(below.cpu(), o["below_merged"])     # (the fp32 and fp64 sorts agree on this seed)
+    # get_grad NORMALISES the gradient (ref_model.py:124-125): where the raw density gradient is small the unit vector is ill-conditioned and
+    # fp32 against fp64 moves it by more than the rounding of a well-conditioned sample -- so: the typical sample to 1e-4, at most 2 % of them
+    # beyond 2e-3 (the weighted normal losses below, which is what the vectors are for, are gated to 5e-4 relative)
+    for got, want in ((dgrad, o["density_grad"]), (coarse_grad, o["coarse_grad"])):
+        err = (got.cpu().double() - want).abs().amax(dim=-1).flatten()
+        assert err.median().item() <= 1e-4 and (err > 2e-3).double().mean().item() <= 0.02, (err.median().item(), (err > 2e-3).double().mean().item(), err.max().item())
+    assert max_abs(wts.detach().cpu().double(), o["weights"]) <= 5e-5 and max_abs(rend.detach().cpu().double(), o["rendered"]) <= 5e-5
+    for name, val in (("normal_loss", nl), ("bf_loss", bf), ("coarse_normal_loss", cnl), ("img_loss", img), ("prop_loss", pl), ("loss", loss)):
+        assert abs(val.item() - float(o[name])) <= 5e-4 * max(1.0, abs(float(o[name]))), (name, val.item(), float(o[name]))
+    for mod, want in ((net, r64), (prop, p64)):
+        for name, prm in mod.named_parameters():
+            wg = want[name].grad
+            assert prm.grad is not None and tuple(prm.grad.shape) == tuple(wg.shape), name
+            diff, top = prm.grad.cpu().double() - wg, max(wg.abs().max().item(), 1e-14)
+            assert diff.norm().item() <= 3e-2 * max(wg.norm().item(), 1e-14) and diff.abs().max().item() <= 0.1 * top, \
+                "%s %s: |err|_2 %.3e of %.3e, max %.3e of %.3e" % (type(mod).__name__, name, diff.norm().item(), wg.norm().item(), diff.abs().max().item(), top)
+
+
 def test_render_image_with_an_ide_level_5_refnerf(A):
     """render_image (procedures.py:34-97) with `-t --ide_level 5`: the Ref-NeRF tile body (coarse / fine merge, forward, softplus(sigma + 0.5),
     compositing with the normal image) call by call on the mirrored ops, the network on the generic path -- same seed, same images as the
