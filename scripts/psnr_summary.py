@@ -37,10 +37,11 @@ if "cpu" in st:
             continue
         for k, name in ((0, "held-out"), (1, "train")):
             d = st[mode][k][0] - st["cpu"][k][0]
-            if st["cpu"][k][3] < 2:          # ONE CPU run has no error bar of its own: place it inside the other path's run-to-run distribution
-                sd = st[mode][k][1]
-                print("gap %s - cpu, %s: %+.2f dB; the single CPU run sits %.1f sd (sd %.2f dB over %d runs) from the %s mean"
-                      % (mode, name, d, abs(d) / sd if sd else 0.0, sd, st[mode][k][3], mode))
+            if st["cpu"][k][3] < 4:          # one to three CPU runs carry no usable error bar of their own: the run-to-run sd of the larger sample stands in
+                sd, nc, nm = st[mode][k][1], st["cpu"][k][3], st[mode][k][3]
+                se = sd * math.sqrt(1.0 / nc + 1.0 / nm)
+                print("gap %s - cpu, %s: %+.2f +- %.2f dB (%.1f sigma; %d CPU run%s, error from the %s runs' sd %.2f dB)"
+                      % (mode, name, d, se, abs(d) / se if se else 0.0, nc, "" if nc == 1 else "s", mode, sd))
                 continue
             se = math.sqrt(st[mode][k][2] ** 2 + st["cpu"][k][2] ** 2)
             print("gap %s - cpu, %s: %+.2f +- %.2f dB (%.1f sigma)" % (mode, name, d, se, abs(d) / se if se else 0.0))

@@ -136,11 +136,15 @@ def run_hip(views, seed, precision):
     from nerf_amd.nerf_base import NeRF
     from nerf_amd.utils import inverseSample
     nerf_amd.set_precision(precision)
-    torch.manual_seed(seed)
     prop, mip = ProposalNetwork(10, 256), MipNeRF(10, 4, 256)
     prop.load_state_dict(W.proposal_state("small"))
     mip.load_state_dict(W.mip_state("small"))
     prop, mip = prop.cuda().train(), mip.cuda().train()
+    # seed AFTER the modules exist: their constructors draw the reference's random initialisation from this same CPU generator (replaced by
+    # load_state_dict above), and run_oracle builds no modules -- seeded before the constructors (rounds 2-4 until the last day) the HIP runs
+    # saw ANOTHER stream of batches and uniforms than the oracle's run of the same seed (scripts/psnr_step0_diff.py found it: all 512 batch
+    # indices of iteration 0 differed).  Distributions over seeds were unaffected; per-seed pairing of CPU against HIP was not a pairing.
+    torch.manual_seed(seed)
     opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=LR)
     res = (FAR - NEAR) / C_N
     hist, held = [], []
