@@ -7,7 +7,11 @@
 #   gpurun --timeout T -- 'NSEED=16 BUDGET_MIN=55 bash scripts/gpu_cpu_psnr.sh'      -> gpurun_out/psnr_cpu/
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/psnr_cpu; mkdir -p $OUT; cd $R
-NSEED=${NSEED:-16}; NCPU=$(nproc); THREADS=${THREADS:-$(( NCPU / NSEED ))}; [ $THREADS -lt 1 ] && THREADS=1
+# MEASURED (round 4, profiles/r04_psnr/short6k/box_host_calibration.log): `nproc` says 256 but the box's container gets far fewer cores --
+# 16 processes x 16 threads made 40 iterations take 390 s (the build container's 2-thread process: 50 s) and starved the HIP runs sharing
+# the host.  bench.py's cpu_baseline finds its best rate at 32 threads: the defaults below stay inside that (8 seeds x 4 threads), and the
+# calibration still decides the iteration count.  Run a 2-minute calibration call (BUDGET_MIN=1 FORCE_ITERS=40) before committing an hour.
+NSEED=${NSEED:-8}; NCPU=${NCPU:-32}; THREADS=${THREADS:-$(( NCPU / NSEED ))}; [ $THREADS -lt 1 ] && THREADS=1
 BUDGET_MIN=${BUDGET_MIN:-55}
 RECIPE="--size 40 --views 25 --held 1 --rays 512 --coarse 32 --fine 64 --lr-mult 3 --hold 0.6"
 SEEDS=$(seq -s, 1 $NSEED)
