@@ -143,7 +143,8 @@ int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_sampl
 
 /* MipNeRF.forward + NeRF.render fused (mip_model.py:41-60 + nerf_base.py:91-113, mul_norm = True, relu density): the
  * (N,S,4) network output stays on chip; the last wavefront of each ray composites it.  `src` must be mode 1 (rays + z) with
- * S in {32, 64, 128}.  Outputs rgb (N,3), depth (N) or NULL, weights (N,S) or NULL. */
+ * S in {32, 64, 128}.  Outputs rgb (N,3), depth (N) or NULL, weights (N,S) or NULL.  256-wide blobs only: NERF_AMD_FINE_W128 in
+ * `precision` is refused (EUNSUPPORTED) -- a NERF_AMD_NET_MIP_128 blob takes nerf_amd_mip_forward + nerf_amd_composite. */
 int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf_amd_samples* src, int white_bkg,
                                    float near, float far, float* rgb, float* depth, float* weights, void* stream);
 
@@ -223,6 +224,14 @@ int nerf_amd_sample_training_rays_dev(const float* rgbs, const int64_t* coords, 
                                       float near, float far, int64_t N, int C, const uint64_t* seed_dev, float* pts, float* lengths,
                                       float* rgb, float* rays, void* stream);
 int nerf_amd_philox_uniforms(float* out, int64_t N, int K, uint64_t rng_seed, const uint64_t* seed_dev, void* stream);
+/* (ABI 121) Either Philox stream of the render kernels as a tensor, for rows that are GLOBAL rays ray_offset .. ray_offset + N - 1: the
+ * uniforms the reference draws per tile with torch.rand (procedures.py:65 stratified jitter -> NERF_AMD_PHILOX_STRAT, K <= 64;
+ * utils.py:115 inverse-CDF -> NERF_AMD_PHILOX_INV), bit-identical to what nerf_amd_render_rays draws in place for the same seed and ray
+ * index -- so a network outside the fused kernels' shapes (the layer-by-layer route) renders with the same random numbers. */
+#define NERF_AMD_PHILOX_INV 0
+#define NERF_AMD_PHILOX_STRAT 1
+int nerf_amd_philox_stream(float* out, int64_t N, int K, uint64_t rng_seed, const uint64_t* seed_dev, int64_t ray_offset, int stream_id,
+                           void* stream);
 int nerf_amd_advance_seed(uint64_t* seed_dev, void* stream);
 
 /* Stratified depths and points (utils.py:87-90, procedures.py:65-66): z = z_base[s] + u*z_jitter (N,S);

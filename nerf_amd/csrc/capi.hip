@@ -57,7 +57,7 @@ int sk_dirs_norm(const float*, int64_t, float*, hipStream_t);
 int sk_dirs_norm_scratch(const float*, int64_t, float*, void*, hipStream_t);
 int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, const float*, float, float, float, float, int64_t, int, uint64_t, const uint64_t*,
                      float*, float*, float*, float*, hipStream_t);
-int sk_philox_uniforms(float*, int64_t, int, uint64_t, const uint64_t*, hipStream_t);
+int sk_philox_uniforms(float*, int64_t, int, uint64_t, const uint64_t*, int64_t, int, hipStream_t);
 size_t gk_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int gk_gemm(int, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*, int64_t, int64_t, float*, int64_t, const float*, int, const float*, int64_t,
             void*, hipStream_t);
@@ -129,7 +129,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 120; }
+int nerf_amd_version(void) { return 121; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -200,7 +200,11 @@ int nerf_amd_mip_forward(const void* packed, int precision, const nerf_amd_sampl
 
 int nerf_amd_mip_forward_composite(const void* packed, int precision, const nerf_amd_samples* src, int white_bkg, float near,
                                    float far, float* rgb, float* depth, float* weights, void* stream) {
-    if (bad_prec(precision)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    const int lflags = precision & ~0xff;                   // layout flags ride in `precision` (nerf_amd.h): strip them before bad_prec
+    precision &= 0xff;
+    if (bad_prec(precision) || (lflags & ~NERF_AMD_FINE_W128)) return fail(NERF_AMD_EINVAL, "unknown precision");
+    if (lflags & NERF_AMD_FINE_W128)                        // (a NET_MIP_128 blob walked by the 256-wide kernel = wrong image + reads past the blob)
+        return fail(NERF_AMD_EUNSUPPORTED, "the 128-wide fine layout has no fused-compositing kernel: use nerf_amd_mip_forward + nerf_amd_composite");
     if (int c = check_samples(src, true)) return c;
     if (src->mode != 1 || !src->z) return fail(NERF_AMD_EUNSUPPORTED, "fused compositing needs mode 1 (rays + z)");
     if (src->ipe) return fail(NERF_AMD_EUNSUPPORTED, "integrated PE: use nerf_amd_mip_forward + nerf_amd_composite");
@@ -317,7 +321,14 @@ int nerf_amd_sample_training_rays_dev(const float* rgbs, const int64_t* coords, 
 int nerf_amd_philox_uniforms(float* out, int64_t N, int K, uint64_t rng_seed, const uint64_t* seed_dev, void* stream) {
     if (N < 0 || K < 0) return fail(NERF_AMD_EINVAL, "negative size");
     if (N * K && !out) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(sk_philox_uniforms(out, N, K, rng_seed, seed_dev, S(stream)), "nerf_amd_philox_uniforms");
+    return hip_status(sk_philox_uniforms(out, N, K, rng_seed, seed_dev, 0, 0, S(stream)), "nerf_amd_philox_uniforms");
+}
+int nerf_amd_philox_stream(float* out, int64_t N, int K, uint64_t rng_seed, const uint64_t* seed_dev, int64_t ray_offset, int stream_id, void* stream) {
+    if (N < 0 || K < 0 || ray_offset < 0) return fail(NERF_AMD_EINVAL, "negative size");
+    if (stream_id != NERF_AMD_PHILOX_INV && stream_id != NERF_AMD_PHILOX_STRAT) return fail(NERF_AMD_EINVAL, "unknown stream_id");
+    if (stream_id == NERF_AMD_PHILOX_STRAT && K > 64) return fail(NERF_AMD_EINVAL, "the stratified stream has 64 slots per ray");
+    if (N * K && !out) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_philox_uniforms(out, N, K, rng_seed, seed_dev, ray_offset, stream_id == NERF_AMD_PHILOX_STRAT, S(stream)), "nerf_amd_philox_stream");
 }
 int nerf_amd_advance_seed(uint64_t* seed_dev, void* stream) {
     if (!seed_dev) return fail(NERF_AMD_EINVAL, "NULL argument");

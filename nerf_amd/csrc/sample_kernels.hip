@@ -1358,12 +1358,16 @@ int sk_train_sampler(const float* rgbs, const int64_t* coords, int64_t P, const 
 // Philox uniforms as a tensor, u (N,K) = the inverse-CDF stream of device_common.h (philox_u_inv) -- for callers that keep the
 // reference's op-by-op structure (inverseSample(weights, depths, u)) but want the draw on the device and, with `seed_dev`, replayable
 // from a captured graph.  One thread per element.
-__global__ void philox_uniforms_kernel(float* __restrict__ out, int64_t N, int K, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+// (ABI 121) `ray_offset`: row n of the tensor is GLOBAL ray ray_offset + n (a chunk / shard of a larger ray list draws the bits the whole
+// list would); `strat`: the stratified-jitter stream u_strat(n, s) (word 0 of the ray's blocks) instead of the inverse-CDF stream
+__global__ void philox_uniforms_kernel(float* __restrict__ out, int64_t N, int K, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                       int64_t ray_offset, int strat) {
     if (seed_dev != nullptr) seed = seed_dev[0];
     const int64_t total = N * K;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / K;
-        out[i] = philox_u_inv(seed, n, (int)(i - n * K));
+        const int k = (int)(i - n * K);
+        out[i] = strat ? philox_u_strat(seed, ray_offset + n, k) : philox_u_inv(seed, ray_offset + n, k);
     }
 }
 // seed <- a new, unrelated key for the next step (golden-ratio increment + a xorshift-multiply mix); one thread
@@ -1373,9 +1377,9 @@ __global__ void advance_seed_kernel(uint64_t* __restrict__ seed_dev) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     seed_dev[0] = x ^ (x >> 31);
 }
-int sk_philox_uniforms(float* out, int64_t N, int K, uint64_t seed, const uint64_t* seed_dev, hipStream_t st) {
+int sk_philox_uniforms(float* out, int64_t N, int K, uint64_t seed, const uint64_t* seed_dev, int64_t ray_offset, int strat, hipStream_t st) {
     if (N * K == 0) return 0;
-    hipLaunchKernelGGL(philox_uniforms_kernel, dim3(blocks_for(N * K, 256)), dim3(256), 0, st, out, N, K, seed, seed_dev);
+    hipLaunchKernelGGL(philox_uniforms_kernel, dim3(blocks_for(N * K, 256)), dim3(256), 0, st, out, N, K, seed, seed_dev, ray_offset, strat);
     return (int)hipGetLastError();
 }
 int sk_advance_seed(uint64_t* seed_dev, hipStream_t st) {

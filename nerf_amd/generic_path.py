@@ -145,6 +145,8 @@ def mip_forward(net, pts: torch.Tensor) -> torch.Tensor:
     held = {}
 
     def bwd(gr, p, *wb):
+        if "a" not in held:
+            raise RuntimeError("nerf_amd: the activations of this forward were already consumed (backward twice over the same graph)")
         a, b, head, c, out, E = (held.pop(k) for k in ("a", "b", "head", "c", "out", "E"))
         gr = gr.reshape(-1, 4).float().contiguous()
         M = gr.shape[0]

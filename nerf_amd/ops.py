@@ -80,7 +80,8 @@ def _prop_prec(packed_prop: torch.Tensor, precision: int, packed_fine: Optional[
 # While a hipGraph is being captured both fall back to torch.empty: the graph's private pool then owns the memory it replays into.
 _PERSISTENT = __import__("os").environ.get("NERF_AMD_PERSISTENT_BUFFERS", "1") != "0"
 _ARENA = {}
-_ARENA_BUSY = set()
+_ARENA_BUSY = {}                # key -> id of the lease that owns the persistent buffer (identity, not just "somebody": a lease that outlives
+                                # release_buffers() must not free the key for a NEWER lease when it dies)
 ARENA_STATS = {"persistent": 0, "fresh": 0, "grown": 0}
 
 
@@ -93,7 +94,8 @@ def set_persistent_buffers(on: bool) -> None:
 
 
 def release_buffers() -> None:
-    """Give the persistent training buffers back to torch's allocator (they are re-created on demand)."""
+    """Give the persistent training buffers back to torch's allocator (they are re-created on demand).  A dump still leased to a pending
+    backward keeps its storage alive through its own view; its lease no longer owns any key afterwards (it cannot un-busy a newer lease)."""
     _ARENA.clear()
     _ARENA_BUSY.clear()
 
@@ -127,11 +129,12 @@ class _Lease:
 
     def __init__(self, key):
         self.key = key
-        _ARENA_BUSY.add(key)
+        _ARENA_BUSY[key] = id(self)
 
     def __del__(self):
         try:
-            _ARENA_BUSY.discard(self.key)
+            if _ARENA_BUSY.get(self.key) == id(self):          # only the owner frees the key
+                del _ARENA_BUSY[self.key]
         except Exception:                                      # (interpreter shutdown: the module's globals may be gone already)
             pass
 
@@ -242,14 +245,20 @@ def mip_forward_samples(packed, precision, s: Samples, shape, device) -> torch.T
 
 def mip_forward_composite(packed, precision, rays: torch.Tensor, z: torch.Tensor, n_samples: int, white_bkg: bool, near: float,
                           far: float, want_depth: bool = True, want_weights: bool = False):
-    """Fine MLP + alpha compositing in one launch (rows 8-10); z (N, >= n_samples) row stride = z.shape[-1]."""
+    """Fine MLP + alpha compositing in one launch (rows 8-10); z (N, >= n_samples) row stride = z.shape[-1].  A NET_MIP_128 blob (the
+    default `packed()` of a fine network of hidden width <= 128) has no fused-epilogue kernel: it takes the two launches of the render
+    path (mip128_kernel + composite_kernel), which the fused epilogue is bit-compatible with."""
     N = rays.shape[0]
     dev = rays.device
+    if int(getattr(packed, "_nerf_amd_layout", 0)) & FINE_W128:
+        rgbo = mip_forward_samples(packed, precision, samples_rays(rays, n_samples, z=z), (N, n_samples), dev)
+        rgb, w, depth, _ = composite(rgbo, z, rays, True, bool(white_bkg), ACT_RELU, (near, far), want_weights=want_weights)
+        return rgb, (depth if want_depth else None), (w if want_weights else None)
     rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((N,), dtype=torch.float32, device=dev) if want_depth else None
     w = torch.empty((N, n_samples), dtype=torch.float32, device=dev) if want_weights else None
     s = samples_rays(rays, n_samples, z=z)
-    check(lib.nerf_amd_mip_forward_composite(_ptr(packed), precision, C.byref(s), int(white_bkg), float(near), float(far), _ptr(rgb),
+    check(lib.nerf_amd_mip_forward_composite(_ptr(packed), _prop_prec(None, precision, packed), C.byref(s), int(white_bkg), float(near), float(far), _ptr(rgb),
                                              _ptr(depth), _ptr(w), _stream()), "nerf_amd_mip_forward_composite")
     return rgb, depth, w
 
@@ -442,6 +451,17 @@ def philox_uniforms(shape, seed: int = 0, seed_dev: Optional[torch.Tensor] = Non
     dev = seed_dev.device if seed_dev is not None else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     out = torch.empty((N, K), dtype=torch.float32, device=dev)
     check(lib.nerf_amd_philox_uniforms(_ptr(out), N, K, int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(seed_dev), _stream()), "nerf_amd_philox_uniforms")
+    return out
+
+
+def philox_stream(shape, seed: int, ray_offset: int = 0, strat: bool = False, device=None) -> torch.Tensor:
+    """u (N,K) of GLOBAL rays ray_offset .. ray_offset+N-1: the render kernels' stratified-jitter (strat, K <= 64) or inverse-CDF Philox
+    stream, bit-identical to their in-place draws for the same seed (nerf_amd_philox_stream)."""
+    N, K = int(shape[0]), int(shape[1])
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    check(lib.nerf_amd_philox_stream(_ptr(out), N, K, int(seed) & 0xFFFFFFFFFFFFFFFF, None, int(ray_offset), 1 if strat else 0, _stream()),
+          "nerf_amd_philox_stream")
     return out
 
 

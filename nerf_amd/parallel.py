@@ -137,12 +137,14 @@ class FlatGradients:
 
     def bind(self) -> None:
         """(re-)point every p.grad at its view -- e.g. after a zero_grad(set_to_none=True)"""
+        self._alive("bind")
         for p in self.params:
             if p.grad is not self.views[p]:
                 p.grad = self.views[p]
 
     def begin_step(self) -> None:
         """open a new accumulation window: views re-bound, autograd-path ranges zeroed, attached modules overwrite on their first backward"""
+        self._alive("begin_step")
         self.bind()
         for m in self._fresh:
             self._fresh[m] = True
@@ -151,6 +153,7 @@ class FlatGradients:
 
     def finalize_window(self) -> None:
         """make the flat buffer hold THIS window's gradients before anything reads it (collective, clip, optimizer): see the class docstring"""
+        self._alive("finalize_window")
         stale = [v for m, fresh in self._fresh.items() if fresh for v in self._direct_views[m]]      # attached, but no backward this window
         for p in self._autograd_params:
             v = self.views[p]
@@ -171,7 +174,7 @@ class FlatGradients:
     def sinks_for(self, module, layers):
         """(weight views, bias views, overwrite?) of an attached module -- called by its backward; None when a layer's parameter is not in
         the buffer (frozen): the module then takes the ordinary autograd path"""
-        if any(l.weight not in self.views or l.bias not in self.views for l in layers):
+        if getattr(self, "_dead", False) or any(l.weight not in self.views or l.bias not in self.views for l in layers):
             return None
         first = self._fresh.get(module, False)
         self._fresh[module] = False
@@ -193,6 +196,15 @@ class FlatGradients:
         for h in getattr(self, "_hooks", []):
             h.remove()
         self._hooks = []
+        # a detached owner is DEAD: a TrainStep that still holds it would otherwise zero the old views in finalize_window()
+        # and re-bind every p.grad to them AFTER the backward wrote into the newer owner's buffer -- all-zero gradients, silently
+        self._dead = True
+        self._fresh, self._direct_views, self._autograd_params, self._autograd_views = {}, {}, [], []
+
+    def _alive(self, what: str) -> None:
+        if getattr(self, "_dead", False):
+            raise RuntimeError("nerf_amd.parallel.FlatGradients.%s: this buffer was detached (a newer FlatGradients owns the modules' gradients); "
+                               "build the TrainStep / optimizer hooks on the live owner" % what)
 
     def all_reduce(self, average: bool = True) -> int:
         """One collective over every gradient; returns the element count.  No-op (after closing the window) outside a process group."""

@@ -3,6 +3,7 @@ signature, tile order, RNG protocol and return dict -- but the whole image goes 
 pipeline in four launches instead of a Python loop over 2500-ray tiles."""
 import argparse
 from collections.abc import Iterable
+from typing import Optional
 
 import torch
 
@@ -43,11 +44,12 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 
 def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096,
-                          is_ref_model: bool = False, cam_dir=None):
+                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None):
     """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
     maxBlurFilter, inverseSample, NeRF.length2pts, network.forward, NeRF.render -- on chunks of rays: the route of networks the fused
     render entry (nerf_amd_render_rays) has no packed layout for.  Every call is a HIP kernel of this package; uniforms that were not
-    given are drawn on the device generator per chunk."""
+    given are the render kernels' own Philox streams for `seed` and the chunk's global ray indices (ops.philox_stream): the image of a
+    seeded render does not depend on whether a network runs fused or layer by layer."""
     from .mip_methods import maxBlurFilter
     from .utils import inverseSample
     N = rays.shape[0]
@@ -58,8 +60,8 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
     for s in range(0, N, chunk):
         r = rays[s: s + chunk].contiguous()
         n = r.shape[0]
-        u1 = u_strat[s: s + n] if u_strat is not None else torch.rand((n, RENDER_COARSE_PNUM), device=rays.device)
-        u2 = u_inv[s: s + n] if u_inv is not None else torch.rand((n, sample_num + 1), device=rays.device)
+        u1 = u_strat[s: s + n] if u_strat is not None else ops.philox_stream((n, RENDER_COARSE_PNUM), seed, s, strat=True, device=rays.device)
+        u2 = u_inv[s: s + n] if u_inv is not None else ops.philox_stream((n, sample_num + 1), seed, s, device=rays.device)
         z, pts = ops.stratified_points(r, z_base, u1.contiguous(), resolution)      # :65-66
         density = prop_net.forward(pts)
         prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z, r[:, 3:]), 0.01)
@@ -142,7 +144,7 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
             raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
         rgb, depth, normal_px = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth),
                                                       is_ref_model=is_ref_model,
-                                                      cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None)
+                                                      cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed)
     elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,

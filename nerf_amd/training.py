@@ -86,6 +86,8 @@ class TrainStep:
             else:
                 flat_grads = FlatGradients([mip_net, prop_net], optimizer)
         self.flat_grads = flat_grads if flat_grads is not False else None
+        if self.flat_grads is not None and getattr(self.flat_grads, "_dead", False):
+            raise ValueError("nerf_amd.training.TrainStep: the FlatGradients passed in was detached by a newer owner of these modules")
         self.grad_clip = float(grad_clip)
         self.graph = None
 

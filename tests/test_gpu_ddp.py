@@ -283,3 +283,90 @@ def test_rccl_process_group_flat_allreduce_eager_and_captured(tmp_path):
     assert got["eager_vs_plain"] == 0.0 and got["l_eager"] == got["l_plain"]
     assert got["graph_vs_eager"] <= 1e-5
     assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(got["l_graph"], got["l_eager"][2:]))
+
+
+def test_detached_flat_gradients_owner_is_dead():
+    """a superseded FlatGradients must not keep working silently.  A newer owner detaches the old one; the old one then refuses
+    bind / begin_step / finalize_window / all_reduce, a TrainStep refuses to be built on it, and the modules' kernels write into the NEW
+    buffer (whose gradients equal ordinary autograd's)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import nerf_amd
+    from nerf_amd import parallel
+    from nerf_amd.optim import Adam
+    from nerf_amd.training import TrainStep
+    nerf_amd.set_precision("fp32")
+    prop, mip = _nets()
+    opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=1e-3, lr_on_device=True)
+    old = parallel.FlatGradients([mip, prop], opt)
+    new = parallel.FlatGradients([mip, prop], opt)                         # detaches `old`
+    assert getattr(old, "_dead", False) and not getattr(new, "_dead", False)
+    for fn in (old.bind, old.begin_step, old.finalize_window, old.all_reduce):
+        with pytest.raises(RuntimeError):
+            fn()
+    with pytest.raises(ValueError):
+        TrainStep(prop, mip, opt, (40, 40), 50.0, NEAR, FAR, ray_num=64, coarse_pnum=C_TRAIN, fine_pnum=F_TRAIN, flat_grads=old)
+    _loss(prop, mip, *_inputs(0)).backward()
+    assert all(p.grad is new.views[p] for p in new.params)
+    prop2, mip2 = _nets()
+    _loss(prop2, mip2, *_inputs(0)).backward()
+    assert torch.equal(new.flat, torch.cat([p.grad.reshape(-1) for p in list(mip2.parameters()) + list(prop2.parameters())]))
+    assert float(new.flat.abs().max()) > 0.0
+
+
+def test_persistent_buffer_arena_overlapping_forwards_and_growth():
+    """the persistent dump arena (ops.leased / ops.scratch) sits on the training-correctness path.  Two training forwards BEFORE
+    either backward -- same network twice, and two modules of the same network id -- must not share a dump: the second forward gets a
+    fresh allocation.  Gradients equal the NERF_AMD_PERSISTENT_BUFFERS=0 ones bit for bit; the arena grows between steps of different
+    sizes; release_buffers() between a forward and its backward neither corrupts that backward nor lets the old lease free a newer one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gc
+    import nerf_amd
+    from nerf_amd import ops
+    from nerf_amd.nerf_base import NeRF
+    nerf_amd.set_precision("bf16")
+
+    def grads_of(n_rays_a, n_rays_b, two_modules, release_between=False):
+        prop, mip = _nets()
+        mipb = _nets()[1] if two_modules else mip
+        g = torch.Generator().manual_seed(5)
+        outs = []
+        for net, n in ((mip, n_rays_a), (mipb, n_rays_b)):
+            pts = torch.cat((torch.rand(n, 16, 3, generator=g) * 2 - 1, torch.nn.functional.normalize(torch.randn(n, 16, 3, generator=g), dim=-1)), -1).cuda()
+            outs.append(net.forward(pts))                                  # training forward: leases the activation dump
+            if release_between:
+                ops.release_buffers()
+        tgt = [torch.rand(o.shape, generator=g).cuda() for o in outs]
+        # backward in forward order: the FIRST forward's dump must still be intact after the second forward ran
+        for o, t in zip(outs, tgt):
+            ((o - t) ** 2).sum().backward()
+        return [p.grad.clone() for p in mip.parameters()] + ([p.grad.clone() for p in mipb.parameters()] if two_modules else [])
+
+    try:
+        for two in (False, True):
+            ops.set_persistent_buffers(True)
+            ops.release_buffers()
+            stats0 = dict(ops.ARENA_STATS)
+            a = grads_of(40, 40, two)
+            assert ops.ARENA_STATS["persistent"] > stats0["persistent"] and ops.ARENA_STATS["fresh"] > stats0["fresh"], ops.ARENA_STATS
+            grown0 = ops.ARENA_STATS["grown"]
+            a_big = grads_of(90, 70, two)                                  # a larger step: the arena grows ...
+            assert ops.ARENA_STATS["grown"] > grown0
+            a_again = grads_of(40, 40, two)                                # ... and a smaller one afterwards reuses it
+            c = grads_of(40, 40, two, release_between=True)
+            gc.collect()
+            d = grads_of(40, 40, two)                                      # leases freed after release_buffers() must not un-busy newer ones
+            ops.set_persistent_buffers(False)
+            b, b_big = grads_of(40, 40, two), grads_of(90, 70, two)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+            for x, y in zip(a_big, b_big):
+                assert torch.equal(x, y)
+            for other in (a_again, c, d):
+                for x, y in zip(other, b):
+                    assert torch.equal(x, y)
+            assert any(float(x.abs().max()) > 0 for x in a)
+    finally:
+        ops.set_persistent_buffers(True)
+        nerf_amd.set_precision("fp32")

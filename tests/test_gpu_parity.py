@@ -2137,6 +2137,19 @@ def test_narrow_mip_tile_policy(A, width):
     with torch.no_grad():
         out = mip.forward_rays(dev(rays), z, 128, ipe_radius=1e-3)
     assert out.shape == (200, 128, 4) and bool(torch.isfinite(out).all())
+    # ... and no fused-compositing kernel (`mip_forward_composite(mip.packed(P), ...)` with a narrow net walked the 352-fragment
+    # blob with the 256-wide kernel): ops takes the two launches and equals the wide blob's fused launch, the C-ABI refuses the flag loudly
+    import ctypes as C
+    for P in (A.ops.F32, A.ops.BF16):
+        for wb in (False, True):
+            n3 = A.ops.mip_forward_composite(mip.packed(P), P, dev(rays), z, 128, wb, NEAR, FAR, want_depth=True, want_weights=True)
+            w3 = A.ops.mip_forward_composite(mip.packed(P, wide=True), P, dev(rays), z, 128, wb, NEAR, FAR, want_depth=True, want_weights=True)
+            assert max_abs(n3[0], w3[0]) <= 2e-6 and max_abs(n3[1], w3[1]) <= 2e-6 and max_abs(n3[2], w3[2]) <= 1e-6
+    s = A.ops.samples_rays(dev(rays), 128, z=z)
+    rgb = torch.empty(200, 3, device="cuda")
+    rc = A.ops.lib.nerf_amd_mip_forward_composite(C.c_void_p(mip.packed(A.ops.BF16).data_ptr()), A.ops.BF16 | A.ops.FINE_W128, C.byref(s), 1, NEAR, FAR,
+                                                  C.c_void_p(rgb.data_ptr()), None, None, None)
+    assert rc != 0
 
 
 def test_refnerf_render_with_scene_contraction(A):
