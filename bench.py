@@ -47,6 +47,10 @@ MAC_PROP, MAC_FINE = 212_992, 527_872                      # per sample (SURVEY.
 FLOP_PER_RAY = 2 * (C_COARSE * MAC_PROP + N_FINE * MAC_FINE)   # 162.4e6
 PEAK_BF16_DENSE = 2.5e15                                   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_F32_MFMA = 157.3e12
+# cpu_baseline.kind: the contract's two values are "reference" (oracle/_ref: the reference's own code built here) and "port" (the oracle).
+# The reference is pure Python and cannot travel to the GPU box, so what is timed is the ORACLE -- said in full beside the code word:
+KIND_DETAIL = ("oracle/nerf_oracle.py: this repo's torch-CPU fp32 restatement of the reference's render path (pinned bit-exact against goldens "
+               "generated from the real reference, tests/golden/make_golden.py); NOT the reference's own source")
 
 
 def parse():
@@ -98,6 +102,116 @@ def _free_port():
     return port
 
 
+class Watchdog:
+    """A stuck N > 1 run must fail LOUDLY inside the driver's slot instead of hanging until it is killed: when the
+    deadline passes, every rank writes one line saying where it was (`PHASE`), dumps every thread's Python stack to stderr, rank 0 prints a
+    partial JSON line (`value: null`, `error`, `phase`) so that the driver's log holds a parsable record, and the process exits non-zero.
+    Armed by default at 900 s when N > 1 (BENCH_DUMP_STACKS_AFTER overrides; 0 = off); the preflight arms its own short one."""
+    phase = "start"
+    rank = 0
+    world = 1
+
+    def __init__(self, seconds: float, what: str, code: int = 124):
+        import threading
+        self.what, self.code = what, code
+        self.timer = threading.Timer(seconds, self.fire, args=(seconds,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        self.timer.cancel()
+
+    def fire(self, seconds):
+        import faulthandler
+        msg = "bench.py: %s did not finish within %.0f s (rank %d of %d, phase: %s)" % (self.what, seconds, Watchdog.rank, Watchdog.world, Watchdog.phase)
+        sys.stderr.write(msg + "\n")
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        sys.stderr.flush()
+        if Watchdog.rank == 0:
+            print(json.dumps({"metric": "rays/sec (64+128 samples), Lego 800x800", "value": None, "unit": "rays/s", "n_gpus": Watchdog.world,
+                              "error": msg, "phase": Watchdog.phase}), flush=True)
+        os._exit(self.code)
+
+
+def set_phase(name: str) -> None:
+    Watchdog.phase = name
+
+
+def device_identity(dev):
+    """what this rank runs on: (index, name, PCI bus id or uuid) -- two ranks reporting the same identity share a GPU"""
+    if dev.type != "cuda":                                   # (--launch-check: the control flow on host tensors)
+        return {"index": None, "name": "cpu", "bus": None, "cus": 0, "gb": 0.0}
+    pr = torch.cuda.get_device_properties(dev)
+    bus = None
+    if hasattr(pr, "pci_bus_id"):
+        bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+    elif hasattr(pr, "uuid"):
+        bus = str(pr.uuid)
+    return {"index": dev.index, "name": pr.name, "bus": bus, "cus": pr.multi_processor_count, "gb": round(pr.total_memory / 2 ** 30, 1)}
+
+
+def preflight(dist, comm, world, rank, backend, dev, limit_s: float = 120.0):
+    """Before anything else of an N > 1 run: prove in seconds that the fabric works, or exit non-zero with ONE line
+    saying what does not.  (i) every rank's device identity, gathered over the host-side group: with RCCL two ranks on one device is an
+    error; (ii) one 3 MB all_reduce (the gradient buffer of --mode train-ddp: 744 069 fp32) and (iii) one 10 MB all_gather (rgb + depth of
+    an 800 x 800 image, the gather of --mode render-strong) over the DATA-PATH backend, results checked element-exact, each timed after
+    one untimed warm-up call; every rank prints its line to stderr.  The whole preflight runs under its own watchdog (`limit_s`)."""
+    set_phase("preflight")
+    wd = Watchdog(limit_s, "the preflight (process-group collectives across %d ranks)" % world, code=125)
+    ident = device_identity(dev)
+    idents = comm.gather(ident)
+    if backend == "nccl":
+        seen = {}
+        for r, d in enumerate(idents):
+            key = d["bus"] if d["bus"] is not None else d["index"]
+            if key in seen:
+                sys.exit("bench.py preflight: ranks %d and %d both run on device %s (%s) -- one process per GPU" % (seen[key], r, key, d["name"]))
+            seen[key] = r
+    on = dev if backend == "nccl" else torch.device("cpu")                  # (gloo: the one-GPU-box smoke path, host tensors)
+    if os.environ.get("BENCH_TEST_HANG") == "preflight" and rank == world - 1:
+        time.sleep(3600)                                                      # (tests: a rank that never reaches the collective)
+    if os.environ.get("BENCH_TEST_HANG") == "mismatch" and rank == world - 1:
+        rank_value_bug = 1.0                                                  # (tests: a fabric that returns wrong sums)
+    else:
+        rank_value_bug = 0.0
+    n_red = 744_069
+    x = torch.full((n_red,), float(rank + 1), dtype=torch.float32, device=on)
+    n_gat = (640_000 * 4 + world - 1) // world                                # floats per rank: 16 B/ray of the image, split over the ranks
+    y = torch.full((n_gat,), float(rank), dtype=torch.float32, device=on)
+    outs = [torch.empty_like(y) for _ in range(world)]
+
+    def timed(fn):
+        fn()                                                                  # warm-up: communicator / ring set-up
+        if on.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        if on.type == "cuda":
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e6
+
+    def red():
+        x.fill_(float(rank + 1) + rank_value_bug)
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    us_red = timed(red)
+    want = world * (world + 1) / 2.0
+    if not bool((x == want).all()):
+        sys.exit("bench.py preflight: rank %d: all_reduce(SUM) of %d floats over %s returned %r, expected %r" % (rank, n_red, backend, float(x[0]), want))
+    us_gat = timed(lambda: dist.all_gather(outs, y))
+    for r, o in enumerate(outs):
+        if not bool((o == float(r)).all()):
+            sys.exit("bench.py preflight: rank %d: all_gather over %s: the chunk of rank %d holds %r" % (rank, backend, r, float(o[0])))
+    sys.stderr.write("bench.py preflight: rank %d/%d on cuda:%s %s [%s] %d CUs %.0f GB | %s all_reduce %.2f MB %.0f us | all_gather %.2f MB %.0f us\n"
+                     % (rank, world, ident["index"], ident["name"], ident["bus"], ident["cus"], ident["gb"], backend, n_red * 4 / 1e6, us_red,
+                        n_gat * 4 * world / 1e6, us_gat))
+    sys.stderr.flush()
+    rows = comm.gather({"rank": rank, "device": ident, "allreduce_us": us_red, "allgather_us": us_gat})
+    wd.cancel()
+    set_phase("setup")
+    return {"backend": backend, "allreduce_bytes": n_red * 4, "allgather_bytes": n_gat * 4 * world, "ranks": rows}
+
+
 def launch_or_verify(a):
     """`--gpus N` is a promise about the number of ranks.  Under a launcher: WORLD_SIZE must equal N.  Stand-alone with N > 1:
     become the launcher (one process per GPU, rendezvous on 127.0.0.1) and exit with the job's status."""
@@ -126,17 +240,22 @@ def launch_check(a, world, rank):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
     assert dist.get_world_size() == a.gpus
     comm = Comm(dist, world, rank, "gloo", torch.device("cpu"))
+    pre = preflight(dist, comm, world, rank, "gloo", torch.device("cpu"), limit_s=float(os.environ.get("BENCH_PREFLIGHT_LIMIT", "120")))
+    set_phase("timed region")
+    if os.environ.get("BENCH_TEST_HANG") == "run" and rank == world - 1:
+        time.sleep(3600)                                     # (tests: a rank stuck in the run -- the default watchdog must end it loudly)
     comm.dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))                            # "the timed region": rank r takes (r + 1) x 10 ms
     local_dt = time.perf_counter() - t0
+    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, 1)
     streams = comm.gather({"rank": rank, "tflops": 1000.0 + rank})
     if rank == 0:
         time.sleep(0.2)                                      # rank 0's extras (cpu_baseline, train_step): the others wait in comm.finish()
         print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(world),
-                          "ms_per_step": dt * 1e3, "ms_per_step_ranks": spread, "per_rank": streams}), flush=True)
+                          "ms_per_step": dt * 1e3, "ms_per_step_ranks": spread, "per_rank": streams, "preflight": pre}), flush=True)
     comm.finish()
 
 
@@ -149,8 +268,11 @@ class Comm:
     def __init__(self, dist, world, rank, backend, dev):
         self.dist, self.world, self.rank, self.backend, self.dev = dist, world, rank, backend, dev
         self.ctl = None
+        self.preflight = None
         if dist is not None and backend != "gloo":
-            self.ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=60))
+            # the ONLY long wait of an N > 1 run: the ranks idle here while rank 0 measures cpu_baseline / train_step alone after the timed
+            # region (a few minutes); 25 minutes keeps even that inside the driver's 1 800 s slot
+            self.ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=25))
 
     def sync(self):
         """the contract's bracket of the timed region: barrier over the data-path backend + device synchronisation"""
@@ -223,7 +345,7 @@ def cpu_baseline_train(n_rays: int = 512, steps: int = 3):
     for _ in range(steps):
         one()
     dt = time.perf_counter() - t0
-    return {"value": steps * n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": steps * n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port", "kind_detail": KIND_DETAIL,
             "sample": "%d training steps of %d rays (64+128 samples; oracle forward, torch autograd backward, torch.optim.Adam), torch CPU fp32, %d threads on a %d-CPU host, %.1f s"
                       % (steps, n_rays, cores, os.cpu_count() or 1, dt)}
 
@@ -265,7 +387,7 @@ def cpu_baseline(n_rays: int):
     for t in range(n_tiles):
         one(t)
     dt = time.perf_counter() - t0
-    return {"value": n_tiles * tile / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": n_tiles * tile / dt, "unit": "rays/s", "cores": cores, "kind": "port", "kind_detail": KIND_DETAIL,
             "sample": "%d rays (%d tiles of 2500) of the same 800x800, 64+128 workload, torch CPU fp32, %d threads (best of 16/32/64/128 on a %d-CPU host), %.1f s"
                       % (n_tiles * tile, n_tiles, cores, ncpu, dt)}
 
@@ -573,6 +695,7 @@ def train_ddp(a, comm):
             step(i)
     comm.sync()
     local_dt = time.perf_counter() - t0
+    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, a.steps)
     ar_ms = [s_.elapsed_time(e_) for s_, e_ in ev] if graph is None else None
@@ -606,7 +729,10 @@ def train_ddp(a, comm):
     if rank == 0:
         if not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_train()
+        if comm.preflight is not None:
+            rec["preflight"] = comm.preflight
         print(json.dumps(rec), flush=True)
+    set_phase("finish (host-side barrier)")
     comm.finish()
 
 
@@ -642,14 +768,17 @@ def render_strong(a, comm):
         out = torch.cat((rgb, depth[:, None]), -1)
         return parallel.gather_shards(out, n, 256) if dist is not None else out
 
+    set_phase("warm-up")
     for i in range(a.warmup):
         step(i)
+    set_phase("timed region")
     comm.sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         img = step(a.warmup + i)
     comm.sync()
     local_dt = time.perf_counter() - t0
+    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, a.steps)
     assert img.shape == (n, 4) and bool(torch.isfinite(img).all())
@@ -676,7 +805,10 @@ def render_strong(a, comm):
     if rank == 0:
         if not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
+        if comm.preflight is not None:
+            rec["preflight"] = comm.preflight
         print(json.dumps(rec), flush=True)
+    set_phase("finish (host-side barrier)")
     comm.finish()
 
 
@@ -685,14 +817,17 @@ def main():
     # read when the HIP runtime initialises, i.e. at the first device call below -- and inherited by the ranks this process may launch
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     a = parse()
-    if os.environ.get("BENCH_DUMP_STACKS_AFTER"):            # debugging aid: every thread's Python stack to stderr after N seconds (and exit)
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["BENCH_DUMP_STACKS_AFTER"]), exit=True)
     launch_or_verify(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus
+    Watchdog.rank, Watchdog.world = rank, world
+    # every thread's Python stack + a partial JSON line + non-zero exit after N seconds: armed by DEFAULT at 900 s when N > 1 (a stuck
+    # collective must show up inside the driver's 1 800 s slot as a message, not as a killed job); BENCH_DUMP_STACKS_AFTER=N overrides, 0 = off
+    limit = int(os.environ.get("BENCH_DUMP_STACKS_AFTER", "900" if world > 1 else "0"))
+    if limit > 0:
+        Watchdog(limit, "the run")
     if a.launch_check:
         return launch_check(a, world, rank)
     dist = None
@@ -703,16 +838,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local % n_dev)
-        long_wait = datetime.timedelta(minutes=60)              # (rank 0 measures the CPU baseline / training rates while the others wait)
+        # DATA-PATH collectives (barriers of the timed region, max-over-ranks, the gradient all_reduce, the image all_gather): 5 minutes.
+        # Nothing on the data path waits for another rank's solo measurement -- that wait is Comm.ctl's (gloo, host side).
+        data_wait = datetime.timedelta(minutes=5)
+        set_phase("init_process_group(%s)" % backend)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % n_dev), timeout=long_wait)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % n_dev), timeout=data_wait)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=long_wait)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=data_wait)
         assert dist.get_world_size() == a.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     comm = Comm(dist, world, rank, backend, dev)
+    comm.preflight = preflight(dist, comm, world, rank, backend, dev) if world > 1 else None
+    set_phase("mode %s" % a.mode)
     if a.mode == "train-ddp":
         return train_ddp(a, comm)
     if a.mode == "render-strong":
@@ -798,14 +938,17 @@ def main():
             ev[timed_idx][1].record()
         return rgb, depth, w
 
+    set_phase("warm-up")
     for i in range(a.warmup):
         step(i)
+    set_phase("timed region")
     comm.sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         out = step(a.warmup + i, i)
     comm.sync()
     local_dt = time.perf_counter() - t0
+    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, a.steps)
     assert os.environ.get("NERF_AMD_LIB") or bool(torch.isfinite(out[0]).all())     # (ablation builds compute garbage)
@@ -873,7 +1016,10 @@ def main():
             rec["train_step"] = train_rate(a.precision)
         if not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_rays)
+        if comm.preflight is not None:
+            rec["preflight"] = comm.preflight
         print(json.dumps(rec), flush=True)
+    set_phase("finish (host-side barrier)")
     comm.finish()
 
 

@@ -235,29 +235,29 @@ def broadcast_parameters(modules: Sequence[torch.nn.Module], src: int = 0, group
 
 
 def render_image_sharded(network, prop_net, render_pose, image_size, focal, near, far, sample_num=128, white_bkg=False,
-                         render_depth=False, gather: bool = True, seed: int = 0, group=None) -> dict:
-    """Ray-sharded whole-image render: rank r renders rays [start_r, end_r) of the raster-order ray list.  Uniforms
-    are drawn on the device from a per-rank seeded generator (the reference's CPU RNG stream is inherently serial)."""
-    from . import ops
-    from .procedures import RENDER_COARSE_PNUM
+                         render_depth=False, gather: bool = True, seed: int = 0, group=None, render_normal=False, contract: bool = False,
+                         ipe=False) -> dict:
+    """Ray-sharded whole-image render: rank r renders a contiguous 256-aligned slice of the image's (tile-ordered) ray list through
+    ``procedures.render_image``'s own body -- MipNeRF, Ref-NeRF and layer-by-layer networks alike.  Every uniform is drawn in the kernels
+    with Philox keyed by (``seed``, GLOBAL ray index), so the gathered image does not depend on the world size: it is bit-identical to
+    ``render_image(..., seed=seed)`` in one process (round 4 drew per-rank ``torch.rand`` tensors: 494 MB / N materialised and an image
+    that changed with N).  No collective on the data path; one all_gather of rgb (+ depth, + normal) at the end, or none (gather=False:
+    ``{"rgb_rays", "depth_rays", "normal_rays", "range"}`` of this rank's slice)."""
+    from .procedures import get_patch_size, render_image
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     H, W = (image_size, image_size) if not isinstance(image_size, (tuple, list)) else image_size
-    fx, fy = (float(focal[1]), float(focal[0])) if isinstance(focal, (tuple, list)) else (float(focal), float(focal))
-    dev = render_pose.device
-    n = H * W
+    sz, patch_num = get_patch_size((H, W))
+    n = H * W if sz is None else patch_num[0] * patch_num[1] * sz * sz               # (rows beyond the last whole tile are not rendered, like the reference)
     start, end = shard_range(n, rank, world, align=256)
-    cnt = end - start
-    prec = ops.current_precision()
-    rays = ops.generate_rays(render_pose[:3], H, W, fx, fy, dev, start, cnt)
-    g = torch.Generator(device=dev).manual_seed(seed * 1000003 + rank)
-    u1 = torch.rand((cnt, RENDER_COARSE_PNUM), device=dev, generator=g)
-    u2 = torch.rand((cnt, sample_num + 1), device=dev, generator=g)
-    z_base = torch.linspace(near, far, RENDER_COARSE_PNUM).to(dev)
-    rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u1, u2, sample_num, near, far,
-                                       white_bkg, want_depth=bool(render_depth))
+    part = render_image(network, prop_net, render_pose, image_size, focal, near, far, sample_num, white_bkg, render_depth, render_normal,
+                        rng="philox", contract=contract, ipe=ipe, seed=int(seed), _shard=(start, end))
     if not gather:
-        return {"rgb_rays": rgb, "depth_rays": depth, "range": (start, end)}
-    out = {"rgb": gather_shards(rgb, n, 256, group).view(H, W, 3).permute(2, 0, 1).contiguous()}
+        part.pop("to_image")
+        return part
+    to_image = part["to_image"]
+    out = {"rgb": to_image(gather_shards(part["rgb_rays"], n, 256, group), 3)}
     if render_depth:
-        out["depth_img"] = gather_shards(depth.unsqueeze(-1), n, 256, group).view(1, H, W).expand(3, -1, -1).contiguous()
+        out["depth_img"] = to_image(gather_shards(part["depth_rays"].unsqueeze(-1), n, 256, group), 1).expand(3, -1, -1).contiguous()
+    if part["normal_rays"] is not None:
+        out["normal_img"] = to_image(gather_shards(part["normal_rays"].unsqueeze(-1), n, 256, group), 1).expand(3, -1, -1).contiguous()
     return out

@@ -44,7 +44,7 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 
 def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096,
-                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None):
+                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None, ray_offset: int = 0):
     """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
     maxBlurFilter, inverseSample, NeRF.length2pts, network.forward, NeRF.render -- on chunks of rays: the route of networks the fused
     render entry (nerf_amd_render_rays) has no packed layout for.  Every call is a HIP kernel of this package; uniforms that were not
@@ -60,8 +60,8 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
     for s in range(0, N, chunk):
         r = rays[s: s + chunk].contiguous()
         n = r.shape[0]
-        u1 = u_strat[s: s + n] if u_strat is not None else ops.philox_stream((n, RENDER_COARSE_PNUM), seed, s, strat=True, device=rays.device)
-        u2 = u_inv[s: s + n] if u_inv is not None else ops.philox_stream((n, sample_num + 1), seed, s, device=rays.device)
+        u1 = u_strat[s: s + n] if u_strat is not None else ops.philox_stream((n, RENDER_COARSE_PNUM), seed, ray_offset + s, strat=True, device=rays.device)
+        u2 = u_inv[s: s + n] if u_inv is not None else ops.philox_stream((n, sample_num + 1), seed, ray_offset + s, device=rays.device)
         z, pts = ops.stratified_points(r, z_base, u1.contiguous(), resolution)      # :65-66
         density = prop_net.forward(pts)
         prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z, r[:, 3:]), 0.01)
@@ -87,7 +87,8 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
 
 def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Tensor, image_size, focal,
                  near: float, far: float, sample_num: int = 128, white_bkg: bool = False, render_depth=False,
-                 render_normal=False, rng: str = "philox", contract: bool = False, ipe=False) -> dict:
+                 render_normal=False, rng: str = "philox", contract: bool = False, ipe=False, seed: Optional[int] = None,
+                 _shard=None) -> dict:
     """Whole-image inference (procedures.py:34-97) -> {"rgb" (3,H,W) [, "depth_img" (3,H,W)]} on
     ``render_pose.device``.  The caller provides ``no_grad``/``eval()`` like for the reference.
     ``rng``, ``contract`` and ``ipe`` are additions.  ``rng``: where the stratified / inverse-CDF uniforms come from --
@@ -97,6 +98,10 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
                  (procedures.py:65, utils.py:115) copied to the device: a seeded run reproduces the reference's image bit for bit in
                  its uniforms (0.5 GB over PCIe per 800x800 image: ~1.4 M rays/s);
       "device":  two torch.rand draws on the device generator.
+    ``seed`` (philox mode): the Philox key itself instead of a draw from the CPU generator.  ``_shard = (start, end)`` (internal:
+    nerf_amd.parallel.render_image_sharded) renders only those rays of the image's TILE-ORDERED ray list -- every uniform is a pure
+    function of (key, global index in that list), so shards reproduce the single-process image bit for bit -- and returns the per-ray
+    outputs ``{"rgb_rays", "depth_rays", "normal_rays", "range", "to_image"}`` instead of images.
     ``contract=True`` applies the Mip-NeRF 360 scene contraction to every sample
     position before the networks encode it (unbounded scenes, BASELINE config 5; not available for Ref-NeRF).  ``ipe`` (BASELINE
     config 3): the fine network reads the integrated positional encoding of the conical frustum between consecutive fine depths
@@ -123,12 +128,19 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     if sz is not None:                                                             # reorder rays tile by tile
         pr, pc = patch_num
         rays = rays.view(H, W, 6)[: pr * sz].reshape(pr, sz, pc, sz, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
-    seed = None
     if rng == "philox":
         u_strat = u_inv = None
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())                         # one draw from the CPU generator: torch.manual_seed governs it
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                     # one draw from the CPU generator: torch.manual_seed governs it
     else:
+        if _shard is not None:
+            raise ValueError("nerf_amd.render_image: a ray shard needs rng='philox' (uniforms keyed by the global ray index)")
+        seed = None
         u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
+    off = 0
+    if _shard is not None:
+        off = int(_shard[0])
+        rays = rays[off: int(_shard[1])].contiguous()
     z_base = torch.linspace(near, far, RENDER_COARSE_PNUM, device="cpu").to(dev)   # procedures.py:52 (CPU linspace bits)
     normal_px = None
     ipe_radius = None
@@ -144,12 +156,13 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
             raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
         rgb, depth, normal_px = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth),
                                                       is_ref_model=is_ref_model,
-                                                      cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed)
+                                                      cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed,
+                                                      ray_offset=off)
     elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,
                                            sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,
-                                           ipe_radius=ipe_radius, seed=seed)
+                                           ipe_radius=ipe_radius, seed=seed, rng_ray_offset=off)
     else:
         # Ref-NeRF branch (procedures.py:71-74): coarse and fine depths are merged and sorted, the last one dropped,
         # sigma -> softplus(sigma + 0.5) before compositing (nerf_amd_render_rays_ref: six launches; the sort is a merge of two
@@ -157,7 +170,7 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         rgb, depth, normal_px, _ = ops.render_rays_ref(prop_net.packed(prec), network.packed(prec), prec, rays, z_base, u_strat, u_inv,
                                                        sample_num, near, far, white_bkg, want_depth=bool(render_depth),
                                                        cam_dir=render_pose[:, -2].contiguous() if render_normal else None, flags=network.kernel_flags,
-                                                       seed=seed, contract=contract)
+                                                       seed=seed, contract=contract, rng_ray_offset=off)
 
     def to_image(t, ch):
         if sz is None:
@@ -167,6 +180,8 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         img[:, : pr * sz] = t.view(pr, pc, sz, sz, ch).permute(4, 0, 2, 1, 3).reshape(ch, pr * sz, pc * sz)
         return img
 
+    if _shard is not None:
+        return {"rgb_rays": rgb, "depth_rays": depth, "normal_rays": normal_px, "range": (off, off + rays.shape[0]), "to_image": to_image}
     result = dict()
     result["rgb"] = to_image(rgb, 3)
     if render_depth:

@@ -2,7 +2,7 @@
 import inspect
 
 MODULES = ("nerf_base", "nerf_helper", "mip_methods", "mip_model", "procedures", "utils", "addtional", "ref_model", "ref_func", "dataset",
-           "param_com", "local_shuffler", "timer")
+           "param_com", "local_shuffler")        # (`nerf.timer` is control plane -- SURVEY section 2 row 18: the entry scripts keep their own)
 
 
 def _default(v):

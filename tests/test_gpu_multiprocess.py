@@ -1,6 +1,7 @@
 """SURVEY.md section 8e on real hardware: two processes (one torch.distributed rank each, gloo rendezvous, both on the box's single
 GPU) render the two halves of an image through the HIP path and gather it; the result must equal the same shards rendered in one
-process.  Also the flat-buffer gradient all-reduce on device tensors."""
+process -- since round 5 the single-process `render_image(seed=...)` itself, bit for bit (in-kernel Philox keyed by the global ray index).
+Also the flat-buffer gradient all-reduce on device tensors."""
 import os
 import sys
 
@@ -9,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-H, SAMPLES, NEAR, FAR = 64, 128, 2.0, 6.0
+H, SAMPLES, NEAR, FAR = 100, 128, 2.0, 6.0          # 100 = 2 x 2 tiles of 50: the tile-ordered ray list is exercised
 
 
 def _nets():
@@ -46,8 +47,16 @@ def _worker(rank, world, port, out_path):
         p.grad = torch.full_like(p, float(rank + 1) * (k + 1))
     n = parallel.allreduce_gradients([mip, prop])
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (k + 1))) for k, p in enumerate(list(mip.parameters()) + list(prop.parameters())))
+    # a 3-way split of the same image inside this rank (sub-groups of one: gather=False slices stitched by hand) is the same image
+    parts = []
+    with torch.no_grad():
+        from nerf_amd.procedures import render_image
+        for r in range(3):
+            s0, e0 = parallel.shard_range(H * H, r, 3, align=256)
+            parts.append(render_image(mip, prop, pose, H, focal, NEAR, FAR, SAMPLES, white_bkg=True, render_depth=True, seed=5, _shard=(s0, e0)))
+    rgb3 = parts[0]["to_image"](torch.cat([q["rgb_rays"] for q in parts]), 3)
     if rank == 0:
-        torch.save({"rgb": img["rgb"].cpu(), "depth": img["depth_img"].cpu(), "n_reduced": n, "grads_ok": ok}, out_path)
+        torch.save({"rgb": img["rgb"].cpu(), "depth": img["depth_img"].cpu(), "n_reduced": n, "grads_ok": ok, "world3_equal": bool(torch.equal(rgb3, img["rgb"]))}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,30 +69,20 @@ def test_two_rank_sharded_render_and_gradient_allreduce(tmp_path):
     mp.spawn(_worker, args=(2, 29533, out_path), nprocs=2, join=True)
     got = torch.load(out_path)
     assert got["grads_ok"] and got["n_reduced"] == 530052 + 214017                     # fine + proposal parameters
-    # the same two shards in this process
+    # ... and the image: the SAME as the single-process render_image with that Philox key, bit for bit (N-independent by construction:
+    # uniforms keyed by the global ray index; round 4's per-rank torch.rand draws made the image depend on the world size)
     sys.path.insert(0, ROOT)
     import nerf_amd
-    from nerf_amd import ops, parallel
-    from nerf_amd.procedures import RENDER_COARSE_PNUM
+    from nerf_amd.procedures import render_image
     nerf_amd.set_precision("fp32")
     prop, mip = _nets()
     pose, focal = _pose_focal()
-    parts_rgb, parts_depth = [], []
     with torch.no_grad():
-        for r in range(2):
-            start, end = parallel.shard_range(H * H, r, 2, align=256)
-            fx, fy = (float(focal[1]), float(focal[0])) if isinstance(focal, (tuple, list)) else (float(focal), float(focal))
-            rays = ops.generate_rays(pose, H, H, fx, fy, pose.device, start, end - start)
-            g = torch.Generator(device=pose.device).manual_seed(5 * 1000003 + r)
-            u1 = torch.rand((end - start, RENDER_COARSE_PNUM), device=pose.device, generator=g)
-            u2 = torch.rand((end - start, SAMPLES + 1), device=pose.device, generator=g)
-            rgb, depth, _, _ = ops.render_rays(prop.packed(ops.F32), mip.packed(ops.F32), ops.F32, rays, torch.linspace(NEAR, FAR, RENDER_COARSE_PNUM).cuda(),
-                                               u1, u2, SAMPLES, NEAR, FAR, True, want_depth=True)
-            parts_rgb.append(rgb)
-            parts_depth.append(depth)
-    want = torch.cat(parts_rgb).view(H, H, 3).permute(2, 0, 1).cpu()
-    assert torch.equal(got["rgb"], want)
-    assert torch.equal(got["depth"][0], torch.cat(parts_depth).view(H, H).cpu())
+        one = render_image(mip, prop, pose, H, focal, NEAR, FAR, SAMPLES, white_bkg=True, render_depth=True, seed=5)
+        other = render_image(mip, prop, pose, H, focal, NEAR, FAR, SAMPLES, white_bkg=True, render_depth=True, seed=6)
+    assert torch.equal(got["rgb"], one["rgb"].cpu()) and torch.equal(got["depth"], one["depth_img"].cpu())
+    assert not torch.equal(one["rgb"], other["rgb"])
+    assert got["world3_equal"]
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel training step

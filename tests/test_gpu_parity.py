@@ -1845,6 +1845,41 @@ def test_philox_uniform_tensor_and_device_seed(A):
     sd2 = torch.tensor([seed], dtype=torch.int64).cuda()
     A.ops.advance_seed(sd2)
     assert int(sd2.item()) == s1
+    # (ABI 121) nerf_amd_philox_stream: both streams for rows that are GLOBAL rays off .. off + N - 1
+    for off in (0, 4096, (1 << 33) + 5):
+        ws, wi = O.philox_uniforms(seed, 29, off, 64, 193)
+        assert torch.equal(A.ops.philox_stream((29, 64), seed, off, strat=True).cpu(), ws)
+        assert torch.equal(A.ops.philox_stream((29, 193), seed, off).cpu(), wi)
+
+
+def test_generic_route_draws_the_fused_kernels_philox_streams(A):
+    """on the layer-by-layer route `rng="philox"` used to become torch.rand on the device generator (the seed drawn from the CPU
+    generator unused).  It now draws the render kernels' own streams per chunk (global ray index), so (i) a seeded generic render is
+    reproducible under torch.manual_seed alone and (ii) it is the image the SAME pipeline produces from the explicit Philox tensors."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.procedures import render_image, _render_rays_by_calls
+    torch.manual_seed(3)
+    mip, prop = MipNeRF(10, 4, 320).cuda().eval(), ProposalNetwork(10, 256).cuda().eval()           # width 320: generic route
+    assert mip._generic()
+    pose = O.pose_spherical(20.0, -30.0, 4.0).cuda()
+    focal = O.fov2focal(0.6911112070083618, (100, 100))
+    with torch.no_grad():
+        torch.manual_seed(11); a = render_image(mip, prop, pose, 100, focal, NEAR, FAR, 64, white_bkg=True)["rgb"]
+        torch.cuda.manual_seed(999)                                                                   # the device generator must not matter
+        torch.manual_seed(11); b = render_image(mip, prop, pose, 100, focal, NEAR, FAR, 64, white_bkg=True)["rgb"]
+        torch.manual_seed(12); c = render_image(mip, prop, pose, 100, focal, NEAR, FAR, 64, white_bkg=True)["rgb"]
+        assert torch.equal(a, b) and not torch.equal(a, c)
+        torch.manual_seed(11)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        rays = A.ops.generate_rays(pose[:3], 100, 100, focal, focal, pose.device)
+        rays = rays.view(100, 100, 6).reshape(2, 50, 2, 50, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
+        z_base = torch.linspace(NEAR, FAR, 64).cuda()
+        u1, u2 = A.ops.philox_stream((10000, 64), seed, 0, strat=True), A.ops.philox_stream((10000, 65), seed, 0)
+        rgb, _, _ = _render_rays_by_calls(mip, prop, rays, z_base, u1, u2, 64, NEAR, FAR, True, False)
+        img = torch.zeros(3, 100, 100, device="cuda")
+        img[:] = rgb.view(2, 2, 50, 50, 3).permute(4, 0, 2, 1, 3).reshape(3, 100, 100)
+        assert torch.equal(a, img)
 
 
 def test_philox_uniforms_are_uniform():

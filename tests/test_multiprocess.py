@@ -114,6 +114,36 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert [r["rank"] for r in rec["per_rank"]] == [0, 1]
 
 
+@pytest.mark.timeout(600)
+def test_bench_preflight_and_loud_failure_of_a_stuck_run():
+    """the first N > 1 run must fail LOUDLY instead of hanging.  On two gloo ranks (the control flow `bench.py --gpus N`
+    runs before any GPU work): (a) the preflight's record -- every rank's device line, a 3 MB all_reduce and a 10 MB all_gather checked
+    element-exact and timed -- is in the JSON line; (b) a fabric returning a wrong sum ends the run with a non-zero status and ONE line
+    naming the collective; (c) a rank that never reaches the preflight's collective trips the preflight's own short watchdog: stacks on
+    stderr, a partial JSON line (`value: null`, `error`, `phase: preflight`) on stdout, non-zero exit; (d) a rank stuck later in the run
+    trips the run's watchdog (armed by default when N > 1; shortened here) the same way."""
+    import json
+    r = _bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    pre = rec["preflight"]
+    assert pre["allreduce_bytes"] == 744069 * 4 and pre["allgather_bytes"] >= 10_000_000 and [q["rank"] for q in pre["ranks"]] == [0, 1]
+    assert all(q["allreduce_us"] > 0 and q["allgather_us"] > 0 for q in pre["ranks"])
+    assert r.stderr.count("bench.py preflight: rank") == 2
+    r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "mismatch"})
+    assert r.returncode != 0 and "bench.py preflight: rank" in r.stderr and "all_reduce(SUM)" in r.stderr and "expected 3.0" in r.stderr
+    r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "preflight", "BENCH_PREFLIGHT_LIMIT": "8"})
+    assert r.returncode != 0
+    assert "the preflight (process-group collectives across 2 ranks) did not finish within 8 s" in r.stderr and "phase: preflight" in r.stderr
+    assert "Thread" in r.stderr or "Stack" in r.stderr or "File" in r.stderr                       # faulthandler's dump
+    part = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert part and part[-1]["value"] is None and part[-1]["phase"] == "preflight" and part[-1]["n_gpus"] == 2
+    r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "run", "BENCH_DUMP_STACKS_AFTER": "12"})
+    assert r.returncode != 0 and "the run did not finish within 12 s" in r.stderr
+    part = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert part and part[-1]["value"] is None and "timed region" in part[-1]["phase"]
+
+
 def test_bench_refuses_fewer_ranks_than_asked():
     """--gpus N must never silently run fewer ranks: a launcher that started a different world size, or (nccl) a box with fewer
     devices than N, is an error."""
