@@ -32,11 +32,7 @@
 
 namespace {
 
-#ifdef MLP_BF16_NARROW
-using PB16 = PBF16;
-#else
 using PB16 = PBF16W;
-#endif
 
 struct Dump {               // a fragment-ordered dump: slot l, subtile s, K group kg -> base + l*layer_stride + (s*16 + kg) * BREG_LDS
     char* base;
@@ -102,7 +98,10 @@ DEVINL f32x8 relu_mask_bits(const f32x8& d, uint32_t w, int kg) {
     return r;
 }
 
-constexpr uint32_t BWD_LDS_ZERO = MLP_RING_BYTES;                    // 1 KiB of zeros: the "bias" of every chain layer
+constexpr uint32_t BWD_LDS_ZERO = MLP_RING_BYTES;                    // 1 KiB of zeros: the "bias" of every chain layer (BWD_ZERO_BIAS = 0: read from here)
+#ifndef BWD_ZERO_BIAS
+#define BWD_ZERO_BIAS 1        /* the chains' accumulators start from the literal 0 (mlp_core.h dense<..., ZB>); 0 = the round-4 form, A/B */
+#endif
 constexpr uint32_t BWD_LDS_MASK = MLP_RING_BYTES + 1024;
 template <class P> constexpr uint32_t bwd_pair_bytes() { return 4 * P::NT * P::BREG_LDS; }          // (2 blocks x 2 halves x NT tiles) mask groups
 template <class P> constexpr uint32_t bwd_lds_total() { return BWD_LDS_MASK + P::NW * 2 * bwd_pair_bytes<P>(); }
@@ -165,7 +164,7 @@ DEVINL void f8_flush_layer(const Dump& dlt, uint32_t scale_lds, int layer, int64
 }
 
 template <class P>
-DEVINL void bwd_prologue(WeightStream<P, MLP_NSLOT, false>& ws, const void* packed, int n_frags) {
+DEVINL void bwd_prologue(WeightStream<P, MLP_NSLOT>& ws, const void* packed, int n_frags) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<float*>(smem + BWD_LDS_ZERO)[i] = 0.0f;
     __syncthreads();
     ws.init(packed, n_frags / P::FPC);
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
                                                               Dump act, Dump dlt) {
     using L = PropBwdLayout;
     using BReg = typename P::BReg;
-    WeightStream<P, MLP_NSLOT, false> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     bwd_prologue<P>(ws, packed, L::CHAIN_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -206,18 +205,18 @@ __global__ __launch_bounds__(P::NW * 64) void prop_bwd_kernel(const void* __rest
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         const MaskedOut<P, 2, 16, F8> O3{a, act, dlt, 3, sub0, lane, mask_lds, scale_lds};
-        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, O3, NoPrev{});
+        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, O3, NoPrev{});
         // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (same chunk parity)
         static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk parity");
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
             const MaskedOut<P, 16, 2, F8> OB{b, act, dlt, 2 - 2 * r, sub0, lane, mask_lds, scale_lds};        // (follows the 2-step head layer in round 0)
             const MaskedOut<P, 16, 16, F8> OA_pend{a, act, dlt, 3 - 2 * r, sub0, lane, mask_lds, scale_lds};
-            d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[1], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 3 - 2 * r, sub0, lane);      // (its last pair was converted during this layer)
             if (r == 0) {
                 const MaskedOut<P, 16, 16, F8> OA{a, act, dlt, 1, sub0, lane, mask_lds, scale_lds};
-                d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+                d = dense<P, 16, 8, L::START[2], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
                 if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 2, sub0, lane);
             }
         }
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
     using L = MipBwdLayout;
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
-    WeightStream<P, MLP_NSLOT, false> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     bwd_prologue<P>(ws, packed, L::N_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -272,11 +271,11 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         // dc = W_rgb2^T dpre, masked by c (activation slot 7) -> b[.][0..7]
         const MaskedOut<P, 2, 16, F8> OC{b, act, dlt, 7, sub0, lane, mask_lds, scale_lds};
-        const Deferred<P, 2, 2> dcp = dense<P, 2, 4, L::START[0]>(ws, BWD_LDS_ZERO,
+        const Deferred<P, 2, 2> dcp = dense<P, 2, 4, L::START[0], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO,
             [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OC, NoPrev{});
         // d6 = [W_fold^T | W_sigma^T] [dc | head], masked by g6 (slot 6) -> a
         const MaskedOut<P, 9, 2, F8> O6{a, act, dlt, 6, sub0, lane, mask_lds, scale_lds};
-        Deferred<P, 6, 2> d = dense<P, 9, 8, L::START[1]>(ws, BWD_LDS_ZERO,
+        Deferred<P, 6, 2> d = dense<P, 9, 8, L::START[1], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO,
             [&](int kg, int t) -> BReg { if (kg < 8) return b[t][kg < 8 ? kg : 0]; return head[t]; }, O6, prev_of(dcp, OC));
         if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 7, sub0, lane);                  // (slot 7's last pair was converted during the d6 layer)
         // d5 .. d0: six 256 x 256 layers ping-ponging between the register buffers (a -> b -> a ...), two code instances
@@ -286,9 +285,9 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
         for (int r = 0; r < 3; ++r) {
             const MaskedOut<P, 16, 9, F8> OB{b, act, dlt, 5 - 2 * r, sub0, lane, mask_lds, scale_lds};       // (follows the 9-step layer in round 0)
             const MaskedOut<P, 16, 16, F8> OA_pend{a, act, dlt, 6 - 2 * r, sub0, lane, mask_lds, scale_lds}, OA{a, act, dlt, 4 - 2 * r, sub0, lane, mask_lds, scale_lds};
-            d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[2], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 6 - 2 * r, sub0, lane);
-            d = dense<P, 16, 8, L::START[3]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            d = dense<P, 16, 8, L::START[3], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             if constexpr (F8) f8_flush_layer<P>(dlt, scale_lds, 5 - 2 * r, sub0, lane);
         }
         const MaskedOut<P, 16, 16, F8> O0{a, act, dlt, 0, sub0, lane, mask_lds, scale_lds};
@@ -300,50 +299,12 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
 }
 
 // ================================================================================================
-// One dgrad layer as its own launch (Ref-NeRF's backward and the density-gradient chains):
-//   out = W^T . x over all samples, x read from a fragment dump (or the constant "ones" head), W^T streamed through the LDS ring;
-//   MASK:  out *= [y > 0] with y from the training forward's dump, written as the next fragment dump (hidden layers);
-//   !MASK: out written (or accumulated) as row-major fp32 -- the gradient w.r.t. a layer INPUT that is not a hidden activation
-//          (the encoded position, Ref-NeRF's directional input vector), in the reference's column order.
-// The fused chains above keep delta in registers across layers; Ref-NeRF's backward has per-sample math between its stages (the
-// integrated directional encoding, normals, the heads), small batches, and two skip layers feeding side outputs, so it is built
-// from these single-layer launches: 1.5 KiB of HBM traffic per sample and layer instead of 1 KiB.
+// Ref-NeRF's backward and the density-gradient chains.  (Rounds 1-2 ran them as single-layer launches --
+// dgrad_layer_kernel, 1.5 KiB of HBM traffic per sample and layer; the fused chains below replaced them in round 3 and the A/B
+// fallback left the sources in round 5: profiles/r03_refnerf_chains_ab.log.)
 // ================================================================================================
-struct LayerIO {
-    const char* x0; int kgx0; const char* x1;               // input K groups [0, kgx0) at x0 + kg*BREG, the rest at x1 + (kg - kgx0)*BREG
-    unsigned long long x_sub_stride;                         // bytes between subtiles of x0 / x1 (16 K groups)
-    int ones_head;                                           // != 0: the input is ONE K group whose slot feature 0 is `1` for every sample
-    const char* mask; char* out;                             // MASK: forward activations / delta out, K group kg at + kg*BREG, subtile stride below
-    unsigned long long io_sub_stride;
-    float* rows; int ld; int accumulate;                     // !MASK: rows[m * ld + feature] (= or +=), ld >= 32 NFB and a multiple of 4
-};
-
-template <class P, int NKG>
-struct StreamMaskedOut {                                     // MaskedOut without the register buffer (nothing follows in this launch)
-    const char* mask; char* out; unsigned long long sub_stride;
-    int64_t sub0; int lane; uint32_t mask_lds;
-    DEVINL void begin_group(int G) const {
-        if (G == 0) vm_wait<0>(); else vm_wait<mask_wait_count<P>(NKG)>();
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int t = 0; t < P::NT; ++t) {
-                    const int kg = 2 * (2 * G + blk) + half;
-                    const char* src = mask + (size_t)(sub0 + t) * sub_stride + (size_t)kg * P::BREG_LDS + lane * 16;
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(mask_lds + (G & 1) * bwd_pair_bytes<P>() + ((blk * 2 + half) * P::NT + t) * P::BREG_LDS);
-#pragma unroll
-                    for (int p = 0; p < P::BREG_LDS / 1024; ++p) glds_piece(src + p * 1024, dst + p * 1024);
-                }
-    }
-    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
-        const typename P::BReg d = to_breg_half<P, false>(acc, half);
-        const uint32_t at = mask_lds + ((fb >> 1) & 1) * bwd_pair_bytes<P>() + (((fb & 1) * 2 + half) * P::NT + t) * P::BREG_LDS + lane * 16;
-        const typename P::BReg v = relu_mask(d, P::unstash(at));
-        P::store_global(out + (size_t)(sub0 + t) * sub_stride + (size_t)(2 * fb + half) * P::BREG_LDS, lane, v);
-    }
-};
+// row-major fp32 side output of a chain layer: the gradient w.r.t. a layer INPUT that is not a hidden activation (the encoded
+// position, Ref-NeRF's directional input vector), in the reference's column order; accumulate = += instead of =
 struct RowsOut {                                             // accumulators 8 half .. 8 half + 7 of block fb = features 32 fb + 8 (2 half + q) + 4 h + 0..3
     float* rows; int ld; int accumulate; int64_t m0; int j, h; int64_t M;
     DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
@@ -359,94 +320,6 @@ struct RowsOut {                                             // accumulators 8 h
     }
 };
 
-template <class P, int NKG, int NFB, bool MASK>
-__global__ __launch_bounds__(P::NW * 64) void dgrad_layer_kernel(const void* __restrict__ packed_layer, int n_frags, LayerIO io, int64_t M) {
-    using BReg = typename P::BReg;
-    WeightStream<P, MLP_NSLOT, false> ws;
-    bwd_prologue<P>(ws, packed_layer, n_frags);
-    const int lane = lane_id(), h = lane >> 5, j = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
-    constexpr int NT = P::NT;
-    constexpr int TS = P::NW * NT * 32;
-    const int64_t n_tiles = (M + TS - 1) / TS;
-    const uint32_t mask_lds = __builtin_amdgcn_readfirstlane(BWD_LDS_MASK + wave * 2 * bwd_pair_bytes<P>());
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t sub0 = tile * (TS / 32) + wave * NT;
-        BReg x[NT][NKG];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int k = 0; k < NKG; ++k) {
-                if (io.ones_head) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) P::set(x[t][k], e, (k == 0 && e == 0 && h == 0) ? 1.0f : 0.0f);
-                } else {
-                    const char* src = (k < io.kgx0 ? io.x0 + (size_t)k * P::BREG_LDS : io.x1 + (size_t)(k - io.kgx0) * P::BREG_LDS) +
-                                      (size_t)(sub0 + t) * io.x_sub_stride;
-                    x[t][k] = P::load_global(src, lane);
-                }
-            }
-        auto IN = [&](int kg, int t) -> BReg { return x[t][kg]; };
-        if constexpr (MASK) {
-            const StreamMaskedOut<P, NKG> O{io.mask, io.out, io.io_sub_stride, sub0, lane, mask_lds};
-            auto d = dense<P, NKG, NFB, 0>(ws, BWD_LDS_ZERO, IN, O, NoPrev{});
-            vm_wait<mask_wait_count<P>(NKG)>();
-            d.flush(O);
-        } else {
-            const RowsOut O{io.rows, io.ld, io.accumulate, sub0 * 32, j, h, M};
-            auto d = dense<P, NKG, NFB, 0>(ws, BWD_LDS_ZERO, IN, O, NoPrev{});
-            d.flush(O);
-        }
-    }
-    ws.drain();
-}
-
-// ================================================================================================
-// Fused chains of Ref-NeRF's backward and the density-gradient chains (RefNeRF.get_grad, train.py:165-168,178): delta stays in
-// registers from layer to layer exactly as in the MipNeRF chain above; what differs is where the ReLU adjoint comes from -- these
-// training forwards' consumers have no bit masks to read (the Ref-NeRF forward dumps none), so a layer's mask is the dumped
-// ACTIVATION itself, DMA'd into LDS one feature-block pair ahead (512 B per sample and layer instead of 32 B; still 1 KiB per sample
-// and layer with the delta store, against 1.5 KiB for the single-layer launches these replace).  The skip layers' side outputs
-// (gradient w.r.t. the directional input vector / the encoded position, fp32 rows in the reference's column order) are ordinary
-// layers of the chain with a row-writing output functor.
-// ================================================================================================
-template <class P, int NKG_CUR, int NKG_PREV, bool STORE>
-struct ActMaskedOut {
-    typename P::BReg (&buf)[P::NT][16];
-    const char* act; char* dlt;                             // K group 0 of subtile 0 of the activation slot / of the delta slot
-    int64_t sub0; int lane; uint32_t mask_lds;
-    static constexpr size_t SUB = 16 * (size_t)P::BREG_LDS;
-    // group G's activations go to pair buffer G & 1.  Its reader is the deferred epilogue, which runs during group G + 1 (after that
-    // group's wait below) or, for the last group, during the first group of the NEXT layer -- whose begin_group(0) therefore waits
-    // with the previous layer's K-step count (NKG_PREV = 0: nothing known about what was issued since -> wait for everything).
-    DEVINL void begin_group(int G) const {
-        if (G == 0) vm_wait<mask_wait_count<P>(NKG_PREV)>(); else vm_wait<mask_wait_count<P>(NKG_CUR)>();
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int t = 0; t < P::NT; ++t) {
-                    const int kg = 2 * (2 * G + blk) + half;
-                    const char* src = act + (size_t)(sub0 + t) * SUB + (size_t)kg * P::BREG_LDS + lane * 16;
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(mask_lds + (G & 1) * bwd_pair_bytes<P>() + ((blk * 2 + half) * P::NT + t) * P::BREG_LDS);
-#pragma unroll
-                    for (int p = 0; p < P::BREG_LDS / 1024; ++p) glds_piece(src + p * 1024, dst + p * 1024);
-                }
-    }
-    DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
-        const typename P::BReg d = to_breg_half<P, false>(acc, half);
-        const uint32_t at = mask_lds + ((fb >> 1) & 1) * bwd_pair_bytes<P>() + (((fb & 1) * 2 + half) * P::NT + t) * P::BREG_LDS + lane * 16;
-        const typename P::BReg v = relu_mask(d, P::unstash(at));
-        buf[t][2 * fb + half] = v;
-        if constexpr (STORE) P::store_global(dlt + (size_t)(sub0 + t) * SUB + (size_t)(2 * fb + half) * P::BREG_LDS, lane, v);
-        else pin(v);
-    }
-    // !STORE: an empty asm that "uses" the slice where the store would have been.  Without any such anchor hipcc's scheduler moves the
-    // conversions of a whole chain around freely and the nine-layer density chain spills 1 300 registers (110 with the anchor).
-    static DEVINL void pin(const bf16x8& r) { asm volatile("" ::"v"(r)); }
-    template <class T> static DEVINL void pin(const T& r) { asm volatile("" ::"v"(r.lo), "v"(r.hi)); }
-};
 
 // Round 4: the Ref-NeRF training forward writes ReLU bit masks too (mlp_kernels.hip ref_kernel: one register per column tile instead of an
 // LDS record), so the fused chains read 32 B per sample and layer like the MipNeRF chain instead of the 512 B of activations above:
@@ -501,7 +374,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
     constexpr int TOP = DEN ? 7 : 16;                                              // activation / delta slot of the chain's first hidden layer
     constexpr int NFB_ROWS = DEN ? 2 : 6, LD = DEN ? 64 : 192;
     constexpr bool STORE = !DEN;
-    WeightStream<P, MLP_NSLOT, false> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     bwd_prologue<P>(ws, stream, DEN ? L::DEN_FRAGS : L::DIR_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -533,20 +406,20 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         const BitMaskedOut<P, 2, STORE, TOP & 1> OT{a, A(TOP), D(TOP), sub0, lane, mask_lds};
-        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[L0] - S0>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OT, NoPrev{});
+        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[L0] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, [&](int kg, int t) -> BReg { return kg == 0 ? head[t] : zero_kg; }, OT, NoPrev{});
         // TOP-1 .. TOP-4 (the fourth is the skip layer through its hidden columns): a -> b -> a -> b -> a
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
             const BitMaskedOut<P, 16, STORE, (TOP - 1) & 1> OB{b, A(TOP - 1 - 2 * r), D(TOP - 1 - 2 * r), sub0, lane, mask_lds};
             const BitMaskedOut<P, 16, STORE, TOP & 1> OA_pend{a, A(TOP - 2 * r), D(TOP - 2 * r), sub0, lane, mask_lds}, OA{a, A(TOP - 2 - 2 * r), D(TOP - 2 - 2 * r), sub0, lane, mask_lds};
-            d = dense<P, 16, 8, L::START[L0 + 1] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
-            d = dense<P, 16, 8, L::START[L0 + 2] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+            d = dense<P, 16, 8, L::START[L0 + 1] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[L0 + 2] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
         }
         // the skip layer's side output from b (= TOP-3, complete); a's last pair (TOP-4) stays pending across it -- the row layer issues no
         // mask DMA, so the pair's activations stay where they are in LDS
         {
             const RowsOut R1{rows, LD, 0, sub0 * 32, j, h, M};
-            const auto r1 = dense<P, 16, NFB_ROWS, L::START[L0 + 5] - S0>(ws, BWD_LDS_ZERO, IN_B, R1, NoPrev{});
+            const auto r1 = dense<P, 16, NFB_ROWS, L::START[L0 + 5] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, R1, NoPrev{});
             r1.flush(R1);
         }
         // TOP-5, TOP-6, TOP-7: a -> b -> a -> b
@@ -554,16 +427,16 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
         for (int r = 0; r < 2; ++r) {
             const BitMaskedOut<P, 16, STORE, (TOP - 5) & 1> OB{b, A(TOP - 5 - 2 * r), D(TOP - 5 - 2 * r), sub0, lane, mask_lds};
             const BitMaskedOut<P, 16, STORE, (TOP - 4) & 1> OA_pend{a, A(TOP - 4 - 2 * r), D(TOP - 4 - 2 * r), sub0, lane, mask_lds};
-            d = dense<P, 16, 8, L::START[L0 + 6] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[L0 + 6] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if (r == 0) {
                 const BitMaskedOut<P, 16, STORE, (TOP - 6) & 1> OA{a, A(TOP - 6), D(TOP - 6), sub0, lane, mask_lds};
-                d = dense<P, 16, 8, L::START[L0 + 7] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+                d = dense<P, 16, 8, L::START[L0 + 7] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             }
         }
         vm_wait<W16>();                                      // (the row layer has no mask wait of its own)
         const BitMaskedOut<P, 16, STORE, (TOP - 7) & 1> OL{b, A(TOP - 7), D(TOP - 7), sub0, lane, mask_lds};
         const RowsOut R2{rows, LD, 1, sub0 * 32, j, h, M};
-        const auto r2 = dense<P, 16, NFB_ROWS, L::START[L0 + 9] - S0>(ws, BWD_LDS_ZERO, IN_B, R2, prev_of(d, OL));
+        const auto r2 = dense<P, 16, NFB_ROWS, L::START[L0 + 9] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, R2, prev_of(d, OL));
         r2.flush(R2);
     }
     ws.drain();
@@ -577,7 +450,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __r
     using L = RefBwdLayout;
     using BReg = typename P::BReg;
     constexpr int S0 = L::SPA_START;
-    WeightStream<P, MLP_NSLOT, false> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     bwd_prologue<P>(ws, stream, L::SPA_FRAGS);
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -604,17 +477,17 @@ __global__ __launch_bounds__(P::NW * 64) void ref_spa_bwd_kernel(const void* __r
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         const BitMaskedOut<P, 10, true, 1> O7{a, A(7), D(7), sub0, lane, mask_lds};
-        Deferred<P, 6, 2> d = dense<P, 10, 8, L::START[10] - S0>(ws, BWD_LDS_ZERO,
+        Deferred<P, 6, 2> d = dense<P, 10, 8, L::START[10] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO,
             [&](int kg, int t) -> BReg { if (kg < 9) return x[t][kg < 9 ? kg : 0]; return zero_kg; }, O7, NoPrev{});
         // S6 .. S0: a -> b -> a ... -> b; round 3 runs the first layer of the body only
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
             const BitMaskedOut<P, 16, true, 0> OB{b, A(6 - 2 * r), D(6 - 2 * r), sub0, lane, mask_lds};
             const BitMaskedOut<P, 16, true, 1> OA_pend{a, A(7 - 2 * r), D(7 - 2 * r), sub0, lane, mask_lds};
-            d = dense<P, 16, 8, L::START[11] - S0>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[11] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if (r < 3) {
                 const BitMaskedOut<P, 16, true, 1> OA{a, A(5 - 2 * r), D(5 - 2 * r), sub0, lane, mask_lds};
-                d = dense<P, 16, 8, L::START[12] - S0>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+                d = dense<P, 16, 8, L::START[12] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             }
         }
         const BitMaskedOut<P, 16, true, 0> O0{b, A(0), D(0), sub0, lane, mask_lds};
@@ -631,7 +504,7 @@ __global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const vo
                                                                         unsigned long long mask_stride, float* __restrict__ d_enc) {
     using L = PropBwdLayout;
     using BReg = typename P::BReg;
-    WeightStream<P, MLP_NSLOT, false> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     bwd_prologue<P>(ws, stream, L::N_FRAGS);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -649,23 +522,23 @@ __global__ __launch_bounds__(P::NW * 64) void prop_density_chain_kernel(const vo
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         auto IN_B = [&](int kg, int t) -> BReg { return b[t][kg]; };
         const BitMaskedOut<P, 2, false, 1> O3{a, A(3), nullptr, sub0, lane, mask_lds};
-        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0]>(ws, BWD_LDS_ZERO, [&](int kg, int) -> BReg { return kg == 0 ? one_kg : zero_kg; }, O3, NoPrev{});
+        Deferred<P, 6, 2> d = dense<P, 2, 8, L::START[0], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, [&](int kg, int) -> BReg { return kg == 0 ? one_kg : zero_kg; }, O3, NoPrev{});
         // d2, d1, d0: a -> b -> a -> b; the two a -> b layers share one code instance through the loop (as in prop_bwd_kernel)
         static_assert(L::START[1] % (2 * P::FPC) == L::START[3] % (2 * P::FPC), "chunk phase");
 #pragma unroll 1
         for (int r = 0; r < 2; ++r) {
             const BitMaskedOut<P, 16, false, 0> OB{b, A(2 - 2 * r), nullptr, sub0, lane, mask_lds};
             const BitMaskedOut<P, 16, false, 1> OA_pend{a, A(3 - 2 * r), nullptr, sub0, lane, mask_lds};
-            d = dense<P, 16, 8, L::START[1]>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
+            d = dense<P, 16, 8, L::START[1], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_A, OB, prev_of(d, OA_pend));
             if (r == 0) {
                 const BitMaskedOut<P, 16, false, 1> OA{a, A(1), nullptr, sub0, lane, mask_lds};
-                d = dense<P, 16, 8, L::START[2]>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
+                d = dense<P, 16, 8, L::START[2], BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, OA, prev_of(d, OB));
             }
         }
         vm_wait<mask_wait_count<P>(16)>();
         const BitMaskedOut<P, 16, false, 0> O0{b, A(0), nullptr, sub0, lane, mask_lds};
         const RowsOut R{d_enc, 64, 0, sub0 * 32, j, h, M};
-        const auto r = dense<P, 16, 2, L::ENC_START>(ws, BWD_LDS_ZERO, IN_B, R, prev_of(d, O0));
+        const auto r = dense<P, 16, 2, L::ENC_START, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, R, prev_of(d, O0));
         r.flush(R);
     }
     ws.drain();
@@ -683,7 +556,7 @@ DEVINL float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // gradient of the positional encoding (nerf_helper.py:38-48 with cat_origin): d_enc (M, ld) in the reference's column order
 // [x y z | sin 2^0 xyz | cos 2^0 xyz | ...] -> dx_c = d[c] + sum_f 2^f (cos(2^f x_c) d_sin - sin(2^f x_c) d_cos), times scale[m]
-__global__ void pe_grad_kernel(const float* __restrict__ d_enc, int ld, const float* __restrict__ x, int x_stride, const float* __restrict__ scale, int scale_stride,
+__global__ __launch_bounds__(256) void pe_grad_kernel(const float* __restrict__ d_enc, int ld, const float* __restrict__ x, int x_stride, const float* __restrict__ scale, int scale_stride,
                                int64_t M, int L, float* __restrict__ out) {
     const int64_t total = M * 3;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -710,7 +583,7 @@ DEVINL float ref_rgb_slope(const float* ax, int c, int srgb) {            // f'(
     return srgb_slope(sigmoid_f(ax[11 + c]) * sigmoid_f(ax[8 + c]) + sigmoid_f(ax[4 + c] - SRGB_LOG3));
 }
 template <int ELEM>
-__global__ void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, int64_t M, char* __restrict__ frag,
+__global__ __launch_bounds__(256) void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, int64_t M, char* __restrict__ frag,
                                       unsigned long long sub_stride, int srgb) {
     for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
         const float* ax = aux + m * 16;
@@ -730,7 +603,7 @@ __global__ void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_str
 //   delta of the bottle-neck = d_allin[0:128] (K groups 0..7), both in fragment order for the heads' dgrad / wgrad.
 // IDE backward (ref_func.py:76-108): out_t = (x + i y)^m P_t(z) exp(-sigma_l k), P_t(z) = sum_k mat[k][t] z^k, sigma_l = l (l + 1) / 2.
 template <int ELEM>
-__global__ void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, const float* __restrict__ d_allin, int ld,
+__global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, const float* __restrict__ d_allin, int ld,
                                        const float* __restrict__ dirs, int dir_stride, const float* __restrict__ mat, int64_t M,
                                        char* __restrict__ frag, unsigned long long sub_stride, int srgb) {
     constexpr int TM[19] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 6, 7, 8};
@@ -845,12 +718,6 @@ constexpr int WG_MAX_JOBS = 8;
 struct WgradJobs { WgradJob j[WG_MAX_JOBS]; };
 
 enum { Y_DMAP = 0, Y_PE10 = 1, Y_PE4 = 2, Y_IDE = 3 };
-#ifndef WGRAD_LOCKSTEP
-#define WGRAD_LOCKSTEP 1
-#endif
-#ifndef WGRAD_EXCHANGE_TRANSPOSED
-#define WGRAD_EXCHANGE_TRANSPOSED 1     /* exchange form: park the transposed blocks (0 = park the raw K groups, every block transposed twice) */
-#endif
 
 // slot (kg, h, e) of a Y operand -> feature (column of the reference weight matrix), or -1
 template <int YKIND> DEVINL int y_slot_feature(int kg, int h, int e) {
@@ -888,10 +755,9 @@ struct F8Raw {
 // KGX / KGY: K groups of X / Y;  WO: waves along the X (row) dimension, 4 / WO along Y
 // XF8 / YF8: the X operand's first source (x0: a delta slot) / the Y operand (a hidden-activation slot) is an fp8 slot; x1 (the head K
 // group) and the encoding operands are always bf16
-template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false, bool XF8 = false, bool YF8 = false>
+template <int KGX, int KGY, int WO, int YKIND, bool XF8 = false, bool YF8 = false>
 __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t n_sub) {
     static_assert(!YF8 || YKIND == Y_DMAP, "only hidden-activation slots are fp8");
-    static_assert(!XCHG || XF8 == YF8, "exchange form: both operands in the same format");
     constexpr int NOB = (KGX + 1) / 2, NIB = (YKIND == Y_DMAP) ? (KGY + 1) / 2 : ((YKIND == Y_PE10 || YKIND == Y_IDE) ? 2 : 1);
     constexpr int WI = 4 / WO, OBW = NOB / WO, IBW = NIB / WI;
     static_assert(NOB % WO == 0 && NIB % WI == 0 && OBW * IBW <= 16, "wave tiling");
@@ -1007,125 +873,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
             for (int a = 0; a < OBW; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][1], yf1, acc[a][b], 0, 0, 0);
         }
     };
-    if constexpr (XCHG) {
-        // Exchange form (the 2 x 2 tiling of the 256 x 256 product).  In the plain form every wave requests all 16 K groups it multiplies,
-        // i.e. the workgroup requests every K group twice and keeps 32 KiB of UNIQUE bytes in flight per CU with one subtile of prefetch --
-        // the kernel's time is that number times the loaded HBM latency, and a second prefetch buffer does not fit the register file.
-        // Here a wave loads only its QUARTER of a subtile (4 of its 8 X K groups, 4 of its 8 Y K groups: 8 KiB, 32 registers), two
-        // subtiles ahead, parks it in LDS when it has landed, and after the workgroup barrier reads its partners' quarters back: the same
-        // 64 operand registers per subtile, but 64 KiB of unique bytes in flight per CU and no duplicate request at all.
-        static_assert(KGX == 16 && KGY == 16 && WO == 2 && YKIND == Y_DMAP, "exchange form: the 2 x 2 tiling of the 256 x 256 product");
-        constexpr uint32_t STAGE = 32 * 1024;                              // X K groups 0..15 | Y K groups 0..15 of one subtile
-        // a quarter in flight: bf16 = 8 B register groups; fp8 = 2 + 2 blocks of two K groups and one dword of scale exponents per operand
-        // (18 registers instead of 32), decoded to bf16 when it is parked -- LDS and everything downstream see bf16 either way
-        struct QuarterBf16 { bf16x8 v[8]; };
-        struct QuarterF8 { F8Raw<4> x, y; };
-        using Quarter = typename std::conditional<XF8, QuarterF8, QuarterBf16>::type;
-        auto load_quarter = [&](int64_t s, Quarter& q) {                   // X K groups 8 wo + 4 wi + k, Y K groups 8 wi + 4 wo + k
-            if constexpr (XF8) {
-                q.x.load(J.x0.base + (size_t)s * J.x0.sub_stride + lane * 16, 8 * wo + 4 * wi);
-                q.y.load(J.y.base + (size_t)s * J.y.sub_stride + lane * 16, 8 * wi + 4 * wo);
-            } else {
-                const char* yb = J.y.base + (size_t)s * J.y.sub_stride + lane * 16;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    q.v[k] = *reinterpret_cast<const bf16x8*>(x_ptr(s, 8 * wo + 4 * wi + k));
-                    q.v[4 + k] = *reinterpret_cast<const bf16x8*>(yb + (size_t)(8 * wi + 4 * wo + k) * 1024);
-                }
-            }
-        };
-        auto clamp_s = [&](int64_t s) { return s < s_end ? s : s_end - 1; };
-        Quarter q0, q1;
-        int buf = 0;
-        if (s_begin < s_end) { load_quarter(s_begin, q0); load_quarter(clamp_s(s_begin + 1), q1); }
-#if WGRAD_EXCHANGE_TRANSPOSED
-        // What is exchanged are the TRANSPOSED blocks: a wave transposes (and converts, and row-sums for the bias) only the two X and two Y
-        // feature blocks of its own quarter, parks them, and reads its partners' two + two transposed blocks after the barrier -- every block
-        // is transposed once per workgroup instead of twice: 8 transposing MFMAs + 32 products per wave and subtile instead of 16 + 32, half
-        // the conversions, and the bias sums spread over all four waves.  LDS traffic is unchanged (a transposed block pair is as big as the
-        // two K groups it came from).  Stage layout: X block gx, half hf at (2 gx + hf) KiB; Y blocks behind them at +16 KiB.
-        // A quarter's registers are refilled (two subtiles ahead) as soon as it has been transposed: two stages, no copies.
-        auto body = [&](int64_t s, Quarter& cur) {
-            bf16x8 own[8];
-            if constexpr (XF8) { cur.x.decode(0, own); cur.y.decode(0, own + 4); }     // (kg0 = 0: the group's own dword, no byte shift)
-            else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) own[k] = cur.v[k];
-            }
-            const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
-            bf16x8 xf[4][2], yf[4][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {                                   // own X blocks 4 wo + 2 wi + a, own Y blocks 4 wi + 2 wo + a
-                f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[2 * a], idx[0], zero16, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[2 * a + 1], idx[1], t, 0, 0, 0);
-                f32x16 u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[4 + 2 * a], idx[0], zero16, 0, 0, 0);
-                u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(own[4 + 2 * a + 1], idx[1], u, 0, 0, 0);
-                xf[a][0] = cvt8(t, 0); xf[a][1] = cvt8(t, 1);
-                yf[a][0] = cvt8(u, 0); yf[a][1] = cvt8(u, 1);
-                if (J.bias_partial != nullptr) {
-                    const float r0 = (t[0] + t[1]) + (t[2] + t[3]), r1 = (t[4] + t[5]) + (t[6] + t[7]), r2 = (t[8] + t[9]) + (t[10] + t[11]),
-                                r3 = (t[12] + t[13]) + (t[14] + t[15]);
-                    bsum[a] += (r0 + r1) + (r2 + r3);
-                }
-                if (a == 1) load_quarter(clamp_s(s + 2), cur);             // `cur` is consumed: refill the same registers, two subtiles ahead
-                                                                            // (unconditional: past the end the last subtile is read again)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    *reinterpret_cast<bf16x8*>(smem + st + (2 * (4 * wo + 2 * wi + a) + hf) * 1024) = xf[a][hf];
-                    *reinterpret_cast<bf16x8*>(smem + st + (16 + 2 * (4 * wi + 2 * wo + a) + hf) * 1024) = yf[a][hf];
-                }
-            }
-            __syncthreads();                                                // everybody's blocks of s are in LDS (and buffer buf^1 is free again)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)                                     // local blocks 0, 1 = own, 2, 3 = the partner's (xmap / ymap undo it)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    xf[2 + a][hf] = *reinterpret_cast<const bf16x8*>(smem + st + (2 * (4 * wo + 2 * (1 - wi) + a) + hf) * 1024);
-                    yf[2 + a][hf] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 2 * (4 * wi + 2 * (1 - wo) + a) + hf) * 1024);
-                }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][0], yf[b][0], acc[a][b], 0, 0, 0);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a][1], yf[b][1], acc[a][b], 0, 0, 0);
-            }
-            buf ^= 1;
-        };
-        for (int64_t s = s_begin; s < s_end;) {
-            body(s, q0); if (++s >= s_end) break;
-            body(s, q1); ++s;
-        }
-#else
-        Quarter q2;
-        bf16x8 own[8], xs[NXK], ys[NYK];
-        for (int64_t s = s_begin; s < s_end; ++s) {
-            load_quarter(clamp_s(s + 2), q2);                               // (unconditional: past the end the last subtile is read again)
-            const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
-            if constexpr (XF8) { q0.x.decode(0, own); q0.y.decode(0, own + 4); }       // (kg0 = 0: the group's own dword, no byte shift)
-            else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) own[k] = q0.v[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                                   // park my quarter of subtile s (it landed: issued two iterations ago)
-                *reinterpret_cast<bf16x8*>(smem + st + (8 * wo + 4 * wi + k) * 1024) = own[k];
-                *reinterpret_cast<bf16x8*>(smem + st + (16 + 8 * wi + 4 * wo + k) * 1024) = own[4 + k];
-            }
-            __syncthreads();                                                // everybody's quarters of s are in LDS (and buffer buf^1 is free again)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                                   // my own quarter from registers, the partners' from LDS.  Register
-                xs[k] = own[k];                                             // arrays must be indexed statically: local blocks 0, 1 = the own K
-                xs[4 + k] = *reinterpret_cast<const bf16x8*>(smem + st + (8 * wo + 4 * (1 - wi) + k) * 1024);   // groups, 2, 3 = the partner's;
-                ys[k] = own[4 + k];                                         // the permutation is undone in the partial's addresses (xmap / ymap)
-                ys[4 + k] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 8 * wi + 4 * (1 - wo) + k) * 1024);
-            }
-            multiply(xs, ys);
-            q0 = q1; q1 = q2;
-            buf ^= 1;
-        }
-#endif
-    } else if constexpr (XF8 || YF8) {
+    if constexpr (XF8 || YF8) {
         // plain form with fp8 operands: the next subtile travels as raw blocks (fewer registers in flight) and is decoded after the multiply
         bf16x8 xs[NXK], ys[NYK], yn[NYK], xn[NXK];
         RawX xr; RawY yr;
@@ -1145,9 +893,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
         };
         if (s_begin < s_end) { fetch(s_begin); land(); }
         for (int64_t s = s_begin; s < s_end; ++s) {
-#if WGRAD_LOCKSTEP
             if constexpr (WO > 1 || WI > 1) __builtin_amdgcn_s_barrier();
-#endif
             fetch((s + 1 < s_end) ? s + 1 : s);
             multiply(xs, ys);
             land();
@@ -1156,12 +902,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
     bf16x8 xs[NXK], ys[NYK], xn[NXK], yn[NYK];
     if (s_begin < s_end) { load_x(s_begin, xs); load_y(s_begin, ys); }
     for (int64_t s = s_begin; s < s_end; ++s) {
-#if WGRAD_LOCKSTEP
         // Waves that share K groups (same wo / same wi) start every subtile together, so that the second request of a K group is served
         // by L1 / L2 while the first is still in flight: FETCH_SIZE falls from 1.47x to 1.00x of the algorithmic bytes (PMC).  The kernel's
         // time does not change (it is bound by bytes in flight, not bandwidth) -- the barrier is there to not waste HBM reads.
         if constexpr (WO > 1 || WI > 1) __builtin_amdgcn_s_barrier();
-#endif
         {   // next subtile in flight while this one is multiplied (the last iteration re-reads its own subtile: unconditional loads)
             const int64_t sn = (s + 1 < s_end) ? s + 1 : s;
             load_x(sn, xn); load_y(sn, yn);
@@ -1173,9 +917,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
         for (int k = 0; k < NYK; ++k) ys[k] = yn[k];
     }
     }
-    // local block index -> block of the wave's rectangle (exchange form: own blocks first, then the partner's)
-    auto xmap = [&](int a) { return XCHG ? ((a < 2) ? 2 * wi + a : 2 * (1 - wi) + a - 2) : a; };
-    auto ymap = [&](int b) { return XCHG ? ((b < 2) ? 2 * wo + b : 2 * (1 - wo) + b - 2) : b; };
     // partial of this workgroup, row-major (32 NOB) x (32 NIB): register r of lane (j, h) = row 32 ob + (r&3) + 8 (r>>2) + 4 h, column 32 ib + j
     float* out = J.partial + (size_t)blockIdx.x * (32 * NOB) * (32 * NIB);
 #pragma unroll
@@ -1184,22 +925,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
         for (int b = 0; b < IBW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * (ob0 + xmap(a)) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                out[(size_t)row * (32 * NIB) + 32 * (ib0 + ymap(b)) + j] = acc[a][b][r];
+                const int row = 32 * (ob0 + a) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)row * (32 * NIB) + 32 * (ib0 + b) + j] = acc[a][b][r];
             }
-    if (XCHG && WGRAD_EXCHANGE_TRANSPOSED) {                // every wave summed the rows of its own two transposed X blocks
-        if (J.bias_partial != nullptr) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-                if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + xmap(a)) + j] = v;
-            }
-        }
-    } else if (J.bias_partial != nullptr && wi == 0) {
+    if (J.bias_partial != nullptr && wi == 0) {
 #pragma unroll
         for (int a = 0; a < OBW; ++a) {
             const float v = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-            if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + xmap(a)) + j] = v;
+            if (h == 0) J.bias_partial[(size_t)blockIdx.x * (32 * NOB) + 32 * (ob0 + a) + j] = v;
         }
     }
 }
@@ -1222,9 +955,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel_bf16(WgradJobs jobs, int64_t
 // against 1.364 / 1.369 ms, profiles/r03_wgrad_pipelined_ab.log): the subtile's time is neither its bytes nor the length of one wave's
 // dependent chain -- the workgroup barrier phase-locks all eight waves, so the LDS phase (96-128 KiB per subtile through a 128 B/clk port)
 // and the MFMA phase (2 x 640 cycles per SIMD) of a subtile do not overlap ACROSS waves whatever one wave does inside its own stream.
-#ifndef WGRAD256_PIPELINED
-#define WGRAD256_PIPELINED 0
-#endif
 template <bool F8>
 __global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n_sub) {
     constexpr f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1266,67 +996,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n
     auto clamp_s = [&](int64_t s) { return s < s_end ? s : s_end - 1; };
     Stage q0, q1;
     int buf = 0;
-    if (s_begin < s_end) { fetch(s_begin, q0); if (!WGRAD256_PIPELINED) fetch(clamp_s(s_begin + 1), q1); }
-#if WGRAD256_PIPELINED
-    // Software pipeline over subtiles: the transposition of subtile s + 1 (4 MFMAs, 16 conversions, the bias row sum, 4 ds_write_b128
-    // into the other stage) runs between the barrier of subtile s and its 16 products, i.e. inside the latency of the 12 ds_read_b128 that
-    // fetch s's transposed blocks.  The un-pipelined body ran transposition -> barrier -> LDS reads -> products as one dependent chain in
-    // ALL eight waves at once (the barrier puts both waves of a SIMD in the same phase, so they never filled each other's gaps):
-    // 3 070 cycles per subtile against 1 280 of MFMA work per SIMD.  One barrier per subtile still orders everything: a wave reaches
-    // barrier(s) only after its products of s - 1 (the last reads of stage buf ^ 1) and its writes of s.
-    auto transpose = [&](int64_t s, Stage& cur, int into, bool live) {    // subtile s (held in `cur`) -> stage `into`; refills `cur` with s + 1
-        bf16x8 ox[2], oy[2];
-        if constexpr (F8) { cur.x.decode(2 * xb, ox); cur.y.decode(2 * yb, oy); }
-        else { ox[0] = cur.x[0]; ox[1] = cur.x[1]; oy[0] = cur.y[0]; oy[1] = cur.y[1]; }
-        f32x16 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ox[0], idx[0], zero16, 0, 0, 0);
-        f32x16 u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oy[0], idx[0], zero16, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ox[1], idx[1], t, 0, 0, 0);
-        u = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oy[1], idx[1], u, 0, 0, 0);
-        fetch(clamp_s(s + 1), cur);                                        // ONE staging set (a second costs 16 registers the kernel does not have at two waves per SIMD)
-        if (J.bias_partial != nullptr) {
-            const float r0 = (t[0] + t[1]) + (t[2] + t[3]), r1 = (t[4] + t[5]) + (t[6] + t[7]), r2 = (t[8] + t[9]) + (t[10] + t[11]),
-                        r3 = (t[12] + t[13]) + (t[14] + t[15]);
-            bsum += live ? (r0 + r1) + (r2 + r3) : 0.0f;
-        }
-        const uint32_t st = (uint32_t)into * STAGE + lane * 16;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            *reinterpret_cast<bf16x8*>(smem + st + (2 * xb + hf) * 1024) = cvt8(t, hf);
-            *reinterpret_cast<bf16x8*>(smem + st + (16 + 2 * yb + hf) * 1024) = cvt8(u, hf);
-        }
-    };
-    auto body = [&](int64_t s, Stage& next) {                              // `next` holds subtile s + 1 (requested one iteration ago)
-        __syncthreads();                                                   // stage buf: all sixteen transposed blocks of s; stage buf ^ 1: free
-        const uint32_t st = (uint32_t)buf * STAGE + lane * 16;
-        // local X block a = block xb ^ a; local Y block b = block 4 wi + ((wo + b) & 3).  The two sample halves (hf) are read separately:
-        // half 0 before the transposition (its latency hides there), half 1 after it, when the transposition's accumulators are dead --
-        // all twelve reads up front cost 48 registers next to them and spilled 146
-        bf16x8 xf[2], yf[4], xg[2], yg[4];
-        auto read_half = [&](int hf, bf16x8 (&x)[2], bf16x8 (&y)[4]) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) x[a] = *reinterpret_cast<const bf16x8*>(smem + st + (2 * (xb ^ a) + hf) * 1024);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) y[b] = *reinterpret_cast<const bf16x8*>(smem + st + (16 + 2 * (4 * wi + ((wo + b) & 3)) + hf) * 1024);
-        };
-        read_half(0, xf, yf);
-        __builtin_amdgcn_sched_barrier(0);
-        transpose(s + 1, next, buf ^ 1, s + 1 < s_end);                    // (past the end: a harmless repeat of the last subtile into the free stage)
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(1, xg, yg);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xg[a], yg[b], acc[a][b], 0, 0, 0);
-        buf ^= 1;
-    };
-    if (s_begin < s_end) transpose(s_begin, q0, 0, true);
-#pragma unroll 1
-    for (int64_t s = s_begin; s < s_end; ++s) body(s, q0);
-#else
+    if (s_begin < s_end) { fetch(s_begin, q0); fetch(clamp_s(s_begin + 1), q1); }
     auto body = [&](int64_t s, Stage& cur) {
         bf16x8 ox[2], oy[2];
         if constexpr (F8) { cur.x.decode(2 * xb, ox); cur.y.decode(2 * yb, oy); }
@@ -1370,7 +1040,6 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(WgradJobs jobs, int64_t n
         body(s, q0); if (++s >= s_end) break;
         body(s, q1); ++s;
     }
-#endif
     // partial of this workgroup, row-major 256 x 256: local X block a -> block xb ^ a; local Y block b -> block 4 wi + ((wo + b) & 3)
     float* out = J.partial + (size_t)blockIdx.x * 256 * 256;
 #pragma unroll
@@ -1596,10 +1265,6 @@ int bwd_grid(int64_t n_tiles) {
 #ifndef BWD_TU
 #define BWD_TU 0
 #endif
-// REF_FUSED_CHAINS=0: the single-layer launches the fused chains replaced, for A/B runs
-#ifndef REF_FUSED_CHAINS
-#define REF_FUSED_CHAINS 1
-#endif
 // TU 3 (round 4): the Ref-NeRF DIRECTIONAL chain alone, compiled WITHOUT -amdgpu-mfma-vgpr-form: with the bit-mask functor hipcc's
 // AGPR-copy rewrite pass segfaults on this one kernel (AMDGPURewriteAGPRCopyMFMA, eliminateSpillsOfReassignedVGPRs); without the flag it
 // compiles with 65 spilled registers (91 in round 3's activation-mask form with the flag).
@@ -1617,9 +1282,6 @@ int launch_dir_chain_t(const char* stream, int64_t M, const char* masks, size_t 
 }
 }  // namespace
 int bwd_launch_dir_chain(int precision, const char* stream, int64_t M, const char* masks, size_t ms, char* dlt, size_t ls, float* rows, hipStream_t st) {
-#ifdef REF_DIR_CHAIN_NARROW                                    // A/B knob: the 8-wave x 32-sample tile for the directional chain -- measured SLOWER
-    if (precision == NERF_AMD_BF16) return launch_dir_chain_t<PBF16>(stream, M, masks, ms, dlt, ls, rows, st);      // (5.87 -> 6.34 ms, profiles/r04_ref_chains_8wave_ab.log)
-#endif
     if (precision == NERF_AMD_BF16) return launch_dir_chain_t<PB16>(stream, M, masks, ms, dlt, ls, rows, st);
     return launch_dir_chain_t<PF32>(stream, M, masks, ms, dlt, ls, rows, st);
 }
@@ -1642,11 +1304,6 @@ int launch_chain_t(int which, const char* stream, int64_t M, const char* act, ch
     if (n_tiles == 0) return 0;
     const size_t lds = bwd_lds_total<P>();
     const dim3 grid(bwd_grid(n_tiles)), block(P::NW * 64);
-#ifdef CHAIN_PROBE                                             // developer switch: compile ONE chain instance (-DCHAIN_PROBE="(kernel<...>)" with
-                                                              // -Rpass-analysis=kernel-resource-usage: seconds instead of minutes per register-pressure experiment)
-    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(CHAIN_PROBE), lds)) return e;
-    return 0;
-#else
     switch (which) {
         case 0:                                                // (its own translation unit: see bwd_launch_dir_chain)
             return bwd_launch_dir_chain(P::PREC, stream, M, masks, ms, dlt, ls, rows, st);
@@ -1663,7 +1320,6 @@ int launch_chain_t(int which, const char* stream, int64_t M, const char* act, ch
             hipLaunchKernelGGL((prop_density_chain_kernel<P>), grid, block, lds, st, stream, M, masks, (unsigned long long)ms, rows);
     }
     return (int)hipGetLastError();
-#endif
 }
 // which: 0 Ref-NeRF directional, 1 Ref-NeRF spatial, 2 Ref-NeRF density gradient, 3 proposal density gradient; `start_frag`: where the
 // chain's stream begins in the blob
@@ -1677,9 +1333,7 @@ int bwd_launch_chain(int which, int precision, const void* blob, int start_frag,
     // the SPATIAL chain of Ref-NeRF on the 8-wave x 32-sample tile: like the training forwards, its delta stores cost issue slots that a second
     // wave per SIMD fills -- 3.61 -> 3.31 ms per 2^14-ray step, same box, alternated twice (profiles/r04_ref_chains_8wave_ab.log; the
     // directional chain, with 65 spilled registers, got slower on it and stays on the wide tile).  -DREF_SPA_CHAIN_WIDE = the A side.
-#ifndef REF_SPA_CHAIN_WIDE
     if (precision == NERF_AMD_BF16 && which == 1) return launch_chain_t<PBF16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
-#endif
     if (precision == NERF_AMD_BF16) return launch_chain_t<PB16>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
     return launch_chain_t<PF32>(which, stream, M, reinterpret_cast<const char*>(act), reinterpret_cast<char*>(dlt), ls, ms, rows, st);
 }
@@ -1712,28 +1366,22 @@ int launch_mip_bwd(const void* packed, const float* g, const float* rgbo, int64_
     return (int)hipGetLastError();
 }
 
-#ifndef WGRAD_EIGHT_WAVES
-#define WGRAD_EIGHT_WAVES 1         /* the 256 x 256 shape on eight waves (two per SIMD), wgrad256_kernel; 0 = the four-wave exchange form */
-#endif
 template <bool F8>
 int launch_wgrad256(const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
     if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(wgrad256_kernel<F8>), 65536)) return e;
     hipLaunchKernelGGL((wgrad256_kernel<F8>), dim3(n_wg, n_jobs), dim3(512), 65536, st, jobs, n_sub);
     return (int)hipGetLastError();
 }
-#ifndef WGRAD_EXCHANGE
-#define WGRAD_EXCHANGE 1            /* the 256 x 256 shape loads quarters and exchanges them through LDS (0 = every wave loads all it multiplies) */
-#endif
-template <int KGX, int KGY, int WO, int YKIND, bool XCHG = false>
+template <int KGX, int KGY, int WO, int YKIND>
 int launch_wgrad(int precision, const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
-    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND, XCHG>), dim3(n_wg, n_jobs), dim3(256), XCHG ? 65536 : 0, st, jobs, n_sub);
+    if (precision == NERF_AMD_BF16) hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
     else hipLaunchKernelGGL((wgrad_kernel_f32<KGX, KGY, WO, YKIND>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
     return (int)hipGetLastError();
 }
 // fp8 dump operands (NERF_AMD_BF16_F8): XF8 / YF8 say which operand comes from an fp8 slot
-template <int KGX, int KGY, int WO, int YKIND, bool XCHG, bool XF8, bool YF8>
+template <int KGX, int KGY, int WO, int YKIND, bool XF8, bool YF8>
 int launch_wgrad_f8(const WgradJobs& jobs, int n_jobs, int n_wg, int64_t n_sub, hipStream_t st) {
-    hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND, XCHG, XF8, YF8>), dim3(n_wg, n_jobs), dim3(256), XCHG ? 65536 : 0, st, jobs, n_sub);
+    hipLaunchKernelGGL((wgrad_kernel_bf16<KGX, KGY, WO, YKIND, XF8, YF8>), dim3(n_wg, n_jobs), dim3(256), 0, st, jobs, n_sub);
     return (int)hipGetLastError();
 }
 
@@ -1785,19 +1433,19 @@ int run_wgrad(int shape, int precision, const Product* prods, int n, int n_wg, i
     if (f8) {
         if (precision != NERF_AMD_BF16) return (int)hipErrorInvalidValue;
         switch (shape) {
-            case 0: if (WGRAD_EIGHT_WAVES) return launch_wgrad256<true>(jobs, n, n_wg, n_sub, st);
-                    return launch_wgrad_f8<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0, true, true>(jobs, n, n_wg, n_sub, st);
-            case 1: return launch_wgrad_f8<16, 4, 4, Y_PE10, false, true, false>(jobs, n, n_wg, n_sub, st);
-            case 2: return launch_wgrad_f8<9, 16, 1, Y_DMAP, false, true, true>(jobs, n, n_wg, n_sub, st);
-            case 3: return launch_wgrad_f8<1, 8, 1, Y_DMAP, false, false, true>(jobs, n, n_wg, n_sub, st);
-            case 4: return launch_wgrad_f8<8, 2, 4, Y_PE4, false, true, false>(jobs, n, n_wg, n_sub, st);
-            case 5: return launch_wgrad_f8<1, 16, 1, Y_DMAP, false, false, true>(jobs, n, n_wg, n_sub, st);
+            case 0: return launch_wgrad256<true>(jobs, n, n_wg, n_sub, st);
+            case 1: return launch_wgrad_f8<16, 4, 4, Y_PE10, true, false>(jobs, n, n_wg, n_sub, st);
+            case 2: return launch_wgrad_f8<9, 16, 1, Y_DMAP, true, true>(jobs, n, n_wg, n_sub, st);
+            case 3: return launch_wgrad_f8<1, 8, 1, Y_DMAP, false, true>(jobs, n, n_wg, n_sub, st);
+            case 4: return launch_wgrad_f8<8, 2, 4, Y_PE4, true, false>(jobs, n, n_wg, n_sub, st);
+            case 5: return launch_wgrad_f8<1, 16, 1, Y_DMAP, false, true>(jobs, n, n_wg, n_sub, st);
         }
         return (int)hipErrorInvalidValue;
     }
     switch (shape) {
-        case 0: if (WGRAD_EIGHT_WAVES && precision == NERF_AMD_BF16) return launch_wgrad256<false>(jobs, n, n_wg, n_sub, st);      // 4 x 2 waves of 2 x 4 blocks
-                return launch_wgrad<16, 16, 2, Y_DMAP, WGRAD_EXCHANGE != 0>(precision, jobs, n, n_wg, n_sub, st);     // 2 x 2 waves of 4 x 4 blocks
+        case 0: if (precision == NERF_AMD_BF16) return launch_wgrad256<false>(jobs, n, n_wg, n_sub, st);      // 4 x 2 waves of 2 x 4 blocks
+                hipLaunchKernelGGL((wgrad_kernel_f32<16, 16, 2, Y_DMAP>), dim3(n_wg, n), dim3(256), 0, st, jobs, n_sub);   // fp32: 2 x 2 waves of 4 x 4 blocks
+                return (int)hipGetLastError();
         case 1: return launch_wgrad<16, 4, 4, Y_PE10>(precision, jobs, n, n_wg, n_sub, st);      // 4 x 1 waves of 2 x 2 blocks
         case 2: return launch_wgrad<9, 16, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);      // NOB 5 x NIB 8: 1 x 4 waves of 5 x 2 blocks
         case 3: return launch_wgrad<1, 8, 1, Y_DMAP>(precision, jobs, n, n_wg, n_sub, st);       // NOB 1 x NIB 4
@@ -1944,46 +1592,14 @@ int bwd_mip_weight_grads(int precision, int64_t M, const void* act_dump, const v
     return (int)hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------ single-layer launches: host side
+// ------------------------------------------------------------------------------------------------ Ref-NeRF backward: host side
 namespace {
-template <class P, int NKG, int NFB, bool MASK>
-int launch_layer_t(const char* layer, int n_frags, const LayerIO& io, int64_t M, hipStream_t st) {
-    constexpr int TS = P::NW * P::NT * 32;
-    const int64_t n_tiles = (M + TS - 1) / TS;
-    if (n_tiles == 0) return 0;
-    const size_t lds = bwd_lds_total<P>();
-    if (int e = nerf_host::allow_dynamic_lds(reinterpret_cast<const void*>(dgrad_layer_kernel<P, NKG, NFB, MASK>), lds)) return e;
-    hipLaunchKernelGGL((dgrad_layer_kernel<P, NKG, NFB, MASK>), dim3(bwd_grid(n_tiles)), dim3(P::NW * 64), lds, st, layer, n_frags, io, M);
-    return (int)hipGetLastError();
-}
-template <int NKG, int NFB, bool MASK>
-int launch_layer(int precision, const void* blob, int start_frag, const LayerIO& io, int64_t M, hipStream_t st) {
-    const size_t fb = precision == NERF_AMD_BF16 ? 1024 : 2048;
-    const char* layer = reinterpret_cast<const char*>(blob) + (size_t)start_frag * fb;
-    if (precision == NERF_AMD_BF16) return launch_layer_t<PB16, NKG, NFB, MASK>(layer, NKG * NFB, io, M, st);
-    return launch_layer_t<PF32, NKG, NFB, MASK>(layer, NKG * NFB, io, M, st);
-}
 struct ChainCtx {                     // addressing of fragment dumps: slot l, K group kg
     int precision; int64_t M; size_t breg, ls, sub;
     ChainCtx(int prec, int64_t m) : precision(prec), M(m), breg(prec == NERF_AMD_BF16 ? 1024 : 2048), ls(mlp_train_layer_stride(prec, m)), sub(16 * breg) {}
     const char* at(const void* dump, int slot, int kg = 0) const { return reinterpret_cast<const char*>(dump) + (size_t)slot * ls + (size_t)kg * breg; }
     char* at(void* dump, int slot, int kg = 0) const { return reinterpret_cast<char*>(dump) + (size_t)slot * ls + (size_t)kg * breg; }
 };
-// hidden layer: delta_out(slot so of `dlt`) = W^T delta_in(slot si of `dlt`) * [act(slot so) > 0]
-template <int NKG>
-int hidden_layer(const ChainCtx& c, const void* blob, int start, const char* x0, int kgx0, const char* x1, int ones, const char* mask, char* out, hipStream_t st) {
-    LayerIO io{};
-    io.x0 = x0; io.kgx0 = kgx0; io.x1 = x1; io.x_sub_stride = c.sub; io.ones_head = ones;
-    io.mask = mask; io.out = out; io.io_sub_stride = c.sub;
-    return launch_layer<NKG, 8, true>(c.precision, blob, start, io, c.M, st);
-}
-template <int NFB>
-int rows_layer(const ChainCtx& c, const void* blob, int start, const char* x, float* rows, int ld, int accumulate, hipStream_t st) {
-    LayerIO io{};
-    io.x0 = x; io.kgx0 = 16; io.x1 = nullptr; io.x_sub_stride = c.sub; io.ones_head = 0;
-    io.rows = rows; io.ld = ld; io.accumulate = accumulate;
-    return launch_layer<16, NFB, false>(c.precision, blob, start, io, c.M, st);
-}
 int blocks_1d(int64_t work) { int64_t b = (work + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -1992,46 +1608,16 @@ int blocks_1d(int64_t work) { int64_t b = (work + 255) / 256; return (int)(b > 4
 // (net 0: activation slots 0..3) and Ref-NeRF's spatial network (net 2: slots 0..7): a dgrad-only chain from the density row down to
 // the encoded position, then the encoding's derivative.  workspace: two delta buffers of one slot each + d_enc rows (M, 64) fp32.
 size_t bwd_density_grad_workspace_bytes(int precision, int64_t M) {
-    return (REF_FUSED_CHAINS ? 0 : 2 * align256(mlp_train_layer_stride(precision, M))) + align256((size_t)M * 64 * 4) + 256;
+    return align256((size_t)M * 64 * 4) + 256;
 }
 int bwd_density_grad(int net, const void* blob, int precision, int64_t M, const void* act, const float* x, int x_stride, const float* scale, int scale_stride,
                      float* out, void* workspace, hipStream_t st) {
     if (M == 0) return 0;
     const ChainCtx c(precision, M);
     Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
-#if REF_FUSED_CHAINS
     float* denc = ws.take((size_t)M * 64);
     if (net == NERF_AMD_NET_PROPOSAL) { if (int e = bwd_launch_chain(3, precision, blob, 0, M, act, nullptr, denc, st)) return e; }
     else if (int e = bwd_launch_chain(2, precision, blob, RefBwdLayout::DEN_START, M, act, nullptr, denc, st)) return e;
-#else
-    char* d[2] = {reinterpret_cast<char*>(ws.take(c.ls / 4)), reinterpret_cast<char*>(ws.take(c.ls / 4))};
-    float* denc = ws.take((size_t)M * 64);
-    int cur = 0;
-    if (net == NERF_AMD_NET_PROPOSAL) {
-        using L = PropBwdLayout;
-        if (int e = hidden_layer<2>(c, blob, L::START[0], nullptr, 2, nullptr, 1, c.at(act, 3), d[cur], st)) return e;        // delta_3 from the head row
-        for (int l = 1; l <= 3; ++l) {                                                                                       // delta_2, delta_1, delta_0
-            if (int e = hidden_layer<16>(c, blob, L::START[l], d[cur], 16, nullptr, 0, c.at(act, 3 - l), d[cur ^ 1], st)) return e;
-            cur ^= 1;
-        }
-        if (int e = rows_layer<2>(c, blob, L::ENC_START, d[cur], denc, 64, 0, st)) return e;
-    } else {
-        using L = RefBwdLayout;
-        if (int e = hidden_layer<2>(c, blob, L::START[18], nullptr, 2, nullptr, 1, c.at(act, 7), d[cur], st)) return e;       // delta_S7 from the density row
-        for (int l = 0; l < 3; ++l) {                                                                                        // S6, S5, S4
-            if (int e = hidden_layer<16>(c, blob, L::START[19 + l], d[cur], 16, nullptr, 0, c.at(act, 6 - l), d[cur ^ 1], st)) return e;
-            cur ^= 1;
-        }
-        if (int e = rows_layer<2>(c, blob, L::START[23], d[cur], denc, 64, 0, st)) return e;                                  // skip layer: its encoding columns
-        if (int e = hidden_layer<16>(c, blob, L::START[22], d[cur], 16, nullptr, 0, c.at(act, 3), d[cur ^ 1], st)) return e;  // ... and its hidden columns -> S3
-        cur ^= 1;
-        for (int l = 0; l < 3; ++l) {                                                                                        // S2, S1, S0
-            if (int e = hidden_layer<16>(c, blob, L::START[24 + l], d[cur], 16, nullptr, 0, c.at(act, 2 - l), d[cur ^ 1], st)) return e;
-            cur ^= 1;
-        }
-        if (int e = rows_layer<2>(c, blob, L::START[27], d[cur], denc, 64, 1, st)) return e;
-    }
-#endif
     hipLaunchKernelGGL(pe_grad_kernel, dim3(blocks_1d(M * 3)), dim3(256), 0, st, denc, 64, x, x_stride, scale, scale_stride, M, 10, out);
     return (int)hipGetLastError();
 }
@@ -2070,38 +1656,14 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
     // stage 1: spec head delta, then the directional network backwards
     if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
     else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
-#if REF_FUSED_CHAINS
     if (int e = bwd_launch_chain(0, precision, blob, L::DIR_START, M, act, dlt, dallin, st)) return e;                            // D7 .. D0 + the input-vector columns
-#else
-    if (int e = hidden_layer<2>(c, blob, L::START[0], D(8, 9), 2, nullptr, 0, A(16), D(16), st)) return e;                    // D7
-    if (int e = hidden_layer<16>(c, blob, L::START[1], D(16), 16, nullptr, 0, A(15), D(15), st)) return e;                    // D6
-    if (int e = hidden_layer<16>(c, blob, L::START[2], D(15), 16, nullptr, 0, A(14), D(14), st)) return e;                    // D5
-    if (int e = hidden_layer<16>(c, blob, L::START[3], D(14), 16, nullptr, 0, A(13), D(13), st)) return e;                    // D4
-    if (int e = rows_layer<6>(c, blob, L::START[5], D(13), dallin, 192, 0, st)) return e;                                     // skip: its input-vector columns
-    if (int e = hidden_layer<16>(c, blob, L::START[4], D(13), 16, nullptr, 0, A(12), D(12), st)) return e;                    // ... hidden columns -> D3
-    if (int e = hidden_layer<16>(c, blob, L::START[6], D(12), 16, nullptr, 0, A(11), D(11), st)) return e;                    // D2
-    if (int e = hidden_layer<16>(c, blob, L::START[7], D(11), 16, nullptr, 0, A(10), D(10), st)) return e;                    // D1
-    if (int e = hidden_layer<16>(c, blob, L::START[8], D(10), 16, nullptr, 0, A(9), D(9), st)) return e;                      // D0
-    if (int e = rows_layer<6>(c, blob, L::START[9], D(9), dallin, 192, 1, st)) return e;
-#endif
     // stage 2: IDE / reflection / normal / head activations backwards -> delta of the heads and of the bottle-neck
     if (elem == 2) hipLaunchKernelGGL(ref_heads_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M,
                                       D(8), (unsigned long long)c.sub, srgb);
     else hipLaunchKernelGGL(ref_heads_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, D(8),
                             (unsigned long long)c.sub, srgb);
     // stage 3: the spatial network backwards
-#if REF_FUSED_CHAINS
     if (int e = bwd_launch_chain(1, precision, blob, L::SPA_START, M, act, dlt, nullptr, st)) return e;                           // S7 .. S0
-#else
-    if (int e = hidden_layer<10>(c, blob, L::START[10], D(8), 10, nullptr, 0, A(7), D(7), st)) return e;                      // S7 from [bottle-neck | heads | 0]
-    if (int e = hidden_layer<16>(c, blob, L::START[11], D(7), 16, nullptr, 0, A(6), D(6), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[12], D(6), 16, nullptr, 0, A(5), D(5), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[13], D(5), 16, nullptr, 0, A(4), D(4), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[14], D(4), 16, nullptr, 0, A(3), D(3), st)) return e;                      // skip layer's hidden columns -> S3
-    if (int e = hidden_layer<16>(c, blob, L::START[15], D(3), 16, nullptr, 0, A(2), D(2), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[16], D(2), 16, nullptr, 0, A(1), D(1), st)) return e;
-    if (int e = hidden_layer<16>(c, blob, L::START[17], D(1), 16, nullptr, 0, A(0), D(0), st)) return e;
-#endif
     // weight gradients
     const int w7 = wgrad_workgroups(n_sub, 7, true), w2 = wgrad_workgroups(n_sub, 2, false), w1h = wgrad_workgroups(n_sub, 1, true),
               w1 = wgrad_workgroups(n_sub, 1, false);

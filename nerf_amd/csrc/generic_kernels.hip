@@ -59,18 +59,11 @@ DEVINL TileId tile_of(const GemmArgs& g) {
     const int64_t q = nwg / 8, r = nwg % 8, xcd = b % 8;
     const int64_t per_slice = (int64_t)g.tiles_m * g.tiles_n;
     TileId t;
-#ifdef GK_PLAIN_GRID                        // A/B build: the order of the former 3-D grid (M tile fastest, no XCD remap)
-    t.tz = b / per_slice;
-    t.tj = (b - t.tz * per_slice) / g.tiles_m;
-    t.ti = b - t.tz * per_slice - t.tj * g.tiles_m;
-    (void)q; (void)r; (void)xcd;
-#else
     const int64_t id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     t.tz = id / per_slice;
     const int64_t rem = id - t.tz * per_slice;
     if (g.tiles_m >= g.tiles_n) { t.ti = rem / g.tiles_n; t.tj = rem - t.ti * g.tiles_n; }
     else { t.tj = rem / g.tiles_m; t.ti = rem - t.tj * g.tiles_m; }
-#endif
     return t;
 }
 

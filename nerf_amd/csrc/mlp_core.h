@@ -8,16 +8,11 @@
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-// Ablation switches (diagnostic builds only: `make ablate`; results are wrong by construction, only timing matters)
-//   ABL_NOEPI  skip bias/ReLU/convert epilogues     ABL_NOPE    skip the sin/cos encodings
-//   ABL_NOBAR  no s_barrier in the chunk protocol    ABL_NOLDSA  A fragments not re-read from LDS
-//   ABL_NOGLDS no global_load_lds refills         ABL_NOVMWAIT no vmcnt wait at chunk boundaries
+// (The round-1..4 timing ablations -- builds without epilogues / encodings / barriers / LDS re-reads / ring refills / dump stores /
+// mask bits -- are retired: their results are in DESIGN.md section 3.2 and profiles/r0[1-4]_*; the switches left the sources in round 5.)
 // MLP_CLOCKPROBE: workgroup 0 overwrites output record 0 with (shader cycles, 100 MHz ticks) -- scripts/gpu_clockprobe.sh
 namespace {
 
-#ifndef MLP_DUMP_NT
-#define MLP_DUMP_NT 1        /* non-temporal stores for the training dumps (see store_global) */
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // precision policies
@@ -30,10 +25,7 @@ struct PBF16 {
     static constexpr int FRAG_BYTES = 1024;    // one A fragment: 32 rows x 16 k, bf16
     static constexpr int FPC = MLP_CHUNK_BYTES / FRAG_BYTES;
     using AReg = bf16x8;                       // one A fragment per lane (4 VGPRs)
-#ifndef MLP_DEPTH_BF16
-#define MLP_DEPTH_BF16 4
-#endif
-    static constexpr int DEPTH = MLP_DEPTH_BF16;   // A fragments prefetched LDS -> VGPR ahead of their MFMA
+    static constexpr int DEPTH = 4;               // A fragments prefetched LDS -> VGPR ahead of their MFMA
     static DEVINL AReg load_a(uint32_t frag_addr) { return *reinterpret_cast<const bf16x8*>(smem + frag_addr); }
     static DEVINL f32x16 mma(const AReg& a, const BReg& b, f32x16 acc) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
@@ -75,13 +67,9 @@ struct PBF16 {
     // training dump: one B register group of a subtile = a 64 x BREG_LDS/64-byte block in fragment order (lane-linear, coalesced)
     // The training dumps are written once and read a whole pass later, while the weight stream lives in the same L2: non-temporal
     // stores (same-box A/B at 16 384 rays: training forwards -6 %, dgrad chains -3...-6 %, the weight-gradient kernels that read the
-    // dumps next -2.5 %; -0.38 ms per step).  -DMLP_DUMP_NT=0 restores plain stores.
+    // dumps next -2.5 %; -0.38 ms per step).
     static DEVINL void store_global(char* block, int lane, const BReg& r) {
-#if MLP_DUMP_NT
         __builtin_nontemporal_store(__builtin_bit_cast(f32x4, r), reinterpret_cast<f32x4*>(block + lane * 16));
-#else
-        *reinterpret_cast<bf16x8*>(block + lane * 16) = r;
-#endif
     }
     static DEVINL BReg load_global(const char* block, int lane) { return *reinterpret_cast<const bf16x8*>(block + lane * 16); }
 };
@@ -98,12 +86,9 @@ struct PBF16W : PBF16 {
 // column tiles per wave (2 x 3 x 8 activation register groups = 192 VGPRs, 96 accumulators: 480 registers with everything else,
 // spill-free), so every A fragment read from LDS feeds three MFMAs and a chunk of the weight ring lasts 24 MFMAs instead of 16.
 // (Four column tiles crash hipcc's AGPR-copy rewrite pass under -amdgpu-mfma-vgpr-form and spill 57 registers without it.)
-#ifndef MLP_NARROW_NT
-#define MLP_NARROW_NT 3
-#endif
 struct PBF16N : PBF16 {
     static constexpr int NW = 4;
-    static constexpr int NT = MLP_NARROW_NT;
+    static constexpr int NT = 3;
 };
 
 struct PF32 {
@@ -152,13 +137,8 @@ struct PF32 {
     }
     static DEVINL void store_global(char* block, int lane, const BReg& r) {
         f32x4 lo = {r[0], r[1], r[2], r[3]}, hi = {r[4], r[5], r[6], r[7]};
-#if MLP_DUMP_NT
         __builtin_nontemporal_store(lo, reinterpret_cast<f32x4*>(block + lane * 16));
         __builtin_nontemporal_store(hi, reinterpret_cast<f32x4*>(block + 1024 + lane * 16));
-#else
-        *reinterpret_cast<f32x4*>(block + lane * 16) = lo;
-        *reinterpret_cast<f32x4*>(block + 1024 + lane * 16) = hi;
-#endif
     }
     static DEVINL BReg load_global(const char* block, int lane) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(block + lane * 16), hi = *reinterpret_cast<const f32x4*>(block + 1024 + lane * 16);
@@ -213,11 +193,7 @@ DEVINL bf16x8 f8_decode_group(uint32_t lo, uint32_t hi, uint32_t E) {
 // into the wave's LDS record `scale_rec` (lane-major, 16 bytes per lane), which f8_flush_scales writes out once the slot's 16 groups are in
 DEVINL void f8_store_group(char* sub_base, int kg, int lane, const u32x2& v, uint32_t E, uint32_t scale_rec) {
     u32x2* dst = reinterpret_cast<u32x2*>(sub_base + (kg >> 1) * 1024 + lane * 16 + (kg & 1) * 8);
-#if MLP_DUMP_NT
     __builtin_nontemporal_store(v, dst);
-#else
-    *dst = v;
-#endif
     *reinterpret_cast<unsigned char*>(smem + scale_rec + lane * 16 + kg) = (unsigned char)E;
 }
 DEVINL void f8_flush_scales(char* sub_base, int lane, uint32_t scale_rec) {
@@ -228,36 +204,12 @@ DEVINL void f8_flush_scales(char* sub_base, int lane, uint32_t scale_rec) {
 // ------------------------------------------------------------------------------------------------
 // weight stream: L2 -> LDS ring, consumed in lock step by all wavefronts of the workgroup
 // ------------------------------------------------------------------------------------------------
-// SAFE: wait for everything (vmcnt(0)) at every barrier instead of a counted wait.  It was the first form of the training kernels,
-// which also issue activation stores; it is not needed: VMEM loads return in order among themselves, so `vmcnt(N)` still proves that
-// all but the last N issued LOADS have landed -- stores in flight only add to the counter, i.e. make the wait stricter, never weaker.
-// Kept behind -DMLP_TRAIN_SAFE_STREAM=1 for A/B runs.
-#ifndef MLP_TRAIN_SAFE_STREAM
-#define MLP_TRAIN_SAFE_STREAM 0
-#endif
-
-// -DMLP_LEAN_RING=1 (A/B experiment, round 3): M0 declared clobbered instead of saved / restored around every LDS-DMA piece and the slot
-// counters wrapped with one AND -- 169 of the 1 111 non-MFMA instructions of a 256 x 256 layer's loop gone (4.34 -> 3.68 per MFMA).
-// Parity-clean; same box, alternated three times: fine kernel 53.60 / 53.70 / 53.95 ms against 53.57 / 53.80 / 54.12 ms -- nothing
-// (profiles/r03_lean_ring_ab.log), although an isolated wave pays 8 cycles for every instruction beyond three per MFMA
-// (scripts/mfma_probe.hip).  The chip is at its power limit on this kernel: time follows energy, and SALU instructions carry none.
-#ifndef MLP_LEAN_RING
-#define MLP_LEAN_RING 0
-#endif
-// STORES (round 4, -DMLP_STORE_AWARE=0 is the A side): the training forwards interleave their activation-dump stores with the ring's
-// LDS-DMA pieces, and on gfx9-class hardware stores count on vmcnt like loads and retire IN ORDER with them (hipcc itself emits
-// `vmcnt(2)` for load, store, store, use) -- so the counted wait `vmcnt(INFLIGHT)` at a chunk boundary also waits until all but INFLIGHT
-// of the wave's recent dump stores have reached memory: HBM write latency on the kernel's critical path every two chunks (the Ref-NeRF
-// training forward, with its 6-slot ring and `vmcnt(4)`, pays 2.1 ms of its 8.9 for its stores, profiles/r04_refnerf_fwd_nodumpstores_ab.log).
-// A store-aware count: the wait needs the pieces of chunk 2b+1 landed, which were issued NSLOT-3 boundaries ago; every VMEM operation
-// issued after them may stay in flight -- (NSLOT-4) chunks of pieces PLUS the dump stores issued since.  The wave counts its dump stores
-// (`note_store`, wave-uniform, folded by the compiler inside straight-line code) per issue interval -- the running interval and a one-byte
-// history of the NSLOT-4 before it: two SGPRs -- and waits with the largest immediate of a small ladder that does not exceed INFLIGHT + stores since.  Counting FEWER stores than were issued
-// (uncounted mask / aux stores, a 32-byte fp32 group that is two instructions) only makes the wait stricter, never weaker.
-#ifndef MLP_STORE_AWARE
-#define MLP_STORE_AWARE 0
-#endif
-template <class P, int NSLOT = MLP_NSLOT, bool SAFE = false, bool STORES = false>
+// The counted wait at a chunk boundary stays valid in the TRAINING kernels, which also issue dump stores: VMEM loads return in order among
+// themselves, so `vmcnt(N)` proves that all but the last N issued loads have landed; stores in flight only add to the counter (a
+// stricter wait, never a weaker one).  Retired experiments, logs under profiles/: a vmcnt(0) "safe" stream (round 2), M0 declared
+// clobbered + power-of-two slot wrap (r03_lean_ring_ab.log: 169 fewer SALU per layer, no time), a store-aware wait ladder
+// (r04_store_aware_wait_ab.log: the waves do not wait for their stores), explicit sched_group_barrier interleaves.
+template <class P, int NSLOT = MLP_NSLOT>
 struct WeightStream {
     static constexpr int LPW = (MLP_CHUNK_BYTES / 1024) / P::NW;     // 1 KiB glds pieces per wave per chunk
     const char* src;        // packed stream + this lane's offset inside a chunk
@@ -268,17 +220,6 @@ struct WeightStream {
     uint32_t cur_slot;
     uint32_t wave_lds;      // wave-uniform LDS offset of this wave's pieces inside a slot
     typename P::AReg q[P::DEPTH];   // A fragments f .. f+DEPTH-1 already in registers (f = next fragment to multiply)
-    static constexpr bool COUNT_STORES = STORES && !SAFE && P::NW <= 4 && MLP_STORE_AWARE;
-    static constexpr int NHIST = NSLOT - 4;     // complete issue intervals a wait looks back over (+ the running one)
-    static_assert(!COUNT_STORES || NHIST <= 4, "one byte per interval in a 32-bit history");
-    uint32_t st_cur;                // COUNT_STORES: dump stores this wave issued since its last issue() ...
-    uint32_t st_hist;               // ... and in the intervals before it, one byte each (byte 0 = the latest complete interval)
-    DEVINL void note_store(int n = 1) {
-#ifndef ABL_NODUMPST
-        if constexpr (COUNT_STORES) st_cur += n;
-#endif
-    }
-
     static DEVINL void dummy_sink(const bf16x8& d) { asm volatile("" ::"v"(d)); }
     template <class T> static DEVINL void dummy_sink(const T& d) { asm volatile("" ::"v"(d.lo), "v"(d.hi)); }
     DEVINL void issue() {
@@ -295,27 +236,14 @@ struct WeightStream {
         // does not pad inside inline asm), so it was dropped.)
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-#if !defined(ABL_NOGLDS) && MLP_LEAN_RING
-            // M0 is declared clobbered instead of saved and restored around every piece (2 of the 5 instructions of a piece): with one wave
-            // per SIMD every instruction beyond ~3 per MFMA costs 8 issue cycles (scripts/mfma_probe.hip)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g + i * 1024), "s"(dst + i * 1024) : "memory", "m0");
-#elif !defined(ABL_NOGLDS)
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
                          : "v"(g + i * 1024), "s"(dst + i * 1024)
                          : "memory");
-#else
-            asm volatile("" ::"v"(g), "s"(dst));
-#endif
         }
         load_idx = (load_idx + 1 == n_chunks) ? 0u : load_idx + 1;
-        if constexpr (MLP_LEAN_RING && (NSLOT & (NSLOT - 1)) == 0) load_slot = (load_slot + 1) & (NSLOT - 1);      // (one SALU instead of add / compare / select)
-        else load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
-        if constexpr (COUNT_STORES) {                  // (a count above 255 wraps DOWN: fewer stores counted = a stricter wait)
-            st_hist = (st_hist << 8) | (st_cur & 0xffu);
-            st_cur = 0;
-        }
+        load_slot = (load_slot + 1 == NSLOT) ? 0u : load_slot + 1;
     }
     // Synchronisation protocol (all code is branch-free; the only conditional instruction is the s_barrier itself):
     //   * chunk boundary i = the moment a wave's register prefetch enters chunk i.  At EVERY boundary a wave waits
@@ -332,7 +260,7 @@ struct WeightStream {
     //     wait, and NSLOT-4 chunks may stay in flight: issued before the wait at boundary 2b are chunks <= 2b+NSLOT-3, needed
     //     complete are chunks <= 2b+1 (read until barrier b+1).
     static constexpr bool TWO_GROUPS = P::NW > 4;
-    static constexpr int INFLIGHT = SAFE ? 0 : (TWO_GROUPS ? NSLOT - 5 : NSLOT - 4) * LPW;
+    static constexpr int INFLIGHT = (TWO_GROUPS ? NSLOT - 5 : NSLOT - 4) * LPW;
     uint32_t late;
 
     DEVINL void init(const void* packed, uint32_t nchunks) {
@@ -342,7 +270,6 @@ struct WeightStream {
         src = reinterpret_cast<const char*>(packed) + (size_t)wave * LPW * 1024 + lane * 16;
         wave_lds = wave * LPW * 1024;
         n_chunks = nchunks;
-        st_cur = 0; st_hist = 0;
         load_idx = 0; load_slot = 0;
         cur_slot = 0;
         cur = lane * 16;
@@ -368,52 +295,23 @@ struct WeightStream {
         const typename P::AReg a = q[F % P::DEPTH];
         constexpr int G = F + P::DEPTH;
         if (G % P::FPC == 0) {
-            if constexpr (MLP_LEAN_RING && (NSLOT & (NSLOT - 1)) == 0) cur_slot = (cur_slot + 1) & (NSLOT - 1);
-            else cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
+            cur_slot = (cur_slot + 1 == NSLOT) ? 0u : cur_slot + 1;
             cur = cur_slot * MLP_CHUNK_BYTES + lane_id() * 16;
             boundary<(G / P::FPC) & 1>();
         }
-#if defined(ABL_NOLDSA)
-#elif defined(ABL_HALFLDS)
-        if (F % 2 == 0) q[F % P::DEPTH] = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES);
-#elif defined(ABL_DUMMYLDS)
-        { const typename P::AReg d = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES); dummy_sink(d); }
-#else
         q[F % P::DEPTH] = P::load_a(cur + (G % P::FPC) * P::FRAG_BYTES);
-#endif
         return a;
     }
     template <int PARITY>
     DEVINL void boundary() {
-        if constexpr (!TWO_GROUPS && PARITY != 0 && !SAFE) { // single group, odd boundary: nothing to wait for, no barrier
+        if constexpr (!TWO_GROUPS && PARITY != 0) {          // single group, odd boundary: nothing to wait for, no barrier
             issue();
             return;
         }
-#ifndef ABL_NOVMWAIT
-        if constexpr (COUNT_STORES) {
-            // needed complete: the pieces issued NSLOT-3 issue() calls ago = the stores of the running interval + NSLOT-4 complete ones
-            uint32_t sum = st_cur;
-#pragma unroll
-            for (int k = 0; k < NHIST; ++k) sum += (st_hist >> (8 * k)) & 0xffu;
-            const uint32_t since = __builtin_amdgcn_readfirstlane(sum);
-            asm volatile("s_cmp_lt_u32 %0, 8\n\ts_cbranch_scc1 .Lw0%=\n\t"
-                         "s_cmp_lt_u32 %0, 16\n\ts_cbranch_scc1 .Lw8%=\n\t"
-                         "s_cmp_lt_u32 %0, 24\n\ts_cbranch_scc1 .Lw16%=\n\t"
-                         "s_waitcnt vmcnt(%4)\n\ts_branch .Lwe%=\n"
-                         ".Lw16%=:\n\ts_waitcnt vmcnt(%3)\n\ts_branch .Lwe%=\n"
-                         ".Lw8%=:\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Lwe%=\n"
-                         ".Lw0%=:\n\ts_waitcnt vmcnt(%1)\n"
-                         ".Lwe%=:"
-                         ::"s"(since), "n"(INFLIGHT), "n"(INFLIGHT + 8), "n"(INFLIGHT + 16), "n"(INFLIGHT + 24) : "memory", "scc");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-        }
-#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         // s_barrier only when this boundary's parity is mine; the branch lives inside the asm so that the compiler
         // sees straight-line code (a C++ `if` here splits every feature block into many basic blocks and spills)
-#ifndef ABL_NOBAR
         asm volatile("s_cmp_lg_u32 %0, %1\n\ts_cbranch_scc1 .Lnobar%=\n\ts_barrier\n.Lnobar%=:" ::"s"(__builtin_amdgcn_readfirstlane(late)), "n"(PARITY) : "memory", "scc");
-#endif
         issue();
     }
     // End of kernel: the early waves ran one barrier more (barrier 0 at init); the late waves supply its partner here.
@@ -458,12 +356,6 @@ template <int S> struct IC { static constexpr int value = S; };
 // accumulators 8*half .. 8*half+7 of a feature block -> the B register group they form for the next layer
 template <class P, bool RELU>
 DEVINL typename P::BReg to_breg_half(const f32x16& acc, int half) {
-#ifdef ABL_NOEPI
-    if constexpr (sizeof(typename P::BReg) == 16) {
-        f32x4 l = {acc[8 * half], acc[8 * half + 1], acc[8 * half + 2], acc[8 * half + 3]};
-        return __builtin_bit_cast(typename P::BReg, l);
-    }
-#endif
     return P::template from_acc<RELU>(acc, 8 * half);
 }
 
@@ -530,15 +422,6 @@ DEVINL void pair_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], f32x16 
 #pragma unroll
         for (int t = 0; t < P::NT; ++t) acc1[t] = P::template mma_pos<POS>(a1, b[t], acc1[t]);
         emit_step<NKG, KG>(prev);
-#ifdef MLP_SCHED_GROUPS                                           // A/B experiment: ask the scheduler for an explicit MFMA / LDS / VALU / SALU interleave per K step
-#pragma unroll
-        for (int q = 0; q < 2 * P::NT; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, MLP_SCHED_GROUPS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
-        }
-#endif
         if constexpr (MORE && KG == (NKG > 3 ? NKG - 3 : 0)) {  // next group's bias: read late (short live range), the
             nb[0] = load_bias(next_bias);                         // latency is covered by the last MFMAs of this pair
             nb[1] = load_bias(next_bias + 128);
@@ -567,26 +450,32 @@ DEVINL void single_k(WS& ws, f32x16 (&acc0)[P::NT], f32x16 (&acc1)[P::NT], InF& 
 template <class T, class = void> struct has_group_hook { static constexpr bool value = false; };
 template <class T> struct has_group_hook<T, decltype(void(static_cast<T*>(nullptr)->begin_group(0)))> { static constexpr bool value = true; };
 
-template <class P, int NKG, int NFB, int START, int G, class WS, class InF, class OutF, class Prev>
+// ZB (round 5): a layer WITHOUT a bias -- every layer of the backward chains (W^T delta).  The accumulators start from the literal zero
+// (the MFMA's C operand becomes the inline constant 0) instead of from a "bias" of zeros read from LDS: no 2 x 16 bias registers per
+// pending feature-block pair (the chains ran at 503-512 registers and spilled 16-65 of them), no 8 ds_read_b128 and 32 v_mov per pair.
+template <class P, int NKG, int NFB, int START, int G, bool ZB, class WS, class InF, class OutF, class Prev>
 DEVINL auto dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, OutF& out, const Prev& prev) {
     static_assert(2 * G < NFB, "group index");
     constexpr int FRAG0 = START + 2 * G * NKG;
+    constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if constexpr (has_group_hook<OutF>::value) out.begin_group(G);
     if constexpr (2 * G + 1 < NFB) {
         Deferred<P, 2 * G, 2> d;
 #pragma unroll
-        for (int t = 0; t < P::NT; ++t) { d.acc[0][t] = cb[0]; d.acc[1][t] = cb[1]; }
+        for (int t = 0; t < P::NT; ++t) {
+            if constexpr (ZB) { d.acc[0][t] = zero; d.acc[1][t] = zero; }
+            else { d.acc[0][t] = cb[0]; d.acc[1][t] = cb[1]; }
+        }
         f32x16 nb[2];
         constexpr bool MORE = 2 * (G + 1) < NFB;
-        pair_k<P, NKG, FRAG0, 0, MORE>(ws, d.acc[0], d.acc[1], nb, bias_lane + 256 * (G + 1), in, prev);
-        if constexpr (MORE) return dense_group<P, NKG, NFB, START, G + 1>(ws, bias_lane, nb, in, out, prev_of(d, out));
+        pair_k<P, NKG, FRAG0, 0, MORE && !ZB>(ws, d.acc[0], d.acc[1], nb, bias_lane + 256 * (G + 1), in, prev);
+        if constexpr (MORE) return dense_group<P, NKG, NFB, START, G + 1, ZB>(ws, bias_lane, nb, in, out, prev_of(d, out));
         else return d;
     } else {
-        constexpr f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         Deferred<P, 2 * G, 1> d;
         f32x16 acc1[P::NT];
 #pragma unroll
-        for (int t = 0; t < P::NT; ++t) { d.acc[0][t] = cb[0]; acc1[t] = zero; }
+        for (int t = 0; t < P::NT; ++t) { if constexpr (ZB) d.acc[0][t] = zero; else d.acc[0][t] = cb[0]; acc1[t] = zero; }
         single_k<P, NKG, FRAG0, 0>(ws, d.acc[0], acc1, in, prev);
 #pragma unroll
         for (int t = 0; t < P::NT; ++t)
@@ -595,14 +484,16 @@ DEVINL auto dense_group(WS& ws, uint32_t bias_lane, f32x16 (&cb)[2], InF& in, Ou
         return d;
     }
 }
-template <class P, int NKG, int NFB, int START, class WS, class InF, class OutF, class Prev>
+template <class P, int NKG, int NFB, int START, bool ZB = false, class WS, class InF, class OutF, class Prev>
 DEVINL auto dense(WS& ws, uint32_t bias_lds, InF&& in, OutF&& out, const Prev& prev) {
     static_assert(START % P::DEPTH == 0 && (NKG * NFB) % P::DEPTH == 0, "layers must start on a prefetch-queue boundary");
     const uint32_t bias_lane = bias_lds + 16 * (lane_id() >> 5);
     f32x16 cb[2];
-    cb[0] = load_bias(bias_lane);
-    if constexpr (NFB > 1) cb[1] = load_bias(bias_lane + 128);
-    return dense_group<P, NKG, NFB, START, 0>(ws, bias_lane, cb, in, out, prev);
+    if constexpr (!ZB) {
+        cb[0] = load_bias(bias_lane);
+        if constexpr (NFB > 1) cb[1] = load_bias(bias_lane + 128);
+    }
+    return dense_group<P, NKG, NFB, START, 0, ZB>(ws, bias_lane, cb, in, out, prev);
 }
 
 }  // namespace

@@ -59,9 +59,6 @@ DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG])
 #pragma unroll
     for (int q = 0; q < 8 * NKG; ++q) {
         float v;
-#ifdef ABL_NOPE
-        if (q < 3 * L) { v = (q % 3 == 0) ? x : ((q % 3 == 1) ? y : z); } else
-#endif
         if (q < 3 * L) {
             const int c = q % 3;
             const float comp = (c == 0) ? x : ((c == 1) ? y : z);
@@ -85,11 +82,8 @@ DEVINL void encode(float x, float y, float z, int h, typename P::BReg (&B)[NKG])
 // sin-type group S and the cos-type group C of that one sample come out of the one sincos chain it runs anyway -- and one
 // v_permlane32_swap per packed dword (upper half of S <-> lower half of C) leaves S = tile 0's registers and C = tile 1's registers in
 // B-operand layout.  Same values bit for bit; half the prologue's fetch / Philox / reduction / doubling instructions per tile.
-// -DMLP_PAIRED_PROLOGUE=0 restores the plain prologue (A/B).
+// (A/B against the plain prologue: profiles/r04_paired_prologue_ab.log.)
 // ------------------------------------------------------------------------------------------------
-#ifndef MLP_PAIRED_PROLOGUE
-#define MLP_PAIRED_PROLOGUE 1
-#endif
 // a = [a.lo | b.lo], b = [a.hi | b.hi]   (lo / hi = lanes 0..31 / 32..63)
 DEVINL void half_swap(uint32_t& a, uint32_t& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -279,9 +273,6 @@ struct ActDump {
 };
 template <class P>
 DEVINL void dump_breg(const ActDump& d, int layer, int64_t subtile, int kg, int lane, const typename P::BReg& r) {
-#ifdef ABL_NODUMPST                                          // timing ablation: the training forward without its activation stores
-    if constexpr (sizeof(typename P::BReg) == 16) { asm volatile("" ::"v"(r)); return; }
-#endif
     P::store_global(d.base + (size_t)layer * d.layer_stride + ((size_t)subtile * 16 + kg) * (size_t)P::BREG_LDS, lane, r);
 }
 
@@ -330,9 +321,6 @@ DEVINL uint32_t breg_bits(const f32x8& v) {
 }
 template <class P>
 DEVINL void mask_or(uint32_t acc_wave, int layer, int t, int kg, int lane, const typename P::BReg& v) {
-#ifdef ABL_NOMASK                                            // timing ablation: no ReLU bit masks (the backward then reads garbage)
-    return;
-#endif
     unsigned* w = reinterpret_cast<unsigned*>(smem + acc_wave + ((layer & 1) * P::NT + t) * 1024 + lane * 16 + (kg >> 2) * 4);
     __hip_atomic_fetch_or(w, breg_bits(v) << (4 * (kg & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -367,7 +355,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN, TRAIN> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -379,26 +367,15 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
     const uint32_t sacc = lds_scaleacc<P>() + wave * 2 * NT * 1024;     // F8: this wave's scale-exponent records
     if constexpr (TRAIN) mask_acc_init<P>(macc, lane);
 
-#ifdef MLP_PHASEPROBE
-    // diagnostic build: shader cycles of wave 0 of workgroup 0 per tile phase (fetch + encode | layer 0 | layers 1-3 | head + store)
-    uint64_t ph[5] = {0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
-#define PHASE_MARK(i) { const uint64_t now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_t; ph_t = now_; }
-#else
-#define PHASE_MARK(i)
-#endif
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int64_t m[NT];
         BReg enc[NT][4];
-        if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE) {
+        if constexpr (NT == 2 && P::FAST_PE) {
             // paired prologue: lane (j, h) fetches and encodes sample j of column tile h for BOTH halves, then the halves trade
             m[0] = tile * TS + (wave * NT) * 32 + j;
             m[1] = m[0] + 32;
             const int64_t mo = h ? m[1] : m[0];
             const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, false);
-#ifdef MLP_PHASEPROBE
-            asm volatile("" ::"v"(sm.x), "v"(sm.y), "v"(sm.z));
-            PHASE_MARK(4)
-#endif
             encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
             half_swap_groups<4>(enc[0], enc[1]);
             if constexpr (TRAIN) {
@@ -412,10 +389,6 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         for (int t = 0; t < NT; ++t) {
             m[t] = tile * TS + (wave * NT + t) * 32 + j;
             const Sample sm = fetch_sample(s, m[t] < s.M ? m[t] : s.M - 1, false);
-#ifdef MLP_PHASEPROBE
-            asm volatile("" ::"v"(sm.x), "v"(sm.y), "v"(sm.z));       // the position is complete here (loads returned)
-            PHASE_MARK(4)
-#endif
             encode<P, 10, 4>(sm.x, sm.y, sm.z, h, enc[t]);
             if constexpr (TRAIN) {                           // the first-layer weight gradient's operand: slot 4, K groups 0..3
 #pragma unroll
@@ -432,7 +405,6 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_hidden<P, F8>(dump, sacc, layer, sub0 + t, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
-                if constexpr (!F8) ws.note_store();              // (store-aware ring wait, mlp_core.h WeightStream)
                 mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
             }
         };
@@ -443,10 +415,8 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
         auto IN_A = [&](int kg, int t) -> BReg { return a[t][kg]; };
         // d = the last feature-block pair of a layer (features 192..255 = K groups 12..15 of the next one), converted
         // into `a` during the first K steps of whatever runs next
-        PHASE_MARK(0)
         Deferred<P, 6, 2> d = dense<P, 4, 8, L::START[0]>(ws, bias0 + L::BIAS_OFF[0] * 4,
             [&](int kg, int t) -> BReg { return enc[t][kg]; }, OA, NoPrev{});
-        PHASE_MARK(1)
         // layers.2/4/6 ping-pong between the two register buffers (a -> b -> a -> b): no copies; the two a->b layers
         // share one code instance through the loop (same chunk parity, asserted)
         static_assert(L::START[1] % (2 * FPC) == L::START[3] % (2 * FPC), "chunk parity");
@@ -463,7 +433,6 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
             }
         }
         lay_pend = lay;
-        PHASE_MARK(2)
         float dens[NT];
         auto OH = [&](int, int t, const f32x16& acc, int half) { if (half == 0) dens[t] = acc[0]; };
         dense<P, 16, 1, L::START[4]>(ws, bias0 + L::BIAS_OFF[4] * 4, IN_B, OH, prev_of(d, OB_pend)).flush(OH);
@@ -471,14 +440,8 @@ __global__ __launch_bounds__(P::NW * 64) void proposal_kernel(const void* __rest
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (h == 0 && m[t] < s.M) density[m[t]] = dens[t];
-        PHASE_MARK(3)
     }
     ws.drain();
-#ifdef MLP_PHASEPROBE
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 5; ++i) reinterpret_cast<uint64_t*>(density)[i] = ph[i];
-#endif
-#undef PHASE_MARK
 }
 
 // ================================================================================================
@@ -511,7 +474,7 @@ __global__ __launch_bounds__(P::NW * 64) void proposal128_kernel(const void* __r
         Deferred<P, HFB - 2, 2> d;
         {
             BReg enc[NT][4];
-            constexpr int PAIRED = (MLP_PAIRED_PROLOGUE && NT >= 2 && P::FAST_PE) ? 2 : 0;       // column tiles 0 and 1 through the paired prologue
+            constexpr int PAIRED = (NT >= 2 && P::FAST_PE) ? 2 : 0;       // column tiles 0 and 1 through the paired prologue
 #pragma unroll
             for (int t = 0; t < NT; ++t) m[t] = tile * TS + (wave * NT + t) * 32 + j;
             if constexpr (PAIRED) {
@@ -570,7 +533,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
 #endif
     if constexpr (FUSED) { if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + lds_tile<P>() + P::NW * P::NT * 32 * 32 + P::NW * P::NT * 8)[threadIdx.x] = 0u; }  // ray tickets
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS);
-    WeightStream<P, MLP_NSLOT, MLP_TRAIN_SAFE_STREAM && TRAIN, TRAIN> ws;
+    WeightStream<P, MLP_NSLOT> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -596,7 +559,6 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             buf[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_hidden<P, F8>(dump, sacc, layer, sub0 + t, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
-                if constexpr (!F8) ws.note_store();              // (store-aware ring wait, mlp_core.h WeightStream)
                 mask_or<P>(macc, layer, t, 2 * fb + half, lane, buf[t][2 * fb + half]);
             }
         };
@@ -610,7 +572,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
         Deferred<P, 6, 2> d;
         {
             BReg enc[NT][4];
-            if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE && !IPE && !FUSED) {
+            if constexpr (NT == 2 && P::FAST_PE && !IPE && !FUSED) {
                 // paired prologue (see encode_pair): lane (j, h) fetches and encodes sample j of column tile h, the halves then trade
                 m[0] = tile * TS + (wave * NT) * 32 + j;
                 m[1] = m[0] + 32;
@@ -723,7 +685,6 @@ __global__ __launch_bounds__(P::NW * 64) void mip_kernel(const void* __restrict_
             c[t][2 * fb + half] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {                                                                       // slot 7: rgb_layer.0 output
                 dump_hidden<P, F8>(dump, sacc, 7, sub0 + t, t, 2 * fb + half, lane, c[t][2 * fb + half]);
-                if constexpr (!F8) ws.note_store();
                 mask_or<P>(macc, 7, t, 2 * fb + half, lane, c[t][2 * fb + half]);
             }
         };
@@ -893,7 +854,7 @@ __global__ __launch_bounds__(P::NW * 64) void mip128_kernel(const void* __restri
             BReg enc[NT][4];
 #pragma unroll
             for (int t = 0; t < NT; ++t) m[t] = tile * TS + (wave * NT + t) * 32 + j;
-            if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE) {
+            if constexpr (NT == 2 && P::FAST_PE) {
                 const int64_t mo = h ? m[1] : m[0];
                 const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, true);
                 encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
@@ -1022,7 +983,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS, REF_LDS_BIAS);
     const float* ide_mat = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + L::stream_bytes(P::PREC)) + L::N_BIAS;
-    WeightStream<P, MLP_NSLOT_REF, false, TRAIN> ws;
+    WeightStream<P, MLP_NSLOT_REF> ws;
     ws.init(packed, L::N_FRAGS / FPC);
     const int lane = lane_id(), h = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (wave-uniform: lets address arithmetic on it run on the scalar unit)
@@ -1053,7 +1014,6 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
             buf[t][kg] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_breg<P>(dump, layer, sub0 + t, kg, lane, buf[t][kg]);
-                ws.note_store();                                   // (store-aware ring wait, mlp_core.h WeightStream)
                 mreg[t] |= breg_bits(buf[t][kg]) << (4 * (kg & 3));
                 if ((kg & 3) == 3) {
                     *reinterpret_cast<uint32_t*>(dump.mask_base + (size_t)layer * dump.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16 + (kg >> 2) * 4) = mreg[t];
@@ -1072,7 +1032,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
             BReg enc[NT][4];
 #pragma unroll
             for (int t = 0; t < NT; ++t) m[t] = tile * TS + (wave * NT + t) * 32 + j;
-            if constexpr (MLP_PAIRED_PROLOGUE && NT == 2 && P::FAST_PE) {        // paired prologue (see encode_pair)
+            if constexpr (NT == 2 && P::FAST_PE) {        // paired prologue (see encode_pair)
                 const int64_t mo = h ? m[1] : m[0];
                 const Sample sm = fetch_sample(s, mo < s.M ? mo : s.M - 1, true);
                 encode_pair<P, 10, 4>(sm.x, sm.y, sm.z, enc[0], enc[1]);
@@ -1272,11 +1232,7 @@ const ActDump NO_DUMP{nullptr, 0ull, nullptr, 0ull};
 
 // bf16 policy of the shipped library: the wide tile (measured 2.5 % faster end to end);
 // -DMLP_BF16_NARROW selects the 8-wave x 32-sample tile for A/B runs
-#ifdef MLP_BF16_NARROW
-using PB16 = PBF16;
-#else
 using PB16 = PBF16W;
-#endif
 
 }  // namespace
 
@@ -1287,9 +1243,6 @@ using PB16 = PBF16W;
 #endif
 #if MLP_TU == 0 || MLP_TU == 1
 int mlp_launch_proposal(const void* packed, int precision, const nerf_amd_samples& s, float* density, hipStream_t st) {
-#ifdef MLP_PROP_NARROW                                   // A/B knob: the 8-wave x 32-sample tile for the (inference) proposal kernel only
-    if (precision == NERF_AMD_BF16) return launch<PBF16, PropLayout>(proposal_kernel<PBF16, false>, packed, s, density, st, NO_DUMP);
-#endif
     if (precision == NERF_AMD_BF16) return launch<PB16, PropLayout>(proposal_kernel<PB16, false>, packed, s, density, st, NO_DUMP);
     return launch<PF32, PropLayout>(proposal_kernel<PF32, false>, packed, s, density, st, NO_DUMP);
 }
@@ -1409,9 +1362,7 @@ int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_sampl
     // ISSUE slots (~80 cycles of the vector-memory path each, during which a lone wave per SIMD issues no MFMA; not a wait: the store-aware
     // ring wait changed nothing, mlp_core.h), which a second wave per SIMD fills: 9.01 -> 8.38 ms per 2^14-ray step, same box, alternated
     // twice (profiles/r04_ref_train_fwd_8wave_ab.log); the dump layout does not depend on the tile policy.  -DREF_TRAIN_WIDE = the A side.
-#ifndef REF_TRAIN_WIDE
     if (precision == NERF_AMD_BF16) return launch_ref<PBF16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
-#endif
     if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
     return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
 }

@@ -1872,7 +1872,8 @@ def test_generic_route_draws_the_fused_kernels_philox_streams(A):
         assert torch.equal(a, b) and not torch.equal(a, c)
         torch.manual_seed(11)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        rays = A.ops.generate_rays(pose[:3], 100, 100, focal, focal, pose.device)
+        fx, fy = (float(focal[1]), float(focal[0])) if isinstance(focal, (tuple, list)) else (float(focal), float(focal))
+        rays = A.ops.generate_rays(pose[:3], 100, 100, fx, fy, pose.device)
         rays = rays.view(100, 100, 6).reshape(2, 50, 2, 50, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6).contiguous()
         z_base = torch.linspace(NEAR, FAR, 64).cuda()
         u1, u2 = A.ops.philox_stream((10000, 64), seed, 0, strat=True), A.ops.philox_stream((10000, 65), seed, 0)
