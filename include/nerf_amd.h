@@ -382,6 +382,19 @@ int    nerf_amd_mip_weight_grads(int precision, int64_t M, const void* act_dump,
  *   packed_bwd: nerf_amd_pack_weights_backward(NERF_AMD_NET_REF, ...) with the 20 tensors of nerf_amd_pack_weights. */
 int    nerf_amd_ref_forward_train_dump(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, const float* bn_noise,
                                        float* rgbo, float* normal, void* dump, float* aux, void* stream);
+/* (ABI 122) The same with the bottle-neck perturbation (ref_model.py:84-85, `spa_info_b + torch.normal(0, w, shape)`) drawn INSIDE the
+ * kernel: N(0, noise_std) deviates from Philox4x32-10 + Box-Muller keyed by (noise_seed -- or *noise_seed_dev, read at run time so that a
+ * captured hipGraph replays fresh noise --, sample index): no (M, 128) noise tensor is written and read back (1.6 GB and one launch per
+ * 2^14-ray step).  nerf_amd_philox_normal materialises exactly those deviates as out (M, 128) for samples sample_offset .. + M - 1
+ * (nerf_amd_ref_forward_train_dump with that tensor gives bit-identical outputs). */
+int    nerf_amd_ref_forward_train_dump_rng(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, uint64_t noise_seed,
+                                           const uint64_t* noise_seed_dev, float noise_std, float* rgbo, float* normal, void* dump, float* aux,
+                                           void* stream);
+int    nerf_amd_philox_normal(float* out, int64_t M, uint64_t rng_seed, const uint64_t* seed_dev, float std, int64_t sample_offset, void* stream);
+/* NERF_AMD_CONTRACTED OR-ed into `net` of nerf_amd_density_grad (round 5): the training forward fetched its samples with
+ * nerf_amd_samples.contract = 1 -- x are the UNcontracted positions; the encoding's derivative is taken at contract(x) and pulled back
+ * through the contraction's Jacobian, so the result is still d density / d x. */
+#define NERF_AMD_CONTRACTED 0x100
 size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M);
 int    nerf_amd_density_grad(int net, const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* x, int x_stride,
                              const float* scale, int scale_stride, float* grad, void* workspace, void* stream);
@@ -395,7 +408,7 @@ int    nerf_amd_adam_step(float* const* params, const float* const* grads, float
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the sampling / compositing rows (what torch.autograd computes for train.py:169-199).
- * One wavefront per ray; S <= 256.  Depths and directions are not differentiated (the reference detaches them too).
+ * One wavefront per ray; S <= 1024 (4, 8 or 16 register chunks of 64 samples, picked by S).  Depths and directions are not differentiated (the reference detaches them too).
  * ------------------------------------------------------------------------------------------------ */
 /* d(get_weights)/d(density) (addtional.py:100-107, nerf_base.py:80-86): d_weights (N,S) -> d_sigma (N,S). */
 int nerf_amd_sigma_to_weights_backward(const float* sigma, const float* z, const float* dirs, int64_t N, int S, int act,

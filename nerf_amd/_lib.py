@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so
 
 F32, BF16 = 0, 1
 BF16_F8 = 2            # NERF_AMD_BF16_F8: bf16 arithmetic, training dumps of the hidden layers in scaled e4m3 (training entry points only)
-EXPECTED_VERSION = 121  # nerf_amd_version() of the library these signatures were written against
+EXPECTED_VERSION = 122  # nerf_amd_version() of the library these signatures were written against
 NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, NET_MIP_128 = 0, 1, 2, 3, 4
 FINE_W128 = 0x200     # layout flag: the fine-network blob is a NET_MIP_128 blob
 PROP_W128 = 0x100     # layout flag OR-ed into `precision`: packed_prop is a NET_PROPOSAL_128 blob
@@ -97,6 +97,9 @@ SIGNATURES = {
     "nerf_amd_mip_weight_grads": (C.c_int, [C.c_int, i64, c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void),
                                            C.POINTER(c_void), c_void, c_void]),
     "nerf_amd_ref_forward_train_dump": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_ref_forward_train_dump_rng": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, C.c_uint64, c_void, C.c_float, c_void, c_void, c_void,
+                                                      c_void, c_void]),
+    "nerf_amd_philox_normal": (C.c_int, [c_void, i64, C.c_uint64, c_void, C.c_float, i64, c_void]),
     "nerf_amd_density_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, i64]),
     "nerf_amd_density_grad": (C.c_int, [C.c_int, c_void, C.c_int, i64, c_void, c_void, C.c_int, c_void, C.c_int, c_void, c_void, c_void]),
     "nerf_amd_ref_backward_workspace_bytes": (C.c_size_t, [C.c_int, i64]),

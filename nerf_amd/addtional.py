@@ -148,16 +148,12 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
                     raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
                 if "bwd_blob" not in held:
                     held["bwd_blob"] = self.packed_backward(prec)
-                if ab._VJP.inputs_only:
-                    if contract:
-                        raise NotImplementedError("nerf_amd: density-gradient normals of contracted positions are not built")
-                    gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1))
+                if ab._VJP.inputs_only:                                  # (contracted positions: through the contraction's Jacobian, round 5)
+                    gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1), contract=contract)
                     return (gx.view(p.shape), *[None] * len(wb))
                 gx = None
                 if ab.POSITION_GRADS and want_pos:                       # d loss / d pts as well (autograd_bridge.POSITION_GRADS)
-                    if contract:
-                        raise NotImplementedError("nerf_amd: position gradients of contracted positions are not built")
-                    gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1)).view(p.shape)
+                    gx = ops.density_grad(ops.NET_PROPOSAL, held["bwd_blob"], prec, held["dump"], p.reshape(-1, 3), scale=g.reshape(-1), contract=contract).view(p.shape)
                 sinks = self.grad_sinks()                                # persistent flat gradient buffer (parallel.FlatGradients)?
                 direct = sinks is not None and sinks[2]
                 kw = wb[:5]

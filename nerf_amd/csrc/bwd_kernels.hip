@@ -574,6 +574,39 @@ __global__ __launch_bounds__(256) void pe_grad_kernel(const float* __restrict__ 
         out[i] = scale ? acc * scale[m * scale_stride] : acc;
     }
 }
+// The same for positions that went through the Mip-NeRF 360 contraction before the encoding (mlp_kernels.hip contract_position; round 5):
+// the encoding's derivative is taken at c(x) and pulled back through the contraction's Jacobian -- for r = |x| > 1, u = x / r,
+// c(x) = (2 - 1/r) u and J = (2 - 1/r) / r (I - u u^T) + u u^T / r^2 (symmetric); J = I inside the unit ball.  One thread per sample.
+__global__ __launch_bounds__(256) void pe_grad_contract_kernel(const float* __restrict__ d_enc, int ld, const float* __restrict__ x, int x_stride,
+                                                               const float* __restrict__ scale, int scale_stride, int64_t M, int L, float* __restrict__ out) {
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+        const float x0 = x[m * x_stride], x1 = x[m * x_stride + 1], x2 = x[m * x_stride + 2];
+        const float r = norm3(x0, x1, x2);
+        const float k = r > 1.0f ? (2.0f - 1.0f / r) / r : 1.0f;
+        const float cx[3] = {x0 * k, x1 * k, x2 * k};
+        const float* d = d_enc + m * ld;
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = d[c];
+            for (int f = 0; f < L; ++f) {
+                const float fr = (float)(1 << f), a = cx[c] * fr;
+                float sn, cs;
+                sincos_quadrant(a, sn, cs);
+                acc += fr * (cs * d[3 + 6 * f + c] - sn * d[3 + 6 * f + 3 + c]);
+            }
+            g[c] = acc;
+        }
+        if (r > 1.0f) {
+            const float u0 = x0 / r, u1 = x1 / r, u2 = x2 / r;
+            const float ug = (u0 * g[0] + u1 * g[1]) + u2 * g[2];
+            const float t = ug * (1.0f / (r * r) - k);               // J g = k g + (1/r^2 - k) (u.g) u
+            g[0] = k * g[0] + t * u0; g[1] = k * g[1] + t * u1; g[2] = k * g[2] + t * u2;
+        }
+        const float sc = scale ? scale[m * scale_stride] : 1.0f;
+        out[m * 3] = g[0] * sc; out[m * 3 + 1] = g[1] * sc; out[m * 3 + 2] = g[2] * sc;
+    }
+}
 
 // Ref-NeRF, stage 1 of the parameter backward: the spec head's delta.  rgb = f(sigmoid(spec) sigmoid(tint) + sigmoid(diffuse - c))
 // (ref_model.py:98-105; f = identity, c = 0, or with use_srgb f = linear_to_srgb, c = log 3): d spec_raw = g_rgb f' sigmoid(tint) sigmoid'(spec),
@@ -583,16 +616,23 @@ DEVINL float ref_rgb_slope(const float* ax, int c, int srgb) {            // f'(
     return srgb_slope(sigmoid_f(ax[11 + c]) * sigmoid_f(ax[8 + c]) + sigmoid_f(ax[4 + c] - SRGB_LOG3));
 }
 template <int ELEM>
-__global__ __launch_bounds__(256) void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, int64_t M, char* __restrict__ frag,
-                                      unsigned long long sub_stride, int srgb) {
-    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
-        const float* ax = aux + m * 16;
+__global__ __launch_bounds__(256) void ref_spec_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, int64_t M, int64_t Mpad,
+                                      char* __restrict__ frag, unsigned long long sub_stride, int srgb) {
+    // every element of the K group is written -- slot features 3..15 and the padding samples M .. Mpad-1 of the last tile as zeros -- so the
+    // slot needs no memset (round 4 zeroed the whole 1.6 GB slot first: 0.24 ms per 2^14-ray step)
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < Mpad; m += (int64_t)gridDim.x * blockDim.x) {
         char* block = frag + (size_t)(m >> 5) * sub_stride;
+        float v[3] = {0.0f, 0.0f, 0.0f};
+        if (m < M) {
+            const float* ax = aux + m * 16;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float sp = sigmoid_f(ax[11 + c]);
-            store_slot_feature<ELEM>(block, (int)(m & 31), c, (g_out[m * g_stride + c] * ref_rgb_slope(ax, c, srgb)) * sigmoid_f(ax[8 + c]) * (sp * (1.0f - sp)));
+            for (int c = 0; c < 3; ++c) {
+                const float sp = sigmoid_f(ax[11 + c]);
+                v[c] = (g_out[m * g_stride + c] * ref_rgb_slope(ax, c, srgb)) * sigmoid_f(ax[8 + c]) * (sp * (1.0f - sp));
+            }
         }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) store_slot_feature<ELEM>(block, (int)(m & 31), f, f < 3 ? v[f] : 0.0f);
     }
 }
 
@@ -604,12 +644,18 @@ __global__ __launch_bounds__(256) void ref_spec_delta_kernel(const float* __rest
 // IDE backward (ref_func.py:76-108): out_t = (x + i y)^m P_t(z) exp(-sigma_l k), P_t(z) = sum_k mat[k][t] z^k, sigma_l = l (l + 1) / 2.
 template <int ELEM>
 __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __restrict__ g_out, int g_stride, const float* __restrict__ aux, const float* __restrict__ d_allin, int ld,
-                                       const float* __restrict__ dirs, int dir_stride, const float* __restrict__ mat, int64_t M,
+                                       const float* __restrict__ dirs, int dir_stride, const float* __restrict__ mat, int64_t M, int64_t Mpad,
                                        char* __restrict__ frag, unsigned long long sub_stride, int srgb) {
     constexpr int TM[19] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 6, 7, 8};
     constexpr int TL[19] = {1, 1, 2, 2, 2, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
     constexpr int BREG = ELEM == 2 ? 1024 : 2048;
-    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < Mpad; m += (int64_t)gridDim.x * blockDim.x) {
+        if (m >= M) {                                        // padding samples of the last tile: zero deltas (the slot is not memset any more)
+            char* sub = frag + (size_t)(m >> 5) * sub_stride;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) store_slot_feature<ELEM>(sub + 8 * BREG, (int)(m & 31), f, 0.0f);
+            continue;
+        }
         const float* ax = aux + m * 16;
         const float* da = d_allin + m * ld;
         const float* g = g_out + m * g_stride;
@@ -683,13 +729,15 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
     // -- the lane's 8 features of its sample are two aligned float4 reads of the row and ONE 16-byte slot of the fragment block, so a wave
     // writes 1 KiB contiguously (it was 128 strided scalar reads and 128 two-byte scattered stores per sample inside the loop above:
     // 1.7 ms per 2^14-ray step).
-    const int64_t n_items = ((M + 31) / 32) * 8 * 64;
+    const int64_t n_items = (Mpad / 32) * 8 * 64;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63), kg = (int)((i >> 6) & 7);
         const int64_t sb = i >> 9, m = sb * 32 + (lane & 31);
-        if (m >= M) continue;
-        const float* da = d_allin + m * ld + 16 * kg + 4 * (lane >> 5);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(da), hi = *reinterpret_cast<const f32x4*>(da + 8);
+        f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = lo;
+        if (m < M) {
+            const float* da = d_allin + m * ld + 16 * kg + 4 * (lane >> 5);
+            lo = *reinterpret_cast<const f32x4*>(da); hi = *reinterpret_cast<const f32x4*>(da + 8);
+        }
         char* blk = frag + (size_t)sb * sub_stride + (size_t)kg * BREG;
         if (ELEM == 2) {
             bf16x8 v;
@@ -1611,14 +1659,15 @@ size_t bwd_density_grad_workspace_bytes(int precision, int64_t M) {
     return align256((size_t)M * 64 * 4) + 256;
 }
 int bwd_density_grad(int net, const void* blob, int precision, int64_t M, const void* act, const float* x, int x_stride, const float* scale, int scale_stride,
-                     float* out, void* workspace, hipStream_t st) {
+                     float* out, void* workspace, hipStream_t st, int contract) {
     if (M == 0) return 0;
     const ChainCtx c(precision, M);
     Carver ws{reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255)};
     float* denc = ws.take((size_t)M * 64);
     if (net == NERF_AMD_NET_PROPOSAL) { if (int e = bwd_launch_chain(3, precision, blob, 0, M, act, nullptr, denc, st)) return e; }
     else if (int e = bwd_launch_chain(2, precision, blob, RefBwdLayout::DEN_START, M, act, nullptr, denc, st)) return e;
-    hipLaunchKernelGGL(pe_grad_kernel, dim3(blocks_1d(M * 3)), dim3(256), 0, st, denc, 64, x, x_stride, scale, scale_stride, M, 10, out);
+    if (contract) hipLaunchKernelGGL(pe_grad_contract_kernel, dim3(blocks_1d(M)), dim3(256), 0, st, denc, 64, x, x_stride, scale, scale_stride, M, 10, out);
+    else hipLaunchKernelGGL(pe_grad_kernel, dim3(blocks_1d(M * 3)), dim3(256), 0, st, denc, 64, x, x_stride, scale, scale_stride, M, 10, out);
     return (int)hipGetLastError();
 }
 
@@ -1650,17 +1699,17 @@ int bwd_ref_backward(const void* blob, int precision, int64_t M, const void* act
     const int elem = precision == NERF_AMD_BF16 ? 2 : 4;
     auto A = [&](int slot, int kg = 0) { return c.at(act, slot, kg); };
     auto D = [&](int slot, int kg = 0) { return c.at((void*)dlt, slot, kg); };
-    // slot 8 of the delta dump: K groups 0..7 delta of the bottle-neck, 8 the head rows, 9 the spec head -- zero it (only a few
-    // features of the head K groups are written)
-    if (int e = (int)hipMemsetAsync(D(8), 0, c.ls, st)) return e;
+    // slot 8 of the delta dump: K groups 0..7 delta of the bottle-neck, 8 the head rows, 9 the spec head -- each written COMPLETELY by the two
+    // element-wise kernels below (unused features and the padding samples up to the tile boundary as zeros): no memset
+    const int64_t Mpad = (int64_t)(c.ls / c.sub) * 32;
     // stage 1: spec head delta, then the directional network backwards
-    if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
-    else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, M, D(8, 9), (unsigned long long)c.sub, srgb);
+    if (elem == 2) hipLaunchKernelGGL(ref_spec_delta_kernel<2>, dim3(blocks_1d(Mpad)), dim3(256), 0, st, g_out, g_stride, aux, M, Mpad, D(8, 9), (unsigned long long)c.sub, srgb);
+    else hipLaunchKernelGGL(ref_spec_delta_kernel<4>, dim3(blocks_1d(Mpad)), dim3(256), 0, st, g_out, g_stride, aux, M, Mpad, D(8, 9), (unsigned long long)c.sub, srgb);
     if (int e = bwd_launch_chain(0, precision, blob, L::DIR_START, M, act, dlt, dallin, st)) return e;                            // D7 .. D0 + the input-vector columns
     // stage 2: IDE / reflection / normal / head activations backwards -> delta of the heads and of the bottle-neck
-    if (elem == 2) hipLaunchKernelGGL(ref_heads_delta_kernel<2>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M,
+    if (elem == 2) hipLaunchKernelGGL(ref_heads_delta_kernel<2>, dim3(blocks_1d(Mpad)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, Mpad,
                                       D(8), (unsigned long long)c.sub, srgb);
-    else hipLaunchKernelGGL(ref_heads_delta_kernel<4>, dim3(blocks_1d(M)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, D(8),
+    else hipLaunchKernelGGL(ref_heads_delta_kernel<4>, dim3(blocks_1d(Mpad)), dim3(256), 0, st, g_out, g_stride, aux, dallin, 192, dirs, dir_stride, ide_table, M, Mpad, D(8),
                             (unsigned long long)c.sub, srgb);
     // stage 3: the spatial network backwards
     if (int e = bwd_launch_chain(1, precision, blob, L::SPA_START, M, act, dlt, nullptr, st)) return e;                           // S7 .. S0

@@ -33,9 +33,9 @@ int pack_ref(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_proposal_bwd(int, const float* const*, void*, hipStream_t);
 int pack_mip_bwd(int, const float* const*, void*, hipStream_t);
 int pack_ref_bwd(int, const float* const*, void*, hipStream_t);
-int mlp_launch_ref_train(const void*, int, const nerf_amd_samples&, float*, float*, const float*, void*, float*, int, hipStream_t);
+int mlp_launch_ref_train(const void*, int, const nerf_amd_samples&, float*, float*, const float*, void*, float*, int, hipStream_t, unsigned long long, const unsigned long long*, float);
 size_t bwd_density_grad_workspace_bytes(int, int64_t);
-int bwd_density_grad(int, const void*, int, int64_t, const void*, const float*, int, const float*, int, float*, void*, hipStream_t);
+int bwd_density_grad(int, const void*, int, int64_t, const void*, const float*, int, const float*, int, float*, void*, hipStream_t, int);
 size_t bwd_ref_workspace_bytes(int, int64_t);
 int bwd_ref_backward(const void*, int, int64_t, const void*, const float*, const float*, int, const float*, int, const float*, float* const*,
                      float* const*, void*, int, hipStream_t);
@@ -58,6 +58,7 @@ int sk_dirs_norm_scratch(const float*, int64_t, float*, void*, hipStream_t);
 int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, const float*, float, float, float, float, int64_t, int, uint64_t, const uint64_t*,
                      float*, float*, float*, float*, hipStream_t);
 int sk_philox_uniforms(float*, int64_t, int, uint64_t, const uint64_t*, int64_t, int, hipStream_t);
+int sk_philox_normal(float*, int64_t, uint64_t, const uint64_t*, float, int64_t, hipStream_t);
 size_t gk_gemm_workspace_bytes(int64_t, int64_t, int64_t);
 int gk_gemm(int, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*, int64_t, int64_t, float*, int64_t, const float*, int, const float*, int64_t,
             void*, hipStream_t);
@@ -129,7 +130,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 121; }
+int nerf_amd_version(void) { return 122; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -550,7 +551,22 @@ int nerf_amd_ref_forward_train_dump(const void* packed, int precision, const ner
     if (int c = check_samples(src, true)) return c;
     if (src->M == 0) return NERF_AMD_OK;
     if (!packed || !rgbo || !dump || !aux) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(mlp_launch_ref_train(packed, precision, *src, rgbo, normal, bn_noise, dump, aux, ref_flags, S(stream)), "nerf_amd_ref_forward_train_dump");
+    return hip_status(mlp_launch_ref_train(packed, precision, *src, rgbo, normal, bn_noise, dump, aux, ref_flags, S(stream), 0, nullptr, 0.0f), "nerf_amd_ref_forward_train_dump");
+}
+int nerf_amd_ref_forward_train_dump_rng(const void* packed, int precision, const nerf_amd_samples* src, int ref_flags, uint64_t noise_seed,
+                                        const uint64_t* noise_seed_dev, float noise_std, float* rgbo, float* normal, void* dump, float* aux, void* stream) {
+    if (bad_prec(precision) || bad_ref_flags(ref_flags)) return fail(NERF_AMD_EINVAL, "unknown precision or ref_flags");
+    if (!(noise_std >= 0.0f)) return fail(NERF_AMD_EINVAL, "noise_std must be >= 0");
+    if (int c = check_samples(src, true)) return c;
+    if (src->M == 0) return NERF_AMD_OK;
+    if (!packed || !rgbo || !dump || !aux) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(mlp_launch_ref_train(packed, precision, *src, rgbo, normal, nullptr, dump, aux, ref_flags, S(stream), noise_seed,
+                                           reinterpret_cast<const unsigned long long*>(noise_seed_dev), noise_std), "nerf_amd_ref_forward_train_dump_rng");
+}
+int nerf_amd_philox_normal(float* out, int64_t M, uint64_t rng_seed, const uint64_t* seed_dev, float std, int64_t sample_offset, void* stream) {
+    if (M < 0 || sample_offset < 0 || !(std >= 0.0f)) return fail(NERF_AMD_EINVAL, "negative size or std");
+    if (M && !out) return fail(NERF_AMD_EINVAL, "NULL argument");
+    return hip_status(sk_philox_normal(out, M, rng_seed, seed_dev, std, sample_offset, S(stream)), "nerf_amd_philox_normal");
 }
 size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M) {
     if (bad_prec(precision) || M < 0 || (net != NERF_AMD_NET_PROPOSAL && net != NERF_AMD_NET_REF)) return 0;
@@ -558,11 +574,13 @@ size_t nerf_amd_density_grad_workspace_bytes(int net, int precision, int64_t M) 
 }
 int nerf_amd_density_grad(int net, const void* packed_bwd, int precision, int64_t M, const void* act_dump, const float* x, int x_stride,
                           const float* scale, int scale_stride, float* grad, void* workspace, void* stream) {
+    const int contract = (net & NERF_AMD_CONTRACTED) ? 1 : 0;   // flag in `net`: the forward saw contracted positions (nerf_amd_samples.contract)
+    net &= ~NERF_AMD_CONTRACTED;
     if (bad_prec(precision) || M < 0 || x_stride < 3) return fail(NERF_AMD_EINVAL, "bad precision, size or stride");
     if (net != NERF_AMD_NET_PROPOSAL && net != NERF_AMD_NET_REF) return fail(NERF_AMD_EUNSUPPORTED, "density gradients exist for the proposal and Ref-NeRF networks");
     if (M == 0) return NERF_AMD_OK;
     if (!packed_bwd || !act_dump || !x || !grad || !workspace) return fail(NERF_AMD_EINVAL, "NULL argument");
-    return hip_status(bwd_density_grad(net, packed_bwd, precision, M, act_dump, x, x_stride, scale, scale_stride, grad, workspace, S(stream)), "nerf_amd_density_grad");
+    return hip_status(bwd_density_grad(net, packed_bwd, precision, M, act_dump, x, x_stride, scale, scale_stride, grad, workspace, S(stream), contract), "nerf_amd_density_grad");
 }
 size_t nerf_amd_ref_backward_workspace_bytes(int precision, int64_t M) {
     if (bad_prec(precision) || M < 0) return 0;
@@ -595,7 +613,7 @@ int nerf_amd_adam_step(float* const* params, const float* const* grads, float* c
 // ---- backward of the sampling / compositing rows ----
 int nerf_amd_sigma_to_weights_backward(const float* sigma, const float* z, const float* dirs, int64_t N, int Sn, int act,
                                        const float* d_weights, float* d_sigma, void* stream) {
-    if (N < 0 || Sn < 1 || Sn > 256) return fail(NERF_AMD_EINVAL, "bad size (S must be 1..256)");
+    if (N < 0 || Sn < 1 || Sn > 1024) return fail(NERF_AMD_EINVAL, "bad size (S must be 1..1024)");
     if (N && (!sigma || !z || !d_weights || !d_sigma)) return fail(NERF_AMD_EINVAL, "NULL argument");
     return hip_status(sk_weights_backward(sigma, 1, 0, z, Sn, dirs, 3, N, Sn, dirs ? 1 : 0, act, 0.0f, nullptr, nullptr, d_weights, nullptr, 0, 0.0f,
                                           1.0f, d_sigma, 1, 0, nullptr, S(stream)), "nerf_amd_sigma_to_weights_backward");
@@ -603,7 +621,7 @@ int nerf_amd_sigma_to_weights_backward(const float* sigma, const float* z, const
 int nerf_amd_composite_backward(const float* rgbo, const float* z, int z_stride, const float* dirs, int dirs_stride, int64_t N, int Sn,
                                 int flags, int act, float sigma_shift, float near, float far, const float* d_rgb,
                                 const float* d_weights, const float* d_depth, float* d_rgbo, void* stream) {
-    if (N < 0 || Sn < 1 || Sn > 256 || z_stride < Sn) return fail(NERF_AMD_EINVAL, "bad size (S must be 1..256)");
+    if (N < 0 || Sn < 1 || Sn > 1024 || z_stride < Sn) return fail(NERF_AMD_EINVAL, "bad size (S must be 1..1024)");
     if (N && (!rgbo || !z || !dirs || !d_rgbo)) return fail(NERF_AMD_EINVAL, "NULL argument");
     if (N && !d_rgb) return fail(NERF_AMD_EINVAL, "d_rgb is required (pass zeros when only the weights carry a gradient)");
     return hip_status(sk_weights_backward(rgbo, 4, 3, z, z_stride, dirs, dirs_stride, N, Sn, flags & 1, act, sigma_shift, rgbo, d_rgb, d_weights,

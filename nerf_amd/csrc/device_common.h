@@ -113,6 +113,26 @@ DEVINL float philox_u_inv(uint64_t seed, int64_t n, int k) {
     return u01_from_bits(q == 0 ? p.w[1] : (q == 1 ? p.w[2] : p.w[3]));
 }
 
+// Normal deviates for Ref-NeRF's bottle-neck perturbation (ref_model.py:84-85: `spa_info_b + torch.normal(0, w, shape)`), drawn where
+// they are added instead of written to and read back from HBM (1.6 GB and a 0.5 ms launch per 2^14-ray step).  One Philox block per
+// (sample m, block q) of stream 'BN' gives EIGHT deviates: its four words are cut into eight 16-bit uniforms (c + 0.5) / 65536 in (0, 1),
+// pairs (lo, hi) of a word feed Box-Muller -- r = sqrt(-2 ln u_lo), z = r (cos, sin)(2 pi u_hi).  16-bit uniforms bound |z| by 4.85 sigma
+// and put the values on a 65 536 x 65 536 polar lattice: ample for a regularising perturbation of standard deviation `std`, and half the
+// Philox calls of full-width uniforms.  Feature f of the 128 of sample m: q = f >> 3 ... the layout the fused kernel's accumulators
+// want: q = 2 (f >> 4) + ((f >> 2) & 1), element (f & 3) + 4 ((f >> 3) & 1)  (oracle twin: oracle.philox_normal).
+constexpr uint32_t PHILOX_STREAM_BN = 0x424Eu;
+DEVINL void philox_normal8(uint64_t seed, int64_t m, int q, float std, float (&z)[8]) {
+    const Philox4 p = philox4x32_10((uint32_t)m, (uint32_t)((uint64_t)m >> 32), (uint32_t)q, PHILOX_STREAM_BN, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float u0 = ((float)(p.w[w] & 0xffffu) + 0.5f) * 1.52587890625e-05f;       // (0, 1)
+        const float u1 = ((float)(p.w[w] >> 16) + 0.5f) * 1.52587890625e-05f;
+        const float r = std * __builtin_sqrtf(-2.0f * __logf(u0));
+        z[2 * w] = r * __builtin_amdgcn_cosf(u1);                                        // v_cos_f32 / v_sin_f32 take REVOLUTIONS: cos(2 pi u1)
+        z[2 * w + 1] = r * __builtin_amdgcn_sinf(u1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Integrated positional encoding, per-frustum part (mip_methods.py:15-33): Gaussian moments of the conical frustum between depths
 // z0 < z1 along a ray of pixel radius r (r2 = fl(r*r) computed in double like Python's `r ** 2`), every operation in the reference's

@@ -977,8 +977,12 @@ DEVINL void ide_encode(float x, float y, float z, float kappa_inv, float nv_dot,
 template <class P, bool TRAIN>
 __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict__ packed, nerf_amd_samples s,
                                                          float* __restrict__ rgbo, float* __restrict__ normal_out,
-                                                         const float* __restrict__ bn_noise, ActDump dump, float* __restrict__ aux, int flags) {
+                                                         const float* __restrict__ bn_noise, ActDump dump, float* __restrict__ aux, int flags,
+                                                         unsigned long long noise_seed, const unsigned long long* __restrict__ noise_seed_dev, float noise_std) {
     using L = RefLayout;
+    // bn_noise == nullptr and noise_std > 0: the bottle-neck perturbation is drawn HERE (device_common.h philox_normal8), keyed by
+    // (seed, sample index) -- `noise_seed_dev` (a device scalar, read at run time: a captured hipGraph replays fresh noise) or `noise_seed`
+    if (noise_seed_dev != nullptr) noise_seed = noise_seed_dev[0];
     using BReg = typename P::BReg;
     constexpr int FPC = P::FPC;
     load_biases(packed, L::stream_bytes(P::PREC), L::N_BIAS, REF_LDS_BIAS);
@@ -1111,6 +1115,11 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
                     const f32x4 n0 = *reinterpret_cast<const f32x4*>(np_), n1 = *reinterpret_cast<const f32x4*>(np_ + 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[8 * half + e] += n0[e]; v[8 * half + 4 + e] += n1[e]; }
+                } else if (noise_std > 0.0f) {
+                    float z[8];
+                    philox_normal8(noise_seed, m[t] < s.M ? m[t] : s.M - 1, 2 * (2 * (fb < 4 ? fb : 0) + half) + h, noise_std, z);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[8 * half + e] += z[e];
                 }
                 bn[t][2 * (fb < 4 ? fb : 0) + half] = to_breg_half<P, false>(v, half);
                 if constexpr (TRAIN) dump_breg<P>(dump, 8, sub0 + t, 2 * (fb < 4 ? fb : 0) + half, lane, bn[t][2 * (fb < 4 ? fb : 0) + half]);
@@ -1340,13 +1349,13 @@ int mlp_launch_mip_train(const void* packed, int precision, const nerf_amd_sampl
 #if MLP_TU == 0 || MLP_TU == 3
 template <class P, bool TRAIN>
 static int launch_ref(const void* packed, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise, ActDump dump, float* aux,
-                      int flags, hipStream_t st) {
+                      int flags, hipStream_t st, unsigned long long seed = 0, const unsigned long long* seed_dev = nullptr, float noise_std = 0.0f) {
     constexpr int TS = P::NW * P::NT * 32;
     const int64_t n_tiles = (s.M + TS - 1) / TS;
     if (n_tiles == 0) return 0;
     const size_t lds = ref_lds_total<P>();
     if (int e = allow_dynamic_lds(reinterpret_cast<const void*>(ref_kernel<P, TRAIN>), lds)) return e;
-    hipLaunchKernelGGL((ref_kernel<P, TRAIN>), dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise, dump, aux, flags);
+    hipLaunchKernelGGL((ref_kernel<P, TRAIN>), dim3(grid_for(n_tiles)), dim3(P::NW * 64), lds, st, packed, s, rgbo, normal, bn_noise, dump, aux, flags, seed, seed_dev, noise_std);
     return (int)hipGetLastError();
 }
 int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
@@ -1356,14 +1365,14 @@ int mlp_launch_ref(const void* packed, int precision, const nerf_amd_samples& s,
 }
 // training forward of Ref-NeRF: activation dump (REF_DUMP_SLOTS slots of mlp_train_layer_stride bytes) + aux (M,16)
 int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_samples& s, float* rgbo, float* normal, const float* bn_noise,
-                         void* dump, float* aux, int flags, hipStream_t st) {
+                         void* dump, float* aux, int flags, hipStream_t st, unsigned long long seed, const unsigned long long* seed_dev, float noise_std) {
     const ActDump d = make_dump(dump, precision, s.M, REF_DUMP_SLOTS);     // 17 activation slots + (round 4) their ReLU bit-mask records
     // bf16 training forward: the 8-wave x 32-sample tile, like the proposal network's -- its 512 dump stores per wave and tile cost their
     // ISSUE slots (~80 cycles of the vector-memory path each, during which a lone wave per SIMD issues no MFMA; not a wait: the store-aware
     // ring wait changed nothing, mlp_core.h), which a second wave per SIMD fills: 9.01 -> 8.38 ms per 2^14-ray step, same box, alternated
     // twice (profiles/r04_ref_train_fwd_8wave_ab.log); the dump layout does not depend on the tile policy.  -DREF_TRAIN_WIDE = the A side.
-    if (precision == NERF_AMD_BF16) return launch_ref<PBF16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
-    if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
-    return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st);
+    if (precision == NERF_AMD_BF16) return launch_ref<PBF16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st, seed, seed_dev, noise_std);
+    if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st, seed, seed_dev, noise_std);
+    return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st, seed, seed_dev, noise_std);
 }
 #endif

@@ -774,11 +774,13 @@ __global__ __launch_bounds__(256) void get_bounds_kernel(const float* __restrict
 
 // ================================================================================================
 // Backward kernels of the sampling / compositing rows: one wavefront per ray, the transmittance
-// product's adjoint is a suffix sum.  Up to 256 samples per ray (4 register chunks).
+// product's adjoint is a suffix sum.  Up to 1 024 samples per ray (4 / 8 / 16 register chunks).
 //   forward:  m_i = exp(-act(sigma_i + shift) * delta_i),  q_i = m_i + 1e-10,  T_i = prod_{j<i} q_j,  w_i = (1 - m_i) T_i
 //   given G_i = dL/dw_i:   dL/dm_j = -G_j T_j + (sum_{i>j} G_i w_i) / q_j,   dL/dsigma_j = dL/dm_j * (-delta_j m_j) * act'(sigma_j + shift)
 // ================================================================================================
-constexpr int BWD_CHUNKS = 4;
+// Rows of any length up to 1 024 samples (round 5: `-t --fine_sample_pnum 256` merges 320 samples per ray, nerf_base.py:91-113 has no limit):
+// the kernel is instantiated for 4 / 8 / 16 register chunks of 64 samples (7 registers per chunk) and the launcher picks by S.
+constexpr int BWD_MAX_CHUNKS = 16;
 struct WeightsBwdArgs {
     const float* sigma; int sigma_stride;      // sigma of sample s of ray n at sigma[(n*S + s) * sigma_stride + sigma_off]
     int sigma_off;
@@ -792,6 +794,7 @@ DEVINL float density_act_grad(float x, int act) {
     if (act == 2) return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
     return 1.0f;
 }
+template <int BWD_CHUNKS>
 __global__ __launch_bounds__(256) void weights_backward_kernel(WeightsBwdArgs a) {
     const int S = a.S;
     const int lane = lane_id();
@@ -1370,6 +1373,27 @@ __global__ void philox_uniforms_kernel(float* __restrict__ out, int64_t N, int K
         out[i] = strat ? philox_u_strat(seed, ray_offset + n, k) : philox_u_inv(seed, ray_offset + n, k);
     }
 }
+// The bottle-neck perturbation of Ref-NeRF's training forward as a tensor, out (M, 128) ~ N(0, std): bit-identical to what ref_kernel
+// draws in place for the same key and sample index (device_common.h philox_normal8) -- for tests, the layer-by-layer route and callers
+// that want the reference's explicit `spa_info_b + noise` (ref_model.py:84-85).  One thread per (sample, block of eight deviates).
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t M, uint64_t seed, const uint64_t* __restrict__ seed_dev, float std, int64_t sample_offset) {
+    if (seed_dev != nullptr) seed = seed_dev[0];
+    const int64_t total = M * 16;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i >> 4;
+        const int q = (int)(i & 15);
+        float z[8];
+        philox_normal8(seed, sample_offset + m, q, std, z);
+        float* row = out + m * 128 + 16 * (q >> 1) + 4 * (q & 1);
+        *reinterpret_cast<f32x4*>(row) = f32x4{z[0], z[1], z[2], z[3]};
+        *reinterpret_cast<f32x4*>(row + 8) = f32x4{z[4], z[5], z[6], z[7]};
+    }
+}
+int sk_philox_normal(float* out, int64_t M, uint64_t seed, const uint64_t* seed_dev, float std, int64_t sample_offset, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(blocks_for(M * 16, 256)), dim3(256), 0, st, out, M, seed, seed_dev, std, sample_offset);
+    return (int)hipGetLastError();
+}
 // seed <- a new, unrelated key for the next step (golden-ratio increment + a xorshift-multiply mix); one thread
 __global__ void advance_seed_kernel(uint64_t* __restrict__ seed_dev) {
     uint64_t x = seed_dev[0] + 0x9E3779B97F4A7C15ull;
@@ -1466,10 +1490,12 @@ int sk_weights_backward(const float* sigma, int sigma_stride, int sigma_off, con
                         const float* d_weights, const float* d_depth, int white_bkg, float near, float far, float* d_sigma,
                         int d_sigma_stride, int d_sigma_off, float* d_rgbo, hipStream_t st) {
     if (N * S == 0) return 0;
-    if (S > BWD_CHUNKS * 64) return (int)hipErrorInvalidValue;
+    if (S > BWD_MAX_CHUNKS * 64) return (int)hipErrorInvalidValue;
     WeightsBwdArgs a{sigma, sigma_stride, sigma_off, z, z_stride, dirs, dirs_stride, N, S, mul_norm, act, sigma_shift, rgbo, d_rgb, d_weights,
                      d_depth, white_bkg, near, far, d_sigma, d_sigma_stride, d_sigma_off, d_rgbo};
-    hipLaunchKernelGGL(weights_backward_kernel, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
+    if (S <= 256) hipLaunchKernelGGL(weights_backward_kernel<4>, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
+    else if (S <= 512) hipLaunchKernelGGL(weights_backward_kernel<8>, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(weights_backward_kernel<16>, dim3(blocks_for(N, WAVES_PER_BLOCK)), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int sk_max_blur_backward(const float* w, const float* g, int64_t N, int S, float* dw, hipStream_t st) {

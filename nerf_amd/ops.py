@@ -273,14 +273,14 @@ REF_SRGB = 1          # NERF_AMD_REF_SRGB: RefNeRF(use_srgb=True) output transfo
 
 
 def ref_forward(packed: torch.Tensor, precision: int, pts: torch.Tensor, want_normal: bool = True, noise: Optional[torch.Tensor] = None,
-                flags: int = 0):
+                flags: int = 0, contract: bool = False):
     """pts (..., 6) = [position | direction] -> (rgbo (..., 4), normal (..., 3))   [ref_model.py:68-106]; `noise` (..., 128) = the
     train-mode bottle-neck perturbation (ref_model.py:84-85), None = eval mode; `flags`: REF_SRGB = the module's use_srgb"""
     pts = _dev(pts, "pts")
     rgbo, normal = _ref_out(pts.shape[:-1], pts.device, want_normal)
     if rgbo.numel() == 0:
         return rgbo, normal
-    s = _samples_pts(pts, 6)
+    s = _samples_pts(pts, 6, contract)
     if noise is None:
         check(lib.nerf_amd_ref_forward(_ptr(packed), precision, C.byref(s), int(flags), _ptr(rgbo), _ptr(normal), _stream()), "nerf_amd_ref_forward")
     else:
@@ -693,7 +693,7 @@ def render_rays_ref(packed_prop, packed_ref, precision, rays, z_base, u_strat, u
 
 
 # ------------------------------------------------------------------------------------------------ backward
-BWD_MAX_SAMPLES = 256          # the backward kernels keep a ray in four 64-lane register chunks
+BWD_MAX_SAMPLES = 1024         # the backward kernels keep a ray in 4 / 8 / 16 register chunks of 64 samples (picked by the row length)
 
 
 def sigma_to_weights_backward(sigma: torch.Tensor, z: torch.Tensor, dirs: Optional[torch.Tensor], act: int, d_weights: torch.Tensor) -> torch.Tensor:
@@ -930,22 +930,41 @@ def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp
 
 
 # ------------------------------------------------------------------------------------------------ Ref-NeRF training / density gradients
-def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, noise: Optional[torch.Tensor], flags: int = 0):
+def ref_forward_train(packed: torch.Tensor, precision: int, pts: torch.Tensor, noise: Optional[torch.Tensor], flags: int = 0,
+                      noise_std: float = 0.0, noise_seed: int = 0, noise_seed_dev: Optional[torch.Tensor] = None, contract: bool = False):
     """RefNeRF.forward in training (ref_model.py:68-106) + the activation dump and the pre-activation head values of the backward.
-    pts (..., 6) -> (rgbo (..., 4), normal (..., 3), dump, aux (M, 16))"""
+    pts (..., 6) -> (rgbo (..., 4), normal (..., 3), dump, aux (M, 16)).  The bottle-neck perturbation (ref_model.py:84-85): `noise`
+    (..., 128) given as a tensor, or -- noise None and noise_std > 0 -- drawn inside the kernel from Philox keyed by `noise_seed` /
+    the device scalar `noise_seed_dev` and the sample index (= ops.philox_normal of the same key)."""
     pts = _dev(pts, "pts")
     rgbo, normal = _ref_out(pts.shape[:-1], pts.device, True)
-    s = _samples_pts(pts, 6)
+    s = _samples_pts(pts, 6, contract)
     dump = leased(("dump", NET_REF), lib.nerf_amd_train_dump_bytes(NET_REF, precision, s.M), pts.device)
     aux = torch.empty((s.M, 16), dtype=torch.float32, device=pts.device)
     if s.M:
-        noise = _dev(noise, "noise") if noise is not None else None
-        check(lib.nerf_amd_ref_forward_train_dump(_ptr(packed), precision, C.byref(s), int(flags), _ptr(noise), _ptr(rgbo), _ptr(normal), _ptr(dump), _ptr(aux),
-                                                  _stream()), "nerf_amd_ref_forward_train_dump")
+        if noise is None and noise_std > 0.0:
+            check(lib.nerf_amd_ref_forward_train_dump_rng(_ptr(packed), precision, C.byref(s), int(flags), int(noise_seed) & 0xFFFFFFFFFFFFFFFF,
+                                                          _ptr(noise_seed_dev), float(noise_std), _ptr(rgbo), _ptr(normal), _ptr(dump), _ptr(aux), _stream()),
+                  "nerf_amd_ref_forward_train_dump_rng")
+        else:
+            noise = _dev(noise, "noise") if noise is not None else None
+            check(lib.nerf_amd_ref_forward_train_dump(_ptr(packed), precision, C.byref(s), int(flags), _ptr(noise), _ptr(rgbo), _ptr(normal), _ptr(dump), _ptr(aux),
+                                                      _stream()), "nerf_amd_ref_forward_train_dump")
     return rgbo, normal, dump, aux
 
 
-def density_grad(net: int, packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+def philox_normal(n_samples: int, std: float, seed: int = 0, seed_dev: Optional[torch.Tensor] = None, sample_offset: int = 0, device=None) -> torch.Tensor:
+    """(n_samples, 128) ~ N(0, std): the bottle-neck perturbation ref_forward_train(noise=None, noise_std=std, ...) draws in place for the
+    same key, as a tensor (nerf_amd_philox_normal)."""
+    dev = seed_dev.device if seed_dev is not None else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty((int(n_samples), 128), dtype=torch.float32, device=dev)
+    check(lib.nerf_amd_philox_normal(_ptr(out), int(n_samples), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(seed_dev), float(std), int(sample_offset), _stream()),
+          "nerf_amd_philox_normal")
+    return out
+
+
+def density_grad(net: int, packed_bwd: torch.Tensor, precision: int, dump: torch.Tensor, x: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                 contract: bool = False) -> torch.Tensor:
     """d density / d position of every sample (RefNeRF.get_grad before its normalisation), times `scale` (M,) -- proposal network or
     Ref-NeRF's spatial network.  x (M, >= 3) contiguous rows; -> (M, 3)."""
     x = _dev(x, "positions")
@@ -953,13 +972,13 @@ def density_grad(net: int, packed_bwd: torch.Tensor, precision: int, dump: torch
     out = torch.empty((M, 3), dtype=torch.float32, device=x.device)
     if M == 0:
         return out
-    ws = scratch(("density_grad", net), lib.nerf_amd_density_grad_workspace_bytes(net, precision, M), x.device)
+    ws = scratch(("density_grad", net), lib.nerf_amd_density_grad_workspace_bytes(net, precision, M), x.device)        # (`contract`: NERF_AMD_CONTRACTED in `net`)
     sc_stride = 0
     if scale is not None:
         if scale.dtype != torch.float32 or not scale.is_cuda or scale.dim() != 1:
             scale = scale.reshape(-1).float().contiguous()
         sc_stride = scale.stride(0)
-    check(lib.nerf_amd_density_grad(net, _ptr(packed_bwd), precision, M, _ptr(dump), _ptr(x), x.shape[1], _ptr(scale), sc_stride, _ptr(out), _ptr(ws),
+    check(lib.nerf_amd_density_grad(net | (0x100 if contract else 0), _ptr(packed_bwd), precision, M, _ptr(dump), _ptr(x), x.shape[1], _ptr(scale), sc_stride, _ptr(out), _ptr(ws),
                                     _stream()), "nerf_amd_density_grad")
     return out
 

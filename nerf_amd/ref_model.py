@@ -153,15 +153,34 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         ws, bs = self._pack_tensors()
         return ops.pack_weights(self._net_id, precision, ws, bs)
 
-    def forward(self, pts: torch.Tensor, ray_d: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """pts (N,S,6) [or (N,S,3) + ray_d (N,S,3)] -> ((N,S,4) = [rgb | raw density], normal (N,S,3))  (ref_model.py:68-106)."""
+    def forward(self, pts: torch.Tensor, ray_d: Optional[torch.Tensor] = None, contract: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """pts (N,S,6) [or (N,S,3) + ray_d (N,S,3)] -> ((N,S,4) = [rgb | raw density], normal (N,S,3))  (ref_model.py:68-106).
+        ``contract`` (an addition; BASELINE configs[4] shapes): the positions go through the Mip-NeRF 360 scene contraction before the
+        encoding -- a flag of the kernels' sample fetch; RefNeRF.get_grad then returns d density / d (uncontracted position)."""
         self._check_config()
         pos, d = pts[..., :3], (pts[..., 3:6] if ray_d is None else ray_d)
         prec = ops.current_precision()
-        noise = None
-        if self.training and self.perturb_bottle_neck_w > 0:                      # ref_model.py:84-85 (drawn here, given to the kernel)
-            noise = torch.normal(0, self.perturb_bottle_neck_w, pos.shape[:-1] + (self.bottle_neck_dim,), device=pos.device)
+        # ref_model.py:84-85, `spa_info_b + torch.normal(0, w, shape)` in training mode.  noise_rng (an addition, like render_image's rng):
+        #   "philox" (default): N(0, w) deviates from Philox4x32-10 + Box-Muller keyed by (one 62-bit draw from torch's CPU generator per
+        #       forward -- torch.manual_seed governs it -- or the device scalar `noise_seed_dev`, which nerf_amd.training.TrainStep points
+        #       at its own per-step key so that a captured hipGraph replays fresh noise) and the sample index.  The training forward draws
+        #       them INSIDE the kernel: no (M, 128) tensor is written and read back (1.6 GB + a 0.5 ms launch per 2^14-ray step);
+        #   "torch": torch.normal on the device generator, as a tensor handed to the kernel (round 1-4 behaviour).
+        noise, noise_kw = None, {}
+        fused_train = (not self._generic()) and ab.needs_grad(pos, d, *self.parameters())
+        if self.training and self.perturb_bottle_neck_w > 0:
+            if getattr(self, "noise_rng", "philox") == "philox" and self.bottle_neck_dim == 128:
+                seed_dev = self.__dict__.get("noise_seed_dev")
+                seed = 0 if seed_dev is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+                if fused_train:
+                    noise_kw = dict(noise_std=float(self.perturb_bottle_neck_w), noise_seed=seed, noise_seed_dev=seed_dev)
+                else:
+                    noise = ops.philox_normal(pos.numel() // 3, self.perturb_bottle_neck_w, seed, seed_dev, device=pos.device).view(pos.shape[:-1] + (128,))
+            else:
+                noise = torch.normal(0, self.perturb_bottle_neck_w, pos.shape[:-1] + (self.bottle_neck_dim,), device=pos.device)
         if self._generic():
+            if contract:
+                raise NotImplementedError("nerf_amd: scene contraction is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves, ide_level <= 4)")
             from . import generic_path
             return generic_path.ref_forward(self, pos, d, noise)
         named = list(self.named_parameters())
@@ -177,20 +196,32 @@ class RefNeRF(PackedWeightsMixin, NeRF):
             shape = pos.shape[:-1]
 
             def hip(p, dd, *wb):
-                pts6 = torch.cat((p, dd), dim=-1).contiguous()
-                rgbo, normal, held["dump"], held["aux"] = ops.ref_forward_train(self.packed(prec), prec, pts6, noise, self.kernel_flags)
+                # train.py:177 hands over the two halves of ONE (N, S, 6) sample tensor (`fine_samples.split((3, 3), dim=-1)`): when the
+                # arguments are exactly those views the kernel reads the tensor they came from -- no cat, no copy
+                if (p.dim() >= 2 and p.stride() == dd.stride() and p.stride(-1) == 1 and p.stride(-2) == 6 and p.shape == dd.shape and
+                        p.untyped_storage().data_ptr() == dd.untyped_storage().data_ptr() and dd.storage_offset() == p.storage_offset() + 3 and
+                        all(p.stride(k) == p.stride(k + 1) * p.shape[k + 1] for k in range(p.dim() - 2))):
+                    pts6 = torch.as_strided(p, tuple(p.shape[:-1]) + (6,), p.stride(), p.storage_offset())
+                else:
+                    pts6 = torch.cat((p, dd), dim=-1).contiguous()
+                rgbo, normal, held["dump"], held["aux"] = ops.ref_forward_train(self.packed(prec), prec, pts6, noise, self.kernel_flags, contract=contract, **noise_kw)
                 held["pts"] = pts6.view(-1, 6)
-                return torch.cat((rgbo, normal), dim=-1)
+                return rgbo, normal                           # two differentiable outputs (callers write into rgbo[..., -1] in place)
 
             def bwd(g, p, dd, *wb):
                 if "dump" not in held:
                     raise RuntimeError("nerf_amd: the activation dump of this forward was already consumed (backward twice over the same graph)")
-                g2 = g.reshape(-1, 7)
+                g_rgbo, g_nrm = g
                 if "bwd_blob" not in held:
                     held["bwd_blob"] = self.packed_backward(prec)
                 if ab._VJP.inputs_only:                       # RefNeRF.get_grad: the density channel's gradient w.r.t. the positions
-                    gx = ops.density_grad(ops.NET_REF, held["bwd_blob"], prec, held["dump"], held["pts"], scale=g2[:, 3])
+                    if g_rgbo is None:
+                        return (torch.zeros_like(p), None, *[None] * len(wb))
+                    gx = ops.density_grad(ops.NET_REF, held["bwd_blob"], prec, held["dump"], held["pts"], scale=g_rgbo.reshape(-1, 4)[:, 3], contract=contract)
                     return (gx.view(p.shape), None, *[None] * len(wb))
+                M_ = held["pts"].shape[0]
+                g2 = torch.cat((g_rgbo.reshape(-1, 4) if g_rgbo is not None else torch.zeros((M_, 4), dtype=torch.float32, device=p.device),
+                                g_nrm.reshape(-1, 3) if g_nrm is not None else torch.zeros((M_, 3), dtype=torch.float32, device=p.device)), dim=-1)
                 gw, gb = ops.ref_backward(held["bwd_blob"], prec, held.pop("dump"), held.pop("aux"), held["pts"][:, 3:], g2, self._ide_table(p.device), self.kernel_flags)
                 by_name = self._grads_by_name(gw, gb)
                 if self.sh_max_level != 4:
@@ -201,9 +232,9 @@ class RefNeRF(PackedWeightsMixin, NeRF):
                 shapes = {n: p_.shape for n, p_ in named}                 # (narrow networks: the padded rows / columns are the discarded part)
                 return (None, None, *[by_name[n][tuple(slice(0, k) for k in shapes[n])] if tuple(by_name[n].shape) != tuple(shapes[n]) else by_name[n]
                                       for n in names])
-            out = ab.HipOp.apply(hip, bwd, 1, pos, d, *params)
-            return out[..., :4].clone(), out[..., 4:].clone()                     # (callers write into rgbo[..., -1] in place)
-        return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise, flags=self.kernel_flags)
+            rgbo, normal = ab.HipOp.apply(hip, bwd, 2, pos, d, *params)
+            return rgbo, normal
+        return ops.ref_forward(self.packed(prec), prec, torch.cat((pos, d), dim=-1).contiguous(), noise=noise, flags=self.kernel_flags, contract=contract)
 
     def _ide_table(self, device, level: int = 4):
         """the (2^(level-1) + 1, T) coefficient matrix of ref_func.py:60-74 on `device` (constant: float64 host loops, uploaded once)"""

@@ -60,8 +60,8 @@ class TrainStep:
         from .ref_model import RefNeRF
         self.is_ref = isinstance(mip_net, RefNeRF)
         self.ipe_radius, self.contract = (None if ipe_radius is None else float(ipe_radius)), bool(contract)
-        if self.is_ref and (self.ipe_radius is not None or self.contract):
-            raise NotImplementedError("nerf_amd.training.TrainStep: integrated PE / scene contraction are wired for the MipNeRF branch")
+        if self.is_ref and self.ipe_radius is not None:
+            raise NotImplementedError("nerf_amd.training.TrainStep: the integrated PE is wired for the MipNeRF branch (the Ref-NeRF kernel encodes points)")
         self.prop_normal = bool(prop_normal) and self.is_ref                              # (train.py: prop_normal only acts with a Ref-NeRF)
         dev = next(mip_net.parameters()).device
         H, W = image_hw
@@ -73,6 +73,8 @@ class TrainStep:
         self.seed = torch.full((1,), seed, dtype=torch.int64, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.img_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        if self.is_ref:                                      # the bottle-neck perturbation keyed by this step's device-resident seed
+            mip_net.__dict__["noise_seed_dev"] = self.seed   # (RefNeRF.forward, noise_rng "philox": a replayed graph draws fresh noise)
         self.prop_loss_fn = ProposalLoss()
         self.grad_hook = grad_hook
         # an explicitly passed FlatGradients is a request for data-parallel averaging; the default one only holds the gradients (ranks of a
@@ -111,9 +113,9 @@ class TrainStep:
         if self.is_ref:                                                                                 # :175-187
             from .ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
             samples, z_f, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, z_f, below)
-            pos, fine_dir = samples.split((3, 3), dim=-1)
-            pos, fine_dir = pos.contiguous().requires_grad_(True), fine_dir.contiguous()
-            rgbo, pred_normal = self.mip_net.forward(pos, fine_dir)
+            pos, fine_dir = samples.split((3, 3), dim=-1)                                               # (views: RefNeRF.forward reads `samples` itself)
+            pos.requires_grad_(True)
+            rgbo, pred_normal = self.mip_net.forward(pos, fine_dir, contract=True) if self.contract else self.mip_net.forward(pos, fine_dir)
             density_grad = -RefNeRF.get_grad(rgbo[..., -1], pos)
             rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
             # train.py:182 passes mip_net.density_act POSITIONALLY, i.e. into `mul_norm`: the depths are not scaled by |d| and the

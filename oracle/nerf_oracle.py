@@ -288,6 +288,28 @@ def philox_uniforms(seed: int, n_rays: int, ray_offset: int = 0, S: int = 64, K:
     return to_f(us), to_f(ui)
 
 
+def philox_normal(seed: int, n_samples: int, std: float, sample_offset: int = 0):
+    """The bottle-neck perturbation the Ref-NeRF training forward draws in place (nerf_amd/csrc/device_common.h philox_normal8; the
+    reference draws torch.normal(0, w, shape) on the device generator, ref_model.py:84-85 -- any N(0, w) stream serves).  (n_samples, 128)
+    fp32: one Philox block per (sample m, q) of stream 'BN' = 0x424E, q = 2 (f >> 4) + ((f >> 2) & 1) for feature f; word w of the block
+    -> 16-bit uniforms u0 = (lo + .5) / 65536, u1 = (hi + .5) / 65536 -> r = sqrt(-2 ln u0), (r cos 2 pi u1, r sin 2 pi u1) = elements
+    2 w, 2 w + 1 of the block's eight deviates; feature f takes element (f & 3) + 4 ((f >> 3) & 1)."""
+    import numpy as np
+    m = np.arange(n_samples, dtype=np.uint64) + np.uint64(sample_offset)
+    mlo, mhi = (m & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None], (m >> np.uint64(32)).astype(np.uint32)[:, None]
+    q = np.arange(16, dtype=np.uint32)[None, :]
+    w = philox4x32_10(mlo, mhi, q + np.zeros_like(mlo), np.uint32(0x424E), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)     # 4 x (n, 16)
+    z = np.empty((n_samples, 16, 8), np.float32)
+    for k in range(4):
+        u0 = ((w[k] & np.uint32(0xFFFF)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -16)
+        u1 = ((w[k] >> np.uint32(16)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -16)
+        r = np.float32(std) * np.sqrt(np.float32(-2.0) * np.log(u0))
+        z[:, :, 2 * k] = r * np.cos(2.0 * np.pi * u1.astype(np.float64)).astype(np.float32)
+        z[:, :, 2 * k + 1] = r * np.sin(2.0 * np.pi * u1.astype(np.float64)).astype(np.float32)
+    f = np.arange(128)
+    return torch.from_numpy(z[:, 2 * (f >> 4) + ((f >> 2) & 1), (f & 3) + 4 * ((f >> 3) & 1)].astype(np.float32))
+
+
 # --------------------------------------------------------------------------------------------
 # row 7: inverse-transform sampling
 # --------------------------------------------------------------------------------------------

@@ -96,6 +96,7 @@ def make_ref_step(n_rays, c_n, f_n, precision, graph=False, graph_warm=3):
     nerf_amd.set_precision(precision)
     torch.manual_seed(0)
     prop, net = ProposalNetwork(10, 256).cuda().train(), RefNeRF(10, 4).cuda().train()
+    net.noise_rng = __import__("os").environ.get("REF_NOISE_RNG", "philox")      # A/B: "torch" = the round-4 torch.normal tensor
     from nerf_amd.optim import Adam
     opt = Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-4)
     o = torch.tensor([0.0, 0.0, 4.0]).expand(n_rays, 3)
@@ -114,9 +115,9 @@ def make_ref_step(n_rays, c_n, f_n, precision, graph=False, graph_warm=3):
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
         fl, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=torch.rand((n_rays, f_n + 1), device="cuda"))
         samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, fl, below)
-        pos, dd = samples.split((3, 3), dim=-1)
-        pos = pos.contiguous().requires_grad_(True)
-        rgbo, nrm = net.forward(pos, dd.contiguous())
+        pos, dd = samples.split((3, 3), dim=-1)              # train.py:177-179: the two views, as the reference passes them
+        pos.requires_grad_(True)
+        rgbo, nrm = net.forward(pos, dd)
         dgrad = -RefNeRF.get_grad(rgbo[..., -1], pos)
         rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
         rend, wts, _ = NeRF.render(rgbo, fl, rays[:, 3:], net.density_act)

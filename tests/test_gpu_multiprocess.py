@@ -295,6 +295,8 @@ def test_refnerf_training_step_captured_in_a_hipgraph():
         net = RefNeRF(10, 4)
         net.load_state_dict(W.ref_state("small"))
         prop, net = prop.train(), net.cuda().train()
+        net.noise_rng = "torch"                                      # the fixed perturbation enters through torch.normal (default: in-kernel Philox,
+                                                                      # whose host-drawn key a capture would bake in -- TrainStep keys it by a device scalar)
         opt = torch.optim.Adam(list(net.parameters()) + list(prop.parameters()), lr=1e-3, capturable=True)
 
         def step():

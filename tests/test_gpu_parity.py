@@ -808,8 +808,9 @@ def _vjp(fn, grad, *args):
     return torch.autograd.grad(y, [l for l in leaves if isinstance(l, torch.Tensor) and l.requires_grad], grad, allow_unused=True)
 
 
-@pytest.mark.parametrize("S,act", [(64, 0), (128, 0), (129, 2), (200, 1), (7, 0)])
+@pytest.mark.parametrize("S,act", [(64, 0), (128, 0), (129, 2), (200, 1), (7, 0), (256, 0), (257, 2), (320, 2), (513, 0), (1024, 2)])
 def test_weights_and_composite_backward_vs_autograd(A, S, act):
+    # (rows above 256 samples: 8 / 16 register chunks since round 5 -- `-t --fine_sample_pnum 256` merges 320 samples per ray)
     import torch_spec as ab
     gen = torch.Generator().manual_seed(S)
     N = 37
@@ -1008,6 +1009,50 @@ def test_get_grad_of_proposal_density_then_parameter_backward(A):
         assert max_abs(a_.cpu(), b_.cpu()) <= 1e-4 * max(1.0, b_.abs().max().item())
 
 
+def test_density_gradient_normals_through_the_scene_contraction(A):
+    """RefNeRF.get_grad of contracted positions used to raise.  d density / d x with the Mip-NeRF 360 contraction in the
+    sample fetch = the encoding's derivative at contract(x) pulled back through the contraction's Jacobian (pe_grad_contract_kernel), for
+    the proposal network (train.py:165-168) and Ref-NeRF's spatial network (train.py:178), against fp64 autograd of
+    oracle.contract -> oracle forward on positions inside AND outside the unit ball; the parameter backward over the same graph still runs."""
+    from nerf_amd.ref_model import RefNeRF
+    A.pkg.set_precision("fp32")
+    gen = torch.Generator().manual_seed(77)
+    M = 300
+    x = torch.randn(M, 1, 3, generator=gen) * torch.linspace(0.2, 8.0, M)[:, None, None]          # |x| from 0.1 to ~20
+    assert int((x.norm(dim=-1) > 1).sum()) > 50 and int((x.norm(dim=-1) < 1).sum()) > 20
+    unit = lambda g: g / torch.clamp(g.norm(dim=-1, keepdim=True), min=1e-5)
+    # proposal network
+    prop, _ = build_nets(A, "small")
+    prop.train()
+    p_ = dev(x).requires_grad_(True)
+    dens = prop.forward(p_, contract=True)
+    got = RefNeRF.get_grad(dens, p_)
+    dens.sum().backward()                                                                           # (the dump is still there for the parameters)
+    assert float(prop._linear_layers()[0].weight.grad.abs().max()) > 0
+    sd = {k: v.double() for k, v in W.proposal_state("small").items()}
+    x64 = x.double().requires_grad_(True)
+    y = O.proposal_forward(sd, O.contract(x64))
+    g64, = torch.autograd.grad(y.sum(), x64)
+    assert max_abs(dens.detach().cpu().double(), y.detach()) <= 2e-5 * max(1.0, y.abs().max().item())
+    assert max_abs(got.cpu().double(), unit(g64)) <= 2e-3, max_abs(got.cpu().double(), unit(g64))
+    # Ref-NeRF
+    net = build_ref(A, "small")
+    d = F.normalize(torch.randn(M, 1, 3, generator=gen), dim=-1)
+    pos = dev(x).requires_grad_(True)
+    rgbo, nrm = net.forward(pos, dev(d), contract=True)
+    got_r = RefNeRF.get_grad(rgbo[..., -1], pos)
+    (rgbo.sum() + nrm.sum()).backward()
+    sdr = {k: v.double() for k, v in W.ref_state("small").items()}
+    x64 = x.double().requires_grad_(True)
+    want, _ = O.ref_forward(sdr, torch.cat((O.contract(x64), d.double()), -1))
+    g64, = torch.autograd.grad(want[..., -1].sum(), x64)
+    assert max_abs(rgbo.detach().cpu().double(), want.detach()) <= 2e-5 * max(1.0, want.abs().max().item())
+    assert max_abs(got_r.cpu().double(), unit(g64)) <= 2e-3, max_abs(got_r.cpu().double(), unit(g64))
+    with torch.no_grad():                                                                           # eval path takes the flag too
+        e_rgbo, _ = net.forward(dev(x), dev(d), contract=True)
+    assert max_abs(e_rgbo.cpu().double(), want.detach()) <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 # HIP fp32 gradient vs the fp64 value, relative to the tensor's largest entry (set from the measured values the test prints; a ReLU whose
 # pre-activation is within rounding of zero can fall on the other side in the kernel, which moves isolated entries by ~1e-3)
 G17_FP64_GATE = {k: 3e-4 for k in ("g_rho_tau", "g_rho_tau_bias", "g_spa2_6", "g_nct", "g_spec", "g_prop_head", "g_bottle", "g_dir0", "g_spa0", "g_prop_l0")}
@@ -1030,6 +1075,7 @@ def test_refnerf_train_step_vs_reference_golden(A, golden):
     net = RefNeRF(10, 4)
     net.load_state_dict(W.ref_state("small"))
     prop, net = prop.cuda().train(), net.cuda().train()
+    net.noise_rng = "torch"                              # the recorded perturbation enters through torch.normal (default: in-kernel Philox)
     rays, zc, tgt = dev(g["rays"]), dev(g["z_coarse"]), dev(g["rgb_tgt"])
     noise = dev(g["noise"])
     C17 = zc.shape[-1]
@@ -1883,6 +1929,62 @@ def test_generic_route_draws_the_fused_kernels_philox_streams(A):
         assert torch.equal(a, img)
 
 
+def test_bottle_neck_noise_in_kernel_philox(A):
+    """Ref-NeRF's train-mode bottle-neck perturbation (ref_model.py:84-85) drawn INSIDE the training forward (round 5): (i) the deviates as
+    a tensor (nerf_amd_philox_normal) equal the oracle's restatement of Philox -> 16-bit uniforms -> Box-Muller to the hardware
+    transcendentals' accuracy, for any sample offset and with the key in device memory; (ii) the training forward that draws them in
+    place is BIT-IDENTICAL -- outputs, aux record, activation dump, ReLU masks -- to the same forward handed that tensor, fp32 and bf16;
+    (iii) the module: reproducible under torch.manual_seed, another seed = another perturbation, `noise_rng = "torch"` restores the
+    device-generator draw; gradients flow (the backward needs no noise: the dump holds the perturbed bottle-neck)."""
+    seed, std = 0x1234567890ABCDEF, 0.1
+    want = O.philox_normal(seed, 300, std, 0)
+    got = A.ops.philox_normal(300, std, seed)
+    assert max_abs(got.cpu(), want) <= 2e-5 * std * 10 and float(got.std()) > 0.09
+    off = (1 << 33) + 77
+    assert max_abs(A.ops.philox_normal(40, std, seed, sample_offset=off).cpu(), O.philox_normal(seed, 40, std, off)) <= 2e-5
+    assert torch.equal(A.ops.philox_normal(100, std, seed)[60:], A.ops.philox_normal(40, std, seed, sample_offset=60))
+    sd = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64).cuda()
+    assert torch.equal(A.ops.philox_normal(300, std, seed_dev=sd), got)
+    net = build_ref(A, "small").train()
+    gen = torch.Generator().manual_seed(9)
+    M = 1000                                                  # ragged: not a tile multiple
+    pts = torch.cat((torch.rand(M, 3, generator=gen) * 2 - 1, F.normalize(torch.randn(M, 3, generator=gen), dim=-1)), -1).cuda()
+    for P in (A.ops.F32, A.ops.BF16):
+        blob = net.packed(P)
+        noise = A.ops.philox_normal(M, std, seed)
+        a = A.ops.ref_forward_train(blob, P, pts, noise, net.kernel_flags)
+        a = [t.clone() for t in a]                            # (the dump is a lease on a persistent buffer: copy before the next forward reuses it)
+        b = A.ops.ref_forward_train(blob, P, pts, None, net.kernel_flags, noise_std=std, noise_seed=seed)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        c = A.ops.ref_forward_train(blob, P, pts, None, net.kernel_flags, noise_std=std, noise_seed_dev=sd)
+        assert torch.equal(a[0], c[0])
+        e = A.ops.ref_forward_train(blob, P, pts, None, net.kernel_flags)                    # no perturbation at all
+        assert not torch.equal(a[0], e[0])
+    A.pkg.set_precision("fp32")
+    pos, d = pts[None, :, :3].contiguous(), pts[None, :, 3:].contiguous()
+    outs = []
+    for s_ in (11, 11, 12):
+        torch.manual_seed(s_)
+        p_ = pos.clone().requires_grad_(True)
+        rgbo, nrm = net.forward(p_, d)
+        outs.append(rgbo.detach().clone())
+        (rgbo.sum() + nrm.sum()).backward()
+        assert float(net.bottle_neck.weight.grad.abs().max()) > 0
+        net.zero_grad()
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    with torch.no_grad():                                     # train mode without gradients: the same perturbation as a tensor into the plain kernel
+        torch.manual_seed(11)
+        rn, _ = net.forward(pos, d)
+    assert max_abs(rn, outs[0]) <= 1e-6
+    net.noise_rng = "torch"
+    torch.manual_seed(11); torch.cuda.manual_seed(3)
+    t1 = net.forward(pos.clone().requires_grad_(True), d)[0].detach().clone()
+    torch.manual_seed(11); torch.cuda.manual_seed(4)
+    t2 = net.forward(pos.clone().requires_grad_(True), d)[0].detach().clone()
+    assert not torch.equal(t1, t2) and not torch.equal(t1, outs[0])       # (the device generator's stream now)
+
+
 def test_philox_uniforms_are_uniform():
     """Statistical sanity of the in-kernel stream (through its oracle twin, bit-equal to the kernels by the test above): one-sample
     Kolmogorov-Smirnov against U[0,1) on 1.2e6 draws of each stream, lag-1 / cross-stream correlations, and the 24-bit lattice."""
@@ -2429,6 +2531,7 @@ def test_refnerf_outside_the_compiled_shapes(A, golden, L, deg, width, srgb):
     noisy = RefNeRF(L, deg, hidden_unit=width, output_dim=width, use_srgb=srgb, perturb_bottle_neck_w=0.1)
     noisy.load_state_dict(sd)
     noisy = noisy.cuda().train()
+    noisy.noise_rng = "torch"
     torch.manual_seed(5); torch.cuda.manual_seed(5)
     with torch.no_grad():
         rn, _ = noisy.forward(pos, dirs)
@@ -2475,6 +2578,7 @@ def test_refnerf_train_step_outside_the_compiled_shapes(A):
     prop.load_state_dict(psd); net.load_state_dict(rsd)
     assert prop._generic() and net._generic()
     prop, net = prop.cuda().train(), net.cuda().train()
+    net.noise_rng = "torch"
     dirs = F.normalize(torch.randn(N, 3, generator=gen) * 0.3 + torch.tensor([0.0, 0.0, -1.0]), dim=-1) * (0.8 + 0.4 * torch.rand(N, 1, generator=gen))
     rays_c = torch.cat((torch.tensor([0.0, 0.0, 4.0]).expand(N, 3) + 0.1 * torch.randn(N, 3, generator=gen), dirs), dim=-1).contiguous()
     zc_c = (torch.linspace(NEAR, FAR - (FAR - NEAR) / C, C) + torch.rand(N, C, generator=gen) * (FAR - NEAR) / C).contiguous()

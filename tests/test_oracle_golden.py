@@ -369,3 +369,19 @@ def test_g22_refnerf_outside_the_compiled_shapes(golden, L, deg, width, srgb):
         got = sd[name].grad[: want.shape[0]]
         assert tuple(got.shape) == tuple(want.shape), key
         assert max_abs(got, want) <= 1e-4 * sc(want), (key, max_abs(got, want), sc(want))
+
+
+def test_philox_normal_is_normal():
+    """The in-kernel bottle-neck perturbation (oracle twin of device_common.h philox_normal8; the GPU test compares the kernel with it):
+    zero mean, unit variance, Kolmogorov-Smirnov against N(0, 1), no correlation between features / neighbouring samples, the 4.85 sigma
+    bound of 16-bit Box-Muller uniforms, and the documented feature -> (block, element) map."""
+    import numpy as np
+    from scipy import stats
+    from oracle import nerf_oracle as O
+    z = O.philox_normal(20260930, 4000, 1.0, 123).numpy().astype(np.float64)
+    assert z.shape == (4000, 128) and abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3 and np.abs(z).max() < 4.86
+    assert stats.kstest(z.ravel(), "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.06 and abs(np.corrcoef(z[:-1].ravel(), z[1:].ravel())[0, 1]) < 5e-3
+    assert abs(stats.kurtosis(z.ravel())) < 0.03
+    half = O.philox_normal(20260930, 2000, 0.5, 123 + 2000).numpy()                      # std scales, the sample offset shifts the rows
+    assert np.allclose(half, 0.5 * z[2000:], atol=1e-6)
