@@ -47,3 +47,18 @@ def golden():
 
 def max_abs(a, b):
     return (a.double() - b.double()).abs().max().item()
+
+
+def gate(name, value, limit):
+    """assert value <= limit AND leave the measured value on record (a gate that prints nothing cannot be told from a slack
+    one): one line per gate on stdout (`pytest -s` / the failure report) and in gpurun_out/measured_gates.log when that directory exists."""
+    line = "GATE %-72s measured %.3e  limit %.1e  (%.0f %% of the limit)" % (name, value, limit, 100.0 * value / limit if limit else 0.0)
+    print(line)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, "measured_gates.log"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+    assert value <= limit, line

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 import weights as W
-from conftest import max_abs
+from conftest import max_abs, gate
 from oracle import nerf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -295,15 +295,18 @@ def test_config4_full_size_contracted_render_properties(A):
                                                              white_bkg=True, contracted=True)
             # 'he' weights (O(1) activations through ten PE octaves) with depths out to 30: the fp32 oracle itself is only defined to a few
             # 1e-4 there (tests/test_gpu_parity.py::test_he_weights_conditioning); the 1e-4 gate is taken on reference-style weights below
-            assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-3 and max_abs(w[pick].cpu(), want_w) <= 1e-3
-            assert max_abs(depth[pick].cpu(), want_depth) <= 5e-3
+            gate("config4 contracted 'he' full size: rgb vs oracle", max_abs(rgb_w[pick].cpu(), want_rgb), 1e-3)
+            gate("config4 contracted 'he' full size: weights vs oracle", max_abs(w[pick].cpu(), want_w), 1e-3)
+            gate("config4 contracted 'he' full size: depth vs oracle", max_abs(depth[pick].cpu(), want_depth), 5e-4)      # (measured 4.2e-5; was 5e-3)
             prop_s, mip_s = build_nets(A, "small", train=False)
             rgb_s2, depth_s2, w_s2, _ = A.ops.render_rays(prop_s.packed(P), mip_s.packed(P), P, R[pick.cuda()].contiguous(), z_base, u1[pick].cuda(), u2[pick].cuda(),
                                                          128, near, far, True, want_depth=True, want_weights=True, contract=True)
             with torch.no_grad():
                 want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("small"), W.mip_state("small"), R[pick].cpu(), u1[pick], u2[pick], near, far, 128,
                                                              white_bkg=True, contracted=True)
-            assert max_abs(rgb_s2.cpu(), want_rgb) <= 1e-4 and max_abs(w_s2.cpu(), want_w) <= 1e-4 and max_abs(depth_s2.cpu(), want_depth) <= 1e-3
+            gate("config4 contracted 'small' full size: rgb vs oracle", max_abs(rgb_s2.cpu(), want_rgb), 1e-4)
+            gate("config4 contracted 'small' full size: weights vs oracle", max_abs(w_s2.cpu(), want_w), 1e-4)
+            gate("config4 contracted 'small' full size: depth vs oracle (depths out to 30)", max_abs(depth_s2.cpu(), want_depth), 1e-4)   # (measured 1.0e-6; was 1e-3)
 
 
 def test_config3_full_size_refnerf_render_properties(A):
@@ -349,6 +352,6 @@ def test_config3_full_size_refnerf_render_properties(A):
             with torch.no_grad():
                 want_rgb, _, extras = O.render_rays_ref(W.proposal_state("small"), W.ref_state("small"), R[pick].cpu(), u1[pick], u2[pick], near, far, n_fine,
                                                         white_bkg=True, cam_z=pose[:, -2])
-            assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4
-            assert max_abs(depth[pick].cpu(), extras["depth_img"]) <= 1e-3
-            assert max_abs(nimg[pick].cpu(), extras["normal_img"]) <= 1e-4
+            gate("config3 Ref-NeRF full size: rgb vs oracle", max_abs(rgb_w[pick].cpu(), want_rgb), 1e-4)
+            gate("config3 Ref-NeRF full size: depth vs oracle", max_abs(depth[pick].cpu(), extras["depth_img"]), 1e-4)       # (measured 1.8e-7; was 1e-3)
+            gate("config3 Ref-NeRF full size: normal image vs oracle", max_abs(nimg[pick].cpu(), extras["normal_img"]), 1e-4)

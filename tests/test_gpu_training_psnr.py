@@ -170,6 +170,8 @@ def run_hip(views, seed, precision):
         loss.backward()
         opt.step()
         hist.append(loss_img.item())
+        if PROGRESS_EVERY and (it + 1) % PROGRESS_EVERY == 0:            # the same trajectory lines as run_oracle's: partial CPU runs pair with these
+            print("PROGRESS mode %s seed %d it %d train-psnr(last 200) %.3f" % (precision, seed, it + 1, psnr(sum(hist[-200:]) / len(hist[-200:]))), flush=True)
         if it + 1 in CHECKPOINTS:
             with torch.no_grad():
                 g = torch.Generator().manual_seed(99)
