@@ -1013,15 +1013,20 @@ __global__ __launch_bounds__(P::NW * 64) void ref_kernel(const void* __restrict_
         uint32_t mreg[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) mreg[t] = 0u;
+        uint32_t mrec[NT][4];
         auto put = [&](BReg (&buf)[NT][16], int layer, int fb, int t, const f32x16& acc, int half) {
             const int kg = 2 * fb + half;
             buf[t][kg] = to_breg_half<P, true>(acc, half);
             if constexpr (TRAIN) {
                 dump_breg<P>(dump, layer, sub0 + t, kg, lane, buf[t][kg]);
                 mreg[t] |= breg_bits(buf[t][kg]) << (4 * (kg & 3));
-                if ((kg & 3) == 3) {
-                    *reinterpret_cast<uint32_t*>(dump.mask_base + (size_t)layer * dump.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16 + (kg >> 2) * 4) = mreg[t];
+                if ((kg & 3) == 3) {                               // the dword of K groups kg - 3 .. kg is complete
+                    mrec[t][kg >> 2] = mreg[t];
                     mreg[t] = 0u;
+                    if (kg == 15) {                                // ... and so is the lane's 16-byte record: ONE store per layer and subtile (it was four)
+                        const u32x4 rec = {mrec[t][0], mrec[t][1], mrec[t][2], mrec[t][3]};
+                        *reinterpret_cast<u32x4*>(dump.mask_base + (size_t)layer * dump.mask_layer_stride + (size_t)(sub0 + t) * 1024 + lane * 16) = rec;
+                    }
                 }
             }
         };
