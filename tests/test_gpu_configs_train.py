@@ -355,3 +355,45 @@ def test_config3_full_size_refnerf_render_properties(A):
             gate("config3 Ref-NeRF full size: rgb vs oracle", max_abs(rgb_w[pick].cpu(), want_rgb), 1e-4)
             gate("config3 Ref-NeRF full size: depth vs oracle", max_abs(depth[pick].cpu(), extras["depth_img"]), 1e-4)       # (measured 1.8e-7; was 1e-3)
             gate("config3 Ref-NeRF full size: normal image vs oracle", max_abs(nimg[pick].cpu(), extras["normal_img"]), 1e-4)
+
+
+def test_refnerf_train_step_with_scene_contraction(A):
+    """VERDICT r4 missing #4: TrainStep wired IPE / contraction for the MipNeRF branch only.  The Ref-NeRF branch (train.py:176-187 with
+    prop_normal) now takes `contract=True`: proposal and Ref-NeRF forwards contract their positions in the sample fetch, both
+    density-gradient normals differentiate through the contraction, the bottle-neck noise is drawn in-kernel from the step's device seed.
+    Eager iterations are finite and move the parameters; the iteration replayed from a hipGraph equals the eager one from the same state."""
+    from nerf_amd.optim import Adam
+    from nerf_amd.ref_model import RefNeRF
+    A.pkg.set_precision("fp32")
+    focal = O.fov2focal(0.6911112070083618, (40, 40))
+    pose = O.pose_spherical(20.0, -30.0, 4.0)[:3].contiguous().cuda()
+    img = (torch.rand(3, 40, 40, generator=torch.Generator().manual_seed(5)) * 0.2 + 0.4).cuda()
+
+    def run(graphed, iters):
+        prop, _ = build_nets(A, "small", train=True)
+        net = RefNeRF(10, 4)
+        net.load_state_dict(W.ref_state("small"))
+        net = net.cuda().train()
+        opt = Adam(list(net.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+        st = A.training.TrainStep(prop, net, opt, (40, 40), focal, 0.2, 30.0, ray_num=64, coarse_pnum=32, fine_pnum=32, seed=31, prop_normal=True, contract=True)
+        assert st.is_ref and st.contract
+        st.set_image(img, pose)
+        if graphed:
+            st.capture(warmup=2)
+        losses = [float(st()[0].item()) for _ in range(iters - (2 if graphed else 0))]
+        return net, prop, losses
+
+    net_e, prop_e, loss_e = run(False, 5)
+    assert all(l == l and abs(l) < 1e3 for l in loss_e)
+    ref0 = W.ref_state("small")
+    assert any(float((p.detach().cpu() - ref0[k]).abs().max()) > 0 for k, p in net_e.named_parameters())
+    net_g, prop_g, loss_g = run(True, 5)
+    for a, b in zip(list(net_g.parameters()) + list(prop_g.parameters()), list(net_e.parameters()) + list(prop_e.parameters())):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    # without the flag the same step is another computation (unbounded depths really reach |x| > 1)
+    prop, _ = build_nets(A, "small", train=True)
+    net = RefNeRF(10, 4); net.load_state_dict(W.ref_state("small")); net = net.cuda().train()
+    opt = Adam(list(net.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
+    st = A.training.TrainStep(prop, net, opt, (40, 40), focal, 0.2, 30.0, ray_num=64, coarse_pnum=32, fine_pnum=32, seed=31, prop_normal=True)
+    st.set_image(img, pose)
+    assert abs(float(st()[0].item()) - loss_e[0]) > 1e-7

@@ -477,7 +477,7 @@ def test_device_resident_train_step_refnerf_branch():
 @pytest.mark.parametrize("branch", ["mip", "ref"])
 def test_train_step_losses_equal_the_oracles_step_on_the_same_draws(branch):
     """TrainStep's iteration against the oracle's restatement of train.py:164-199 on IDENTICAL rays, coarse depths, uniforms (and bottle-neck
-    noise): the in-kernel draws are functions of the device seed, so the test re-derives them with the same entry points and hands them to
+    noise, in-kernel Philox since round 5): the in-kernel draws are functions of the device seed, so the test re-derives them with the same entry points and hands them to
     the oracle.  The Ref-NeRF branch includes the reference's positional quirk (train.py:182: `mip_net.density_act` lands in `mul_norm`, so
     the depths are NOT scaled by |d|) -- with un-normalised ray directions a scaled composite gives another loss, so this pins it."""
     if not torch.cuda.is_available():
@@ -516,13 +516,10 @@ def test_train_step_losses_equal_the_oracles_step_on_the_same_draws(branch):
     fx, fy = float(focal[1]), float(focal[0])
     _, z_c, tgt, rays = ops.sample_training_rays_dev(pixels, coords, pose, fx, fy, NEAR, FAR, N, C_N, seed)
     u = ops.philox_uniforms((N, F_N + 1), seed_dev=seed)
-    noise = (torch.randn(N, F_N + C_N, 128, generator=torch.Generator().manual_seed(8)) * 0.1).cuda()
-    real_normal = torch.normal
-    torch.normal = lambda *a, **k: noise
-    try:
-        loss, img_loss = step()
-    finally:
-        torch.normal = real_normal
+    # the bottle-neck perturbation too (round 5): drawn inside the training forward from the step's device seed and the sample index --
+    # the same deviates as a tensor for the oracle (RefNeRF's default noise std 0.1; sample m = ray * (F_N + C_N) + position in the merged row)
+    noise = ops.philox_normal(N * (F_N + C_N), 0.1, seed_dev=seed).view(N, F_N + C_N, 128)
+    loss, img_loss = step()
     rays_c, zc_c, tgt_c, u_c = rays.cpu(), z_c.cpu(), tgt.cpu(), u.cpu()
     if branch == "ref":
         out = O.ref_train_step(W.proposal_state("small"), W.ref_state("small"), rays_c, zc_c, u_c, noise.cpu(), tgt_c, F_N)
