@@ -25,13 +25,10 @@
 
 namespace {
 
-#ifndef GK_GBK
-#define GK_GBK 32
-#endif
-// contraction elements per LDS stage: 32.  -DGK_GBK=64 (two 32-wide sub-tiles per stage, twice the loads in flight) was measured on the box
+// contraction elements per LDS stage: 32.  A 64-wide stage (two 32-wide sub-tiles, twice the loads in flight) was measured and retired
 // (profiles/r04_generic_gemm_gbk64_relayout_ab.log): bf16 forward / input gradient unchanged (208 vs 210, 113 vs 113 TFLOP/s), weight gradient
 // +3 %, the fp32 parity mode 12-20 % SLOWER (one workgroup less per CU: 66 KiB of LDS) -> not the stage length that bounds this kernel.
-constexpr int GBM = 128, GBN = 128, GBK = GK_GBK;
+constexpr int GBM = 128, GBN = 128, GBK = 32;
 static_assert(GBK == 32 || GBK == 64, "GBK");
 
 struct GemmArgs {
