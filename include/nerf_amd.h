@@ -509,6 +509,11 @@ int nerf_amd_ref_combine_backward(const float* g_rgbo, int64_t g_stride, const f
 int nerf_amd_positional_encoding_backward(const float* d_enc, int64_t d_enc_stride, const float* x, int64_t x_stride, int64_t M, int L,
                                           int cat_origin, float* d_x, void* stream);
 int nerf_amd_add_rows(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int64_t M, int cols, void* stream);
+/* (ABI 123) Mip-NeRF 360 scene contraction as a stage of the layer-by-layer route (the fused kernels apply it in their sample fetch:
+ * nerf_amd_samples.contract): g == NULL -> out (M,3) = contract(x); g (M, g_stride >= 3) = a gradient w.r.t. contract(x) -> out (M,3) = its
+ * pull-back through the contraction's Jacobian (what RefNeRF.get_grad needs, ref_model.py:119-125).  Not in the reference (BASELINE
+ * configs[4]); the definition is oracle.contract. */
+int nerf_amd_contract_positions(const float* x, int64_t x_stride, int64_t M, const float* g, int64_t g_stride, float* out, void* stream);
 
 #ifdef __cplusplus
 }

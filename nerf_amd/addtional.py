@@ -119,10 +119,8 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
         BASELINE configs[4]): Mip-NeRF 360 scene contraction of the positions before the encoding."""
         self._check_config()
         if self._generic():
-            if contract:
-                raise NotImplementedError("nerf_amd: scene contraction is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
             from . import generic_path
-            return generic_path.proposal_forward(self, pts)
+            return generic_path.proposal_forward(self, pts, contract=contract)
         prec = ops.current_precision()
         layers = self._linear_layers()
         params = [l.weight for l in layers] + [l.bias for l in layers]

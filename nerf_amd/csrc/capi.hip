@@ -70,6 +70,7 @@ int gr_combine(const float*, int64_t, const float*, int64_t, int64_t, int, float
 int gr_combine_backward(const float*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, int, float*, int64_t, float*, int64_t, hipStream_t);
 int gr_pe_backward(const float*, int64_t, const float*, int64_t, int64_t, int, int, float*, hipStream_t);
 int gr_add_rows(float*, int64_t, const float*, int64_t, int64_t, int, hipStream_t);
+int gr_contract(const float*, int64_t, int64_t, const float*, int64_t, float*, hipStream_t);
 int sk_advance_seed(uint64_t*, hipStream_t);
 int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
@@ -130,7 +131,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 122; }
+int nerf_amd_version(void) { return 123; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -853,6 +854,12 @@ int nerf_amd_positional_encoding_backward(const float* d_enc, int64_t d_enc_stri
     if (M && (!d_enc || !x || !d_x)) return fail(NERF_AMD_EINVAL, "nerf_amd_positional_encoding_backward: NULL argument");
     if (d_enc_stride < 6 * L + (cat_origin ? 3 : 0) || x_stride < 3) return fail(NERF_AMD_EINVAL, "nerf_amd_positional_encoding_backward: row stride too small");
     return hip_status(gr_pe_backward(d_enc, d_enc_stride, x, x_stride, M, L, cat_origin ? 1 : 0, d_x, S(stream)), "nerf_amd_positional_encoding_backward");
+}
+
+int nerf_amd_contract_positions(const float* x, int64_t x_stride, int64_t M, const float* g, int64_t g_stride, float* out, void* stream) {
+    if (M < 0 || x_stride < 3 || (g && g_stride < 3)) return fail(NERF_AMD_EINVAL, "nerf_amd_contract_positions: bad size or stride");
+    if (M && (!x || !out)) return fail(NERF_AMD_EINVAL, "nerf_amd_contract_positions: NULL argument");
+    return hip_status(gr_contract(x, x_stride, M, g, g_stride, out, S(stream)), "nerf_amd_contract_positions");
 }
 
 int nerf_amd_add_rows(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int64_t M, int cols, void* stream) {

@@ -197,6 +197,33 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, 
 
 unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// Mip-NeRF 360 scene contraction (Barron et al. 2022, eq. 10; mlp_kernels.hip contract_position, the same operations in the same order)
+// for the layer-by-layer route, where it is a stage of its own in front of the encoder: out = contract(x) (g == nullptr), or the
+// pull-back of a gradient g w.r.t. contract(x) through the contraction's (symmetric) Jacobian: J = I inside the unit ball,
+// (2 - 1/r) / r (I - u u^T) + u u^T / r^2 outside (r = |x|, u = x / r).  One thread per position.
+__global__ __launch_bounds__(256) void contract_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, const float* __restrict__ g, int64_t ldg,
+                                                       float* __restrict__ out) {
+    for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+        const float x0 = x[m * ldx], x1 = x[m * ldx + 1], x2 = x[m * ldx + 2];
+        const float r = norm3(x0, x1, x2);
+        const float k = r > 1.0f ? (2.0f - 1.0f / r) / r : 1.0f;
+        if (g == nullptr) {
+            float o0 = x0, o1 = x1, o2 = x2;
+            if (r > 1.0f) { o0 *= k; o1 *= k; o2 *= k; }
+            out[m * 3] = o0; out[m * 3 + 1] = o1; out[m * 3 + 2] = o2;
+        } else {
+            float g0 = g[m * ldg], g1 = g[m * ldg + 1], g2 = g[m * ldg + 2];
+            if (r > 1.0f) {
+                const float u0 = x0 / r, u1 = x1 / r, u2 = x2 / r;
+                const float ug = (u0 * g0 + u1 * g1) + u2 * g2;
+                const float t = ug * (1.0f / (r * r) - k);
+                g0 = k * g0 + t * u0; g1 = k * g1 + t * u1; g2 = k * g2 + t * u2;
+            }
+            out[m * 3] = g0; out[m * 3 + 1] = g1; out[m * 3 + 2] = g2;
+        }
+    }
+}
+
 }  // namespace
 
 #define GR_DEG_SWITCH(CALL)                                                       \
@@ -243,6 +270,12 @@ int gr_combine_backward(const float* g, int64_t ldg, const float* heads, int64_t
 int gr_pe_backward(const float* d_enc, int64_t ldd, const float* x, int64_t ldx, int64_t M, int L, int cat_origin, float* d_x, hipStream_t st) {
     if (M == 0) return 0;
     hipLaunchKernelGGL(pe_backward_kernel, dim3(blocks(M * 3)), dim3(256), 0, st, d_enc, ldd, x, ldx, M, L, cat_origin, d_x);
+    return (int)hipGetLastError();
+}
+
+int gr_contract(const float* x, int64_t ldx, int64_t M, const float* g, int64_t ldg, float* out, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(contract_kernel, dim3(blocks(M)), dim3(256), 0, st, x, ldx, M, g, ldg, out);
     return (int)hipGetLastError();
 }
 

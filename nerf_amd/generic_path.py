@@ -10,8 +10,8 @@ modules, with no torch arithmetic and no library GEMM.  torch only owns the buff
 This is the COMPATIBILITY path of the shape arguments: activations make a round trip through HBM per layer (fp32 rows), so it runs at a
 fraction of the fused kernels' rate -- every shape the fused kernels are compiled for (widths <= 256, <= 10 octaves, either cat_origin)
 keeps them.  Sample positions get a gradient inside RefNeRF.get_grad only (d density / d position: a dgrad-only chain + the encoding's
-adjoint, like on the fused path; the reference's loss never uses another, utils.py:35-36); scene contraction and the integrated PE are
-flags of the fused kernels' sample fetch only.  RefNeRF takes this path as well (`ref_forward`: hidden width > 256, > 10 octaves, or
+adjoint, like on the fused path; the reference's loss never uses another, utils.py:35-36); scene contraction is a stage of its own in front of the
+encoder here (`ops.contract_positions`, round 5); the integrated PE is a flag of the fused kernels' sample fetch only.  RefNeRF takes this path as well (`ref_forward`: hidden width > 256, > 10 octaves, or
 `--ide_level 5`, whose 36 spherical-harmonic terms the fused kernel's three IDE K groups do not hold).
 """
 from typing import List, Tuple
@@ -63,15 +63,20 @@ def _chain_back(prec: int, delta: torch.Tensor, layers: List[torch.nn.Linear], i
 
 
 # ---------------------------------------------------------------------------------------------------------------- ProposalNetwork
-def proposal_forward(net, pts: torch.Tensor) -> torch.Tensor:
-    """ProposalNetwork.forward (addtional.py:88-96) for a generic-shape module: pts (N,C,3) -> density (N,C)."""
+def proposal_forward(net, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
+    """ProposalNetwork.forward (addtional.py:88-96) for a generic-shape module: pts (N,C,3) -> density (N,C).  `contract` (round 5):
+    Mip-NeRF 360 scene contraction as a stage in front of the encoder (ops.contract_positions; the fused kernels do it in their sample
+    fetch); get_grad pulls the encoding's gradient back through its Jacobian."""
     prec = ops.current_precision()
     layers = net._linear_layers()
     params = [l.weight for l in layers] + [l.bias for l in layers]
     shape = pts.shape[:-1]
 
     def run(p, keep=None):
-        x = _encode_positions(p.reshape(-1, 3).float(), net.position_flevel, net.cat_origin)
+        xc = p.reshape(-1, 3).float()
+        if contract:
+            xc = ops.contract_positions(xc)
+        x = _encode_positions(xc, net.position_flevel, net.cat_origin)
         acts = [x]
         for l in layers[:4]:
             acts.append(_linear(prec, acts[-1], l, RELU))
@@ -91,7 +96,10 @@ def proposal_forward(net, pts: torch.Tensor) -> torch.Tensor:
             acts = held["acts"]
             delta = ops.gemm(prec, g.reshape(-1, 1).float().contiguous(), layers[4].weight.detach(), mask=acts[4])
             d_enc, _ = _dgrad_only(prec, delta, layers[:4], acts[:4], acts[0].shape[1])
-            gx = ops.positional_encoding_backward(d_enc, p.reshape(-1, 3).float().contiguous(), net.position_flevel, net.cat_origin)
+            x_raw = p.reshape(-1, 3).float().contiguous()
+            gx = ops.positional_encoding_backward(d_enc, ops.contract_positions(x_raw) if contract else x_raw, net.position_flevel, net.cat_origin)
+            if contract:
+                gx = ops.contract_positions(x_raw, grad=gx)
             return (gx.view(p.shape), *[None] * len(wb))
         acts = held.pop("acts")
         ones = torch.ones((acts[0].shape[0], 1), dtype=torch.float32, device=g.device)
@@ -104,8 +112,9 @@ def proposal_forward(net, pts: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------------- MipNeRF
-def mip_forward(net, pts: torch.Tensor) -> torch.Tensor:
-    """MipNeRF.forward (mip_model.py:41-60) for a generic-shape module: pts (N,S,6) = [position | raw direction] -> (N,S,4)."""
+def mip_forward(net, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
+    """MipNeRF.forward (mip_model.py:41-60) for a generic-shape module: pts (N,S,6) = [position | raw direction] -> (N,S,4); `contract`:
+    scene contraction of the positions in front of the encoder (they carry no gradient on this path)."""
     prec = ops.current_precision()
     L = net._linear_layers()             # lin_block1 x4, lin_block2 x3, bottle_neck, opacity_head, rgb_layer.0, rgb_layer.2
     params = net._params()
@@ -114,7 +123,7 @@ def mip_forward(net, pts: torch.Tensor) -> torch.Tensor:
     def run(p, keep=None):
         p2 = p.reshape(-1, 6).float()
         M = p2.shape[0]
-        ex = _encode_positions(p2[:, :3], net.position_flevel, net.cat_origin)
+        ex = _encode_positions(ops.contract_positions(p2[:, :3]) if contract else p2[:, :3], net.position_flevel, net.cat_origin)
         ed = _encode_directions(p2[:, 3:6], net.cat_origin)
         E, W = ex.shape[1], net.hidden_unit
         a = [ex]
@@ -186,7 +195,7 @@ def _dgrad_only(prec: int, delta: torch.Tensor, layers, inputs, enc_cols: int):
     return d_enc, d_hid
 
 
-def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise) -> Tuple[torch.Tensor, torch.Tensor]:
+def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise, contract: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """RefNeRF.forward (ref_model.py:68-106) for a module the fused Ref-NeRF kernel is not compiled for (hidden width > 256, > 10 position
     octaves, ide_level 5): pos, dirs (N,S,3) -> ((N,S,4) = [rgb | raw density], predicted normal (N,S,3)).  Layer products on nerf_amd_gemm,
     the stages between them (normal / reflection / IDE / colour combination) on the element-wise kernels of generic_ref_kernels.hip; the
@@ -208,7 +217,8 @@ def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise) -> Tuple[torc
     table = net._ide_table(pos.device, deg)
 
     def run(p, dd, keep=None):
-        x = p.reshape(-1, 3).float().contiguous()
+        x_raw = p.reshape(-1, 3).float().contiguous()
+        x = ops.contract_positions(x_raw) if contract else x_raw             # (`contract`: the stage in front of the encoder, see proposal_forward)
         dv = dd.reshape(-1, 3).float().contiguous()
         M, dev = x.shape[0], x.device
         ex = _encode_positions(x, net.position_flevel, net.cat_origin)
@@ -243,7 +253,7 @@ def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise) -> Tuple[torc
         spec = _linear(prec, q[-1], sph, SIGMOID)
         rgbo = ops.ref_combine(heads, spec, flags)
         if keep is not None:
-            keep.update(x=x, dv=dv, a=a, b=b, heads=heads, r=r, q=q, spec=spec, E=E, w_heads=w_heads)
+            keep.update(x=x, x_raw=x_raw, dv=dv, a=a, b=b, heads=heads, r=r, q=q, spec=spec, E=E, w_heads=w_heads)
         return torch.cat((rgbo, normal), dim=-1).view(*shape, 7)
 
     if not ab.needs_grad(pos, dirs, *params):
@@ -264,9 +274,12 @@ def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise) -> Tuple[torc
             d_enc1, _ = _dgrad_only(prec, d_hid, S1, a[:4], E)
             ops.add_rows_(d_enc, d_enc1)
             gx = ops.positional_encoding_backward(d_enc, held["x"], net.position_flevel, net.cat_origin)
+            if contract:
+                gx = ops.contract_positions(held["x_raw"], grad=gx)
             return (gx.view(p.shape), None, *[None] * len(wb))
         heads, r, q, spec, w_heads = (held.pop(k) for k in ("heads", "r", "q", "spec", "w_heads"))
         x, dv = held.pop("x"), held.pop("dv")
+        held.pop("x_raw", None)
         held.pop("a"); held.pop("b")
         ones = torch.ones((M, 1), dtype=torch.float32, device=dev)
         G = {}

@@ -115,10 +115,8 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         `contract` (not in the reference; BASELINE configs[4]): Mip-NeRF 360 scene contraction of the positions before the encoding."""
         self._check_config()
         if self._generic():
-            if contract:
-                raise NotImplementedError("nerf_amd: scene contraction is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
             from . import generic_path
-            return generic_path.mip_forward(self, pts)
+            return generic_path.mip_forward(self, pts, contract=contract)
         prec = ops.current_precision()
         params = self._params()
         if ab.needs_grad(pts, *params):
@@ -144,9 +142,9 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         if rays.requires_grad or z.requires_grad:
             raise NotImplementedError("nerf_amd: MipNeRF.forward_rays differentiates the parameters only (rays / depths must not require grad)")
         if self._generic():
-            if contract or ipe_radius is not None:
-                raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
-            return self.forward(NeRF.length2pts(rays, z[:, :n_samples].contiguous()))
+            if ipe_radius is not None:
+                raise NotImplementedError("nerf_amd: the integrated PE is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+            return self.forward(NeRF.length2pts(rays, z[:, :n_samples].contiguous()), contract=contract)
         rays, z = ops._dev(rays, "rays"), ops._dev(z, "z")
         if ipe_radius is not None and ipe_dir_norm is None:
             ipe_dir_norm = ops.dirs_norm(rays)

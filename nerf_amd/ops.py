@@ -1132,6 +1132,19 @@ def positional_encoding_backward(d_enc: torch.Tensor, x: torch.Tensor, L: int, c
     return out
 
 
+def contract_positions(x: torch.Tensor, grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Mip-NeRF 360 scene contraction of (M,3) positions (grad None), or the pull-back of `grad` (M,3) = a gradient w.r.t. contract(x)
+    through the contraction's Jacobian (nerf_amd_contract_positions: the layer-by-layer route's stage; the fused kernels contract in
+    their sample fetch)."""
+    x = _rows(x, "x", 3)
+    M = x.shape[0]
+    out = torch.empty((M, 3), dtype=torch.float32, device=x.device)
+    g = _rows(grad, "grad", 3) if grad is not None else None
+    check(lib.nerf_amd_contract_positions(_ptr(x), int(x.stride(0)), M, _ptr(g), int(g.stride(0)) if g is not None else 0, _ptr(out), _stream()),
+          "nerf_amd_contract_positions")
+    return out
+
+
 def add_rows_(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """dst += src over (M, cols) fp32 device views with unit column stride"""
     if tuple(dst.shape) != tuple(src.shape) or dst.dim() != 2 or dst.dtype != torch.float32 or src.dtype != torch.float32 or not dst.is_cuda:

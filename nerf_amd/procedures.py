@@ -44,7 +44,7 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 
 def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096,
-                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None, ray_offset: int = 0):
+                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None, ray_offset: int = 0, contract: bool = False):
     """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
     maxBlurFilter, inverseSample, NeRF.length2pts, network.forward, NeRF.render -- on chunks of rays: the route of networks the fused
     render entry (nerf_amd_render_rays) has no packed layout for.  Every call is a HIP kernel of this package; uniforms that were not
@@ -63,17 +63,17 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
         u1 = u_strat[s: s + n] if u_strat is not None else ops.philox_stream((n, RENDER_COARSE_PNUM), seed, ray_offset + s, strat=True, device=rays.device)
         u2 = u_inv[s: s + n] if u_inv is not None else ops.philox_stream((n, sample_num + 1), seed, ray_offset + s, device=rays.device)
         z, pts = ops.stratified_points(r, z_base, u1.contiguous(), resolution)      # :65-66
-        density = prop_net.forward(pts)
+        density = prop_net.forward(pts, contract=True) if contract else prop_net.forward(pts)
         prop_w = maxBlurFilter(ProposalNetwork.get_weights(density, z, r[:, 3:]), 0.01)
         fine, _ = inverseSample(prop_w, z, sample_num + 1, sort=True, u=u2.contiguous())
         normal = None
         if is_ref_model:                                                             # :71-74
             samples, fine = NeRF.coarseFineMerge(r, z, fine)
-            rgbo, normal = network.forward(samples)
+            rgbo, normal = network.forward(samples, contract=True) if contract else network.forward(samples)
             rgbo[..., -1] = torch.nn.functional.softplus(rgbo[..., -1] + 0.5)
         else:
             fine = fine[..., :-1].contiguous()
-            rgbo = network.forward(NeRF.length2pts(r, fine))
+            rgbo = network.forward(NeRF.length2pts(r, fine), contract=True) if contract else network.forward(NeRF.length2pts(r, fine))
         part, _, extras = NeRF.render(rgbo, fine, r[:, 3:], white_bkg=white_bkg, density_act=torch.nn.functional.relu,
                                       render_depth=(near, far) if render_depth else None,
                                       normal_info=(normal, cam_dir) if cam_dir is not None else None)
@@ -152,12 +152,12 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     if generic:
         # a network LARGER than the fused kernels' compiled shapes (hidden width > 256, > 10 octaves): the reference's tile body
         # (procedures.py:62-85) call by call on the mirrored ops -- the networks run layer by layer (nerf_amd/generic_path.py)
-        if contract or ipe:
-            raise NotImplementedError("nerf_amd: scene contraction / integrated PE are flags of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+        if ipe:
+            raise NotImplementedError("nerf_amd: the integrated PE is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
         rgb, depth, normal_px = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth),
                                                       is_ref_model=is_ref_model,
                                                       cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed,
-                                                      ray_offset=off)
+                                                      ray_offset=off, contract=contract)
     elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,

@@ -179,10 +179,8 @@ class RefNeRF(PackedWeightsMixin, NeRF):
             else:
                 noise = torch.normal(0, self.perturb_bottle_neck_w, pos.shape[:-1] + (self.bottle_neck_dim,), device=pos.device)
         if self._generic():
-            if contract:
-                raise NotImplementedError("nerf_amd: scene contraction is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves, ide_level <= 4)")
             from . import generic_path
-            return generic_path.ref_forward(self, pos, d, noise)
+            return generic_path.ref_forward(self, pos, d, noise, contract=contract)
         named = list(self.named_parameters())
         params = [p for _, p in named]
         if ab.needs_grad(pos, d, *params):

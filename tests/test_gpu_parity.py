@@ -757,8 +757,9 @@ def test_error_reporting(A):
     with pytest.raises(NerfAmdError):
         A.ops.mip_forward_composite(build_nets(A, "small")[1].packed(A.ops.F32), A.ops.F32, torch.rand(4, 6).cuda(),
                                     torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
-    with pytest.raises(NotImplementedError):                           # scene contraction is a flag of the fused kernels' sample fetch only
-        A.addtional.ProposalNetwork(10, 512).cuda().forward(torch.rand(2, 3, 3).cuda(), contract=True)
+    with pytest.raises(NotImplementedError):                           # the integrated PE is a flag of the fused kernels' sample fetch only
+        A.mip_model.MipNeRF(10, 4, 512).cuda().eval().forward_rays(torch.rand(2, 6).cuda(), torch.rand(2, 5).cuda().sort(-1)[0], 4, ipe_radius=1e-3)
+    assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda() * 5, contract=True).shape == (2, 3)   # (round 5)
     assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # wider than compiled: generic path
     assert A.addtional.ProposalNetwork(10).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # class default 128: zero-padded
 
@@ -1021,6 +1022,60 @@ def _normals_close(name, got, want, x, g64):
     assert len(bad) <= 0.02 * err.numel(), (name, len(bad), info)
     if len(bad):
         print("contracted normals (%s): %d of %d samples beyond 2e-3 (index, |x|, error, |g64|): %s" % (name, len(bad), err.numel(), info))
+
+
+def test_scene_contraction_on_the_layer_by_layer_route(A):
+    """Round 5: scene contraction used to raise for every network outside the compiled shapes.  It is a stage in front of the encoder there
+    (nerf_amd_contract_positions; RefNeRF.get_grad pulls the encoding's gradient back through the contraction's Jacobian).  Width-320
+    networks (generic path) with contract=True: the stage itself and its pull-back against oracle.contract / fp64 autograd; proposal
+    density, its density-gradient normals and the MipNeRF output against the fp64 oracle on contracted positions; and the networks' whole
+    render_image(contract=True) against oracle.render_rays(contracted=True) on the Philox uniforms."""
+    from nerf_amd.addtional import ProposalNetwork
+    from nerf_amd.mip_model import MipNeRF
+    from nerf_amd.procedures import render_image
+    from nerf_amd.ref_model import RefNeRF
+    A.pkg.set_precision("fp32")
+    gen = torch.Generator().manual_seed(91)
+    M = 400
+    x = torch.randn(M, 3, generator=gen) * torch.linspace(0.2, 8.0, M)[:, None]
+    g = torch.randn(M, 3, generator=gen)
+    x64 = x.double().requires_grad_(True)
+    c64 = O.contract(x64)
+    (c64 * g.double()).sum().backward()
+    assert max_abs(A.ops.contract_positions(dev(x)).cpu(), c64.detach()) <= 2e-6
+    assert max_abs(A.ops.contract_positions(dev(x), grad=dev(g)).cpu(), x64.grad) <= 2e-6 * max(1.0, x64.grad.abs().max().item())
+    torch.manual_seed(17)
+    prop, mip = ProposalNetwork(10, 320).cuda().eval(), MipNeRF(10, 4, 320).cuda().eval()
+    assert prop._generic() and mip._generic()
+    psd = {k: v.detach().cpu() for k, v in prop.state_dict().items()}
+    msd = {k: v.detach().cpu() for k, v in mip.state_dict().items()}
+    unit = lambda v: v / torch.clamp(v.norm(dim=-1, keepdim=True), min=1e-5)
+    p_ = dev(x[:, None, :]).requires_grad_(True)
+    dens = prop.forward(p_, contract=True)
+    got_n = RefNeRF.get_grad(dens, p_)
+    x64 = x[:, None, :].double().requires_grad_(True)
+    y = O.proposal_forward({k: v.double() for k, v in psd.items()}, O.contract(x64))
+    g64, = torch.autograd.grad(y.sum(), x64)
+    assert max_abs(dens.detach().cpu().double(), y.detach()) <= 2e-5 * max(1.0, y.abs().max().item())
+    _normals_close("generic proposal", got_n.cpu().double(), unit(g64), x, g64)
+    d = F.normalize(torch.randn(M, 3, generator=gen), dim=-1)
+    with torch.no_grad():
+        rgbo = mip.forward(dev(torch.cat((x, d), -1)[:, None, :]), contract=True)
+        want = O.mip_forward({k: v.double() for k, v in msd.items()}, torch.cat((O.contract(x.double()), d.double()), -1)[:, None, :])
+    assert max_abs(rgbo.cpu().double(), want) <= 2e-5 * max(1.0, want.abs().max().item())
+    # the whole render: 40 x 40, unbounded depths, Philox uniforms re-derived for the oracle
+    pose = O.pose_spherical(20.0, -30.0, 4.0)
+    focal = O.fov2focal(0.6911112070083618, (40, 40))
+    near, far, n_f, seed = 0.2, 30.0, 64, 777
+    with torch.no_grad():
+        res = render_image(mip, prop, pose.cuda(), 40, focal, near, far, n_f, white_bkg=True, render_depth=True, contract=True, seed=seed)
+    fx, fy = (float(focal[1]), float(focal[0])) if isinstance(focal, (tuple, list)) else (float(focal), float(focal))
+    rays = A.ops.generate_rays(pose[:3].cuda(), 40, 40, fx, fy, torch.device("cuda", 0)).cpu()          # 40 % 40 == 0: ONE tile = raster order
+    u1, u2 = O.philox_uniforms(seed, 1600, 0, 64, n_f + 1)
+    with torch.no_grad():
+        w_rgb, _, w_depth = O.render_rays(psd, msd, rays, u1, u2, near, far, n_f, white_bkg=True, contracted=True)
+    gate("generic-route contracted render_image: rgb vs oracle", max_abs(res["rgb"].cpu(), w_rgb.view(40, 40, 3).permute(2, 0, 1)), 1e-4)
+    gate("generic-route contracted render_image: depth vs oracle", max_abs(res["depth_img"][0].cpu(), w_depth.view(40, 40)), 1e-4)
 
 
 def test_density_gradient_normals_through_the_scene_contraction(A):
@@ -2489,8 +2544,9 @@ def test_networks_larger_than_the_compiled_shapes(A, L, cat, w_mip, w_prop):
     assert max_abs(yb[..., :3].cpu(), want_y[..., :3]) <= 0.06
     with pytest.raises(NotImplementedError):                                          # no position gradient on the generic path: refused at forward time
         mip.train().forward(pts.cuda().requires_grad_(True))
-    with pytest.raises(NotImplementedError):
-        mip.forward(pts.cuda(), contract=True)
+    with torch.no_grad():                                                             # scene contraction: a stage in front of the encoder on this path
+        yc = mip.eval().forward(pts.cuda() * 4.0, contract=True)                     # (values: test_scene_contraction_on_the_layer_by_layer_route)
+    assert yc.shape == want_y.shape and bool(torch.isfinite(yc).all())
 
 
 @pytest.mark.parametrize("L,deg,width,srgb", [(10, 5, 256, False), (10, 4, 320, False), (11, 3, 288, True)])
