@@ -112,9 +112,11 @@ def proposal_forward(net, pts: torch.Tensor, contract: bool = False) -> torch.Te
 
 
 # ---------------------------------------------------------------------------------------------------------------- MipNeRF
-def mip_forward(net, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
+def mip_forward(net, pts: torch.Tensor, contract: bool = False, encoded_x: torch.Tensor = None) -> torch.Tensor:
     """MipNeRF.forward (mip_model.py:41-60) for a generic-shape module: pts (N,S,6) = [position | raw direction] -> (N,S,4); `contract`:
-    scene contraction of the positions in front of the encoder (they carry no gradient on this path)."""
+    scene contraction of the positions in front of the encoder (they carry no gradient on this path); `encoded_x` (N,S,6 L): the
+    encoding columns that follow the position, given instead of positional_encoding(position) -- the integrated PE of
+    MipNeRF.forward_rays(ipe_radius=...) (mip_methods.py:47-58 through nerf_amd_ipe_feature), with the frustum mean as the position."""
     prec = ops.current_precision()
     L = net._linear_layers()             # lin_block1 x4, lin_block2 x3, bottle_neck, opacity_head, rgb_layer.0, rgb_layer.2
     params = net._params()
@@ -123,7 +125,11 @@ def mip_forward(net, pts: torch.Tensor, contract: bool = False) -> torch.Tensor:
     def run(p, keep=None):
         p2 = p.reshape(-1, 6).float()
         M = p2.shape[0]
-        ex = _encode_positions(ops.contract_positions(p2[:, :3]) if contract else p2[:, :3], net.position_flevel, net.cat_origin)
+        if encoded_x is not None:
+            enc = encoded_x.reshape(M, -1).float()
+            ex = torch.cat((p2[:, :3], enc), dim=-1) if net.cat_origin else enc.contiguous()
+        else:
+            ex = _encode_positions(ops.contract_positions(p2[:, :3]) if contract else p2[:, :3], net.position_flevel, net.cat_origin)
         ed = _encode_directions(p2[:, 3:6], net.cat_origin)
         E, W = ex.shape[1], net.hidden_unit
         a = [ex]

@@ -143,7 +143,13 @@ class MipNeRF(PackedWeightsMixin, NeRF):
             raise NotImplementedError("nerf_amd: MipNeRF.forward_rays differentiates the parameters only (rays / depths must not require grad)")
         if self._generic():
             if ipe_radius is not None:
-                raise NotImplementedError("nerf_amd: the integrated PE is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+                # layer-by-layer route: the stand-alone integrated-PE encoder (nerf_amd_ipe_feature) feeds [frustum mean | feature] to the layers
+                if contract:
+                    raise NotImplementedError("nerf_amd: integrated PE WITH scene contraction is a combination of the fused kernels' sample fetch only")
+                from . import generic_path
+                feat, mu, _ = ops.ipe_feature(z[:, : n_samples + 1].contiguous(), rays, self.position_flevel, float(ipe_radius), ipe_dir_norm)
+                pts = torch.cat((mu, rays[:, None, 3:6].expand(-1, n_samples, -1)), dim=-1).contiguous()
+                return generic_path.mip_forward(self, pts, encoded_x=feat)
             return self.forward(NeRF.length2pts(rays, z[:, :n_samples].contiguous()), contract=contract)
         rays, z = ops._dev(rays, "rays"), ops._dev(z, "z")
         if ipe_radius is not None and ipe_dir_norm is None:

@@ -44,7 +44,8 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
 
 
 def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096,
-                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None, ray_offset: int = 0, contract: bool = False):
+                          is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None, ray_offset: int = 0, contract: bool = False,
+                          ipe_radius: Optional[float] = None, ipe_dir_norm=None):
     """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
     maxBlurFilter, inverseSample, NeRF.length2pts, network.forward, NeRF.render -- on chunks of rays: the route of networks the fused
     render entry (nerf_amd_render_rays) has no packed layout for.  Every call is a HIP kernel of this package; uniforms that were not
@@ -71,6 +72,9 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
             samples, fine = NeRF.coarseFineMerge(r, z, fine)
             rgbo, normal = network.forward(samples, contract=True) if contract else network.forward(samples)
             rgbo[..., -1] = torch.nn.functional.softplus(rgbo[..., -1] + 0.5)
+        elif ipe_radius is not None:                                                  # frusta between the sample_num + 1 sorted depths
+            rgbo = network.forward_rays(r, fine.contiguous(), sample_num, ipe_radius=ipe_radius, ipe_dir_norm=ipe_dir_norm)
+            fine = fine[..., :-1].contiguous()
         else:
             fine = fine[..., :-1].contiguous()
             rgbo = network.forward(NeRF.length2pts(r, fine), contract=True) if contract else network.forward(NeRF.length2pts(r, fine))
@@ -152,12 +156,13 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     if generic:
         # a network LARGER than the fused kernels' compiled shapes (hidden width > 256, > 10 octaves): the reference's tile body
         # (procedures.py:62-85) call by call on the mirrored ops -- the networks run layer by layer (nerf_amd/generic_path.py)
-        if ipe:
-            raise NotImplementedError("nerf_amd: the integrated PE is a flag of the fused kernels' sample fetch (hidden width <= 256, <= 10 octaves)")
+        if ipe and contract:
+            raise NotImplementedError("nerf_amd: integrated PE WITH scene contraction is a combination of the fused kernels' sample fetch only")
         rgb, depth, normal_px = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth),
                                                       is_ref_model=is_ref_model,
                                                       cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed,
-                                                      ray_offset=off, contract=contract)
+                                                      ray_offset=off, contract=contract, ipe_radius=ipe_radius,
+                                                      ipe_dir_norm=ops.dirs_norm(rays) if ipe_radius is not None else None)   # (mip_methods.py:31: ONE norm over the call's rays)
     elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,

@@ -757,8 +757,8 @@ def test_error_reporting(A):
     with pytest.raises(NerfAmdError):
         A.ops.mip_forward_composite(build_nets(A, "small")[1].packed(A.ops.F32), A.ops.F32, torch.rand(4, 6).cuda(),
                                     torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
-    with pytest.raises(NotImplementedError):                           # the integrated PE is a flag of the fused kernels' sample fetch only
-        A.mip_model.MipNeRF(10, 4, 512).cuda().eval().forward_rays(torch.rand(2, 6).cuda(), torch.rand(2, 5).cuda().sort(-1)[0], 4, ipe_radius=1e-3)
+    with pytest.raises(NotImplementedError):                           # integrated PE WITH contraction: the fused kernels' sample fetch only
+        A.mip_model.MipNeRF(10, 4, 512).cuda().eval().forward_rays(torch.rand(2, 6).cuda(), torch.rand(2, 5).cuda().sort(-1)[0], 4, ipe_radius=1e-3, contract=True)
     assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda() * 5, contract=True).shape == (2, 3)   # (round 5)
     assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # wider than compiled: generic path
     assert A.addtional.ProposalNetwork(10).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # class default 128: zero-padded
@@ -1076,6 +1076,16 @@ def test_scene_contraction_on_the_layer_by_layer_route(A):
         w_rgb, _, w_depth = O.render_rays(psd, msd, rays, u1, u2, near, far, n_f, white_bkg=True, contracted=True)
     gate("generic-route contracted render_image: rgb vs oracle", max_abs(res["rgb"].cpu(), w_rgb.view(40, 40, 3).permute(2, 0, 1)), 1e-4)
     gate("generic-route contracted render_image: depth vs oracle", max_abs(res["depth_img"][0].cpu(), w_depth.view(40, 40)), 1e-4)
+    # ... and the integrated PE (mip_methods.py:15-58) on the same route: the stand-alone encoder feeds [frustum mean | feature] to the layers
+    near, far = 2.0, 6.0
+    radius = 2.0 / (12.0 ** 0.5) / fx
+    with torch.no_grad():
+        res = render_image(mip, prop, pose.cuda(), 40, focal, near, far, n_f, white_bkg=True, render_depth=True, ipe=True, seed=seed)
+        w_rgb, _, w_depth = O.render_rays(psd, msd, rays, u1, u2, near, far, n_f, white_bkg=True, ipe_radius=radius)
+    gate("generic-route integrated-PE render_image: rgb vs oracle", max_abs(res["rgb"].cpu(), w_rgb.view(40, 40, 3).permute(2, 0, 1)), 1e-4)
+    gate("generic-route integrated-PE render_image: depth vs oracle", max_abs(res["depth_img"][0].cpu(), w_depth.view(40, 40)), 1e-4)
+    with pytest.raises(NotImplementedError):                                  # the COMBINATION stays with the fused kernels' sample fetch
+        render_image(mip, prop, pose.cuda(), 40, focal, near, far, n_f, ipe=True, contract=True)
 
 
 def test_density_gradient_normals_through_the_scene_contraction(A):
