@@ -26,7 +26,9 @@ def stats(xs):
 
 
 def main():
-    files = sorted(glob.glob(os.path.join(D, "cpu_seed*.log"))) + sorted(glob.glob(os.path.join(D, "hip_10000_seeds*.log")))
+    # (the box-host partial runs first: a container run of the same seed, when it exists, overrides them iteration by iteration)
+    files = sorted(glob.glob(os.path.join(D, "box_host_partial", "cpu_seed*.log"))) + sorted(glob.glob(os.path.join(D, "cpu_seed*.log"))) + \
+        sorted(glob.glob(os.path.join(D, "hip_10000_seeds*.log")))
     prog = {}                                                  # mode -> seed -> {iteration: train psnr}
     done = {}
     for f in files:
