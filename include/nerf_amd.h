@@ -515,6 +515,30 @@ int nerf_amd_add_rows(float* dst, int64_t dst_stride, const float* src, int64_t 
  * configs[4]); the definition is oracle.contract. */
 int nerf_amd_contract_positions(const float* x, int64_t x_stride, int64_t M, const float* g, int64_t g_stride, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Layer products on bf16 rows (ABI 124): the INFERENCE route of the networks above under bf16 precision (forward only; nerf_amd_gemm
+ * stays the fp32 parity mode and the backward).  One nn.Linear (+ activation) of mip_model.py:41-60 / addtional.py:88-96 /
+ * ref_model.py:68-106:
+ *
+ *     C[m, n] = act( sum_k X[m, k] * W[n, k] + bias[n] ),   m < M, n < N, k < K
+ *
+ *   X     bf16 rows, row stride ldx ELEMENTS (a multiple of 8), 16-byte aligned; elements K .. roundup(K, 8) - 1 of a row must be finite
+ *         (they meet packed zero weights): the padding nerf_amd_rows_to_bf16 writes, or the neighbouring columns of a wider buffer
+ *   W     the layer's weight (N, K) as bf16 rows, zero-padded to (n_pad, ldw): n_pad a multiple of 256 >= N, ldw a multiple of 32 >= K
+ *         (nerf_amd_rows_to_bf16 with rows = n_pad, fill = ldw packs an fp32 nn.Linear.weight)
+ *   bias  n_pad floats (zeros beyond N), 16-byte aligned
+ *   C     out_bf16 != 0: bf16 rows for the next layer (N % 4 == 0, ldc % 4 == 0, 8-byte aligned); else fp32 rows (any N / ldc): the
+ *         heads, and the inputs of the element-wise stages
+ *   act   0 none / 1 ReLU / 2 sigmoid
+ * 256 x 256 outputs per workgroup, both operands global -> LDS by DMA through a 4-slot ring, v_mfma_f32_32x32x16_bf16, fp32 accumulation:
+ * the values nerf_amd_gemm(NERF_AMD_BF16) computes (it rounds the same operands on their way into LDS), at 3x its rate. */
+int nerf_amd_rows_gemm(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, const void* W, int64_t ldw, int64_t n_pad,
+                       const float* bias, int act, void* C, int64_t ldc, int out_bf16, void* stream);
+/* dst[m, j] = bf16(src[m, j]) (RNE) for m < rows_src, j < cols; 0 for the rest of rows x fill: fp32 rows (row stride src_stride floats)
+ * into a column range of bf16 rows (dst = first element of the range, row stride dst_stride elements) with the zero padding above */
+int nerf_amd_rows_to_bf16(const float* src, int64_t rows_src, int64_t src_stride, int64_t rows, int cols, int fill, void* dst,
+                          int64_t dst_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so
 
 F32, BF16 = 0, 1
 BF16_F8 = 2            # NERF_AMD_BF16_F8: bf16 arithmetic, training dumps of the hidden layers in scaled e4m3 (training entry points only)
-EXPECTED_VERSION = 123  # nerf_amd_version() of the library these signatures were written against
+EXPECTED_VERSION = 124  # nerf_amd_version() of the library these signatures were written against
 NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, NET_MIP_128 = 0, 1, 2, 3, 4
 FINE_W128 = 0x200     # layout flag: the fine-network blob is a NET_MIP_128 blob
 PROP_W128 = 0x100     # layout flag OR-ed into `precision`: packed_prop is a NET_PROPOSAL_128 blob
@@ -125,6 +125,8 @@ SIGNATURES = {
     "nerf_amd_positional_encoding_backward": (C.c_int, [c_void, i64, c_void, i64, i64, C.c_int, C.c_int, c_void, c_void]),
     "nerf_amd_contract_positions": (C.c_int, [c_void, i64, i64, c_void, i64, c_void, c_void]),
     "nerf_amd_add_rows": (C.c_int, [c_void, i64, c_void, i64, i64, C.c_int, c_void]),
+    "nerf_amd_rows_gemm": (C.c_int, [i64, i64, i64, c_void, i64, c_void, i64, i64, c_void, C.c_int, c_void, i64, C.c_int, c_void]),
+    "nerf_amd_rows_to_bf16": (C.c_int, [c_void, i64, i64, i64, C.c_int, C.c_int, c_void, i64, c_void]),
 }
 
 

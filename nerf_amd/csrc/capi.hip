@@ -71,6 +71,8 @@ int gr_combine_backward(const float*, int64_t, const float*, int64_t, const floa
 int gr_pe_backward(const float*, int64_t, const float*, int64_t, int64_t, int, int, float*, hipStream_t);
 int gr_add_rows(float*, int64_t, const float*, int64_t, int64_t, int, hipStream_t);
 int gr_contract(const float*, int64_t, int64_t, const float*, int64_t, float*, hipStream_t);
+int rg_rows_gemm(int64_t, int64_t, int64_t, const void*, int64_t, const void*, int64_t, int64_t, const float*, int, void*, int64_t, int, hipStream_t);
+int rg_rows_to_bf16(const float*, int64_t, int64_t, int64_t, int, int, void*, int64_t, hipStream_t);
 int sk_advance_seed(uint64_t*, hipStream_t);
 int sk_cone_parameters(const float*, int64_t, int, float, float*, float*, float*, hipStream_t);
 int sk_generate_rays(const float*, int, int, float, float, int64_t, int64_t, float*, hipStream_t);
@@ -131,7 +133,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 123; }
+int nerf_amd_version(void) { return 124; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -867,6 +869,30 @@ int nerf_amd_add_rows(float* dst, int64_t dst_stride, const float* src, int64_t 
     if (M * cols && (!dst || !src)) return fail(NERF_AMD_EINVAL, "nerf_amd_add_rows: NULL argument");
     if (dst_stride < cols || src_stride < cols) return fail(NERF_AMD_EINVAL, "nerf_amd_add_rows: row stride smaller than cols");
     return hip_status(gr_add_rows(dst, dst_stride, src, src_stride, M, cols, S(stream)), "nerf_amd_add_rows");
+}
+
+int nerf_amd_rows_gemm(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, const void* W, int64_t ldw, int64_t n_pad, const float* bias, int act, void* C,
+                       int64_t ldc, int out_bf16, void* stream) {
+    if (M < 0 || N < 0 || K < 1 || N > 65535LL * 256) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: bad size");
+    if (M == 0 || N == 0) return 0;
+    if (!X || !W || !bias || !C) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: NULL argument");
+    if (act < 0 || act > 2) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: act must be 0 (none), 1 (ReLU) or 2 (sigmoid)");
+    if ((ldx & 7) || ldx < (K + 7) / 8 * 8 || (reinterpret_cast<uintptr_t>(X) & 15u))
+        return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: X must be 16-byte aligned bf16 rows with a stride that is a multiple of 8 elements >= roundup(K, 8)");
+    if ((ldw & 31) || ldw < K || (n_pad & 255) || n_pad < N || (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(bias) & 15u))
+        return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: W must be packed (n_pad % 256 == 0 rows >= N, ldw % 32 == 0 >= K, 16-byte aligned), bias 16-byte aligned");
+    if (ldc < N) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: row stride of C smaller than N");
+    if (out_bf16 && ((N & 3) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 7u)))
+        return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: bf16 output needs N % 4 == 0, ldc % 4 == 0 and an 8-byte aligned C");
+    return hip_status(rg_rows_gemm(M, N, K, X, ldx, W, ldw, n_pad, bias, act, C, ldc, out_bf16, S(stream)), "nerf_amd_rows_gemm");
+}
+
+int nerf_amd_rows_to_bf16(const float* src, int64_t rows_src, int64_t src_stride, int64_t rows, int cols, int fill, void* dst, int64_t dst_stride, void* stream) {
+    if (rows < 0 || rows_src < 0 || rows_src > rows || cols < 0 || fill < cols) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_to_bf16: bad size");
+    if (rows * fill == 0) return 0;
+    if (!dst || (rows_src * cols && !src)) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_to_bf16: NULL argument");
+    if (src_stride < cols || dst_stride < fill) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_to_bf16: row stride smaller than the columns written");
+    return hip_status(rg_rows_to_bf16(src, rows_src, src_stride, rows, cols, fill, dst, dst_stride, S(stream)), "nerf_amd_rows_to_bf16");
 }
 
 }  // extern "C"

@@ -23,6 +23,56 @@ from . import ops
 
 RELU, SIGMOID = 1, 2
 
+# The inference route on bf16 rows (round 5; nerf_amd_rows_gemm): a forward that nobody differentiates, under bf16 precision, carries its
+# activations from layer to layer as bf16 rows -- the values the fp32-row route computes (it rounds the same operands to bf16 on their way
+# into LDS) at a third of the HBM traffic and 3x the product rate.  False = the fp32-row route everywhere (A/B measurements, tests).
+ROWS_ROUTE = True
+
+
+def _rows_route(prec: int, keep, layers) -> bool:
+    """bf16 precision, no activations to keep for a backward, and every hidden width a multiple of 8 (16-byte row pieces)"""
+    return ROWS_ROUTE and keep is None and (prec & 0xff) == ops.BF16 and all(l.out_features % 8 == 0 for l in layers)
+
+
+def _packed(net, key, layers, columns=None) -> "ops.PackedLinear":
+    """the layer's parameters in nerf_amd_rows_gemm's layout, re-packed when a parameter changed (optimizer steps bump `_version`); several
+    `layers` = their rows stacked into one product (Ref-NeRF's heads)"""
+    layers = layers if isinstance(layers, (list, tuple)) else [layers]
+    cache = net.__dict__.setdefault("_rows_packed", {})
+    stamp = tuple((t.data_ptr(), t._version, str(t.device)) for l in layers for t in (l.weight, l.bias))
+    hit = cache.get(key)
+    if hit is None or hit[0] != stamp:
+        w = torch.cat([l.weight.detach() for l in layers], dim=0) if len(layers) > 1 else layers[0].weight.detach()
+        b = torch.cat([l.bias.detach() for l in layers], dim=0) if len(layers) > 1 else layers[0].bias.detach()
+        hit = (stamp, ops.PackedLinear(w, b, columns))
+        cache[key] = hit
+    return hit[1]
+
+
+def _bf16_rows(src: torch.Tensor, width: int = 0, col0: int = 0) -> torch.Tensor:
+    """fp32 rows -> a fresh bf16 buffer (M, max(width, col0 + roundup(cols, 8))) holding them at column col0 (zero padding to the next 8)"""
+    M, cols = src.shape
+    buf = torch.empty((M, max(width, col0 + ops._pad(cols, 8))), dtype=torch.bfloat16, device=src.device)
+    return ops.rows_to_bf16(src, buf, col0)
+
+
+def _skip_rows(net, key_prefix, first, second, ex: torch.Tensor):
+    """encoding -> `first` (4 x Linear+ReLU) -> cat(encoding, hidden) -> `second` (Linear+ReLU each) on bf16 rows: mip_model.py:53-56 /
+    ref_model.py:74-77.  The concatenation keeps the hidden features FIRST (aligned column 0 for the product that writes them); the packed
+    weight of second[0] has its input columns re-ordered to match."""
+    M, E = ex.shape
+    W = first[3].out_features
+    h = _bf16_rows(ex)[:, :E]
+    for i, l in enumerate(first[:3]):
+        h = ops.rows_gemm(h, _packed(net, (key_prefix, 1, i), l), RELU)
+    skip = torch.empty((M, W + ops._pad(E, 8)), dtype=torch.bfloat16, device=ex.device)
+    ops.rows_gemm(h, _packed(net, (key_prefix, 1, 3), first[3]), RELU, out=skip[:, :W])
+    ops.rows_to_bf16(ex, skip, W)
+    h = ops.rows_gemm(skip[:, :W + E], _packed(net, (key_prefix, 2, 0), second[0], columns=[(E, W), (0, E)]), RELU)
+    for i, l in enumerate(second[1:]):
+        h = ops.rows_gemm(h, _packed(net, (key_prefix, 2, i + 1), l), RELU)
+    return h
+
 
 def _encode_positions(x: torch.Tensor, levels: int, cat_origin: bool) -> torch.Tensor:
     """(M,3) -> [x | sin 2^0 x | cos 2^0 x | ...] (nerf_helper.py:38-48 behind the raw position, mip_model.py:50-51)"""
@@ -77,6 +127,11 @@ def proposal_forward(net, pts: torch.Tensor, contract: bool = False) -> torch.Te
         if contract:
             xc = ops.contract_positions(xc)
         x = _encode_positions(xc, net.position_flevel, net.cat_origin)
+        if _rows_route(prec, keep, layers[:4]):
+            h = _bf16_rows(x)[:, :x.shape[1]]
+            for i, l in enumerate(layers[:4]):
+                h = ops.rows_gemm(h, _packed(net, ("prop", i), l), RELU)
+            return ops.rows_gemm(h, _packed(net, ("prop", 4), layers[4]), out_dtype=torch.float32).view(shape)
         acts = [x]
         for l in layers[:4]:
             acts.append(_linear(prec, acts[-1], l, RELU))
@@ -132,6 +187,17 @@ def mip_forward(net, pts: torch.Tensor, contract: bool = False, encoded_x: torch
             ex = _encode_positions(ops.contract_positions(p2[:, :3]) if contract else p2[:, :3], net.position_flevel, net.cat_origin)
         ed = _encode_directions(p2[:, 3:6], net.cat_origin)
         E, W = ex.shape[1], net.hidden_unit
+        if _rows_route(prec, keep, L[:8] + [L[9]]):
+            g = _skip_rows(net, "mip", L[:4], L[4:7], ex)
+            out = torch.empty((M, 4), dtype=torch.float32, device=p.device)
+            ops.rows_gemm(g, _packed(net, ("mip", 8), L[8]), out=out[:, 3:4])                           # opacity_head (:57)
+            Bn, Ed = L[7].out_features, ed.shape[1]
+            head = torch.empty((M, Bn + ops._pad(Ed, 8)), dtype=torch.bfloat16, device=p.device)
+            ops.rows_gemm(g, _packed(net, ("mip", 7), L[7]), out=head[:, :Bn])                          # bottle_neck (:58)
+            ops.rows_to_bf16(ed, head, Bn)
+            c = ops.rows_gemm(head[:, :Bn + Ed], _packed(net, ("mip", 9), L[9]), RELU)                  # rgb_layer.0 on cat(bottle-neck, encoded_r) (:59)
+            ops.rows_gemm(c, _packed(net, ("mip", 10), L[10]), SIGMOID, out=out[:, :3])
+            return out.view(*shape, 4)
         a = [ex]
         for l in L[:3]:
             a.append(_linear(prec, a[-1], l, RELU))
@@ -229,6 +295,24 @@ def ref_forward(net, pos: torch.Tensor, dirs: torch.Tensor, noise, contract: boo
         M, dev = x.shape[0], x.device
         ex = _encode_positions(x, net.position_flevel, net.cat_origin)
         E, W = ex.shape[1], net.hidden_unit
+        if noise is None and Bd % 8 == 0 and _rows_route(prec, keep, S1 + S2 + D1 + D2):
+            g = _skip_rows(net, "spa", S1, S2, ex)
+            heads = ops.rows_gemm(g, _packed(net, "heads", [nct, rt]), out_dtype=torch.float32)
+            Wd = D1[3].out_features
+            cat2 = torch.empty((M, Wd + ops._pad(Din, 8)), dtype=torch.bfloat16, device=dev)            # [r_tmp | bottle-neck | IDE real | IDE imag | n.d]
+            ops.rows_gemm(g, _packed(net, "bn", bn), out=cat2[:, Wd:Wd + Bd])
+            dir_in = torch.empty((M, Din - Bd), dtype=torch.float32, device=dev)
+            normal = ops.ref_dir_inputs(heads, dv, deg, table, dir_in)
+            ops.rows_to_bf16(dir_in, cat2, Wd + Bd)
+            h = cat2[:, Wd:Wd + Din]
+            for i, l in enumerate(D1[:3]):
+                h = ops.rows_gemm(h, _packed(net, ("dir", 1, i), l), RELU)
+            ops.rows_gemm(h, _packed(net, ("dir", 1, 3), D1[3]), RELU, out=cat2[:, :Wd])
+            h = ops.rows_gemm(cat2[:, :Wd + Din], _packed(net, ("dir", 2, 0), D2[0], columns=[(Din, Wd), (0, Din)]), RELU)
+            for i, l in enumerate(D2[1:]):
+                h = ops.rows_gemm(h, _packed(net, ("dir", 2, i + 1), l), RELU)
+            spec = ops.rows_gemm(h, _packed(net, "spec", sph), SIGMOID, out_dtype=torch.float32)
+            return torch.cat((ops.ref_combine(heads, spec, flags), normal), dim=-1).view(*shape, 7)
         a = [ex]
         for l in S1[:3]:
             a.append(_linear(prec, a[-1], l, RELU))

@@ -1154,3 +1154,65 @@ def add_rows_(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("nerf_amd.add_rows_: unit column stride")
     check(lib.nerf_amd_add_rows(_ptr(dst), int(dst.stride(0)), _ptr(src), int(src.stride(0)), M, cols, _stream()), "nerf_amd_add_rows")
     return dst
+
+
+# ---------------------------------------------------------------------------------------------------------------- layer products on bf16 rows
+def _pad(n: int, m: int) -> int:
+    return (int(n) + m - 1) // m * m
+
+
+def rows_to_bf16(src: torch.Tensor, dst: torch.Tensor, col0: int = 0, fill: Optional[int] = None, rows: Optional[int] = None) -> torch.Tensor:
+    """dst[:rows, col0 : col0 + fill] = bf16(src) (RNE), zeros beyond src's rows / columns (nerf_amd_rows_to_bf16): fp32 rows -- an encoding,
+    an element-wise stage's output, an nn.Linear.weight -- into a column range of 2-D bf16 rows, with the zero padding nerf_amd_rows_gemm's
+    last chunk (and the packed weights' tile rows) rely on.  `fill` defaults to src's width rounded up to 8 (clipped to dst)."""
+    src, _, s1 = _view2d(src, "src")
+    if s1 != 1:
+        src = src.contiguous()
+    if dst.dim() != 2 or dst.dtype != torch.bfloat16 or not dst.is_cuda or (dst.shape[1] > 1 and dst.stride(1) != 1):
+        raise RuntimeError("nerf_amd.rows_to_bf16: dst must be 2-D bfloat16 device rows with unit column stride")
+    R, cols = src.shape
+    rows = R if rows is None else int(rows)
+    fill = min(_pad(cols, 8), dst.shape[1] - col0) if fill is None else int(fill)
+    if rows > dst.shape[0] or R > rows or col0 < 0 or col0 + fill > dst.shape[1] or fill < cols:
+        raise RuntimeError("nerf_amd.rows_to_bf16: the column range [%d, %d) x %d rows does not fit dst %s" % (col0, col0 + fill, rows, tuple(dst.shape)))
+    check(lib.nerf_amd_rows_to_bf16(_ptr(src), R, int(src.stride(0)), rows, cols, fill, dst.data_ptr() + 2 * col0, int(dst.stride(0)), _stream()),
+          "nerf_amd_rows_to_bf16")
+    return dst
+
+
+class PackedLinear:
+    """An nn.Linear's parameters in nerf_amd_rows_gemm's layout: weight (N, K) as zero-padded bf16 rows (n_pad % 256 == 0, ldw % 32 == 0), bias
+    as n_pad floats.  `columns` = [(first column, count), ...] re-orders the input features (the concatenations of the reference put the
+    encoding FIRST, mip_model.py:55 / ref_model.py:76,95; the bf16 rows keep the hidden features first so that every product writes at an
+    aligned column 0)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], columns=None):
+        w = weight.detach().float()
+        if columns is not None:
+            w = torch.cat([w[:, c0:c0 + n] for c0, n in columns], dim=1)
+        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        self.n_pad, self.ldw = _pad(self.N, 256), _pad(self.K, 32)
+        self.weight = torch.empty((self.n_pad, self.ldw), dtype=torch.bfloat16, device=w.device)
+        rows_to_bf16(w.contiguous(), self.weight, 0, self.ldw, self.n_pad)
+        self.bias = torch.zeros((self.n_pad,), dtype=torch.float32, device=w.device)
+        if bias is not None:
+            self.bias[:self.N] = bias.detach().float().reshape(-1)
+
+
+def rows_gemm(x: torch.Tensor, layer: PackedLinear, act: int = 0, out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """out[m, n] = act(sum_k x[m, k] W[n, k] + bias[n]) (nerf_amd_rows_gemm): x (M, K) bf16 rows -- a view whose row stride is a multiple of 8
+    elements, 16-byte aligned, with finite elements up to the next multiple of 8 columns; out: (M, N) bf16 rows for the next layer (N % 4
+    == 0) or fp32 rows (heads / element-wise stages), given as a view or allocated."""
+    if x.dim() != 2 or x.dtype != torch.bfloat16 or not x.is_cuda or (x.shape[1] > 1 and x.stride(1) != 1):
+        raise RuntimeError("nerf_amd.rows_gemm: x must be 2-D bfloat16 device rows with unit column stride")
+    M, K = x.shape
+    if K != layer.K:
+        raise RuntimeError("nerf_amd.rows_gemm: x has %d columns, the packed layer %d" % (K, layer.K))
+    if out is None:
+        out = torch.empty((M, layer.N if out_dtype == torch.float32 else _pad(layer.N, 8)), dtype=out_dtype, device=x.device)[:, :layer.N]
+    if tuple(out.shape) != (M, layer.N) or out.dtype not in (torch.bfloat16, torch.float32) or not out.is_cuda or (layer.N > 1 and out.stride(1) != 1):
+        raise RuntimeError("nerf_amd.rows_gemm: out must be a (%d, %d) bfloat16 / float32 device view with unit column stride" % (M, layer.N))
+    check(lib.nerf_amd_rows_gemm(M, layer.N, K, x.data_ptr(), int(x.stride(0)) if M > 1 else _pad(K, 8), layer.weight.data_ptr(), layer.ldw, layer.n_pad,
+                                 layer.bias.data_ptr(), int(act), out.data_ptr(), max(int(out.stride(0)), layer.N) if M > 1 else _pad(layer.N, 8),
+                                 1 if out.dtype == torch.bfloat16 else 0, _stream()), "nerf_amd_rows_gemm")
+    return out
