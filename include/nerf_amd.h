@@ -524,7 +524,7 @@ int nerf_amd_contract_positions(const float* x, int64_t x_stride, int64_t M, con
  *
  *   X     bf16 rows, row stride ldx ELEMENTS (a multiple of 8), 16-byte aligned; elements K .. roundup(K, 8) - 1 of a row must be finite
  *         (they meet packed zero weights): the padding nerf_amd_rows_to_bf16 writes, or the neighbouring columns of a wider buffer
- *   W     the layer's weight (N, K) as bf16 rows, zero-padded to (n_pad, ldw): n_pad a multiple of 256 >= N, ldw a multiple of 32 >= K
+ *   W     the layer's weight (N, K) as bf16 rows, zero-padded to (n_pad, ldw): n_pad a multiple of 256 >= N, ldw a multiple of 64 >= K
  *         (nerf_amd_rows_to_bf16 with rows = n_pad, fill = ldw packs an fp32 nn.Linear.weight)
  *   bias  n_pad floats (zeros beyond N), 16-byte aligned
  *   C     out_bf16 != 0: bf16 rows for the next layer (N % 4 == 0, ldc % 4 == 0, 8-byte aligned); else fp32 rows (any N / ldc): the

@@ -879,8 +879,8 @@ int nerf_amd_rows_gemm(int64_t M, int64_t N, int64_t K, const void* X, int64_t l
     if (act < 0 || act > 2) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: act must be 0 (none), 1 (ReLU) or 2 (sigmoid)");
     if ((ldx & 7) || ldx < (K + 7) / 8 * 8 || (reinterpret_cast<uintptr_t>(X) & 15u))
         return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: X must be 16-byte aligned bf16 rows with a stride that is a multiple of 8 elements >= roundup(K, 8)");
-    if ((ldw & 31) || ldw < K || (n_pad & 255) || n_pad < N || (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(bias) & 15u))
-        return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: W must be packed (n_pad % 256 == 0 rows >= N, ldw % 32 == 0 >= K, 16-byte aligned), bias 16-byte aligned");
+    if ((ldw & 63) || ldw < K || (n_pad & 255) || n_pad < N || (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(bias) & 15u))
+        return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: W must be packed (n_pad % 256 == 0 rows >= N, ldw % 64 == 0 >= K, 16-byte aligned), bias 16-byte aligned");
     if (ldc < N) return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: row stride of C smaller than N");
     if (out_bf16 && ((N & 3) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 7u)))
         return fail(NERF_AMD_EINVAL, "nerf_amd_rows_gemm: bf16 output needs N % 4 == 0, ldc % 4 == 0 and an 8-byte aligned C");

@@ -1181,7 +1181,7 @@ def rows_to_bf16(src: torch.Tensor, dst: torch.Tensor, col0: int = 0, fill: Opti
 
 
 class PackedLinear:
-    """An nn.Linear's parameters in nerf_amd_rows_gemm's layout: weight (N, K) as zero-padded bf16 rows (n_pad % 256 == 0, ldw % 32 == 0), bias
+    """An nn.Linear's parameters in nerf_amd_rows_gemm's layout: weight (N, K) as zero-padded bf16 rows (n_pad % 256 == 0, ldw % 64 == 0), bias
     as n_pad floats.  `columns` = [(first column, count), ...] re-orders the input features (the concatenations of the reference put the
     encoding FIRST, mip_model.py:55 / ref_model.py:76,95; the bf16 rows keep the hidden features first so that every product writes at an
     aligned column 0)."""
@@ -1191,7 +1191,7 @@ class PackedLinear:
         if columns is not None:
             w = torch.cat([w[:, c0:c0 + n] for c0, n in columns], dim=1)
         self.N, self.K = int(w.shape[0]), int(w.shape[1])
-        self.n_pad, self.ldw = _pad(self.N, 256), _pad(self.K, 32)
+        self.n_pad, self.ldw = _pad(self.N, 256), _pad(self.K, 64)
         self.weight = torch.empty((self.n_pad, self.ldw), dtype=torch.bfloat16, device=w.device)
         rows_to_bf16(w.contiguous(), self.weight, 0, self.ldw, self.n_pad)
         self.bias = torch.zeros((self.n_pad,), dtype=torch.float32, device=w.device)
