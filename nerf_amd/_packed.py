@@ -133,6 +133,7 @@ class PackedWeightsMixin:
 
     def invalidate_packed(self) -> None:
         self.__dict__.setdefault("_packed_cache", {}).clear()
+        self.__dict__.setdefault("_rows_packed", {}).clear()          # the bf16-rows route's per-layer packing (generic_path._packed)
 
     def train(self, mode: bool = True):
         self.invalidate_packed()

@@ -35,17 +35,20 @@ def _rows_route(prec: int, keep, layers) -> bool:
 
 
 def _packed(net, key, layers, columns=None) -> "ops.PackedLinear":
-    """the layer's parameters in nerf_amd_rows_gemm's layout, re-packed when a parameter changed (optimizer steps bump `_version`); several
-    `layers` = their rows stacked into one product (Ref-NeRF's heads)"""
+    """the layer's parameters in nerf_amd_rows_gemm's layout, with PackedWeightsMixin's cache rules: eval mode -- cached under (data_ptr,
+    _version) of its tensors (optimizer steps and load_state_dict bump `_version`; `invalidate_packed()` / a train() / eval() switch drop
+    the cache); train mode -- packed on every call (a hipGraph-replayed step changes parameters without `_version` moving).  Several
+    `layers` = their rows stacked into one product (Ref-NeRF's heads)."""
     layers = layers if isinstance(layers, (list, tuple)) else [layers]
     cache = net.__dict__.setdefault("_rows_packed", {})
     stamp = tuple((t.data_ptr(), t._version, str(t.device)) for l in layers for t in (l.weight, l.bias))
-    hit = cache.get(key)
+    hit = None if net.training else cache.get(key)
     if hit is None or hit[0] != stamp:
         w = torch.cat([l.weight.detach() for l in layers], dim=0) if len(layers) > 1 else layers[0].weight.detach()
         b = torch.cat([l.bias.detach() for l in layers], dim=0) if len(layers) > 1 else layers[0].bias.detach()
         hit = (stamp, ops.PackedLinear(w, b, columns))
-        cache[key] = hit
+        if not net.training:
+            cache[key] = hit
     return hit[1]
 
 

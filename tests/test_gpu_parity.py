@@ -2592,6 +2592,11 @@ def test_layer_products_on_bf16_rows(A, golden):
             mip.opacity_head[0].bias.sub_(1.0)
         gate("bf16 rows: opacity after bias += 1 (re-pack on a parameter update)", max_abs(after[..., 3] - 1.0, before[..., 3]), 1e-5)
         assert torch.equal(after[..., :3], before[..., :3])
+        mip.train()                                                                                  # train mode: packed per call, never cached (PackedWeightsMixin's rule:
+        with torch.no_grad():                                                                        # a graph-replayed step moves no version counter)
+            tr = mip.forward(pts.cuda())
+        assert not mip.__dict__["_rows_packed"] and torch.equal(tr, before)
+        mip.eval()
     finally:
         generic_path.ROWS_ROUTE = True
         A.pkg.set_precision("fp32")
