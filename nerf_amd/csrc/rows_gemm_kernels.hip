@@ -245,19 +245,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINB) void rows_gemm_kernel(RowsGemm
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // a row of the image = BN / 4 lanes x 8 bytes: a wave instruction stores RPI = 256 / BN complete rows
-        constexpr int LPR = C::BN / 4, RPI = 64 / LPR, ROWS_W = C::BM / (C::WM * C::WN);
-        const int64_t n = n0 + 4 * (lane % LPR);
-        if (n < g.N) {                                            // (N % 4 == 0: a lane's four features are inside or outside together)
-            uint16_t* Cb = reinterpret_cast<uint16_t*>(g.C);
+        // the image as 8-byte units (four features), LPR = BN / 4 per sample row: thread t stores units t, t + THREADS, ... -- a wave
+        // instruction writes 512 contiguous bytes of a row (or several complete rows)
+        constexpr int LPR = C::BN / 4;
+        uint16_t* Cb = reinterpret_cast<uint16_t*>(g.C);
 #pragma unroll 8
-            for (int i = 0; i < ROWS_W / RPI; ++i) {
-                typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-                const int ml = ROWS_W * wave + RPI * i + lane / LPR;
-                if (m0 + ml < g.M) {
-                    const u32x2 v = *reinterpret_cast<const u32x2*>(rg_smem + ml * C::CT_LD + (lane % LPR) * 8);
-                    *reinterpret_cast<u32x2*>(Cb + (m0 + ml) * g.ldc + n) = v;
-                }
+        for (int i = 0; i < C::BM * LPR / C::THREADS; ++i) {
+            typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+            const int u = (int)threadIdx.x + i * C::THREADS;
+            const int ml = u / LPR, c4 = u % LPR;
+            const int64_t n = n0 + 4 * c4;
+            if (m0 + ml < g.M && n < g.N) {                       // (N % 4 == 0: a unit's four features are inside or outside together)
+                const u32x2 v = *reinterpret_cast<const u32x2*>(rg_smem + ml * C::CT_LD + c4 * 8);
+                *reinterpret_cast<u32x2*>(Cb + (m0 + ml) * g.ldc + n) = v;
             }
         }
     } else {
@@ -325,7 +325,8 @@ int rg_rows_gemm(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, co
     // Two tile configurations (profiles/r05_rows_gemm_tile_config_ab.log, five candidates on one box): wide layers whose feature count fills
     // 256-wide tiles run 256 x 256 tiles with full-cache-line stages (8 wavefronts, one workgroup per CU: fewest operand bytes per product,
     // +5-8 % at 512 / 1024); everything else -- ragged feature tiles, the heads, the 256-wide layers of Ref-NeRF -- 128 x 256 tiles with
-    // 64-byte row pieces and two workgroups per CU.  (128 x 128 x 64 in 2 or 3 slots and 128 x 256 x 64 with 8 wavefronts measured 4-25 % slower.)
+    // 64-byte row pieces and two workgroups per CU.  (128 x 128 x 64 in 2 or 3 slots and 128 x 256 x 64 with 8 wavefronts measured 4-25 % slower; whole-row tiles 128 x 512 x 32 -- the
+    // activations read once, the output written in whole rows -- 5-8 % slower than 256 x 256 x 64 at 512 / 1024.)
     if (N >= 512 && N % 256 == 0) return rows_launch<RowsCfg<256, 256, 64, 2, 4, 2, 1>>(g, out_bf16, st);
     return rows_launch<RowsCfg<128, 256, 32, 3, 2, 2, 2>>(g, out_bf16, st);
 }
