@@ -7,9 +7,11 @@ backward is the same GEMM in its two other stride forms (input gradient with the
 contraction over the samples, split over workgroups and summed in a fixed order) -- what torch.autograd computes for the reference's
 modules, with no torch arithmetic and no library GEMM.  torch only owns the buffers (and concatenates / slices them).
 
-This is the COMPATIBILITY path of the shape arguments: activations make a round trip through HBM per layer (fp32 rows), so it runs at a
-fraction of the fused kernels' rate -- every shape the fused kernels are compiled for (widths <= 256, <= 10 octaves, either cat_origin)
-keeps them.  Sample positions get a gradient inside RefNeRF.get_grad only (d density / d position: a dgrad-only chain + the encoding's
+This is the COMPATIBILITY path of the shape arguments: activations make a round trip through HBM per layer, so it runs at a fraction of
+the fused kernels' rate -- every shape the fused kernels are compiled for (widths <= 256, <= 10 octaves, either cat_origin) keeps them.
+Two routes: fp32 rows on `nerf_amd_gemm` (everything that is differentiated, and the fp32 parity mode), and -- round 5 -- bf16 rows on
+`nerf_amd_rows_gemm` for forwards nobody differentiates under bf16 precision (rendering): the same values at a third of the traffic and
+~3x the rate (`_rows_route`, `_skip_rows` below).  Sample positions get a gradient inside RefNeRF.get_grad only (d density / d position: a dgrad-only chain + the encoding's
 adjoint, like on the fused path; the reference's loss never uses another, utils.py:35-36); scene contraction is a stage of its own in front of the
 encoder here (`ops.contract_positions`, round 5); the integrated PE is a flag of the fused kernels' sample fetch only.  RefNeRF takes this path as well (`ref_forward`: hidden width > 256, > 10 octaves, or
 `--ide_level 5`, whose 36 spherical-harmonic terms the fused kernel's three IDE K groups do not hold).
