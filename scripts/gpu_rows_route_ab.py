@@ -37,6 +37,15 @@ prop256 = ProposalNetwork(10, 256).cuda().eval()
 cases.append(("MipNeRF + proposal, width 512", 400, lambda s, f: procedures.render_image(mip512, prop512, pose, s, f, 2.0, 6.0, 128, white_bkg=True)))
 ref5, ref4 = RefNeRF(10, 5).cuda().eval(), RefNeRF(10, 4).cuda().eval()
 cases.append(("RefNeRF ide_level 5", 200, lambda s, f: procedures.render_image(ref5, prop256, pose, s, f, 2.0, 6.0, 128, white_bkg=True, render_normal=True)))
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+if only:                                                  # one case, bf16 rows only, a few images: the profiling entry (scripts/gpu_rows_route_prof.sh)
+    name, size, fn = cases[1 if only == "ref5" else 0]
+    focal = fov2Focal(0.6911112070083618, (size, size))
+    with torch.no_grad():
+        for _ in range(3):
+            fn(size, focal)
+    torch.cuda.synchronize()
+    sys.exit(0)
 with torch.no_grad():
     for name, size, fn in cases:
         focal = fov2Focal(0.6911112070083618, (size, size))

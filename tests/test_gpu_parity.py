@@ -2592,10 +2592,12 @@ def test_layer_products_on_bf16_rows(A, golden):
             mip.opacity_head[0].bias.sub_(1.0)
         gate("bf16 rows: opacity after bias += 1 (re-pack on a parameter update)", max_abs(after[..., 3] - 1.0, before[..., 3]), 1e-5)
         assert torch.equal(after[..., :3], before[..., :3])
+        with torch.no_grad():
+            again = mip.forward(pts.cuda())                                                          # ((b + 1) - 1 is not b in fp32: the eval value after the round trip)
         mip.train()                                                                                  # train mode: packed per call, never cached (PackedWeightsMixin's rule:
         with torch.no_grad():                                                                        # a graph-replayed step moves no version counter)
             tr = mip.forward(pts.cuda())
-        assert not mip.__dict__["_rows_packed"] and torch.equal(tr, before)
+        assert not mip.__dict__["_rows_packed"] and torch.equal(tr, again)
         mip.eval()
     finally:
         generic_path.ROWS_ROUTE = True
