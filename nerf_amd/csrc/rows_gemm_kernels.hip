@@ -23,7 +23,8 @@
 // 215 of nerf_amd_gemm.  Probes on the same box: products + epilogue without the operand loads 0.163 ms, loads + epilogue without the
 // products 0.205 ms, the epilogue alone (268 MB of output rows) 0.093 ms, all three 0.266 ms -- the launch is bound by the memory
 // system (operand delivery L2 -> LDS at ~6 TB/s chip-wide, rows at 2-3 TB/s of HBM), not by the matrix cores (26 % busy); staggering the
-// two resident workgroups, nt loads and nt stores changed nothing.  The step beyond is the fused kernels' design (activations never
+// two resident workgroups, nt loads and nt stores, and taking the activations through registers
+// (global_load_dwordx4 -> ds_write_b128) instead of the LDS DMA all changed nothing.  The step beyond is the fused kernels' design (activations never
 // leave the CU), not a better tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
