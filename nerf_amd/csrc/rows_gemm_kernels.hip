@@ -45,7 +45,8 @@ struct RowsCfg {
     static constexpr int RPP = 64 / CH;                             // rows of a 1 KiB piece (one global_load_lds_dwordx4): 16 or 8
     static constexpr int XIMG = BM * ROWB, WIMG = BN * ROWB, SLOT = XIMG + WIMG;      // a stage's images: [activations | weights]
     static constexpr int CT_LD = BN * 2 + 8;                        // row stride of the transposed output image (/ 4 = 2 mod 32: ds_write_b64 of 16 rows hit 32 banks once)
-    static constexpr int LDS = BM * CT_LD > SLOTS * SLOT ? BM * CT_LD : SLOTS * SLOT;
+    static constexpr int BIAS_OFF = BM * CT_LD > SLOTS * SLOT ? BM * CT_LD : SLOTS * SLOT;      // the tile's BN bias values, behind the ring / output image
+    static constexpr int LDS = BIAS_OFF + BN * 4;
     static constexpr int XLOADS = XIMG / (THREADS * 16), WLOADS = WIMG / (THREADS * 16), LOADS = XLOADS + WLOADS;
     static constexpr int KSTEPS = BK / 16;
     static_assert((BK == 32 || BK == 64) && XLOADS >= 1 && WLOADS >= 1 && MB >= 1 && NB >= 1 && SLOTS >= 2, "RowsCfg");
@@ -129,6 +130,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINB) void rows_gemm_kernel(RowsGemm
     rows_tile_of(g, ti, tj);
     const int64_t m0 = ti * C::BM, n0 = tj * C::BN;
     const int S = (int)((g.K + C::BK - 1) / C::BK);
+    // the tile's bias values go to LDS once (first version: sixteen dependent f32x4 loads from L2 per lane in the epilogue, each behind
+    // its own vmcnt(0) -- 11.6 us of the 32 us a workgroup lived)
+    float bias_v = 0.0f;
+    if (threadIdx.x < C::BN) bias_v = g.bias[n0 + threadIdx.x];
 
     // ---- the loader: 1 KiB pieces (RPP rows x ROWB bytes) of the operand images; lane -> row lane / CH of the piece, position lane % CH
     const char* xsrc[C::XLOADS];
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINB) void rows_gemm_kernel(RowsGemm
 #pragma unroll
     for (int s = 0; s < C::SLOTS - 1; ++s)
         if (s < S) issue(s);
+    if (threadIdx.x < C::BN) reinterpret_cast<float*>(rg_smem + C::BIAS_OFF)[threadIdx.x] = bias_v;      // (visible after the first barrier below)
     uint32_t slot = 0;
     for (int s = 0; s < S; ++s) {
         // stages <= s + SLOTS - 2 are issued: stage s must have landed -- my pieces here, everybody's after the barrier
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINB) void rows_gemm_kernel(RowsGemm
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nl = 32 * NB * wn + 32 * nb + 8 * q + 4 * kh;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n0 + nl);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(rg_smem + C::BIAS_OFF + nl * 4);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINB) void rows_gemm_kernel(RowsGemm
                 if (m >= g.M) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t n = n0 + 32 * NB * wn + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (n < g.N) Cf[m * g.ldc + n] = activate(acc[nb][mb][r] + g.bias[n], g.act);
+                    const int nl = 32 * NB * wn + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (n0 + nl < g.N) Cf[m * g.ldc + n0 + nl] = activate(acc[nb][mb][r] + reinterpret_cast<const float*>(rg_smem + C::BIAS_OFF)[nl], g.act);
                 }
             }
         }
