@@ -333,7 +333,8 @@ int rg_rows_gemm(int64_t M, int64_t N, int64_t K, const void* X, int64_t ldx, co
     // 256-wide tiles run 256 x 256 tiles with full-cache-line stages (8 wavefronts, one workgroup per CU: fewest operand bytes per product,
     // +5-8 % at 512 / 1024); everything else -- ragged feature tiles, the heads, the 256-wide layers of Ref-NeRF -- 128 x 256 tiles with
     // 64-byte row pieces and two workgroups per CU.  (128 x 128 x 64 in 2 or 3 slots and 128 x 256 x 64 with 8 wavefronts measured 4-25 % slower; whole-row tiles 128 x 512 x 32 -- the
-    // activations read once, the output written in whole rows -- 5-8 % slower than 256 x 256 x 64 at 512 / 1024.)
+    // activations read once, the output written in whole rows -- 5-8 % slower than 256 x 256 x 64 at 512 / 1024; hipBLASLt's own shape for these sizes, 256 x 256 x 32 on FOUR wavefronts of
+    // 128 x 128 (accumulators in 256 AGPRs), 25-40 % slower with this file's per-stage schedule.)
     if (N >= 512 && N % 256 == 0) return rows_launch<RowsCfg<256, 256, 64, 2, 4, 2, 1>>(g, out_bf16, st);
     return rows_launch<RowsCfg<128, 256, 32, 3, 2, 2, 2>>(g, out_bf16, st);
 }
