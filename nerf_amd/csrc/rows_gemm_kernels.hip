@@ -20,12 +20,13 @@
 // weights.  Epilogue: bias + activation in registers, bf16, transposed through the (then idle) ring into full row pieces.
 //
 // Where it stands (262 144 x 512 x 512, profiles/r05_rows_gemm_*): 520-570 TFLOP/s sustained (598 in a five-launch profile), against
-// 215 of nerf_amd_gemm.  Probes on the same box: products + epilogue without the operand loads 0.163 ms, loads + epilogue without the
-// products 0.205 ms, the epilogue alone (268 MB of output rows) 0.093 ms, all three 0.266 ms -- the launch is bound by the memory
-// system (operand delivery L2 -> LDS at ~6 TB/s chip-wide, rows at 2-3 TB/s of HBM), not by the matrix cores (26 % busy); staggering the
-// two resident workgroups, nt loads and nt stores, and taking the activations through registers
-// (global_load_dwordx4 -> ds_write_b128) instead of the LDS DMA all changed nothing.  The step beyond is the fused kernels' design (activations never
-// leave the CU), not a better tile.
+// 215 of nerf_amd_gemm and 713 of hipBLASLt's plain product (256 x 256 x 32 tiles on four wavefronts of 128 x 128, hand-scheduled).
+// Probes on one box: products + epilogue without the operand loads 0.163 ms, loads + epilogue without the products 0.205 ms, the
+// epilogue alone (268 MB of output rows) 0.093 ms, all three 0.266 ms -- the launch waits for the memory system (operand delivery
+// L2 -> LDS at ~6 TB/s chip-wide, rows at 2-3 TB/s of HBM; TCP_PENDING_STALL half of every CU's cycles), the matrix cores are 26 % busy.
+// Measured and not kept: 64 x / 128 x 128-wide and whole-row tiles, the library's tile shape, staggering the two resident workgroups,
+// nt loads / stores, the activations through registers (global_load_dwordx4 -> ds_write_b128) instead of the DMA: all within +- 5 % or
+// slower.  The step beyond is the fused kernels' design (activations never leave the CU) or the library's hand-scheduled loop.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
