@@ -43,7 +43,11 @@ def _draw_uniforms(H, W, sample_num, sz, patch_num, device, rng):
     return u1.view(-1, RENDER_COARSE_PNUM).to(device), u2.view(-1, sample_num + 1).to(device)
 
 
-def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: int = 4096,
+# rays per chunk of the layer-by-layer route (the reference tiles an image the same way, procedures.py:53-56)
+GENERIC_CHUNK_RAYS = 4096
+
+
+def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, render_depth, chunk: Optional[int] = None,
                           is_ref_model: bool = False, cam_dir=None, seed: Optional[int] = None, ray_offset: int = 0, contract: bool = False,
                           ipe_radius: Optional[float] = None, ipe_dir_norm=None):
     """The tile body of procedures.py:62-85 as the reference writes it -- stratified depths, ProposalNetwork.forward, get_weights,
@@ -54,6 +58,7 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
     from .mip_methods import maxBlurFilter
     from .utils import inverseSample
     N = rays.shape[0]
+    chunk = GENERIC_CHUNK_RAYS if chunk is None else chunk
     rgb = torch.empty((N, 3), dtype=torch.float32, device=rays.device)
     depth = torch.empty((N,), dtype=torch.float32, device=rays.device) if render_depth else None
     normal_px = torch.empty((N,), dtype=torch.float32, device=rays.device) if cam_dir is not None else None

@@ -37,6 +37,15 @@ prop256 = ProposalNetwork(10, 256).cuda().eval()
 cases.append(("MipNeRF + proposal, width 512", 400, lambda s, f: procedures.render_image(mip512, prop512, pose, s, f, 2.0, 6.0, 128, white_bkg=True)))
 ref5, ref4 = RefNeRF(10, 5).cuda().eval(), RefNeRF(10, 4).cuda().eval()
 cases.append(("RefNeRF ide_level 5", 200, lambda s, f: procedures.render_image(ref5, prop256, pose, s, f, 2.0, 6.0, 128, white_bkg=True, render_normal=True)))
+if "--chunks" in sys.argv:                               # rays per chunk of the layer-by-layer route: do the activations of a chunk stay in the 256 MB Infinity Cache?
+    with torch.no_grad():
+        for name, size, fn in cases:
+            focal = fov2Focal(0.6911112070083618, (size, size))
+            for ch in (4096, 2048, 1024, 512, 256, 4096, 1024):
+                procedures.GENERIC_CHUNK_RAYS = ch
+                t = timed(lambda: fn(size, focal))
+                print("%-32s %dx%d  chunk %5d rays  %7.1f ms = %6.0f k rays/s" % (name, size, size, ch, t * 1e3, size * size / t / 1e3), flush=True)
+    sys.exit(0)
 only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 if only:                                                  # one case, bf16 rows only, a few images: the profiling entry (scripts/gpu_rows_route_prof.sh)
     name, size, fn = cases[1 if only == "ref5" else 0]
