@@ -25,8 +25,8 @@
 // epilogue alone (268 MB of output rows) 0.093 ms, all three 0.266 ms -- the launch waits for the memory system (operand delivery
 // L2 -> LDS at ~6 TB/s chip-wide, rows at 2-3 TB/s of HBM; TCP_PENDING_STALL half of every CU's cycles), the matrix cores are 26 % busy.
 // Measured and not kept: 64 x / 128 x 128-wide and whole-row tiles, the library's tile shape, staggering the two resident workgroups,
-// nt loads / stores, the activations through registers (global_load_dwordx4 -> ds_write_b128) instead of the DMA: all within +- 5 % or
-// slower.  The step beyond is the fused kernels' design (activations never leave the CU) or the library's hand-scheduled loop.
+// nt loads / stores, the activations through registers (global_load_dwordx4 -> ds_write_b128) instead of the DMA, the same four
+// stages ahead of the weights: all within +- 5 % or slower.  The step beyond is the fused kernels' design (activations never leave the CU) or the library's hand-scheduled loop.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
