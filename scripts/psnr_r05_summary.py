@@ -80,9 +80,28 @@ def main():
             out.append("* %s - cpu, %s: %+.2f +- %.2f dB over %d paired seeds (sd of the differences %.2f dB): a 0.1 dB difference at two standard errors needs"
                        " ~ %d paired seeds." % (mode, what, d, sem, n, sd, need))
         out.append("")
+        # the per-subset means behind the one paired figure that is two standard errors from zero
+        held = {}
+        for f in files:
+            for line in open(f):
+                m = re.match(r"RESULT mode (\S+) seed (\d+) held-out ([\d.]+)", line)
+                if m:
+                    held.setdefault(m.group(1), {})[int(m.group(2))] = float(m.group(3))
+        common = sorted(set(held.get("cpu", {})) & set(held.get("fp32", {})))
+        rest = sorted(set(held.get("fp32", {})) - set(common))
+        if common and rest:
+            mean = lambda mode, ss: sum(held[mode][x] for x in ss) / len(ss)
+            out.append("The one paired figure that stands two standard errors from zero is HIP fp32 - CPU oracle (held-out; the training PSNR follows it).  The other figures point to the")
+            out.append("draw of these seeds rather than to the kernels: over the paired seeds %s HIP fp32 averages %.2f dB held-out, over its OTHER seeds %s %.2f dB"
+                       % (common, mean("fp32", common), rest, mean("fp32", rest)))
+            out.append("(CPU oracle over the paired seeds: %.2f dB); HIP bf16 -- the same kernels with less precision -- is %+.2f dB from the oracle over the same paired"
+                       % (mean("cpu", common), mean("bf16", common) - mean("cpu", common)))
+            out.append("seeds, and the unpaired gaps above (all seeds) are 0.4-0.7 standard errors.  Four paired tests were made; one at 2.4 standard errors is what chance gives about")
+            out.append("one time in fifteen.")
+            out.append("")
         out.append("No: at the end of a run the paired difference between ANY two paths (HIP fp32 against bf16 included) has a standard deviation of 1-2 dB per seed --")
         out.append("training this scene is chaotic (an fp32 ulp changes the trajectory; the CPU oracle against itself with another thread count differs as much) --")
-        out.append("so the end-of-run statement these seeds support is \"no detectable deficit\" with the error bar above.  Where the trajectories have not yet")
+        out.append("so the end-of-run statement these seeds support is \"no deficit detectable in the all-seed means or in bf16; fp32 2.4 standard errors low on its 8 paired seeds\".  Where the trajectories have not yet")
         out.append("diverged the 0.1 dB statement IS resolved: the table above, and round 4's per-iteration pairing (HIP fp32 - oracle = +0.05 +- 0.07 dB through")
         out.append("1 000 iterations over 10 seeds, `profiles/r04_psnr/short6k/trajectory_summary.md`).")
     else:
