@@ -89,6 +89,33 @@ def test_mip_module_param_count_and_order():
     assert not ProposalNetwork(10, 256)._generic() and not MipNeRF(8, 4, 200)._generic()
 
 
+def test_which_forwards_take_the_bf16_rows_route():
+    """generic_path._rows_route (round 5): the layer-by-layer networks carry their activations as bf16 rows (nerf_amd_rows_gemm) only when
+    nobody differentiates the forward, under bf16 precision, with hidden widths that are multiples of 8 -- everything else stays on the
+    fp32-row route (nerf_amd_gemm); train mode never caches a packed layer (PackedWeightsMixin's rule)."""
+    from nerf_amd import generic_path as G, ops
+    from nerf_amd.mip_model import MipNeRF
+    lin = lambda i, o: torch.nn.Linear(i, o)
+    assert G._rows_route(ops.BF16, None, [lin(63, 320), lin(320, 512)])
+    assert G._rows_route(ops.BF16 | 0x100, None, [lin(63, 320)])                       # layout flags ride in the upper bits of `precision`
+    assert not G._rows_route(ops.F32, None, [lin(63, 320)])                             # the fp32 parity mode
+    assert not G._rows_route(ops.BF16, {}, [lin(63, 320)])                              # activations kept for a backward
+    assert not G._rows_route(ops.BF16, None, [lin(63, 300)])                            # 300 % 8 != 0: no 16-byte row pieces
+    G.ROWS_ROUTE = False
+    try:
+        assert not G._rows_route(ops.BF16, None, [lin(63, 320)])
+    finally:
+        G.ROWS_ROUTE = True
+    m = MipNeRF(10, 4, 320)
+    m.__dict__.setdefault("_rows_packed", {})["x"] = 1
+    m.invalidate_packed()
+    assert not m.__dict__["_rows_packed"]                                               # one invalidation for both packed forms
+    m.__dict__["_rows_packed"]["x"] = 1
+    m.train()
+    assert not m.__dict__["_rows_packed"]                                               # a train() / eval() switch drops the cache
+    assert ops._pad(575, 64) == 576 and ops._pad(512, 64) == 512 and ops._pad(3, 256) == 256
+
+
 def test_host_scalars_and_patching(golden):
     from nerf_amd import utils, procedures
     g = golden("g01_raygen")
