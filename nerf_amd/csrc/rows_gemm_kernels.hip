@@ -50,7 +50,7 @@ struct RowsCfg {
     static constexpr int LDS = BIAS_OFF + BN * 4;
     static constexpr int XLOADS = XIMG / (THREADS * 16), WLOADS = WIMG / (THREADS * 16), LOADS = XLOADS + WLOADS;
     static constexpr int KSTEPS = BK / 16;
-    static_assert((BK == 32 || BK == 64) && XLOADS >= 1 && WLOADS >= 1 && MB >= 1 && NB >= 1 && SLOTS >= 2, "RowsCfg");
+    static_assert((BK == 32 || BK == 64) && XLOADS >= 1 && WLOADS >= 1 && MB >= 1 && NB >= 1 && SLOTS >= 2 && SLOTS <= 4 && THREADS >= BN, "RowsCfg");
     // the bank swizzle: row r keeps its chunk c at position c ^ swz(r) -- the 16 lanes of a ds_read_b128 service group read 16 different rows
     // (mod 16) at one chunk index, and land on 16 different 16-byte slots of the 256-byte bank row
     static DEVINL int swz(int r) { return CH == 4 ? (r >> 2) & 3 : (r >> 1) & 7; }
