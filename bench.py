@@ -38,7 +38,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 H = W = 800
 C_COARSE, N_FINE = 64, 128
@@ -93,6 +92,27 @@ def parse():
     return p.parse_args()
 
 
+def committed_traffic(key: str):
+    """-> (bytes per launch / step or None, {"round", "measured_by", "stale", ...}): the counter-measured HBM traffic committed in
+    profiles/pmc_traffic.json (PMC collection needs the profiler around the process, so it is not measured in this run) together with the
+    kernel-source hashes it was measured on -- `stale: true` when the tree's sources are not those any more (a kernel change must not
+    silently keep an old traffic figure: VERDICT r5 item 7)."""
+    import hashlib
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tfile):
+        return None, None
+    rec = json.load(open(tfile)).get(key)
+    if not isinstance(rec, dict):
+        return None, None
+    changed = []
+    for f, want in rec.get("sources", {}).items():
+        path = os.path.join(ROOT, "nerf_amd", "csrc", f)
+        have = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None
+        if have != want:
+            changed.append(f)
+    return rec["bytes"], {"round": rec.get("round"), "measured_by": rec.get("measured_by"), "stale": bool(changed), "sources_changed_since": changed}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -102,14 +122,34 @@ def _free_port():
     return port
 
 
+METRIC_NAME = "rays/sec (64+128 samples), Lego 800x800"
+AFTER_TIMED = "after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)"
+
+
+def partial_record(msg: str) -> None:
+    """One parsable line on stdout saying that no measurement exists and why (`value: null`).  EVERY rank may print one (tagged with its
+    rank): the launcher tears the whole job down as soon as ONE rank exits, so a record that only rank 0 could write is lost whenever
+    another rank's watchdog wins the race (tests/test_multiprocess.py failed exactly there in the full-suite order)."""
+    print(json.dumps({"metric": METRIC_NAME, "value": None, "unit": "rays/s", "n_gpus": Watchdog.world, "rank": Watchdog.rank,
+                      "error": msg, "phase": Watchdog.phase}), flush=True)
+
+
 class Watchdog:
     """A stuck N > 1 run must fail LOUDLY inside the driver's slot instead of hanging until it is killed: when the
-    deadline passes, every rank writes one line saying where it was (`PHASE`), dumps every thread's Python stack to stderr, rank 0 prints a
-    partial JSON line (`value: null`, `error`, `phase`) so that the driver's log holds a parsable record, and the process exits non-zero.
-    Armed by default at 900 s when N > 1 (BENCH_DUMP_STACKS_AFTER overrides; 0 = off); the preflight arms its own short one."""
+    deadline passes, every rank writes one line saying where it was (`PHASE`), dumps every thread's Python stack to stderr and prints a
+    rank-tagged partial JSON line (`value: null`, `error`, `phase`, `rank`) so that the driver's log holds a parsable record whichever rank
+    fires first; ranks other than 0 then wait GRACE seconds before exiting (rank 0's own watchdog, armed at the same deadline, gets its
+    line out before the launcher's tear-down), and the process exits non-zero.  Armed by default when N > 1: 900 s up to the end of the
+    timed region, re-armed for the phase in which rank 0 measures alone so that the whole run stays inside 1 620 s of the driver's 1 800 s
+    slot (BENCH_DUMP_STACKS_AFTER overrides the first limit; 0 = off); the preflight arms its own short one."""
     phase = "start"
     rank = 0
     world = 1
+    done = False                 # the final record is out: a termination after this point needs no partial line
+    run = None                   # the whole-run watchdog (re-armed per phase)
+    t0 = time.monotonic()
+    GRACE = float(os.environ.get("BENCH_WATCHDOG_GRACE", "15"))
+    TOTAL = 1620.0
 
     def __init__(self, seconds: float, what: str, code: int = 124):
         import threading
@@ -127,14 +167,56 @@ class Watchdog:
         sys.stderr.write(msg + "\n")
         faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
         sys.stderr.flush()
-        if Watchdog.rank == 0:
-            print(json.dumps({"metric": "rays/sec (64+128 samples), Lego 800x800", "value": None, "unit": "rays/s", "n_gpus": Watchdog.world,
-                              "error": msg, "phase": Watchdog.phase}), flush=True)
+        if not Watchdog.done:
+            partial_record(msg)
+        if Watchdog.rank != 0:
+            time.sleep(Watchdog.GRACE)
         os._exit(self.code)
+
+    @classmethod
+    def arm_run(cls, seconds: float, what: str = "the run"):
+        if cls.run is not None:
+            cls.run.cancel()
+        cls.run = cls(seconds, what) if seconds > 0 else None
+
+    @classmethod
+    def rearm_after_timed_region(cls):
+        """The phase in which the other ranks idle at the host-side barrier while rank 0 measures cpu_baseline / train_step alone (the 25-minute
+        gloo group): a healthy run may spend longer here than the first limit allows, so the deadline becomes "the whole run inside
+        TOTAL seconds" (the 900 s default used to pre-empt the 25-minute control-group timeout)."""
+        if cls.run is not None:
+            left = max(60.0, cls.TOTAL - (time.monotonic() - cls.t0))
+            cls.arm_run(left, "the run (deadline of the whole run: %.0f s)" % cls.TOTAL)
 
 
 def set_phase(name: str) -> None:
     Watchdog.phase = name
+    if name == AFTER_TIMED:
+        Watchdog.rearm_after_timed_region()
+
+
+def install_termination_record() -> None:
+    """A rank the launcher terminates (SIGTERM: another rank died first -- rank 0 included) still leaves a parsable record.  The C-level
+    handler feeds a wake-up pipe at once, even while the main thread sits inside a collective or a device synchronisation (a Python-level
+    handler alone would wait for that call to return); a watcher thread prints the rank-tagged partial line and exits 143."""
+    import signal
+    import threading
+    r, w = os.pipe()
+    os.set_blocking(w, False)
+    signal.signal(signal.SIGTERM, lambda *_: None)
+    signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+    def watch():
+        while True:
+            b = os.read(r, 1)
+            if b and b[0] == signal.SIGTERM:
+                break
+        if not Watchdog.done:
+            partial_record("bench.py: rank %d of %d was terminated by the launcher (SIGTERM: another rank exited first), phase: %s"
+                           % (Watchdog.rank, Watchdog.world, Watchdog.phase))
+        sys.stderr.flush()
+        os._exit(143)
+    threading.Thread(target=watch, daemon=True, name="termination-record").start()
 
 
 def device_identity(dev):
@@ -228,7 +310,24 @@ def launch_or_verify(a):
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd))
+    # the ranks' stdout passes through this process: if the job dies without ANY record (a rank killed outright, the launcher itself
+    # failing) the launcher writes the partial line, so that `python bench.py --gpus N` never ends non-zero without a parsable line
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1)
+    seen = False
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                rec = json.loads(line)
+                seen = seen or "value" in rec or "launch_check" in rec
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc != 0 and not seen:
+        Watchdog.world, Watchdog.phase = a.gpus, "unknown (no rank left a record)"
+        partial_record("bench.py: the %d-rank job exited with status %d and no rank printed a record (see stderr)" % (a.gpus, rc))
+    sys.exit(rc)
 
 
 def launch_check(a, world, rank):
@@ -244,11 +343,17 @@ def launch_check(a, world, rank):
     set_phase("timed region")
     if os.environ.get("BENCH_TEST_HANG") == "run" and rank == world - 1:
         time.sleep(3600)                                     # (tests: a rank stuck in the run -- the default watchdog must end it loudly)
+    if os.environ.get("BENCH_TEST_HANG") == "rank0-dies" and rank == 0:
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)                 # (tests: rank 0 dies FIRST and silently -- the survivors must leave the record)
+    if os.environ.get("BENCH_TEST_HANG") == "all-die":
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)                 # (tests: nobody is left to write a record -- the launching bench.py does)
     comm.dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))                            # "the timed region": rank r takes (r + 1) x 10 ms
     local_dt = time.perf_counter() - t0
-    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
+    set_phase(AFTER_TIMED)
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, 1)
     streams = comm.gather({"rank": rank, "tflops": 1000.0 + rank})
@@ -256,6 +361,7 @@ def launch_check(a, world, rank):
         time.sleep(0.2)                                      # rank 0's extras (cpu_baseline, train_step): the others wait in comm.finish()
         print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "max_over_ranks": float(world),
                           "ms_per_step": dt * 1e3, "ms_per_step_ranks": spread, "per_rank": streams, "preflight": pre}), flush=True)
+        Watchdog.done = True
     comm.finish()
 
 
@@ -302,6 +408,7 @@ class Comm:
     def finish(self):
         if self.dist is not None:
             self.barrier()
+            Watchdog.done = True                             # rank 0's record is out (it printed before this barrier)
             self.dist.destroy_process_group()
 
 
@@ -315,7 +422,7 @@ def cpu_baseline_train(n_rays: int = 512, steps: int = 3):
     """The reference's training step on the host cores (the oracle's restatement of train.py:164-199 under torch autograd + torch.optim.Adam,
     fp32), `steps` steps of `n_rays` rays at 64 + 128 samples after one warm-up step."""
     import torch.nn.functional as F
-    import weights as Wt
+    from nerf_amd import synthetic_weights as Wt
     from oracle import nerf_oracle as O
     torch.manual_seed(0)
     prop = {k: v.clone().requires_grad_(True) for k, v in Wt.proposal_state("small").items()}
@@ -354,7 +461,7 @@ def cpu_baseline(n_rays: int):
     """The reference CPU path (= the oracle, proven equal to the reference by tests/test_oracle_golden.py),
     fp32, all host cores, on the first `n_rays` rays of the same image; one 2500-ray tile at a time like
     render_image does."""
-    import weights as Wt
+    from nerf_amd import synthetic_weights as Wt
     from oracle import nerf_oracle as O
     prop_sd, mip_sd = Wt.proposal_state("small"), Wt.mip_state("small")
     pose = O.pose_spherical(30.0, -30.0, 4.0)[:3]
@@ -542,15 +649,22 @@ def train_rate(precision):
     for n, iters in ((512, 60), (4096, 40), (16384, 30)):
         out["rays_%d" % n] = entry(n, mod.make_step(n, 64, 128, precision), iters, 5, profile_kernels=(n == 16384))
     out["rays_512_hipgraph"] = entry(512, mod.make_step(512, 64, 128, precision, graph=True), 100, 5)
+    # the reference's DEFAULT training batch (--sample_ray_num 1024, procedures.py:170), eager and replayed from a hipGraph; `kernel_sum`
+    # = the kernels' own durations with every launch gap removed + the number of launches of one step
+    out["rays_1024"] = entry(1024, mod.make_step(1024, 64, 128, precision), 60, 5, profile_kernels=True)
+    out["rays_1024_hipgraph"] = entry(1024, mod.make_step(1024, 64, 128, precision, graph=True), 100, 5)
+    for k in ("rays_1024", "rays_1024_hipgraph"):
+        out[k]["roofline_frac"] = out[k]["rays_per_s"] * 3 * FLOP_PER_RAY / peak
     best = out["rays_16384"]["rays_per_s"]
     out["roofline"] = {"bound": "mfma", "kernel": "whole training step, 16384 rays (3 x 162.4 MFLOP/ray)", "achieved": best * 3 * FLOP_PER_RAY / 1e12,
                        "peak": peak / 1e12, "unit": "TFLOP/s", "frac": best * 3 * FLOP_PER_RAY / peak, "traffic": None}
     # measured traffic of one step from the committed PMC passes, and the bandwidth it implies at this run's step time, next to the
     # algorithmic floor of the dump design (2 KiB per sample and hidden layer)
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    step_bytes = json.load(open(tfile)).get("train_step_16384_%s" % precision) if os.path.exists(tfile) else None
+    step_bytes, step_src = committed_traffic("train_step_16384_%s" % precision)
     floor_bytes = 16384 * (N_FINE * 8 + C_COARSE * 4) * 2048.0
     out["roofline"]["traffic"] = step_bytes
+    out["roofline"]["traffic_source"] = step_src
+    out["roofline"]["traffic_stale"] = step_src["stale"] if step_src else None
     out["roofline"]["hbm"] = {"algorithmic_bytes": floor_bytes, "measured_bytes": step_bytes, "peak_tbps": 8.0,
                               "achieved_tbps": (step_bytes * best / 16384 / 1e12) if step_bytes else None,
                               "algorithmic_tbps": floor_bytes * best / 16384 / 1e12}
@@ -562,6 +676,11 @@ def train_rate(precision):
         e["roofline_frac"] = e["rays_per_s"] * 3 * ref_flop_per_ray / peak
         e["note"] = "Ref-NeRF step with prop_normal (train.py:176-187); roofline_frac = 3 x %.1f MFLOP/ray (forward + dgrad + wgrad; the two density-gradient chains not counted) / MFMA peak" % (ref_flop_per_ray / 1e6)
         out["refnerf_rays_%d" % n] = e
+    for graph in (False, True):                            # the reference's default batch on the Ref-NeRF branch
+        step = mod.make_ref_step(1024, 64, 128, precision, graph=graph)
+        e = entry(1024, step, 60 if graph else 30, 3, profile_kernels=not graph)
+        e["roofline_frac"] = e["rays_per_s"] * 3 * ref_flop_per_ray / peak
+        out["refnerf_rays_1024" + ("_hipgraph" if graph else "")] = e
     import nerf_amd
     nerf_amd.set_precision(precision)
     return out
@@ -695,7 +814,7 @@ def train_ddp(a, comm):
             step(i)
     comm.sync()
     local_dt = time.perf_counter() - t0
-    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
+    set_phase(AFTER_TIMED)
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, a.steps)
     ar_ms = [s_.elapsed_time(e_) for s_, e_ in ev] if graph is None else None
@@ -732,6 +851,7 @@ def train_ddp(a, comm):
         if comm.preflight is not None:
             rec["preflight"] = comm.preflight
         print(json.dumps(rec), flush=True)
+        Watchdog.done = True
     set_phase("finish (host-side barrier)")
     comm.finish()
 
@@ -740,7 +860,7 @@ def render_strong(a, comm):
     """--mode render-strong: ONE 800x800 image per step, its 640 000 rays split into `world` contiguous shards (no collective on
     the data path), every uniform drawn in-kernel as a function of the GLOBAL ray index -- so the image does not depend on N -- and one
     all_gather of rgb + depth (16 B/ray) at the end of the step.  value = image rays / max-over-ranks time; "scaling": "strong"."""
-    import weights as Wt
+    from nerf_amd import synthetic_weights as Wt
     from nerf_amd import ops, parallel
     from nerf_amd.addtional import ProposalNetwork
     from nerf_amd.mip_model import MipNeRF
@@ -778,7 +898,7 @@ def render_strong(a, comm):
         img = step(a.warmup + i)
     comm.sync()
     local_dt = time.perf_counter() - t0
-    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
+    set_phase(AFTER_TIMED)
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, a.steps)
     assert img.shape == (n, 4) and bool(torch.isfinite(img).all())
@@ -808,6 +928,7 @@ def render_strong(a, comm):
         if comm.preflight is not None:
             rec["preflight"] = comm.preflight
         print(json.dumps(rec), flush=True)
+        Watchdog.done = True
     set_phase("finish (host-side barrier)")
     comm.finish()
 
@@ -826,8 +947,9 @@ def main():
     # every thread's Python stack + a partial JSON line + non-zero exit after N seconds: armed by DEFAULT at 900 s when N > 1 (a stuck
     # collective must show up inside the driver's 1 800 s slot as a message, not as a killed job); BENCH_DUMP_STACKS_AFTER=N overrides, 0 = off
     limit = int(os.environ.get("BENCH_DUMP_STACKS_AFTER", "900" if world > 1 else "0"))
-    if limit > 0:
-        Watchdog(limit, "the run")
+    Watchdog.arm_run(limit)
+    if world > 1:
+        install_termination_record()
     if a.launch_check:
         return launch_check(a, world, rank)
     dist = None
@@ -858,7 +980,7 @@ def main():
     if a.mode == "render-strong":
         return render_strong(a, comm)
 
-    import weights as Wt
+    from nerf_amd import synthetic_weights as Wt
     from nerf_amd import ops
     from nerf_amd.addtional import ProposalNetwork
     from nerf_amd.mip_model import MipNeRF
@@ -948,7 +1070,7 @@ def main():
         out = step(a.warmup + i, i)
     comm.sync()
     local_dt = time.perf_counter() - t0
-    set_phase("after the timed region (max over ranks, per-rank statistics, rank 0's solo measurements)")
+    set_phase(AFTER_TIMED)
     dt = comm.max_over_ranks(local_dt)
     spread = rank_spread(comm, local_dt, a.steps)
     assert os.environ.get("NERF_AMD_LIB") or bool(torch.isfinite(out[0]).all())     # (ablation builds compute garbage)
@@ -974,10 +1096,7 @@ def main():
     if rank == 0:
         # HBM traffic of the dominant kernel per launch: rocprofv3 PMC passes of this same command (profiles/*pmc*), FETCH_SIZE
         # doubled per the gfx950 note of MI355X_MICROARCH.md; null when no profile for this configuration is committed
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("%s_%s" % (a.model, a.precision))
+        traffic, traffic_src = committed_traffic("%s_%s" % (a.model, a.precision))
         rec = {
             "metric": "rays/s (64+128 samples), 800x800" if not is_ref else "rays/s (64+192 samples, Ref-NeRF), 800x800", "value": world * a.steps * n_rays / dt, "unit": "rays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "ms_per_step_ranks": spread,
@@ -992,8 +1111,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                          "ms_per_launch": fine_ms, "ms_per_launch_ranks": fine_ms_ranks, "flop_per_launch": fine_flops, "traffic": traffic,
-                         "traffic_source": ("not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, committed as "
-                                            "profiles/pmc_traffic.json (PMC collection needs the profiler around the process)") if traffic is not None else None,
+                         "traffic_source": dict(traffic_src, note="not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same "
+                                                "command, committed in profiles/pmc_traffic.json with the kernel-source hashes") if traffic is not None else None,
+                         "traffic_stale": traffic_src["stale"] if traffic_src else None,
                          # MFMA work actually issued (512 MAC per 32x16 fragment and sample; padded K, bottle_neck folded away)
                          "executed_tflops": executed_flops / (fine_ms * 1e-3) / 1e12, "executed_frac": executed_flops / (fine_ms * 1e-3) / peak},
             "roofline_proposal": {"bound": "mfma", "kernel": "proposal_kernel (63->%dx4->1, %d MAC/sample, stratified sample fetch + encoding in the prologue)" % (wd, mac_prop),
@@ -1019,9 +1139,17 @@ def main():
         if comm.preflight is not None:
             rec["preflight"] = comm.preflight
         print(json.dumps(rec), flush=True)
+        Watchdog.done = True
     set_phase("finish (host-side barrier)")
     comm.finish()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:                               # (SystemExit included: the preflight's one-line refusals)
+        # an N > 1 rank that dies of an exception (a collective whose peer vanished, a refused preflight) leaves the record as well
+        failed = not isinstance(e, SystemExit) or e.code not in (None, 0)
+        if failed and Watchdog.world > 1 and "WORLD_SIZE" in os.environ and not Watchdog.done:
+            partial_record("bench.py: rank %d of %d ended with %s: %s" % (Watchdog.rank, Watchdog.world, type(e).__name__, str(e)[:300]))
+        raise

@@ -1,0 +1,7 @@
+"""`nerf.param_com` served by the MI355X-native package: every name of nerf_amd.param_com."""
+from nerf_amd.param_com import *          # noqa: F401,F403
+import nerf_amd.param_com as _impl
+
+
+def __getattr__(name):              # names a star import does not bind (leading underscore, late additions)
+    return getattr(_impl, name)

@@ -1,0 +1,7 @@
+"""`nerf.ref_func` served by the MI355X-native package: every name of nerf_amd.ref_func."""
+from nerf_amd.ref_func import *          # noqa: F401,F403
+import nerf_amd.ref_func as _impl
+
+
+def __getattr__(name):              # names a star import does not bind (leading underscore, late additions)
+    return getattr(_impl, name)

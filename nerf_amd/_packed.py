@@ -10,8 +10,9 @@ class PackedWeightsMixin:
     """Keeps one fragment-ordered weight blob per precision and re-packs it (a GPU kernel, a few microseconds) when the parameters
     may have changed.
 
-    * eval mode: the blob is cached under (data_ptr, tensor._version) of every parameter, i.e. re-packed after an optimizer step or
-      load_state_dict done by the Python process;
+    * eval mode: the blob is cached under (data_ptr, tensor._version) of every parameter + `ops.PARAM_GENERATION` (bumped by every
+      nerf_amd_adam_step launch and every replayed TrainStep graph, which write parameters through raw pointers), i.e. re-packed after
+      an optimizer step -- torch's or this package's -- or load_state_dict;
     * train mode: ALWAYS re-packed and never cached -- parameters also change without `_version` moving (a training step replayed
       from a hipGraph updates them on the device only), so a version key cannot be trusted while training;
     * every train()/eval() switch and `invalidate_packed()` drop the cache, so the first eval-mode render after (graph-replayed)
@@ -129,7 +130,7 @@ class PackedWeightsMixin:
         return ops.pack_weights_backward(self._net_id, precision, self.kernel_params()[0])
 
     def _packed_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (ops.PARAM_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def invalidate_packed(self) -> None:
         self.__dict__.setdefault("_packed_cache", {}).clear()

@@ -690,7 +690,10 @@ int nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int pr
     if (ipe) {                                              // row 12 inside the fine pass: the direction norm of this ray batch
         if (!(camera->ipe_radius > 0.0f)) return fail(NERF_AMD_EINVAL, "integrated PE needs a positive ipe_radius");
         // (the density buffer is scratch until the proposal pass below writes it: room for the 256 fp64 workgroup partials when N >= 8)
-        if (int e = (N >= 8) ? sk_dirs_norm_scratch(rays, N, dir_norm, density, st) : sk_dirs_norm(rays, N, dir_norm, st))
+        // a caller that renders a SHARD of a ray list hands over the norm of the whole list (camera->ipe_dir_norm): the norm of
+        // mip_methods.py:31 is over all rays of the reference's call, not over the rays this launch happens to hold
+        if (camera->ipe_dir_norm) dir_norm = const_cast<float*>(camera->ipe_dir_norm);
+        else if (int e = (N >= 8) ? sk_dirs_norm_scratch(rays, N, dir_norm, density, st) : sk_dirs_norm(rays, N, dir_norm, st))
             return hip_status(e, "direction norm");
     }
     const float jitter = (far - near) / (float)n_fine;      // procedures.py:59

@@ -38,12 +38,13 @@ def _rows_route(prec: int, keep, layers) -> bool:
 
 def _packed(net, key, layers, columns=None) -> "ops.PackedLinear":
     """the layer's parameters in nerf_amd_rows_gemm's layout, with PackedWeightsMixin's cache rules: eval mode -- cached under (data_ptr,
-    _version) of its tensors (optimizer steps and load_state_dict bump `_version`; `invalidate_packed()` / a train() / eval() switch drop
+    _version) of its tensors + ops.PARAM_GENERATION (torch's optimizer steps and load_state_dict bump `_version`, this package's Adam and
+    replayed graphs bump the generation; `invalidate_packed()` / a train() / eval() switch drop
     the cache); train mode -- packed on every call (a hipGraph-replayed step changes parameters without `_version` moving).  Several
     `layers` = their rows stacked into one product (Ref-NeRF's heads)."""
     layers = layers if isinstance(layers, (list, tuple)) else [layers]
     cache = net.__dict__.setdefault("_rows_packed", {})
-    stamp = tuple((t.data_ptr(), t._version, str(t.device)) for l in layers for t in (l.weight, l.bias))
+    stamp = (ops.PARAM_GENERATION[0],) + tuple((t.data_ptr(), t._version, str(t.device)) for l in layers for t in (l.weight, l.bias))
     hit = None if net.training else cache.get(key)
     if hit is None or hit[0] != stamp:
         w = torch.cat([l.weight.detach() for l in layers], dim=0) if len(layers) > 1 else layers[0].weight.detach()

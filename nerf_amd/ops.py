@@ -616,7 +616,7 @@ def resample(density, z, z_base, u_strat, z_jitter, rays, u_inv, K, softplus=Fal
 def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv, n_fine, near, far, white_bkg,
                 want_depth=True, want_weights=False, workspace: Optional[torch.Tensor] = None, camera: Optional[Samples] = None,
                 ray_offset: int = 0, n_rays: Optional[int] = None, contract: bool = False, ipe_radius: Optional[float] = None,
-                seed: Optional[int] = None, rng_ray_offset: int = 0):
+                seed: Optional[int] = None, rng_ray_offset: int = 0, ipe_dir_norm: Optional[torch.Tensor] = None):
     """The tile body of render_image (procedures.py:64-85) for all given rays in four launches.  `contract`: Mip-NeRF 360 scene
     contraction of every sample position (proposal and fine) before encoding.  `ipe_radius`: the fine pass encodes the conical frusta
     between consecutive fine depths with the integrated PE (mip_methods.py:15-58; explicit `rays` required).
@@ -637,6 +637,9 @@ def render_rays(packed_prop, packed_mip, precision, rays, z_base, u_strat, u_inv
             if rays is None:
                 raise ValueError("nerf_amd: integrated PE needs an explicit ray table")
             camera.ipe, camera.ipe_radius = 1, float(ipe_radius)
+            # the direction norm of mip_methods.py:31 is over ALL rays of the reference's call: a caller holding only a shard of them
+            # passes the whole list's norm (ops.dirs_norm of it); default = the norm of `rays`, computed by the entry point
+            camera.ipe_dir_norm = _dev(ipe_dir_norm, "ipe_dir_norm").data_ptr() if ipe_dir_norm is not None else None
         if in_kernel_rng:
             camera.rng_seed, camera.rng_ray_offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_ray_offset)
     if n_rays is None:
@@ -913,6 +916,16 @@ def mip_weight_grads(precision: int, M: int, dump: torch.Tensor, delta: torch.Te
     return gw, gb
 
 
+# Parameters updated through raw pointers (nerf_amd_adam_step, a replayed hipGraph) never move torch's `_version`: this counter is part
+# of every packed-weight cache key (PackedWeightsMixin.packed, generic_path._packed) and is bumped by whatever writes parameters behind
+# torch's back, so that an eval-mode module never renders with weights packed before the update.
+PARAM_GENERATION = [0]
+
+
+def parameters_changed() -> None:
+    PARAM_GENERATION[0] += 1
+
+
 def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp_avg: Sequence[torch.Tensor], exp_avg_sq: Sequence[torch.Tensor],
               step: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0,
               lr_dev: Optional[torch.Tensor] = None) -> None:
@@ -927,6 +940,7 @@ def adam_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], exp
     numel = (C.c_int64 * n)(*[p.numel() for p in params])
     check(lib.nerf_amd_adam_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), numel, n, _ptr(step),
                                  float(lr), _ptr(lr_dev), float(beta1), float(beta2), float(eps), float(grad_scale), _stream()), "nerf_amd_adam_step")
+    parameters_changed()
 
 
 # ------------------------------------------------------------------------------------------------ Ref-NeRF training / density gradients

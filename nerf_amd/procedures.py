@@ -147,6 +147,9 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
         seed = None
         u_strat, u_inv = _draw_uniforms(H, W, sample_num, sz, patch_num, dev, rng)
     off = 0
+    # integrated PE: ONE direction norm over the call's rays (mip_methods.py:31) -- taken BEFORE a shard is cut out, so that every shard
+    # encodes with the norm of the whole image and the gathered image equals the single-process one
+    ipe_dir_norm = ops.dirs_norm(rays) if ipe else None
     if _shard is not None:
         off = int(_shard[0])
         rays = rays[off: int(_shard[1])].contiguous()
@@ -167,12 +170,12 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
                                                       is_ref_model=is_ref_model,
                                                       cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed,
                                                       ray_offset=off, contract=contract, ipe_radius=ipe_radius,
-                                                      ipe_dir_norm=ops.dirs_norm(rays) if ipe_radius is not None else None)   # (mip_methods.py:31: ONE norm over the call's rays)
+                                                      ipe_dir_norm=ipe_dir_norm)
     elif not is_ref_model:
         # (a narrow fine network has no integrated-PE kernel: with ipe its 256-wide -- zero-padded -- blob is used)
         rgb, depth, _, _ = ops.render_rays(prop_net.packed(prec), network.packed(prec, wide=bool(ipe)), prec, rays, z_base, u_strat, u_inv,
                                            sample_num, near, far, white_bkg, want_depth=bool(render_depth), contract=contract,
-                                           ipe_radius=ipe_radius, seed=seed, rng_ray_offset=off)
+                                           ipe_radius=ipe_radius, seed=seed, rng_ray_offset=off, ipe_dir_norm=ipe_dir_norm)
     else:
         # Ref-NeRF branch (procedures.py:71-74): coarse and fine depths are merged and sorted, the last one dropped,
         # sigma -> softplus(sigma + 0.5) before compositing (nerf_amd_render_rays_ref: six launches; the sort is a merge of two

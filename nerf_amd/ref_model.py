@@ -171,6 +171,8 @@ class RefNeRF(PackedWeightsMixin, NeRF):
         if self.training and self.perturb_bottle_neck_w > 0:
             if getattr(self, "noise_rng", "philox") == "philox" and self.bottle_neck_dim == 128:
                 seed_dev = self.__dict__.get("noise_seed_dev")
+                if seed_dev is not None and seed_dev.device != pos.device:
+                    seed_dev = None                          # a TrainStep's key on ANOTHER device (module moved since): host-drawn key instead
                 seed = 0 if seed_dev is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
                 if fused_train:
                     noise_kw = dict(noise_std=float(self.perturb_bottle_neck_w), noise_seed=seed, noise_seed_dev=seed_dev)

@@ -93,6 +93,19 @@ class TrainStep:
         self.grad_clip = float(grad_clip)
         self.graph = None
 
+    def release(self) -> None:
+        """Take this step's device-resident noise key off the Ref-NeRF module again (planted by the constructor): a module that outlives
+        its TrainStep -- moved to another device, trained by hand -- draws its bottle-neck noise key from torch's CPU generator as before."""
+        net = getattr(self, "mip_net", None)
+        if net is not None and getattr(self, "is_ref", False) and net.__dict__.get("noise_seed_dev") is getattr(self, "seed", None):
+            net.__dict__.pop("noise_seed_dev", None)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
     # ---------------------------------------------------------------------------------------------------------------- the iteration
     def _body(self):
         pixels, coords = randomFromOneImage(self.image, self.crop_xy)                     # pure indexing on the device (cached table)
@@ -196,6 +209,7 @@ class TrainStep:
         if self.graph is not None:
             self.opt.sync_lr()                                                            # a scheduler may have rewritten param_groups' lr
             self.graph.replay()
+            ops.parameters_changed()                                                      # (the captured Adam launch ran: packed caches are stale)
         else:
             self._body()
         return self.loss, self.img_loss

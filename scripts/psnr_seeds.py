@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--ckpts", type=int, default=3, help="held-out renders at the end of the run (every 100 iterations), averaged")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--resume-dir", default=None, help="cpu mode: save / resume the run state under this directory")
+    ap.add_argument("--keep-all", action="store_true", help="cpu mode: keep EVERY 250-iteration state (+ held-out PSNR) for scripts/psnr_windows.py")
     a = ap.parse_args()
     if a.threads > 0:
         torch.set_num_threads(a.threads)
@@ -52,7 +53,8 @@ def main():
         for seed in [int(s) for s in a.seeds.split(",")]:
             t0 = time.time()
             if mode == "cpu":
-                hist, held = T.run_oracle(views, seed, None if a.resume_dir is None else os.path.join(a.resume_dir, "cpu_seed%d.state" % seed))
+                hist, held = T.run_oracle(views, seed, None if a.resume_dir is None else os.path.join(a.resume_dir, "cpu_seed%d.state" % seed),
+                                          keep_all=a.keep_all)
             elif mode == "bf16-fp8dumps":                                # bf16 arithmetic, training dumps in scaled e4m3 (nerf_amd.set_train_dumps)
                 import nerf_amd
                 nerf_amd.set_train_dumps("fp8")

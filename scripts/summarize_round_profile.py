@@ -75,10 +75,13 @@ lines += ["* %s: %.3f GB" % (k, v / 1e9) for k, v in traffic.items()]
 lines += ["", "Algorithmic bytes per launch (DESIGN.md section 2): mip_kernel 0.35 GB in + 1.31 GB out = 1.66 GB; proposal 0.18 + 0.16 = 0.34 GB; "
           "resample 0.49 GB in the default Philox mode (0.99 GB with resident uniforms); composite 1.98 GB."]
 open(os.path.join(DST, prefix + "_pmc_summary.md"), "w").write("\n".join(lines) + "\n")
-tfile = os.path.join(DST, "pmc_traffic.json")
-tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
-tj.update({"mip_bf16": traffic.get("mip_kernel"),
-           "_source": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command; bytes per "
-                      "launch of the dominant kernel)" % prefix})
-json.dump(tj, open(tfile, "w"), indent=1)
+# recorded WITH the hashes of the kernel sources of this tree (bench.py flags the figure as stale when they change)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import update_pmc_traffic as upt
+tj = json.load(open(upt.FILE)) if os.path.exists(upt.FILE) else {}
+if traffic.get("mip_kernel"):
+    tj["mip_bf16"] = {"bytes": traffic["mip_kernel"], "round": prefix.split("_")[0], "sources": upt.source_hashes("mip_bf16"),
+                      "measured_by": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command; bytes per "
+                                     "launch of the dominant kernel)" % prefix}
+json.dump(tj, open(upt.FILE, "w"), indent=1)
 print("\n".join(lines))

@@ -45,11 +45,12 @@ for c in val:
         steps_pmc = len(set(r["Dispatch_Id"] for r in rows if "mip_bwd_kernel" in r["Kernel_Name"] or "ref_heads_delta_kernel" in r["Kernel_Name"]))
 step_bytes = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / max(1, steps_pmc)
 lines += ["", "Whole step (all dispatches of the run / %d steps): %.2f GB of HBM traffic." % (steps_pmc, step_bytes / 1e9)]
-tfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
-tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
-tj["train_step_%s" % cfg] = step_bytes
-tj["_source_train_step"] = "scripts/gpu_train_profile.sh PMC=1 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_train_rate.py), all dispatches of a step"
-json.dump(tj, open(tfile, "w"), indent=1)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import update_pmc_traffic as upt
+tj = json.load(open(upt.FILE)) if os.path.exists(upt.FILE) else {}
+tj["train_step_%s" % cfg] = {"bytes": step_bytes, "round": os.environ.get("ROUND_TAG", "r06"), "sources": upt.source_hashes("train_step_%s" % cfg),
+                             "measured_by": "scripts/gpu_train_profile.sh PMC=1 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_train_rate.py), all dispatches of a step"}
+json.dump(tj, open(upt.FILE, "w"), indent=1)
 out = "\n".join(lines) + "\n"
 open(os.path.join(d, "train_pmc_summary.md"), "w").write(out)
 print(out)

@@ -73,6 +73,28 @@ def write_signatures():
     print("wrote g20_signatures.json (%d names)" % sum(len(v) for v in rec.values()))
 
 
+def write_entry_imports():
+    """G23: the names the reference's entry scripts import from `nerf.*` (train.py:12-20, ddp_train.py:17-25, model_average.py:16-27),
+    `*` resolved to the public names the star import binds -- the list a `nerf` stand-in package must serve (SURVEY.md section 8b:
+    "importable as nerf.*").  Data (module and attribute names), no source text."""
+    import importlib
+    import json
+    import sigtools
+    rec = {}
+    for script in sigtools.ENTRY_SCRIPTS:
+        imp = sigtools.entry_imports(os.path.join(REF, script))
+        for m, names in imp.items():
+            if "*" in names:
+                mod = importlib.import_module("nerf." + m)
+                public = getattr(mod, "__all__", None) or [n for n, o in vars(mod).items()
+                                                           if not n.startswith("_") and getattr(o, "__module__", None) == mod.__name__]
+                imp[m] = sorted(set(n for n in names if n != "*") | set(public))
+        rec[script] = imp
+    with open(os.path.join(HERE, "g23_entry_imports.json"), "w") as f:
+        json.dump(rec, f, indent=0, sort_keys=True)
+    print("wrote g23_entry_imports.json (%d names)" % sum(len(v) for s in rec.values() for v in s.values()))
+
+
 def write_shallow_encodings():
     """G21: the reference's three networks built with FEWER encoding octaves and / or cat_origin=False (constructor arguments,
     mip_model.py:15-18, addtional.py:61, ref_model.py:17-24) -- forward values and (the first 8 rows of) parameter gradients of sum(out * G) from the REAL modules.
@@ -138,6 +160,7 @@ def write_generic_refnerf():
 def main():
     install_shims()
     if "--signatures-only" in sys.argv:
+        write_entry_imports()
         return write_signatures()
     if "--shallow-only" in sys.argv:
         return write_shallow_encodings()

@@ -2,7 +2,22 @@
 import inspect
 
 MODULES = ("nerf_base", "nerf_helper", "mip_methods", "mip_model", "procedures", "utils", "addtional", "ref_model", "ref_func", "dataset",
-           "param_com", "local_shuffler")        # (`nerf.timer` is control plane -- SURVEY section 2 row 18: the entry scripts keep their own)
+           "param_com", "local_shuffler", "timer")
+ENTRY_SCRIPTS = ("train.py", "ddp_train.py", "model_average.py")
+
+
+def entry_imports(path):
+    """{module: [names]} of every `from nerf.<module> import ...` statement of a script (golden G23: the reference's entry scripts;
+    `*` is recorded as "*")."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    out = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith("nerf."):
+            out.setdefault(node.module[5:], [])
+            out[node.module[5:]] += [a.name for a in node.names]
+    return {k: sorted(set(v)) for k, v in out.items()}
 
 
 def _default(v):

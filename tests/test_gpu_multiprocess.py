@@ -85,6 +85,56 @@ def test_two_rank_sharded_render_and_gradient_allreduce(tmp_path):
     assert got["world3_equal"]
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_three_way_shards_with_integrated_pe_equal_the_whole_image(wide):
+    """with `ipe=` the direction norm of mip_methods.py:31 is ONE norm over the rays of the call.  A shard used to
+    take the norm of its own rays only (i_m_ddt = 1 - dd / norm off by ~sqrt(world)), so the gathered image depended on the world size.
+    The norm is now taken over the whole tile-ordered ray list before a shard is cut: three shards stitched together ARE the
+    single-process image, bit for bit, on the fused route and (`wide`: hidden width 320 -> layer by layer) on the generic one; a shard
+    rendered with its OWN norm differs (the regression this guards)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import nerf_amd
+    from nerf_amd import ops, parallel
+    from nerf_amd.procedures import render_image
+    nerf_amd.set_precision("fp32")
+    if wide:
+        import weights as W
+        from nerf_amd.addtional import ProposalNetwork
+        from nerf_amd.mip_model import MipNeRF
+        prop, mip = ProposalNetwork(10, 320), MipNeRF(10, 4, 320)
+        prop.load_state_dict(W.proposal_state("small", hidden=320))
+        mip.load_state_dict(W.mip_state("small", hidden=320))
+        prop, mip = prop.cuda().eval(), mip.cuda().eval()
+    else:
+        prop, mip = _nets()
+    pose, focal = _pose_focal()
+    with torch.no_grad():
+        one = render_image(mip, prop, pose, H, focal, NEAR, FAR, SAMPLES, white_bkg=True, render_depth=True, seed=5, ipe=True)
+        plain = render_image(mip, prop, pose, H, focal, NEAR, FAR, SAMPLES, white_bkg=True, render_depth=True, seed=5)
+        parts = []
+        for r in range(3):
+            s0, e0 = parallel.shard_range(H * H, r, 3, align=256)
+            parts.append(render_image(mip, prop, pose, H, focal, NEAR, FAR, SAMPLES, white_bkg=True, render_depth=True, seed=5, ipe=True, _shard=(s0, e0)))
+    rgb3 = parts[0]["to_image"](torch.cat([q["rgb_rays"] for q in parts]), 3)
+    dep3 = parts[0]["to_image"](torch.cat([q["depth_rays"] for q in parts]).unsqueeze(-1), 1)
+    assert torch.equal(rgb3, one["rgb"]) and torch.equal(dep3.expand(3, -1, -1), one["depth_img"])
+    assert not torch.equal(one["rgb"], plain["rgb"])                                    # the integrated PE is really on
+    if not wide:
+        # the regression: a shard encoded with the norm of its own rays is another image
+        s0, e0 = parallel.shard_range(H * H, 1, 3, align=256)
+        fx, fy = (float(focal[1]), float(focal[0])) if isinstance(focal, (tuple, list)) else (float(focal), float(focal))
+        rays = ops.generate_rays(pose, H, H, fx, fy, pose.device)
+        rays = rays.view(H, H, 6).reshape(2, 50, 2, 50, 6).permute(0, 2, 1, 3, 4).reshape(-1, 6)[s0:e0].contiguous()
+        P = ops.current_precision()
+        z_base = torch.linspace(NEAR, FAR, 64).cuda()
+        with torch.no_grad():
+            own, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P, wide=True), P, rays, z_base, None, None, SAMPLES, NEAR, FAR, True,
+                                           ipe_radius=2.0 / (12.0 ** 0.5) / fx, seed=5, rng_ray_offset=s0)
+        assert not torch.equal(own, parts[1]["rgb_rays"])
+
+
 # ------------------------------------------------------------------------------------------------ data-parallel training step
 N_TRAIN, C_TRAIN, F_TRAIN = 64, 32, 64
 

@@ -63,9 +63,26 @@ def psnr(mse):
     return -10.0 * math.log10(max(mse, 1e-12))
 
 
-def run_oracle(views, seed, resume=None):
+def held_out_oracle(prop, mip, views):
+    """PSNR of the held-out views through the oracle's render path with FIXED uniforms (a private generator: the training stream is not touched)."""
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(99)
+        psd, msd = {k: v.detach() for k, v in prop.items()}, {k: v.detach() for k, v in mip.items()}
+        vals = []
+        for rays_h, tgt_h in views[len(views) - N_HELD:]:
+            u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g), torch.rand(rays_h.shape[0], F_N + 1, generator=g)
+            rgb = torch.cat([O.render_rays(psd, msd, rays_h[a:a + HELD_CHUNK], u1[a:a + HELD_CHUNK], u2[a:a + HELD_CHUNK], NEAR, FAR, F_N,
+                                           white_bkg=True)[0] for a in range(0, rays_h.shape[0], HELD_CHUNK)])
+            vals.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+    return sum(vals) / len(vals)
+
+
+def run_oracle(views, seed, resume=None, keep_all=False, init=None, stop=None):
     """`resume`: a path; the whole state (weights, Adam moments, the generator, the histories) is saved there every 250 iterations and a
-    run restarted with the same path continues bit-identically (the hours-long CPU runs of scripts/psnr_seeds.py)."""
+    run restarted with the same path continues bit-identically (the hours-long CPU runs of scripts/psnr_seeds.py).  `keep_all`: every one
+    of those states is ALSO kept as `<resume>.it<NNNNN>` together with the held-out PSNR at that iteration (`held_at`) -- the checkpoints
+    scripts/psnr_windows.py teacher-forces the HIP paths from.  `init` (a state as saved here) + `stop`: run the WINDOW [init['it'], stop)
+    from that exact state (parameters, Adam moments, step counts, generator position) and return its losses + the held-out PSNR at `stop`."""
     torch.manual_seed(seed)
     prop = {k: v.clone().requires_grad_(True) for k, v in W.proposal_state("small").items()}
     mip = {k: v.clone().requires_grad_(True) for k, v in W.mip_state("small").items()}
@@ -86,11 +103,25 @@ def run_oracle(views, seed, resume=None):
         opt.load_state_dict(st["opt"])
         torch.set_rng_state(st["rng"])
         hist, held, start = st["hist"], st["held"], st["it"]
-    for it in range(start, ITERS):
-        if resume is not None and it > start and it % 250 == 0:
-            torch.save({"prop": {k: v.detach() for k, v in prop.items()}, "mip": {k: v.detach() for k, v in mip.items()}, "opt": opt.state_dict(),
-                        "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": it, "recipe": recipe}, resume + ".tmp")
+    if init is not None:
+        assert resume is None and tuple(init["recipe"]) == recipe, (init.get("recipe"), recipe)
+        with torch.no_grad():
+            for k, v in init["prop"].items():
+                prop[k].copy_(v)
+            for k, v in init["mip"].items():
+                mip[k].copy_(v)
+        opt.load_state_dict(init["opt"])
+        torch.set_rng_state(init["rng"])
+        start = init["it"]
+    for it in range(start, ITERS if stop is None else stop):
+        if resume is not None and (it > start or (keep_all and it == 0)) and it % 250 == 0:
+            state = {"prop": {k: v.detach() for k, v in prop.items()}, "mip": {k: v.detach() for k, v in mip.items()}, "opt": opt.state_dict(),
+                     "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": it, "recipe": recipe}
+            torch.save(state, resume + ".tmp")
             os.replace(resume + ".tmp", resume)
+            if keep_all:
+                state["held_at"] = held_out_oracle(prop, mip, views)
+                torch.save(state, resume + ".it%05d" % it)
         rays_all, rgb_all = views[it % (len(views) - N_HELD)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,))
         rays, tgt = rays_all[idx], rgb_all[idx]
@@ -113,21 +144,52 @@ def run_oracle(views, seed, resume=None):
         hist.append(loss_img.item())
         if PROGRESS_EVERY and (it + 1) % PROGRESS_EVERY == 0:            # the hours-long CPU runs: a partial run still leaves its trajectory
             print("PROGRESS seed %d it %d train-psnr(last 200) %.3f" % (seed, it + 1, psnr(sum(hist[-200:]) / len(hist[-200:]))), flush=True)
-        if it + 1 in CHECKPOINTS:
-            with torch.no_grad():                                        # held-out views, fixed uniforms
-                g = torch.Generator().manual_seed(99)
-                psd, msd = {k: v.detach() for k, v in prop.items()}, {k: v.detach() for k, v in mip.items()}
-                vals = []
-                for rays_h, tgt_h in views[len(views) - N_HELD:]:
-                    u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g), torch.rand(rays_h.shape[0], F_N + 1, generator=g)
-                    rgb = torch.cat([O.render_rays(psd, msd, rays_h[a:a + HELD_CHUNK], u1[a:a + HELD_CHUNK], u2[a:a + HELD_CHUNK], NEAR, FAR, F_N,
-                                                   white_bkg=True)[0] for a in range(0, rays_h.shape[0], HELD_CHUNK)])
-                    vals.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
-                held.append(sum(vals) / len(vals))
+        if it + 1 in CHECKPOINTS and stop is None:
+            held.append(held_out_oracle(prop, mip, views))                # held-out views, fixed uniforms
+    if stop is not None:
+        return hist, [held_out_oracle(prop, mip, views)]
+    if keep_all and resume is not None:                                   # the end of the run closes the last window
+        torch.save({"prop": {k: v.detach() for k, v in prop.items()}, "mip": {k: v.detach() for k, v in mip.items()}, "opt": opt.state_dict(),
+                    "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": ITERS, "recipe": recipe,
+                    "held_at": held_out_oracle(prop, mip, views)}, resume + ".it%05d" % ITERS)
     return hist, held
 
 
-def run_hip(views, seed, precision):
+def held_out_hip(prop, mip, gviews, n_views):
+    """the same held-out figure through the HIP render path (the uniforms of held_out_oracle, copied to the device)"""
+    from nerf_amd import ops
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(99)
+        P = ops.current_precision()
+        vals = []
+        for rays_h, tgt_h in gviews[n_views - N_HELD:]:
+            u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g).cuda(), torch.rand(rays_h.shape[0], F_N + 1, generator=g).cuda()
+            rgb, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P), P, rays_h, torch.linspace(NEAR, FAR, 64).cuda(), u1, u2, F_N, NEAR, FAR, True)
+            vals.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
+    return sum(vals) / len(vals)
+
+
+def load_oracle_state(init, prop, mip, opt):
+    """A state saved by run_oracle (parameters as name -> tensor, torch.optim.Adam's state_dict over list(mip) + list(prop), the CPU
+    generator) into the HIP modules + their optimizer: parameters and both Adam moments by NAME (the state_dict indexes by position),
+    step counts as they are, the generator position exactly."""
+    prop.load_state_dict({k: v.detach().clone() for k, v in init["prop"].items()})
+    mip.load_state_dict({k: v.detach().clone() for k, v in init["mip"].items()})
+    names = ["mip." + k for k in init["mip"]] + ["prop." + k for k in init["prop"]]            # the oracle's optimizer order
+    by_name = {n: init["opt"]["state"].get(i) for i, n in enumerate(names)}
+    for pre, mod in (("mip.", mip), ("prop.", prop)):
+        for k, p in mod.named_parameters():
+            st = by_name[pre + k]
+            if st is None:                                                                       # (iteration 0: no moments yet)
+                continue
+            opt.state[p] = {"step": st["step"].detach().clone(), "exp_avg": st["exp_avg"].detach().clone().to(p.device),
+                            "exp_avg_sq": st["exp_avg_sq"].detach().clone().to(p.device)}
+    torch.set_rng_state(init["rng"])
+
+
+def run_hip(views, seed, precision, init=None, stop=None):
+    """`init` (a state saved by run_oracle) + `stop`: the window [init['it'], stop) teacher-forced from the ORACLE's exact state --
+    parameters, Adam moments, step counts, generator position -- on the HIP path; returns the window's losses + the held-out PSNR at `stop`."""
     import nerf_amd
     from nerf_amd import ops
     from nerf_amd.addtional import ProposalNetwork, ProposalLoss, getBounds
@@ -149,7 +211,11 @@ def run_hip(views, seed, precision):
     res = (FAR - NEAR) / C_N
     hist, held = [], []
     gviews = [(r.cuda(), c.cuda()) for r, c in views]
-    for it in range(ITERS):
+    start = 0
+    if init is not None:
+        load_oracle_state(init, prop, mip, opt)
+        start = init["it"]
+    for it in range(start, ITERS if stop is None else stop):
         rays_all, rgb_all = gviews[it % (len(views) - N_HELD)]
         idx = torch.randint(0, rays_all.shape[0], (RAYS,)).cuda()
         rays, tgt = rays_all[idx].contiguous(), rgb_all[idx]
@@ -172,16 +238,10 @@ def run_hip(views, seed, precision):
         hist.append(loss_img.item())
         if PROGRESS_EVERY and (it + 1) % PROGRESS_EVERY == 0:            # the same trajectory lines as run_oracle's: partial CPU runs pair with these
             print("PROGRESS mode %s seed %d it %d train-psnr(last 200) %.3f" % (precision, seed, it + 1, psnr(sum(hist[-200:]) / len(hist[-200:]))), flush=True)
-        if it + 1 in CHECKPOINTS:
-            with torch.no_grad():
-                g = torch.Generator().manual_seed(99)
-                P = ops.current_precision()
-                vals = []
-                for rays_h, tgt_h in gviews[len(views) - N_HELD:]:
-                    u1, u2 = torch.rand(rays_h.shape[0], 64, generator=g).cuda(), torch.rand(rays_h.shape[0], F_N + 1, generator=g).cuda()
-                    rgb, _, _, _ = ops.render_rays(prop.packed(P), mip.packed(P), P, rays_h, torch.linspace(NEAR, FAR, 64).cuda(), u1, u2, F_N, NEAR, FAR, True)
-                    vals.append(psnr(torch.mean((rgb - tgt_h) ** 2).item()))
-                held.append(sum(vals) / len(vals))
+        if it + 1 in CHECKPOINTS and stop is None:
+            held.append(held_out_hip(prop, mip, gviews, len(views)))     # (train mode: packed() re-packs the current weights on every call)
+    if stop is not None:
+        held = [held_out_hip(prop, mip, gviews, len(views))]
     nerf_amd.set_precision("fp32")
     return hist, held
 

@@ -141,7 +141,28 @@ def test_bench_preflight_and_loud_failure_of_a_stuck_run():
     r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "run", "BENCH_DUMP_STACKS_AFTER": "12"})
     assert r.returncode != 0 and "the run did not finish within 12 s" in r.stderr
     part = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert part and part[-1]["value"] is None and "timed region" in part[-1]["phase"]
+    assert part and all(q["value"] is None and "timed region" in q["phase"] and "rank" in q for q in part), part
+
+
+@pytest.mark.timeout(600)
+def test_bench_leaves_a_record_whichever_rank_dies_first():
+    """the loud-failure path must not depend on rank 0 winning a race.  (a) The stuck rank's watchdog fires with NO grace
+    period (the order that lost rank 0's record in round 5): a parsable partial line is on stdout all the same, because every rank writes
+    its own rank-tagged line and a rank the launcher terminates writes one from its SIGTERM watcher.  (b) Rank 0 is killed outright first
+    (SIGKILL, no handler runs): the surviving rank leaves the record.  (c) Every rank is killed: the launching `bench.py --gpus N`
+    process writes the line itself.  The job's status is non-zero in all three."""
+    import json
+    recs = lambda r: [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "run", "BENCH_DUMP_STACKS_AFTER": "10", "BENCH_WATCHDOG_GRACE": "0"})
+    part = recs(r)
+    assert r.returncode != 0 and part and all(q["value"] is None and q["n_gpus"] == 2 for q in part), (r.stdout[-2000:], r.stderr[-2000:])
+    r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "rank0-dies"})
+    part = recs(r)
+    assert r.returncode != 0 and part and all(q["value"] is None for q in part), (r.stdout[-2000:], r.stderr[-2000:])
+    assert any(q.get("rank") == 1 and "terminated by the launcher" in q["error"] for q in part), part
+    r = _bench("--gpus", "2", "--launch-check", env={"BENCH_TEST_HANG": "all-die"})
+    part = recs(r)
+    assert r.returncode != 0 and len(part) == 1 and part[0]["value"] is None and "no rank printed a record" in part[0]["error"], (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_bench_refuses_fewer_ranks_than_asked():
