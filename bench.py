@@ -669,6 +669,7 @@ def train_rate(precision):
                               "achieved_tbps": (step_bytes * best / 16384 / 1e12) if step_bytes else None,
                               "algorithmic_tbps": floor_bytes * best / 16384 / 1e12}
     out["iteration_512"] = iteration_rate(precision)
+    out["iteration_1024"] = iteration_rate(precision, n_rays=1024)      # the reference's default --sample_ray_num through TrainStep (fused loss kernels)
     # Ref-NeRF (BASELINE configs[3]) with prop_normal: the reference's batch and the paper's 2^14-ray batch, 64 + (128 + 64 merged) samples
     ref_flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
     for n, iters in ((512, 40), (16384, 10)):

@@ -273,7 +273,9 @@ struct ActDump {
 };
 template <class P>
 DEVINL void dump_breg(const ActDump& d, int layer, int64_t subtile, int kg, int lane, const typename P::BReg& r) {
+#ifndef ABL_NODUMPST   // cost probe (scripts/gpu_ref_fwd_probe.sh): the training forwards WITHOUT their activation stores -- wrong results, right cost
     P::store_global(d.base + (size_t)layer * d.layer_stride + ((size_t)subtile * 16 + kg) * (size_t)P::BREG_LDS, lane, r);
+#endif
 }
 
 // The backward's ReLU adjoint only needs [y > 0]: next to the activations (the weight gradients' operand) the training forwards
@@ -1376,7 +1378,9 @@ int mlp_launch_ref_train(const void* packed, int precision, const nerf_amd_sampl
     // ISSUE slots (~80 cycles of the vector-memory path each, during which a lone wave per SIMD issues no MFMA; not a wait: the store-aware
     // ring wait changed nothing, mlp_core.h), which a second wave per SIMD fills: 9.01 -> 8.38 ms per 2^14-ray step, same box, alternated
     // twice (profiles/r04_ref_train_fwd_8wave_ab.log); the dump layout does not depend on the tile policy.  -DREF_TRAIN_WIDE = the A side.
+#ifndef REF_TRAIN_WIDE
     if (precision == NERF_AMD_BF16) return launch_ref<PBF16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st, seed, seed_dev, noise_std);
+#endif
     if (precision == NERF_AMD_BF16) return launch_ref<PB16, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st, seed, seed_dev, noise_std);
     return launch_ref<PF32, true>(packed, s, rgbo, normal, bn_noise, d, aux, flags, st, seed, seed_dev, noise_std);
 }

@@ -95,6 +95,53 @@ def write_entry_imports():
     print("wrote g23_entry_imports.json (%d names)" % sum(len(v) for s in rec.values() for v in s.values()))
 
 
+def write_config0_train_step():
+    """G24: BASELINE configs[0] at ITS shape -- one training iteration of train.py:151-218 (non-ref) on a 200 x 200 image, 256 rays, 32 + 64
+    samples, run by the REAL reference: randomFromOneImage -> validSampler -> ProposalNetwork -> get_weights -> maxBlurFilter ->
+    inverseSample -> MipNeRF -> NeRF.render -> getBounds / ProposalLoss / MSE -> backward -> Adam step at the reference's learning-rate
+    rule (train.py:56: lr * sample_ray_num / 512; scheduler value of iteration 0, nerf_base.py:115-134).  Stored: the draws (ray indices,
+    stratified and inverse-CDF uniforms), the step's outputs, slices of the parameter gradients and of the parameters AFTER the step."""
+    from nerf import nerf_base, mip_model, addtional, utils, mip_methods
+    import torch.nn.functional as F
+    import weights as W
+    near, far, N, C_, F_ = 2.0, 6.0, 256, 32, 64
+    pose = utils.pose_spherical(52.0, -30.0, 4.0)[:3]
+    focal = utils.fov2Focal(0.6911112070083618, (200, 200))
+    img = torch.rand(3, 200, 200, generator=torch.Generator().manual_seed(24))
+    prop = addtional.ProposalNetwork(10, 256); prop.load_state_dict(W.proposal_state("small")); prop.train()
+    mip = mip_model.MipNeRF(10, 4, 256); mip.load_state_dict(W.mip_state("small")); mip.train()
+    lr = 5e-4 * N / 512
+    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=lr, betas=(0.9, 0.999))
+    sch = nerf_base.DecayLrScheduler(0.01, 0.1, 100000, lr, 500)
+    pix, coords = utils.randomFromOneImage(img, (1.0, 1.0))
+    torch.manual_seed(240)
+    pts_c, len_c, rgb_tgt, rays_c = utils.validSampler(pix, coords, pose, N, C_, focal, near, far, True)
+    torch.manual_seed(240)
+    idx = torch.randint(0, coords.shape[0], (N,)); u_strat = torch.rand(N, C_)
+    density = F.softplus(prop.forward(pts_c))
+    pw = mip_methods.maxBlurFilter(addtional.ProposalNetwork.get_weights(density, len_c, rays_c[:, 3:]), 0.01)
+    torch.manual_seed(241)
+    fl, below = utils.inverseSample(pw, len_c, F_ + 1, sort=True)
+    torch.manual_seed(241)
+    u_inv = torch.rand(N, F_ + 1)
+    fl = fl[..., :-1]
+    rgbo = mip.forward(nerf_base.NeRF.length2pts(rays_c, fl))
+    rend, wts, _ = nerf_base.NeRF.render(rgbo, fl, rays_c[:, 3:])
+    img_loss = torch.nn.MSELoss()(rend, rgb_tgt)
+    p_loss = addtional.ProposalLoss()(addtional.getBounds(pw, below), wts.detach())
+    opt.zero_grad()
+    (p_loss + img_loss).backward()
+    _, lr0 = sch.update_opt_lr(0, opt)
+    grads = {"g_mip_l1": mip.lin_block1[0].weight.grad[:8].clone(), "g_mip_skip": mip.lin_block2[0].weight.grad[:8].clone(),
+             "g_mip_rgb": mip.rgb_layer[2].weight.grad.clone(), "g_mip_sigma": mip.opacity_head[0].weight.grad.clone(),
+             "g_prop_l0": prop.layers[0].weight.grad[:8].clone(), "g_prop_head": prop.layers[8].weight.grad.clone()}
+    opt.step()
+    npz("g24_config0_train_step", pose=pose, focal=np.array(focal), img=img, idx=idx, u_strat=u_strat, u_inv=u_inv, rays=rays_c, rgb_tgt=rgb_tgt,
+        z_coarse=len_c, z_fine=fl, below=below, rendered=rend, weights=wts, img_loss=img_loss, prop_loss=p_loss, lr=np.float64(lr0),
+        p_mip_rgb_after=mip.rgb_layer[2].weight.detach(), p_mip_l1_after=mip.lin_block1[0].weight.detach()[:8],
+        p_prop_head_after=prop.layers[8].weight.detach(), p_prop_l0_after=prop.layers[0].weight.detach()[:8], **grads)
+
+
 def write_shallow_encodings():
     """G21: the reference's three networks built with FEWER encoding octaves and / or cat_origin=False (constructor arguments,
     mip_model.py:15-18, addtional.py:61, ref_model.py:17-24) -- forward values and (the first 8 rows of) parameter gradients of sum(out * G) from the REAL modules.
@@ -162,6 +209,8 @@ def main():
     if "--signatures-only" in sys.argv:
         write_entry_imports()
         return write_signatures()
+    if "--config0-only" in sys.argv:
+        return write_config0_train_step()
     if "--shallow-only" in sys.argv:
         return write_shallow_encodings()
     if "--generic-ref-only" in sys.argv:
@@ -499,7 +548,9 @@ def main():
 
     write_shallow_encodings()
     write_generic_refnerf()
+    write_entry_imports()
     write_signatures()
+    write_config0_train_step()
 
 
 if __name__ == "__main__":

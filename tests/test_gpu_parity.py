@@ -463,16 +463,18 @@ def test_render_through_the_nerf_shim_package(A, golden):
             del sys.modules[k]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_full_size_properties(A, prec):
-    """BASELINE config 2 size (800x800, 64+128; fp32 on a 200k-ray slab to bound run time): properties that
-    need no oracle at this scale + an oracle spot check on a random subset."""
-    prop, mip = build_nets(A, "he")
+@pytest.mark.parametrize("prec,tag", [("fp32", "small"), ("fp32", "he"), ("bf16", "he")])
+def test_full_size_properties(A, prec, tag):
+    """BASELINE config 2 size (800x800, 64+128, all 640 000 rays in both precisions): properties that need no oracle at this scale + an
+    oracle spot check on a random subset (fp32: 2 048 rays; reference-style `small` weights at the north star's 1e-4, the O(1)-activation
+    `he` stress weights at 2.5e-4 -- on those the fp32 REFERENCE itself sits ~1e-4 from the exact value of its own expressions,
+    test_he_weights_conditioning)."""
+    prop, mip = build_nets(A, tag)
     P = A.ops.F32 if prec == "fp32" else A.ops.BF16
     H = Wd = 800
     pose = O.pose_spherical(20.0, -30.0, 4.0)[:3]
     f = O.fov2focal(0.6911112070083618, (H, Wd))
-    n = H * Wd if prec == "bf16" else 200_000
+    n = H * Wd                                               # the whole image in both precisions (round 6: fp32 used to stop at a 200 000-ray slab)
     rays = A.ops.generate_rays(pose, H, Wd, f[1], f[0], "cuda", 0, n)
     gen = torch.Generator(device="cuda").manual_seed(9)
     u1 = torch.rand(n, 64, device="cuda", generator=gen)
@@ -492,13 +494,15 @@ def test_full_size_properties(A, prec):
                                       u2[lo:lo + cnt].contiguous(), 128, NEAR, FAR, True, want_depth=True, want_weights=True)
     assert torch.equal(r2, rgb_w[lo:lo + cnt]) and torch.equal(d2, depth[lo:lo + cnt]) and torch.equal(w2, w[lo:lo + cnt])
     # oracle spot check on a random subset
-    pick = torch.randperm(n, generator=torch.Generator().manual_seed(2))[:192]
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(2))[:2048 if prec == "fp32" else 192]
     with torch.no_grad():
-        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state("he"), W.mip_state("he"), rays[pick].cpu(), u1[pick].cpu(),
+        want_rgb, want_w, want_depth = O.render_rays(W.proposal_state(tag), W.mip_state(tag), rays[pick].cpu(), u1[pick].cpu(),
                                                      u2[pick].cpu(), NEAR, FAR, 128, white_bkg=True, emulate_bf16=False)
     if prec == "fp32":
-        assert max_abs(rgb_w[pick].cpu(), want_rgb) <= 1e-4 and max_abs(depth[pick].cpu(), want_depth) <= 1e-4
-        assert max_abs(w[pick].cpu(), want_w) <= 1e-4
+        tol = 1e-4 if tag == "small" else 2.5e-4
+        gate("full-size fp32 [%s] rgb vs oracle, 2048 rays of 640000" % tag, max_abs(rgb_w[pick].cpu(), want_rgb), tol)
+        gate("full-size fp32 [%s] depth vs oracle, 2048 rays of 640000" % tag, max_abs(depth[pick].cpu(), want_depth), tol)
+        gate("full-size fp32 [%s] weights vs oracle, 2048 rays of 640000" % tag, max_abs(w[pick].cpu(), want_w), tol)
     else:
         mse16 = torch.mean((rgb_w[pick].cpu() - want_rgb) ** 2).item()
         print("\nfull-size bf16 spot check ('he' weights): MSE %.2e = %.1f dB" % (mse16, -10 * math.log10(max(mse16, 1e-12))))
@@ -506,6 +510,77 @@ def test_full_size_properties(A, prec):
 
 
 BF16_HE_SPOT_MSE = 1.5e-4                                 # measured on MI355X (round 3): 4.3e-5 (43.6 dB) on the O(1)-activation 'he' weights
+
+
+# per-stage limits of the full-size bf16 check below: (density, rgb channels of rgbo, sigma channel of rgbo -- each relative to the stage's
+# largest |value| -- , final rgb abs, depth abs).  Set from the values the first run on MI355X recorded (profiles/r06_measured_gates.log).
+# first run (round 6, one MI355X): small 8.1e-4 / 1.7e-5 / 2.1e-3 / 1.1e-5 / 6.2e-6; he 3.1e-3 / 8.9e-3 / 9.4e-3 (end to end, `he` is judged by MSE only:
+# on O(1)-activation weights one inverse-CDF bucket that tips the other way changes a ray's colour by O(1) -- measured max 0.81 on 1 of 2 048 rays)
+BF16_STAGE_LIMITS = {"small": (2.5e-3, 1e-4, 6e-3, 1e-4, 1e-4), "he": (1e-2, 3e-2, 3e-2, None, None)}
+
+
+@pytest.mark.parametrize("tag", ["small", "he"])
+def test_full_size_bf16_render_stage_by_stage_against_the_bf16_oracle(A, tag):
+    """VERDICT r5 item 8 -- the headline dtype at the headline size.  ONE 800 x 800, 64 + 128 bf16 render through nerf_amd_render_rays;
+    on 2 048 random rays of it every stage is compared with the oracle fed the HIP path's OWN previous stage (teacher-forced, so that one
+    flipped inverse-CDF bucket does not drown the comparison):
+      density  = proposal MLP on the stratified points    vs the oracle's proposal_forward in bf16-operand emulation
+      z_fine   = weights -> blur -> inverse-CDF sampling  vs the oracle's fp32 rows 5-7 on the HIP density (fp32 stage: tight)
+      rgbo     = fine MLP at the HIP z_fine               vs the oracle's mip_forward in bf16-operand emulation
+      rgb / depth / weights = compositing of the HIP rgbo vs the oracle's composite (fp32 stage: tight)
+    and the end-to-end image against the oracle's bf16-emulated render of the same rays.  Every figure goes through conftest.gate (value
+    on record next to the limit)."""
+    prop, mip = build_nets(A, tag)
+    P = A.ops.BF16
+    H = Wd = 800
+    pose = O.pose_spherical(20.0, -30.0, 4.0)[:3]
+    f = O.fov2focal(0.6911112070083618, (H, Wd))
+    n = H * Wd
+    rays = A.ops.generate_rays(pose, H, Wd, f[1], f[0], "cuda", 0, n)
+    gen = torch.Generator(device="cuda").manual_seed(19)
+    u1 = torch.rand(n, 64, device="cuda", generator=gen)
+    u2 = torch.rand(n, 129, device="cuda", generator=gen)
+    z_base = torch.linspace(NEAR, FAR, 64).cuda()
+    rgb, depth, w, ws = A.ops.render_rays(prop.packed(P), mip.packed(P), P, rays, z_base, u1, u2, 128, NEAR, FAR, True, want_depth=True, want_weights=True)
+    torch.cuda.synchronize()
+    # the intermediates of that launch sequence, in the entry point's workspace: density (N,64) | z_fine (N,129) | rgbo (N,128,4), 256-byte aligned
+    base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr()
+    al = lambda b: (b + 255) // 256 * 256
+    o_d, o_z = base, base + al(n * 64 * 4)
+    o_r = o_z + al(n * 129 * 4)
+    dens = ws[o_d: o_d + n * 64 * 4].view(torch.float32).view(n, 64)
+    z_fine = ws[o_z: o_z + n * 129 * 4].view(torch.float32).view(n, 129)
+    rgbo = ws[o_r: o_r + n * 128 * 16].view(torch.float32).view(n, 128, 4)
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(5))[:2048]
+    r, a1, a2 = rays[pick].cpu(), u1[pick].cpu(), u2[pick].cpu()
+    d_hip, z_hip, c_hip = dens[pick].cpu(), z_fine[pick].cpu(), rgbo[pick].cpu()
+    psd, msd = W.proposal_state(tag), W.mip_state(tag)
+    lim = BF16_STAGE_LIMITS[tag]
+    with torch.no_grad():
+        z_c = O.stratified_render(NEAR, FAR, 128, a1)
+        pts_c = r[:, None, :3] + z_c[..., None] * r[:, None, 3:]
+        d_want = O.proposal_forward(psd, pts_c, emulate_bf16=True)
+        gate("full-size bf16 [%s] density vs bf16-emulated oracle, rel. to max |density|" % tag, max_abs(d_hip, d_want) / d_want.abs().max().item(), lim[0])
+        z_want, _ = O.inverse_sample(O.max_blur(O.sigma_to_weights(d_hip, z_c, r[:, 3:]), 0.01), z_c, a2, sort=True)
+        gate("full-size bf16 [%s] z_fine from the HIP density vs oracle rows 5-7 (fp32)" % tag, max_abs(z_hip, z_want), 2e-5)
+        c_want = O.mip_forward(msd, O.length2pts(r, z_hip[:, :-1]), emulate_bf16=True)
+        gate("full-size bf16 [%s] rgb of rgbo vs bf16-emulated oracle" % tag, max_abs(c_hip[..., :3], c_want[..., :3]), lim[1])
+        gate("full-size bf16 [%s] sigma of rgbo vs bf16-emulated oracle, rel. to max |sigma|" % tag,
+             max_abs(c_hip[..., 3], c_want[..., 3]) / c_want[..., 3].abs().max().item(), lim[2])
+        rgb_c, w_c, ex = O.composite(c_hip, z_hip[:, :-1], r[:, 3:], white_bkg=True, render_depth=(NEAR, FAR))
+        gate("full-size bf16 [%s] rgb from the HIP rgbo vs oracle composite (fp32)" % tag, max_abs(rgb[pick].cpu(), rgb_c), 2e-5)
+        gate("full-size bf16 [%s] weights from the HIP rgbo vs oracle composite (fp32)" % tag, max_abs(w[pick].cpu(), w_c), 2e-5)
+        gate("full-size bf16 [%s] depth from the HIP rgbo vs oracle composite (fp32)" % tag, max_abs(depth[pick].cpu(), ex["depth_img"]), 1e-4)
+        e_rgb, e_w, e_depth = O.render_rays(psd, msd, r, a1, a2, NEAR, FAR, 128, white_bkg=True, emulate_bf16=True)
+        if lim[3] is not None:
+            gate("full-size bf16 [%s] end-to-end rgb vs the oracle's bf16-emulated render" % tag, max_abs(rgb[pick].cpu(), e_rgb), lim[3])
+            gate("full-size bf16 [%s] end-to-end depth vs the oracle's bf16-emulated render" % tag, max_abs(depth[pick].cpu(), e_depth), lim[4])
+        mse = torch.mean((rgb[pick].cpu() - e_rgb) ** 2).item()
+        # (`he`: 6.8e-4 measured, almost all of it from ~1 ray in 2 048 whose inverse-CDF draw fell into the neighbouring bucket -- an O(1) colour
+        #  change on these weights; the teacher-forced stages above are the statement, this figure is on record only)
+        gate("full-size bf16 [%s] end-to-end image MSE vs the oracle's bf16-emulated render (dB = -10 log10)" % tag, mse, 1e-6 if tag == "small" else 3e-3)
+        off = ((rgb[pick].cpu() - e_rgb).abs().amax(dim=-1) > 0.05).float().mean().item()
+        gate("full-size bf16 [%s] fraction of rays further than 0.05 from the oracle's bf16-emulated render" % tag, off, 1e-4 if tag == "small" else 1e-2)
 
 
 # ------------------------------------------------------------------------------------------------ row 13: Ref-NeRF
@@ -1851,6 +1926,56 @@ def test_render_weights_carry_gradient(A):
         loss.backward()
         scale = ref.grad.abs().max().item()
         assert max_abs(x.grad.cpu(), ref.grad) <= 2e-5 * max(1.0, scale), (use_rgb, use_w)
+
+
+def test_config0_training_iteration_vs_reference_golden(A, golden):
+    """BASELINE configs[0] at ITS shape on the HIP path: one whole iteration of train.py:151-218 -- randomFromOneImage on a 200 x 200 image,
+    validSampler with the reference's CPU stream (256 rays, 32 coarse depths), both networks, inverseSample (65 draws), compositing, the
+    two losses, backward through the hand-written kernels, DecayLrScheduler + the one-launch Adam -- against the REAL reference's run of
+    the same iteration (golden G24; weak #3 of round 5's review: the 32-ray G14 was the only train-step golden)."""
+    from nerf_amd.nerf_base import DecayLrScheduler
+    from nerf_amd.optim import Adam
+    g = golden("g24_config0_train_step")
+    N = 256
+    prop, mip = build_nets(A, "small")
+    prop.train(); mip.train()
+    A.pkg.set_precision("fp32")
+    lr = 5e-4 * N / 512                                                                  # train.py:56
+    opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=lr, betas=(0.9, 0.999))
+    sch = DecayLrScheduler(0.01, 0.1, 100000, lr, 500)
+    pix, coords = A.utils.randomFromOneImage(dev(g["img"]), (1.0, 1.0))
+    torch.manual_seed(240)
+    pts, z_c, tgt, rays = A.utils.validSampler(pix, coords, dev(g["pose"]), N, 32, tuple(g["focal"].tolist()), NEAR, FAR, True, rng="reference")
+    assert torch.equal(z_c.cpu(), g["z_coarse"]) and torch.equal(tgt.cpu(), g["rgb_tgt"]) and max_abs(rays.cpu(), g["rays"]) <= 1e-6
+    density = F.softplus(prop.forward(pts))
+    pw = A.mip_methods.maxBlurFilter(A.addtional.ProposalNetwork.get_weights(density, z_c, rays[:, 3:]), 0.01)
+    torch.manual_seed(241)
+    fl, below = A.utils.inverseSample(pw, z_c, 65, sort=True)                             # the reference's own draw (utils.py:115) from the CPU generator
+    fl = fl[..., :-1].contiguous()
+    assert max_abs(fl.cpu(), g["z_fine"]) <= 2e-5 and (below.cpu() != g["below"]).float().mean().item() <= 0.01
+    rgbo = mip.forward(A.nerf_base.NeRF.length2pts(rays, fl))
+    rend, wts, _ = A.nerf_base.NeRF.render(rgbo, fl, rays[:, 3:])
+    img_loss = torch.nn.MSELoss()(rend, tgt)
+    p_loss = A.addtional.ProposalLoss()(A.addtional.getBounds(pw, below), wts.detach())
+    opt.zero_grad()
+    (p_loss + img_loss).backward()
+    gate("config0 train step: rendered vs reference", max_abs(rend.detach().cpu(), g["rendered"]), 1e-5)
+    gate("config0 train step: weights vs reference", max_abs(wts.detach().cpu(), g["weights"]), 1e-5)
+    assert abs(img_loss.item() - g["img_loss"]) <= 1e-6 and abs(p_loss.item() - g["prop_loss"]) <= 1e-4 * max(1.0, g["prop_loss"])
+    rel = lambda got, want: max_abs(got.cpu(), want) / max(want.abs().max().item(), 1e-30)
+    gate("config0 train step: d rgb_layer.2", rel(mip.rgb_layer[2].weight.grad, g["g_mip_rgb"]), 1e-4)
+    gate("config0 train step: d proposal head", rel(prop.layers[8].weight.grad, g["g_prop_head"]), 1e-4)
+    gate("config0 train step: d opacity head", rel(mip.opacity_head[0].weight.grad, g["g_mip_sigma"]), 5e-3)
+    gate("config0 train step: d skip layer rows 0-7", rel(mip.lin_block2[0].weight.grad[:8], g["g_mip_skip"]), 5e-2)
+    gate("config0 train step: d first layer rows 0-7", rel(mip.lin_block1[0].weight.grad[:8], g["g_mip_l1"]), 5e-2)
+    gate("config0 train step: d proposal first layer rows 0-7", rel(prop.layers[0].weight.grad[:8], g["g_prop_l0"]), 5e-2)
+    _, lr0 = sch.update_opt_lr(0, opt)
+    assert lr0 == g["lr"]
+    opt.step()
+    assert max_abs(mip.rgb_layer[2].weight.detach().cpu(), g["p_mip_rgb_after"]) <= 1e-8                 # |step| = lr0 sign(g): the same parameters
+    assert max_abs(prop.layers[8].weight.detach().cpu(), g["p_prop_head_after"]) <= 1e-8
+    assert max_abs(mip.lin_block1[0].weight.detach().cpu()[:8], g["p_mip_l1_after"]) <= 2.5 * lr0        # (a sign flip of a cancelling entry = 2 lr0)
+    assert max_abs(prop.layers[0].weight.detach().cpu()[:8], g["p_prop_l0_after"]) <= 2.5 * lr0
 
 
 # ------------------------------------------------------------------------------------------------ optimizer

@@ -115,6 +115,27 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
 
 
 @pytest.mark.timeout(600)
+def test_bench_launch_check_with_eight_ranks():
+    """the driver's largest launch -- `--gpus 8` -- through everything bench.py does around the GPU work (rendezvous on
+    127.0.0.1, preflight collectives across EIGHT ranks checked element-exact, barriers, max over ranks, per-rank gathers, rank 0's solo leg
+    while seven ranks wait at the host-side barrier, ONE JSON line) on gloo ranks: ddp_train.py:307-323 spawns its `gpus` processes the same way."""
+    import json
+    r = _bench("--gpus", "8", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                            # rank 0's line and nothing else
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["max_over_ranks"] == 8.0
+    sp = rec["ms_per_step_ranks"]
+    assert len(sp["all"]) == 8 and sp["max"] == max(sp["all"]) and abs(rec["ms_per_step"] - sp["max"]) < 1e-6
+    assert sp["all"][7] > sp["all"][0] >= 9.0                                         # rank r "works" (r + 1) x 10 ms
+    assert [q["rank"] for q in rec["per_rank"]] == list(range(8))
+    pre = rec["preflight"]
+    assert [q["rank"] for q in pre["ranks"]] == list(range(8)) and r.stderr.count("bench.py preflight: rank") == 8
+    assert pre["allgather_bytes"] >= 10_000_000
+
+
+@pytest.mark.timeout(600)
 def test_bench_preflight_and_loud_failure_of_a_stuck_run():
     """the first N > 1 run must fail LOUDLY instead of hanging.  On two gloo ranks (the control flow `bench.py --gpus N`
     runs before any GPU work): (a) the preflight's record -- every rank's device line, a 3 MB all_reduce and a 10 MB all_gather checked

@@ -200,6 +200,53 @@ def test_g14_train_step_forward_and_losses(golden):
     assert abs(O.loss_psnr(img_loss).item() - g["psnr"]) <= 1e-4
 
 
+def test_g24_config0_train_step_with_adam(golden):
+    """BASELINE configs[0] at its own shape (200 x 200 image, 256 rays, 32 + 64 samples): ONE iteration of train.py:151-218 run by the real
+    reference (golden G24) -- the oracle restates it end to end: pixel rays, stratified depths, both networks, sampling, compositing, losses,
+    torch autograd gradients and the Adam step at the scheduler's iteration-0 learning rate (the CPU plumbing leg of the config)."""
+    g = golden("g24_config0_train_step")
+    N = 256
+    pose, focal = g["pose"], tuple(g["focal"].tolist())
+    img = g["img"]
+    pix, coords = O.pixel_table(img, (1.0, 1.0))                      # utils.py:47-69
+    d = O.ray_dirs_pixels(coords[g["idx"]], pose, focal)
+    rays = torch.cat((pose[:, -1].expand(N, -1), d), -1)
+    assert torch.equal(rays, g["rays"]) and torch.equal(pix[g["idx"]], g["rgb_tgt"])
+    z_c = O.stratified_train(NEAR, FAR, 32, g["u_strat"])
+    assert torch.equal(z_c, g["z_coarse"])
+    prop = {k: v.clone().requires_grad_(True) for k, v in W.proposal_state("small").items()}
+    mip = {k: v.clone().requires_grad_(True) for k, v in W.mip_state("small").items()}
+    lr = 5e-4 * N / 512
+    opt = torch.optim.Adam(list(mip.values()) + list(prop.values()), lr=lr, betas=(0.9, 0.999))
+    dens = F.softplus(O.proposal_forward(prop, pose[:, -1] + d[:, None, :] * z_c[:, :, None]))
+    pw = O.max_blur(O.sigma_to_weights(dens, z_c, d), 0.01)
+    z_f, below = O.inverse_sample(pw, z_c, g["u_inv"], sort=True)
+    z_f = z_f[..., :-1]
+    rend, wts, _ = O.composite(O.mip_forward(mip, O.length2pts(rays, z_f)), z_f, d)
+    img_loss = torch.mean((rend - g["rgb_tgt"]) ** 2)
+    p_loss = O.proposal_loss(O.get_bounds(pw, below), wts.detach())
+    (p_loss + img_loss).backward()
+    assert max_abs(z_f.detach(), g["z_fine"]) <= 2e-6 and (below != g["below"]).float().mean().item() <= 0.01
+    assert max_abs(rend.detach(), g["rendered"]) <= 2e-6 and max_abs(wts.detach(), g["weights"]) <= 2e-6
+    assert abs(img_loss.item() - g["img_loss"]) <= 1e-6 and abs(p_loss.item() - g["prop_loss"]) <= 1e-5 * max(1, g["prop_loss"])
+    rel = lambda got, want: max_abs(got, want) / max(want.abs().max().item(), 1e-30)
+    assert rel(mip["rgb_layer.2.weight"].grad, g["g_mip_rgb"]) <= 1e-4 and rel(prop["layers.8.weight"].grad, g["g_prop_head"]) <= 1e-4
+    assert rel(mip["opacity_head.0.weight"].grad, g["g_mip_sigma"]) <= 5e-3
+    assert rel(mip["lin_block2.0.weight"].grad[:8], g["g_mip_skip"]) <= 5e-2 and rel(mip["lin_block1.0.weight"].grad[:8], g["g_mip_l1"]) <= 5e-2
+    lr0 = lr * (0.01 * (1.0 - 0.0) + 0.0)                            # DecayLrScheduler(0.01, 0.1, 100000, lr, 500) at train_cnt 0 (nerf_base.py:115-134)
+    assert lr0 == g["lr"]
+    for gr in opt.param_groups:
+        gr["lr"] = lr0
+    opt.step()
+    # the first Adam step moves every parameter by lr0 * sign(grad) (up to eps): compare the parameters after the step
+    for key, name in (("p_mip_rgb_after", "rgb_layer.2.weight"), ("p_mip_l1_after", "lin_block1.0.weight")):
+        got = mip[name].detach()
+        got = got[:8] if key.endswith("l1_after") else got
+        assert max_abs(got, g[key]) <= 2.5 * lr0, key                # a sign flip of a cancelling gradient entry moves a parameter by 2 lr0
+        assert (got - g[key]).abs().gt(1e-9).float().mean().item() <= (0.0 if "rgb" in key else 0.3), key
+    assert max_abs(prop["layers.8.weight"].detach(), g["p_prop_head_after"]) <= 1e-9
+
+
 def test_g15_lr_schedule(golden):
     g = golden("g15_lr")
     min_r, decay_r, step, lr, warm = 0.01, 0.1, 100000, 3e-4, 500             # nerf_base.py:115-134
