@@ -435,7 +435,10 @@ int nerf_amd_get_bounds_backward(const int64_t* below, const float* d_bounds, in
  * workspace: nerf_amd_render_workspace_bytes(N, n_fine) bytes of device scratch.
  * ------------------------------------------------------------------------------------------------ */
 /* (With camera != NULL and camera->ipe != 0 -- the descriptor may accompany explicit rays just to carry flags -- the FINE pass uses
- * the integrated positional encoding of the frusta between consecutive fine depths, radius camera->ipe_radius; `rays` must be given.) */
+ * the integrated positional encoding of the frusta between consecutive fine depths, radius camera->ipe_radius; `rays` must be given.
+ * The direction norm of mip_methods.py:31 is taken over the N rays of this call, or -- camera->ipe_dir_norm != NULL -- read from that
+ * device scalar: a caller rendering a SHARD of a ray list passes the norm of the whole list (nerf_amd_dirs_norm), so that the shards of an
+ * image encode exactly like the single call over all of its rays.) */
 size_t nerf_amd_render_workspace_bytes(int64_t N, int n_fine);
 int    nerf_amd_render_rays(const void* packed_prop, const void* packed_mip, int precision,
                             const float* rays, const nerf_amd_samples* camera, int64_t ray_offset,

@@ -60,6 +60,7 @@ def main():
             st = torch.load(f0, weights_only=False)
             for mode in a.modes.split(","):
                 t0 = time.time()
+                extra = ""
                 if mode == "cpu":                                   # the oracle's own continuation: its kept histories
                     if not os.path.exists(f1):
                         continue
@@ -70,11 +71,12 @@ def main():
                     held = held[0]
                 else:
                     hist, held = T.run_hip(views, seed, mode, init=st, stop=k + WINDOW)
+                    extra = "  held-out-fp32render %.5f" % held[1] if len(held) > 1 else ""
                     held = held[0]
                 assert len(hist) == WINDOW, len(hist)
                 mse = sum(hist) / len(hist)
                 print("WINDOW mode %s seed %d start %d lr %.4e train-psnr %.5f held-out %.5f first-loss %.9e last50-psnr %.5f threads %d  %.0f s"
-                      % (mode, seed, k, T.SCHED(k), T.psnr(mse), held, hist[0], T.psnr(sum(hist[-50:]) / 50), torch.get_num_threads(), time.time() - t0), flush=True)
+                      % (mode, seed, k, T.SCHED(k), T.psnr(mse), held, hist[0], T.psnr(sum(hist[-50:]) / 50), torch.get_num_threads(), time.time() - t0) + extra, flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Summary of the teacher-forced PSNR windows (scripts/psnr_windows.py): paired differences against the oracle's own continuation, per phase of
+the learning-rate schedule (warm-up: the window starting at 0; hold: starts 250 ... 5 750; decay: starts >= 6 000), mean +- s.e.m. over the
+(seed, window) pairs, for the HIP fp32 path, the HIP bf16 path and the NULL control (the oracle itself with another thread count).
+    psnr_windows_summary.py LOG [LOG ...] > profiles/r06_psnr/summary.md"""
+import math
+import re
+import sys
+
+rec = {}
+pat = re.compile(r"WINDOW mode (\S+) seed (\d+) start (\d+) lr (\S+) train-psnr (\S+) held-out (\S+) first-loss (\S+) last50-psnr (\S+) threads (\d+)")
+for f in sys.argv[1:]:
+    for line in open(f):
+        m = pat.search(line)
+        if m:
+            mode, seed, start = m.group(1), int(m.group(2)), int(m.group(3))
+            rec[(mode, seed, start)] = {"lr": float(m.group(4)), "train": float(m.group(5)), "held": float(m.group(6)), "first": float(m.group(7)),
+                                        "last50": float(m.group(8)), "threads": int(m.group(9))}
+            m2 = re.search(r"held-out-fp32render (\S+)", line)
+            if m2:                                                  # bf16-TRAINED weights rendered by the fp32 kernels: its own pseudo-mode
+                rec[(mode + "-train/fp32-render", seed, start)] = dict(rec[(mode, seed, start)], held=float(m2.group(1)))
+
+
+def phase(start):
+    return "warm-up (0-250)" if start == 0 else ("hold (lr 4.5e-4)" if start < 6000 else "decay (100x over 4 000 it)")
+
+
+def stats(xs):
+    n = len(xs)
+    if n == 0:
+        return float("nan"), float("nan"), float("nan"), 0
+    m = sum(xs) / n
+    sd = math.sqrt(sum((x - m) ** 2 for x in xs) / max(n - 1, 1))
+    return m, sd / math.sqrt(n), sd, n
+
+
+modes = [m for m in ("fp32", "bf16", "bf16-train/fp32-render", "null") if any(k[0] == m for k in rec)]
+keys = sorted({(k[1], k[2]) for k in rec if k[0] == "cpu"})
+seeds = sorted({k[0] for k in keys})
+print("# PSNR at equal iterations, teacher-forced 250-iteration windows (round 6)\n")
+print("Every window starts from the CPU oracle's OWN state at a checkpoint of its 10 000-iteration run (parameters, both Adam moments, step counts, the")
+print("position of the CPU generator that draws batches and uniforms) and runs the next 250 iterations on the identical draws through: the oracle")
+print("itself (`cpu`: its kept trajectory, 1 thread), the oracle restarted with another thread count (`null`: the control -- same program, another")
+print("summation order), the HIP fp32 path and the HIP bf16 path.  Figures: training PSNR of those 250 iterations (mean image loss -> dB) and the held-out")
+print("render at the window's end, as PAIRED differences against `cpu`.  Recipe: `scripts/psnr_seeds.py --size 40 --views 25 --held 1 --rays 512 --coarse 32")
+print("--fine 64 --iters 10000 --lr-mult 3 --hold 0.6` (profiles/r05_psnr), seeds %s, %d windows.\n" % (seeds, len(keys)))
+print("## Per phase: paired difference to the oracle's own continuation, dB (mean +- s.e.m.; sd; n windows)\n")
+print("| phase | path | training PSNR of the window | held-out PSNR at the window's end | max |difference| train / held-out |")
+print("|---|---|---|---|---|")
+for ph in ("warm-up (0-250)", "hold (lr 4.5e-4)", "decay (100x over 4 000 it)", "all"):
+    for mode in modes:
+        dt, dh = [], []
+        for seed, start in keys:
+            if (ph == "all" or phase(start) == ph) and (mode, seed, start) in rec:
+                c, r = rec[("cpu", seed, start)], rec[(mode, seed, start)]
+                dt.append(r["train"] - c["train"])
+                dh.append(r["held"] - c["held"])
+        if not dt:
+            continue
+        mt, st, sdt, n = stats(dt)
+        mh, sh, sdh, _ = stats(dh)
+        print("| %s | %s | %+.4f +- %.4f (sd %.4f; n = %d) | %+.4f +- %.4f (sd %.4f) | %.3f / %.3f |"
+              % (ph, mode, mt, st, sdt, n, mh, sh, sdh, max(abs(x) for x in dt), max(abs(x) for x in dh)))
+print("\n## Every window\n")
+print("| seed | start | lr at start | oracle train dB | oracle held-out dB | " + " | ".join("%s - oracle, train / held-out" % m for m in modes) + " |")
+print("|---|---|---|---|---|" + "---|" * len(modes))
+for seed, start in keys:
+    c = rec[("cpu", seed, start)]
+    cells = []
+    for mode in modes:
+        r = rec.get((mode, seed, start))
+        cells.append("%+.4f / %+.4f" % (r["train"] - c["train"], r["held"] - c["held"]) if r else "-")
+    print("| %d | %d | %.3e | %.3f | %.3f | %s |" % (seed, start, c["lr"], c["train"], c["held"], " | ".join(cells)))
+# first-iteration agreement: the window's first loss is computed from the IDENTICAL state on the identical batch
+print("\n## First iteration of every window (identical state, identical batch): relative difference of the image loss\n")
+for mode in modes:
+    xs = [abs(rec[(mode, s, k)]["first"] - rec[("cpu", s, k)]["first"]) / rec[("cpu", s, k)]["first"] for s, k in keys if (mode, s, k) in rec]
+    if xs:
+        print("* %s: max %.2e, mean %.2e over %d windows" % (mode, max(xs), sum(xs) / len(xs), len(xs)))

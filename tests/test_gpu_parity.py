@@ -1962,13 +1962,28 @@ def test_config0_training_iteration_vs_reference_golden(A, golden):
     gate("config0 train step: rendered vs reference", max_abs(rend.detach().cpu(), g["rendered"]), 1e-5)
     gate("config0 train step: weights vs reference", max_abs(wts.detach().cpu(), g["weights"]), 1e-5)
     assert abs(img_loss.item() - g["img_loss"]) <= 1e-6 and abs(p_loss.item() - g["prop_loss"]) <= 1e-4 * max(1.0, g["prop_loss"])
+    # Gradients.  The yardstick is the EXACT value of the same step (fp64 oracle + torch.autograd on the CPU, same fine depths and bins): tensors
+    # whose entries are sums of thousands of cancelling terms carry fp32 summation-order noise in EVERY fp32 evaluation -- the reference's own
+    # opacity-head gradient (max entry 2.3e-9) sits 8.6 % from the exact value at this batch -- so the HIP gradient must be within 1e-4 of the
+    # reference's where that is conditioned (rgb / proposal heads) and no further from the exact value than 2x the reference is elsewhere.
+    d64 = lambda sd: {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    p64, m64 = d64(W.proposal_state("small")), d64(W.mip_state("small"))
+    r64, z64, fl64 = g["rays"].double(), g["z_coarse"].double(), fl.detach().cpu().double()
+    dens64 = F.softplus(O.proposal_forward(p64, r64[:, None, :3] + r64[:, None, 3:] * z64[:, :, None]))
+    pw64 = O.max_blur(O.sigma_to_weights(dens64, z64, r64[:, 3:]), 0.01)
+    rend64, wts64, _ = O.composite(O.mip_forward(m64, O.length2pts(r64, fl64)), fl64, r64[:, 3:])
+    (torch.mean((rend64 - g["rgb_tgt"].double()) ** 2) + O.proposal_loss(O.get_bounds(pw64, below.cpu()), wts64.detach())).backward()
     rel = lambda got, want: max_abs(got.cpu(), want) / max(want.abs().max().item(), 1e-30)
-    gate("config0 train step: d rgb_layer.2", rel(mip.rgb_layer[2].weight.grad, g["g_mip_rgb"]), 1e-4)
-    gate("config0 train step: d proposal head", rel(prop.layers[8].weight.grad, g["g_prop_head"]), 1e-4)
-    gate("config0 train step: d opacity head", rel(mip.opacity_head[0].weight.grad, g["g_mip_sigma"]), 5e-3)
-    gate("config0 train step: d skip layer rows 0-7", rel(mip.lin_block2[0].weight.grad[:8], g["g_mip_skip"]), 5e-2)
-    gate("config0 train step: d first layer rows 0-7", rel(mip.lin_block1[0].weight.grad[:8], g["g_mip_l1"]), 5e-2)
-    gate("config0 train step: d proposal first layer rows 0-7", rel(prop.layers[0].weight.grad[:8], g["g_prop_l0"]), 5e-2)
+    gate("config0 train step: d rgb_layer.2 vs reference", rel(mip.rgb_layer[2].weight.grad, g["g_mip_rgb"]), 1e-4)
+    gate("config0 train step: d proposal head vs reference", rel(prop.layers[8].weight.grad, g["g_prop_head"]), 1e-4)
+    for name, have, gold, exact in (("opacity head", mip.opacity_head[0].weight.grad, g["g_mip_sigma"], m64["opacity_head.0.weight"].grad),
+                                    ("skip layer rows 0-7", mip.lin_block2[0].weight.grad[:8], g["g_mip_skip"], m64["lin_block2.0.weight"].grad[:8]),
+                                    ("first layer rows 0-7", mip.lin_block1[0].weight.grad[:8], g["g_mip_l1"], m64["lin_block1.0.weight"].grad[:8]),
+                                    ("proposal first layer rows 0-7", prop.layers[0].weight.grad[:8], g["g_prop_l0"], p64["layers.0.weight"].grad[:8])):
+        top = exact.abs().max().item()
+        ref_exact = (gold.double() - exact).abs().max().item() / top
+        hip_exact = (have.detach().cpu().double() - exact).abs().max().item() / top
+        gate("config0 train step: d %s, HIP vs fp64 (the reference's fp32 is %.1e from it)" % (name, ref_exact), hip_exact, max(2.0 * ref_exact, 2e-5))
     _, lr0 = sch.update_opt_lr(0, opt)
     assert lr0 == g["lr"]
     opt.step()

@@ -242,6 +242,9 @@ def run_hip(views, seed, precision, init=None, stop=None):
             held.append(held_out_hip(prop, mip, gviews, len(views)))     # (train mode: packed() re-packs the current weights on every call)
     if stop is not None:
         held = [held_out_hip(prop, mip, gviews, len(views))]
+        if precision != "fp32":                                          # the SAME weights rendered by the fp32 kernels: separates what bf16
+            nerf_amd.set_precision("fp32")                               # TRAINING did to the weights from what a bf16 RENDER adds on top
+            held.append(held_out_hip(prop, mip, gviews, len(views)))
     nerf_amd.set_precision("fp32")
     return hist, held
 
