@@ -130,8 +130,16 @@ def partial_record(msg: str) -> None:
     """One parsable line on stdout saying that no measurement exists and why (`value: null`).  EVERY rank may print one (tagged with its
     rank): the launcher tears the whole job down as soon as ONE rank exits, so a record that only rank 0 could write is lost whenever
     another rank's watchdog wins the race (tests/test_multiprocess.py failed exactly there in the full-suite order)."""
-    print(json.dumps({"metric": METRIC_NAME, "value": None, "unit": "rays/s", "n_gpus": Watchdog.world, "rank": Watchdog.rank,
-                      "error": msg, "phase": Watchdog.phase}), flush=True)
+    line = json.dumps({"metric": METRIC_NAME, "value": None, "unit": "rays/s", "n_gpus": Watchdog.world, "rank": Watchdog.rank,
+                       "error": msg[:1500], "phase": Watchdog.phase}) + "\n"
+    # ONE write of the whole line (< PIPE_BUF: atomic on a pipe): several ranks write their records into the launcher's stdout at the same
+    # moment, and print()'s separate writes of text and newline interleaved two records on one line (seen under load in the CPU suite)
+    try:
+        sys.stdout.flush()
+        os.write(sys.stdout.fileno(), line.encode())
+    except (OSError, ValueError, AttributeError):
+        sys.stdout.write(line)
+        sys.stdout.flush()
 
 
 class Watchdog:
