@@ -173,6 +173,12 @@ int nerf_amd_positional_encoding(const float* x, int64_t M, int L, float* out, v
  * (SURVEY.md 8a row 12); golden G12 pins the function. */
 int nerf_amd_ipe_feature(const float* z, const float* rays, int64_t N, int S, int L, float r, const float* dir_norm,
                          float* feat, float* mu, float* mu_t, void* stream);
+/* (ABI 125) the same with the Mip-NeRF 360 scene contraction of the frustum MEAN before the lift (the diagonal covariance stays metric):
+ * what the fused kernels' sample fetch computes for `ipe` + `contract` together (BASELINE configs[2] + configs[4]); `mu` receives the
+ * CONTRACTED mean.  Not in the reference (mip_methods.py has no contraction): the build's own definition, oracle.ipe_feature(contracted=True).
+ * The layer-by-layer route of networks larger than the compiled shapes encodes with it. */
+int nerf_amd_ipe_feature_contracted(const float* z, const float* rays, int64_t N, int S, int L, float r, const float* dir_norm,
+                                    float* feat, float* mu, float* mu_t, void* stream);
 /* coneParameters (mip_methods.py:15-23): z (N, S+1) -> mu_t, sigma_t^2, sigma_r^2, each (N, S). */
 int nerf_amd_cone_parameters(const float* z, int64_t N, int S, float r, float* mu_t, float* var_t, float* var_r, void* stream);
 /* sqrt(sum of squares) of the direction halves of rays (N,6) -> out (1 float on the device); fp64 accumulation, fixed order. */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("NERF_AMD_LIB") or os.path.join(_HERE, "libnerf_amd.so
 
 F32, BF16 = 0, 1
 BF16_F8 = 2            # NERF_AMD_BF16_F8: bf16 arithmetic, training dumps of the hidden layers in scaled e4m3 (training entry points only)
-EXPECTED_VERSION = 124  # nerf_amd_version() of the library these signatures were written against
+EXPECTED_VERSION = 125  # nerf_amd_version() of the library these signatures were written against
 NET_PROPOSAL, NET_MIP, NET_REF, NET_PROPOSAL_128, NET_MIP_128 = 0, 1, 2, 3, 4
 FINE_W128 = 0x200     # layout flag: the fine-network blob is a NET_MIP_128 blob
 PROP_W128 = 0x100     # layout flag OR-ed into `precision`: packed_prop is a NET_PROPOSAL_128 blob
@@ -47,6 +47,7 @@ SIGNATURES = {
     "nerf_amd_ref_forward_train": (C.c_int, [c_void, C.c_int, C.POINTER(Samples), C.c_int, c_void, c_void, c_void, c_void]),
     "nerf_amd_positional_encoding": (C.c_int, [c_void, i64, C.c_int, c_void, c_void]),
     "nerf_amd_ipe_feature": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
+    "nerf_amd_ipe_feature_contracted": (C.c_int, [c_void, c_void, i64, C.c_int, C.c_int, C.c_float, c_void, c_void, c_void, c_void, c_void]),
     "nerf_amd_cone_parameters": (C.c_int, [c_void, i64, C.c_int, C.c_float, c_void, c_void, c_void, c_void]),
     "nerf_amd_dirs_norm": (C.c_int, [c_void, i64, c_void, c_void]),
     "nerf_amd_generate_rays": (C.c_int, [c_float_p, C.c_int, C.c_int, C.c_float, C.c_float, i64, i64, c_void, c_void]),

@@ -52,7 +52,7 @@ int pack_proposal128(int, const float* const*, const float* const*, void*, hipSt
 int pack_mip128(int, const float* const*, const float* const*, void*, hipStream_t);
 int pack_mip(int, const float* const*, const float* const*, void*, hipStream_t);
 int sk_positional_encoding(const float*, int64_t, int, float*, hipStream_t);
-int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, hipStream_t);
+int sk_ipe_feature(const float*, const float*, int64_t, int, int, float, const float*, float*, float*, float*, int, hipStream_t);
 int sk_dirs_norm(const float*, int64_t, float*, hipStream_t);
 int sk_dirs_norm_scratch(const float*, int64_t, float*, void*, hipStream_t);
 int sk_train_sampler(const float*, const int64_t*, int64_t, const float*, const float*, float, float, float, float, int64_t, int, uint64_t, const uint64_t*,
@@ -133,7 +133,7 @@ bool bad_prec(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 extern "C" {
 
 const char* nerf_amd_last_error(void) { return g_err; }
-int nerf_amd_version(void) { return 124; }
+int nerf_amd_version(void) { return 125; }
 
 int nerf_amd_device_info(int* n_cu, int* arch_is_gfx950) {
     int dev = 0;
@@ -247,7 +247,14 @@ int nerf_amd_ipe_feature(const float* z, const float* rays, int64_t N, int Sn, i
     if (N < 0 || Sn < 0 || L < 1 || L > 15) return fail(NERF_AMD_EINVAL, "bad size or L (1..15)");
     if (N * Sn && (!z || !rays || !dir_norm || !feat)) return fail(NERF_AMD_EINVAL, "NULL argument");
     const float r2 = (float)((double)r * (double)r);        // Python's `r ** 2` is a double, rounded when it meets the fp32 tensor
-    return hip_status(sk_ipe_feature(z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t, S(stream)), "nerf_amd_ipe_feature");
+    return hip_status(sk_ipe_feature(z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t, 0, S(stream)), "nerf_amd_ipe_feature");
+}
+int nerf_amd_ipe_feature_contracted(const float* z, const float* rays, int64_t N, int Sn, int L, float r, const float* dir_norm, float* feat, float* mu,
+                                    float* mu_t, void* stream) {
+    if (N < 0 || Sn < 0 || L < 1 || L > 15) return fail(NERF_AMD_EINVAL, "bad size or L (1..15)");
+    if (N * Sn && (!z || !rays || !dir_norm || !feat)) return fail(NERF_AMD_EINVAL, "NULL argument");
+    const float r2 = (float)((double)r * (double)r);
+    return hip_status(sk_ipe_feature(z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t, 1, S(stream)), "nerf_amd_ipe_feature_contracted");
 }
 int nerf_amd_cone_parameters(const float* z, int64_t N, int Sn, float r, float* mu_t, float* var_t, float* var_r, void* stream) {
     if (N < 0 || Sn < 0) return fail(NERF_AMD_EINVAL, "negative size");

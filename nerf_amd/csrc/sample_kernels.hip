@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void pe_kernel(const float* __restrict__ x, in
 //   out[.., 6 l + 3 t + c] = (t ? cos : sin)(2^l mu_c) * exp(-0.5 * (4^l diag_c))     (multFreq :36-45, ipe_feature :51-58)
 __global__ __launch_bounds__(256) void ipe_feature_kernel(const float* __restrict__ z, const float* __restrict__ rays, int64_t N, int S, int L,
                                                            float r2, const float* __restrict__ dir_norm, float* __restrict__ feat,
-                                                           float* __restrict__ mu_out, float* __restrict__ mu_t_out) {
+                                                           float* __restrict__ mu_out, float* __restrict__ mu_t_out, int contract) {
     float* stage = reinterpret_cast<float*>(smem);
     float (*mom)[6] = reinterpret_cast<float (*)[6]>(stage + ENC_TILE * 6 * L);
     const int64_t total = N * S;
@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256) void ipe_feature_kernel(const float* __restric
             const float* ry = rays + n * 6;
 #pragma unroll
             for (int k = 0; k < 3; ++k) cone_mean_cov(c, ry[k], ry[3 + k], dn, mom[sl][k], mom[sl][3 + k]);
+            if (contract) {                                  // Mip-NeRF 360 contraction of the frustum MEAN (the covariance stays metric): the fused
+                const float nn = norm3(mom[sl][0], mom[sl][1], mom[sl][2]);   // kernels' sample fetch does the same (mlp_kernels.hip contract_position)
+                if (nn > 1.0f) {
+                    const float kk = (2.0f - 1.0f / nn) / nn;
+                    mom[sl][0] *= kk; mom[sl][1] *= kk; mom[sl][2] *= kk;
+                }
+            }
             if (mu_out) { mu_out[m * 3] = mom[sl][0]; mu_out[m * 3 + 1] = mom[sl][1]; mu_out[m * 3 + 2] = mom[sl][2]; }
             if (mu_t_out) mu_t_out[m] = c.mu_t;
         });
@@ -1328,9 +1335,9 @@ int sk_positional_encoding(const float* x, int64_t M, int L, float* out, hipStre
     return (int)hipGetLastError();
 }
 int sk_ipe_feature(const float* z, const float* rays, int64_t N, int Sn, int L, float r2, const float* dir_norm, float* feat, float* mu,
-                   float* mu_t, hipStream_t st) {
+                   float* mu_t, int contract, hipStream_t st) {
     if (N * Sn == 0) return 0;
-    hipLaunchKernelGGL(ipe_feature_kernel, dim3(blocks_for(N * Sn, ENC_TILE)), dim3(256), enc_lds_bytes(L), st, z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t);
+    hipLaunchKernelGGL(ipe_feature_kernel, dim3(blocks_for(N * Sn, ENC_TILE)), dim3(256), enc_lds_bytes(L), st, z, rays, N, Sn, L, r2, dir_norm, feat, mu, mu_t, contract);
     return (int)hipGetLastError();
 }
 int sk_cone_parameters(const float* z, int64_t N, int Sn, float r2, float* mu_t, float* var_t, float* var_r, hipStream_t st) {

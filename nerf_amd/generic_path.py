@@ -13,7 +13,7 @@ Two routes: fp32 rows on `nerf_amd_gemm` (everything that is differentiated, and
 `nerf_amd_rows_gemm` for forwards nobody differentiates under bf16 precision (rendering): the same values at a third of the traffic and
 ~3x the rate (`_rows_route`, `_skip_rows` below).  Sample positions get a gradient inside RefNeRF.get_grad only (d density / d position: a dgrad-only chain + the encoding's
 adjoint, like on the fused path; the reference's loss never uses another, utils.py:35-36); scene contraction is a stage of its own in front of the
-encoder here (`ops.contract_positions`, round 5); the integrated PE is a flag of the fused kernels' sample fetch only.  RefNeRF takes this path as well (`ref_forward`: hidden width > 256, > 10 octaves, or
+encoder here (`ops.contract_positions`, round 5); the integrated PE comes from the stand-alone encoder (`ops.ipe_feature`, with `contract=` since round 6: MipNeRF.forward_rays).  RefNeRF takes this path as well (`ref_forward`: hidden width > 256, > 10 octaves, or
 `--ide_level 5`, whose 36 spherical-harmonic terms the fused kernel's three IDE K groups do not hold).
 """
 from typing import List, Tuple

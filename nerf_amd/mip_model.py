@@ -144,10 +144,11 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         if self._generic():
             if ipe_radius is not None:
                 # layer-by-layer route: the stand-alone integrated-PE encoder (nerf_amd_ipe_feature) feeds [frustum mean | feature] to the layers
-                if contract:
-                    raise NotImplementedError("nerf_amd: integrated PE WITH scene contraction is a combination of the fused kernels' sample fetch only")
+                # (with `contract` the encoder contracts the frustum mean itself -- nerf_amd_ipe_feature_contracted, round 6; the layers then
+                #  see [contracted mean | feature] and must NOT contract again)
                 from . import generic_path
-                feat, mu, _ = ops.ipe_feature(z[:, : n_samples + 1].contiguous(), rays, self.position_flevel, float(ipe_radius), ipe_dir_norm)
+                feat, mu, _ = ops.ipe_feature(z[:, : n_samples + 1].contiguous(), rays, self.position_flevel, float(ipe_radius), ipe_dir_norm,
+                                              contract=bool(contract))
                 pts = torch.cat((mu, rays[:, None, 3:6].expand(-1, n_samples, -1)), dim=-1).contiguous()
                 return generic_path.mip_forward(self, pts, encoded_x=feat)
             return self.forward(NeRF.length2pts(rays, z[:, :n_samples].contiguous()), contract=contract)

@@ -323,8 +323,9 @@ def cone_parameters(z: torch.Tensor, r: float):
     return tuple(out)
 
 
-def ipe_feature(z: torch.Tensor, rays: torch.Tensor, L: int, r: float, dir_norm: Optional[torch.Tensor] = None):
-    """ipe_feature (mip_methods.py:47-58): z (N,S+1), rays (N,6) -> feat (N,S,6L), mu (N,S,3), mu_t (N,S)."""
+def ipe_feature(z: torch.Tensor, rays: torch.Tensor, L: int, r: float, dir_norm: Optional[torch.Tensor] = None, contract: bool = False):
+    """ipe_feature (mip_methods.py:47-58): z (N,S+1), rays (N,6) -> feat (N,S,6L), mu (N,S,3), mu_t (N,S).  `contract` (an addition): the
+    frustum mean goes through the Mip-NeRF 360 contraction before the lift (nerf_amd_ipe_feature_contracted); `mu` is the contracted mean."""
     z, rays = _dev(z, "zvals"), _dev(rays, "cam_rays")
     N, S = z.shape[0], z.shape[1] - 1
     if dir_norm is None:
@@ -332,8 +333,8 @@ def ipe_feature(z: torch.Tensor, rays: torch.Tensor, L: int, r: float, dir_norm:
     feat = torch.empty((N, S, 6 * L), dtype=torch.float32, device=z.device)
     mu = torch.empty((N, S, 3), dtype=torch.float32, device=z.device)
     mu_t = torch.empty((N, S), dtype=torch.float32, device=z.device)
-    check(lib.nerf_amd_ipe_feature(_ptr(z), _ptr(rays), N, S, L, float(r), _ptr(dir_norm), _ptr(feat), _ptr(mu), _ptr(mu_t), _stream()),
-          "nerf_amd_ipe_feature")
+    fn, name = (lib.nerf_amd_ipe_feature_contracted, "nerf_amd_ipe_feature_contracted") if contract else (lib.nerf_amd_ipe_feature, "nerf_amd_ipe_feature")
+    check(fn(_ptr(z), _ptr(rays), N, S, L, float(r), _ptr(dir_norm), _ptr(feat), _ptr(mu), _ptr(mu_t), _stream()), name)
     return feat, mu, mu_t
 
 

@@ -78,7 +78,7 @@ def _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sampl
             rgbo, normal = network.forward(samples, contract=True) if contract else network.forward(samples)
             rgbo[..., -1] = torch.nn.functional.softplus(rgbo[..., -1] + 0.5)
         elif ipe_radius is not None:                                                  # frusta between the sample_num + 1 sorted depths
-            rgbo = network.forward_rays(r, fine.contiguous(), sample_num, ipe_radius=ipe_radius, ipe_dir_norm=ipe_dir_norm)
+            rgbo = network.forward_rays(r, fine.contiguous(), sample_num, ipe_radius=ipe_radius, ipe_dir_norm=ipe_dir_norm, contract=contract)
             fine = fine[..., :-1].contiguous()
         else:
             fine = fine[..., :-1].contiguous()
@@ -164,8 +164,6 @@ def render_image(network: NeRF, prop_net: ProposalNetwork, render_pose: torch.Te
     if generic:
         # a network LARGER than the fused kernels' compiled shapes (hidden width > 256, > 10 octaves): the reference's tile body
         # (procedures.py:62-85) call by call on the mirrored ops -- the networks run layer by layer (nerf_amd/generic_path.py)
-        if ipe and contract:
-            raise NotImplementedError("nerf_amd: integrated PE WITH scene contraction is a combination of the fused kernels' sample fetch only")
         rgb, depth, normal_px = _render_rays_by_calls(network, prop_net, rays, z_base, u_strat, u_inv, sample_num, near, far, white_bkg, bool(render_depth),
                                                       is_ref_model=is_ref_model,
                                                       cam_dir=render_pose[:, -2].contiguous() if (render_normal and is_ref_model) else None, seed=seed,

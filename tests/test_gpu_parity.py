@@ -876,8 +876,9 @@ def test_error_reporting(A):
     with pytest.raises(NerfAmdError):
         A.ops.mip_forward_composite(build_nets(A, "small")[1].packed(A.ops.F32), A.ops.F32, torch.rand(4, 6).cuda(),
                                     torch.rand(4, 101).cuda(), 100, False, 2.0, 6.0)       # S not in {32, 64, 128}
-    with pytest.raises(NotImplementedError):                           # integrated PE WITH contraction: the fused kernels' sample fetch only
-        A.mip_model.MipNeRF(10, 4, 512).cuda().eval().forward_rays(torch.rand(2, 6).cuda(), torch.rand(2, 5).cuda().sort(-1)[0], 4, ipe_radius=1e-3, contract=True)
+    with torch.no_grad():                                              # integrated PE WITH contraction layer by layer (round 6; used to raise)
+        assert A.mip_model.MipNeRF(10, 4, 512).cuda().eval().forward_rays(torch.rand(2, 6).cuda(), torch.rand(2, 5).cuda().sort(-1)[0], 4, ipe_radius=1e-3,
+                                                                            contract=True).shape == (2, 4, 4)
     assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda() * 5, contract=True).shape == (2, 3)   # (round 5)
     assert A.addtional.ProposalNetwork(10, 512).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # wider than compiled: generic path
     assert A.addtional.ProposalNetwork(10).cuda().eval().forward(torch.rand(2, 3, 3).cuda()).shape == (2, 3)   # class default 128: zero-padded
@@ -1216,8 +1217,26 @@ def test_scene_contraction_on_the_layer_by_layer_route(A):
         w_rgb, _, w_depth = O.render_rays(psd, msd, rays, u1, u2, near, far, n_f, white_bkg=True, ipe_radius=radius)
     gate("generic-route integrated-PE render_image: rgb vs oracle", max_abs(res["rgb"].cpu(), w_rgb.view(40, 40, 3).permute(2, 0, 1)), 1e-4)
     gate("generic-route integrated-PE render_image: depth vs oracle", max_abs(res["depth_img"][0].cpu(), w_depth.view(40, 40)), 1e-4)
-    with pytest.raises(NotImplementedError):                                  # the COMBINATION stays with the fused kernels' sample fetch
-        render_image(mip, prop, pose.cuda(), 40, focal, near, far, n_f, ipe=True, contract=True)
+    # ... and BOTH together (round 6: nerf_amd_ipe_feature_contracted; the combination used to be refused on this route): first the encoder
+    # itself -- frustum means contracted, covariances metric -- against oracle.ipe_feature(contracted=True) on depths out to z = 30, then
+    # the whole unbounded render against oracle.render_rays(contracted=True, ipe_radius=...)
+    near, far = 0.2, 30.0
+    zt = torch.sort(torch.rand(1600, n_f + 1, generator=gen) * (far - near) + near, dim=-1)[0]
+    dn = A.ops.dirs_norm(dev(rays))
+    feat, mu, mu_t = A.ops.ipe_feature(dev(zt), dev(rays), 10, radius, dn, contract=True)
+    with torch.no_grad():
+        w_feat, w_mu, w_mut = O.ipe_feature(zt, rays, 10, radius, dn.cpu(), contracted=True)
+    assert float((w_mu.norm(dim=-1) > 1.0).float().mean()) > 0.5                                      # most frusta lie outside the unit ball
+    gate("contracted integrated-PE encoder: contracted mean vs oracle", max_abs(mu.cpu(), w_mu), 2e-6)
+    gate("contracted integrated-PE encoder: feature vs oracle", max_abs(feat.cpu(), w_feat), 2e-5)   # (sin / cos of 2^9 x contracted mean: 1e-6 of argument error x 512)
+    assert max_abs(mu_t.cpu(), w_mut) <= 1e-5
+    plain_feat, plain_mu, _ = A.ops.ipe_feature(dev(zt), dev(rays), 10, radius, dn)
+    assert not torch.equal(plain_mu, mu) and max_abs(A.ops.contract_positions(plain_mu.view(-1, 3)).view_as(mu), mu) <= 2e-6
+    with torch.no_grad():
+        res = render_image(mip, prop, pose.cuda(), 40, focal, near, far, n_f, white_bkg=True, render_depth=True, ipe=True, contract=True, seed=seed)
+        w_rgb, _, w_depth = O.render_rays(psd, msd, rays, u1, u2, near, far, n_f, white_bkg=True, contracted=True, ipe_radius=radius)
+    gate("generic-route contracted integrated-PE render_image: rgb vs oracle", max_abs(res["rgb"].cpu(), w_rgb.view(40, 40, 3).permute(2, 0, 1)), 1e-4)
+    gate("generic-route contracted integrated-PE render_image: depth vs oracle", max_abs(res["depth_img"][0].cpu(), w_depth.view(40, 40)), 1e-3)
 
 
 def test_density_gradient_normals_through_the_scene_contraction(A):
