@@ -44,7 +44,7 @@ def test_struct_layout_matches_header():
 def test_pure_queries_without_gpu():
     from nerf_amd import _lib
     lib = _lib.lib
-    assert lib.nerf_amd_version() == 124
+    assert lib.nerf_amd_version() == 125
     assert lib.nerf_amd_packed_bytes(_lib.NET_PROPOSAL, _lib.BF16) == 432 * 1024 + 1056 * 4
     fold = (128 * 256 + 128) * 4                       # scratch of the bottle_neck -> rgb_layer.0 fold
     assert lib.nerf_amd_packed_bytes(_lib.NET_MIP, _lib.BF16) == 928 * 1024 + 1984 * 4 + fold
