@@ -104,6 +104,7 @@ def write_config0_train_step():
     from nerf import nerf_base, mip_model, addtional, utils, mip_methods
     import torch.nn.functional as F
     import weights as W
+    torch.set_num_threads(8)                                 # (like main(): the summation order of the CPU GEMMs is part of the fixture)
     near, far, N, C_, F_ = 2.0, 6.0, 256, 32, 64
     pose = utils.pose_spherical(52.0, -30.0, 4.0)[:3]
     focal = utils.fov2Focal(0.6911112070083618, (200, 200))

@@ -1228,7 +1228,9 @@ def test_scene_contraction_on_the_layer_by_layer_route(A):
         w_feat, w_mu, w_mut = O.ipe_feature(zt, rays, 10, radius, dn.cpu(), contracted=True)
     assert float((w_mu.norm(dim=-1) > 1.0).float().mean()) > 0.5                                      # most frusta lie outside the unit ball
     gate("contracted integrated-PE encoder: contracted mean vs oracle", max_abs(mu.cpu(), w_mu), 2e-6)
-    gate("contracted integrated-PE encoder: feature vs oracle", max_abs(feat.cpu(), w_feat), 2e-5)   # (sin / cos of 2^9 x contracted mean: 1e-6 of argument error x 512)
+    # (the highest octave's argument is 512 x the contracted mean: the mean's 3.6e-7 -- one or two ulps, the contraction's norm / divide are not
+    #  the oracle's operation order -- may show up as 1.8e-4 in sin / cos; measured 3.9e-5)
+    gate("contracted integrated-PE encoder: feature vs oracle", max_abs(feat.cpu(), w_feat), 2e-4)
     assert max_abs(mu_t.cpu(), w_mut) <= 1e-5
     plain_feat, plain_mu, _ = A.ops.ipe_feature(dev(zt), dev(rays), 10, radius, dn)
     assert not torch.equal(plain_mu, mu) and max_abs(A.ops.contract_positions(plain_mu.view(-1, 3)).view_as(mu), mu) <= 2e-6
