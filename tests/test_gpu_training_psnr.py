@@ -33,6 +33,7 @@ N_HELD = 1                           # held-out views (the last N_HELD of the sc
 HELD_CHUNK = 4096                    # rays per held-out render call (bounds the oracle's activation memory at 200x200 views)
 PROGRESS_EVERY = int(os.environ.get("PSNR_PROGRESS_EVERY", "0"))   # run_oracle: a PROGRESS line every so many iterations (0 = none)
 SCHED = None                         # optional it -> learning rate (the long runs use nerf_base.DecayLrScheduler's rule, train.py:133,200)
+SAVE_EVERY = 250                     # run_oracle(resume=...): iterations between saved states (the window length of scripts/psnr_windows.py)
 
 
 def analytic_scene(n_views=None):
@@ -114,7 +115,7 @@ def run_oracle(views, seed, resume=None, keep_all=False, init=None, stop=None):
         torch.set_rng_state(init["rng"])
         start = init["it"]
     for it in range(start, ITERS if stop is None else stop):
-        if resume is not None and (it > start or (keep_all and it == 0)) and it % 250 == 0:
+        if resume is not None and (it > start or (keep_all and it == 0)) and it % SAVE_EVERY == 0:
             state = {"prop": {k: v.detach() for k, v in prop.items()}, "mip": {k: v.detach() for k, v in mip.items()}, "opt": opt.state_dict(),
                      "rng": torch.get_rng_state(), "hist": hist, "held": held, "it": it, "recipe": recipe}
             torch.save(state, resume + ".tmp")
