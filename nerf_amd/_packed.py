@@ -25,6 +25,20 @@ class PackedWeightsMixin:
     def _linear_layers(self) -> List[torch.nn.Linear]:
         raise NotImplementedError
 
+    def _layers(self) -> List[torch.nn.Linear]:
+        """`_linear_layers()` resolved ONCE per module: the lookup walks nn.Module.__getattr__ and nn.Sequential.__getitem__ for every layer
+        (~300 attribute look-ups per training step over both networks, 7 % of the eager 1 024-ray iteration's host time,
+        scripts/gpu_host_profile.py).  The layer OBJECTS of a network never change after construction -- load_state_dict, .to() and the
+        optimizers write into the same Parameters; a caller who swaps a layer object for another calls `_layers_changed()`."""
+        c = self.__dict__.get("_layers_cache")
+        if c is None:
+            c = self.__dict__["_layers_cache"] = list(self._linear_layers())
+        return c
+
+    def _layers_changed(self) -> None:
+        self.__dict__.pop("_layers_cache", None)
+        self.invalidate_packed()
+
     # ---- narrower networks (--prop_net_width / --nerf_net_width < 256) ---------------------------------------------------------------
     # The kernels are compiled for 256-wide hidden layers.  A network with hidden_unit < 256 is evaluated EXACTLY by them with its
     # tensors zero-padded to the compiled shapes: the padded units have zero weights and zero bias, so they output relu(0) = 0 and feed
@@ -54,7 +68,7 @@ class PackedWeightsMixin:
     def kernel_params(self, shapes=None):
         """-> (weights, biases) in the kernels' shapes (the parameters themselves when nothing is padded); `shapes` overrides
         _kernel_weight_shapes() (the narrow-tile layout of a network)"""
-        layers = self._linear_layers()
+        layers = self._layers()
         shapes = self._kernel_weight_shapes() if shapes is None else shapes
         ws, bs = [l.weight for l in layers], [l.bias for l in layers]
         if shapes is None or all(tuple(w.shape) == tuple(s) for w, s in zip(ws, shapes)):
@@ -79,7 +93,7 @@ class PackedWeightsMixin:
 
     def unpad_grads(self, gW, gb):
         """gradients in the kernels' shapes -> the parameters' shapes"""
-        layers = self._linear_layers()
+        layers = self._layers()
         segs = self._column_segments() or [None] * len(layers)
 
         def cols(g, l, seg):
@@ -106,7 +120,7 @@ class PackedWeightsMixin:
         owner = self.__dict__.get("_grad_owner")
         if owner is None or self._generic():
             return None
-        layers = self._linear_layers()
+        layers = self._layers()
         shapes = self._kernel_weight_shapes()
         if shapes is not None and any(tuple(l.weight.shape) != tuple(sh) for l, sh in zip(layers, shapes)):
             return None

@@ -122,7 +122,7 @@ class ProposalNetwork(PackedWeightsMixin, nn.Module):
             from . import generic_path
             return generic_path.proposal_forward(self, pts, contract=contract)
         prec = ops.current_precision()
-        layers = self._linear_layers()
+        layers = self._layers()
         params = [l.weight for l in layers] + [l.bias for l in layers]
         if ab.needs_grad(pts, *params):
             if pts.numel() == 0:                                         # an empty batch: nothing to launch, zero gradients for every parameter

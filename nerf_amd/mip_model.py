@@ -77,7 +77,7 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         return blob
 
     def _params(self):
-        layers = self._linear_layers()
+        layers = self._layers()
         return [l.weight for l in layers] + [l.bias for l in layers]
 
     def _train_op(self, prec, run_forward, *tensors):

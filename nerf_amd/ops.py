@@ -46,7 +46,15 @@ def current_precision() -> int:
     return BF16 if torch.is_autocast_enabled() else F32
 
 
+# torch.cuda.current_stream() builds a Stream object through three layers of Python (~10 us; thirteen calls per 1 024-ray training
+# step = 9 % of the eager iteration's host time, scripts/gpu_host_profile.py); the raw handle comes straight from the C extension.
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return _RAW_STREAM(_CUR_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
