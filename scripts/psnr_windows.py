@@ -40,7 +40,10 @@ def main():
     ap.add_argument("--at", default="all", help="window starts (iterations, multiples of 250) or 'all' = every kept state that has a successor")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10000)
+    ap.add_argument("--len", type=int, default=WINDOW, help="window length (a multiple of 250; default 250).  --at 6000 --len 4000 = the WHOLE decay phase "
+                                                             "teacher-forced once, from the oracle's state at the end of the hold phase")
     a = ap.parse_args()
+    WIN = a.len
     if a.threads > 0:
         torch.set_num_threads(a.threads)
     # the recipe of profiles/r05_psnr (psnr_seeds.py --size 40 --views 25 --held 1 --rays 512 --coarse 32 --fine 64 --iters 10000 --lr-mult 3 --hold 0.6)
@@ -52,9 +55,9 @@ def main():
     for seed in [int(s) for s in a.seeds.split(",")]:
         base = os.path.join(a.states, "cpu_seed%d.state" % seed)
         have = sorted(int(f.rsplit(".it", 1)[1]) for f in os.listdir(a.states) if f.startswith("cpu_seed%d.state.it" % seed))
-        starts = [k for k in have if k + WINDOW in have] if a.at == "all" else [int(k) for k in a.at.split(",")]
+        starts = [k for k in have if k + WIN in have] if a.at == "all" else [int(k) for k in a.at.split(",")]
         for k in starts:
-            f0, f1 = base + ".it%05d" % k, base + ".it%05d" % (k + WINDOW)
+            f0, f1 = base + ".it%05d" % k, base + ".it%05d" % (k + WIN)
             if not os.path.exists(f0):
                 continue
             st = torch.load(f0, weights_only=False)
@@ -65,18 +68,18 @@ def main():
                     if not os.path.exists(f1):
                         continue
                     nx = torch.load(f1, weights_only=False)
-                    hist, held = nx["hist"][k:k + WINDOW], nx["held_at"]
+                    hist, held = nx["hist"][k:k + WIN], nx["held_at"]
                 elif mode == "null":
-                    hist, held = T.run_oracle(views, seed, init=st, stop=k + WINDOW)
+                    hist, held = T.run_oracle(views, seed, init=st, stop=k + WIN)
                     held = held[0]
                 else:
-                    hist, held = T.run_hip(views, seed, mode, init=st, stop=k + WINDOW)
+                    hist, held = T.run_hip(views, seed, mode, init=st, stop=k + WIN)
                     extra = "  held-out-fp32render %.5f" % held[1] if len(held) > 1 else ""
                     held = held[0]
-                assert len(hist) == WINDOW, len(hist)
+                assert len(hist) == WIN, len(hist)
                 mse = sum(hist) / len(hist)
-                print("WINDOW mode %s seed %d start %d lr %.4e train-psnr %.5f held-out %.5f first-loss %.9e last50-psnr %.5f threads %d  %.0f s"
-                      % (mode, seed, k, T.SCHED(k), T.psnr(mse), held, hist[0], T.psnr(sum(hist[-50:]) / 50), torch.get_num_threads(), time.time() - t0) + extra, flush=True)
+                print(("WINDOW" if WIN == WINDOW else "LONGWINDOW len %d" % WIN) + " mode %s seed %d start %d lr %.4e train-psnr %.5f held-out %.5f first-loss %.9e last50-psnr %.5f threads %d  %.0f s"
+                      % (mode, seed, k, T.SCHED(k), T.psnr(mse), held, hist[0], T.psnr(sum(hist[-200:]) / 200) if WIN > WINDOW else T.psnr(sum(hist[-50:]) / 50), torch.get_num_threads(), time.time() - t0) + extra, flush=True)
 
 
 if __name__ == "__main__":

@@ -21,6 +21,20 @@ for f in sys.argv[1:]:
                 rec[(mode + "-train/fp32-render", seed, start)] = dict(rec[(mode, seed, start)], held=float(m2.group(1)))
 
 
+# the whole decay phase teacher-forced ONCE (psnr_windows.py --at 6000 --len 4000): the oracle's state at the end of the hold phase -> 10 000
+long_rec = {}
+lpat = re.compile(r"LONGWINDOW len (\d+) mode (\S+) seed (\d+) start (\d+) lr (\S+) train-psnr (\S+) held-out (\S+) first-loss (\S+) last50-psnr (\S+) threads (\d+)")
+for f in sys.argv[1:]:
+    for line in open(f):
+        m = lpat.search(line)
+        if m:
+            key = (m.group(2), int(m.group(3)), int(m.group(4)), int(m.group(1)))
+            long_rec[key] = {"train": float(m.group(6)), "held": float(m.group(7)), "tail": float(m.group(9))}
+            m2 = re.search(r"held-out-fp32render (\S+)", line)
+            if m2:
+                long_rec[(m.group(2) + "-train/fp32-render",) + key[1:]] = dict(long_rec[key], held=float(m2.group(1)))
+
+
 def phase(start):
     return "warm-up (0-250)" if start == 0 else ("hold (lr 4.5e-4)" if start < 6000 else "decay (100x over 4 000 it)")
 
@@ -77,3 +91,29 @@ for mode in modes:
     xs = [abs(rec[(mode, s, k)]["first"] - rec[("cpu", s, k)]["first"]) / rec[("cpu", s, k)]["first"] for s, k in keys if (mode, s, k) in rec]
     if xs:
         print("* %s: max %.2e, mean %.2e over %d windows" % (mode, max(xs), sum(xs) / len(xs), len(xs)))
+
+if long_rec:
+    print("\n## The whole decay phase in ONE window: the oracle's state at iteration 6 000 -> 10 000 on each path\n")
+    print("End-of-run figures of a path that inherits the oracle's basin at the end of the hold phase and runs the 4 000 decay iterations itself, against the")
+    print("oracle's own end of run: training PSNR of the last 200 iterations and the held-out render at iteration 10 000 (dB, path - oracle).\n")
+    lkeys = sorted({k[1:] for k in long_rec if k[0] == "cpu"})
+    lmodes = [m for m in ("fp32", "bf16", "bf16-train/fp32-render", "null") if any(k[0] == m for k in long_rec)]
+    print("| seed | window | oracle train (last 200) | oracle held-out | " + " | ".join("%s - oracle: train (last 200) / held-out" % m for m in lmodes) + " |")
+    print("|---|---|---|---|" + "---|" * len(lmodes))
+    acc = {m: ([], []) for m in lmodes}
+    for k in lkeys:
+        c = long_rec[("cpu",) + k]
+        cells = []
+        for m in lmodes:
+            r = long_rec.get((m,) + k)
+            if r:
+                acc[m][0].append(r["tail"] - c["tail"]); acc[m][1].append(r["held"] - c["held"])
+                cells.append("%+.4f / %+.4f" % (r["tail"] - c["tail"], r["held"] - c["held"]))
+            else:
+                cells.append("-")
+        print("| %d | %d -> %d | %.3f | %.3f | %s |" % (k[0], k[1], k[1] + k[2], c["tail"], c["held"], " | ".join(cells)))
+    for m in lmodes:
+        if acc[m][0]:
+            mt, st, sdt, n = stats(acc[m][0])
+            mh, sh, sdh, _ = stats(acc[m][1])
+            print("\n* %s - oracle over %d seeds: training PSNR (last 200 iterations) %+.4f +- %.4f dB (sd %.4f), held-out %+.4f +- %.4f dB (sd %.4f)" % (m, n, mt, st, sdt, mh, sh, sdh))

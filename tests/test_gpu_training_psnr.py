@@ -341,3 +341,36 @@ def test_psnr_at_equal_iterations():
     for k in ("fp32", "bf16"):
         assert abs(mean(held[k]) - mean(held["cpu"])) <= 0.1, (k, held)
         assert abs(mean(tails[k]) - mean(tails["cpu"])) <= 0.1, (k, tails)
+
+
+def test_teacher_forced_window_from_the_oracles_state(tmp_path):
+    """Round 6: the comparison that cancels the chaos.  The oracle trains 80 iterations and keeps its state at iteration 40 (parameters, both
+    Adam moments, step counts, the position of the generator that draws batches and uniforms); the HIP paths run iterations 40-80 FROM THAT
+    STATE on the identical draws.  The first loss of the window is computed from identical weights on an identical batch (1e-5 fp32), and the
+    training PSNR of the window -- the statistic of profiles/r06_psnr/summary.md -- agrees with the oracle's own continuation to 0.03 dB
+    (fp32) / 0.1 dB (bf16): no trajectory is older than 40 iterations, so no basin lottery enters.  scripts/psnr_windows.py runs the same
+    thing at 250 iterations per window over the oracle's whole 10 000-iteration runs."""
+    global ITERS, CHECKPOINTS, SAVE_EVERY
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    saved = (ITERS, CHECKPOINTS, SAVE_EVERY)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    try:
+        ITERS, CHECKPOINTS, SAVE_EVERY = 80, (), 40
+        views = analytic_scene()
+        path = str(tmp_path / "cpu_seed5.state")
+        hist, _ = run_oracle(views, 5, path, keep_all=True)
+        st = torch.load(path + ".it00040", weights_only=False)
+        end = torch.load(path + ".it00080", weights_only=False)
+        assert st["it"] == 40 and len(st["opt"]["state"]) > 0
+        want = psnr(sum(hist[40:80]) / 40)
+        for prec, tol_first, tol_db in (("fp32", 1e-5, 0.03), ("bf16", 5e-3, 0.1)):
+            h, held = run_hip(views, 5, prec, init=st, stop=80)
+            assert len(h) == 40
+            assert abs(h[0] - hist[40]) <= tol_first * hist[40], (prec, h[0], hist[40])
+            got = psnr(sum(h) / 40)
+            print("teacher-forced window 40-80 (%s): train PSNR %.4f dB, oracle's own continuation %.4f dB; held-out %.3f vs %.3f dB" % (prec, got, want, held[0], end["held_at"]))
+            assert abs(got - want) <= tol_db, (prec, got, want)
+            assert abs(held[0] - end["held_at"]) <= 0.5, (prec, held, end["held_at"])        # (one early-training render: noisy in every path)
+    finally:
+        ITERS, CHECKPOINTS, SAVE_EVERY = saved
