@@ -869,6 +869,23 @@ def test_non_contiguous_inputs_and_side_stream(A):
     assert torch.equal(r1, r2) and torch.equal(w1, w2)
 
 
+def test_kernels_launch_on_torchs_current_stream(A):
+    """ops._stream() takes the raw handle of torch's CURRENT stream from the C extension (round 6: torch.cuda.current_stream() cost ~10 us per
+    call, thirteen calls per small training step): it must follow `torch.cuda.stream(...)` contexts and graph capture exactly like the
+    Stream object did -- and a kernel launched inside a side-stream context must be ordered on that stream."""
+    assert A.ops._stream() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert A.ops._stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+        x = torch.rand(1000, 3, device="cuda")
+        y = A.ops.positional_encoding(x, 4)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    ev.synchronize()
+    assert A.ops._stream() == torch.cuda.current_stream().cuda_stream != side.cuda_stream
+    assert max_abs(y.cpu(), O.positional_encoding(x.cpu(), 4)) <= 2e-6
+
+
 def test_error_reporting(A):
     from nerf_amd._lib import NerfAmdError
     with pytest.raises(NerfAmdError):                                  # C < 3 is rejected by the C-ABI with a message
