@@ -117,3 +117,40 @@ if long_rec:
             mt, st, sdt, n = stats(acc[m][0])
             mh, sh, sdh, _ = stats(acc[m][1])
             print("\n* %s - oracle over %d seeds: training PSNR (last 200 iterations) %+.4f +- %.4f dB (sd %.4f), held-out %+.4f +- %.4f dB (sd %.4f)" % (m, n, mt, st, sdt, mh, sh, sdh))
+
+# The free-running NULL: the same oracle, the same seeds, run twice (round 5: profiles/r05_psnr/cpu_seed*.log; round 6: the trajectories the
+# windows start from) with different thread configurations -- training PSNR of the last 200 iterations at equal iterations, paired per seed.
+import glob
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def progress(path):
+    out = {}
+    for line in open(path):
+        m = re.search(r"PROGRESS seed (\d+) it (\d+) train-psnr\(last 200\) (\S+)", line)
+        if m:
+            out[int(m.group(2))] = float(m.group(3))
+    return out
+
+
+a_dir, b_dir = os.path.join(ROOT, "profiles", "r05_psnr"), os.path.join(ROOT, "profiles", "r06_psnr")
+pairs = []
+for fb in sorted(glob.glob(os.path.join(b_dir, "cpu_seed*.log"))):
+    fa = os.path.join(a_dir, os.path.basename(fb))
+    if os.path.exists(fa):
+        pairs.append((os.path.basename(fb), progress(fa), progress(fb)))
+if pairs:
+    print("\n## The free-running null: the oracle against ITSELF\n")
+    print("The CPU oracle ran the same seeds in round 5 (`profiles/r05_psnr/cpu_seed*.log`) and again in round 6 (the trajectories the windows start from,")
+    print("`profiles/r06_psnr/cpu_seed*.log`) -- the same program on the same draws with another thread configuration, i.e. another fp32 summation order.")
+    print("Training PSNR of the last 200 iterations at equal iterations, round 6 - round 5, paired over the %d common seeds:\n" % len(pairs))
+    print("| iteration | oracle (r06) - oracle (r05), dB: mean +- s.e.m. (sd; per seed) |")
+    print("|---|---|")
+    for it in (500, 1000, 2000, 3000, 4000, 5000, 6000, 6500, 7000, 8000, 9000, 10000):
+        d = [b[it] - a[it] for _, a, b in pairs if it in a and it in b]
+        if d:
+            m, se, sd, n = stats(d)
+            print("| %d | %+.3f +- %.3f (sd %.3f; %s) |" % (it, m, se, sd, " ".join("%+.2f" % x for x in d)))
+    print("\nRound 5's free-running figure for the HIP fp32 path against the oracle, -0.32 +- 0.15 dB over 12 seeds at the end of the run (sd 0.51), is to be read")
+    print("against THIS spread: two runs of the oracle itself differ by as much per seed once the trajectories have left each other.")
