@@ -64,7 +64,8 @@ def parse():
     p.add_argument("--fused", action="store_true",
                    help="fine MLP with the fused compositing epilogue (one launch for rows 8-10) instead of two launches; A/B switch")
     p.add_argument("--model", default="mip", choices=["mip", "ref"],
-                   help="mip = BASELINE configs[1] (the headline); ref = Ref-NeRF render path (configs[3] shape: 64 + 192 merged samples)")
+                   help="mip = BASELINE configs[1] (the headline); ref = Ref-NeRF (configs[3] shape: 64 + 192 merged samples): the render path, or with "
+                        "--mode train-ddp the data-parallel training step with prop_normal")
     p.add_argument("--weights", default="small", choices=["small", "he", "zero"],
                    help="closed-form test weights; 'zero' is a power/DVFS diagnostic, never a reported number")
     p.add_argument("--cpu-rays", type=int, default=20000, help="rays of the same workload timed on the host cores (~14 s of CPU work)")
@@ -756,8 +757,16 @@ def train_ddp(a, comm):
     nerf_amd.set_train_dumps(a.train_dumps)
     n_rays, c_n, f_n = a.train_rays, C_COARSE, N_FINE
     near, far = (0.2, 30.0) if a.contract else (NEAR, FAR)
+    is_ref = a.model == "ref"                                         # BASELINE configs[3]: Ref-NeRF with prop_normal (train.py:164-199, ref branch)
+    if is_ref and (a.ipe or a.contract or a.train_dumps != "bf16"):
+        sys.exit("bench.py: --mode train-ddp --model ref takes no --ipe / --contract / fp8 dumps")
     torch.manual_seed(0)                                              # same initial weights on every rank ...
-    prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
+    if is_ref:
+        from nerf_amd.ref_model import BackFaceLoss, RefNeRF, WeightedNormalLoss
+        prop, mip = ProposalNetwork(10, 256).to(dev).train(), RefNeRF(10, 4).to(dev).train()
+        wnl, bfl = WeightedNormalLoss(), BackFaceLoss()
+    else:
+        prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
     if dist is not None:
         parallel.broadcast_parameters([mip, prop], src=0)             # ... and made sure of (ddp_train.py:98 DDP does this at wrap time)
     from nerf_amd.optim import Adam                                   # torch.optim.Adam's update as one HIP launch
@@ -777,9 +786,40 @@ def train_ddp(a, comm):
     n_grad = flat.flat.numel()
     ploss = ProposalLoss()
 
+    def ref_loss(z_c):
+        """the Ref-NeRF branch of train.py:164-199 with prop_normal: density-gradient normals of both networks (RefNeRF.get_grad), merged
+        coarse + fine depths, normal / back-face / coarse-normal losses"""
+        pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous().requires_grad_(True)
+        dens = prop.forward(pts)
+        coarse_grad = -RefNeRF.get_grad(dens, pts)
+        pw = maxBlurFilter(ProposalNetwork.get_weights(F.softplus(dens), z_c, rays[:, 3:]), 0.01)
+        ops.advance_seed(seed_dev)
+        fl, below = inverseSample(pw, z_c, f_n + 1, sort=True, u=ops.philox_uniforms((n_rays, f_n + 1), seed_dev=seed_dev))
+        samples, fl, below, sort_ids = NeRF.coarseFineMerge(rays, z_c, fl, below)
+        pos, dd = samples.split((3, 3), dim=-1)
+        pos.requires_grad_(True)
+        rgbo, nrm = mip.forward(pos, dd)
+        dgrad = -RefNeRF.get_grad(rgbo[..., -1], pos)
+        rgbo[..., -1] = F.softplus(rgbo[..., -1] + 0.5)
+        rend, wts, _ = NeRF.render(rgbo, fl, rays[:, 3:], mip.density_act)             # (the reference's positional quirk, train.py:182)
+        cnl = wnl(pw, RefNeRF.coarse_grad_select(dgrad, sort_ids, c_n).detach(), coarse_grad)
+        return ploss(getBounds(pw, below), wts.detach()) + torch.mean((rend - tgt) ** 2) + 4e-4 * (wnl(wts, dgrad, nrm) + 0.1 * cnl) + 0.1 * bfl(wts, nrm, dd)
+
     def step(timed_idx=None):
         u_c = ops.philox_uniforms((n_rays, c_n), seed_dev=seed_dev)   # (device-resident seed: nothing in the step reads host state)
         z_c = base + u_c * res
+        if is_ref:
+            loss = ref_loss(z_c)
+            flat.begin_step()
+            loss.backward()
+            if timed_idx is not None:
+                ev[timed_idx][0].record()
+            flat.all_reduce()
+            if timed_idx is not None:
+                ev[timed_idx][1].record()
+            opt.step()
+            ops.advance_seed(seed_dev)
+            return
         pts = (rays[:, None, :3] + rays[:, None, 3:] * z_c[:, :, None]).contiguous()
         dens = F.softplus(prop.forward(pts, contract=a.contract))
         pw = maxBlurFilter(ProposalNetwork.get_weights(dens, z_c, rays[:, 3:]), 0.01)
@@ -829,17 +869,21 @@ def train_ddp(a, comm):
     ar_ms = [s_.elapsed_time(e_) for s_, e_ in ev] if graph is None else None
     ar_ranks = comm.gather((sum(ar_ms) / a.steps * 1e3) if ar_ms else None)
     flop_per_ray = 3 * FLOP_PER_RAY                                      # forward + dgrad + wgrad
+    if is_ref:                                                           # 64 proposal + (128 + 64 merged) Ref-NeRF samples; the two density-gradient chains not counted
+        flop_per_ray = 3 * 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
     achieved = a.steps * n_rays * flop_per_ray / dt / 1e12               # per GPU
     rec = None
     if rank == 0:
         variant = ("Mip-NeRF + integrated PE (BASELINE configs[2])" if a.ipe else "NeRF / Mip-NeRF point PE") + (", scene contraction, near/far 0.2/30 (configs[4])" if a.contract else "")
+        if is_ref:
+            variant = "Ref-NeRF with prop_normal (BASELINE configs[3]): 64 proposal + 192 merged samples, IDE, density-gradient normals of both networks"
         rec = {"metric": "training rays/s (64+128 samples, fwd + bwd + gradient all_reduce + Adam)", "value": world * a.steps * n_rays / dt,
                "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "ms_per_step_ranks": spread,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
                "data": "synthetic",
-               "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, MipNeRF(10,4,256) + ProposalNetwork(10,256); %s%s"
-                                      % (n_rays, variant, ("; step replayed from a hipGraph (collective inside)" if graph is not None else "") +
+               "config": {"workload": "train.py:164-199 body + Adam on %d synthetic rays per rank, 64+128 samples, %s + ProposalNetwork(10,256); %s%s"
+                                      % (n_rays, "RefNeRF(10,4)" if is_ref else "MipNeRF(10,4,256)", variant, ("; step replayed from a hipGraph (collective inside)" if graph is not None else "") +
                                          ("; training dumps in scaled e4m3" if a.train_dumps == "fp8" else "")),
                           "rays_per_step_per_gpu": n_rays, "parallelism": "ray-sharded replicas (dp%d), one flat gradient all_reduce per step" % world},
                "allreduce": {"elements": n_grad, "bytes": 4 * n_grad,

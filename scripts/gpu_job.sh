@@ -26,6 +26,7 @@ while [ $# -gt 0 ]; do
               python bench.py --mode render-strong --steps 10 --warmup 3 > $OUT/bench_render_strong.json 2>/dev/null
               for f in "" "--ipe" "--contract" "--hipgraph" "--train-dumps fp8"; do python bench.py --mode train-ddp --steps 20 --warmup 5 --no-cpu-baseline $f 2>/dev/null | tail -1; done > $OUT/bench_train_variants.jsonl
               python bench.py --mode train-ddp --steps 50 --warmup 5 --train-rays 512 --hipgraph --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/bench_train_variants.jsonl
+              python bench.py --mode train-ddp --model ref --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/bench_train_variants.jsonl
               tail -c 600 $OUT/bench_default.json ;;
     profile)  bash scripts/gpu_round_profile.sh > $OUT/round_profile.log 2>&1; tail -3 $OUT/round_profile.log ;;
     trainprof) PMC=${PMC:-1} bash scripts/gpu_train_profile.sh "${args[@]}" > $OUT/train_profile.log 2>&1; tail -3 $OUT/train_profile.log ;;

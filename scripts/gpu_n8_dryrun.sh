@@ -5,7 +5,7 @@
 # (worst case: eight ranks share one device, so the timed region is ~8x a real node's).   -> gpurun_out/$TAG/n8_dryrun.log
 R=${GRAFT_REPO_ROOT:-.}; cd $R; TAG=${TAG:-r06_n8}; mkdir -p gpurun_out/$TAG; LOG=gpurun_out/$TAG/n8_dryrun.log; : > $LOG
 export BENCH_BACKEND=gloo
-for n in ${NS:-8}; do for m in "" "--mode render-strong" "--mode train-ddp"; do
+for n in ${NS:-8}; do for m in "" "--mode render-strong" "--mode train-ddp" "--mode train-ddp --model ref --train-rays 4096"; do
   t0=$(date +%s)
   timeout 1700 python bench.py --gpus $n $m > gpurun_out/$TAG/n${n}_out.txt 2> gpurun_out/$TAG/n${n}_err.txt; rc=$?
   echo "=== bench.py --gpus $n $m : rc=$rc  wall $(( $(date +%s) - t0 )) s" | tee -a $LOG

@@ -624,7 +624,7 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("mode", ["render", "render-strong", "train-ddp"])
+@pytest.mark.parametrize("mode", ["render", "render-strong", "train-ddp", "train-ddp-ref"])
 def test_bench_n_gt_1_path_runs_on_the_box_and_its_line_is_self_contained(mode, tmp_path):
     """What the driver's scaling run executes -- `bench.py --gpus N` with WORLD_SIZE > 1: process group, per-rank device, barriers around
     the timed region, max-over-ranks, the JSON line -- runs here with two ranks on the one GPU for all three modes (the only thing a
@@ -633,7 +633,8 @@ def test_bench_n_gt_1_path_runs_on_the_box_and_its_line_is_self_contained(mode, 
     produce the SAME image bit for bit whatever N is (every uniform is a function of the global ray index)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    extra = {"render": [], "render-strong": ["--mode", "render-strong"], "train-ddp": ["--mode", "train-ddp", "--train-rays", "2048"]}[mode]
+    extra = {"render": [], "render-strong": ["--mode", "render-strong"], "train-ddp": ["--mode", "train-ddp", "--train-rays", "2048"],
+             "train-ddp-ref": ["--mode", "train-ddp", "--model", "ref", "--train-rays", "1024"]}[mode]      # (BASELINE configs[3] on the DP training path)
     img = {}
     if mode == "render-strong":
         img = {1: str(tmp_path / "img1.pt"), 2: str(tmp_path / "img2.pt")}
@@ -660,6 +661,9 @@ def test_bench_n_gt_1_path_runs_on_the_box_and_its_line_is_self_contained(mode, 
     if mode == "train-ddp":
         assert two["allreduce"]["backend"] == "gloo" and two["allreduce"]["us_per_step"] > 0 and len(two["allreduce"]["us_per_step_ranks"]) == 2
         assert two["allreduce"]["elements"] == 530052 + 214017
+    if mode == "train-ddp-ref":
+        assert two["allreduce"]["backend"] == "gloo" and two["allreduce"]["us_per_step"] > 0
+        assert two["allreduce"]["elements"] == 1075854 + 214017 and "Ref-NeRF" in two["config"]["workload"]      # 5.16 MB per step
     if mode == "render-strong":
         a, b = torch.load(img[1]), torch.load(img[2])
         assert a.shape == (800 * 800, 4) and torch.equal(a, b)              # N = 2 == N = 1, bit for bit
