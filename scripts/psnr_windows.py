@@ -10,6 +10,7 @@ draws batches and uniforms: `psnr_seeds.py --modes cpu --keep-all` keeps one eve
     null     the oracle restarted from the state with ANOTHER thread count (the same program, another summation order: the control)
     fp32     the HIP path, fp32-MFMA kernels
     bf16     the HIP path, bf16 kernels
+    fp32-native / bf16-native   the same with the package's own one-launch Adam (device-side step count and float64 learning rate) instead of torch's
 
 on the identical draws.  Compared per window: the training PSNR of those 250 iterations (mean image loss -> dB) and the held-out render
 at the window's end.  Variance between trajectories is cancelled because no trajectory is older than 250 iterations.
@@ -72,8 +73,9 @@ def main():
                 elif mode == "null":
                     hist, held = T.run_oracle(views, seed, init=st, stop=k + WIN)
                     held = held[0]
-                else:
-                    hist, held = T.run_hip(views, seed, mode, init=st, stop=k + WIN)
+                else:                                               # "fp32" / "bf16" (torch's CUDA Adam, like the oracle's torch CPU Adam) or
+                    prec, native = (mode[:-7], True) if mode.endswith("-native") else (mode, False)   # "...-native": nerf_amd.optim.Adam(lr_on_device=True)
+                    hist, held = T.run_hip(views, seed, prec, init=st, stop=k + WIN, native_adam=native)
                     extra = "  held-out-fp32render %.5f" % held[1] if len(held) > 1 else ""
                     held = held[0]
                 assert len(hist) == WIN, len(hist)

@@ -17,7 +17,7 @@ for f in sys.argv[1:]:
             rec[(mode, seed, start)] = {"lr": float(m.group(4)), "train": float(m.group(5)), "held": float(m.group(6)), "first": float(m.group(7)),
                                         "last50": float(m.group(8)), "threads": int(m.group(9))}
             m2 = re.search(r"held-out-fp32render (\S+)", line)
-            if m2:                                                  # bf16-TRAINED weights rendered by the fp32 kernels: its own pseudo-mode
+            if m2 and mode == "bf16":                               # bf16-TRAINED weights rendered by the fp32 kernels: its own pseudo-mode
                 rec[(mode + "-train/fp32-render", seed, start)] = dict(rec[(mode, seed, start)], held=float(m2.group(1)))
 
 
@@ -31,7 +31,7 @@ for f in sys.argv[1:]:
             key = (m.group(2), int(m.group(3)), int(m.group(4)), int(m.group(1)))
             long_rec[key] = {"train": float(m.group(6)), "held": float(m.group(7)), "tail": float(m.group(9))}
             m2 = re.search(r"held-out-fp32render (\S+)", line)
-            if m2:
+            if m2 and m.group(2) == "bf16":
                 long_rec[(m.group(2) + "-train/fp32-render",) + key[1:]] = dict(long_rec[key], held=float(m2.group(1)))
 
 
@@ -48,7 +48,7 @@ def stats(xs):
     return m, sd / math.sqrt(n), sd, n
 
 
-modes = [m for m in ("fp32", "bf16", "bf16-train/fp32-render", "null") if any(k[0] == m for k in rec)]
+modes = [m for m in ("fp32", "fp32-native", "bf16", "bf16-native", "bf16-train/fp32-render", "null") if any(k[0] == m for k in rec)]
 keys = sorted({(k[1], k[2]) for k in rec if k[0] == "cpu"})
 seeds = sorted({k[0] for k in keys})
 print("# PSNR at equal iterations, teacher-forced 250-iteration windows (round 6)\n")
@@ -97,7 +97,7 @@ if long_rec:
     print("End-of-run figures of a path that inherits the oracle's basin at the end of the hold phase and runs the 4 000 decay iterations itself, against the")
     print("oracle's own end of run: training PSNR of the last 200 iterations and the held-out render at iteration 10 000 (dB, path - oracle).\n")
     lkeys = sorted({k[1:] for k in long_rec if k[0] == "cpu"})
-    lmodes = [m for m in ("fp32", "bf16", "bf16-train/fp32-render", "null") if any(k[0] == m for k in long_rec)]
+    lmodes = [m for m in ("fp32", "fp32-native", "bf16", "bf16-native", "bf16-train/fp32-render", "null") if any(k[0] == m for k in long_rec)]
     print("| seed | window | oracle train (last 200) | oracle held-out | " + " | ".join("%s - oracle: train (last 200) / held-out" % m for m in lmodes) + " |")
     print("|---|---|---|---|" + "---|" * len(lmodes))
     acc = {m: ([], []) for m in lmodes}

@@ -188,7 +188,7 @@ def load_oracle_state(init, prop, mip, opt):
     torch.set_rng_state(init["rng"])
 
 
-def run_hip(views, seed, precision, init=None, stop=None):
+def run_hip(views, seed, precision, init=None, stop=None, native_adam=False):
     """`init` (a state saved by run_oracle) + `stop`: the window [init['it'], stop) teacher-forced from the ORACLE's exact state --
     parameters, Adam moments, step counts, generator position -- on the HIP path; returns the window's losses + the held-out PSNR at `stop`."""
     import nerf_amd
@@ -208,7 +208,11 @@ def run_hip(views, seed, precision, init=None, stop=None):
     # saw ANOTHER stream of batches and uniforms than the oracle's run of the same seed (scripts/psnr_step0_diff.py found it: all 512 batch
     # indices of iteration 0 differed).  Distributions over seeds were unaffected; per-seed pairing of CPU against HIP was not a pairing.
     torch.manual_seed(seed)
-    opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=LR)
+    if native_adam:                                                      # the package's own optimizer: ONE HIP launch over all tensors, step count and
+        from nerf_amd.optim import Adam                                  # learning rate (float64) in device memory -- what TrainStep / bench.py train with
+        opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=LR, lr_on_device=True)
+    else:
+        opt = torch.optim.Adam(list(mip.parameters()) + list(prop.parameters()), lr=LR)
     res = (FAR - NEAR) / C_N
     hist, held = [], []
     gviews = [(r.cuda(), c.cuda()) for r, c in views]
