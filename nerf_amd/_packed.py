@@ -35,8 +35,17 @@ class PackedWeightsMixin:
             c = self.__dict__["_layers_cache"] = list(self._linear_layers())
         return c
 
+    def _layer_params(self):
+        """([weights], [biases]) of `_layers()`, resolved once like the layers themselves (each `l.weight` is an nn.Module.__getattr__ call)"""
+        c = self.__dict__.get("_layer_params_cache")
+        if c is None:
+            layers = self._layers()
+            c = self.__dict__["_layer_params_cache"] = ([l.weight for l in layers], [l.bias for l in layers])
+        return c
+
     def _layers_changed(self) -> None:
         self.__dict__.pop("_layers_cache", None)
+        self.__dict__.pop("_layer_params_cache", None)
         self.invalidate_packed()
 
     # ---- narrower networks (--prop_net_width / --nerf_net_width < 256) ---------------------------------------------------------------
@@ -68,11 +77,10 @@ class PackedWeightsMixin:
     def kernel_params(self, shapes=None):
         """-> (weights, biases) in the kernels' shapes (the parameters themselves when nothing is padded); `shapes` overrides
         _kernel_weight_shapes() (the narrow-tile layout of a network)"""
-        layers = self._layers()
         shapes = self._kernel_weight_shapes() if shapes is None else shapes
-        ws, bs = [l.weight for l in layers], [l.bias for l in layers]
+        ws, bs = self._layer_params()
         if shapes is None or all(tuple(w.shape) == tuple(s) for w, s in zip(ws, shapes)):
-            return ws, bs
+            return list(ws), list(bs)
         pw, pb = [], []
         segs = self._column_segments() or [None] * len(ws)
         with torch.no_grad():

@@ -77,8 +77,8 @@ class MipNeRF(PackedWeightsMixin, NeRF):
         return blob
 
     def _params(self):
-        layers = self._layers()
-        return [l.weight for l in layers] + [l.bias for l in layers]
+        ws, bs = self._layer_params()
+        return ws + bs
 
     def _train_op(self, prec, run_forward, *tensors):
         """Training forward (activation dump) + the hand-written backward on it (mlp_backward.py) as one autograd node.

@@ -164,9 +164,17 @@ def leased(tag, nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ weights
+def _raw(t: torch.Tensor, name: str) -> torch.Tensor:
+    """a parameter as the kernels read it: the tensor itself when it already is contiguous fp32 on the device (the usual case: no detach /
+    conversion objects per tensor -- 44 of them per training step), else `_dev`'s converted copy"""
+    if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous():
+        return t
+    return _dev(t.detach(), name)
+
+
 def pack_weights(net: int, precision: int, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
-    ws = [_dev(w.detach(), "weight") for w in weights]
-    bs = [_dev(b.detach(), "bias") for b in biases]
+    ws = [_raw(w, "weight") for w in weights]
+    bs = [_raw(b, "bias") for b in biases]
     nbytes = lib.nerf_amd_packed_bytes(net, precision)
     packed = torch.empty(nbytes, dtype=torch.uint8, device=ws[0].device)
     n = len(ws)
@@ -847,7 +855,7 @@ def _ptr_array(tensors):
 
 def pack_weights_backward(net: int, precision: int, weights: Sequence[torch.Tensor]) -> torch.Tensor:
     """The TRANSPOSED weights of a network in the dgrad-chain kernels' fragment order (same tensor order as pack_weights)."""
-    ws = [_dev(w.detach(), "weight") for w in weights]
+    ws = [_raw(w, "weight") for w in weights]
     blob = torch.empty(lib.nerf_amd_packed_backward_bytes(net, precision), dtype=torch.uint8, device=ws[0].device)
     check(lib.nerf_amd_pack_weights_backward(net, precision, _ptr_array(ws), len(ws), _ptr(blob), _stream()), "nerf_amd_pack_weights_backward")
     return blob
