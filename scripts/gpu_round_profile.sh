@@ -2,7 +2,7 @@
 # Round profile: kernel-trace stats + PMC traffic passes of the default bench command; outputs under gpurun_out/round/
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round; mkdir -p $OUT
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-ref --no-train-rate"
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gemm-ref --no-train-rate ${BENCH_EXTRA}"     # BENCH_EXTRA="--model ref": the Ref-NeRF render
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- $B > $OUT/kt.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT -o p1 -- $B > $OUT/p1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o p2 -- $B > $OUT/p2.log 2>&1

@@ -79,6 +79,10 @@ open(os.path.join(DST, prefix + "_pmc_summary.md"), "w").write("\n".join(lines) 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import update_pmc_traffic as upt
 tj = json.load(open(upt.FILE)) if os.path.exists(upt.FILE) else {}
+if traffic.get("ref_kernel") and not traffic.get("mip_kernel"):            # a profile of `bench.py --model ref` (BENCH_EXTRA="--model ref")
+    tj["ref_bf16"] = {"bytes": traffic["ref_kernel"], "round": prefix.split("_")[0], "sources": upt.source_hashes("ref_bf16"),
+                      "measured_by": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --model ref`; bytes per launch "
+                                     "of ref_kernel)" % prefix}
 if traffic.get("mip_kernel"):
     tj["mip_bf16"] = {"bytes": traffic["mip_kernel"], "round": prefix.split("_")[0], "sources": upt.source_hashes("mip_bf16"),
                       "measured_by": "profiles/%s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command; bytes per "
