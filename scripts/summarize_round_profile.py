@@ -49,7 +49,7 @@ lines = ["# %s -- rocprofv3 summary of `python bench.py --steps 5 --warmup 2 --n
          "| kernel | avg ms (kernel-trace) | MFMA busy cycles/launch | MFMA pipe busy | clock GHz (profiled pass) | WAIT_ANY | WAIT_INST | FETCH_SIZE KiB | WRITE_SIZE KiB | LDS bank conflicts |",
          "|---|---|---|---|---|---|---|---|---|---|"]
 traffic = {}
-for k in ("mip_kernel", "proposal_kernel", "resample_kernel", "composite_kernel"):
+for k in ("mip_kernel", "ref_kernel", "proposal_kernel", "resample_kernel", "composite_kernel"):
     if k not in mean:
         continue
     m = mean[k]
@@ -63,7 +63,7 @@ for k in ("mip_kernel", "proposal_kernel", "resample_kernel", "composite_kernel"
         k, stats.get(k, float("nan")), m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), 100 * busy, clk, 100 * m.get("SQ_WAIT_ANY", 0) / wc,
         100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, fetch, write, m.get("SQ_LDS_BANK_CONFLICT", 0.0)))
 lines += ["", "Instruction mix per MFMA (pass 4 `SQ_INSTS_*` / pass 1 `SQ_VALU_MFMA_BUSY_CYCLES` / 32; SQ_INSTS_VALU includes the MFMAs):", ""]
-for k in ("mip_kernel", "proposal_kernel"):
+for k in ("mip_kernel", "ref_kernel", "proposal_kernel"):
     if k in mean and mean[k].get("SQ_VALU_MFMA_BUSY_CYCLES"):
         m = mean[k]
         n_mfma = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 32.0
