@@ -141,6 +141,7 @@ def partial_record(msg: str) -> None:
     except (OSError, ValueError, AttributeError):
         sys.stdout.write(line)
         sys.stdout.flush()
+    Watchdog.done = True                                     # one record per rank: the termination watcher does not add a second one
 
 
 class Watchdog:

@@ -38,8 +38,10 @@ class PackedWeightsMixin:
     def _layer_params(self):
         """([weights], [biases]) of `_layers()`, resolved once like the layers themselves (each `l.weight` is an nn.Module.__getattr__ call)"""
         c = self.__dict__.get("_layer_params_cache")
-        if c is None:
-            layers = self._layers()
+        layers = self._layers()
+        # (Parameters are written in place by load_state_dict / .to() / the optimizers; a caller that ASSIGNS new Parameter objects to the
+        #  layers is caught by the identity check of the first and the last one -- anything finer calls `_layers_changed()`)
+        if c is None or c[0][0] is not layers[0].weight or c[1][-1] is not layers[-1].bias:
             c = self.__dict__["_layer_params_cache"] = ([l.weight for l in layers], [l.bias for l in layers])
         return c
 
