@@ -680,6 +680,13 @@ def train_rate(precision):
                               "algorithmic_tbps": floor_bytes * best / 16384 / 1e12}
     out["iteration_512"] = iteration_rate(precision)
     out["iteration_1024"] = iteration_rate(precision, n_rays=1024)      # the reference's default --sample_ray_num through TrainStep (fused loss kernels)
+    # the product's own iteration at the large batch: device-side sampler, fused loss kernels, one-launch Adam (the `rays_16384` /
+    # `refnerf_rays_16384` figures above run the reference-style body of scripts/gpu_train_rate.py with its torch expressions)
+    out["iteration_16384"] = iteration_rate(precision, n_rays=16384, iters=30)
+    out["refnerf_iteration_16384"] = iteration_rate(precision, n_rays=16384, iters=10, ref=True)
+    for k, fl in (("iteration_16384", 3 * FLOP_PER_RAY), ("refnerf_iteration_16384", 3 * 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616))):
+        for m in ("eager", "hipgraph"):
+            out[k][m]["roofline_frac"] = out[k][m]["rays_per_s"] * fl / peak
     # Ref-NeRF (BASELINE configs[3]) with prop_normal: the reference's batch and the paper's 2^14-ray batch, 64 + (128 + 64 merged) samples
     ref_flop_per_ray = 2 * (C_COARSE * MAC_PROP + (N_FINE + C_COARSE) * 1_071_616)
     for n, iters in ((512, 40), (16384, 10)):
@@ -697,7 +704,7 @@ def train_rate(precision):
     return out
 
 
-def iteration_rate(precision, n_rays=512, iters=200):
+def iteration_rate(precision, n_rays=512, iters=200, ref=False):
     """The reference's whole training ITERATION (train.py:151-218: ray sampling from an 800x800 image included) through
     nerf_amd.training.TrainStep -- pose, pixel table, seed, Adam step count and learning rate in device memory, every random number drawn
     in kernels -- eager and replayed from a hipGraph, with the learning rate rewritten on the host every iteration like DecayLrScheduler."""
@@ -715,11 +722,15 @@ def iteration_rate(precision, n_rays=512, iters=200):
     pose = O.pose_spherical(30.0, -30.0, 4.0)[:3].contiguous().to(dev)
     focal = O.fov2focal(0.6911112070083618, (H, W))
     for mode in ("eager", "hipgraph"):
-        prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
+        if ref:                                              # BASELINE configs[3]: the Ref-NeRF branch with prop_normal (train.py:176-187)
+            from nerf_amd.ref_model import RefNeRF
+            prop, mip = ProposalNetwork(10, 256).to(dev).train(), RefNeRF(10, 4).to(dev).train()
+        else:
+            prop, mip = ProposalNetwork(10, 256).to(dev).train(), MipNeRF(10, 4, 256).to(dev).train()
         opt = Adam(list(mip.parameters()) + list(prop.parameters()), lr=5e-4, lr_on_device=True)
         # (gradients in TrainStep's own flat buffer, WITHOUT the data-parallel all_reduce: in an N > 1 run only rank 0 measures this, and a
         #  collective that one rank enters alone never returns -- the two-rank GPU test of round 4 found exactly that hang)
-        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11)
+        step = TrainStep(prop, mip, opt, (H, W), focal, 2.0, 6.0, ray_num=n_rays, coarse_pnum=C_COARSE, fine_pnum=N_FINE, seed=11, prop_normal=ref)
         step.set_image(img, pose)
         if mode == "hipgraph":
             step.capture(warmup=3)
