@@ -305,20 +305,35 @@ __global__ __launch_bounds__(P::NW * 64) void mip_bwd_kernel(const void* __restr
 // ================================================================================================
 // row-major fp32 side output of a chain layer: the gradient w.r.t. a layer INPUT that is not a hidden activation (the encoded
 // position, Ref-NeRF's directional input vector), in the reference's column order; accumulate = += instead of =
-struct RowsOut {                                             // accumulators 8 half .. 8 half + 7 of block fb = features 32 fb + 8 (2 half + q) + 4 h + 0..3
+// BF (round 6, bf16 precision only): the rows travel as bf16 -- same (M, ld) ELEMENT layout, half the bytes.  Used for the directional
+// chain's (M, 192) gradient w.r.t. Ref-NeRF's input vector, which is written, read back + added to + rewritten, and read a third time
+// (ref_heads_delta_kernel): 9.6 GB per 2^14-ray step as fp32, 2.2 % of the step (profiles/r06_dir_chain_rows_bf16_cost_probe.log).  Its
+// first 128 columns become bf16 delta fragments anyway; the 39 IDE / n.d columns feed an fp32 element-wise stage whose outputs are bf16 deltas.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+template <bool BF = false>
+struct RowsOutT {                                            // accumulators 8 half .. 8 half + 7 of block fb = features 32 fb + 8 (2 half + q) + 4 h + 0..3
     float* rows; int ld; int accumulate; int64_t m0; int j, h; int64_t M;
     DEVINL void operator()(int fb, int t, const f32x16& acc, int half) const {
         const int64_t m = m0 + t * 32 + j;
         if (m >= M) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            f32x4* p = reinterpret_cast<f32x4*>(rows + m * ld + 32 * fb + 8 * (2 * half + q) + 4 * h);
+            const int64_t at = m * ld + 32 * fb + 8 * (2 * half + q) + 4 * h;
             f32x4 v = {acc[8 * half + 4 * q], acc[8 * half + 4 * q + 1], acc[8 * half + 4 * q + 2], acc[8 * half + 4 * q + 3]};
-            if (accumulate) { const f32x4 o = *p; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
-            *p = v;
+            if constexpr (BF) {
+                bf16x4* p = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(rows) + at);
+                if (accumulate) { const bf16x4 o = *p; v[0] += (float)o[0]; v[1] += (float)o[1]; v[2] += (float)o[2]; v[3] += (float)o[3]; }
+                const bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *p = w;
+            } else {
+                f32x4* p = reinterpret_cast<f32x4*>(rows + at);
+                if (accumulate) { const f32x4 o = *p; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                *p = v;
+            }
         }
     }
 };
+using RowsOut = RowsOutT<false>;
 
 
 // Round 4: the Ref-NeRF training forward writes ReLU bit masks too (mlp_kernels.hip ref_kernel: one register per column tile instead of an
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
                                                                 char* __restrict__ dlt, unsigned long long layer_stride, float* __restrict__ rows) {
     using L = RefBwdLayout;
     using BReg = typename P::BReg;
+    using RowsT = RowsOutT<(!DEN && P::PREC == NERF_AMD_BF16)>;     // the directional chain's input-vector gradient travels as bf16 rows in bf16 precision
     constexpr int L0 = DEN ? 18 : 0, S0 = DEN ? L::DEN_START : L::DIR_START;      // first layer of the chain in the layer table, its stream start
     constexpr int TOP = DEN ? 7 : 16;                                              // activation / delta slot of the chain's first hidden layer
     constexpr int NFB_ROWS = DEN ? 2 : 6, LD = DEN ? 64 : 192;
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
         // the skip layer's side output from b (= TOP-3, complete); a's last pair (TOP-4) stays pending across it -- the row layer issues no
         // mask DMA, so the pair's activations stay where they are in LDS
         {
-            const RowsOut R1{rows, LD, 0, sub0 * 32, j, h, M};
+            const RowsT R1{rows, LD, 0, sub0 * 32, j, h, M};
             const auto r1 = dense<P, 16, NFB_ROWS, L::START[L0 + 5] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, R1, NoPrev{});
             r1.flush(R1);
         }
@@ -435,7 +451,7 @@ __global__ __launch_bounds__(P::NW * 64) void ref_chain9_kernel(const void* __re
         }
         vm_wait<W16>();                                      // (the row layer has no mask wait of its own)
         const BitMaskedOut<P, 16, STORE, (TOP - 7) & 1> OL{b, A(TOP - 7), D(TOP - 7), sub0, lane, mask_lds};
-        const RowsOut R2{rows, LD, 1, sub0 * 32, j, h, M};
+        const RowsT R2{rows, LD, 1, sub0 * 32, j, h, M};
         const auto r2 = dense<P, 16, NFB_ROWS, L::START[L0 + 9] - S0, BWD_ZERO_BIAS>(ws, BWD_LDS_ZERO, IN_B, R2, prev_of(d, OL));
         r2.flush(R2);
     }
@@ -657,7 +673,11 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
             continue;
         }
         const float* ax = aux + m * 16;
-        const float* da = d_allin + m * ld;
+        // (bf16 precision: the directional chain wrote the rows as bf16, RowsOutT<true>; fp32 precision: fp32 rows)
+        auto DA = [&](int c) -> float {
+            if constexpr (ELEM == 2) return (float)(reinterpret_cast<const __bf16*>(d_allin)[m * ld + c]);
+            else return d_allin[m * ld + c];
+        };
         const float* g = g_out + m * g_stride;
         const float dx = dirs[m * dir_stride], dy = dirs[m * dir_stride + 1], dz = dirs[m * dir_stride + 2];
         // forward quantities
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
                 poly = __builtin_fmaf(mat[k * 19 + t], zp[k], poly);
                 if (k >= 1) dpoly = __builtin_fmaf((float)k * mat[k * 19 + t], zp[k - 1], dpoly);
             }
-            const float gr = da[128 + t], gi = da[128 + 19 + t];
+            const float gr = DA(128 + t), gi = DA(128 + 19 + t);
             const float A = gr * re[mm] + gi * im[mm];
             d_rz += A * att[li] * dpoly;
             d_kinv -= A * poly * sig[li] * att[li];
@@ -701,7 +721,7 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
             d_ry += (float)k * (d_im[k] * re[k - 1] - d_re[k] * im[k - 1]);
         }
         // normal: gradient from the loss (predicted normal output), from n.d and from the reflection r = d - 2 (d.n) n
-        const float g_nd = da[166];
+        const float g_nd = DA(166);
         const float rdotn = (d_rx * nx + d_ry * ny) + d_rz * nz;
         float dnx = g[4] + g_nd * dx - 2.0f * (rdotn * dx + dot * d_rx);
         float dny = g[5] + g_nd * dy - 2.0f * (rdotn * dy + dot * d_ry);
@@ -733,17 +753,25 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63), kg = (int)((i >> 6) & 7);
         const int64_t sb = i >> 9, m = sb * 32 + (lane & 31);
+        char* blk = frag + (size_t)sb * sub_stride + (size_t)kg * BREG;
+        if constexpr (ELEM == 2) {                           // bf16 rows -> the bf16 fragment block: a pure re-ordering
+            bf16x4 lo4 = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f}, hi4 = lo4;
+            if (m < M) {
+                const __bf16* da = reinterpret_cast<const __bf16*>(d_allin) + m * ld + 16 * kg + 4 * (lane >> 5);
+                lo4 = *reinterpret_cast<const bf16x4*>(da); hi4 = *reinterpret_cast<const bf16x4*>(da + 8);
+            }
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo4[e]; v[4 + e] = hi4[e]; }
+            *reinterpret_cast<bf16x8*>(blk + lane * 16) = v;
+            continue;
+        }
         f32x4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = lo;
         if (m < M) {
             const float* da = d_allin + m * ld + 16 * kg + 4 * (lane >> 5);
             lo = *reinterpret_cast<const f32x4*>(da); hi = *reinterpret_cast<const f32x4*>(da + 8);
         }
-        char* blk = frag + (size_t)sb * sub_stride + (size_t)kg * BREG;
         if (ELEM == 2) {
-            bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = (__bf16)lo[e]; v[4 + e] = (__bf16)hi[e]; }
-            *reinterpret_cast<bf16x8*>(blk + lane * 16) = v;
         } else {
             *reinterpret_cast<f32x4*>(blk + lane * 16) = lo;
             *reinterpret_cast<f32x4*>(blk + 1024 + lane * 16) = hi;
