@@ -321,9 +321,26 @@ struct RowsOutT {                                            // accumulators 8 h
             const int64_t at = m * ld + 32 * fb + 8 * (2 * half + q) + 4 * h;
             f32x4 v = {acc[8 * half + 4 * q], acc[8 * half + 4 * q + 1], acc[8 * half + 4 * q + 2], acc[8 * half + 4 * q + 3]};
             if constexpr (BF) {
-                bf16x4* p = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(rows) + at);
-                if (accumulate) { const bf16x4 o = *p; v[0] += (float)o[0]; v[1] += (float)o[1]; v[2] += (float)o[2]; v[3] += (float)o[3]; }
-                const bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                // The two lane halves hold interleaved 4-column groups (h = 0: +0..3 and +8..11, h = 1: +4..7 and +12..15).  One
+                // v_permlane32_swap per value hands lane h the CONTIGUOUS columns +8 h .. +8 h + 7, so the 16 columns of (fb, half) go out as
+                // one 16-byte load / store per lane instead of two 8-byte ones -- the chain pays per store INSTRUCTION, not per byte.
+                if (q == 1) continue;
+                f32x4 v1 = {acc[8 * half + 4], acc[8 * half + 5], acc[8 * half + 6], acc[8 * half + 7]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, v[i]), __builtin_bit_cast(uint32_t, v1[i]), false, false);
+                    v[i] = __builtin_bit_cast(float, (uint32_t)r[0]); v1[i] = __builtin_bit_cast(float, (uint32_t)r[1]);
+                }
+                // after the swap: h = 0 holds [own group 0 | partner's group 0] = columns +0..7, h = 1 [partner's group 1 | own group 1] = +8..15
+                bf16x8* p = reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(rows) + m * ld + 32 * fb + 16 * half + 8 * h);
+                if (accumulate) {
+                    const bf16x8 o = *p;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] += (float)o[i]; v1[i] += (float)o[4 + i]; }
+                }
+                bf16x8 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] = (__bf16)v[i]; w[4 + i] = (__bf16)v1[i]; }
                 *p = w;
             } else {
                 f32x4* p = reinterpret_cast<f32x4*>(rows + at);
@@ -568,6 +585,25 @@ DEVINL void store_slot_feature(char* block, int j, int f, float v) {
     if (ELEM == 2) reinterpret_cast<__bf16*>(block)[lane * 8 + e] = (__bf16)v;
     else reinterpret_cast<float*>(block)[(e >> 2) * 256 + lane * 4 + (e & 3)] = v;
 }
+// all 16 features of sample j of a K group at once: the two lane records (j, h = 0 / 1) of the block as 16-byte pieces (bf16: two stores
+// instead of sixteen 2-byte ones; fp32: four f32x4) -- feature f lives in lane half (f & 7) >> 2, element 4 (f >> 3) + (f & 3)
+template <int ELEM>
+DEVINL void store_slot_features16(char* block, int j, const float (&v)[16]) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int lane = j + 32 * hh;
+        const float a0 = v[4 * hh], a1 = v[4 * hh + 1], a2 = v[4 * hh + 2], a3 = v[4 * hh + 3];
+        const float b0 = v[8 + 4 * hh], b1 = v[8 + 4 * hh + 1], b2 = v[8 + 4 * hh + 2], b3 = v[8 + 4 * hh + 3];
+        if constexpr (ELEM == 2) {
+            const bf16x8 w = {(__bf16)a0, (__bf16)a1, (__bf16)a2, (__bf16)a3, (__bf16)b0, (__bf16)b1, (__bf16)b2, (__bf16)b3};
+            *reinterpret_cast<bf16x8*>(block + lane * 16) = w;
+        } else {
+            const f32x4 lo = {a0, a1, a2, a3}, hi = {b0, b1, b2, b3};
+            *reinterpret_cast<f32x4*>(block + lane * 16) = lo;
+            *reinterpret_cast<f32x4*>(block + 1024 + lane * 16) = hi;
+        }
+    }
+}
 DEVINL float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // gradient of the positional encoding (nerf_helper.py:38-48 with cat_origin): d_enc (M, ld) in the reference's column order
@@ -668,8 +704,8 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
     for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < Mpad; m += (int64_t)gridDim.x * blockDim.x) {
         if (m >= M) {                                        // padding samples of the last tile: zero deltas (the slot is not memset any more)
             char* sub = frag + (size_t)(m >> 5) * sub_stride;
-#pragma unroll
-            for (int f = 0; f < 16; ++f) store_slot_feature<ELEM>(sub + 8 * BREG, (int)(m & 31), f, 0.0f);
+            const float zero16[16] = {};
+            store_slot_features16<ELEM>(sub + 8 * BREG, (int)(m & 31), zero16);
             continue;
         }
         const float* ax = aux + m * 16;
@@ -742,8 +778,10 @@ __global__ __launch_bounds__(256) void ref_heads_delta_kernel(const float* __res
         dh[7] = g[3];
         char* sub = frag + (size_t)(m >> 5) * sub_stride;
         const int j = (int)(m & 31);
+        float out16[16];
 #pragma unroll
-        for (int f = 0; f < 16; ++f) store_slot_feature<ELEM>(sub + 8 * BREG, j, f, f < 11 ? dh[f] : 0.0f);
+        for (int f = 0; f < 16; ++f) out16[f] = f < 11 ? dh[f] : 0.0f;
+        store_slot_features16<ELEM>(sub + 8 * BREG, j, out16);
     }
     // delta of the bottle-neck = d_allin[:, 0:128] -> K groups 0..7 in fragment order.  Round 4: one work item per (subtile, K group, lane)
     // -- the lane's 8 features of its sample are two aligned float4 reads of the row and ONE 16-byte slot of the fragment block, so a wave
